@@ -1,0 +1,72 @@
+"""ctypes binding of libbear_hip.so (C ABI: include/bear_hip.h).
+
+Fails loudly: a missing library raises ImportError with the build command, and every
+non-zero status from the library raises BearError.  No compute path exists outside the
+library.
+"""
+import ctypes
+import os
+
+# torch ships its own libamdhip64 (SONAME libamdhip64.so.7); importing it first makes the
+# dynamic loader bind libbear_hip.so to that same runtime instance, so device pointers and
+# streams are shared with torch.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbear_hip.so")
+
+SYMBOLS = [
+    "bear_abi_version", "bear_strerror", "bear_last_hip_error", "bear_ws_create", "bear_ws_destroy",
+    "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
+    "bear_count_rows", "bear_parse_counts_tsv",
+]
+
+
+class BearError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = _lib.bear_strerror(status).decode() if _lib is not None else "?"
+        hip = _lib.bear_last_hip_error() if (_lib is not None and status == -4) else 0
+        super().__init__(f"{where}: {msg} (status {status}" + (f", hipError {hip})" if hip else ")"))
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). bear_amd has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u64, dbl, cint = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_int
+    L.bear_abi_version.restype = cint
+    L.bear_strerror.restype = ctypes.c_char_p
+    L.bear_strerror.argtypes = [cint]
+    L.bear_last_hip_error.restype = cint
+    L.bear_ws_create.argtypes = [cint, ctypes.POINTER(vp)]
+    L.bear_ws_destroy.argtypes = [vp]
+    L.bear_dm_prior_f64.argtypes = [vp, vp, vp, u64, dbl, dbl, cint, vp, vp, vp]
+    L.bear_dm_ref_f64.argtypes = [vp, vp, vp, u64, dbl, dbl, dbl, dbl, cint, vp, vp]
+    L.bear_synth_counts_u32.argtypes = [u64, u64, u64, cint, vp, vp, vp, vp]
+    L.bear_synth_prior_f64.argtypes = [u64, u64, u64, vp, vp]
+    L.bear_count_rows.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]
+    L.bear_parse_counts_tsv.argtypes = [ctypes.c_char_p, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int and name not in ("bear_abi_version", "bear_last_hip_error"):
+            fn.restype = cint
+    _lib = L
+    return L
+
+
+def lib():
+    return _load()
+
+
+def check(status, where):
+    if status != 0:
+        raise BearError(status, where)

@@ -1,0 +1,119 @@
+// bear_math.h -- fp64 device math for the Dirichlet-multinomial hot path (gfx950).
+//
+// gfx950 has no fp64 transcendental hardware beyond v_rcp_f64 / v_rsq_f64 seeds, so the
+// lgamma / digamma differences of bear_model/core.py:73-74 (TFP lbeta -> tf.math.lgamma,
+// autodiff -> digamma) are re-derived for integer counts c >= 1:
+//
+//   D(x, c) = lgamma(x + c) - lgamma(x) = sum_{j<c} log(x + j)      (log rising factorial)
+//   P(x, c) = psi(x + c)    - psi(x)    = sum_{j<c} 1 / (x + j)
+//
+//   c <= BEAR_KPROD : p = prod_j (x + j), p' = dp/dx by the product rule (2 FMA-class ops
+//                     per factor); D = log p, P = p'/p -- one log + one reciprocal per item.
+//   c >  BEAR_KPROD : shift x up to y = x + m >= BEAR_TSTIR with the same product, then the
+//                     Stirling series difference between y and y + (c - m), written with
+//                     log1p(c'/y) so that no large terms cancel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BEAR_KPROD 16u   // longest run evaluated as a plain product
+#define BEAR_TSTIR 8.0   // smallest argument handed to the Stirling series
+
+struct bear_dp {
+  double D;  // lgamma(x+c) - lgamma(x)
+  double P;  // psi(x+c) - psi(x)
+};
+
+// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps (no IEEE division fix-up sequence).
+__device__ __forceinline__ double bear_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+
+__device__ __forceinline__ double bear_log(double x) { return log(x); }
+
+// log1p for t >= 0 of any magnitude, accurate when t is tiny (u-correction form).
+__device__ __forceinline__ double bear_log1p_pos(double t) {
+  double u = 1.0 + t;
+  double d = t - (u - 1.0);  // rounding remainder of 1 + t
+  return bear_log(u) + d * bear_rcp(u);
+}
+
+// Stirling tail of lgamma:  lgamma(y) = (y - 1/2) log y - y + log(2 pi)/2 + bear_stir_lg(1/y)
+__device__ __forceinline__ double bear_stir_lg(double r) {
+  double r2 = r * r;
+  double s = 1.0 / 156.0;
+  s = __builtin_fma(s, r2, -691.0 / 360360.0);
+  s = __builtin_fma(s, r2, 1.0 / 1188.0);
+  s = __builtin_fma(s, r2, -1.0 / 1680.0);
+  s = __builtin_fma(s, r2, 1.0 / 1260.0);
+  s = __builtin_fma(s, r2, -1.0 / 360.0);
+  s = __builtin_fma(s, r2, 1.0 / 12.0);
+  return s * r;
+}
+
+// Stirling tail of digamma:  psi(y) = log y - 1/(2y) - bear_stir_psi(1/y)
+__device__ __forceinline__ double bear_stir_psi(double r) {
+  double r2 = r * r;
+  double s = 1.0 / 12.0;
+  s = __builtin_fma(s, r2, -691.0 / 32760.0);
+  s = __builtin_fma(s, r2, 1.0 / 132.0);
+  s = __builtin_fma(s, r2, -1.0 / 240.0);
+  s = __builtin_fma(s, r2, 1.0 / 252.0);
+  s = __builtin_fma(s, r2, -1.0 / 120.0);
+  s = __builtin_fma(s, r2, 1.0 / 12.0);
+  return s * r2;
+}
+
+// D, P between y and y + c for y >= BEAR_TSTIR, c >= 1 (c as double, exact integer).
+__device__ __forceinline__ bear_dp bear_stirling_diff(double y, double c) {
+  double y1 = y + c;
+  double ry = bear_rcp(y), ry1 = bear_rcp(y1);
+  double l1p = bear_log1p_pos(c * ry);  // log(y1 / y)
+  double ly = bear_log(y);
+  bear_dp o;
+  // (y1-1/2) log y1 - (y-1/2) log y - c  ==  (y1-1/2) log(y1/y) + c (log y - 1)
+  o.D = __builtin_fma(y1 - 0.5, l1p, c * (ly - 1.0)) + (bear_stir_lg(ry1) - bear_stir_lg(ry));
+  o.P = l1p - 0.5 * (ry1 - ry) - (bear_stir_psi(ry1) - bear_stir_psi(ry));
+  return o;
+}
+
+// General item (x > 0, c >= 1).
+__device__ __forceinline__ bear_dp bear_dm_item(double x, uint32_t c) {
+  uint32_t m = c;  // factors taken by the product
+  if (c > BEAR_KPROD) {
+    // shift so that x + m >= TSTIR (m = 0 when x is already large)
+    double need = BEAR_TSTIR - x;
+    m = need > 0.0 ? (uint32_t)ceil(need) : 0u;  // <= 8 < c
+  }
+  double p = 1.0, dp = 0.0, t = x;
+  for (uint32_t j = 0; j < m; ++j) {
+    dp = __builtin_fma(dp, t, p);
+    p *= t;
+    t += 1.0;
+  }
+  bear_dp o;
+  o.D = 0.0;
+  o.P = 0.0;
+  if (m > 0) {
+    o.D = bear_log(p);
+    o.P = dp * bear_rcp(p);
+  }
+  if (m < c) {
+    bear_dp s = bear_stirling_diff(t, (double)(c - m));
+    o.D += s.D;
+    o.P += s.P;
+  }
+  return o;
+}
+
+// ---- reductions -----------------------------------------------------------------
+__device__ __forceinline__ double bear_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}

@@ -1,0 +1,118 @@
+"""Thin torch-facing wrappers over the C ABI (one call = one asynchronous launch on the
+current torch stream).  Tensors are passed as raw device pointers; nothing here computes."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+EPSILON = 1e-7  # keras epsilon, bear_model/core.py:8
+
+
+class Workspace:
+    """Owns a bear_ws handle for one device (per-block partial sums)."""
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("bear_amd requires an MI355X (HIP) device; there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().bear_ws_create(self.device.index, ctypes.byref(h)), "bear_ws_create")
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().bear_ws_destroy(h)
+            except Exception:
+                pass
+
+    @property
+    def handle(self):
+        return self._h
+
+
+_default_ws = {}
+
+
+def default_workspace(device):
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    ws = _default_ws.get(idx)
+    if ws is None:
+        ws = _default_ws[idx] = Workspace(torch.device("cuda", idx))
+    return ws
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_rows(t, dtype, name):
+    if not (t.is_cuda and t.dtype == dtype and t.dim() == 2 and t.shape[1] == 5 and t.is_contiguous()):
+        raise ValueError(f"{name} must be a contiguous CUDA tensor of shape [N, 5] and dtype {dtype}")
+
+
+def counts_dtype():
+    """Counts travel as 32-bit words (KMC's counter range, summarize.py:66-67). torch has no
+    general uint32 arithmetic, so int32 storage is used and reinterpreted by the kernel."""
+    return torch.int32
+
+
+def dm_prior(counts, prior, h_signed, eps=EPSILON, train_ar=False, want_grad=False, out=None, ws=None):
+    """sum LL and d/dh_signed over rows (bear_net._train_step arithmetic, bear_net.py:146-197).
+    Returns (out[2] device tensor, grad_prior or None)."""
+    _check_rows(counts, torch.int32, "counts")
+    _check_rows(prior, torch.float64, "prior")
+    if counts.shape[0] != prior.shape[0]:
+        raise ValueError("counts and prior must have the same number of rows")
+    ws = ws or default_workspace(counts.device)
+    if out is None:
+        out = torch.empty(2, dtype=torch.float64, device=counts.device)
+    grad = torch.empty_like(prior) if want_grad else None
+    with torch.cuda.device(counts.device):
+        st = _lib.lib().bear_dm_prior_f64(ws.handle, _ptr(counts), _ptr(prior), counts.shape[0], float(h_signed), float(eps),
+                                          int(bool(train_ar)), _ptr(out), _ptr(grad), _stream())
+    _lib.check(st, "bear_dm_prior_f64")
+    return out, grad
+
+
+def dm_ref(train, ref, h_signed, tau_signed, nu_signed, eps=EPSILON, train_ar=False, out=None, ws=None):
+    """[sum LL, d/dh_signed, d/dtau_signed, d/dnet_weight_signed] (bear_ref._train_step
+    arithmetic with the stop net function, bear_ref.py:207-259)."""
+    _check_rows(train, torch.int32, "train")
+    _check_rows(ref, torch.int32, "ref")
+    if train.shape[0] != ref.shape[0]:
+        raise ValueError("train and ref must have the same number of rows")
+    ws = ws or default_workspace(train.device)
+    if out is None:
+        out = torch.empty(4, dtype=torch.float64, device=train.device)
+    with torch.cuda.device(train.device):
+        st = _lib.lib().bear_dm_ref_f64(ws.handle, _ptr(train), _ptr(ref), train.shape[0], float(h_signed), float(tau_signed),
+                                        float(nu_signed), float(eps), int(bool(train_ar)), _ptr(out), _stream())
+    _lib.check(st, "bear_dm_ref_f64")
+    return out
+
+
+def synth_counts(seed, row0, n_rows, device, dense=False, want=("train", "test", "ref")):
+    """Rows [row0, row0+n_rows) of the synthetic k=13 table, generated on the device."""
+    bufs = {k: torch.empty((n_rows, 5), dtype=torch.int32, device=device) for k in want}
+    with torch.cuda.device(device):
+        st = _lib.lib().bear_synth_counts_u32(int(seed), int(row0), int(n_rows), int(bool(dense)), _ptr(bufs.get("train")),
+                                              _ptr(bufs.get("test")), _ptr(bufs.get("ref")), _stream())
+    _lib.check(st, "bear_synth_counts_u32")
+    return bufs
+
+
+def synth_prior(seed, row0, n_rows, device):
+    prior = torch.empty((n_rows, 5), dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        st = _lib.lib().bear_synth_prior_f64(int(seed), int(row0), int(n_rows), _ptr(prior), _stream())
+    _lib.check(st, "bear_synth_prior_f64")
+    return prior

@@ -1,0 +1,118 @@
+/*
+ * bear_hip.h -- C ABI of libbear_hip.so: the MI355X (gfx950) implementation of BEAR's
+ * empirical-Bayes training hot path.
+ *
+ * The reference (debbiemarkslab/BEAR) is pure Python on TensorFlow; it has no FFI.  The
+ * boundary below is what a reference maintainer binds through ctypes (INTEGRATION.md
+ * shows the stub) to replace, per batch, the TensorFlow graph built by
+ *   bear_model/bear_net.py:146-197  (_train_step)       -> bear_dm_prior_f64
+ *   bear_model/bear_ref.py:207-259  (_train_step)       -> bear_dm_ref_f64
+ *   bear_model/core.py:73-74, 138-139 (counts_log_prob) -> both (train_ar selects)
+ *   bear_model/dataloader.py:35-46  (TSV -> tensors)    -> bear_parse_counts_tsv
+ *
+ * Conventions
+ *   - every entry point returns an int status: BEAR_OK (0) or a negative bear_status;
+ *     bear_strerror() names it.  Nothing throws across the boundary.
+ *   - the CALLER owns every buffer.  Pointers marked [dev] are device pointers valid on
+ *     the workspace's device (e.g. torch.Tensor.data_ptr()), 16-byte aligned, row-major.
+ *     The library owns only the bear_ws handle.
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream).  Outputs are valid after the stream is synchronised.
+ *   - re-entrant across distinct workspaces / streams; one workspace must not be used
+ *     by two streams at once.
+ *   - the calling thread's current HIP device must be the workspace's device.
+ *   - count rows are 5 wide: A, C, G, T (or U) and the stop symbol, in the order of
+ *     bear_model/core.py:146-147; counts are uint32 (KMC's counter limit, summarize.py:66-67).
+ *   - there is NO CPU fallback: without a gfx950 device the compute entry points fail
+ *     with BEAR_ERR_NO_DEVICE.
+ */
+#ifndef BEAR_HIP_H
+#define BEAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEAR_ABI_VERSION 1
+#define BEAR_ROW_WIDTH 5 /* alphabet_size + 1 for dna/rna */
+
+typedef enum bear_status {
+  BEAR_OK = 0,
+  BEAR_ERR_INVALID_ARG = -1, /* null / misaligned pointer, bad flag */
+  BEAR_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+  BEAR_ERR_WRONG_DEVICE = -3,/* current device != workspace device */
+  BEAR_ERR_HIP = -4,         /* a HIP runtime call failed; see bear_last_hip_error() */
+  BEAR_ERR_NOMEM = -5,
+  BEAR_ERR_IO = -6,          /* file could not be opened / read */
+  BEAR_ERR_PARSE = -7        /* malformed count-table row */
+} bear_status;
+
+typedef struct bear_ws bear_ws; /* opaque workspace: per-block partial sums + launch geometry */
+
+int bear_abi_version(void);
+const char *bear_strerror(int status);
+/* hipError_t of the most recent failing HIP call on this thread (0 if none). */
+int bear_last_hip_error(void);
+
+/* Allocates the workspace on `device` (makes no change to the caller's current device). */
+int bear_ws_create(int device, bear_ws **out);
+int bear_ws_destroy(bear_ws *ws);
+
+/*
+ * bear_net._train_step arithmetic for one batch / shard, unscaled
+ * (bear_model/bear_net.py:146-197; alpha = prior / exp(h_signed) + eps, bear_net.py:43;
+ *  AR mode probs = prior + eps, bear_net.py:68).
+ *   counts  [dev] uint32 [n_rows, 5]   transition counts of the training column
+ *   prior   [dev] double [n_rows, 5]   ar_func(kmers) rows
+ *   out     [dev] double [2]           out[0] = sum_i LL_i ; out[1] = d out[0] / d h_signed
+ *                                      (0 in AR mode, bear_net.py:194-196)
+ *   grad_prior [dev, nullable] double [n_rows, 5]  dLL_i / d prior_ib
+ * The caller applies the -(num_kmers / batch) scale of bear_net.py:190-191.
+ */
+int bear_dm_prior_f64(bear_ws *ws, const uint32_t *counts, const double *prior, uint64_t n_rows,
+                      double h_signed, double eps, int train_ar, double *out, double *grad_prior,
+                      void *stream);
+
+/*
+ * bear_ref._train_step arithmetic with the stop net-function (bear_model/bear_ref.py:207-259,
+ * prior from bear_ref.py:30-33, 63-68, reference column preprocessed as bear_ref.py:332-337,
+ * net function bear_model/ar_funcs.py:121-126), unscaled.
+ *   train, ref [dev] uint32 [n_rows, 5]
+ *   out        [dev] double [4] = { sum LL, d/d h_signed, d/d tau_signed, d/d net_weight_signed }
+ */
+int bear_dm_ref_f64(bear_ws *ws, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
+                    double h_signed, double tau_signed, double nu_signed, double eps, int train_ar,
+                    double *out, void *stream);
+
+/*
+ * Synthetic "k=13 sparse" count table for measurement: rows
+ * [row0, row0 + n_rows) of a table defined by a counter-based hash of (seed, row), so any
+ * shard of the same table can be generated independently on any GPU.
+ *   train, test, ref [dev, each nullable] uint32 [n_rows, 5]
+ *   dense != 0 selects the large-count stress distribution (ysd1-like, counts 1e3..3e5).
+ */
+int bear_synth_counts_u32(uint64_t seed, uint64_t row0, uint64_t n_rows, int dense, uint32_t *train,
+                          uint32_t *test, uint32_t *ref, void *stream);
+/* prior [dev] double [n_rows, 5]: positive rows summing to 1 (softmax of hashed logits). */
+int bear_synth_prior_f64(uint64_t seed, uint64_t row0, uint64_t n_rows, double *prior, void *stream);
+
+/*
+ * Host-side reader of the summarize.py count-table format (bear_model/summarize.py:429-449;
+ * replaces the CsvDataset + tfio decode_json path of bear_model/dataloader.py:35-46).
+ * Row: kmer '\t' '[[' c,c,c,c,c '],[' ... ']]' '\n' with num_ds groups of 5.
+ *   bear_count_rows: number of non-empty lines.
+ *   bear_parse_counts_tsv: fills, for rows [0, max_rows):
+ *     kmers  [host] char  [max_rows, lag]      (no terminator; '[' padded as in the file)
+ *     counts [host] uint32 [num_ds, max_rows, 5] (planar by dataset column)
+ *   *n_rows_out receives the number of rows parsed.
+ */
+int bear_count_rows(const char *path, uint64_t *n_rows_out);
+int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint64_t max_rows, char *kmers,
+                          uint32_t *counts, uint64_t *n_rows_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEAR_HIP_H */

@@ -1,0 +1,318 @@
+"""CPU oracle for the BEAR empirical-Bayes training hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is a NumPy/SciPy restatement of the arithmetic the reference executes in
+TensorFlow / TensorFlow-Probability on its training + evaluation path.  It is the
+*checker* for the HIP kernels in ``bear_amd/csrc``; nothing in the product package
+imports it.  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` may import this module.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * TensorFlow, tensorflow_probability and tensorflow_io are not installable in the
+    build container or on the GPU box, so the reference modules (all of which import
+    TF at module scope) cannot be executed here.  The arithmetic itself lives in the
+    un-vendored dependency ``tensorflow_probability==0.11.1`` (reference
+    ``requirements.txt:11``): ``DirichletMultinomial.log_prob``,
+    ``Multinomial.log_prob`` and ``tfp.math.log_combinations``.
+  * PINNED by the reference's own tests: the Dirichlet-multinomial closed form
+    (``bear_model/tests/test_core.py:23-26``), the multinomial closed form
+    (``test_core.py:59-60``), the parsed first batch of the bundled ysd1 table
+    (``tests/test_dataloader.py:25-32``), and the BMM marginal closed form
+    (``tests/test_dataloader.py:42-49``, ``tests/test_run.py:26-30``).  Those closed
+    forms are written with ``scipy.special.loggamma`` in the reference tests; this
+    module evaluates exactly the same expressions.
+  * PARITY UNPINNED by any reference-held vector: the BEAR-mode ELBO value on real
+    data and every gradient.  They are pinned here only through the closed forms
+    above plus (a) torch-fp64 autograd of the same closed form and (b) mpmath at 50
+    digits (tests/test_oracle.py).
+
+Every function cites the reference lines it follows (paths relative to
+``/root/reference``).
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.special import gammaln, digamma
+
+# keras epsilon: bear_model/core.py:8, bear_net.py:4, bear_ref.py:6
+EPSILON = 1e-7
+
+# bear_model/core.py:142-153 (start symbol '[' / stop symbol ']' share the last column)
+ALPHABETS = {
+    "dna": "ACGT",
+    "rna": "ACGU",
+    "prot": "ARNDCEQGHILKMFPSTWYV",
+}
+
+
+# --------------------------------------------------------------------------- core
+def dm_counts_log_prob(concentration, counts):
+    """DM log-probability of an *ordered* sequence of transitions.
+
+    bear_model/core.py:73-74: ``counts_dist.log_prob(value) - log_combinations(n, value)``
+    with TFP's ``DirichletMultinomial.log_prob = lbeta(conc + counts) - lbeta(conc)
+    + log_combinations`` -- the two multinomial coefficients cancel, leaving
+    ``sum_b[lgamma(a_b + c_b) - lgamma(a_b)] - [lgamma(A + n) - lgamma(A)]``;
+    pinned by bear_model/tests/test_core.py:23-26.
+    """
+    a = np.asarray(concentration, dtype=np.float64)
+    c = np.asarray(counts, dtype=np.float64)
+    a_b, c_b = np.broadcast_arrays(a, c)
+    A = a_b.sum(-1)
+    n = c_b.sum(-1)
+    return (gammaln(a_b + c_b) - gammaln(a_b)).sum(-1) - (gammaln(A + n) - gammaln(A))
+
+
+def dm_grad_concentration(concentration, counts):
+    """d counts_log_prob / d concentration (what tf.GradientTape yields through
+    lgamma -> digamma; bear_net.py:193, bear_ref.py:255):
+    ``g_b = psi(a_b + c_b) - psi(a_b) - psi(A + n) + psi(A)``."""
+    a = np.asarray(concentration, dtype=np.float64)
+    c = np.asarray(counts, dtype=np.float64)
+    a_b, c_b = np.broadcast_arrays(a, c)
+    A = a_b.sum(-1, keepdims=True)
+    n = c_b.sum(-1, keepdims=True)
+    return digamma(a_b + c_b) - digamma(a_b) - digamma(A + n) + digamma(A)
+
+
+def multinomial_counts_log_prob(probs, counts):
+    """Ordered multinomial log-probability, bear_model/core.py:138-139
+    (``sum_b c_b log p_b``; pinned by tests/test_core.py:59-60).  TFP uses
+    ``multiply_no_nan`` so a zero count times log(0) contributes 0."""
+    p = np.asarray(probs, dtype=np.float64)
+    c = np.asarray(counts, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(c == 0, 0.0, c * np.log(p))
+    return t.sum(-1)
+
+
+def one_hot(kmers, alphabet="dna"):
+    """bear_model/core.py:156-174 -- one-hot of equal-length strings; the start
+    symbol '[' is the last column; unknown letters give an all-zero row."""
+    letters = ALPHABETS[alphabet] + "["
+    lut = np.full(256, -1, dtype=np.int64)
+    for i, ch in enumerate(letters):
+        lut[ord(ch)] = i
+    arr = np.frombuffer("".join(kmers).encode(), dtype=np.uint8).reshape(len(kmers), -1)
+    idx = lut[arr]
+    out = np.zeros(idx.shape + (len(letters),), dtype=np.float64)
+    valid = idx >= 0
+    ii, jj = np.nonzero(valid)
+    out[ii, jj, idx[ii, jj]] = 1.0
+    return out
+
+
+# --------------------------------------------------------------------------- ar_funcs
+def softmax(z):
+    z = z - z.max(-1, keepdims=True)
+    e = np.exp(z)
+    return e / e.sum(-1, keepdims=True)
+
+
+def ar_func_linear(onehot, mat):
+    """bear_model/ar_funcs.py:43-45: softmax(einsum('...jk,jkl->...l', kmers, mat))."""
+    return softmax(np.einsum("...jk,jkl->...l", onehot, mat))
+
+
+def ar_func_stop(onehot, alphabet_size=4):
+    """bear_model/ar_funcs.py:121-126: constant [0,...,0,1]."""
+    stop = np.zeros(alphabet_size + 1)
+    stop[-1] = 1.0
+    return stop
+
+
+def _normalize_layer(x, axes):
+    """bear_model/ar_funcs.py:5-20 (tf.nn.moments = biased variance)."""
+    mean = x.mean(axis=axes, keepdims=True)
+    var = x.var(axis=axes, keepdims=True)
+    return (x - mean) / np.sqrt(var + 1e-5)
+
+
+def _elu(x):
+    return np.where(x > 0, x, np.expm1(np.minimum(x, 0.0)))
+
+
+def ar_func_cnn(onehot, params):
+    """bear_model/ar_funcs.py:91-97.  ``params`` in the reference's return order
+    (ar_funcs.py:98-99): filters, intercept0, weights1, intercept1, weights2,
+    intercept2, scale0, scale1."""
+    filters, int0, w1, int1, w2, int2, sc0, sc1 = params
+    fw = filters.shape[0]
+    L = onehot.shape[-2]
+    # conv1d VALID, stride 1: out[..., p, f] = sum_{w,k} x[..., p+w, k] filters[w, k, f]
+    windows = np.stack([onehot[..., p:p + fw, :] for p in range(L - fw + 1)], axis=-3)
+    conv = np.einsum("...pwk,wkf->...pf", windows, filters)
+    nn0 = sc0 * _normalize_layer(conv, (-1,)) + int0
+    t1 = np.tensordot(_elu(nn0), w1, axes=[[-2, -1], [0, 1]])
+    nn1 = sc1 * _normalize_layer(t1, (-1,)) + int1
+    nn2 = np.tensordot(_elu(nn1), w2, axes=[[-1], [0]]) + int2
+    return softmax(nn2)
+
+
+# --------------------------------------------------------------------------- bear_ref prior
+def ref_input(ref_counts, eps=EPSILON):
+    """bear_ref.py:332-337: ``(counts[:, ds_loc_ref] + epsilon) * not_stop``."""
+    r = np.asarray(ref_counts, dtype=np.float64) + eps
+    r[..., -1] = 0.0
+    return r
+
+
+def counts_to_probs(ref_in, tau):
+    """bear_ref.py:9-33 (Jukes-Cantor mutation of the L1-normalised reference row)."""
+    A = ref_in.shape[-1] - 1
+    norm = ref_in / np.abs(ref_in).sum(-1, keepdims=True)
+    shape = np.r_[np.ones(A), 0.0]
+    return (1.0 / A) * shape + np.exp(-tau) * (norm - (1.0 / A) * shape)
+
+
+def ref_ar_func(net_probs, ref_in, tau_signed, nu_signed):
+    """bear_ref.py:63-68: ``(nw*net(kmers) + counts_to_probs(ref, tau)) / (nw + 1)``."""
+    nw = np.exp(nu_signed)
+    tau = np.exp(tau_signed)
+    return (nw * net_probs + counts_to_probs(ref_in, tau)) / (nw + 1.0)
+
+
+# --------------------------------------------------------------------------- train steps
+def bear_net_step(counts, prior, h_signed, train_ar=False, eps=EPSILON):
+    """Sum log-likelihood of one batch and its gradients for ``bear_net._train_step``
+    (bear_net.py:146-197) *before* the ``-(num_kmers / B)`` scaling of
+    bear_net.py:190-191.
+
+    counts: [B, A+1] transition counts; prior: [B, A+1] = ar_func(kmers).
+    Returns dict(ll, d_h_signed, d_prior[B, A+1]).
+      BEAR mode (bear_net.py:43-44): alpha = prior / exp(h_signed) + eps.
+      AR mode   (bear_net.py:68-69): probs = prior + eps (h_signed gets no gradient,
+      bear_net.py:194-196).
+    """
+    c = np.asarray(counts, dtype=np.float64)
+    f = np.asarray(prior, dtype=np.float64)
+    f = np.broadcast_to(f, c.shape)
+    if train_ar:
+        p = f + eps
+        ll = multinomial_counts_log_prob(p, c).sum()
+        return dict(ll=ll, d_h_signed=0.0, d_prior=c / p)
+    h = np.exp(h_signed)
+    a = f / h + eps
+    ll = dm_counts_log_prob(a, c).sum()
+    g = dm_grad_concentration(a, c)
+    return dict(ll=ll, d_h_signed=float((g * (-f / h)).sum()), d_prior=g / h)
+
+
+def bear_ref_step(counts, ref_counts, h_signed, tau_signed, nu_signed,
+                  train_ar=False, net_probs=None, eps=EPSILON):
+    """``bear_ref._train_step`` (bear_ref.py:207-259) for one batch, unscaled.
+
+    ``net_probs`` defaults to the stop function (ar_funcs.py:121-126, config 2/4).
+    Returns dict(ll, d_h_signed, d_tau_signed, d_nu_signed, d_net[B, A+1]).
+    """
+    c = np.asarray(counts, dtype=np.float64)
+    r = ref_input(ref_counts, eps)
+    Asz = c.shape[-1] - 1
+    if net_probs is None:
+        net_probs = ar_func_stop(None, Asz)
+    g_net = np.broadcast_to(np.asarray(net_probs, dtype=np.float64), c.shape)
+    nw = np.exp(nu_signed)
+    tau = np.exp(tau_signed)
+    E = np.exp(-tau)
+    shape = np.r_[np.ones(Asz), 0.0]
+    norm = r / r.sum(-1, keepdims=True)
+    base = (1.0 / Asz) * shape + E * (norm - (1.0 / Asz) * shape)
+    f = (nw * g_net + base) / (nw + 1.0)
+    # partials of f w.r.t. the signed parameters
+    df_dtau_s = (-tau * E) * (norm - (1.0 / Asz) * shape) / (nw + 1.0)
+    df_dnu_s = nw * (g_net - f) / (nw + 1.0)
+    if train_ar:
+        p = f + eps
+        ll = multinomial_counts_log_prob(p, c).sum()
+        dLdf = c / p
+        d_h = 0.0
+    else:
+        h = np.exp(h_signed)
+        a = f / h + eps
+        ll = dm_counts_log_prob(a, c).sum()
+        g = dm_grad_concentration(a, c)
+        dLdf = g / h
+        d_h = float((g * (-f / h)).sum())
+    return dict(ll=ll, d_h_signed=d_h,
+                d_tau_signed=float((dLdf * df_dtau_s).sum()),
+                d_nu_signed=float((dLdf * df_dnu_s).sum()),
+                d_net=dLdf * nw / (nw + 1.0))
+
+
+# --------------------------------------------------------------------------- BMM / evaluation
+def bmm_likelihood(counts, alpha):
+    """dataloader.py:111-113, 120-147: for every dataset column and every alpha,
+    ``sum_i lbeta(c_i + alpha) - lbeta(alpha)``.  counts [N, num_ds, A+1] -> [num_ds, V].
+    Closed form pinned by tests/test_dataloader.py:42-49."""
+    c = np.asarray(counts, dtype=np.float64)[:, :, None, :]
+    al = np.asarray(alpha, dtype=np.float64)[:, None]
+    x = c + al
+    lb1 = gammaln(x).sum(-1) - gammaln(x.sum(-1))
+    y = 0 * c + al
+    lb0 = gammaln(y).sum(-1) - gammaln(y.sum(-1))
+    return (lb1 - lb0).sum(0)
+
+
+def _ml_output(values, noise_scale, rng):
+    """core.py:69-71 / 134-136: argmax with Gaussian tie-breaking noise."""
+    if rng is None:
+        return np.argmax(values, axis=-1)
+    return np.argmax(values + noise_scale * rng.standard_normal(values.shape), axis=-1)
+
+
+def evaluation_step(test_counts, prior, h, van_reg, train_counts=None, eps=EPSILON, rng=None):
+    """bear_net._evaluation_step (bear_net.py:323-371) on one batch.
+
+    prior [B, A+1] = ar_func(...) rows; ``h`` scalar or [H] (h_scan, bear_net.py:523).
+    With rng=None ties are broken by first index (deterministic oracle); accuracy
+    parity on tied rows is statistical in the reference.
+    Returns the 7 partial sums of bear_net.py:370-371.
+    """
+    ct = np.asarray(test_counts, dtype=np.float64)
+    f = np.broadcast_to(np.asarray(prior, dtype=np.float64), ct.shape)
+    van = np.asarray(van_reg, dtype=np.float64)
+    hs = np.atleast_1d(np.asarray(h, dtype=np.float64))
+    if train_counts is not None:
+        ctr = np.asarray(train_counts, dtype=np.float64)
+        van_cond = ctr[:, None, :] + van[:, None]
+        cond = ctr
+    else:
+        van_cond = van[:, None] * np.ones((1, ct.shape[-1]))
+        van_cond = np.broadcast_to(van_cond, (ct.shape[0],) + van_cond.shape)
+        cond = 0.0
+    conc_ear = f[None] / hs[:, None, None] + cond + eps          # [H, B, A+1]
+    ll_ear = dm_counts_log_prob(conc_ear, ct[None]).sum(-1)       # [H]
+    probs = f + eps
+    ll_arm = multinomial_counts_log_prob(probs, ct).sum()
+    conc_van = 0.0 / 1.0 + van_cond + eps                          # [B, V, A+1]
+    ll_van = dm_counts_log_prob(conc_van, ct[:, None, :]).sum(0)   # [V]
+    ml_ear = _ml_output(conc_ear, 100 * eps, rng)                  # [H, B]
+    ml_arm = _ml_output(probs, eps, rng)
+    ml_van = _ml_output(conc_van, 100 * eps, rng)                  # [B, V]
+    cor_ear = np.take_along_axis(np.broadcast_to(ct[None], conc_ear.shape),
+                                 ml_ear[..., None], -1)[..., 0].sum(-1)
+    cor_arm = np.take_along_axis(ct, ml_arm[:, None], -1).sum()
+    cor_van = np.take_along_axis(np.broadcast_to(ct[:, None, :], conc_van.shape),
+                                 ml_van[..., None], -1)[..., 0].sum(0)
+    total_len = ct.sum()
+    if np.ndim(h) == 0:
+        ll_ear, cor_ear = ll_ear[0], cor_ear[0]
+    return ll_ear, ll_arm, ll_van, cor_ear, cor_arm, cor_van, total_len
+
+
+# --------------------------------------------------------------------------- count-table text format
+def parse_counts_tsv(path, num_ds):
+    """Restates what dataloader.py:35-46 yields for a whole file: k-mer strings and a
+    float64 [N, num_ds, A+1] tensor.  Row format from summarize.py:429-449:
+    ``kmer \t [[g0 A,C,G,T,$],[g1 ...],...]``."""
+    import json
+    kmers, rows = [], []
+    with open(path) as fh:
+        for line in fh:
+            if not line.strip():
+                continue
+            k, m = line.rstrip("\n").split("\t")
+            kmers.append(k)
+            rows.append(json.loads(m))
+    arr = np.asarray(rows, dtype=np.float64)
+    assert arr.shape[1] == num_ds
+    return kmers, arr

@@ -1,0 +1,168 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle on the same seeded
+inputs.  Tolerance: north_star asks 1e-9 relative on the fp64 ELBO; we hold 1e-11 on the
+ELBO and 1e-9 (relative to the L1 mass of the gradient terms) on gradients."""
+import numpy as np
+import pytest
+
+import bear_oracle as o
+import c_oracle as co
+from util import dense_table, edge_table, prior_rows, sparse_table
+
+pytestmark = pytest.mark.gpu
+
+ELBO_RTOL = 1e-11
+GRAD_RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+def _to_dev(a, dev):
+    import torch
+    if a.dtype == np.uint32:
+        return torch.from_numpy(a.view(np.int32).copy()).to(dev)
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _close(got, want, rtol, scale=None):
+    scale = abs(want) if scale is None else scale
+    assert abs(got - want) <= rtol * max(scale, 1e-300), (got, want, abs(got - want) / max(scale, 1e-300))
+
+
+def _grad_scale_ref(tr, rf, args):
+    # L1 mass of the per-row gradient terms (sum |.| before cancellation)
+    r = o.bear_ref_step(tr, rf, *args)
+    return np.abs(r["d_net"]).sum() + abs(r["ll"]) * 1e-6 + 1.0
+
+
+CASES_REF = {
+    "ysd1": None,
+    "sparse": lambda: sparse_table(20011, 11)[::2],
+    "sparse_hot": lambda: sparse_table(4099, 12, lam_scale=6.0)[::2],
+    "dense": lambda: dense_table(3001, 13),
+    "edge": lambda: (edge_table(), edge_table(1) // 9),
+    "one_row": lambda: (np.array([[3, 0, 1, 0, 0]], np.uint32), np.array([[1, 0, 0, 0, 0]], np.uint32)),
+}
+PARAMS = [(0.0, np.log(1 / 30), -np.log(100)), (-4.2, -1.0, 0.3), (2.5, 1.2, -7.0)]
+
+
+@pytest.mark.parametrize("case", list(CASES_REF))
+@pytest.mark.parametrize("train_ar", [False, True])
+def test_dm_ref_parity(case, train_ar, dev, ysd1):
+    from bear_amd import kernels
+    if case == "ysd1":
+        tr, rf = ysd1[1][:, 0].astype(np.uint32), ysd1[1][:, 2].astype(np.uint32)
+    else:
+        tr, rf = CASES_REF[case]()
+    d_tr, d_rf = _to_dev(tr, dev), _to_dev(rf, dev)
+    for args in PARAMS:
+        want = co.dm_ref(tr, rf, *args, train_ar=train_ar, nthreads=4)
+        got = kernels.dm_ref(d_tr, d_rf, *args, train_ar=train_ar).cpu().numpy()
+        _close(got[0], want[0], ELBO_RTOL)
+        scale = np.abs(want[1:]).max() + abs(want[0]) * 1e-3
+        for k in range(1, 4):
+            _close(got[k], want[k], GRAD_RTOL, scale)
+
+
+def test_dm_ref_known_answers(dev, ysd1):
+    """SURVEY.md 8c / BASELINE.md section 2 known answers on the bundled table."""
+    from bear_amd import kernels
+    tr, rf = ysd1[1][:, 0].astype(np.uint32), ysd1[1][:, 2].astype(np.uint32)
+    got = kernels.dm_ref(_to_dev(tr, dev), _to_dev(rf, dev), 0.0, np.log(1 / 30), -np.log(100)).cpu().numpy()
+    _close(got[0], -152711537.8567275, 1e-12)
+    for g, w in zip(got[1:], [-4080.3988585483107, 147.56530806373428, 902.7364555205095]):
+        _close(g, w, 1e-9)
+    got = kernels.dm_ref(_to_dev(tr, dev), _to_dev(rf, dev), 0.0, np.log(1 / 30), -np.log(100), train_ar=True).cpu().numpy()
+    _close(got[0], -155088323.57920885, 1e-12)
+
+
+@pytest.mark.parametrize("case", ["ysd1", "sparse", "sparse_hot", "dense", "edge", "one_row"])
+@pytest.mark.parametrize("train_ar", [False, True])
+def test_dm_prior_parity(case, train_ar, dev, ysd1):
+    from bear_amd import kernels
+    if case == "ysd1":
+        tr = ysd1[1][:, 0].astype(np.uint32)
+    else:
+        tr = CASES_REF[case]()[0]
+    n = len(tr)
+    for seed, h_s, conc in [(1, 0.0, 1.0), (2, -3.0, 0.2), (3, 1.7, 5.0)]:
+        f = prior_rows(n, seed, conc)
+        want, wg = co.dm_prior(tr, f, h_s, train_ar=train_ar, want_grad=True, nthreads=4)
+        out, g = kernels.dm_prior(_to_dev(tr, dev), _to_dev(f, dev), h_s, train_ar=train_ar, want_grad=True)
+        out, g = out.cpu().numpy(), g.cpu().numpy()
+        _close(out[0], want[0], ELBO_RTOL)
+        _close(out[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
+        assert np.allclose(g, wg, rtol=1e-9, atol=1e-9 * np.abs(wg).max())
+        out2, g2 = kernels.dm_prior(_to_dev(tr, dev), _to_dev(f, dev), h_s, train_ar=train_ar, want_grad=False)
+        assert g2 is None
+        assert np.array_equal(out2.cpu().numpy(), out)  # same grid -> bitwise reproducible
+
+
+def test_test_core_construction_on_gpu(dev):
+    """bear_model/tests/test_core.py:7-26 re-stated: random Poisson counts [3,5,5] with a
+    broadcast concentration [5,5]; DM counts_log_prob == SciPy closed form."""
+    from scipy.special import loggamma
+    from bear_amd import kernels
+    rng = np.random.default_rng(21)
+    trans = rng.poisson(size=(3, 5, 5)).astype(np.uint32)
+    conc = rng.exponential(size=(5, 5))
+    want = (np.sum(loggamma(conc + trans) - loggamma(conc), axis=-1)
+            - (loggamma(conc.sum(-1) + trans.sum(-1)) - loggamma(conc.sum(-1)))).sum()
+    c = trans.reshape(-1, 5)
+    f = np.broadcast_to(conc, trans.shape).reshape(-1, 5).copy()
+    out, _ = kernels.dm_prior(_to_dev(c, dev), _to_dev(f, dev), 0.0, eps=0.0)
+    _close(out.cpu().numpy()[0], want, 1e-12)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 255, 1023, 1024, 1025, 4097])
+def test_ragged_sizes(n, dev):
+    from bear_amd import kernels
+    import torch
+    tr, _, rf = sparse_table(max(n, 1), 31)
+    tr, rf = tr[:n], rf[:n]
+    f = prior_rows(max(n, 1), 5)[:n]
+    args = (0.1, -3.0, -4.0)
+    want = co.dm_ref(tr, rf, *args) if n else np.zeros(4)
+    d_tr = _to_dev(tr, dev) if n else torch.empty((0, 5), dtype=torch.int32, device=dev)
+    d_rf = _to_dev(rf, dev) if n else torch.empty((0, 5), dtype=torch.int32, device=dev)
+    got = kernels.dm_ref(d_tr, d_rf, *args).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-10, atol=1e-12)
+    if n:
+        want2, _ = co.dm_prior(tr, f, 0.1)
+        got2, _ = kernels.dm_prior(d_tr, _to_dev(f, dev), 0.1)
+        assert np.allclose(got2.cpu().numpy(), want2, rtol=1e-10, atol=1e-12)
+
+
+def test_additivity_and_permutation_full_size(dev):
+    """Size-independent properties at a bench-scale table (synthetic generator on device):
+    the sum over the table equals the sum over its shards (what row-sharding across GPUs
+    relies on), and sampled chunks agree with the oracle."""
+    import torch
+    from bear_amd import kernels
+    N = 20_000_000
+    t = kernels.synth_counts(20211012, 0, N, dev, want=("train", "ref"))
+    args = (0.0, np.log(1 / 30), -np.log(100))
+    full = kernels.dm_ref(t["train"], t["ref"], *args).cpu().numpy()
+    cuts = [0, 1, 1023, 5_000_001, 13_333_337, N]
+    parts = sum(kernels.dm_ref(t["train"][a:b].contiguous(), t["ref"][a:b].contiguous(), *args).cpu().numpy()
+                for a, b in zip(cuts[:-1], cuts[1:]))
+    assert np.allclose(full, parts, rtol=1e-12)
+    # shard generation is position-independent: rows [a, b) generated alone equal the slice
+    a, b = 7_000_003, 7_050_003
+    s = kernels.synth_counts(20211012, a, b - a, dev, want=("train", "ref"))
+    assert torch.equal(s["train"], t["train"][a:b]) and torch.equal(s["ref"], t["ref"][a:b])
+    # sampled-chunk parity against the oracle
+    tr = s["train"].cpu().numpy().view(np.uint32)
+    rf = s["ref"].cpu().numpy().view(np.uint32)
+    want = co.dm_ref(tr, rf, *args, nthreads=4)
+    got = kernels.dm_ref(s["train"], s["ref"], *args).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-10)
+    f = kernels.synth_prior(20211012, a, b - a, dev)
+    want2, _ = co.dm_prior(tr, f.cpu().numpy(), -0.5, nthreads=4)
+    got2, _ = kernels.dm_prior(s["train"], f, -0.5)
+    assert np.allclose(got2.cpu().numpy(), want2, rtol=1e-10)
+    assert abs(f.sum(1) - 1).max().item() < 1e-12
