@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libbear_hip.so")
 
 SYMBOLS = [
     "bear_abi_version", "bear_strerror", "bear_last_hip_error", "bear_ws_create", "bear_ws_destroy",
-    "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
+    "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_dm_items_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
     "bear_count_rows", "bear_parse_counts_tsv",
 ]
 
@@ -51,6 +51,7 @@ def _load():
     L.bear_ws_destroy.argtypes = [vp]
     L.bear_dm_prior_f64.argtypes = [vp, vp, vp, u64, dbl, dbl, cint, vp, vp, vp]
     L.bear_dm_ref_f64.argtypes = [vp, vp, vp, u64, dbl, dbl, dbl, dbl, cint, vp, vp]
+    L.bear_dm_items_f64.argtypes = [vp, vp, vp, u64, cint, vp, vp, vp]
     L.bear_synth_counts_u32.argtypes = [u64, u64, u64, cint, vp, vp, vp, vp]
     L.bear_synth_prior_f64.argtypes = [u64, u64, u64, vp, vp]
     L.bear_count_rows.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]

@@ -82,13 +82,16 @@ __device__ __forceinline__ bear_dp bear_stirling_diff(double y, double c) {
   return o;
 }
 
-// General item (x > 0, c >= 1).
-__device__ __forceinline__ bear_dp bear_dm_item(double x, uint32_t c) {
-  uint32_t m = c;  // factors taken by the product
-  if (c > BEAR_KPROD) {
+// General item (x > 0, c >= 1; c is an exact integer carried as a double so that row totals
+// beyond the uint32 range -- five columns at KMC's counter limit -- stay exact).
+__device__ __forceinline__ bear_dp bear_dm_item(double x, double c) {
+  uint32_t m;  // factors taken by the product
+  if (c > (double)BEAR_KPROD || x > 0x1p60) {
     // shift so that x + m >= TSTIR (m = 0 when x is already large)
     double need = BEAR_TSTIR - x;
     m = need > 0.0 ? (uint32_t)ceil(need) : 0u;  // <= 8 < c
+  } else {
+    m = (uint32_t)c;
   }
   double p = 1.0, dp = 0.0, t = x;
   for (uint32_t j = 0; j < m; ++j) {
@@ -103,12 +106,34 @@ __device__ __forceinline__ bear_dp bear_dm_item(double x, uint32_t c) {
     o.D = bear_log(p);
     o.P = dp * bear_rcp(p);
   }
-  if (m < c) {
-    bear_dp s = bear_stirling_diff(t, (double)(c - m));
+  if ((double)m < c) {
+    bear_dp s = bear_stirling_diff(t, c - (double)m);
     o.D += s.D;
     o.P += s.P;
   }
   return o;
+}
+
+// ---- table-driven log -------------------------------------------------------------
+// log(p) for finite p > 0 (normal or subnormal).  p = m * 2^e with m in [0.5, 1); the top 7
+// mantissa bits pick r_i ~ 1/m from a 128-entry table {r_i, -log r_i} (built on the host with
+// libm, staged in LDS); t = m r_i - 1 is one exact-rounded FMA with |t| <= 2^-8 and
+//   log p = e ln2 - log r_i + log1p(t),   log1p by a degree-6 Taylor polynomial (|err| < 3e-18).
+// ~15 fp64-rate instructions + one 16-byte LDS read, versus ~60 for the library log.
+#define BEAR_LOGTAB_N 128
+__device__ __forceinline__ double bear_log_tab(double p, const double2 *__restrict__ tab) {
+  const double m = __builtin_amdgcn_frexp_mant(p);
+  const int e = __builtin_amdgcn_frexp_exp(p);
+  const uint32_t hi = (uint32_t)(__double_as_longlong(m) >> 32);
+  const double2 rl = tab[(hi >> 13) & 127u];
+  const double t = __builtin_fma(m, rl.x, -1.0);
+  double q = -1.0 / 6.0;
+  q = __builtin_fma(q, t, 0.2);
+  q = __builtin_fma(q, t, -0.25);
+  q = __builtin_fma(q, t, 1.0 / 3.0);
+  q = __builtin_fma(q, t, -0.5);
+  const double l1p = __builtin_fma(t * t, q, t);
+  return __builtin_fma((double)e, 0.6931471805599453094, rl.y + l1p);
 }
 
 // ---- reductions -----------------------------------------------------------------

@@ -100,6 +100,19 @@ def dm_ref(train, ref, h_signed, tau_signed, nu_signed, eps=EPSILON, train_ar=Fa
     return out
 
 
+def dm_items(x, c, path=0, ws=None):
+    """D = lgamma(x+c) - lgamma(x), P = digamma(x+c) - digamma(x) per item (diagnostic entry)."""
+    if not (x.is_cuda and x.dtype == torch.float64 and x.is_contiguous() and c.is_cuda and c.dtype == torch.int32
+            and c.is_contiguous() and x.shape == c.shape and x.dim() == 1):
+        raise ValueError("x: contiguous CUDA float64 [n]; c: contiguous CUDA int32 [n]")
+    ws = ws or default_workspace(x.device)
+    D, P = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        st = _lib.lib().bear_dm_items_f64(ws.handle, _ptr(x), _ptr(c), x.shape[0], int(path), _ptr(D), _ptr(P), _stream())
+    _lib.check(st, "bear_dm_items_f64")
+    return D, P
+
+
 def synth_counts(seed, row0, n_rows, device, dense=False, want=("train", "test", "ref")):
     """Rows [row0, row0+n_rows) of the synthetic k=13 table, generated on the device."""
     bufs = {k: torch.empty((n_rows, 5), dtype=torch.int32, device=device) for k in want}

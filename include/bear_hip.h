@@ -87,6 +87,17 @@ int bear_dm_ref_f64(bear_ws *ws, const uint32_t *train, const uint32_t *ref, uin
                     double *out, void *stream);
 
 /*
+ * The primitive underneath both entry points, item by item (tests / diagnostics): for x > 0 and
+ * integer c >= 0,  D[i] = lgamma(x+c) - lgamma(x)  and  P[i] = digamma(x+c) - digamma(x)
+ * -- the two quantities TFP's lbeta and its autodiff yield in bear_model/core.py:73-74.
+ *   path 0: the code path the fused kernels choose (product + table log for c <= 31, shifted
+ *           Stirling series above);  path 1: the general routine for every item.
+ *   x, D, P [dev] double [n];  c [dev] uint32 [n]
+ */
+int bear_dm_items_f64(bear_ws *ws, const double *x, const uint32_t *c, uint64_t n, int path, double *D,
+                      double *P, void *stream);
+
+/*
  * Synthetic "k=13 sparse" count table for measurement: rows
  * [row0, row0 + n_rows) of a table defined by a counter-based hash of (seed, row), so any
  * shard of the same table can be generated independently on any GPU.
