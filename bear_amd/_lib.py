@@ -13,11 +13,12 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbear_hip.so")
+LIB_PATH = os.environ.get("BEAR_AMD_LIB") or os.path.join(_HERE, "libbear_hip.so")  # env: developer A/B builds
 
 SYMBOLS = [
     "bear_abi_version", "bear_strerror", "bear_last_hip_error", "bear_ws_create", "bear_ws_destroy",
-    "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_dm_items_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
+    "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_dm_items_f64",
+    "bear_plan_create", "bear_plan_destroy", "bear_plan_bytes", "bear_dm_prior_plan_f64", "bear_dm_ref_plan_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
     "bear_count_rows", "bear_parse_counts_tsv",
 ]
 
@@ -51,6 +52,12 @@ def _load():
     L.bear_ws_destroy.argtypes = [vp]
     L.bear_dm_prior_f64.argtypes = [vp, vp, vp, u64, dbl, dbl, cint, vp, vp, vp]
     L.bear_dm_ref_f64.argtypes = [vp, vp, vp, u64, dbl, dbl, dbl, dbl, cint, vp, vp]
+    L.bear_plan_create.argtypes = [vp, vp, u64, cint, ctypes.POINTER(vp)]
+    L.bear_plan_destroy.argtypes = [vp]
+    L.bear_plan_bytes.argtypes = [vp]
+    L.bear_plan_bytes.restype = u64
+    L.bear_dm_prior_plan_f64.argtypes = [vp, vp, vp, vp, u64, dbl, dbl, vp, vp]
+    L.bear_dm_ref_plan_f64.argtypes = [vp, vp, vp, vp, u64, dbl, dbl, dbl, dbl, vp, vp]
     L.bear_dm_items_f64.argtypes = [vp, vp, vp, u64, cint, vp, vp, vp]
     L.bear_synth_counts_u32.argtypes = [u64, u64, u64, cint, vp, vp, vp, vp]
     L.bear_synth_prior_f64.argtypes = [u64, u64, u64, vp, vp]
@@ -58,6 +65,8 @@ def _load():
     L.bear_parse_counts_tsv.argtypes = [ctypes.c_char_p, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
     for name in SYMBOLS:
         fn = getattr(L, name)
+        if name == "bear_plan_bytes":
+            continue
         if fn.restype is ctypes.c_int and name not in ("bear_abi_version", "bear_last_hip_error"):
             fn.restype = cint
     _lib = L

@@ -30,6 +30,7 @@ struct bear_ws {
   int max_blocks;
   double *partials;  // [max_blocks][BEAR_MAX_OUT]
   double *logtab;    // [BEAR_LOGTAB_N][2] = {r_i, -log r_i} (bear_math.h, bear_log_tab)
+  unsigned long long *dbg;  // developer timing buffer [max_blocks][8][6]
 };
 
 struct bear_params {

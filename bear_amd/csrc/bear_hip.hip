@@ -12,6 +12,7 @@
 #include "bear_common.h"
 #include "kernels_rows.h"
 #include "kernels_sorted.h"
+#include "kernels_plan.h"
 #include "kernels_synth.h"
 
 // ------------------------------------------------------------------ C ABI
@@ -55,6 +56,7 @@ int bear_ws_create(int device, bear_ws **out) {
       ws->max_blocks = ws->num_cu * 8;
       e = hipMalloc(&ws->partials, sizeof(double) * BEAR_MAX_OUT * (size_t)ws->max_blocks);
       if (e == hipSuccess) e = hipMalloc(&ws->logtab, sizeof(double) * 2 * BEAR_LOGTAB_N);
+      if (e == hipSuccess) e = hipMalloc(&ws->dbg, sizeof(unsigned long long) * 48 * (size_t)ws->max_blocks);
       if (e == hipSuccess) {
         // {r_i, -log r_i}: r_i = 1 / midpoint of the i-th mantissa cell of [0.5, 1) (bear_log_tab)
         double tab[2 * BEAR_LOGTAB_N];
@@ -66,8 +68,23 @@ int bear_ws_create(int device, bear_ws **out) {
         e = hipMemcpy(ws->logtab, tab, sizeof(tab), hipMemcpyHostToDevice);
       }
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_sorted_kernel),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_sorted_kernel<0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(srt_lds_n));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_sorted_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(srt_lds_n));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_sorted_kernel<9>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(srt_lds_n));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_ref_plan_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_r));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_ref_sorted_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(srt_lds_r));
@@ -93,6 +110,7 @@ int bear_ws_destroy(bear_ws *ws) {
   (void)hipSetDevice(ws->device);
   (void)hipFree(ws->partials);
   (void)hipFree(ws->logtab);
+  (void)hipFree(ws->dbg);
   (void)hipSetDevice(prev);
   delete ws;
   return BEAR_OK;
@@ -140,8 +158,15 @@ int bear_dm_prior_f64(bear_ws *ws, const uint32_t *counts, const double *prior, 
   int grid = grid_for(ws, n_rows);
   if (!train_ar && !grad_prior) {
     grid = grid_sorted(ws, n_rows);
-    hipLaunchKernelGGL(dm_prior_sorted_kernel, dim3(grid), dim3(SRT_THREADS), sizeof(srt_lds_n), s, counts, prior, n_rows, prm,
-                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
+    const char *dbg = getenv("BEAR_DEBUG_STOP");  // developer switch: phase timing (results are then meaningless)
+    const int stop = dbg ? atoi(dbg) : 0;
+    const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+    if (stop == 1)
+      hipLaunchKernelGGL(dm_prior_sorted_kernel<1>, dim3(grid), dim3(SRT_THREADS), sizeof(srt_lds_n), s, counts, prior, n_rows, prm, lt, ws->partials, ws->dbg);
+    else if (stop == 9)
+      hipLaunchKernelGGL(dm_prior_sorted_kernel<9>, dim3(grid), dim3(SRT_THREADS), sizeof(srt_lds_n), s, counts, prior, n_rows, prm, lt, ws->partials, ws->dbg);
+    else
+      hipLaunchKernelGGL(dm_prior_sorted_kernel<0>, dim3(grid), dim3(SRT_THREADS), sizeof(srt_lds_n), s, counts, prior, n_rows, prm, lt, ws->partials, ws->dbg);
   } else if (train_ar) {
     if (grad_prior)
       hipLaunchKernelGGL((dm_prior_kernel<true, true>), dim3(grid), dim3(BEAR_THREADS), 0, s, counts, prior, n_rows, prm, grad_prior, ws->partials);
@@ -192,6 +217,202 @@ int bear_dm_ref_f64(bear_ws *ws, const uint32_t *train, const uint32_t *ref, uin
   return BEAR_OK;
 }
 
+// ------------------------------------------------------------------ plans
+struct bear_plan {
+  int device;
+  int ncol;
+  uint64_t n_rows;
+  const uint32_t *counts;  // the buffer the plan was built from (identity check only)
+  pln_tile_info *info;
+  uint16_t *items;
+  pln_heavy_col *heavy_col;
+  pln_heavy_row *heavy_row;
+  uint64_t *heavy_stop;
+  uint64_t n_heavy[3];
+  uint64_t bytes;
+};
+
+static void plan_free(bear_plan *p) {
+  if (!p) return;
+  (void)hipFree(p->info);
+  (void)hipFree(p->items);
+  (void)hipFree(p->heavy_col);
+  (void)hipFree(p->heavy_row);
+  (void)hipFree(p->heavy_stop);
+  delete p;
+}
+
+int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int ncol, bear_plan **out) {
+  if (!out) return BEAR_ERR_INVALID_ARG;
+  *out = nullptr;
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if ((ncol != 4 && ncol != 5) || (n_rows && !counts) || misaligned(counts)) return BEAR_ERR_INVALID_ARG;
+  bear_plan *p = new (std::nothrow) bear_plan();
+  if (!p) return BEAR_ERR_NOMEM;
+  memset(p, 0, sizeof(*p));
+  p->device = ws->device;
+  p->ncol = ncol;
+  p->n_rows = n_rows;
+  p->counts = counts;
+  const uint64_t n_tiles = (n_rows + PLN_TILE - 1) / PLN_TILE;
+  if (n_tiles == 0) {
+    *out = p;
+    return BEAR_OK;
+  }
+  uint32_t *d_nlight = nullptr;
+  unsigned long long *d_cnt = nullptr;  // [0..2] heavy counts, [3..5] fill cursors
+  pln_tile_info *h_info = nullptr;
+  uint32_t *h_nlight = nullptr;
+  hipError_t e = hipMalloc(&d_nlight, sizeof(uint32_t) * n_tiles);
+  if (e == hipSuccess) e = hipMalloc(&d_cnt, sizeof(unsigned long long) * 6);
+  if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(unsigned long long) * 6);
+  int grid = (int)(n_tiles < (uint64_t)ws->num_cu * 4 ? n_tiles : (uint64_t)ws->num_cu * 4);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(plan_count_kernel, dim3(grid), dim3(PLN_BUILD_THREADS), 0, 0, counts, n_rows, ncol, d_nlight, d_cnt);
+    e = hipGetLastError();
+  }
+  unsigned long long h_cnt[3] = {0, 0, 0};
+  if (e == hipSuccess) {
+    h_nlight = (uint32_t *)malloc(sizeof(uint32_t) * n_tiles);
+    h_info = (pln_tile_info *)malloc(sizeof(pln_tile_info) * n_tiles);
+    if (!h_nlight || !h_info) {
+      free(h_nlight);
+      free(h_info);
+      (void)hipFree(d_nlight);
+      (void)hipFree(d_cnt);
+      plan_free(p);
+      return BEAR_ERR_NOMEM;
+    }
+    e = hipMemcpy(h_nlight, d_nlight, sizeof(uint32_t) * n_tiles, hipMemcpyDeviceToHost);
+  }
+  if (e == hipSuccess) e = hipMemcpy(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
+  uint64_t off16 = 0;
+  if (e == hipSuccess) {
+    for (uint64_t t = 0; t < n_tiles; ++t) {
+      h_info[t].off16 = (uint32_t)off16;
+      h_info[t].n_light = h_nlight[t];
+      off16 += (((uint64_t)h_nlight[t] + 63u) & ~63ull) / 8;  // padded items * 2 B / 16 B
+    }
+    if (off16 > 0xffffffffull) e = hipErrorOutOfMemory;
+  }
+  const uint64_t item_bytes = off16 * 16 + 1024;  // slack: the last DMA piece may be read in full
+  if (e == hipSuccess) e = hipMalloc(&p->info, sizeof(pln_tile_info) * n_tiles);
+  if (e == hipSuccess) e = hipMalloc(&p->items, item_bytes);
+  if (e == hipSuccess) e = hipMemset(p->items, 0, item_bytes);
+  for (int k = 0; k < 3; ++k) p->n_heavy[k] = h_cnt[k];
+  if (e == hipSuccess && h_cnt[0]) e = hipMalloc(&p->heavy_col, sizeof(pln_heavy_col) * h_cnt[0]);
+  if (e == hipSuccess && h_cnt[1]) e = hipMalloc(&p->heavy_row, sizeof(pln_heavy_row) * h_cnt[1]);
+  if (e == hipSuccess && h_cnt[2]) e = hipMalloc(&p->heavy_stop, sizeof(uint64_t) * h_cnt[2]);
+  if (e == hipSuccess) e = hipMemcpy(p->info, h_info, sizeof(pln_tile_info) * n_tiles, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(plan_fill_kernel, dim3(grid), dim3(PLN_BUILD_THREADS), 0, 0, counts, n_rows, ncol, p->info, p->items,
+                       p->heavy_col, p->heavy_row, p->heavy_stop, d_cnt + 3);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  free(h_nlight);
+  free(h_info);
+  (void)hipFree(d_nlight);
+  (void)hipFree(d_cnt);
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    plan_free(p);
+    return e == hipErrorOutOfMemory ? BEAR_ERR_NOMEM : BEAR_ERR_HIP;
+  }
+  p->bytes = item_bytes + sizeof(pln_tile_info) * n_tiles + sizeof(pln_heavy_col) * h_cnt[0] +
+             sizeof(pln_heavy_row) * h_cnt[1] + sizeof(uint64_t) * h_cnt[2];
+  *out = p;
+  return BEAR_OK;
+}
+
+int bear_plan_destroy(bear_plan *plan) {
+  if (!plan) return BEAR_OK;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(plan->device);
+  plan_free(plan);
+  (void)hipSetDevice(prev);
+  return BEAR_OK;
+}
+
+uint64_t bear_plan_bytes(const bear_plan *plan) { return plan ? plan->bytes : 0; }
+
+static pln_view plan_view(const bear_plan *p) {
+  pln_view v;
+  v.info = p->info;
+  v.items = p->items;
+  v.heavy_col = p->heavy_col;
+  v.heavy_row = p->heavy_row;
+  v.heavy_stop = p->heavy_stop;
+  v.n_heavy_col = p->n_heavy[0];
+  v.n_heavy_row = p->n_heavy[1];
+  v.n_heavy_stop = p->n_heavy[2];
+  return v;
+}
+
+static int grid_plan(const bear_ws *ws, uint64_t n_rows) {
+  uint64_t tiles = (n_rows + PLN_TILE - 1) / PLN_TILE;
+  uint64_t g = (uint64_t)ws->num_cu * 2;  // two resident blocks per CU (LDS-limited)
+  if (g > (uint64_t)ws->max_blocks) g = ws->max_blocks;
+  if (tiles < g) g = tiles;
+  return g < 1 ? 1 : (int)g;
+}
+
+int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
+                           uint64_t n_rows, double h_signed, double eps, double *out, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!plan || !out || (n_rows && (!counts || !prior))) return BEAR_ERR_INVALID_ARG;
+  if (plan->ncol != 5 || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
+    return BEAR_ERR_INVALID_ARG;
+  if (misaligned(counts) || misaligned(prior) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bear_params prm;
+  memset(&prm, 0, sizeof(prm));
+  prm.inv_h = 1.0 / exp(h_signed);
+  prm.eps = eps;
+  const int grid = grid_plan(ws, n_rows);
+  if (getenv("BEAR_DEBUG_TIMING"))  // developer switch: diagnostic build with in-kernel stamps
+    hipLaunchKernelGGL(dm_prior_plan_kernel<1>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, counts, prior, n_rows, prm,
+                       plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials, ws->dbg);
+  else
+    hipLaunchKernelGGL(dm_prior_plan_kernel<0>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, counts, prior, n_rows, prm,
+                       plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials, ws->dbg);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref,
+                         uint64_t n_rows, double h_signed, double tau_signed, double nu_signed, double eps,
+                         double *out, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!plan || !out || (n_rows && (!train || !ref))) return BEAR_ERR_INVALID_ARG;
+  if (plan->ncol != 4 || plan->n_rows != n_rows || plan->counts != train || plan->device != ws->device)
+    return BEAR_ERR_INVALID_ARG;
+  if (misaligned(train) || misaligned(ref) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bear_params prm;
+  const double tau = exp(tau_signed), nw = exp(nu_signed);
+  prm.inv_h = 1.0 / exp(h_signed);
+  prm.eps = eps;
+  prm.E = exp(-tau);
+  prm.tauE = tau * prm.E;
+  prm.tau = tau;
+  prm.V = 1.0 / (nw + 1.0);
+  prm.nw = nw;
+  const int grid = grid_plan(ws, n_rows);
+  hipLaunchKernelGGL(dm_ref_plan_kernel, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, train, ref, n_rows, prm,
+                     plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 4, out);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
 int bear_dm_items_f64(bear_ws *ws, const double *x, const uint32_t *c, uint64_t n, int path, double *D, double *P,
                       void *stream) {
   int st = check_ws(ws);
@@ -204,6 +425,24 @@ int bear_dm_items_f64(bear_ws *ws, const double *x, const uint32_t *c, uint64_t 
                      reinterpret_cast<const double2 *>(ws->logtab), D, P);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
+}
+
+// Developer probe (not part of include/bear_hip.h): resident blocks per CU the runtime reports for
+// the two sorted kernels at their dynamic-LDS sizes.
+// Developer probe: copies the phase-timing buffer written by BEAR_DEBUG_STOP=9 (n u64 words) to the host.
+int bear_debug_read_timing(bear_ws *ws, unsigned long long *host, int n_words) {
+  if (!ws || !host) return BEAR_ERR_INVALID_ARG;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(host, ws->dbg, sizeof(unsigned long long) * (size_t)n_words, hipMemcpyDeviceToHost));
+  return BEAR_OK;
+}
+
+int bear_debug_occupancy(int which) {
+  int nb = -1;
+  hipError_t e = which == 0
+      ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dm_prior_sorted_kernel<0>, SRT_THREADS, sizeof(srt_lds_n))
+      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dm_ref_sorted_kernel, SRT_THREADS, sizeof(srt_lds_r));
+  return e == hipSuccess ? nb : -1000 - (int)e;
 }
 
 int bear_synth_counts_u32(uint64_t seed, uint64_t row0, uint64_t n_rows, int dense, uint32_t *train,

@@ -57,6 +57,10 @@ def _stream():
 def _check_rows(t, dtype, name):
     if not (t.is_cuda and t.dtype == dtype and t.dim() == 2 and t.shape[1] == 5 and t.is_contiguous()):
         raise ValueError(f"{name} must be a contiguous CUDA tensor of shape [N, 5] and dtype {dtype}")
+    if t.data_ptr() % 16:
+        # the C ABI wants 16-byte aligned rows; a slice of a [N,5] tensor may start on any row
+        t = t.clone()
+    return t
 
 
 def counts_dtype():
@@ -68,8 +72,8 @@ def counts_dtype():
 def dm_prior(counts, prior, h_signed, eps=EPSILON, train_ar=False, want_grad=False, out=None, ws=None):
     """sum LL and d/dh_signed over rows (bear_net._train_step arithmetic, bear_net.py:146-197).
     Returns (out[2] device tensor, grad_prior or None)."""
-    _check_rows(counts, torch.int32, "counts")
-    _check_rows(prior, torch.float64, "prior")
+    counts = _check_rows(counts, torch.int32, "counts")
+    prior = _check_rows(prior, torch.float64, "prior")
     if counts.shape[0] != prior.shape[0]:
         raise ValueError("counts and prior must have the same number of rows")
     ws = ws or default_workspace(counts.device)
@@ -86,8 +90,8 @@ def dm_prior(counts, prior, h_signed, eps=EPSILON, train_ar=False, want_grad=Fal
 def dm_ref(train, ref, h_signed, tau_signed, nu_signed, eps=EPSILON, train_ar=False, out=None, ws=None):
     """[sum LL, d/dh_signed, d/dtau_signed, d/dnet_weight_signed] (bear_ref._train_step
     arithmetic with the stop net function, bear_ref.py:207-259)."""
-    _check_rows(train, torch.int32, "train")
-    _check_rows(ref, torch.int32, "ref")
+    train = _check_rows(train, torch.int32, "train")
+    ref = _check_rows(ref, torch.int32, "ref")
     if train.shape[0] != ref.shape[0]:
         raise ValueError("train and ref must have the same number of rows")
     ws = ws or default_workspace(train.device)
@@ -97,6 +101,65 @@ def dm_ref(train, ref, h_signed, tau_signed, nu_signed, eps=EPSILON, train_ar=Fa
         st = _lib.lib().bear_dm_ref_f64(ws.handle, _ptr(train), _ptr(ref), train.shape[0], float(h_signed), float(tau_signed),
                                         float(nu_signed), float(eps), int(bool(train_ar)), _ptr(out), _stream())
     _lib.check(st, "bear_dm_ref_f64")
+    return out
+
+
+class Plan:
+    """Count-dependent part of the hot path for a table that stays resident across optimizer steps
+    (work items sorted by count; include/bear_hip.h "Planned variants").  Keeps the count tensor alive."""
+
+    def __init__(self, counts, ncol, ws=None):
+        counts = _check_rows(counts, torch.int32, "counts")
+        self.counts = counts
+        self.ncol = int(ncol)
+        self.ws = ws or default_workspace(counts.device)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(counts.device):
+            torch.cuda.current_stream().synchronize()  # plan construction runs on the default stream
+            st = _lib.lib().bear_plan_create(self.ws.handle, _ptr(counts), counts.shape[0], self.ncol, ctypes.byref(h))
+        _lib.check(st, "bear_plan_create")
+        self._h = h
+
+    @property
+    def nbytes(self):
+        return int(_lib.lib().bear_plan_bytes(self._h))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().bear_plan_destroy(h)
+            except Exception:
+                pass
+
+
+def dm_prior_planned(plan, prior, h_signed, eps=EPSILON, out=None):
+    """Planned twin of dm_prior (BEAR mode, no gradient rows): [sum LL, d/dh_signed]."""
+    counts = plan.counts
+    _check_rows(prior, torch.float64, "prior")
+    if prior.data_ptr() % 16 or prior.shape[0] != counts.shape[0] or plan.ncol != 5:
+        raise ValueError("prior must be 16-byte aligned with one row per planned context (plan ncol=5)")
+    if out is None:
+        out = torch.empty(2, dtype=torch.float64, device=counts.device)
+    with torch.cuda.device(counts.device):
+        st = _lib.lib().bear_dm_prior_plan_f64(plan.ws.handle, plan._h, _ptr(counts), _ptr(prior), counts.shape[0],
+                                               float(h_signed), float(eps), _ptr(out), _stream())
+    _lib.check(st, "bear_dm_prior_plan_f64")
+    return out
+
+
+def dm_ref_planned(plan, ref, h_signed, tau_signed, nu_signed, eps=EPSILON, out=None):
+    """Planned twin of dm_ref (BEAR mode): [sum LL, d/dh_signed, d/dtau_signed, d/dnet_weight_signed]."""
+    train = plan.counts
+    _check_rows(ref, torch.int32, "ref")
+    if ref.data_ptr() % 16 or ref.shape[0] != train.shape[0] or plan.ncol != 4:
+        raise ValueError("ref must be 16-byte aligned with one row per planned context (plan ncol=4)")
+    if out is None:
+        out = torch.empty(4, dtype=torch.float64, device=train.device)
+    with torch.cuda.device(train.device):
+        st = _lib.lib().bear_dm_ref_plan_f64(plan.ws.handle, plan._h, _ptr(train), _ptr(ref), train.shape[0], float(h_signed),
+                                             float(tau_signed), float(nu_signed), float(eps), _ptr(out), _stream())
+    _lib.check(st, "bear_dm_ref_plan_f64")
     return out
 
 

@@ -87,6 +87,28 @@ int bear_dm_ref_f64(bear_ws *ws, const uint32_t *train, const uint32_t *ref, uin
                     double *out, void *stream);
 
 /*
+ * Planned variants: the per-step hot path for a count table that stays resident in HBM across
+ * optimizer steps (the reference re-reads one cached table every epoch, bear_model/dataloader.py:47-48).
+ * A plan holds what depends on the counts only -- per 512-context tile the (context, column) work
+ * items sorted by count, as uint16 offsets, plus global lists of the rare large-count items -- so
+ * the per-step kernels do no sorting.  Results are identical to the unplanned entry points.
+ *   bear_plan_create: synchronous; `ncol` = 5 for bear_dm_prior_plan_f64 (all columns are items),
+ *     4 for bear_dm_ref_plan_f64 (the stop column has a context-independent concentration).
+ *     The plan is valid for exactly the buffer contents it was built from; rebuild after any change.
+ *   bear_plan_bytes: device bytes held by the plan (= extra HBM traffic per step).
+ * The library owns the plan's device memory; bear_plan_destroy releases it.
+ */
+typedef struct bear_plan bear_plan;
+int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int ncol, bear_plan **out);
+int bear_plan_destroy(bear_plan *plan);
+uint64_t bear_plan_bytes(const bear_plan *plan);
+int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
+                           uint64_t n_rows, double h_signed, double eps, double *out, void *stream);
+int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref,
+                         uint64_t n_rows, double h_signed, double tau_signed, double nu_signed, double eps,
+                         double *out, void *stream);
+
+/*
  * The primitive underneath both entry points, item by item (tests / diagnostics): for x > 0 and
  * integer c >= 0,  D[i] = lgamma(x+c) - lgamma(x)  and  P[i] = digamma(x+c) - digamma(x)
  * -- the two quantities TFP's lbeta and its autodiff yield in bear_model/core.py:73-74.

@@ -12,10 +12,14 @@ t = kernels.synth_counts(20211012, 0, N, dev, want=("train", "ref"))
 f = kernels.synth_prior(20211012, 0, N, dev) if mode in ("both", "prior") else None
 args = (0.0, float(np.log(1 / 30)), float(-np.log(100)))
 torch.cuda.synchronize()
+planned = os.environ.get("BEAR_PROF_UNPLANNED") is None
+if planned:
+    plan_n = kernels.Plan(t["train"], 5) if mode in ("both", "prior") else None
+    plan_r = kernels.Plan(t["train"], 4) if mode in ("both", "ref") else None
 for _ in range(reps):
     if mode in ("both", "prior"):
-        kernels.dm_prior(t["train"], f, 0.0)
+        kernels.dm_prior_planned(plan_n, f, 0.0) if planned else kernels.dm_prior(t["train"], f, 0.0)
     if mode in ("both", "ref"):
-        kernels.dm_ref(t["train"], t["ref"], *args)
+        kernels.dm_ref_planned(plan_r, t["ref"], *args) if planned else kernels.dm_ref(t["train"], t["ref"], *args)
 torch.cuda.synchronize()
 print("done")

@@ -18,7 +18,15 @@ wr = co.dm_ref(tr, rf, *args, nthreads=8); wn, _ = co.dm_prior(tr, f[:M].cpu().n
 gr = kernels.dm_ref(t["train"][:M], t["ref"][:M], *args).cpu().numpy(); gn = kernels.dm_prior(t["train"][:M], f[:M], 0.0)[0].cpu().numpy()
 print("rel err ref  ", np.abs(gr - wr) / np.abs(wr))
 print("rel err prior", np.abs(gn - wn) / np.abs(wn))
-for name, fn, bpr in [("ref", lambda: kernels.dm_ref(t["train"], t["ref"], *args), 40),
+import time as _t
+_t0 = _t.time(); plan_r = kernels.Plan(t["train"], 4); plan_n = kernels.Plan(t["train"], 5); torch.cuda.synchronize()
+print("plan build (both) %.3f s; bytes/row: ref %.2f net %.2f" % (_t.time() - _t0, plan_r.nbytes / N, plan_n.nbytes / N))
+gpr = kernels.dm_ref_planned(plan_r, t["ref"], *args).cpu().numpy(); gpn = kernels.dm_prior_planned(plan_n, f, 0.0).cpu().numpy()
+wr_full = kernels.dm_ref(t["train"], t["ref"], *args).cpu().numpy(); wn_full = kernels.dm_prior(t["train"], f, 0.0)[0].cpu().numpy()
+print("planned vs unplanned rel diff", np.abs(gpr - wr_full) / np.abs(wr_full), np.abs(gpn - wn_full) / np.abs(wn_full))
+for name, fn, bpr in [("ref_plan", lambda: kernels.dm_ref_planned(plan_r, t["ref"], *args), 40),
+                      ("prior_plan", lambda: kernels.dm_prior_planned(plan_n, f, 0.0), 60),
+                      ("ref", lambda: kernels.dm_ref(t["train"], t["ref"], *args), 40),
                       ("prior", lambda: kernels.dm_prior(t["train"], f, 0.0)[0], 60),
                       ("prior+grad", lambda: kernels.dm_prior(t["train"], f, 0.0, want_grad=True)[0], 60),
                       ("ref_ar", lambda: kernels.dm_ref(t["train"], t["ref"], *args, train_ar=True), 40)]:

@@ -201,8 +201,9 @@ def test_item_paths_against_mpmath_grid(dev):
         D, P = kernels.dm_items(dx, dc, path=path)
         D, P = D.cpu().numpy(), P.cpu().numpy()
         # absolute tolerance scaled by the L1 mass of the sum (sum |log(x+j)|), relative 1e-13
-        massD = np.array([np.sum(np.abs(np.log(x + np.arange(min(int(c), 64))))) + abs(d) for x, c, d in zip(X, C, Dw)])
-        assert np.all(np.abs(D - Dw) <= 2e-13 * massD + 1e-300), (path, np.max(np.abs(D - Dw) / (massD + 1e-300)))
+        massD = np.array([np.sum(np.abs(np.log(x + np.arange(min(int(c), 64))))) + abs(d) + abs(gammaln(x)) * (c > 0)
+                          for x, c, d in zip(X, C, Dw)])
+        assert np.all(np.abs(D - Dw) <= 4e-13 * massD + 1e-15), (path, np.max(np.abs(D - Dw) / (massD + 1e-300)))
         assert np.all(np.abs(P - Pw) <= 1e-13 * np.abs(Pw) + 1e-300), (path, np.max(np.abs(P - Pw) / (np.abs(Pw) + 1e-300)))
     # out-of-domain concentration -> NaN, never a silent number
     bad = torch.tensor([0.0, -1.0, float("nan")], dtype=torch.float64, device=dev)
@@ -223,3 +224,64 @@ def test_sorted_kernel_matches_rows_kernel(dev):
     # d/dh_signed is also recoverable from the gradient rows: sum g * (-prior)
     dh = -(g * d_f).sum().item()
     assert abs(dh - a.cpu().numpy()[1]) <= 1e-10 * abs(dh)
+
+
+@pytest.mark.parametrize("case", ["ysd1", "sparse", "sparse_hot", "dense", "edge", "one_row"])
+def test_planned_kernels_parity(case, dev, ysd1):
+    """The planned (sort-at-load-time) kernels against the oracle, and against the unplanned
+    kernels, on every case incl. ragged tiles, Stirling-path items and uint32-range counts."""
+    from bear_amd import kernels
+    if case == "ysd1":
+        tr, rf = ysd1[1][:, 0].astype(np.uint32), ysd1[1][:, 2].astype(np.uint32)
+    else:
+        tr, rf = CASES_REF[case]()
+    d_tr, d_rf = _to_dev(tr, dev), _to_dev(rf, dev)
+    plan_r = kernels.Plan(d_tr, 4)
+    plan_n = kernels.Plan(d_tr, 5)
+    assert plan_r.nbytes > 0 and plan_n.nbytes >= plan_r.nbytes
+    for args in PARAMS:
+        want = co.dm_ref(tr, rf, *args, nthreads=4)
+        got = kernels.dm_ref_planned(plan_r, d_rf, *args).cpu().numpy()
+        _close(got[0], want[0], ELBO_RTOL)
+        scale = np.abs(want[1:]).max() + abs(want[0]) * 1e-3
+        for k in range(1, 4):
+            _close(got[k], want[k], GRAD_RTOL, scale)
+        assert np.allclose(got, kernels.dm_ref(d_tr, d_rf, *args).cpu().numpy(), rtol=1e-11, atol=1e-9 * scale)
+    n = len(tr)
+    for seed, h_s, conc in [(1, 0.0, 1.0), (2, -3.0, 0.2), (3, 1.7, 5.0)]:
+        f = prior_rows(n, seed, conc)
+        if seed == 3:
+            f = f * np.linspace(0.5, 3.0, n)[:, None]  # rows that do not sum to one: every context owns its A
+        want, _ = co.dm_prior(tr, f, h_s, nthreads=4)
+        got = kernels.dm_prior_planned(plan_n, _to_dev(f, dev), h_s).cpu().numpy()
+        _close(got[0], want[0], ELBO_RTOL)
+        _close(got[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
+
+
+def test_planned_full_size_chunks(dev):
+    """Bench-scale table: planned == unplanned on the whole table; planned on sampled chunks ==
+    oracle; a plan refuses a different buffer."""
+    import torch
+    from bear_amd import kernels, _lib
+    N = 10_000_019
+    t = kernels.synth_counts(20211012, 0, N, dev, want=("train", "ref"))
+    f = kernels.synth_prior(20211012, 0, N, dev)
+    args = (0.3, np.log(1 / 30) + 0.1, -np.log(100))
+    pr, pn = kernels.Plan(t["train"], 4), kernels.Plan(t["train"], 5)
+    a = kernels.dm_ref_planned(pr, t["ref"], *args).cpu().numpy()
+    b = kernels.dm_ref(t["train"], t["ref"], *args).cpu().numpy()
+    assert np.allclose(a, b, rtol=1e-12)
+    a = kernels.dm_prior_planned(pn, f, -0.4).cpu().numpy()
+    b = kernels.dm_prior(t["train"], f, -0.4)[0].cpu().numpy()
+    assert np.allclose(a, b, rtol=1e-12)
+    lo, hi = 4_000_003, 4_100_003
+    tr, rf = t["train"][lo:hi].clone(), t["ref"][lo:hi].clone()
+    fc = f[lo:hi].clone()
+    got = kernels.dm_prior_planned(kernels.Plan(tr, 5), fc, -0.4).cpu().numpy()
+    want, _ = co.dm_prior(tr.cpu().numpy().view(np.uint32), fc.cpu().numpy(), -0.4, nthreads=4)
+    assert np.allclose(got, want, rtol=1e-10)
+    with pytest.raises(_lib.BearError):
+        other = t["train"].clone()
+        pn2 = kernels.Plan(other, 5)
+        pn2.counts = t["train"]  # wrong buffer for this plan
+        kernels.dm_prior_planned(pn2, f, 0.0)
