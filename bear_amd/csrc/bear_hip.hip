@@ -77,10 +77,13 @@ int bear_ws_create(int device, bear_ws **out) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_sorted_kernel<9>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(srt_lds_n));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<0>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<0, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<1>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<0, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<1, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_ref_plan_kernel),
@@ -228,6 +231,7 @@ struct bear_plan {
   pln_heavy_col *heavy_col;
   pln_heavy_row *heavy_row;
   uint64_t *heavy_stop;
+  unsigned long long *hist;  // [64]
   uint64_t n_heavy[3];
   uint64_t bytes;
 };
@@ -239,6 +243,7 @@ static void plan_free(bear_plan *p) {
   (void)hipFree(p->heavy_col);
   (void)hipFree(p->heavy_row);
   (void)hipFree(p->heavy_stop);
+  (void)hipFree(p->hist);
   delete p;
 }
 
@@ -267,9 +272,11 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   hipError_t e = hipMalloc(&d_nlight, sizeof(uint32_t) * n_tiles);
   if (e == hipSuccess) e = hipMalloc(&d_cnt, sizeof(unsigned long long) * 6);
   if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(unsigned long long) * 6);
+  if (e == hipSuccess) e = hipMalloc(&p->hist, sizeof(unsigned long long) * 2 * SRT_NKEY);
+  if (e == hipSuccess) e = hipMemset(p->hist, 0, sizeof(unsigned long long) * 2 * SRT_NKEY);
   int grid = (int)(n_tiles < (uint64_t)ws->num_cu * 4 ? n_tiles : (uint64_t)ws->num_cu * 4);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(plan_count_kernel, dim3(grid), dim3(PLN_BUILD_THREADS), 0, 0, counts, n_rows, ncol, d_nlight, d_cnt);
+    hipLaunchKernelGGL(plan_count_kernel, dim3(grid), dim3(PLN_BUILD_THREADS), 0, 0, counts, n_rows, ncol, d_nlight, d_cnt, p->hist);
     e = hipGetLastError();
   }
   unsigned long long h_cnt[3] = {0, 0, 0};
@@ -345,6 +352,7 @@ static pln_view plan_view(const bear_plan *p) {
   v.heavy_col = p->heavy_col;
   v.heavy_row = p->heavy_row;
   v.heavy_stop = p->heavy_stop;
+  v.hist = p->hist;
   v.n_heavy_col = p->n_heavy[0];
   v.n_heavy_row = p->n_heavy[1];
   v.n_heavy_stop = p->n_heavy[2];
@@ -360,7 +368,8 @@ static int grid_plan(const bear_ws *ws, uint64_t n_rows) {
 }
 
 int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
-                           uint64_t n_rows, double h_signed, double eps, double *out, void *stream) {
+                           uint64_t n_rows, double h_signed, double eps, int prior_normalized, double *out,
+                           void *stream) {
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
   if (!plan || !out || (n_rows && (!counts || !prior))) return BEAR_ERR_INVALID_ARG;
@@ -374,11 +383,14 @@ int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *c
   prm.eps = eps;
   const int grid = grid_plan(ws, n_rows);
   if (getenv("BEAR_DEBUG_TIMING"))  // developer switch: diagnostic build with in-kernel stamps
-    hipLaunchKernelGGL(dm_prior_plan_kernel<1>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, counts, prior, n_rows, prm,
-                       plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials, ws->dbg);
+    hipLaunchKernelGGL((dm_prior_plan_kernel<1, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, counts, prior, n_rows,
+                       prm, plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials, ws->dbg);
+  else if (prior_normalized)
+    hipLaunchKernelGGL((dm_prior_plan_kernel<0, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, counts, prior, n_rows,
+                       prm, plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials, ws->dbg);
   else
-    hipLaunchKernelGGL(dm_prior_plan_kernel<0>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, counts, prior, n_rows, prm,
-                       plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials, ws->dbg);
+    hipLaunchKernelGGL((dm_prior_plan_kernel<0, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, counts, prior, n_rows,
+                       prm, plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials, ws->dbg);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
   HIP_TRY(hipGetLastError());

@@ -57,9 +57,12 @@ struct pln_heavy_row {
 // column items, heavy contexts (n > SRT_CL) and, for ncol == 4, heavy stop counts.
 __global__ __launch_bounds__(PLN_BUILD_THREADS) void plan_count_kernel(const uint32_t *__restrict__ counts, uint64_t n_rows,
                                                                   int ncol, uint32_t *__restrict__ n_light,
-                                                                  unsigned long long *__restrict__ heavy_counts) {
+                                                                  unsigned long long *__restrict__ heavy_counts,
+                                                                  unsigned long long *__restrict__ hist) {
   __shared__ uint32_t s_light;
   __shared__ uint32_t s_heavy[3];
+  __shared__ uint32_t s_hist[2 * SRT_NKEY];  // [0..31]: contexts by total n, [32..63]: by stop count (n, c <= SRT_CL)
+  if (threadIdx.x < 2 * SRT_NKEY) s_hist[threadIdx.x] = 0;
   const uint64_t n_tiles = (n_rows + PLN_TILE - 1) / PLN_TILE;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     if (threadIdx.x == 0) {
@@ -83,7 +86,10 @@ __global__ __launch_bounds__(PLN_BUILD_THREADS) void plan_count_kernel(const uin
       if (light) atomicAdd(&s_light, light);
       if (hcol) atomicAdd(&s_heavy[0], hcol);
       if (nsat > SRT_CL) atomicAdd(&s_heavy[1], 1u);
-      if (ncol == 4 && counts[r * 5 + 4] > SRT_CL) atomicAdd(&s_heavy[2], 1u);
+      else if (nsat != 0) atomicAdd(&s_hist[nsat - 1], 1u);
+      const uint32_t c4 = counts[r * 5 + 4];
+      if (ncol == 4 && c4 > SRT_CL) atomicAdd(&s_heavy[2], 1u);
+      else if (ncol == 4 && c4 != 0) atomicAdd(&s_hist[SRT_NKEY + c4 - 1], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(PLN_BUILD_THREADS) void plan_count_kernel(const uin
     }
     __syncthreads();
   }
+  if (threadIdx.x < 2 * SRT_NKEY && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
 }
 
 // Pass 2: per tile, counting sort of the product-path items by c (LDS histogram, replicated 8x),
@@ -185,6 +192,7 @@ struct pln_view {  // device-side view of a plan
   const pln_heavy_col *heavy_col;
   const pln_heavy_row *heavy_row;
   const uint64_t *heavy_stop;
+  const unsigned long long *hist;  // [0..31] contexts with total n = j+1, [32..63] with stop count j+1 (<= SRT_CL)
   uint64_t n_heavy_col, n_heavy_row, n_heavy_stop;
 };
 
@@ -258,7 +266,10 @@ struct pln_lds_n {
   uint32_t ticket[2];                   // per buffer parity; zeroed one tile ahead
 };
 
-template <int TIMING>  // 1: diagnostic build recording per-wave s_memtime totals {top wait, stage issue, work, tiles}
+// NORM: the caller asserts that every prior row sums to one (true for every ar_func of the reference,
+// all of which end in a softmax, ar_funcs.py:44,97,121-126).  Then A = u + 5 eps for every context
+// and the context terms collapse to the plan's histogram over n: no per-context pass at all.
+template <int TIMING, bool NORM>  // TIMING 1: diagnostic build recording per-wave s_memtime totals
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_prior_plan_kernel(const uint32_t *__restrict__ counts,
                                                                         const double *__restrict__ prior, uint64_t n_rows,
                                                                         bear_params prm, pln_view pv,
@@ -340,9 +351,9 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_prior_plan
     // Work list of the tile, most expensive first: item units from the sorted tail down, then the
     // 64-context row chunks.  Waves draw tickets until the list is exhausted.
     const uint32_t n_units = (((ti_cur.n_light + 63u) & ~63u) + 64u * PLN_ILP - 1) / (64u * PLN_ILP);
-    const uint32_t n_work = n_units + PLN_TILE / 64;
+    const uint32_t n_work = n_units + (NORM ? 0u : PLN_TILE / 64);
     for (uint32_t w = pln_ticket(&S.ticket[buf], lane); w < n_work; w = pln_ticket(&S.ticket[buf], lane)) {
-      if (w < n_units) {
+      if (NORM || w < n_units) {
         // ---- D: column items
         pln_unit<PLN_ILP>(
             S.items[buf], ti_cur.n_light, n_units - 1 - w, lane, S.logtab,
@@ -420,6 +431,11 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_prior_plan
     const bear_dp o = srt_general(A, h.n);
     acc[0] -= o.D;
     acc[1] = __builtin_fma(A - eps5, o.P, acc[1]);
+  }
+  if (NORM && blockIdx.x == 0 && tid < SRT_CL) {  // context terms with the shared A, weighted by their multiplicity
+    const double m = (double)pv.hist[tid];
+    acc[0] -= m * S.tabD[tid];
+    acc[1] = __builtin_fma(u * m, S.tabP[tid], acc[1]);
   }
   __syncthreads();
   block_store_partials<2>(acc, partials);
@@ -522,11 +538,12 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_ref_plan_k
     const uint32_t *trn = S.trn[buf];
     const uint32_t *rfc = S.ref[buf];
     if (tid == 0) S.ticket[buf ^ 1u] = 0;
+    // The context term (x = A) and the stop column (x = x4) have the same concentration in every
+    // context: their sums over the table are the plan's histograms times two small tables (added
+    // once, after the loop).  Per tile only the column items b < 4 remain.
     const uint32_t n_units = (((ti_cur.n_light + 63u) & ~63u) + 64u * PLN_ILP - 1) / (64u * PLN_ILP);
-    const uint32_t n_work = n_units + PLN_TILE / 64;
-    for (uint32_t w = pln_ticket(&S.ticket[buf], lane); w < n_work; w = pln_ticket(&S.ticket[buf], lane)) {
-      if (w < n_units) {
-        // ---- D: column items b < 4
+    for (uint32_t w = pln_ticket(&S.ticket[buf], lane); w < n_units; w = pln_ticket(&S.ticket[buf], lane)) {
+      {
         pln_unit<PLN_ILP>(
             S.items[buf], ti_cur.n_light, n_units - 1 - w, lane, S.logtab,
             [&](uint32_t off, double *x) {
@@ -536,29 +553,6 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_ref_plan_k
               return trn[off];
             },
             accumulate);
-        continue;
-      }
-      // ---- A: context term and stop column from the tables (x is the same for every context)
-      const uint32_t row = (w - n_units) * 64u + lane;
-      const uint32_t rr = row < rows ? row : rows - 1;
-      uint32_t c[5], nsat = 0;
-#pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        c[b] = trn[rr * 5 + b];
-        const uint32_t s = nsat + c[b];
-        nsat = s < nsat ? 0xffffffffu : s;
-      }
-      if (row < rows) {
-        if (nsat != 0 && nsat <= SRT_CL) {
-          acc[0] -= S.tabD[0][nsat - 1];
-          acc[1] = __builtin_fma(u, S.tabP[0][nsat - 1], acc[1]);
-        }
-        if (c[4] != 0 && c[4] <= SRT_CL) {
-          const double P = S.tabP[1][c[4] - 1];
-          acc[0] += S.tabD[1][c[4] - 1];
-          acc[1] = __builtin_fma(eps - x4, P, acc[1]);
-          acc[3] = __builtin_fma(VU * nwV, P, acc[3]);  // d alpha_4/d nu_s = u nw V^2
-        }
       }
     }
     ti_cur = ti_nxt;
@@ -584,6 +578,15 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_ref_plan_k
     acc[0] += o.D;
     acc[1] = __builtin_fma(eps - x4, o.P, acc[1]);
     acc[3] = __builtin_fma(VU * nwV, o.P, acc[3]);
+  }
+  if (blockIdx.x == 0 && tid < SRT_CL) {
+    const double mn = (double)pv.hist[tid], m4 = (double)pv.hist[SRT_NKEY + tid];
+    acc[0] -= mn * S.tabD[0][tid];                                // context terms: -D(A, n)
+    acc[1] = __builtin_fma(u * mn, S.tabP[0][tid], acc[1]);
+    const double P4 = m4 * S.tabP[1][tid];                        // stop column: +D(x4, c)
+    acc[0] += m4 * S.tabD[1][tid];
+    acc[1] = __builtin_fma(eps - x4, P4, acc[1]);
+    acc[3] = __builtin_fma(VU * nwV, P4, acc[3]);                 // d alpha_4/d nu_s = u nw V^2
   }
   __syncthreads();
   block_store_partials<4>(acc, partials);

@@ -133,8 +133,9 @@ class Plan:
                 pass
 
 
-def dm_prior_planned(plan, prior, h_signed, eps=EPSILON, out=None):
-    """Planned twin of dm_prior (BEAR mode, no gradient rows): [sum LL, d/dh_signed]."""
+def dm_prior_planned(plan, prior, h_signed, eps=EPSILON, out=None, normalized=False):
+    """Planned twin of dm_prior (BEAR mode, no gradient rows): [sum LL, d/dh_signed].
+    normalized=True asserts that every prior row sums to one (any softmax output)."""
     counts = plan.counts
     _check_rows(prior, torch.float64, "prior")
     if prior.data_ptr() % 16 or prior.shape[0] != counts.shape[0] or plan.ncol != 5:
@@ -143,7 +144,7 @@ def dm_prior_planned(plan, prior, h_signed, eps=EPSILON, out=None):
         out = torch.empty(2, dtype=torch.float64, device=counts.device)
     with torch.cuda.device(counts.device):
         st = _lib.lib().bear_dm_prior_plan_f64(plan.ws.handle, plan._h, _ptr(counts), _ptr(prior), counts.shape[0],
-                                               float(h_signed), float(eps), _ptr(out), _stream())
+                                               float(h_signed), float(eps), int(bool(normalized)), _ptr(out), _stream())
     _lib.check(st, "bear_dm_prior_plan_f64")
     return out
 

@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: k-mer contexts/sec of the fused
+DM-marginal + gradient hot path at k=13, fp64, with the ELBO checked against the CPU oracle.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--contexts C] [--workload net|ref]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over the rank's resident shard of a synthetic k=13 count
+table (C contexts per GPU, weak scaling): the planned DM-marginal + d/dh kernel, its fixed-order
+finalize kernel and, for N > 1, the single RCCL all-reduce of (ELBO, gradients) -- what
+bear_net.py:290 + :278-282 do once per optimizer step.  Inputs are resident in HBM before the timed
+region; the plan (count-only sort) is built once per table like the reference's
+cached dataset and its build time is reported, not timed.
+
+workload "net" (default, the headline of BASELINE.md section 3): bear_net DM-marginal + d/dh over
+count rows + fp64 prior rows, 60 algorithmic bytes per context.  workload "ref": bear_ref with the
+stop (flat) AR prior of BASELINE.json configs[1], train + reference count rows, 40 B per context.
+The other workload is measured too and reported under "also".
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+BYTES_PER_CONTEXT = {"net": 60, "ref": 40}
+SEED = 20211012
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--contexts", type=float, default=1e8, help="contexts per GPU")
+    ap.add_argument("--workload", choices=["net", "ref"], default="net")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs MI355X devices"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from bear_amd import kernels
+
+    n = int(args.contexts)
+    row0 = rank * n  # contiguous row shards of one global table
+    h_s, tau_s, nu_s = 0.0, float(np.log(1 / 30)), float(-np.log(100))  # reference initial values
+
+    t = kernels.synth_counts(SEED, row0, n, dev, want=("train", "ref"))
+    prior = kernels.synth_prior(SEED, row0, n, dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    plans = {"net": kernels.Plan(t["train"], 5), "ref": kernels.Plan(t["train"], 4)}
+    torch.cuda.synchronize()
+    plan_build_s = time.time() - t0
+
+    outs = {"net": torch.zeros(2, dtype=torch.float64, device=dev), "ref": torch.zeros(4, dtype=torch.float64, device=dev)}
+
+    def launch(wl):
+        if wl == "net":
+            kernels.dm_prior_planned(plans["net"], prior, h_s, out=outs["net"])
+        else:
+            kernels.dm_ref_planned(plans["ref"], t["ref"], h_s, tau_s, nu_s, out=outs["ref"])
+
+    def step(wl, ev=None):
+        if ev is not None:
+            ev[0].record()
+        launch(wl)
+        if ev is not None:
+            ev[1].record()
+        if world > 1:
+            dist.all_reduce(outs[wl])  # one packed RCCL all-reduce of (ELBO, gradients) per step
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def measure(wl, steps, warmup):
+        for _ in range(warmup):
+            step(wl)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t_start = time.perf_counter()
+        for k in range(steps):
+            step(wl, evs[k])
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        if world > 1:
+            el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            elapsed = float(el.item())
+        # kernel-only duration (main kernel + finalize), HIP events on the launch stream
+        k_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        return elapsed, k_ms, outs[wl].cpu().numpy().copy()
+
+    primary = args.workload
+    other = "ref" if primary == "net" else "net"
+    elapsed, k_ms, result = measure(primary, args.steps, args.warmup)
+    o_elapsed, o_k_ms, o_result = measure(other, max(5, args.steps // 5), 2)
+    norm_ms = None
+    if rank == 0:  # the same net kernel with the caller asserting normalised prior rows
+        for _ in range(2):
+            kernels.dm_prior_planned(plans["net"], prior, h_s, normalized=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            kernels.dm_prior_planned(plans["net"], prior, h_s, normalized=True)
+        e1.record()
+        torch.cuda.synchronize()
+        norm_ms = e0.elapsed_time(e1) / 10
+
+    total = n * world
+    value = total * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    bpc = BYTES_PER_CONTEXT[primary]
+    achieved = n * bpc / (k_ms * 1e-3) / 1e9  # per-GPU algorithmic GB/s of the dominant kernel
+
+    line = None
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(primary, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "k-mer contexts/sec (DM-marginal+grad h), k=13",
+            "value": value,
+            "unit": "contexts/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("bear_net DM-marginal + d/dh over count rows + fp64 prior rows (mode N), k=13, "
+                             if primary == "net" else
+                             "bear_ref with the stop (flat) AR prior (BASELINE configs[1], mode R), k=13, ")
+                            + f"{n:.3g} synthetic contexts per GPU x {world} GPU, planned kernels",
+                "contexts_per_gpu": n,
+                "bytes_per_context": bpc,
+                "parallelism": f"rows sharded over {world} GPU, one RCCL all-reduce of (ELBO, grads) per step" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "kernel": "dm_prior_plan_kernel" if primary == "net" else "dm_ref_plan_kernel",
+                "kernel_ms": k_ms,
+            },
+            "plan_build_s": plan_build_s,
+            "plan_bytes_per_context": plans[primary].nbytes / n,
+            "result": result.tolist(),
+            "also": {
+                other: {
+                    "contexts_per_s": total / (o_elapsed / max(5, args.steps // 5)),
+                    "kernel_ms": o_k_ms,
+                    "achieved_GBps": n * BYTES_PER_CONTEXT[other] / (o_k_ms * 1e-3) / 1e9,
+                    "frac": n * BYTES_PER_CONTEXT[other] / (o_k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                },
+                "net_prior_normalized_asserted": None if norm_ms is None else {
+                    "kernel_ms": norm_ms, "contexts_per_s_per_gpu": n / (norm_ms * 1e-3)},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"], line["elbo_rel_err_vs_cpu"] = cpu_baseline(kernels, t, prior, primary, (h_s, tau_s, nu_s), dev)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(kernels, t, prior, workload, params, dev):
+    """The oracle's C restatement (libm lgamma_r + series digamma, OpenMP over all host cores)
+    on a bounded sample of the same table; also the GPU-vs-CPU ELBO relative error on it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle as co  # checker only: never on the measured or shipped path
+
+    cores = os.cpu_count() or 1
+    h_s, tau_s, nu_s = params
+
+    def run(m):
+        tr = t["train"][:m].cpu().numpy().view(np.uint32)
+        if workload == "net":
+            f = prior[:m].cpu().numpy()
+            t0 = time.perf_counter()
+            out, _ = co.dm_prior(tr, f, h_s, nthreads=cores)
+            return time.perf_counter() - t0, out
+        rf = t["ref"][:m].cpu().numpy().view(np.uint32)
+        t0 = time.perf_counter()
+        out = co.dm_ref(tr, rf, h_s, tau_s, nu_s, nthreads=cores)
+        return time.perf_counter() - t0, out
+
+    n = t["train"].shape[0]
+    run(min(n, 200_000))  # thread start-up
+    dt, _ = run(min(n, 2_000_000))
+    rate = min(n, 2_000_000) / dt
+    m = int(min(n, 30_000_000, max(2_000_000, rate * 12)))  # ~12 s of CPU work
+    dt, want = run(m)
+    if workload == "net":
+        got = kernels.dm_prior(t["train"][:m], prior[:m], h_s)[0].cpu().numpy()
+        p = kernels.Plan(t["train"][:m].clone(), 5)
+        got_p = kernels.dm_prior_planned(p, prior[:m].clone(), h_s).cpu().numpy()
+    else:
+        got = kernels.dm_ref(t["train"][:m], t["ref"][:m], h_s, tau_s, nu_s).cpu().numpy()
+        p = kernels.Plan(t["train"][:m].clone(), 4)
+        got_p = kernels.dm_ref_planned(p, t["ref"][:m].clone(), h_s, tau_s, nu_s).cpu().numpy()
+    rel = float(max(abs(got[0] - want[0]), abs(got_p[0] - want[0])) / abs(want[0]))
+    base = {
+        "value": m / dt,
+        "unit": "contexts/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {m} contexts of the same synthetic table, oracle/bear_oracle.c (libm lgamma_r + series digamma, "
+                  f"OpenMP x{cores}); TensorFlow is not installable here, so this restatement stands in for the TF-CPU path",
+    }
+    return base, rel
+
+
+if __name__ == "__main__":
+    main()

@@ -102,8 +102,14 @@ typedef struct bear_plan bear_plan;
 int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int ncol, bear_plan **out);
 int bear_plan_destroy(bear_plan *plan);
 uint64_t bear_plan_bytes(const bear_plan *plan);
+/* prior_normalized != 0: the caller asserts that every row of `prior` sums to one -- true for each
+ * ar_func of the reference, all of which end in a softmax (bear_model/ar_funcs.py:44,97,121-126).
+ * The concentration total A = 1/h + 5 eps is then shared by all contexts and the context terms
+ * come from the plan's histogram of totals; with 0 the kernel sums each row and uses the shared A
+ * only where the sum is 1 to 2 ulp. */
 int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
-                           uint64_t n_rows, double h_signed, double eps, double *out, void *stream);
+                           uint64_t n_rows, double h_signed, double eps, int prior_normalized, double *out,
+                           void *stream);
 int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref,
                          uint64_t n_rows, double h_signed, double tau_signed, double nu_signed, double eps,
                          double *out, void *stream);

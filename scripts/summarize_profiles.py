@@ -1,0 +1,55 @@
+"""Condenses gpurun_out/<tag>_{stats,fetch,write,sq} (rocprofv3 csv) into profiles/<tag>_*.{csv,md,json}."""
+import collections, csv, glob, json, os, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+out_md = [f"# rocprofv3 summary, round tag {tag}", "", "Command: `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline` under",
+          "`rocprofv3 --kernel-trace --stats` (kernel stats) and, in separate passes, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`,",
+          "`--pmc SQ_*` (scripts/profile_round.sh).", ""]
+ks = glob.glob(os.path.join(src, f"{tag}_stats", "**", "*_kernel_stats.csv"), recursive=True)
+if ks:
+    rows = list(csv.DictReader(open(ks[0])))
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as fh:
+        w = csv.DictWriter(fh, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(rows)
+    out_md += ["## kernel stats (--kernel-trace --stats)", "", "| kernel | calls | avg ns | total % |", "|---|---|---|---|"]
+    for r in rows:
+        out_md.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['Percentage']} |")
+    out_md.append("")
+traffic = {}
+def pmc(kind):
+    fs = glob.glob(os.path.join(src, f"{tag}_{kind}", "**", "*_counter_collection.csv"), recursive=True)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in fs:
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+for kind in ("fetch", "write", "sq"):
+    agg = pmc(kind)
+    if not agg: continue
+    out_md += [f"## PMC pass: {kind}", "", "| kernel | counter | mean per launch |", "|---|---|---|"]
+    for k, v in agg.items():
+        if "plan_kernel" not in k and "sorted" not in k: continue
+        for c, x in v.items():
+            out_md.append(f"| `{k[:40]}` | {c} | {sum(x)/len(x):.0f} |")
+            name = "ref" if "dm_ref" in k else ("net_norm" if "true>" in k else "net")
+            if c == "FETCH_SIZE":
+                # FETCH_SIZE is in KiB and, on gfx950, counts a wide coalesced stream at half its bytes
+                # (MI355X_MICROARCH.md, HBM): bytes = FETCH_SIZE * 1024 * 2
+                traffic.setdefault(name, {})["fetch_bytes_per_launch"] = sum(x) / len(x) * 1024 * 2
+            if c == "WRITE_SIZE":
+                traffic.setdefault(name, {})["write_bytes_per_launch"] = sum(x) / len(x) * 1024
+    out_md.append("")
+for name, d in traffic.items():
+    d["bytes_per_launch"] = d.get("fetch_bytes_per_launch", 0) + d.get("write_bytes_per_launch", 0)
+if traffic:
+    json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+    json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+    out_md += ["## HBM traffic per launch (corrected as MI355X_MICROARCH.md prescribes)", "", "```", json.dumps(traffic, indent=1), "```", ""]
+log = os.path.join(src, f"{tag}_stats.log")
+if os.path.exists(log):
+    last = [l for l in open(log).read().splitlines() if l.startswith("{")]
+    if last:
+        out_md += ["## bench line of the profiled run (profiled runs clock lower than un-profiled ones)", "", "```", last[-1], "```", ""]
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(out_md))
+print("\n".join(out_md))

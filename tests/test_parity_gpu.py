@@ -256,6 +256,10 @@ def test_planned_kernels_parity(case, dev, ysd1):
         got = kernels.dm_prior_planned(plan_n, _to_dev(f, dev), h_s).cpu().numpy()
         _close(got[0], want[0], ELBO_RTOL)
         _close(got[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
+        if seed != 3:  # rows sum to one: the caller may assert it (context terms from the plan's histogram)
+            got = kernels.dm_prior_planned(plan_n, _to_dev(f, dev), h_s, normalized=True).cpu().numpy()
+            _close(got[0], want[0], ELBO_RTOL)
+            _close(got[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
 
 
 def test_planned_full_size_chunks(dev):
