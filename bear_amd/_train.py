@@ -1,0 +1,143 @@
+"""Shared machinery of the bear_net / bear_ref drivers: resident shards, Keras-equivalent Adam,
+the per-step reduce, and the held-out evaluation built on the DM kernels."""
+import math
+
+import numpy as np
+import torch
+
+from . import core, dist, kernels
+from .dataloader import CountDataset
+
+epsilon = core.epsilon
+
+
+class KerasAdam:
+    """tf.keras.optimizers.Adam defaults (beta 0.9 / 0.999, epsilon 1e-7) with Keras' update
+    ``theta -= lr_t * m / (sqrt(v) + eps)``, ``lr_t = lr sqrt(1 - b2^t) / (1 - b1^t)``
+    (the reference builds it by name, bear_net.py:264-265)."""
+
+    def __init__(self, params, learning_rate, beta_1=0.9, beta_2=0.999, eps=1e-7):
+        self.params = list(params)
+        self.lr, self.b1, self.b2, self.eps = float(learning_rate), beta_1, beta_2, eps
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.t = 0
+
+    @torch.no_grad()
+    def apply_gradients(self, grads):
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        for p, g, m, v in zip(self.params, grads, self.m, self.v):
+            if g is None:
+                continue
+            g = g.to(p.dtype).to(p.device)
+            m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+            p.sub_(lr_t * m / (v.sqrt() + self.eps))
+
+
+def make_optimizer(name, params, learning_rate):
+    if name == "Adam":
+        return KerasAdam(params, learning_rate)
+    opt = getattr(torch.optim, name)(params, lr=learning_rate)
+
+    class _Wrap:
+        def apply_gradients(self, grads):
+            for p, g in zip(params, grads):
+                p.grad = None if g is None else g.to(p.dtype).to(p.device)
+            opt.step()
+    return _Wrap()
+
+
+def require_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("bear_amd trains on MI355X only (libbear_hip.so has no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class ResidentBatches:
+    """This rank's row shard of every batch of one epoch, uploaded once: per batch the device slabs of the
+    requested dataset columns, the k-mer codes, and (lazily) the kernel plans."""
+
+    def __init__(self, data, columns, device, want_codes=False):
+        if not isinstance(data, CountDataset):
+            raise TypeError("train / evaluation expect the CountDataset returned by bear_amd.dataloader")
+        self.data, self.device = data, device
+        self.batches = []
+        codes = data.codes() if want_codes else None
+        for a, b in data.batch_bounds():
+            lo, hi = dist.shard_rows(b - a)
+            lo, hi = a + lo, a + hi
+            entry = {"global_rows": b - a, "rows": hi - lo}
+            for name, col in columns.items():
+                entry[name] = torch.from_numpy(np.ascontiguousarray(data.counts[col, lo:hi]).view(np.int32)).to(device)
+            if codes is not None:
+                entry["codes"] = torch.from_numpy(np.ascontiguousarray(codes[lo:hi])).to(device)
+            entry["plans"] = {}
+            self.batches.append(entry)
+
+    def plan(self, k, column, ncol):
+        e = self.batches[k]
+        key = (column, ncol)
+        if key not in e["plans"]:
+            e["plans"][key] = kernels.Plan(e[column], ncol)
+        return e["plans"][key]
+
+
+def counts_f64(t):
+    """uint32 counts carried in int32 storage -> float64."""
+    return torch.where(t < 0, t.to(torch.float64) + 4294967296.0, t.to(torch.float64))
+
+
+def evaluation_sums(test, prior, h, van_reg, train=None, eps=epsilon, generator=None):
+    """The 7 partial sums of ``_evaluation_step`` (bear_net.py:323-371) for this rank's rows.
+    test / train: uint32 [n,5] device slabs; prior: float64 [n,5] = ar_func rows; h: float or 1-D sequence
+    (h_scan, bear_net.py:523).  Every log-likelihood is one launch of the DM kernels on a prepared
+    concentration / probability slab; the arg-max bookkeeping is elementwise torch."""
+    dev = test.device
+    ct = counts_f64(test)
+    ctr = counts_f64(train) if train is not None else None
+    hs = [float(x) for x in np.atleast_1d(np.asarray(h, dtype=np.float64))]
+    van = [float(v) for v in np.atleast_1d(np.asarray(van_reg, dtype=np.float64))]
+    n = test.shape[0]
+
+    def noisy_correct(values, scale):
+        noise = scale * torch.randn(values.shape, dtype=values.dtype, device=dev, generator=generator)
+        idx = torch.argmax(values + noise, dim=-1, keepdim=True)
+        return torch.gather(ct, 1, idx).sum().item()
+
+    ll_ear, cor_ear = [], []
+    for hv in hs:
+        conc = prior / hv + (ctr if ctr is not None else 0.0)                       # bear_net.py:43, :335-337
+        ll_ear.append(kernels.dm_prior(test, conc.contiguous(), 0.0, eps=eps)[0][0].item() if n else 0.0)
+        cor_ear.append(noisy_correct(conc + eps, 100 * eps) if n else 0.0)
+    ll_arm = kernels.dm_prior(test, prior.contiguous(), 0.0, eps=eps, train_ar=True)[0][0].item() if n else 0.0
+    cor_arm = noisy_correct(prior + eps, eps) if n else 0.0                         # core.py:134-136
+    ll_van, cor_van = [], []
+    for v in van:
+        conc = (ctr + v) if ctr is not None else torch.full((n, 5), v, dtype=torch.float64, device=dev)
+        ll_van.append(kernels.dm_prior(test, conc.contiguous(), 0.0, eps=eps)[0][0].item() if n else 0.0)
+        cor_van.append(noisy_correct(conc + eps, 100 * eps) if n else 0.0)
+    total_len = ct.sum().item()
+    return (np.array(ll_ear), ll_arm, np.array(ll_van), np.array(cor_ear), cor_arm, np.array(cor_van), total_len)
+
+
+def reduce_evaluation(parts, device, scalar_h):
+    """Sums the per-rank partials with one all-reduce and forms the reference's 9-tuple
+    (bear_net.py:459-463)."""
+    flat = torch.tensor(np.concatenate([np.atleast_1d(np.asarray(p, dtype=np.float64)).reshape(-1) for p in parts]),
+                        dtype=torch.float64, device=device if dist.world()[1] > 1 and torch.cuda.is_available() else "cpu")
+    dist.allreduce_sum_(flat)
+    flat = flat.cpu().numpy()
+    sizes = [np.atleast_1d(np.asarray(p)).size for p in parts]
+    out, k = [], 0
+    for s in sizes:
+        out.append(flat[k:k + s])
+        k += s
+    ll_ear, ll_arm, ll_van, cor_ear, cor_arm, cor_van, total = out
+    ll_arm, cor_arm, total = ll_arm[0], cor_arm[0], total[0]
+    if scalar_h:
+        ll_ear, cor_ear = ll_ear[0], cor_ear[0]
+    return (ll_ear, ll_arm, ll_van,
+            np.exp(-ll_ear / total), np.exp(-ll_arm / total), np.exp(-ll_van / total),
+            cor_ear / total, cor_arm / total, cor_van / total)

@@ -1,0 +1,99 @@
+"""AR-function plugin surface: host mirror of ``bear_model/ar_funcs.py``.
+
+``make_ar_func_<name>(lag, alphabet_size, **af_kwargs, dtype) -> (ar_func, params)`` exactly as the
+reference (selected with ``getattr(ar_funcs, 'make_ar_func_' + name)``, models/train_bear_net.py:103).
+``ar_func`` maps contexts to transition-probability rows ``[..., alphabet_size + 1]`` (the "prior rows"
+of the DM kernels).  Contexts are accepted in the reference's one-hot form ``[..., lag, A+1]`` or, to
+avoid materialising 5.2 GB of one-hot at 1e7 contexts, as integer codes ``[..., lag]``
+(-1 = unknown letter = all-zero one-hot row).  Parameters are torch tensors with ``requires_grad``; the
+small dense algebra (K <= 330) stays in PyTorch-ROCm ops, the DM kernels consume the rows.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _is_codes(x):
+    return not x.dtype.is_floating_point
+
+
+def _l2_normalize(x, dims):
+    return x / torch.sqrt(torch.clamp((x * x).sum(dim=dims, keepdim=True), min=1e-12))
+
+
+def _normalize_layer(layer, reduce_dims=(-1,)):
+    """ar_funcs.py:5-20 (tf.nn.moments: biased variance)."""
+    mean = layer.mean(dim=reduce_dims, keepdim=True)
+    var = layer.var(dim=reduce_dims, unbiased=False, keepdim=True)
+    return (layer - mean) / torch.sqrt(var + 1e-5)
+
+
+def make_ar_func_linear(lag, alphabet_size, dtype=torch.float64, device=None, generator=None):
+    """ar_funcs.py:23-46: softmax(einsum('...jk,jkl->...l', kmers, mat)); mat = 0.05 * l2-normalised N(0,1)."""
+    mat = torch.randn(lag, alphabet_size + 1, alphabet_size + 1, dtype=dtype, device=device, generator=generator)
+    mat = (0.05 * _l2_normalize(mat, (1,))).requires_grad_(True)
+
+    def ar_func(kmers):
+        if _is_codes(kmers):
+            idx = kmers.long()
+            pos = torch.arange(lag, device=idx.device)
+            rows = mat[pos, idx.clamp(min=0)]                        # [..., lag, A+1]
+            rows = rows * (idx >= 0).unsqueeze(-1).to(rows.dtype)
+            z = rows.sum(-2)
+        else:
+            z = torch.einsum("...jk,jkl->...l", kmers, mat)
+        return torch.softmax(z, dim=-1)
+    return ar_func, [mat]
+
+
+def make_ar_func_cnn(lag, alphabet_size, filter_width=8, num_filters=30, kmer_layer1_width=16,
+                     dtype=torch.float64, device=None, generator=None):
+    """ar_funcs.py:49-99.  Returns params in the reference's order (ar_funcs.py:98-99):
+    filters, intercept0, weights1, intercept1, weights2, intercept2, scale0, scale1."""
+    filter_width, num_filters, kmer_layer1_width = int(filter_width), int(num_filters), int(kmer_layer1_width)
+    small_start = 0.05
+    A1 = alphabet_size + 1
+    P = lag - filter_width + 1
+    kw = dict(dtype=dtype, device=device)
+    filters = _l2_normalize(torch.randn(filter_width, A1, num_filters, generator=generator, **kw), (0, 1)).requires_grad_(True)
+    kmer_intercept0 = torch.ones(P, num_filters, **kw).requires_grad_(True)
+    kmer_scale0 = torch.ones(P, num_filters, **kw).requires_grad_(True)
+    kmer_weights1 = _l2_normalize(torch.randn(P, num_filters, kmer_layer1_width, generator=generator, **kw), (0,)).requires_grad_(True)
+    kmer_intercept1 = torch.ones(kmer_layer1_width, **kw).requires_grad_(True)
+    kmer_scale1 = torch.ones(kmer_layer1_width, **kw).requires_grad_(True)
+    kmer_weights2 = (small_start * _l2_normalize(torch.randn(kmer_layer1_width, A1, generator=generator, **kw), (0,))).requires_grad_(True)
+    kmer_intercept2 = torch.zeros(A1, **kw).requires_grad_(True)
+
+    def conv(data):
+        if _is_codes(data):
+            idx = data.long()
+            valid = (idx >= 0).to(filters.dtype)
+            idx = idx.clamp(min=0)
+            out = 0
+            for w in range(filter_width):   # conv1d VALID over a one-hot input = gather-sum
+                sl = idx[..., w:w + P]
+                out = out + filters[w][sl] * valid[..., w:w + P].unsqueeze(-1)
+            return out                                   # [..., P, nf]
+        x = data.reshape((-1,) + data.shape[-2:]).transpose(1, 2)          # [B, A1, lag]
+        y = F.conv1d(x, filters.permute(2, 1, 0))                          # [B, nf, P]
+        return y.transpose(1, 2).reshape(data.shape[:-2] + (P, num_filters))
+
+    def ar_func(data):
+        nn0 = kmer_scale0 * _normalize_layer(conv(data)) + kmer_intercept0
+        t1 = torch.tensordot(F.elu(nn0), kmer_weights1, dims=([-2, -1], [0, 1]))
+        nn1 = kmer_scale1 * _normalize_layer(t1) + kmer_intercept1
+        nn2 = torch.tensordot(F.elu(nn1), kmer_weights2, dims=([-1], [0])) + kmer_intercept2
+        return torch.softmax(nn2, dim=-1)
+    return ar_func, [filters, kmer_intercept0, kmer_weights1, kmer_intercept1, kmer_weights2, kmer_intercept2,
+                     kmer_scale0, kmer_scale1]
+
+
+def make_ar_func_stop(lag, alphabet_size, dtype=torch.float64, device=None, generator=None):
+    """ar_funcs.py:102-127: always predicts a stop; no parameters (for the reference AR model)."""
+    stop = torch.zeros(alphabet_size + 1, dtype=dtype, device=device)
+    stop[-1] = 1
+
+    def ar_func(y):
+        return stop
+    ar_func.is_stop = True  # lets bear_ref pick the fused reference-prior kernels
+    return ar_func, []

@@ -1,0 +1,116 @@
+"""BEAR / AR models with a parametric AR function: host mirror of ``bear_model/bear_net.py``.
+
+``train`` (bear_net.py:200-321), ``evaluation`` (:387-463), ``h_scan`` (:465-531),
+``change_scope_params`` (:103-143) with the reference's signatures.  Per batch shard and step the
+AR rows come from the plugin (``ar_funcs``, PyTorch-ROCm ops with autograd), and the DM / multinomial
+log-likelihood, its gradient w.r.t. ``h_signed`` and w.r.t. the AR rows come from one launch of
+``bear_dm_prior_f64``; the row gradient is fed back through ``ar_func`` by ``Tensor.backward``.
+"""
+import numpy as np
+import torch
+
+from . import _train, core, dist, kernels
+
+epsilon = core.epsilon
+
+
+def _create_params(lag, alphabet_size, make_ar_func, af_kwargs, dtype=torch.float64, device=None):
+    """bear_net.py:73-100."""
+    ar_func, ar_func_params = make_ar_func(lag, alphabet_size, **af_kwargs, dtype=dtype, device=device)
+    h_signed = torch.tensor(0.0, dtype=dtype, device=device, requires_grad=True)
+    return [h_signed] + ar_func_params, h_signed, ar_func
+
+
+def change_scope_params(lag, alphabet_size, make_ar_func, af_kwargs, params, dtype=torch.float64, device=None):
+    """bear_net.py:103-143."""
+    new, h_signed, ar_func = _create_params(lag, alphabet_size, make_ar_func, af_kwargs, dtype, device)
+    with torch.no_grad():
+        for p, q in zip(new, params):
+            p.copy_(torch.as_tensor(q, dtype=p.dtype))
+    return new, h_signed, ar_func
+
+
+def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwargs,
+          learning_rate, optimizer_name, train_ar, acc_steps=1,
+          params_restart=None, writer=None, loss_save=None, dtype=torch.float64):
+    """bear_net.train (bear_net.py:200-321); returns ``(params, h_signed, ar_func)``."""
+    if dtype != torch.float64:
+        raise NotImplementedError("the HIP kernels compute in float64")
+    device = _train.require_device()
+    alphabet_size = len(core.alphabets_tf[alphabet]) - 1
+    if params_restart is None:
+        params, h_signed, ar_func = _create_params(lag, alphabet_size, make_ar_func, af_kwargs, dtype, device)
+    else:
+        params, h_signed, ar_func = change_scope_params(lag, alphabet_size, make_ar_func, af_kwargs, params_restart, dtype, device)
+    ar_params = params[1:]
+    optimizer = _train.make_optimizer(optimizer_name, params, learning_rate)
+    res = _train.ResidentBatches(data, {"train": ds_loc}, device, want_codes=True)
+    n_batches = len(res.batches)
+    acc = [torch.zeros_like(p) for p in params]
+    loss, step = 0.0, 1
+    out = torch.zeros(2, dtype=torch.float64, device=device)
+    for _ in range(data.repeats):
+        for k in range(n_batches):
+            e = res.batches[k]
+            scale = -(num_kmers / e["global_rows"])                    # bear_net.py:190-191 with the global batch
+            for p in ar_params:
+                p.grad = None
+            if e["rows"]:
+                prior = ar_func(e["codes"]).expand(e["rows"], alphabet_size + 1).contiguous()
+                need_rows = prior.requires_grad
+                _, grad_rows = kernels.dm_prior(e["train"], prior.detach(), h_signed.item(), train_ar=train_ar,
+                                                want_grad=need_rows, out=out)
+                if need_rows:
+                    prior.backward(scale * grad_rows)                  # d loss / d AR parameters
+            else:
+                out.zero_()
+            flat, unpack = dist.pack([out] + [p.grad if p.grad is not None else torch.zeros_like(p) for p in ar_params])
+            dist.allreduce_sum_(flat)                                  # one packed all-reduce: loss, d/dh, AR grads
+            parts = unpack(flat)
+            loss += scale * parts[0][0].item()
+            if not train_ar:
+                acc[0] += scale * parts[0][1]                          # AR mode: h_signed gets no gradient (bear_net.py:194-196)
+            for a, g in zip(acc[1:], parts[1:]):
+                a += g.to(a.dtype)
+            if step % acc_steps == 0:
+                if writer is not None:
+                    writer.add_scalar("elbo", -loss / acc_steps, step)
+                if loss_save is not None:
+                    loss_save.append(-loss / acc_steps)
+                optimizer.apply_gradients([None if train_ar else acc[0]] + acc[1:])
+                for a in acc:
+                    a.zero_()
+                loss = 0.0
+            step += 1
+    return params, h_signed, ar_func
+
+
+def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype, generator):
+    device = _train.require_device()
+    use_train = ds_loc_train >= 0
+    cols = {"test": ds_loc_test}
+    if use_train:
+        cols["train"] = ds_loc_train
+    res = _train.ResidentBatches(data, cols, device, want_codes=True)
+    total = None
+    with torch.no_grad():
+        for e in res.batches:
+            prior = ar_func(e["codes"]).expand(e["rows"], 5).contiguous() if e["rows"] else torch.zeros((0, 5), dtype=dtype, device=device)
+            part = _train.evaluation_sums(e["test"], prior, h, van_reg, e.get("train"), generator=generator)
+            total = part if total is None else tuple(a + b for a, b in zip(total, part))
+    return total, device
+
+
+def evaluation(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype=torch.float64, generator=None):
+    """bear_net.evaluation (bear_net.py:387-463) -> the reference's 9-tuple."""
+    hv = float(torch.as_tensor(h).detach().cpu().item())
+    total, device = _eval(data, ds_loc_train, ds_loc_test, alphabet, hv, ar_func, van_reg, dtype, generator)
+    return _train.reduce_evaluation(total, device, True)
+
+
+def h_scan(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, dtype=torch.float64, generator=None):
+    """bear_net.h_scan (bear_net.py:465-531): BEAR log-likelihood, perplexity and accuracy for a vector of h."""
+    hs = torch.as_tensor(h).detach().cpu().numpy().reshape(-1)
+    total, device = _eval(data, ds_loc_train, ds_loc_test, alphabet, hs, ar_func, np.ones(1), dtype, generator)
+    r = _train.reduce_evaluation(total, device, False)
+    return r[0], r[3], r[6]

@@ -1,0 +1,155 @@
+"""Count-table ingestion: host mirror of ``bear_model/dataloader.py``.
+
+``dataloader(file, alphabet, batch_size, num_ds, cache, header, n_par, dtype)`` keeps the reference
+signature (dataloader.py:6-7) and, iterated, yields the reference's batches
+``(kmers [B] bytes, counts [B, num_ds, A+1])`` in file order with a short last batch
+(dataloader.py:31-37).  Underneath, the file is parsed ONCE by the C++ reader in libbear_hip.so
+(``bear_parse_counts_tsv``: mmap + in-place integer parse, replacing CsvDataset + JSON decoding,
+dataloader.py:35-46) into k-mer bytes and planar ``uint32 [num_ds, N, 5]`` slabs, which
+``bear_net.train`` / ``bear_ref.train`` upload once and keep resident.
+"""
+import ctypes
+import json
+
+import numpy as np
+import torch
+
+from . import _lib, core, kernels
+
+
+class CountDataset:
+    """Parsed count table: ``kmers`` uint8 [N, lag] (ASCII), ``counts`` uint32 [num_ds, N, A+1]."""
+
+    def __init__(self, kmers, counts, alphabet, batch_size, dtype=torch.float64, repeats=1):
+        self.kmers = kmers
+        self.counts = counts
+        self.alphabet = alphabet
+        self.batch_size = int(batch_size)
+        self.dtype = dtype
+        self.repeats = int(repeats)
+        self._device_cache = {}
+
+    # ---- reference-shaped view -----------------------------------------------------------------
+    @property
+    def num_rows(self):
+        return self.counts.shape[1]
+
+    @property
+    def num_ds(self):
+        return self.counts.shape[0]
+
+    @property
+    def lag(self):
+        return self.kmers.shape[1]
+
+    def batch_bounds(self):
+        """Row ranges of the batches of one epoch (last one short: no drop_remainder, dataloader.py:37)."""
+        B, N = self.batch_size, self.num_rows
+        return [(a, min(a + B, N)) for a in range(0, N, B)]
+
+    def __len__(self):
+        return len(self.batch_bounds()) * self.repeats
+
+    def __iter__(self):
+        np_dtype = np.float64 if self.dtype == torch.float64 else np.float32
+        for _ in range(self.repeats):
+            for a, b in self.batch_bounds():
+                km = np.array([bytes(r) for r in self.kmers[a:b]])
+                yield km, torch.from_numpy(self.counts[:, a:b].transpose(1, 0, 2).astype(np_dtype))
+
+    def repeat(self, epochs):
+        """tf.data ``.repeat(epochs)`` (models/train_bear_net.py:88)."""
+        return CountDataset(self.kmers, self.counts, self.alphabet, self.batch_size, self.dtype, self.repeats * int(epochs))
+
+    # ---- packed device view --------------------------------------------------------------------
+    def codes(self):
+        return core.encode_kmers(self.kmers, self.alphabet)
+
+    def device_column(self, ds_loc, device, rows=None):
+        """uint32 [n, 5] slab of one dataset column on `device` (int32 storage), cached."""
+        key = (int(ds_loc), str(device), rows)
+        t = self._device_cache.get(key)
+        if t is None:
+            a, b = rows if rows is not None else (0, self.num_rows)
+            t = torch.from_numpy(np.ascontiguousarray(self.counts[ds_loc, a:b]).view(np.int32)).to(device)
+            self._device_cache[key] = t
+        return t
+
+
+def concatenate(datasets):
+    """Several count files of one table (models/train_bear_net.py:79-87 interleaves them; rows are
+    independent and pre-shuffled, so concatenation is an equivalent batch stream)."""
+    d0 = datasets[0]
+    return CountDataset(np.concatenate([d.kmers for d in datasets]), np.concatenate([d.counts for d in datasets], axis=1),
+                        d0.alphabet, d0.batch_size, d0.dtype)
+
+
+def _sniff_lag(file, header, delim):
+    with open(file, "rb") as fh:
+        if header:
+            fh.readline()
+        for line in fh:
+            if line.strip():
+                return line.split(delim)[0].__len__()
+    return 0
+
+
+def dataloader(file, alphabet, batch_size, num_ds, cache=True, header=False, n_par=1, dtype=torch.float64):
+    """dataloader.py:6-50.  ``cache`` / ``n_par`` are accepted for signature compatibility: the table
+    is always parsed once and kept."""
+    if header:
+        raise NotImplementedError("dense count tables written by summarize.py have no header")
+    L = _lib.lib()
+    n = ctypes.c_uint64()
+    _lib.check(L.bear_count_rows(str(file).encode(), ctypes.byref(n)), "bear_count_rows")
+    lag = _sniff_lag(file, header, b"\t")
+    A1 = len(core.alphabets_tf[alphabet])
+    if A1 != 5:
+        raise NotImplementedError("the HIP kernels are built for 4-letter alphabets (+ stop): dna / rna")
+    kmers = np.zeros((n.value, lag), dtype=np.uint8)
+    counts = np.zeros((num_ds, n.value, A1), dtype=np.uint32)
+    got = ctypes.c_uint64()
+    _lib.check(L.bear_parse_counts_tsv(str(file).encode(), int(num_ds), int(lag), n.value, kmers.ctypes.data,
+                                       counts.ctypes.data, ctypes.byref(got)), "bear_parse_counts_tsv")
+    assert got.value == n.value
+    return CountDataset(kmers, counts, alphabet, batch_size, dtype)
+
+
+def sparse_dataloader(file, alphabet, batch_size, num_ds, cache=False, header=True, n_par=1, dtype=torch.float64):
+    """dataloader.py:52-109: ``kmer; [[ds, col], ...]; [vals]`` rows with a header line."""
+    A1 = len(core.alphabets_tf[alphabet])
+    kmers, rows = [], []
+    with open(file) as fh:
+        if header:
+            fh.readline()
+        for line in fh:
+            if not line.strip():
+                continue
+            k, pos, vals = [s.strip() for s in line.rstrip("\n").split(";")]
+            dense = np.zeros((num_ds, A1), dtype=np.uint32)
+            for (d, c), v in zip(json.loads(pos), json.loads(vals)):
+                dense[d, c] = v
+            kmers.append(k.encode())
+            rows.append(dense)
+    lag = len(kmers[0]) if kmers else 0
+    km = np.frombuffer(b"".join(kmers), dtype=np.uint8).reshape(len(kmers), lag).copy()
+    counts = np.stack(rows, axis=1) if rows else np.zeros((num_ds, 0, A1), dtype=np.uint32)
+    return CountDataset(km, np.ascontiguousarray(counts), alphabet, batch_size, dtype)
+
+
+def bmm_likelihood(data, alpha, dtype=torch.float64, device=None):
+    """dataloader.py:120-147: BMM marginal ``sum_i lbeta(c_i + alpha) - lbeta(alpha)`` for every dataset
+    column and every alpha -> [num_ds, len(alpha)].  Each (column, alpha) is one launch of the DM kernel
+    with the constant prior alpha (h = 1, eps = 0)."""
+    if not isinstance(data, CountDataset):
+        raise TypeError("bmm_likelihood expects the CountDataset returned by dataloader()")
+    device = torch.device(device or "cuda")
+    alpha = np.atleast_1d(np.asarray(alpha, dtype=np.float64))
+    out = torch.zeros((data.num_ds, len(alpha)), dtype=torch.float64)
+    n = data.num_rows
+    for j, a in enumerate(alpha):
+        prior = torch.full((n, 5), float(a), dtype=torch.float64, device=device)
+        for d in range(data.num_ds):
+            res, _ = kernels.dm_prior(data.device_column(d, device), prior, 0.0, eps=0.0)
+            out[d, j] = res[0].item()
+    return out.to(dtype)

@@ -1,0 +1,151 @@
+"""Config-driven training / evaluation driver shared by train_bear_net.py and train_bear_ref.py
+(host mirror of bear_model/models/train_bear_{net,ref}.py:31-204; same .cfg keys and semantics)."""
+import datetime
+import json
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from bear_amd import ar_funcs, bear_net, bear_ref, core, dataloader, dist
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _count_lines(path):
+    n = 0
+    with open(path, "rb") as fh:
+        for block in iter(lambda: fh.read(1 << 22), b""):
+            n += block.count(b"\n")
+    return n
+
+
+def _writer(out_folder):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(out_folder)
+    except Exception:
+        return None
+
+
+def main(config, kind):
+    """kind: 'net' or 'ref'.  Returns what the reference's main() returns (1, or (1, ll_van, perp_van)
+    when train_test is on, models/train_bear_net.py:197-200)."""
+    rank, _ = dist.world()
+    mod = bear_net if kind == "net" else bear_ref
+    time_stamp = datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
+    of = config["general"]["out_folder"]
+    if of == "TEST":
+        out_folder = os.path.join(PKG, "models", "out_data", "logs", time_stamp)
+    elif of[-1] == "*":
+        out_folder = of[:-1]
+    else:
+        out_folder = os.path.join(of, "logs", time_stamp)
+    os.makedirs(out_folder, exist_ok=True)
+    torch.manual_seed(int(config["general"]["seed"]))
+    dtype = getattr(torch, config["general"]["precision"])
+    writer = _writer(out_folder) if rank == 0 else None
+
+    if config["data"]["files_path"] == "TEST":
+        files = [os.path.join(PKG, "data", "ysd1_lag_5_file_0_preshuf.tsv")]
+    else:
+        fp = config["data"]["files_path"]
+        files = sorted(os.path.join(fp, f) for f in os.listdir(fp) if f.startswith(config["data"]["start_token"]))
+    num_kmers = sum(_count_lines(f) for f in files)
+    kmer_batch_size = float(config["train"]["batch_size"])
+    kmer_batch_size = int(num_kmers * kmer_batch_size) if kmer_batch_size <= 1 else int(kmer_batch_size)
+    epochs = config["train"]["epochs"]
+    epochs = int(epochs[:-1]) // (1 + num_kmers // kmer_batch_size) + 1 if epochs[-1] == "s" else int(epochs)
+    num_ds = int(config["data"]["num_ds"])
+    load = dataloader.sparse_dataloader if config["data"]["sparse"] == "True" else dataloader.dataloader
+    parts = [load(f, config["data"]["alphabet"], kmer_batch_size, num_ds, cache=config["train"]["cache"] == "True", dtype=dtype)
+             for f in files]
+    data = parts[0] if len(parts) == 1 else dataloader.concatenate(parts)
+    data_train = data.repeat(epochs)
+
+    result_file = os.path.join(out_folder, "results.pickle")
+    config["results"]["out_folder"] = out_folder
+    config["results"]["file"] = result_file
+
+    def save_config():
+        if rank == 0:
+            with open(os.path.join(out_folder, "config.cfg"), "w") as cw:
+                config.write(cw)
+    save_config()
+
+    ds_loc = int(config["data"]["train_column"])
+    ds_loc_ref = int(config["data"]["reference_column"])
+    alphabet = config["data"]["alphabet"]
+    alphabet_size = len(core.alphabets_tf[alphabet]) - 1
+    lag = int(config["hyperp"]["lag"])
+    make_ar_func = getattr(ar_funcs, "make_ar_func_" + config["model"]["ar_func_name"])
+    af_kwargs = json.loads(config["model"]["af_kwargs"])
+    learning_rate = float(config["train"]["learning_rate"])
+    optimizer_name = config["train"]["optimizer_name"]
+    train_ar = config["train"]["train_ar"] == "True"
+    acc_steps = int(config["train"]["accumulation_steps"])
+
+    params_restart = None
+    if config["train"]["restart"] == "True":
+        with open(os.path.join(config["train"]["restart_path"], "results.pickle"), "rb") as fr:
+            params_restart = pickle.load(fr)["params"]
+
+    extra = (ds_loc_ref,) if kind == "ref" else ()
+    if config["train"]["train"] == "True":
+        loss_save = []
+        params, h_signed, ar_func = mod.train(
+            data_train, num_kmers, epochs, ds_loc, *extra, alphabet, lag, make_ar_func, af_kwargs,
+            learning_rate, optimizer_name, train_ar=train_ar, acc_steps=acc_steps,
+            params_restart=params_restart, writer=writer, loss_save=loss_save, dtype=dtype)
+        if rank == 0:
+            try:
+                import matplotlib
+                matplotlib.use("Agg")
+                from matplotlib import pyplot as plt
+                plt.figure(figsize=[10, 10])
+                plt.xlabel("steps", fontsize=30)
+                plt.ylabel("loss", fontsize=30)
+                plt.plot(loss_save)
+                plt.tight_layout()
+                plt.savefig(os.path.join(out_folder, "loss.png"), dpi=100)
+                plt.close()
+            except Exception:
+                pass
+    else:
+        assert config["train"]["restart"] == "True"
+        params, h_signed, ar_func = mod.change_scope_params(lag, alphabet_size, make_ar_func, af_kwargs, params_restart, dtype=dtype,
+                                                            device=torch.device("cuda", torch.cuda.current_device()))
+
+    config["results"]["h"] = str(torch.exp(h_signed).item())
+    if kind == "ref":
+        tau = torch.exp(params[1]).item()
+        config["results"]["error_rate"] = str(1 - np.exp(-tau))
+        nw = torch.exp(params[2]).item()
+        config["results"]["stop_rate"] = str(1 / (nw / (1 + nw)))
+    save_config()
+    if rank == 0:
+        with open(result_file, "wb") as rw:
+            pickle.dump({"params": [p.detach().cpu().numpy() for p in params]}, rw)
+
+    h = torch.exp(h_signed).detach()
+    ret = 1
+    if config["test"]["test"] == "True":
+        ds_loc_test = int(config["data"]["test_column"])
+        van_reg = np.array(json.loads(config["test"]["van_reg"]))
+        r = mod.evaluation(data, ds_loc, ds_loc_test, *extra, alphabet, h, ar_func, van_reg)
+        for name, v in zip(["heldout_loglikelihood_BEAR", "heldout_loglikelihood_AR", "heldout_loglikelihood_BMM",
+                            "heldout_perplex_BEAR", "heldout_perplex_AR", "heldout_perplex_BMM",
+                            "heldout_accuracy_BEAR", "heldout_accuracy_AR", "heldout_accuracy_BMM"], r):
+            config["results"][name] = json.dumps(np.asarray(v).tolist()) if np.ndim(v) else str(float(v))
+        save_config()
+    if config["test"]["train_test"] == "True":
+        van_reg = np.array(json.loads(config["test"]["van_reg"]))
+        r = mod.evaluation(data, -1, ds_loc, *extra, alphabet, h, ar_func, van_reg)
+        for name, v in zip(["loglikelihood_BEAR", "loglikelihood_AR", "loglikelihood_BMM",
+                            "perplex_BEAR", "perplex_AR", "perplex_BMM",
+                            "accuracy_BEAR", "accuracy_AR", "accuracy_BMM"], r):
+            config["results"][name] = json.dumps(np.asarray(v).tolist()) if np.ndim(v) else str(float(v))
+        save_config()
+        ret = (1, np.asarray(r[2]), np.asarray(r[5]))
+    return ret

@@ -1,0 +1,60 @@
+"""World-size-2 gloo tests of the N > 1 path on CPU: row sharding + the single packed all-reduce of a step.
+Per-shard partial sums come from the oracle here (the HIP kernels need a GPU); the reduce, the packing and the
+loss scaling are the product code of bear_amd.dist."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import ROOT
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["BEAR_ROOT"]); sys.path.insert(0, os.path.join(os.environ["BEAR_ROOT"], "oracle")); sys.path.insert(0, os.path.join(os.environ["BEAR_ROOT"], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import bear_oracle as o
+from bear_amd import dist as bdist
+from util import sparse_table, prior_rows
+dist.init_process_group("gloo")
+rank, world = bdist.world()
+assert world == 2
+train, _, ref = sparse_table(10007, 3)
+f = prior_rows(10007, 4)
+args = (0.2, np.log(1 / 30), -np.log(100))
+lo, hi = bdist.shard_rows(len(train))
+# bear_ref step: packed [sum LL, d/dh, d/dtau, d/dnu]
+r = o.bear_ref_step(train[lo:hi], ref[lo:hi], *args)
+packed = torch.tensor([r["ll"], r["d_h_signed"], r["d_tau_signed"], r["d_nu_signed"]], dtype=torch.float64)
+bdist.allreduce_sum_(packed)
+full = o.bear_ref_step(train, ref, *args)
+want = np.array([full["ll"], full["d_h_signed"], full["d_tau_signed"], full["d_nu_signed"]])
+assert np.allclose(packed.numpy(), want, rtol=1e-12), (packed, want)
+# bear_net step: loss + d/dh + a list of AR-parameter gradients in one packed all-reduce
+rn = o.bear_net_step(train[lo:hi], f[lo:hi], -0.3)
+g_mat = torch.tensor(rn["d_prior"].sum(0)).reshape(1, 5)            # stand-in for a parameter-shaped gradient
+flat, unpack = bdist.pack([torch.tensor([rn["ll"], rn["d_h_signed"]]), g_mat, torch.zeros(3, 2)])
+bdist.allreduce_sum_(flat)
+a, b, c = unpack(flat)
+fulln = o.bear_net_step(train, f, -0.3)
+assert np.allclose(a.numpy(), [fulln["ll"], fulln["d_h_signed"]], rtol=1e-12)
+assert np.allclose(b.numpy().reshape(-1), fulln["d_prior"].sum(0), rtol=1e-10) and c.shape == (3, 2)
+# loss scale uses the GLOBAL batch (SURVEY quirk 1): -(num_kmers / B_global) * sum over all ranks
+num_kmers, B = 50000, len(train)
+assert np.isclose(-(num_kmers / B) * packed[0].item(), -(num_kmers / B) * full["ll"], rtol=1e-12)
+if rank == 0:
+    print("DIST_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_step(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, BEAR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "DIST_OK" in p.stdout

@@ -1,0 +1,115 @@
+"""CPU tests of the host logic: plugin surface, data plane, optimizer, sharding helpers, config semantics."""
+import configparser
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bear_oracle as o
+from bear_amd import ar_funcs, core, dataloader, dist, _train
+from conftest import GOLDEN, ROOT, YSD1
+
+
+def test_ar_funcs_match_oracle():
+    g = torch.Generator().manual_seed(0)
+    kmers = ["ACGTA", "[[ACG", "TTTTN", "GATTA", "[[[[["]
+    codes = torch.as_tensor(core.encode_kmers(kmers))
+    oh = core.tf_one_hot(kmers, "dna")
+    assert np.array_equal(oh.numpy(), o.one_hot(kmers))
+    f, p = ar_funcs.make_ar_func_linear(5, 4, generator=g)
+    assert p[0].shape == (5, 5, 5) and p[0].requires_grad
+    assert np.allclose((p[0] ** 2).sum(1).detach().numpy(), 0.05 ** 2)      # 0.05 * l2_normalize(axis=1), ar_funcs.py:41-42
+    want = o.ar_func_linear(o.one_hot(kmers), p[0].detach().numpy())
+    assert np.allclose(f(oh).detach().numpy(), want, atol=1e-15) and np.allclose(f(codes).detach().numpy(), want, atol=1e-15)
+    f, p = ar_funcs.make_ar_func_cnn(5, 4, filter_width=3, num_filters=6, generator=g)
+    assert [tuple(x.shape) for x in p] == [(3, 5, 6), (3, 6), (3, 6, 16), (16,), (16, 5), (5,), (3, 6), (16,)]
+    want = o.ar_func_cnn(o.one_hot(kmers), [x.detach().numpy() for x in p])
+    assert np.allclose(f(oh).detach().numpy(), want, atol=1e-14) and np.allclose(f(codes).detach().numpy(), want, atol=1e-14)
+    f, p = ar_funcs.make_ar_func_stop(5, 4)
+    assert p == [] and f(oh).tolist() == [0, 0, 0, 0, 1]
+    # gradients flow through the code path
+    f, p = ar_funcs.make_ar_func_linear(5, 4, generator=g)
+    f(codes).log().sum().backward()
+    assert p[0].grad is not None and torch.isfinite(p[0].grad).all()
+
+
+def test_plugin_lookup_by_name():
+    # models/train_bear_net.py:103
+    for name in ("linear", "cnn", "stop"):
+        assert callable(getattr(ar_funcs, "make_ar_func_" + name))
+
+
+def test_dataloader_reference_golden_batches():
+    # bear_model/tests/test_dataloader.py:20-32
+    data = dataloader.dataloader(YSD1, "dna", 3, 3)
+    kmers, counts = next(iter(data))
+    assert np.all(kmers == np.array([b"TAATC", b"CGGTC", b"ACGCT"]))
+    counts_real = [[[14837, 15127, 22260, 16279, 446], [5029, 5095, 7408, 5487, 134], [16, 16, 23, 17, 0]],
+                   [[61890, 729, 39733, 35956, 1017], [20524, 239, 13199, 12046, 309], [69, 0, 45, 39, 0]],
+                   [[13965, 23135, 73870, 37045, 1035], [4705, 7591, 24532, 12305, 385], [14, 25, 81, 39, 0]]]
+    assert np.all(counts.numpy() == np.array(counts_real))
+    assert counts.dtype == torch.float64
+    assert len(list(data)) == 1365 / 3
+    big = dataloader.dataloader(YSD1, "dna", 2000, 3)
+    k2, c2 = next(iter(big))
+    assert len(c2) == 1365 < 2000 and len(big) == 1            # one short batch (no drop_remainder)
+    assert len(big.repeat(4)) == 4
+    assert big.codes().shape == (1365, 5) and (big.codes() == 4).any()   # '[' padded prefixes
+
+
+def test_sparse_dataloader():
+    s = dataloader.sparse_dataloader(os.path.join(GOLDEN, "ex_seqs_kmap_for_var_pred.csv"), "dna", 4, 1)
+    assert s.num_rows == 9 and s.lag == 3 and s.num_ds == 1
+    k, c = next(iter(s))
+    assert k[0] == b"CTT" and c[0, 0].tolist() == [0, 0, 0, 0, 1] and c[2, 0].tolist() == [0, 0, 0, 1, 0]
+
+
+def test_keras_adam_update_rule():
+    p = [torch.tensor(1.0, dtype=torch.float64), torch.tensor([0.5, -2.0], dtype=torch.float64)]
+    opt = _train.KerasAdam(p, 0.01)
+    g = [torch.tensor(3.0, dtype=torch.float64), torch.tensor([1e-3, -4.0], dtype=torch.float64)]
+    opt.apply_gradients(g)
+    # first step: m = 0.1 g, v = 0.001 g^2, lr_t = lr sqrt(1-b2)/(1-b1): theta -= lr_t m / (sqrt(v) + 1e-7)
+    lr_t = 0.01 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    want0 = 1.0 - lr_t * 0.3 / (np.sqrt(0.009) + 1e-7)
+    assert abs(p[0].item() - want0) < 1e-15
+    opt.apply_gradients([None, g[1]])
+    assert abs(p[0].item() - want0) < 1e-15                    # None gradient leaves the variable alone (AR mode h_signed)
+
+
+def test_shard_rows_partition():
+    for n in (0, 1, 7, 1365, 10 ** 9 + 3):
+        for w in (1, 2, 3, 8):
+            r = [dist.shard_rows(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r[:-1], r[1:]))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+    flat, unpack = dist.pack([torch.ones(2), torch.arange(6.0).reshape(2, 3)])
+    a, b = unpack(flat * 2)
+    assert a.tolist() == [2, 2] and b.shape == (2, 3) and b[1, 2] == 10
+
+
+def test_config_files_have_reference_keys():
+    d = os.path.join(ROOT, "bear_amd", "models", "config_files")
+    want = {"general": {"out_folder", "seed", "precision"},
+            "data": {"files_path", "start_token", "sparse", "num_ds", "alphabet", "train_column", "test_column", "reference_column"},
+            "hyperp": {"lag"},
+            "train": {"train", "epochs", "batch_size", "optimizer_name", "learning_rate", "train_ar", "accumulation_steps", "cache",
+                      "restart", "restart_path"},
+            "test": {"test", "train_test", "van_reg"}, "model": {"ar_func_name", "af_kwargs"}, "results": set()}
+    names = sorted(os.listdir(d))
+    assert names == ["bear_cnn_ar.cfg", "bear_cnn_bear.cfg", "bear_lin_ar.cfg", "bear_lin_bear.cfg", "bear_stop_ar.cfg",
+                     "bear_stop_bear.cfg", "bear_test.cfg"]
+    for n in names:
+        c = configparser.ConfigParser()
+        c.read(os.path.join(d, n))
+        assert {s: set(c[s].keys()) for s in c.sections()} == want, n
+
+
+def test_training_needs_a_device():
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    with pytest.raises(RuntimeError):
+        _train.require_device()

@@ -1,0 +1,196 @@
+"""GPU tests of the host drivers: a few optimizer steps of bear_ref.train / bear_net.train against an
+oracle-driven replica of the same loop, held-out evaluation against the oracle, the reference's own
+test_run / test_core / test_dataloader checks re-stated on the HIP path."""
+import configparser
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy.special import loggamma
+
+import bear_oracle as o
+from bear_amd import ar_funcs, bear_net, bear_ref, core, dataloader
+from conftest import ROOT, YSD1
+
+pytestmark = pytest.mark.gpu
+
+
+def keras_adam_np(p, g, m, v, t, lr=0.01, b1=0.9, b2=0.999, eps=1e-7):
+    m[...] = b1 * m + (1 - b1) * g
+    v[...] = b2 * v + (1 - b2) * g * g
+    lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    p[...] = p - lr_t * m / (np.sqrt(v) + eps)
+
+
+@pytest.mark.parametrize("train_ar", [False, True])
+def test_bear_ref_train_matches_oracle_loop(train_ar, ysd1):
+    _, counts = ysd1
+    data = dataloader.dataloader(YSD1, "dna", 500, 3)          # 3 batches per epoch, last one short (365 rows)
+    steps_epochs = 2
+    loss_save = []
+    params, h_signed, ar_func = bear_ref.train(data.repeat(steps_epochs), 1365, steps_epochs, 0, 2, "dna", 5,
+                                               ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", train_ar, loss_save=loss_save)
+    p = np.array([0.0, np.log(1 / 30), -np.log(100)])
+    m, v = np.zeros(3), np.zeros(3)
+    want_loss, t = [], 0
+    for _ in range(steps_epochs):
+        for a in range(0, 1365, 500):
+            b = min(a + 500, 1365)
+            r = o.bear_ref_step(counts[a:b, 0], counts[a:b, 2], *p, train_ar=train_ar)
+            scale = -(1365 / (b - a))
+            want_loss.append(-scale * r["ll"])
+            g = scale * np.array([r["d_h_signed"], r["d_tau_signed"], r["d_nu_signed"]])
+            t += 1
+            if train_ar:                                       # h_signed gets no gradient in AR mode
+                keras_adam_np(p[1:], g[1:], m[1:], v[1:], t)
+            else:
+                keras_adam_np(p, g, m, v, t)
+    got = np.array([x.item() for x in params])
+    assert np.allclose(loss_save, want_loss, rtol=1e-10)
+    assert np.allclose(got, p, rtol=1e-8, atol=1e-10)
+    assert h_signed is params[0]
+    # the returned ar_func reproduces bear_ref.py:63-68
+    oh = core.tf_one_hot(["ACGTA"], "dna", device="cuda")
+    ref_in = torch.tensor([[3 + 1e-7, 1e-7, 1 + 1e-7, 1e-7, 0.0]], dtype=torch.float64, device="cuda")
+    want = o.ref_ar_func(o.ar_func_stop(None), ref_in.cpu().numpy(), got[1], got[2])
+    assert np.allclose(ar_func(oh, ref_in).detach().cpu().numpy(), want, rtol=1e-12)
+
+
+@pytest.mark.parametrize("name,kw,train_ar", [("linear", {}, False), ("linear", {}, True), ("cnn", {"filter_width": 3, "num_filters": 5}, False)])
+def test_bear_net_train_matches_oracle_loop(name, kw, train_ar, ysd1):
+    _, counts = ysd1
+    data = dataloader.dataloader(YSD1, "dna", 700, 3)          # 2 batches (700 + 665)
+    make = getattr(ar_funcs, "make_ar_func_" + name)
+    torch.manual_seed(3)
+    _, init = make(5, 4, **kw)
+    init_np = [x.detach().numpy().copy() for x in init]
+    restart = [np.array(0.1)] + init_np
+    loss_save = []
+    params, h_signed, ar_func = bear_net.train(data.repeat(2), 1365, 2, 0, "dna", 5, make, kw, 0.01, "Adam", train_ar,
+                                               params_restart=restart, loss_save=loss_save)
+    # replica on CPU: torch autograd through the same plugin, likelihood and row gradients from the oracle
+    f_cpu, p_cpu = make(5, 4, **kw)
+    with torch.no_grad():
+        for a, b in zip(p_cpu, init_np):
+            a.copy_(torch.as_tensor(b))
+    h = np.array(0.1)
+    flat = [h] + [x.detach().numpy() for x in p_cpu]
+    ms = [np.zeros_like(x) for x in flat]
+    vs = [np.zeros_like(x) for x in flat]
+    codes = torch.as_tensor(data.codes())
+    want_loss, t = [], 0
+    for _ in range(2):
+        for a in range(0, 1365, 700):
+            b = min(a + 700, 1365)
+            for q in p_cpu:
+                q.grad = None
+            prior = f_cpu(codes[a:b])
+            r = o.bear_net_step(counts[a:b, 0], prior.detach().numpy(), float(h), train_ar=train_ar)
+            scale = -(1365 / (b - a))
+            prior.backward(torch.as_tensor(scale * r["d_prior"]))
+            want_loss.append(-scale * r["ll"])
+            t += 1
+            if not train_ar:
+                gh = np.array(scale * r["d_h_signed"])
+                keras_adam_np(h, gh, ms[0], vs[0], t)
+            for i, q in enumerate(p_cpu):
+                arr = q.detach().numpy()
+                keras_adam_np(arr, q.grad.numpy(), ms[i + 1], vs[i + 1], t)
+    assert np.allclose(loss_save, want_loss, rtol=1e-9)
+    assert np.isclose(params[0].item(), float(h), rtol=1e-7, atol=1e-9)
+    for got, want in zip(params[1:], p_cpu):
+        assert np.allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-6, atol=1e-8)
+
+
+def test_evaluation_matches_oracle(ysd1):
+    kmers, counts = ysd1
+    data = dataloader.dataloader(YSD1, "dna", 400, 3)
+    torch.manual_seed(1)
+    f, p = ar_funcs.make_ar_func_linear(5, 4, device="cuda")
+    van = np.array([0.1, 1.0, 10.0])
+    prior = o.ar_func_linear(o.one_hot(kmers), p[0].detach().cpu().numpy())
+    for use_train in (True, False):
+        got = bear_net.evaluation(data, 0 if use_train else -1, 1, "dna", torch.tensor(0.37), f, van)
+        w = o.evaluation_step(counts[:, 1], prior, 0.37, van, counts[:, 0] if use_train else None)
+        total = w[6]
+        assert np.isclose(got[0], w[0], rtol=1e-11) and np.isclose(got[1], w[1], rtol=1e-11)
+        assert np.allclose(got[2], w[2], rtol=1e-11)
+        assert np.isclose(got[3], np.exp(-w[0] / total), rtol=1e-10) and np.allclose(got[5], np.exp(-w[2] / total), rtol=1e-10)
+        # accuracies: ties are broken randomly in the reference (core.py:69-71); allow the tied mass
+        assert abs(got[6] - w[3] / total) < 2e-3 and abs(got[7] - w[4] / total) < 2e-3
+        if use_train:
+            assert np.all(np.abs(got[8] - w[5] / total) < 2e-3)
+        else:  # constant concentration: all five columns tie, the reference picks one at random per context
+            assert np.all(np.abs(got[8] - 0.2) < 0.03)
+    hs = np.array([0.05, 0.37, 2.0])
+    ll, perp, acc = bear_net.h_scan(data, 0, 1, "dna", torch.tensor(hs), f)
+    for i, hv in enumerate(hs):
+        w = o.evaluation_step(counts[:, 1], prior, hv, np.ones(1), counts[:, 0])
+        assert np.isclose(ll[i], w[0], rtol=1e-11)
+    # bear_ref.evaluation (stop net function)
+    _, _, arf = bear_ref._create_params(5, 4, ar_funcs.make_ar_func_stop, {}, device=torch.device("cuda"))
+    got = bear_ref.evaluation(data, 0, 1, 2, "dna", torch.tensor(0.5), arf, van)
+    pri = o.ref_ar_func(o.ar_func_stop(None), o.ref_input(counts[:, 2]), np.log(1 / 30), -np.log(100))
+    w = o.evaluation_step(counts[:, 1], pri, 0.5, van, counts[:, 0])
+    assert np.isclose(got[0], w[0], rtol=1e-11) and np.isclose(got[1], w[1], rtol=1e-11) and np.allclose(got[2], w[2], rtol=1e-11)
+
+
+@pytest.mark.parametrize("kind", ["net", "ref"])
+def test_run_config_driver(kind, ysd1):
+    """bear_model/tests/test_run.py:12-51 re-stated: the bear_test.cfg workflow returns 1 and the train-set BMM
+    log-likelihoods / perplexities equal the closed-form BMM marginals with alpha + epsilon."""
+    from bear_amd.models import train_bear_net, train_bear_ref
+    config = configparser.ConfigParser()
+    config.read(os.path.join(ROOT, "bear_amd", "models", "config_files", "bear_test.cfg"))
+    mod = train_bear_net if kind == "net" else train_bear_ref
+    if kind == "ref":
+        config["model"]["ar_func_name"] = "stop"
+    exit_code, ll_van, perp_van = mod.main(config)
+    assert exit_code == 1
+    _, counts = ysd1
+    data = dataloader.dataloader(YSD1, "dna", 2000, 3)
+    alpha = np.array([0.1, 1.0, 10.0]) + 1e-7
+    calc = dataloader.bmm_likelihood(data, alpha)
+    train_liks = calc[0].numpy()
+    assert np.allclose(train_liks, ll_van)
+    assert np.allclose(np.exp(-train_liks / counts[:, 0].sum()), perp_van)
+    assert np.allclose(train_liks, [-152712571.34208858, -152709051.39618373, -152745386.28243095], rtol=1e-12)
+    out = config["results"]["out_folder"]
+    assert os.path.exists(os.path.join(out, "results.pickle")) and os.path.exists(os.path.join(out, "config.cfg"))
+    assert "heldout_perplex_BEAR" in config["results"] and "h" in config["results"]
+
+
+def test_bmm_likelihood_reference_test(ysd1):
+    # bear_model/tests/test_dataloader.py:34-49
+    _, counts = ysd1
+    data = dataloader.dataloader(YSD1, "dna", 2000, 3)
+    alpha = np.array([0.1, 1.0, 10.0])
+    true_liks = np.sum((np.sum(loggamma(counts[:, :, None, :] + alpha[:, None]), axis=-1)
+                        - loggamma(np.sum(counts[:, :, None, :] + alpha[:, None], axis=-1)))
+                       - (np.sum(loggamma(0 * counts[:, :, None, :] + alpha[:, None]), axis=-1)
+                          - loggamma(np.sum(0 * counts[:, :, None, :] + alpha[:, None], axis=-1))), axis=0)
+    assert np.allclose(true_liks, dataloader.bmm_likelihood(data, alpha).numpy(), rtol=1e-12)
+
+
+def test_core_distributions_reference_tests():
+    # bear_model/tests/test_core.py:7-26 and 42-60 on the HIP path
+    rng = np.random.default_rng(5)
+    shape = np.array([3, 5])
+    trans = rng.poisson(size=np.r_[shape, 5]).astype(float)
+    total = trans.sum(-1)
+    conc = rng.exponential(size=np.r_[shape[1], 5])
+    dist = core.tfpDirichletMultinomialPerm(torch.tensor(total, device="cuda"), torch.tensor(conc, device="cuda"))
+    assert np.all(dist._sample_n(7).cpu().numpy() == np.zeros(np.r_[7, shape, 5]))
+    assert np.all(dist.ml_output().cpu().numpy() == np.argmax(conc, axis=-1))
+    want = (np.sum(loggamma(conc + trans) - loggamma(conc), axis=-1) - (loggamma(conc.sum(-1) + total) - loggamma(conc.sum(-1))))
+    assert np.allclose(dist.counts_log_prob(torch.tensor(trans)).cpu().numpy(), want, rtol=1e-12)
+    probs = conc / conc.sum(-1, keepdims=True)
+    md = core.tfpMultinomialPerm(torch.tensor(total, device="cuda"), torch.tensor(probs, device="cuda"))
+    assert np.allclose(md.counts_log_prob(torch.tensor(trans)).cpu().numpy(), np.sum(np.log(probs) * trans, axis=-1))
+    assert np.all(md.ml_output().cpu().numpy() == np.argmax(probs, axis=-1))
+    # tie breaking (test_core.py:29-39): only tied maxima are ever returned, both of them
+    d2 = core.tfpDirichletMultinomialPerm(torch.tensor([1.0], device="cuda"), torch.tensor([1.0, 0.5, 1.0], device="cuda"))
+    seen = {int(d2.ml_output().item()) for _ in range(200)}
+    assert seen == {0, 2}
