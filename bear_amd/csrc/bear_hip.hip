@@ -361,7 +361,7 @@ static pln_view plan_view(const bear_plan *p) {
 
 static int grid_plan(const bear_ws *ws, uint64_t n_rows) {
   uint64_t tiles = (n_rows + PLN_TILE - 1) / PLN_TILE;
-  uint64_t g = (uint64_t)ws->num_cu * 2;  // two resident blocks per CU (LDS-limited)
+  uint64_t g = (uint64_t)ws->num_cu * PLN_BLOCKS_PER_CU;  // resident blocks per CU (LDS-limited)
   if (g > (uint64_t)ws->max_blocks) g = ws->max_blocks;
   if (tiles < g) g = tiles;
   return g < 1 ? 1 : (int)g;

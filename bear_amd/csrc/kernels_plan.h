@@ -22,16 +22,21 @@
 #pragma once
 #include "kernels_sorted.h"
 
-#define PLN_TILE 512
+#ifndef PLN_TILE
+#define PLN_TILE 1024                        // contexts per tile (measured: 1024 x 1 block beats 512 x 2 blocks)
+#endif
+#ifndef PLN_BLOCKS_PER_CU
+#define PLN_BLOCKS_PER_CU 1                  // LDS-limited residency the grid is sized for
+#endif
 #ifndef PLN_THREADS
-#define PLN_THREADS 512                      // evaluation kernels: 8 waves drawing work tickets (measured best of 512..1024)
+#define PLN_THREADS 1024                     // evaluation kernels: 16 waves drawing work tickets
 #endif
 #define PLN_WAVES (PLN_THREADS / 64)
 #ifndef PLN_ILP
 #define PLN_ILP 1                            // items per lane per unit in the planned kernels
 #endif
-#define PLN_WAVES_PER_SIMD (2 * PLN_WAVES / 4)  // two resident blocks per CU
-#define PLN_BUILD_THREADS 512                // plan construction: one context per thread
+#define PLN_WAVES_PER_SIMD (PLN_BLOCKS_PER_CU * PLN_WAVES / 4)
+#define PLN_BUILD_THREADS PLN_TILE           // plan construction: one context per thread
 #define PLN_SENTINEL (PLN_TILE * 5)          // flat offset of the neutral cell (c = 0, prior = 1)
 #define PLN_ITEMS_MAX (PLN_TILE * 5 + 64)    // padded light list of one tile, worst case
 
