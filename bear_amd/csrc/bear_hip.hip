@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "bear_common.h"
 #include "kernels_rows.h"
 #include "kernels_sorted.h"
@@ -77,13 +79,10 @@ int bear_ws_create(int device, bear_ws **out) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_sorted_kernel<9>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(srt_lds_n));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<0, false>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<0, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<1, false>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_ref_plan_kernel),
@@ -226,20 +225,21 @@ struct bear_plan {
   int ncol;
   uint64_t n_rows;
   const uint32_t *counts;  // the buffer the plan was built from (identity check only)
-  pln_tile_info *info;
-  uint16_t *items;
+  pln_tile *tiles;
+  unsigned char *stream;
   pln_heavy_col *heavy_col;
   pln_heavy_row *heavy_row;
   uint64_t *heavy_stop;
   unsigned long long *hist;  // [64]
+  uint64_t n_tiles;
   uint64_t n_heavy[3];
   uint64_t bytes;
 };
 
 static void plan_free(bear_plan *p) {
   if (!p) return;
-  (void)hipFree(p->info);
-  (void)hipFree(p->items);
+  (void)hipFree(p->tiles);
+  (void)hipFree(p->stream);
   (void)hipFree(p->heavy_col);
   (void)hipFree(p->heavy_row);
   (void)hipFree(p->heavy_stop);
@@ -260,74 +260,90 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   p->ncol = ncol;
   p->n_rows = n_rows;
   p->counts = counts;
-  const uint64_t n_tiles = (n_rows + PLN_TILE - 1) / PLN_TILE;
-  if (n_tiles == 0) {
+  hipError_t e = hipMalloc(&p->hist, sizeof(unsigned long long) * 2 * SRT_NKEY);
+  if (e == hipSuccess) e = hipMemset(p->hist, 0, sizeof(unsigned long long) * 2 * SRT_NKEY);
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    plan_free(p);
+    return BEAR_ERR_HIP;
+  }
+  if (n_rows == 0) {
     *out = p;
     return BEAR_OK;
   }
-  uint32_t *d_nlight = nullptr;
+  // ---- pass A: product-path items per group of 4 contexts, heavy counts, histograms
+  const uint64_t n_quads = (n_rows + PLN_QUAD - 1) / PLN_QUAD;
+  uint8_t *d_quad = nullptr, *h_quad = nullptr;
   unsigned long long *d_cnt = nullptr;  // [0..2] heavy counts, [3..5] fill cursors
-  pln_tile_info *h_info = nullptr;
-  uint32_t *h_nlight = nullptr;
-  hipError_t e = hipMalloc(&d_nlight, sizeof(uint32_t) * n_tiles);
+  std::vector<pln_tile> tiles;
+  e = hipMalloc(&d_quad, n_quads);
   if (e == hipSuccess) e = hipMalloc(&d_cnt, sizeof(unsigned long long) * 6);
   if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(unsigned long long) * 6);
-  if (e == hipSuccess) e = hipMalloc(&p->hist, sizeof(unsigned long long) * 2 * SRT_NKEY);
-  if (e == hipSuccess) e = hipMemset(p->hist, 0, sizeof(unsigned long long) * 2 * SRT_NKEY);
-  int grid = (int)(n_tiles < (uint64_t)ws->num_cu * 4 ? n_tiles : (uint64_t)ws->num_cu * 4);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(plan_count_kernel, dim3(grid), dim3(PLN_BUILD_THREADS), 0, 0, counts, n_rows, ncol, d_nlight, d_cnt, p->hist);
+    uint64_t gb = (n_quads + 255) / 256;
+    const int grid = (int)(gb < (uint64_t)ws->num_cu * 8 ? gb : (uint64_t)ws->num_cu * 8);
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(grid), dim3(256), 0, 0, counts, n_rows, ncol, d_quad, d_cnt, p->hist);
     e = hipGetLastError();
   }
   unsigned long long h_cnt[3] = {0, 0, 0};
   if (e == hipSuccess) {
-    h_nlight = (uint32_t *)malloc(sizeof(uint32_t) * n_tiles);
-    h_info = (pln_tile_info *)malloc(sizeof(pln_tile_info) * n_tiles);
-    if (!h_nlight || !h_info) {
-      free(h_nlight);
-      free(h_info);
-      (void)hipFree(d_nlight);
-      (void)hipFree(d_cnt);
-      plan_free(p);
-      return BEAR_ERR_NOMEM;
-    }
-    e = hipMemcpy(h_nlight, d_nlight, sizeof(uint32_t) * n_tiles, hipMemcpyDeviceToHost);
+    h_quad = (uint8_t *)malloc(n_quads);
+    if (!h_quad) e = hipErrorOutOfMemory;
   }
+  if (e == hipSuccess) e = hipMemcpy(h_quad, d_quad, n_quads, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
+  // ---- tiles: greedy cut so that a tile holds <= PLN_NI items and <= PLN_RMAX contexts
   uint64_t off16 = 0;
   if (e == hipSuccess) {
-    for (uint64_t t = 0; t < n_tiles; ++t) {
-      h_info[t].off16 = (uint32_t)off16;
-      h_info[t].n_light = h_nlight[t];
-      off16 += (((uint64_t)h_nlight[t] + 63u) & ~63ull) / 8;  // padded items * 2 B / 16 B
+    uint64_t q = 0;
+    while (q < n_quads) {
+      uint32_t items = 0, rows = 0;
+      const uint64_t q0 = q;
+      while (q < n_quads && rows + PLN_QUAD <= PLN_RMAX && items + h_quad[q] <= PLN_NI) {
+        items += h_quad[q];
+        rows += PLN_QUAD;
+        ++q;
+      }
+      pln_tile ti;
+      ti.row0 = q0 * PLN_QUAD;
+      if (ti.row0 + rows > n_rows) rows = (uint32_t)(n_rows - ti.row0);  // ragged end of the table
+      ti.rows_items = (rows << 16) | items;
+      ti.off16 = (uint32_t)off16;
+      off16 += pln_block_bytes(rows, items) / 16;
+      if (off16 > 0xffffffffull) {
+        e = hipErrorOutOfMemory;
+        break;
+      }
+      tiles.push_back(ti);
     }
-    if (off16 > 0xffffffffull) e = hipErrorOutOfMemory;
   }
-  const uint64_t item_bytes = off16 * 16 + 1024;  // slack: the last DMA piece may be read in full
-  if (e == hipSuccess) e = hipMalloc(&p->info, sizeof(pln_tile_info) * n_tiles);
-  if (e == hipSuccess) e = hipMalloc(&p->items, item_bytes);
-  if (e == hipSuccess) e = hipMemset(p->items, 0, item_bytes);
+  free(h_quad);
+  (void)hipFree(d_quad);
+  p->n_tiles = tiles.size();
+  const uint64_t stream_bytes = off16 * 16 + 1024;  // slack: a DMA piece may be issued for a partial KiB
   for (int k = 0; k < 3; ++k) p->n_heavy[k] = h_cnt[k];
+  if (e == hipSuccess) e = hipMalloc(&p->tiles, sizeof(pln_tile) * (tiles.size() + 1));
+  if (e == hipSuccess) e = hipMalloc(&p->stream, stream_bytes);
+  if (e == hipSuccess) e = hipMemset(p->stream, 0, stream_bytes);
   if (e == hipSuccess && h_cnt[0]) e = hipMalloc(&p->heavy_col, sizeof(pln_heavy_col) * h_cnt[0]);
   if (e == hipSuccess && h_cnt[1]) e = hipMalloc(&p->heavy_row, sizeof(pln_heavy_row) * h_cnt[1]);
   if (e == hipSuccess && h_cnt[2]) e = hipMalloc(&p->heavy_stop, sizeof(uint64_t) * h_cnt[2]);
-  if (e == hipSuccess) e = hipMemcpy(p->info, h_info, sizeof(pln_tile_info) * n_tiles, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->tiles, tiles.data(), sizeof(pln_tile) * tiles.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(plan_fill_kernel, dim3(grid), dim3(PLN_BUILD_THREADS), 0, 0, counts, n_rows, ncol, p->info, p->items,
+    const uint64_t nt = tiles.size();
+    const int grid = (int)(nt < (uint64_t)ws->num_cu * 2 ? nt : (uint64_t)ws->num_cu * 2);
+    hipLaunchKernelGGL(plan_fill_kernel, dim3(grid), dim3(1024), 0, 0, counts, n_rows, ncol, p->tiles, nt, p->stream,
                        p->heavy_col, p->heavy_row, p->heavy_stop, d_cnt + 3);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
-  free(h_nlight);
-  free(h_info);
-  (void)hipFree(d_nlight);
   (void)hipFree(d_cnt);
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
     plan_free(p);
     return e == hipErrorOutOfMemory ? BEAR_ERR_NOMEM : BEAR_ERR_HIP;
   }
-  p->bytes = item_bytes + sizeof(pln_tile_info) * n_tiles + sizeof(pln_heavy_col) * h_cnt[0] +
+  p->bytes = stream_bytes + sizeof(pln_tile) * tiles.size() + sizeof(pln_heavy_col) * h_cnt[0] +
              sizeof(pln_heavy_row) * h_cnt[1] + sizeof(uint64_t) * h_cnt[2];
   *out = p;
   return BEAR_OK;
@@ -347,23 +363,23 @@ uint64_t bear_plan_bytes(const bear_plan *plan) { return plan ? plan->bytes : 0;
 
 static pln_view plan_view(const bear_plan *p) {
   pln_view v;
-  v.info = p->info;
-  v.items = p->items;
+  v.tiles = p->tiles;
+  v.stream = p->stream;
   v.heavy_col = p->heavy_col;
   v.heavy_row = p->heavy_row;
   v.heavy_stop = p->heavy_stop;
   v.hist = p->hist;
+  v.n_tiles = p->n_tiles;
   v.n_heavy_col = p->n_heavy[0];
   v.n_heavy_row = p->n_heavy[1];
   v.n_heavy_stop = p->n_heavy[2];
   return v;
 }
 
-static int grid_plan(const bear_ws *ws, uint64_t n_rows) {
-  uint64_t tiles = (n_rows + PLN_TILE - 1) / PLN_TILE;
-  uint64_t g = (uint64_t)ws->num_cu * PLN_BLOCKS_PER_CU;  // resident blocks per CU (LDS-limited)
+static int grid_plan(const bear_ws *ws, uint64_t n_tiles) {
+  uint64_t g = (uint64_t)ws->num_cu;  // one resident 1024-thread block per CU (LDS ring)
   if (g > (uint64_t)ws->max_blocks) g = ws->max_blocks;
-  if (tiles < g) g = tiles;
+  if (n_tiles < g) g = n_tiles;
   return g < 1 ? 1 : (int)g;
 }
 
@@ -375,22 +391,20 @@ int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *c
   if (!plan || !out || (n_rows && (!counts || !prior))) return BEAR_ERR_INVALID_ARG;
   if (plan->ncol != 5 || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
     return BEAR_ERR_INVALID_ARG;
-  if (misaligned(counts) || misaligned(prior) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  if (misaligned(prior) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   bear_params prm;
   memset(&prm, 0, sizeof(prm));
   prm.inv_h = 1.0 / exp(h_signed);
   prm.eps = eps;
-  const int grid = grid_plan(ws, n_rows);
-  if (getenv("BEAR_DEBUG_TIMING"))  // developer switch: diagnostic build with in-kernel stamps
-    hipLaunchKernelGGL((dm_prior_plan_kernel<1, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, counts, prior, n_rows,
-                       prm, plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials, ws->dbg);
-  else if (prior_normalized)
-    hipLaunchKernelGGL((dm_prior_plan_kernel<0, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, counts, prior, n_rows,
-                       prm, plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials, ws->dbg);
+  const int grid = grid_plan(ws, plan->n_tiles);
+  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  if (prior_normalized)
+    hipLaunchKernelGGL(dm_prior_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
+                       plan_view(plan), lt, ws->partials);
   else
-    hipLaunchKernelGGL((dm_prior_plan_kernel<0, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, counts, prior, n_rows,
-                       prm, plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials, ws->dbg);
+    hipLaunchKernelGGL(dm_prior_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
+                       plan_view(plan), lt, ws->partials);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
   HIP_TRY(hipGetLastError());
@@ -405,7 +419,7 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
   if (!plan || !out || (n_rows && (!train || !ref))) return BEAR_ERR_INVALID_ARG;
   if (plan->ncol != 4 || plan->n_rows != n_rows || plan->counts != train || plan->device != ws->device)
     return BEAR_ERR_INVALID_ARG;
-  if (misaligned(train) || misaligned(ref) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  if (misaligned(ref) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   bear_params prm;
   const double tau = exp(tau_signed), nw = exp(nu_signed);
@@ -416,9 +430,9 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
   prm.tau = tau;
   prm.V = 1.0 / (nw + 1.0);
   prm.nw = nw;
-  const int grid = grid_plan(ws, n_rows);
-  hipLaunchKernelGGL(dm_ref_plan_kernel, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, train, ref, n_rows, prm,
-                     plan_view(plan), reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
+  const int grid = grid_plan(ws, plan->n_tiles);
+  hipLaunchKernelGGL(dm_ref_plan_kernel, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan),
+                     reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 4, out);
   HIP_TRY(hipGetLastError());

@@ -2,48 +2,53 @@
 // table that stays resident in HBM across optimizer steps (every epoch of bear_net.train /
 // bear_ref.train re-reads the same cached count table, bear_model/dataloader.py:47-48).
 //
-// The counting sort of kernels_sorted.h depends on the counts only, and the counts never change
-// between steps -- only h, the prior rows and (tau, nu) do.  So the sort moves to load time:
+// Everything that depends on the counts only is done ONCE, at load time (bear_plan_create); the
+// counts never change between steps -- only h, the prior rows and (tau, nu) do.
 //
-//   plan (built once per table, bear_plan_create):
-//     * per tile of PLN_TILE contexts: the work items of the product path (column b of context r
-//       with 1 <= c <= SRT_CL), as uint16 flat offsets r*5+b sorted by ascending c and padded
-//       to a multiple of 64 with a sentinel; ~2.4 B per context on k-mer tables
-//     * global lists of the rare items that take the Stirling path (c > SRT_CL): column items
-//       {flat offset, c} and contexts {row, n}
-//   step  (bear_dm_prior_plan_f64 / bear_dm_ref_plan_f64), per tile, ONE barrier:
-//     0  the next tile's count rows, prior rows and item list stream into the other half of a
-//        double buffer by LDS-DMA while the current tile is evaluated
-//     A  one thread per context: n = sum c, S = sum prior; the context term -D(A, n) comes from
-//        a per-block table whenever A is shared (S = 1 to 2 ulp; always in mode R)
-//     D  units of 64 x SRT_ILP sorted items: p = prod (x+j), p' by the product rule, one table
-//        log and one reciprocal per item; all lanes busy, loops wave-uniform
-//     after the tiles: the global Stirling-path lists, densely packed over all threads.
+//   plan = a sorted sparse encoding of the count table:
+//     * the table is cut into tiles of consecutive contexts such that every tile holds at most
+//       PLN_UNITS x 64 product-path work items (column b of context r with 1 <= c <= SRT_CL) and at most
+//       PLN_RMAX contexts: on k-mer tables every tile is exactly 16 full 64-lane units, one per wave
+//     * per tile, one contiguous block: thresholds E[c] = #items with count <= c (the items are sorted
+//       by count, so an item's count follows from its position), the row totals n (uint8, 0 = none or
+//       large), the items as uint16 flat offsets r*5+b
+//     * global lists of the rare Stirling-path items (c > SRT_CL) and rows (n > SRT_CL), and histograms of
+//       the row totals / stop counts for the terms whose concentration is shared by all contexts
+//   step (bear_dm_prior_plan_f64 / bear_dm_ref_plan_f64), per tile, ONE barrier:
+//     0  the prior rows (mode N) / reference rows (mode R) and the plan block of a later tile stream
+//        into a ring of LDS buffers by LDS-DMA while the current tile is evaluated; the count rows
+//        themselves are not read at all
+//     D  wave w evaluates unit w: p = prod (x+j), p' by the product rule, one table log and one
+//        reciprocal per item; loops are wave-uniform (sorted), all lanes busy (full units)
+//     A  (mode N without the normalisation promise) wave w walks contexts 64w .. 64w+63: S = sum prior,
+//        context term from the shared-A table when S = 1 to 2 ulp, own product otherwise
+//     after the tiles: the global Stirling-path lists, densely packed over all threads, and the
+//     histogram x table terms.
 #pragma once
 #include "kernels_sorted.h"
 
-#ifndef PLN_TILE
-#define PLN_TILE 1024                        // contexts per tile (measured: 1024 x 1 block beats 512 x 2 blocks)
-#endif
-#ifndef PLN_BLOCKS_PER_CU
-#define PLN_BLOCKS_PER_CU 1                  // LDS-limited residency the grid is sized for
-#endif
-#ifndef PLN_THREADS
-#define PLN_THREADS 1024                     // evaluation kernels: 16 waves drawing work tickets
-#endif
+#define PLN_THREADS 1024
 #define PLN_WAVES (PLN_THREADS / 64)
-#ifndef PLN_ILP
-#define PLN_ILP 1                            // items per lane per unit in the planned kernels
+#ifndef PLN_UNITS
+#define PLN_UNITS 32                          // units per tile: two per wave, drawn dynamically, dearest first
 #endif
-#define PLN_WAVES_PER_SIMD (PLN_BLOCKS_PER_CU * PLN_WAVES / 4)
-#define PLN_BUILD_THREADS PLN_TILE           // plan construction: one context per thread
-#define PLN_SENTINEL (PLN_TILE * 5)          // flat offset of the neutral cell (c = 0, prior = 1)
-#define PLN_ITEMS_MAX (PLN_TILE * 5 + 64)    // padded light list of one tile, worst case
+#define PLN_NI (PLN_UNITS * 64)               // product-path items per tile (at most)
+#ifndef PLN_RMAX
+#define PLN_RMAX 1792                         // contexts per tile (at most; LDS)
+#endif
+#define PLN_QUAD 4                            // tiles start on multiples of 4 contexts (16-byte aligned rows)
+#define PLN_SENTINEL (PLN_RMAX * 5)           // flat offset of the neutral cell (prior = 1 / ref row = 0)
+#ifndef PLN_NBUF
+#define PLN_NBUF 2                            // LDS ring depth: tiles in flight = PLN_NBUF - 1
+#endif
+#define PLN_BLOCK_MAX (64 + PLN_RMAX + PLN_NI * 2)  // bytes of one tile's plan block: E | nrow | items
 
-struct pln_tile_info {
-  uint32_t off16;    // start of the tile's item list in the plan's item array, in 16-byte units
-  uint32_t n_light;  // real (unpadded) number of items
+struct pln_tile {
+  uint64_t row0;
+  uint32_t rows_items;  // rows << 16 | n_light
+  uint32_t off16;       // start of the tile's block in the plan stream, 16-byte units
 };
+static_assert(sizeof(pln_tile) == 16, "tile descriptors are fetched with one s_load_dwordx4");
 
 struct pln_heavy_col {
   uint64_t off;  // flat offset row*5+b into the [N,5] arrays
@@ -55,29 +60,29 @@ struct pln_heavy_row {
   double n;  // exact row total (may exceed 2^32)
 };
 
+__host__ __device__ inline uint32_t pln_block_bytes(uint32_t rows, uint32_t n_light) {
+  return 64u + ((rows + 15u) & ~15u) + (((n_light + 63u) & ~63u) * 2u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // plan construction
 // ---------------------------------------------------------------------------------------------
-// Pass 1: per tile, number of product-path items in columns [0, ncol); global counts of heavy
-// column items, heavy contexts (n > SRT_CL) and, for ncol == 4, heavy stop counts.
-__global__ __launch_bounds__(PLN_BUILD_THREADS) void plan_count_kernel(const uint32_t *__restrict__ counts, uint64_t n_rows,
-                                                                  int ncol, uint32_t *__restrict__ n_light,
-                                                                  unsigned long long *__restrict__ heavy_counts,
-                                                                  unsigned long long *__restrict__ hist) {
-  __shared__ uint32_t s_light;
+// Pass A: number of product-path items per group of 4 contexts (uint8), global counts of heavy column
+// items / heavy contexts / heavy stop counts, histograms of row totals and stop counts <= SRT_CL.
+__global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restrict__ counts, uint64_t n_rows, int ncol,
+                                                        uint8_t *__restrict__ quad_light,
+                                                        unsigned long long *__restrict__ heavy_counts,
+                                                        unsigned long long *__restrict__ hist) {
   __shared__ uint32_t s_heavy[3];
-  __shared__ uint32_t s_hist[2 * SRT_NKEY];  // [0..31]: contexts by total n, [32..63]: by stop count (n, c <= SRT_CL)
+  __shared__ uint32_t s_hist[2 * SRT_NKEY];
+  if (threadIdx.x < 3) s_heavy[threadIdx.x] = 0;
   if (threadIdx.x < 2 * SRT_NKEY) s_hist[threadIdx.x] = 0;
-  const uint64_t n_tiles = (n_rows + PLN_TILE - 1) / PLN_TILE;
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    if (threadIdx.x == 0) {
-      s_light = 0;
-      s_heavy[0] = s_heavy[1] = s_heavy[2] = 0;
-    }
-    __syncthreads();
-    const uint64_t r = tile * PLN_TILE + threadIdx.x;
-    if (r < n_rows) {
-      uint32_t light = 0, hcol = 0, nsat = 0;
+  __syncthreads();
+  const uint64_t n_quads = (n_rows + PLN_QUAD - 1) / PLN_QUAD;
+  for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < n_quads; g += (uint64_t)gridDim.x * 256) {
+    uint32_t light = 0;
+    for (uint64_t r = PLN_QUAD * g; r < PLN_QUAD * g + PLN_QUAD && r < n_rows; ++r) {
+      uint32_t nsat = 0, hcol = 0;
 #pragma unroll
       for (int b = 0; b < 5; ++b) {
         const uint32_t c = counts[r * 5 + b];
@@ -88,7 +93,6 @@ __global__ __launch_bounds__(PLN_BUILD_THREADS) void plan_count_kernel(const uin
           hcol += (c > SRT_CL);
         }
       }
-      if (light) atomicAdd(&s_light, light);
       if (hcol) atomicAdd(&s_heavy[0], hcol);
       if (nsat > SRT_CL) atomicAdd(&s_heavy[1], 1u);
       else if (nsat != 0) atomicAdd(&s_hist[nsat - 1], 1u);
@@ -96,67 +100,80 @@ __global__ __launch_bounds__(PLN_BUILD_THREADS) void plan_count_kernel(const uin
       if (ncol == 4 && c4 > SRT_CL) atomicAdd(&s_heavy[2], 1u);
       else if (ncol == 4 && c4 != 0) atomicAdd(&s_hist[SRT_NKEY + c4 - 1], 1u);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      n_light[tile] = s_light;
-      for (int k = 0; k < 3; ++k)
-        if (s_heavy[k]) atomicAdd(&heavy_counts[k], (unsigned long long)s_heavy[k]);
-    }
-    __syncthreads();
+    quad_light[g] = (uint8_t)light;
   }
+  __syncthreads();
+  if (threadIdx.x < 3 && s_heavy[threadIdx.x]) atomicAdd(&heavy_counts[threadIdx.x], (unsigned long long)s_heavy[threadIdx.x]);
   if (threadIdx.x < 2 * SRT_NKEY && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
 }
 
-// Pass 2: per tile, counting sort of the product-path items by c (LDS histogram, replicated 8x),
-// written as a padded uint16 list; heavy items appended to the global lists.
-__global__ __launch_bounds__(PLN_BUILD_THREADS) void plan_fill_kernel(const uint32_t *__restrict__ counts, uint64_t n_rows,
-                                                                 int ncol, const pln_tile_info *__restrict__ info,
-                                                                 uint16_t *__restrict__ items,
-                                                                 pln_heavy_col *__restrict__ heavy_col,
-                                                                 pln_heavy_row *__restrict__ heavy_row,
-                                                                 uint64_t *__restrict__ heavy_stop,
-                                                                 unsigned long long *__restrict__ cursors) {
+// Pass B: one block per tile: counting sort of the tile's product-path items by count (LDS histogram,
+// replicated 8x) -> thresholds, row totals and sorted uint16 item list written as one block; heavy
+// items appended to the global lists.
+__global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restrict__ counts, uint64_t n_rows, int ncol,
+                                                         const pln_tile *__restrict__ tiles, uint64_t n_tiles,
+                                                         unsigned char *__restrict__ stream,
+                                                         pln_heavy_col *__restrict__ heavy_col,
+                                                         pln_heavy_row *__restrict__ heavy_row,
+                                                         uint64_t *__restrict__ heavy_stop,
+                                                         unsigned long long *__restrict__ cursors) {
+  constexpr int RPT = (PLN_RMAX + 1023) / 1024;  // contexts per thread
   __shared__ uint32_t hist[SRT_NHIST];
   __shared__ uint32_t offs[SRT_NHIST];
-  __shared__ uint32_t scan[SRT_WAVES];
-  __shared__ uint16_t sorted[PLN_ITEMS_MAX];
+  __shared__ uint32_t scan[16];
+  __shared__ uint16_t sorted[PLN_NI + 64];
   const uint32_t tid = threadIdx.x, rep = tid & (SRT_REP - 1);
-  const uint64_t n_tiles = (n_rows + PLN_TILE - 1) / PLN_TILE;
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const pln_tile ti = tiles[t];
+    const uint32_t rows = ti.rows_items >> 16, n_light = ti.rows_items & 0xffffu;
+    unsigned char *blk = stream + (size_t)ti.off16 * 16;
+    uint16_t *E = reinterpret_cast<uint16_t *>(blk);
+    uint8_t *nrow = blk + 64;
+    uint16_t *items = reinterpret_cast<uint16_t *>(blk + 64 + ((rows + 15u) & ~15u));
     if (tid < SRT_NHIST) hist[tid] = 0;
     __syncthreads();
-    const uint64_t r = tile * PLN_TILE + tid;
-    uint32_t c[5] = {0, 0, 0, 0, 0}, rank[5] = {0, 0, 0, 0, 0};
-    if (r < n_rows) {
-      double n = 0.0;
+    uint32_t c[RPT][5], rank[RPT][5];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const uint32_t lr = tid + 1024u * k;
 #pragma unroll
       for (int b = 0; b < 5; ++b) {
-        c[b] = counts[r * 5 + b];
-        n += (double)c[b];
+        c[k][b] = 0;
+        rank[k][b] = 0;
       }
-      if (n > (double)SRT_CL) {
-        const unsigned long long k = atomicAdd(&cursors[1], 1ull);
-        heavy_row[k].row = r;
-        heavy_row[k].n = n;
-      }
-      if (ncol == 4 && c[4] > SRT_CL) heavy_stop[atomicAdd(&cursors[2], 1ull)] = c[4];
+      if (lr < rows) {
+        const uint64_t r = ti.row0 + lr;
+        double n = 0.0;
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        if (b >= ncol) c[b] = 0;
-        if (c[b] > SRT_CL) {
-          const unsigned long long k = atomicAdd(&cursors[0], 1ull);
-          heavy_col[k].off = r * 5 + b;
-          heavy_col[k].c = c[b];
-          c[b] = 0;
+        for (int b = 0; b < 5; ++b) {
+          c[k][b] = counts[r * 5 + b];
+          n += (double)c[k][b];
         }
-        if (c[b] != 0) rank[b] = atomicAdd(&hist[(c[b] - 1) * SRT_REP + rep], 1u);
+        nrow[lr] = (n >= 1.0 && n <= (double)SRT_CL) ? (uint8_t)n : (uint8_t)0;
+        if (n > (double)SRT_CL) {
+          const unsigned long long q = atomicAdd(&cursors[1], 1ull);
+          heavy_row[q].row = r;
+          heavy_row[q].n = n;
+        }
+        if (ncol == 4 && c[k][4] > SRT_CL) heavy_stop[atomicAdd(&cursors[2], 1ull)] = c[k][4];
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          if (b >= ncol) c[k][b] = 0;
+          if (c[k][b] > SRT_CL) {
+            const unsigned long long q = atomicAdd(&cursors[0], 1ull);
+            heavy_col[q].off = r * 5 + b;
+            heavy_col[q].c = c[k][b];
+            c[k][b] = 0;
+          }
+          if (c[k][b] != 0) rank[k][b] = atomicAdd(&hist[(c[k][b] - 1) * SRT_REP + rep], 1u);
+        }
+      } else if (lr < ((rows + 15u) & ~15u)) {
+        nrow[lr] = 0;
       }
     }
     __syncthreads();
     {
-      uint32_t total;
       const uint32_t v = tid < SRT_NHIST ? hist[tid] : 0u;
-      // plain block scan (same shape as srt_block_exscan, with ordinary barriers)
       const int lane = tid & 63, wave = tid >> 6;
       uint32_t incl = v;
 #pragma unroll
@@ -167,23 +184,20 @@ __global__ __launch_bounds__(PLN_BUILD_THREADS) void plan_fill_kernel(const uint
       if (lane == 63) scan[wave] = incl;
       __syncthreads();
       uint32_t base = 0;
-      total = 0;
-      for (int w = 0; w < SRT_WAVES; ++w) {
-        if (w < wave) base += scan[w];
-        total += scan[w];
-      }
+      for (int w = 0; w < wave; ++w) base += scan[w];
       if (tid < SRT_NHIST) offs[tid] = base + incl - v;
-      (void)total;
     }
     __syncthreads();
+    // thresholds: E[c] = number of items with count <= c (start of key c in the sorted order)
+    if (tid < 32) E[tid] = (uint16_t)(tid < SRT_CL ? offs[tid * SRT_REP] : n_light);
 #pragma unroll
-    for (int b = 0; b < 5; ++b)
-      if (c[b] != 0) sorted[offs[(c[b] - 1) * SRT_REP + rep] + rank[b]] = (uint16_t)(tid * 5 + b);
+    for (int k = 0; k < RPT; ++k)
+#pragma unroll
+      for (int b = 0; b < 5; ++b)
+        if (c[k][b] != 0) sorted[offs[(c[k][b] - 1) * SRT_REP + rep] + rank[k][b]] = (uint16_t)((tid + 1024u * k) * 5 + b);
     __syncthreads();
-    const pln_tile_info ti = info[tile];
-    const uint32_t padded = (ti.n_light + 63u) & ~63u;
-    uint16_t *dst = items + (size_t)ti.off16 * 8;
-    for (uint32_t i = tid; i < padded; i += PLN_BUILD_THREADS) dst[i] = i < ti.n_light ? sorted[i] : (uint16_t)PLN_SENTINEL;
+    const uint32_t padded = (n_light + 63u) & ~63u;
+    for (uint32_t i = tid; i < padded; i += 1024) items[i] = i < n_light ? sorted[i] : (uint16_t)PLN_SENTINEL;
     __syncthreads();
   }
 }
@@ -192,60 +206,63 @@ __global__ __launch_bounds__(PLN_BUILD_THREADS) void plan_fill_kernel(const uint
 // per-step evaluation
 // ---------------------------------------------------------------------------------------------
 struct pln_view {  // device-side view of a plan
-  const pln_tile_info *info;
-  const uint16_t *items;
+  const pln_tile *tiles;
+  const unsigned char *stream;
   const pln_heavy_col *heavy_col;
   const pln_heavy_row *heavy_row;
   const uint64_t *heavy_stop;
   const unsigned long long *hist;  // [0..31] contexts with total n = j+1, [32..63] with stop count j+1 (<= SRT_CL)
-  uint64_t n_heavy_col, n_heavy_row, n_heavy_stop;
+  uint64_t n_tiles, n_heavy_col, n_heavy_row, n_heavy_stop;
 };
 
-// DMA of `bytes` (multiple of 16) to LDS: whole 1 KiB pieces round-robin over the waves, the last
-// partial piece with the surplus lanes masked off.
-__device__ __forceinline__ void pln_dma(void *lds, const void *src, uint32_t bytes, uint32_t wave, uint32_t lane) {
+// DMA of `bytes` (multiple of 16) to LDS: 1 KiB pieces round-robin over the waves starting at wave
+// `first` (so successive slabs spread over different waves), the last piece with surplus lanes masked.
+// Returns the number of DMA instructions this wave issued.  Inline asm on purpose: see kernels_sorted.h.
+__device__ __forceinline__ uint32_t pln_dma(void *lds, const void *src, uint32_t bytes, uint32_t wave, uint32_t lane,
+                                            uint32_t first) {
   const uint32_t d = (uint32_t)(uintptr_t)lds;
   const unsigned char *s = static_cast<const unsigned char *>(src) + lane * 16u;
   const uint32_t pieces = (bytes + 1023u) >> 10;
-  for (uint32_t piece = wave; piece < pieces; piece += PLN_WAVES) {
+  uint32_t issued = 0;
+  for (uint32_t piece = (wave + PLN_WAVES - (first % PLN_WAVES)) % PLN_WAVES; piece < pieces; piece += PLN_WAVES) {
     const unsigned char *g = s + (piece << 10);
     const uint32_t m = srt_uniform(d + (piece << 10));
     if ((piece << 10) + lane * 16u < bytes)
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m) : "memory", "m0");
+    ++issued;
+  }
+  return issued;
+}
+
+// Waits until at most `younger` of this wave's vector-memory operations are outstanding (vmcnt is an
+// immediate, hence the ladder; a wave issues at most 3 DMA pieces per tile).
+__device__ __forceinline__ void pln_wait_all_but(uint32_t younger) {
+  switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
 
-// Units of sorted product-path items of the current tile.  `decode(off, &x)` returns the item's
-// count and writes its concentration; `accumulate(x, o)` folds D, P into the thread's sums.
-template <int ILP, typename Decode, typename Accum>
-__device__ __forceinline__ void pln_unit(const uint16_t *items, uint32_t n_light, uint32_t un, uint32_t lane,
-                                         const double2 *logtab, Decode decode, Accum accumulate) {
-  const uint32_t padded = (n_light + 63u) & ~63u;
-  const uint32_t base = un * 64u * ILP;
-  uint32_t ci[ILP];
-  double x[ILP];
-  bear_dp o[ILP];
-#pragma unroll
-  for (int i = 0; i < ILP; ++i) {
-    const uint32_t idx = base + 64u * i + lane;
-    const uint32_t off = idx < padded ? (uint32_t)items[idx] : (uint32_t)PLN_SENTINEL;
-    ci[i] = decode(off, &x[i]);
+// Scalar (s_load_dwordx4) fetch of a tile descriptor: a vector-memory load here would make the compiler
+// wait for vmcnt(0) at its first use -- and vmcnt is in order, so that wait would drain the DMA ring.
+__device__ __forceinline__ pln_tile pln_load_tile(const pln_view &pv, uint64_t t) {
+  pln_tile ti;
+  ti.row0 = 0;
+  ti.rows_items = 0;
+  ti.off16 = 0;
+  if (t < pv.n_tiles) {
+    const __attribute__((address_space(4))) pln_tile *tc = (const __attribute__((address_space(4))) pln_tile *)(uintptr_t)pv.tiles;
+    ti.row0 = tc[t].row0;
+    ti.rows_items = tc[t].rows_items;
+    ti.off16 = tc[t].off16;
   }
-  // smallest / largest count: first lane of the unit, last occupied lane of the last occupied slice
-  uint32_t cmax = 0;
-#pragma unroll
-  for (int i = 0; i < ILP; ++i) {
-    const uint32_t lo = base + 64u * i;
-    if (n_light > lo) {
-      const uint32_t n = n_light - lo > 64u ? 64u : n_light - lo;
-      const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)ci[i], (int)(n - 1u));
-      cmax = v > cmax ? v : cmax;
-    }
-  }
-  const uint32_t cmin = n_light - base >= 64u * ILP ? (uint32_t)__builtin_amdgcn_readlane((int)ci[0], 0) : 0u;
-  srt_light<ILP>(x, ci, cmin, cmax, logtab, o);
-#pragma unroll
-  for (int i = 0; i < ILP; ++i) accumulate(x[i], o[i]);
+  return ti;
 }
 
 // Dynamic work distribution inside a tile: every wave draws tickets from an LDS counter.
@@ -255,44 +272,49 @@ __device__ __forceinline__ uint32_t pln_ticket(uint32_t *counter, uint32_t lane)
   return srt_uniform(t);
 }
 
-// Guarded synchronous staging for the ragged last tile (any block size).
-__device__ __forceinline__ void pln_stage(uint32_t *lds, const uint32_t *src, uint32_t n_dwords) {
-  for (uint32_t i = threadIdx.x; i < n_dwords; i += blockDim.x) lds[i] = src[i];
+// Counts of the 64 items of unit `un` from the tile's thresholds: an item's count is the number of
+// thresholds E[c] that do not exceed its index.  Returns the lane's count (0 beyond n_light) and the
+// wave-uniform range of the unit.
+__device__ __forceinline__ uint32_t pln_unit_counts(const uint16_t *E, uint32_t n_light, uint32_t un, uint32_t lane,
+                                                    uint32_t *cmin, uint32_t *cmax) {
+  const uint32_t base = un * 64u, idx = base + lane;
+  const uint32_t last = (base + 64u <= n_light ? base + 64u : n_light) - 1u;  // last occupied index (unit not empty)
+  const uint32_t e = lane < 32u ? (uint32_t)E[lane] : 0xffffffffu;
+  const uint32_t lo = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(e <= base));
+  const uint32_t hi = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(e <= last));
+  uint32_t c = lo;
+  for (uint32_t k = lo; k < hi; ++k) c += idx >= (uint32_t)__builtin_amdgcn_readlane((int)e, (int)k) ? 1u : 0u;
+  *cmin = base + 64u <= n_light ? lo : 0u;  // un-predicated factors only in full units
+  *cmax = hi;
+  return idx < n_light ? c : 0u;
 }
 
 // ---- mode N ---------------------------------------------------------------------------------
+struct pln_buf_n {
+  double pri[PLN_RMAX * 5 + 2];                      // [PLN_SENTINEL] = 1.0
+  __attribute__((aligned(16))) unsigned char blk[PLN_BLOCK_MAX];  // E[32] u16 | nrow u8[rows~16] | items u16[n_light~64]
+};
 struct pln_lds_n {
-  double pri[2][PLN_TILE * 5 + 2];      // [.][PLN_SENTINEL] = 1.0
-  uint32_t cnt[2][PLN_TILE * 5 + 4];    // [.][PLN_SENTINEL] = 0
-  uint16_t items[2][PLN_ITEMS_MAX];
+  pln_buf_n buf[PLN_NBUF];
   double2 logtab[BEAR_LOGTAB_N];
-  double tabD[SRT_NKEY];                // D(u + 5 eps, j + 1)
+  double tabD[SRT_NKEY];  // D(u + 5 eps, j + 1)
   double tabP[SRT_NKEY];
-  uint32_t ticket[2];                   // per buffer parity; zeroed one tile ahead
+  uint32_t ticket[PLN_NBUF];  // per ring slot; zeroed one tile ahead
 };
 
 // NORM: the caller asserts that every prior row sums to one (true for every ar_func of the reference,
 // all of which end in a softmax, ar_funcs.py:44,97,121-126).  Then A = u + 5 eps for every context
 // and the context terms collapse to the plan's histogram over n: no per-context pass at all.
-template <int TIMING, bool NORM>  // TIMING 1: diagnostic build recording per-wave s_memtime totals
-__global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_prior_plan_kernel(const uint32_t *__restrict__ counts,
-                                                                        const double *__restrict__ prior, uint64_t n_rows,
-                                                                        bear_params prm, pln_view pv,
-                                                                        const double2 *__restrict__ logtab_g,
-                                                                        double *__restrict__ partials,
-                                                                        unsigned long long *__restrict__ dbg) {
-  unsigned long long tph[4] = {0, 0, 0, 0}, t_prev = 0;
-#define PLN_STAMP(k)                                              \
-  if (TIMING) {                                                   \
-    const unsigned long long now = __builtin_amdgcn_s_memtime();  \
-    tph[k] += now - t_prev;                                       \
-    t_prev = now;                                                 \
-  }
+template <bool NORM>
+__global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kernel(const double *__restrict__ prior,
+                                                                                    uint64_t n_rows, bear_params prm,
+                                                                                    pln_view pv,
+                                                                                    const double2 *__restrict__ logtab_g,
+                                                                                    double *__restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_n &S = *reinterpret_cast<pln_lds_n *>(srt_smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
-  const uint64_t n_tiles = (n_rows + PLN_TILE - 1) / PLN_TILE;
   double acc[2] = {0.0, 0.0};
 
   if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
@@ -301,101 +323,95 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_prior_plan
     S.tabD[tid] = o.D;
     S.tabP[tid] = o.P;
   }
-  if (tid < 2) {
-    S.pri[tid][PLN_SENTINEL] = 1.0;
-    S.cnt[tid][PLN_SENTINEL] = 0;
+  if (tid < PLN_NBUF) {
+    S.buf[tid].pri[PLN_SENTINEL] = 1.0;
     S.ticket[tid] = 0;
   }
 
-  auto stage = [&](uint64_t tile, uint32_t buf, pln_tile_info ti) {
-    const uint64_t row0 = tile * PLN_TILE;
-    if (n_rows - row0 >= PLN_TILE) {
-      pln_dma(S.pri[buf], prior + row0 * 5, PLN_TILE * 40, wave, lane);
-      pln_dma(S.cnt[buf], counts + row0 * 5, PLN_TILE * 20, wave, lane);
-    } else {
-      const uint32_t rows = (uint32_t)(n_rows - row0);
-      pln_stage(S.cnt[buf], counts + row0 * 5, rows * 5);
-      pln_stage(reinterpret_cast<uint32_t *>(S.pri[buf]), reinterpret_cast<const uint32_t *>(prior + row0 * 5), rows * 10);
+  // Streams tile `ti` into ring slot `b`; returns the number of DMA instructions this wave issued.
+  auto stage = [&](const pln_tile &ti, uint32_t b) -> uint32_t {
+    const uint32_t rows = ti.rows_items >> 16, n_light = ti.rows_items & 0xffffu;
+    if (rows == 0) return 0u;
+    const uint32_t pbytes = rows * 40u;
+    uint32_t k = pln_dma(S.buf[b].pri, prior + ti.row0 * 5, pbytes & ~15u, wave, lane, 0);
+    if (pbytes & 15u) {  // odd row count (last tile only): the trailing 8 bytes through the SCALAR path --
+      // a vector load here would be followed by s_waitcnt vmcnt(0), which drains the DMA ring
+      const __attribute__((address_space(4))) double *tail =
+          (const __attribute__((address_space(4))) double *)(uintptr_t)(prior + (ti.row0 + rows) * 5 - 1);
+      const double v = *tail;
+      if (tid == 0) S.buf[b].pri[rows * 5 - 1] = v;
     }
-    pln_dma(S.items[buf], pv.items + (size_t)ti.off16 * 8, ((ti.n_light + 63u) & ~63u) * 2u, wave, lane);
-  };
-  // Scalar (s_load) fetch of a tile descriptor: a vector-memory load here would make the compiler
-  // wait for vmcnt(0) at its first use -- and vmcnt is in order, so that wait would also drain
-  // the LDS-DMA queue of the next tile.
-  auto load_info = [&](uint64_t tile) {
-    pln_tile_info ti;
-    ti.off16 = 0;
-    ti.n_light = 0;
-    if (tile < n_tiles) {
-      const __attribute__((address_space(4))) pln_tile_info *ic =
-          (const __attribute__((address_space(4))) pln_tile_info *)(uintptr_t)pv.info;
-      ti.off16 = ic[tile].off16;
-      ti.n_light = ic[tile].n_light;
-    }
-    return ti;
+    k += pln_dma(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, pln_block_bytes(rows, n_light), wave, lane, (pbytes + 1023u) >> 10);
+    return k;
   };
 
   const uint64_t G = gridDim.x;
-  uint64_t tile = blockIdx.x;
-  uint32_t buf = 0;
-  pln_tile_info ti_cur = load_info(tile), ti_nxt = load_info(tile + G);
-  if (tile < n_tiles) stage(tile, 0, ti_cur);
-  for (; tile < n_tiles; tile += G, buf ^= 1u) {
-    const uint64_t row0 = tile * PLN_TILE;
-    const uint32_t rows = (uint32_t)((n_rows - row0 < PLN_TILE) ? (n_rows - row0) : PLN_TILE);
-    if (TIMING) t_prev = __builtin_amdgcn_s_memtime();
-    srt_wait_dma();  // this wave's pieces of the current tile have landed
-    srt_sync();      // ... and everybody else's; the previous tile is fully consumed
-    PLN_STAMP(0)
-    if (tile + G < n_tiles) stage(tile + G, buf ^ 1u, ti_nxt);
-    const pln_tile_info ti_nn = load_info(tile + 2 * G);
-    PLN_STAMP(1)
-    const double *pri = S.pri[buf];
-    const uint32_t *cnt = S.cnt[buf];
-    if (tid == 0) S.ticket[buf ^ 1u] = 0;  // next tile's counter (its last readers passed the barrier above)
-    // Work list of the tile, most expensive first: item units from the sorted tail down, then the
-    // 64-context row chunks.  Waves draw tickets until the list is exhausted.
-    const uint32_t n_units = (((ti_cur.n_light + 63u) & ~63u) + 64u * PLN_ILP - 1) / (64u * PLN_ILP);
-    const uint32_t n_work = n_units + (NORM ? 0u : PLN_TILE / 64);
-    for (uint32_t w = pln_ticket(&S.ticket[buf], lane); w < n_work; w = pln_ticket(&S.ticket[buf], lane)) {
+  uint64_t t = blockIdx.x;
+  pln_tile ring[PLN_NBUF];  // descriptors of tiles t, t+G, ... ; ring[0] is the current one
+  uint32_t inflight[PLN_NBUF];
+#pragma unroll
+  for (int k = 0; k < PLN_NBUF; ++k) {
+    ring[k] = pln_load_tile(pv, t + (uint64_t)k * G);
+    inflight[k] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < PLN_NBUF - 1; ++k) inflight[k] = srt_uniform(stage(ring[k], k));
+  uint32_t slot = 0;
+  for (; t < pv.n_tiles; t += G) {
+    // wait for the current tile: everything except the DMA pieces of the younger tiles in flight
+    uint32_t younger = 0;
+#pragma unroll
+    for (int k = 1; k < PLN_NBUF - 1; ++k) younger += inflight[k];
+    pln_wait_all_but(srt_uniform(younger));  // scalar waits ignore EXEC: the selector must be provably wave-uniform
+    srt_sync();  // everybody's pieces have landed; the previous tile's slot is fully consumed
+    const uint32_t free_slot = (slot + PLN_NBUF - 1) % PLN_NBUF;
+    const uint32_t issued = srt_uniform(stage(ring[PLN_NBUF - 1], free_slot));  // refill it with the tile PLN_NBUF - 1 ahead
+    const pln_tile cur = ring[0];
+#pragma unroll
+    for (int k = 0; k < PLN_NBUF - 1; ++k) {
+      ring[k] = ring[k + 1];
+      inflight[k] = k + 1 < PLN_NBUF - 1 ? inflight[k + 1] : issued;
+    }
+    ring[PLN_NBUF - 1] = pln_load_tile(pv, t + (uint64_t)PLN_NBUF * G);
+
+    const pln_buf_n &B = S.buf[slot];
+    const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
+    const uint16_t *E = reinterpret_cast<const uint16_t *>(B.blk);
+    const uint8_t *nrow = B.blk + 64;
+    const uint16_t *items = reinterpret_cast<const uint16_t *>(B.blk + 64 + ((rows + 15u) & ~15u));
+    if (tid == 0) S.ticket[(slot + 1) % PLN_NBUF] = 0;  // next tile's counter (its last readers passed the barrier above)
+    // Work list of the tile, dearest first: item units from the sorted tail down (long loops), then the
+    // 64-context chunks of the context terms.  Waves draw tickets until the list is exhausted.
+    const uint32_t n_units = (n_light + 63u) >> 6;
+    const uint32_t n_work = n_units + (NORM ? 0u : (rows + 63u) >> 6);
+    for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_work; w = pln_ticket(&S.ticket[slot], lane)) {
       if (NORM || w < n_units) {
-        // ---- D: column items
-        pln_unit<PLN_ILP>(
-            S.items[buf], ti_cur.n_light, n_units - 1 - w, lane, S.logtab,
-            [&](uint32_t off, double *x) {
-              *x = __builtin_fma(pri[off], u, eps);
-              return cnt[off];
-            },
-            [&](double x, const bear_dp &o) {
-              acc[0] += o.D;
-              acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
-            });
+        // ---- D: one unit of column items
+        const uint32_t un = n_units - 1u - w;
+        uint32_t cmin, cmax;
+        const uint32_t ci[1] = {pln_unit_counts(E, n_light, un, lane, &cmin, &cmax)};
+        const uint32_t off = items[un * 64u + lane];
+        const double x[1] = {__builtin_fma(B.pri[off], u, eps)};
+        bear_dp o[1];
+        srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
+        acc[0] += o[0].D;
+        acc[1] = __builtin_fma(eps - x[0], o[0].P, acc[1]);
         continue;
       }
       // ---- A: context terms  -D(A, n), (A - 5 eps) P(A, n)   with A = S u + 5 eps
       const uint32_t row = (w - n_units) * 64u + lane;
       const uint32_t rr = row < rows ? row : rows - 1;
-      uint32_t c[5];
       double f[5];
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        c[b] = cnt[rr * 5 + b];
-        f[b] = pri[rr * 5 + b];
-      }
+      for (int b = 0; b < 5; ++b) f[b] = B.pri[rr * 5 + b];
       const double S5 = ((f[0] + f[1]) + (f[2] + f[3])) + f[4];
-      uint32_t nsat = 0;
-#pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        const uint32_t s = nsat + c[b];
-        nsat = s < nsat ? 0xffffffffu : s;
-      }
-      if (row >= rows || nsat > SRT_CL) nsat = 0;  // totals beyond SRT_CL are in the plan's heavy list
+      const uint32_t n = row < rows ? (uint32_t)nrow[rr] : 0u;  // 0: empty context, or a total beyond SRT_CL (heavy list)
       const bool shared = __builtin_fabs(S5 - 1.0) <= SRT_SUM1_TOL;
-      if (nsat != 0 && shared) {
-        acc[0] -= S.tabD[nsat - 1];
-        acc[1] = __builtin_fma(u, S.tabP[nsat - 1], acc[1]);
+      if (n != 0 && shared) {
+        acc[0] -= S.tabD[n - 1];
+        acc[1] = __builtin_fma(u, S.tabP[n - 1], acc[1]);
       }
-      const uint32_t own = (nsat != 0 && !shared) ? nsat : 0u;  // general concentrations: own A
+      const uint32_t own = (n != 0 && !shared) ? n : 0u;  // general concentrations: own A
       if (__builtin_amdgcn_ballot_w64(own != 0)) {
         uint32_t cm = own;
 #pragma unroll
@@ -411,14 +427,8 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_prior_plan
         acc[1] = __builtin_fma(xa[0] - eps5, o[0].P, acc[1]);
       }
     }
-    PLN_STAMP(2)
-    if (TIMING) tph[3] += 1;
-    ti_cur = ti_nxt;
-    ti_nxt = ti_nn;
+    slot = (slot + 1) % PLN_NBUF;
   }
-#undef PLN_STAMP
-  if (TIMING && dbg && lane == 0)
-    for (int k = 0; k < 4; ++k) dbg[((size_t)blockIdx.x * PLN_WAVES + wave) * 4 + k] = tph[k];
   srt_wait_dma();
   // ---- Stirling-path items of the whole table, densely packed over the grid
   const uint64_t gtid = (uint64_t)blockIdx.x * PLN_THREADS + tid, gsz = (uint64_t)gridDim.x * PLN_THREADS;
@@ -447,21 +457,23 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_prior_plan
 }
 
 // ---- mode R ---------------------------------------------------------------------------------
+struct pln_buf_r {
+  uint32_t ref[PLN_RMAX * 5 + 4];  // [PLN_SENTINEL .. +3] = 0
+  __attribute__((aligned(16))) unsigned char blk[PLN_BLOCK_MAX];
+};
 struct pln_lds_r {
-  uint32_t trn[2][PLN_TILE * 5 + 4];   // [.][PLN_SENTINEL] = 0
-  uint32_t ref[2][PLN_TILE * 5 + 4];
-  uint16_t items[2][PLN_ITEMS_MAX];
+  pln_buf_r buf[PLN_NBUF];
   double2 logtab[BEAR_LOGTAB_N];
-  double tabD[2][SRT_NKEY];            // [0]: context term (x = A), [1]: stop column (x = x4)
+  double tabD[2][SRT_NKEY];  // [0]: context term (x = A), [1]: stop column (x = x4)
   double tabP[2][SRT_NKEY];
-  uint32_t ticket[2];
+  uint32_t ticket[PLN_NBUF];
 };
 
-__global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_ref_plan_kernel(const uint32_t *__restrict__ train,
-                                                                      const uint32_t *__restrict__ ref, uint64_t n_rows,
-                                                                      bear_params prm, pln_view pv,
-                                                                      const double2 *__restrict__ logtab_g,
-                                                                      double *__restrict__ partials) {
+__global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel(const uint32_t *__restrict__ ref,
+                                                                                  uint64_t n_rows, bear_params prm,
+                                                                                  pln_view pv,
+                                                                                  const double2 *__restrict__ logtab_g,
+                                                                                  double *__restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_r &S = *reinterpret_cast<pln_lds_r *>(srt_smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
@@ -472,7 +484,6 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_ref_plan_k
   const double tau = prm.tau;
   const double w2c = tau * (eps + 0.25 * VU);  // d alpha/d tau_s = -tau x + w2c
   const double nwV = prm.nw * prm.V;
-  const uint64_t n_tiles = (n_rows + PLN_TILE - 1) / PLN_TILE;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
 
   if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
@@ -482,38 +493,27 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_ref_plan_k
     S.tabD[which][j] = o.D;
     S.tabP[which][j] = o.P;
   }
-  if (tid < 2) S.ticket[tid] = 0;
-  if (tid < 8) {  // neutral cell: count 0, reference row of zeros (4 words)
-    S.trn[tid >> 2][PLN_SENTINEL + (tid & 3)] = 0;
-    S.ref[tid >> 2][PLN_SENTINEL + (tid & 3)] = 0;
-  }
+  if (tid < PLN_NBUF) S.ticket[tid] = 0;
+  if (tid < 4 * PLN_NBUF) S.buf[tid >> 2].ref[PLN_SENTINEL + (tid & 3)] = 0;  // neutral cell: reference row of zeros
 
-  auto stage = [&](uint64_t tile, uint32_t buf, pln_tile_info ti) {
-    const uint64_t row0 = tile * PLN_TILE;
-    if (n_rows - row0 >= PLN_TILE) {
-      pln_dma(S.trn[buf], train + row0 * 5, PLN_TILE * 20, wave, lane);
-      pln_dma(S.ref[buf], ref + row0 * 5, PLN_TILE * 20, wave, lane);
-    } else {
-      const uint32_t rows = (uint32_t)(n_rows - row0);
-      pln_stage(S.trn[buf], train + row0 * 5, rows * 5);
-      pln_stage(S.ref[buf], ref + row0 * 5, rows * 5);
+  auto stage = [&](const pln_tile &ti, uint32_t b) -> uint32_t {
+    const uint32_t rows = ti.rows_items >> 16, n_light = ti.rows_items & 0xffffu;
+    if (rows == 0) return 0u;
+    const uint32_t rbytes = rows * 20u;
+    uint32_t k = pln_dma(S.buf[b].ref, ref + ti.row0 * 5, rbytes & ~15u, wave, lane, 0);
+    if (rbytes & 15u) {  // row count not a multiple of 4 (last tile only): trailing dwords through the SCALAR path
+      const uint32_t w0 = (rbytes & ~15u) >> 2, nw = (rbytes & 15u) >> 2;
+      const __attribute__((address_space(4))) uint32_t *tail =
+          (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)(ref + ti.row0 * 5 + w0);
+      const uint32_t v0 = tail[0], v1 = nw > 1 ? tail[1] : 0u, v2 = nw > 2 ? tail[2] : 0u;
+      if (tid == 0) {
+        S.buf[b].ref[w0] = v0;
+        if (nw > 1) S.buf[b].ref[w0 + 1] = v1;
+        if (nw > 2) S.buf[b].ref[w0 + 2] = v2;
+      }
     }
-    pln_dma(S.items[buf], pv.items + (size_t)ti.off16 * 8, ((ti.n_light + 63u) & ~63u) * 2u, wave, lane);
-  };
-  // Scalar (s_load) fetch of a tile descriptor: a vector-memory load here would make the compiler
-  // wait for vmcnt(0) at its first use -- and vmcnt is in order, so that wait would also drain
-  // the LDS-DMA queue of the next tile.
-  auto load_info = [&](uint64_t tile) {
-    pln_tile_info ti;
-    ti.off16 = 0;
-    ti.n_light = 0;
-    if (tile < n_tiles) {
-      const __attribute__((address_space(4))) pln_tile_info *ic =
-          (const __attribute__((address_space(4))) pln_tile_info *)(uintptr_t)pv.info;
-      ti.off16 = ic[tile].off16;
-      ti.n_light = ic[tile].n_light;
-    }
-    return ti;
+    k += pln_dma(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, pln_block_bytes(rows, n_light), wave, lane, (rbytes + 1023u) >> 10);
+    return k;
   };
   // bear_ref.py:30-33 (Jukes-Cantor on the L1-normalised reference row), :63-68 (mix), bear_ref.py:106
   auto alpha_from = [&](double rb, double R) {
@@ -529,39 +529,55 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES_PER_SIMD) void dm_ref_plan_k
   };
 
   const uint64_t G = gridDim.x;
-  uint64_t tile = blockIdx.x;
-  uint32_t buf = 0;
-  pln_tile_info ti_cur = load_info(tile), ti_nxt = load_info(tile + G);
-  if (tile < n_tiles) stage(tile, 0, ti_cur);
-  for (; tile < n_tiles; tile += G, buf ^= 1u) {
-    const uint64_t row0 = tile * PLN_TILE;
-    const uint32_t rows = (uint32_t)((n_rows - row0 < PLN_TILE) ? (n_rows - row0) : PLN_TILE);
-    srt_wait_dma();
+  uint64_t t = blockIdx.x;
+  pln_tile ring[PLN_NBUF];
+  uint32_t inflight[PLN_NBUF];
+#pragma unroll
+  for (int k = 0; k < PLN_NBUF; ++k) {
+    ring[k] = pln_load_tile(pv, t + (uint64_t)k * G);
+    inflight[k] = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < PLN_NBUF - 1; ++k) inflight[k] = srt_uniform(stage(ring[k], k));
+  uint32_t slot = 0;
+  for (; t < pv.n_tiles; t += G) {
+    uint32_t younger = 0;
+#pragma unroll
+    for (int k = 1; k < PLN_NBUF - 1; ++k) younger += inflight[k];
+    pln_wait_all_but(srt_uniform(younger));  // scalar waits ignore EXEC: the selector must be provably wave-uniform
     srt_sync();
-    if (tile + G < n_tiles) stage(tile + G, buf ^ 1u, ti_nxt);
-    const pln_tile_info ti_nn = load_info(tile + 2 * G);
-    const uint32_t *trn = S.trn[buf];
-    const uint32_t *rfc = S.ref[buf];
-    if (tid == 0) S.ticket[buf ^ 1u] = 0;
+    const uint32_t free_slot = (slot + PLN_NBUF - 1) % PLN_NBUF;
+    const uint32_t issued = srt_uniform(stage(ring[PLN_NBUF - 1], free_slot));
+    const pln_tile cur = ring[0];
+#pragma unroll
+    for (int k = 0; k < PLN_NBUF - 1; ++k) {
+      ring[k] = ring[k + 1];
+      inflight[k] = k + 1 < PLN_NBUF - 1 ? inflight[k + 1] : issued;
+    }
+    ring[PLN_NBUF - 1] = pln_load_tile(pv, t + (uint64_t)PLN_NBUF * G);
+
+    const pln_buf_r &B = S.buf[slot];
+    const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
+    const uint16_t *E = reinterpret_cast<const uint16_t *>(B.blk);
+    const uint16_t *items = reinterpret_cast<const uint16_t *>(B.blk + 64 + ((rows + 15u) & ~15u));
+    if (tid == 0) S.ticket[(slot + 1) % PLN_NBUF] = 0;
     // The context term (x = A) and the stop column (x = x4) have the same concentration in every
     // context: their sums over the table are the plan's histograms times two small tables (added
-    // once, after the loop).  Per tile only the column items b < 4 remain.
-    const uint32_t n_units = (((ti_cur.n_light + 63u) & ~63u) + 64u * PLN_ILP - 1) / (64u * PLN_ILP);
-    for (uint32_t w = pln_ticket(&S.ticket[buf], lane); w < n_units; w = pln_ticket(&S.ticket[buf], lane)) {
-      {
-        pln_unit<PLN_ILP>(
-            S.items[buf], ti_cur.n_light, n_units - 1 - w, lane, S.logtab,
-            [&](uint32_t off, double *x) {
-              const uint32_t *rr = &rfc[((off * 52429u) >> 18) * 5u];  // row start: 5 * (off / 5), off < 2^16
-              const double R = (double)(((uint64_t)rr[0] + rr[1]) + ((uint64_t)rr[2] + rr[3])) + 4.0 * eps;  // bear_ref.py:335-337, 30
-              *x = alpha_from((double)rfc[off], R);
-              return trn[off];
-            },
-            accumulate);
-      }
+    // once, after the loop).  Per tile only the column items b < 4 remain; waves draw units, dearest first.
+    const uint32_t n_units = (n_light + 63u) >> 6;
+    for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_units; w = pln_ticket(&S.ticket[slot], lane)) {
+      const uint32_t un = n_units - 1u - w;
+      uint32_t cmin, cmax;
+      const uint32_t ci[1] = {pln_unit_counts(E, n_light, un, lane, &cmin, &cmax)};
+      const uint32_t off = items[un * 64u + lane];
+      const uint32_t *rr = &B.ref[((off * 52429u) >> 18) * 5u];  // row start: 5 * (off / 5), off < 2^16
+      const double R = (double)(((uint64_t)rr[0] + rr[1]) + ((uint64_t)rr[2] + rr[3])) + 4.0 * eps;  // bear_ref.py:335-337, 30
+      const double x[1] = {alpha_from((double)B.ref[off], R)};
+      bear_dp o[1];
+      srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
+      accumulate(x[0], o[0]);
     }
-    ti_cur = ti_nxt;
-    ti_nxt = ti_nn;
+    slot = (slot + 1) % PLN_NBUF;
   }
   srt_wait_dma();
   // ---- Stirling-path items of the whole table
