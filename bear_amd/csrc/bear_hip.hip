@@ -444,7 +444,7 @@ int bear_dm_items_f64(bear_ws *ws, const double *x, const uint32_t *c, uint64_t 
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
   if (n == 0) return BEAR_OK;
-  if (!x || !c || !D || !P || path < 0 || path > 1) return BEAR_ERR_INVALID_ARG;
+  if (!x || !c || !D || !P || path < 0 || path > 2) return BEAR_ERR_INVALID_ARG;
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 0x7fffffffull) return BEAR_ERR_INVALID_ARG;
   hipLaunchKernelGGL(dm_items_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, c, n, path,

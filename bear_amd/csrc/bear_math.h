@@ -136,6 +136,55 @@ __device__ __forceinline__ double bear_log_tab(double p, const double2 *__restri
   return __builtin_fma((double)e, 0.6931471805599453094, rl.y + l1p);
 }
 
+// log1p-type polynomial shared with bear_log_tab: log(1 + t) for |t| <= 2^-8 (|err| < 3e-18).
+__device__ __forceinline__ double bear_log1p_small(double t) {
+  double q = -1.0 / 6.0;
+  q = __builtin_fma(q, t, 0.2);
+  q = __builtin_fma(q, t, -0.25);
+  q = __builtin_fma(q, t, 1.0 / 3.0);
+  q = __builtin_fma(q, t, -0.5);
+  return __builtin_fma(t * t, q, t);
+}
+
+// General item on the table log (x > 0 finite, c >= 1 an exact integer in a double): the same
+// shifted-Stirling evaluation as bear_dm_item at ~150 instead of ~500 instructions.
+//   log(y1 / y) = log1p(r), r = c'/y: the polynomial when r < 2^-8, else the table log of u = 1 + r plus
+//   the rounding remainder (r - (u - 1)) / u  (absolute error ~1e-16 against a value >= 2^-8).
+__device__ __forceinline__ bear_dp bear_dm_item_fast(double x, double c, const double2 *__restrict__ tab) {
+  uint32_t m;  // factors taken by the product
+  const bool stir = c > (double)BEAR_KPROD || x > 0x1p60;
+  if (stir) {
+    const double need = BEAR_TSTIR - x;
+    m = need > 0.0 ? (uint32_t)ceil(need) : 0u;  // <= 8 < c
+  } else {
+    m = (uint32_t)c;
+  }
+  double p = 1.0, dp = 0.0, t = x;
+  for (uint32_t j = 0; j < m; ++j) {
+    dp = __builtin_fma(dp, t, p);
+    p *= t;
+    t += 1.0;
+  }
+  bear_dp o;
+  o.D = 0.0;
+  o.P = 0.0;
+  if (m > 0) {
+    o.D = bear_log_tab(p, tab);
+    o.P = dp * bear_rcp(p);
+  }
+  if (stir) {
+    const double y = t, cc = c - (double)m, y1 = y + cc;
+    const double ry = bear_rcp(y), ry1 = bear_rcp(y1);
+    const double r = cc * ry;
+    const double ly = bear_log_tab(y, tab);
+    const double u1 = 1.0 + r;
+    const double l1p = r < 0x1p-8 ? bear_log1p_small(r) : __builtin_fma(r - (u1 - 1.0), bear_rcp(u1), bear_log_tab(u1, tab));
+    o.D += __builtin_fma(y1 - 0.5, l1p, cc * (ly - 1.0)) + (bear_stir_lg(ry1) - bear_stir_lg(ry));
+    o.P += l1p - 0.5 * (ry1 - ry) - (bear_stir_psi(ry1) - bear_stir_psi(ry));
+  }
+  return o;
+}
+
 // ---- reductions -----------------------------------------------------------------
 __device__ __forceinline__ double bear_wave_sum(double v) {
 #pragma unroll

@@ -319,7 +319,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
 
   if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
   if (tid < SRT_NKEY) {
-    const bear_dp o = srt_general(u + eps5, (double)(tid + 1));
+    const bear_dp o = srt_general_fast(u + eps5, (double)(tid + 1), logtab_g);
     S.tabD[tid] = o.D;
     S.tabP[tid] = o.P;
   }
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
   for (uint64_t i = gtid; i < pv.n_heavy_col; i += gsz) {
     const pln_heavy_col h = pv.heavy_col[i];
     const double x = __builtin_fma(prior[h.off], u, eps);
-    const bear_dp o = srt_general(x, (double)h.c);
+    const bear_dp o = srt_general_fast(x, (double)h.c, S.logtab);
     acc[0] += o.D;
     acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
   }
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
     const pln_heavy_row h = pv.heavy_row[i];
     const double *f = prior + h.row * 5;
     const double A = __builtin_fma(((f[0] + f[1]) + (f[2] + f[3])) + f[4], u, eps5);
-    const bear_dp o = srt_general(A, h.n);
+    const bear_dp o = srt_general_fast(A, h.n, S.logtab);
     acc[0] -= o.D;
     acc[1] = __builtin_fma(A - eps5, o.P, acc[1]);
   }
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
   if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
   if (tid < 2 * SRT_NKEY) {
     const int which = tid / SRT_NKEY, j = tid % SRT_NKEY;
-    const bear_dp o = srt_general(which ? x4 : A, (double)(j + 1));
+    const bear_dp o = srt_general_fast(which ? x4 : A, (double)(j + 1), logtab_g);
     S.tabD[which][j] = o.D;
     S.tabP[which][j] = o.P;
   }
@@ -587,15 +587,15 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
     const uint32_t *rr = ref + (h.off / 5) * 5;
     const double R = (double)(((uint64_t)rr[0] + rr[1]) + ((uint64_t)rr[2] + rr[3])) + 4.0 * eps;
     const double x = alpha_from((double)ref[h.off], R);
-    accumulate(x, srt_general(x, (double)h.c));
+    accumulate(x, srt_general_fast(x, (double)h.c, S.logtab));
   }
   for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
-    const bear_dp o = srt_general(A, pv.heavy_row[i].n);
+    const bear_dp o = srt_general_fast(A, pv.heavy_row[i].n, S.logtab);
     acc[0] -= o.D;
     acc[1] = __builtin_fma(u, o.P, acc[1]);
   }
   for (uint64_t i = gtid; i < pv.n_heavy_stop; i += gsz) {
-    const bear_dp o = srt_general(x4, (double)pv.heavy_stop[i]);
+    const bear_dp o = srt_general_fast(x4, (double)pv.heavy_stop[i], S.logtab);
     acc[0] += o.D;
     acc[1] = __builtin_fma(eps - x4, o.P, acc[1]);
     acc[3] = __builtin_fma(VU * nwV, o.P, acc[3]);

@@ -107,6 +107,11 @@ __device__ __noinline__ bear_dp srt_general(double x, double c) {
   if (!(x > 0.0)) return bear_dp{__builtin_nan(""), __builtin_nan("")};
   return bear_dm_item(x, c);
 }
+// The same on the table log (LDS or global table): ~3x fewer instructions.
+__device__ __noinline__ bear_dp srt_general_fast(double x, double c, const double2 *tab) {
+  if (!(x > 0.0) || !(x < 0x1p1000)) return bear_dp{__builtin_nan(""), __builtin_nan("")};
+  return bear_dm_item_fast(x, c, tab);
+}
 
 // Product-path evaluation of ILP light items per lane: D = log prod_{j<c}(x+j), P = sum 1/(x+j).
 // Every lane runs `cmin` un-predicated factors (wave-uniform lower bound of the occupied lanes'
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(256) void dm_items_kernel(const double *__restrict_
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const bool on = i < n;
   const uint32_t ci = on ? c[i] : 0u;
-  const bool light = path == 0 && ci <= SRT_CL;
+  const bool light = path == 0 && ci <= SRT_CL;  // path 1 / 2: library-log / table-log general routine for every item
   const double xi[1] = {on && light ? x[i] : 1.0};
   const uint32_t cl[1] = {light ? ci : 0u};
   // wave-uniform bounds of an unsorted wave: cmin = 0 (everything predicated), cmax = wave maximum
@@ -624,7 +629,7 @@ __global__ __launch_bounds__(256) void dm_items_kernel(const double *__restrict_
   if (!light) {
     o[0].D = 0.0;
     o[0].P = 0.0;
-    if (ci != 0) o[0] = srt_general(x[i], (double)ci);
+    if (ci != 0) o[0] = path == 2 ? srt_general_fast(x[i], (double)ci, logtab) : srt_general(x[i], (double)ci);
   }
   if (on) {
     D[i] = o[0].D;

@@ -119,7 +119,8 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
  * integer c >= 0,  D[i] = lgamma(x+c) - lgamma(x)  and  P[i] = digamma(x+c) - digamma(x)
  * -- the two quantities TFP's lbeta and its autodiff yield in bear_model/core.py:73-74.
  *   path 0: the code path the fused kernels choose (product + table log for c <= 31, shifted
- *           Stirling series above);  path 1: the general routine for every item.
+ *           Stirling series above);  path 1 / 2: the general routine for every item, on the library
+ *           log / on the table log (the form the planned kernels use for large counts).
  *   x, D, P [dev] double [n];  c [dev] uint32 [n]
  */
 int bear_dm_items_f64(bear_ws *ws, const double *x, const uint32_t *c, uint64_t n, int path, double *D,
