@@ -276,7 +276,7 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   uint8_t *d_quad = nullptr, *h_quad = nullptr;
   unsigned long long *d_cnt = nullptr;  // [0..2] heavy counts, [3..5] fill cursors
   std::vector<pln_tile> tiles;
-  e = hipMalloc(&d_quad, n_quads);
+  e = hipMalloc(&d_quad, 3 * n_quads);
   if (e == hipSuccess) e = hipMalloc(&d_cnt, sizeof(unsigned long long) * 6);
   if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(unsigned long long) * 6);
   if (e == hipSuccess) {
@@ -287,29 +287,38 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   }
   unsigned long long h_cnt[3] = {0, 0, 0};
   if (e == hipSuccess) {
-    h_quad = (uint8_t *)malloc(n_quads);
+    h_quad = (uint8_t *)malloc(3 * n_quads);
     if (!h_quad) e = hipErrorOutOfMemory;
   }
-  if (e == hipSuccess) e = hipMemcpy(h_quad, d_quad, n_quads, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(h_quad, d_quad, 3 * n_quads, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
   // ---- tiles: greedy cut so that a tile holds <= PLN_NI items and <= PLN_RMAX contexts
   uint64_t off16 = 0;
   if (e == hipSuccess) {
     uint64_t q = 0;
     while (q < n_quads) {
-      uint32_t items = 0, rows = 0;
+      uint32_t items = 0, rows = 0, hcol = 0, hrow = 0;
       const uint64_t q0 = q;
       while (q < n_quads && rows + PLN_QUAD <= PLN_RMAX && items + h_quad[q] <= PLN_NI) {
         items += h_quad[q];
+        hcol += h_quad[n_quads + q];
+        hrow += h_quad[2 * n_quads + q];
         rows += PLN_QUAD;
         ++q;
       }
       pln_tile ti;
+      memset(&ti, 0, sizeof(ti));
       ti.row0 = q0 * PLN_QUAD;
       if (ti.row0 + rows > n_rows) rows = (uint32_t)(n_rows - ti.row0);  // ragged end of the table
+      // large-count items evaluated inside the tile (their rows are in LDS anyway); the surplus of very dense
+      // tiles goes to the global lists.  Mode R needs no row data for large totals: they stay global.
+      const uint32_t hc = hcol < PLN_HCAP ? hcol : PLN_HCAP;
+      const uint32_t hr = ncol == 5 ? (hrow < PLN_HCAP ? hrow : PLN_HCAP) : 0u;
       ti.rows_items = (rows << 16) | items;
       ti.off16 = (uint32_t)off16;
-      off16 += pln_block_bytes(rows, items) / 16;
+      ti.hc_hr = (hc << 16) | hr;
+      ti.blk16 = pln_block_layout(rows, items, hc, hr).end / 16;
+      off16 += ti.blk16;
       if (off16 > 0xffffffffull) {
         e = hipErrorOutOfMemory;
         break;
@@ -337,6 +346,9 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
+  unsigned long long h_used[3] = {0, 0, 0};  // entries that actually went to the global lists
+  if (e == hipSuccess) e = hipMemcpy(h_used, d_cnt + 3, sizeof(h_used), hipMemcpyDeviceToHost);
+  for (int k = 0; k < 3; ++k) p->n_heavy[k] = h_used[k];
   (void)hipFree(d_cnt);
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;

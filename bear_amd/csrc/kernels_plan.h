@@ -34,21 +34,41 @@
 #endif
 #define PLN_NI (PLN_UNITS * 64)               // product-path items per tile (at most)
 #ifndef PLN_RMAX
-#define PLN_RMAX 1792                         // contexts per tile (at most; LDS)
+#define PLN_RMAX 1664                         // contexts per tile (at most; LDS)
 #endif
+#define PLN_HCAP 128                          // large-count items / contexts evaluated inside a tile (rest: global lists)
 #define PLN_QUAD 4                            // tiles start on multiples of 4 contexts (16-byte aligned rows)
 #define PLN_SENTINEL (PLN_RMAX * 5)           // flat offset of the neutral cell (prior = 1 / ref row = 0)
 #ifndef PLN_NBUF
 #define PLN_NBUF 2                            // LDS ring depth: tiles in flight = PLN_NBUF - 1
 #endif
-#define PLN_BLOCK_MAX (64 + PLN_RMAX + PLN_NI * 2)  // bytes of one tile's plan block: E | nrow | items
+// bytes of one tile's plan block: E | nrow | items | heavy column items (off, c) | heavy contexts (row, n)
+#define PLN_BLOCK_MAX (64 + PLN_RMAX + PLN_NI * 2 + PLN_HCAP * (2 + 4 + 2 + 8))
 
 struct pln_tile {
   uint64_t row0;
   uint32_t rows_items;  // rows << 16 | n_light
   uint32_t off16;       // start of the tile's block in the plan stream, 16-byte units
+  uint32_t hc_hr;       // in-tile large-count column items << 16 | in-tile large-total contexts
+  uint32_t blk16;       // size of the block in 16-byte units
+  uint64_t pad;
 };
-static_assert(sizeof(pln_tile) == 16, "tile descriptors are fetched with one s_load_dwordx4");
+static_assert(sizeof(pln_tile) == 32, "tile descriptors are fetched with one s_load_dwordx8");
+
+struct pln_layout {  // byte offsets inside a tile's block (all multiples of 16)
+  uint32_t nrow, items, hoff, hcnt, hrow, hn, end;
+};
+__host__ __device__ inline pln_layout pln_block_layout(uint32_t rows, uint32_t n_light, uint32_t hc, uint32_t hr) {
+  pln_layout L;
+  L.nrow = 64u;
+  L.items = L.nrow + ((rows + 15u) & ~15u);
+  L.hoff = L.items + (((n_light + 63u) & ~63u) * 2u);
+  L.hcnt = L.hoff + (((hc + 7u) & ~7u) * 2u);
+  L.hrow = L.hcnt + (((hc + 3u) & ~3u) * 4u);
+  L.hn = L.hrow + (((hr + 7u) & ~7u) * 2u);
+  L.end = L.hn + (((hr + 1u) & ~1u) * 8u);
+  return L;
+}
 
 struct pln_heavy_col {
   uint64_t off;  // flat offset row*5+b into the [N,5] arrays
@@ -60,17 +80,13 @@ struct pln_heavy_row {
   double n;  // exact row total (may exceed 2^32)
 };
 
-__host__ __device__ inline uint32_t pln_block_bytes(uint32_t rows, uint32_t n_light) {
-  return 64u + ((rows + 15u) & ~15u) + (((n_light + 63u) & ~63u) * 2u);
-}
-
 // ---------------------------------------------------------------------------------------------
 // plan construction
 // ---------------------------------------------------------------------------------------------
 // Pass A: number of product-path items per group of 4 contexts (uint8), global counts of heavy column
 // items / heavy contexts / heavy stop counts, histograms of row totals and stop counts <= SRT_CL.
 __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restrict__ counts, uint64_t n_rows, int ncol,
-                                                        uint8_t *__restrict__ quad_light,
+                                                        uint8_t *__restrict__ quad_light,  // [3][n_quads]: light, heavy cols, heavy rows
                                                         unsigned long long *__restrict__ heavy_counts,
                                                         unsigned long long *__restrict__ hist) {
   __shared__ uint32_t s_heavy[3];
@@ -80,7 +96,7 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
   __syncthreads();
   const uint64_t n_quads = (n_rows + PLN_QUAD - 1) / PLN_QUAD;
   for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < n_quads; g += (uint64_t)gridDim.x * 256) {
-    uint32_t light = 0;
+    uint32_t light = 0, qhc = 0, qhr = 0;
     for (uint64_t r = PLN_QUAD * g; r < PLN_QUAD * g + PLN_QUAD && r < n_rows; ++r) {
       uint32_t nsat = 0, hcol = 0;
 #pragma unroll
@@ -93,6 +109,8 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
           hcol += (c > SRT_CL);
         }
       }
+      qhc += hcol;
+      qhr += nsat > SRT_CL;
       if (hcol) atomicAdd(&s_heavy[0], hcol);
       if (nsat > SRT_CL) atomicAdd(&s_heavy[1], 1u);
       else if (nsat != 0) atomicAdd(&s_hist[nsat - 1], 1u);
@@ -101,6 +119,8 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
       else if (ncol == 4 && c4 != 0) atomicAdd(&s_hist[SRT_NKEY + c4 - 1], 1u);
     }
     quad_light[g] = (uint8_t)light;
+    quad_light[n_quads + g] = (uint8_t)qhc;
+    quad_light[2 * n_quads + g] = (uint8_t)qhr;
   }
   __syncthreads();
   if (threadIdx.x < 3 && s_heavy[threadIdx.x]) atomicAdd(&heavy_counts[threadIdx.x], (unsigned long long)s_heavy[threadIdx.x]);
@@ -122,15 +142,26 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
   __shared__ uint32_t offs[SRT_NHIST];
   __shared__ uint32_t scan[16];
   __shared__ uint16_t sorted[PLN_NI + 64];
+  __shared__ uint32_t s_hc, s_hr;
   const uint32_t tid = threadIdx.x, rep = tid & (SRT_REP - 1);
   for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const pln_tile ti = tiles[t];
     const uint32_t rows = ti.rows_items >> 16, n_light = ti.rows_items & 0xffffu;
+    const uint32_t hc_cap = ti.hc_hr >> 16, hr_cap = ti.hc_hr & 0xffffu;
+    const pln_layout L = pln_block_layout(rows, n_light, hc_cap, hr_cap);
     unsigned char *blk = stream + (size_t)ti.off16 * 16;
     uint16_t *E = reinterpret_cast<uint16_t *>(blk);
-    uint8_t *nrow = blk + 64;
-    uint16_t *items = reinterpret_cast<uint16_t *>(blk + 64 + ((rows + 15u) & ~15u));
+    uint8_t *nrow = blk + L.nrow;
+    uint16_t *items = reinterpret_cast<uint16_t *>(blk + L.items);
+    uint16_t *hoff = reinterpret_cast<uint16_t *>(blk + L.hoff);
+    uint32_t *hcnt = reinterpret_cast<uint32_t *>(blk + L.hcnt);
+    uint16_t *hrow = reinterpret_cast<uint16_t *>(blk + L.hrow);
+    double *hn = reinterpret_cast<double *>(blk + L.hn);
     if (tid < SRT_NHIST) hist[tid] = 0;
+    if (tid == 0) {
+      s_hc = 0;
+      s_hr = 0;
+    }
     __syncthreads();
     uint32_t c[RPT][5], rank[RPT][5];
 #pragma unroll
@@ -151,18 +182,30 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
         }
         nrow[lr] = (n >= 1.0 && n <= (double)SRT_CL) ? (uint8_t)n : (uint8_t)0;
         if (n > (double)SRT_CL) {
-          const unsigned long long q = atomicAdd(&cursors[1], 1ull);
-          heavy_row[q].row = r;
-          heavy_row[q].n = n;
+          const uint32_t k2 = hr_cap ? atomicAdd(&s_hr, 1u) : 0xffffffffu;
+          if (k2 < hr_cap) {  // evaluated inside the tile (prior row already in LDS)
+            hrow[k2] = (uint16_t)lr;
+            hn[k2] = n;
+          } else {
+            const unsigned long long q = atomicAdd(&cursors[1], 1ull);
+            heavy_row[q].row = r;
+            heavy_row[q].n = n;
+          }
         }
         if (ncol == 4 && c[k][4] > SRT_CL) heavy_stop[atomicAdd(&cursors[2], 1ull)] = c[k][4];
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
           if (b >= ncol) c[k][b] = 0;
           if (c[k][b] > SRT_CL) {
-            const unsigned long long q = atomicAdd(&cursors[0], 1ull);
-            heavy_col[q].off = r * 5 + b;
-            heavy_col[q].c = c[k][b];
+            const uint32_t k2 = hc_cap ? atomicAdd(&s_hc, 1u) : 0xffffffffu;
+            if (k2 < hc_cap) {
+              hoff[k2] = (uint16_t)(lr * 5 + b);
+              hcnt[k2] = c[k][b];
+            } else {
+              const unsigned long long q = atomicAdd(&cursors[0], 1ull);
+              heavy_col[q].off = r * 5 + b;
+              heavy_col[q].c = c[k][b];
+            }
             c[k][b] = 0;
           }
           if (c[k][b] != 0) rank[k][b] = atomicAdd(&hist[(c[k][b] - 1) * SRT_REP + rep], 1u);
@@ -188,8 +231,11 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
       if (tid < SRT_NHIST) offs[tid] = base + incl - v;
     }
     __syncthreads();
-    // thresholds: E[c] = number of items with count <= c (start of key c in the sorted order)
-    if (tid < 32) E[tid] = (uint16_t)(tid < SRT_CL ? offs[tid * SRT_REP] : n_light);
+    // thresholds: E[c] = number of items with count <= c (start of key c in the sorted order); the last
+    // two slots carry the in-tile heavy list lengths
+    if (tid < 30) E[tid] = (uint16_t)(tid < SRT_CL ? offs[tid * SRT_REP] : n_light);
+    if (tid == 30) E[30] = (uint16_t)hc_cap;
+    if (tid == 31) E[31] = (uint16_t)hr_cap;
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
 #pragma unroll
@@ -249,18 +295,23 @@ __device__ __forceinline__ void pln_wait_all_but(uint32_t younger) {
   }
 }
 
-// Scalar (s_load_dwordx4) fetch of a tile descriptor: a vector-memory load here would make the compiler
+// Scalar (s_load) fetch of a tile descriptor: a vector-memory load here would make the compiler
 // wait for vmcnt(0) at its first use -- and vmcnt is in order, so that wait would drain the DMA ring.
 __device__ __forceinline__ pln_tile pln_load_tile(const pln_view &pv, uint64_t t) {
   pln_tile ti;
   ti.row0 = 0;
   ti.rows_items = 0;
   ti.off16 = 0;
+  ti.hc_hr = 0;
+  ti.blk16 = 0;
+  ti.pad = 0;
   if (t < pv.n_tiles) {
     const __attribute__((address_space(4))) pln_tile *tc = (const __attribute__((address_space(4))) pln_tile *)(uintptr_t)pv.tiles;
     ti.row0 = tc[t].row0;
     ti.rows_items = tc[t].rows_items;
     ti.off16 = tc[t].off16;
+    ti.hc_hr = tc[t].hc_hr;
+    ti.blk16 = tc[t].blk16;
   }
   return ti;
 }
@@ -279,7 +330,7 @@ __device__ __forceinline__ uint32_t pln_unit_counts(const uint16_t *E, uint32_t 
                                                     uint32_t *cmin, uint32_t *cmax) {
   const uint32_t base = un * 64u, idx = base + lane;
   const uint32_t last = (base + 64u <= n_light ? base + 64u : n_light) - 1u;  // last occupied index (unit not empty)
-  const uint32_t e = lane < 32u ? (uint32_t)E[lane] : 0xffffffffu;
+  const uint32_t e = lane < 30u ? (uint32_t)E[lane] : 0xffffffffu;  // E[30], E[31]: heavy list lengths
   const uint32_t lo = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(e <= base));
   const uint32_t hi = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(e <= last));
   uint32_t c = lo;
@@ -330,7 +381,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
 
   // Streams tile `ti` into ring slot `b`; returns the number of DMA instructions this wave issued.
   auto stage = [&](const pln_tile &ti, uint32_t b) -> uint32_t {
-    const uint32_t rows = ti.rows_items >> 16, n_light = ti.rows_items & 0xffffu;
+    const uint32_t rows = ti.rows_items >> 16;
     if (rows == 0) return 0u;
     const uint32_t pbytes = rows * 40u;
     uint32_t k = pln_dma(S.buf[b].pri, prior + ti.row0 * 5, pbytes & ~15u, wave, lane, 0);
@@ -341,7 +392,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
       const double v = *tail;
       if (tid == 0) S.buf[b].pri[rows * 5 - 1] = v;
     }
-    k += pln_dma(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, pln_block_bytes(rows, n_light), wave, lane, (pbytes + 1023u) >> 10);
+    k += pln_dma(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, ti.blk16 * 16u, wave, lane, (pbytes + 1023u) >> 10);
     return k;
   };
 
@@ -376,18 +427,44 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
 
     const pln_buf_n &B = S.buf[slot];
     const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
+    const uint32_t hc = cur.hc_hr >> 16, hr = cur.hc_hr & 0xffffu;
+    const pln_layout L = pln_block_layout(rows, n_light, hc, hr);
     const uint16_t *E = reinterpret_cast<const uint16_t *>(B.blk);
-    const uint8_t *nrow = B.blk + 64;
-    const uint16_t *items = reinterpret_cast<const uint16_t *>(B.blk + 64 + ((rows + 15u) & ~15u));
+    const uint8_t *nrow = B.blk + L.nrow;
+    const uint16_t *items = reinterpret_cast<const uint16_t *>(B.blk + L.items);
     if (tid == 0) S.ticket[(slot + 1) % PLN_NBUF] = 0;  // next tile's counter (its last readers passed the barrier above)
-    // Work list of the tile, dearest first: item units from the sorted tail down (long loops), then the
-    // 64-context chunks of the context terms.  Waves draw tickets until the list is exhausted.
+    // Work list of the tile, dearest first: the large-count column items and contexts (Stirling path), the
+    // item units from the sorted tail down (long loops), then the 64-context chunks of the context terms.
+    // Waves draw tickets until the list is exhausted.
+    const uint32_t n_hcu = (hc + 63u) >> 6, n_hru = (hr + 63u) >> 6, n_heavy = n_hcu + n_hru;
     const uint32_t n_units = (n_light + 63u) >> 6;
-    const uint32_t n_work = n_units + (NORM ? 0u : (rows + 63u) >> 6);
+    const uint32_t n_work = n_heavy + n_units + (NORM ? 0u : (rows + 63u) >> 6);
     for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_work; w = pln_ticket(&S.ticket[slot], lane)) {
-      if (NORM || w < n_units) {
+      if (w < n_hcu) {  // large-count column items of this tile
+        const uint32_t i = w * 64u + lane;
+        if (i < hc) {
+          const uint32_t off = reinterpret_cast<const uint16_t *>(B.blk + L.hoff)[i];
+          const double x = __builtin_fma(B.pri[off], u, eps);
+          const bear_dp o = srt_general_fast(x, (double)reinterpret_cast<const uint32_t *>(B.blk + L.hcnt)[i], S.logtab);
+          acc[0] += o.D;
+          acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
+        }
+        continue;
+      }
+      if (w < n_heavy) {  // contexts of this tile with a large total
+        const uint32_t i = (w - n_hcu) * 64u + lane;
+        if (i < hr) {
+          const double *f = &B.pri[(uint32_t)reinterpret_cast<const uint16_t *>(B.blk + L.hrow)[i] * 5u];
+          const double A = NORM ? u + eps5 : __builtin_fma(((f[0] + f[1]) + (f[2] + f[3])) + f[4], u, eps5);
+          const bear_dp o = srt_general_fast(A, reinterpret_cast<const double *>(B.blk + L.hn)[i], S.logtab);
+          acc[0] -= o.D;
+          acc[1] = __builtin_fma(A - eps5, o.P, acc[1]);
+        }
+        continue;
+      }
+      if (NORM || w < n_heavy + n_units) {
         // ---- D: one unit of column items
-        const uint32_t un = n_units - 1u - w;
+        const uint32_t un = n_heavy + n_units - 1u - w;
         uint32_t cmin, cmax;
         const uint32_t ci[1] = {pln_unit_counts(E, n_light, un, lane, &cmin, &cmax)};
         const uint32_t off = items[un * 64u + lane];
@@ -399,7 +476,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
         continue;
       }
       // ---- A: context terms  -D(A, n), (A - 5 eps) P(A, n)   with A = S u + 5 eps
-      const uint32_t row = (w - n_units) * 64u + lane;
+      const uint32_t row = (w - n_heavy - n_units) * 64u + lane;
       const uint32_t rr = row < rows ? row : rows - 1;
       double f[5];
 #pragma unroll
@@ -497,7 +574,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
   if (tid < 4 * PLN_NBUF) S.buf[tid >> 2].ref[PLN_SENTINEL + (tid & 3)] = 0;  // neutral cell: reference row of zeros
 
   auto stage = [&](const pln_tile &ti, uint32_t b) -> uint32_t {
-    const uint32_t rows = ti.rows_items >> 16, n_light = ti.rows_items & 0xffffu;
+    const uint32_t rows = ti.rows_items >> 16;
     if (rows == 0) return 0u;
     const uint32_t rbytes = rows * 20u;
     uint32_t k = pln_dma(S.buf[b].ref, ref + ti.row0 * 5, rbytes & ~15u, wave, lane, 0);
@@ -512,7 +589,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
         if (nw > 2) S.buf[b].ref[w0 + 2] = v2;
       }
     }
-    k += pln_dma(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, pln_block_bytes(rows, n_light), wave, lane, (rbytes + 1023u) >> 10);
+    k += pln_dma(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, ti.blk16 * 16u, wave, lane, (rbytes + 1023u) >> 10);
     return k;
   };
   // bear_ref.py:30-33 (Jukes-Cantor on the L1-normalised reference row), :63-68 (mix), bear_ref.py:106
@@ -558,15 +635,29 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
 
     const pln_buf_r &B = S.buf[slot];
     const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
+    const uint32_t hc = cur.hc_hr >> 16;
+    const pln_layout L = pln_block_layout(rows, n_light, hc, cur.hc_hr & 0xffffu);
     const uint16_t *E = reinterpret_cast<const uint16_t *>(B.blk);
-    const uint16_t *items = reinterpret_cast<const uint16_t *>(B.blk + 64 + ((rows + 15u) & ~15u));
+    const uint16_t *items = reinterpret_cast<const uint16_t *>(B.blk + L.items);
     if (tid == 0) S.ticket[(slot + 1) % PLN_NBUF] = 0;
     // The context term (x = A) and the stop column (x = x4) have the same concentration in every
     // context: their sums over the table are the plan's histograms times two small tables (added
     // once, after the loop).  Per tile only the column items b < 4 remain; waves draw units, dearest first.
+    const uint32_t n_hcu = (hc + 63u) >> 6;
     const uint32_t n_units = (n_light + 63u) >> 6;
-    for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_units; w = pln_ticket(&S.ticket[slot], lane)) {
-      const uint32_t un = n_units - 1u - w;
+    for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_hcu + n_units; w = pln_ticket(&S.ticket[slot], lane)) {
+      if (w < n_hcu) {  // large-count column items of this tile (Stirling path), first
+        const uint32_t i = w * 64u + lane;
+        if (i < hc) {
+          const uint32_t off = reinterpret_cast<const uint16_t *>(B.blk + L.hoff)[i];
+          const uint32_t *rr = &B.ref[((off * 52429u) >> 18) * 5u];
+          const double R = (double)(((uint64_t)rr[0] + rr[1]) + ((uint64_t)rr[2] + rr[3])) + 4.0 * eps;
+          const double x = alpha_from((double)B.ref[off], R);
+          accumulate(x, srt_general_fast(x, (double)reinterpret_cast<const uint32_t *>(B.blk + L.hcnt)[i], S.logtab));
+        }
+        continue;
+      }
+      const uint32_t un = n_hcu + n_units - 1u - w;
       uint32_t cmin, cmax;
       const uint32_t ci[1] = {pln_unit_counts(E, n_light, un, lane, &cmin, &cmax)};
       const uint32_t off = items[un * 64u + lane];
