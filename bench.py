@@ -150,7 +150,10 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(primary, {}).get("bytes_per_launch")
+                ent = tj.get(primary, {})
+                traffic = ent.get("bytes_per_launch")
+                if traffic is not None:  # measured at ent["contexts_per_launch"]; traffic is linear in the shard size
+                    traffic = traffic * n / float(ent.get("contexts_per_launch", n))
             except Exception:
                 traffic = None
         line = {

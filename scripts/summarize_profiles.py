@@ -42,6 +42,7 @@ for kind in ("fetch", "write", "sq"):
     out_md.append("")
 for name, d in traffic.items():
     d["bytes_per_launch"] = d.get("fetch_bytes_per_launch", 0) + d.get("write_bytes_per_launch", 0)
+    d["contexts_per_launch"] = 100000000  # bench.py default (--contexts 1e8); bench.py scales linearly for other sizes
 if traffic:
     json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
