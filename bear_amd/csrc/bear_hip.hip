@@ -171,14 +171,14 @@ int bear_dm_prior_f64(bear_ws *ws, const uint32_t *counts, const double *prior, 
       hipLaunchKernelGGL(dm_prior_sorted_kernel<0>, dim3(grid), dim3(SRT_THREADS), sizeof(srt_lds_n), s, counts, prior, n_rows, prm, lt, ws->partials, ws->dbg);
   } else if (train_ar) {
     if (grad_prior)
-      hipLaunchKernelGGL((dm_prior_kernel<true, true>), dim3(grid), dim3(BEAR_THREADS), 0, s, counts, prior, n_rows, prm, grad_prior, ws->partials);
+      hipLaunchKernelGGL((dm_prior_kernel<true, true>), dim3(grid), dim3(BEAR_THREADS), 0, s, counts, prior, n_rows, prm, grad_prior, reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
     else
-      hipLaunchKernelGGL((dm_prior_kernel<true, false>), dim3(grid), dim3(BEAR_THREADS), 0, s, counts, prior, n_rows, prm, grad_prior, ws->partials);
+      hipLaunchKernelGGL((dm_prior_kernel<true, false>), dim3(grid), dim3(BEAR_THREADS), 0, s, counts, prior, n_rows, prm, grad_prior, reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
   } else {
     if (grad_prior)
-      hipLaunchKernelGGL((dm_prior_kernel<false, true>), dim3(grid), dim3(BEAR_THREADS), 0, s, counts, prior, n_rows, prm, grad_prior, ws->partials);
+      hipLaunchKernelGGL((dm_prior_kernel<false, true>), dim3(grid), dim3(BEAR_THREADS), 0, s, counts, prior, n_rows, prm, grad_prior, reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
     else
-      hipLaunchKernelGGL((dm_prior_kernel<false, false>), dim3(grid), dim3(BEAR_THREADS), 0, s, counts, prior, n_rows, prm, grad_prior, ws->partials);
+      hipLaunchKernelGGL((dm_prior_kernel<false, false>), dim3(grid), dim3(BEAR_THREADS), 0, s, counts, prior, n_rows, prm, grad_prior, reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
   }
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
@@ -205,9 +205,9 @@ int bear_dm_ref_f64(bear_ws *ws, const uint32_t *train, const uint32_t *ref, uin
   prm.nw = nw;
   int grid = grid_for(ws, n_rows);
   if (train_ar) {
-    hipLaunchKernelGGL((dm_ref_kernel<true>), dim3(grid), dim3(BEAR_THREADS), 0, s, train, ref, n_rows, prm, ws->partials);
+    hipLaunchKernelGGL((dm_ref_kernel<true>), dim3(grid), dim3(BEAR_THREADS), 0, s, train, ref, n_rows, prm, reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
   } else if (getenv("BEAR_ROWS_KERNEL")) {  // developer switch: v1 row-per-thread kernel (A/B measurements)
-    hipLaunchKernelGGL((dm_ref_kernel<false>), dim3(grid), dim3(BEAR_THREADS), 0, s, train, ref, n_rows, prm, ws->partials);
+    hipLaunchKernelGGL((dm_ref_kernel<false>), dim3(grid), dim3(BEAR_THREADS), 0, s, train, ref, n_rows, prm, reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
   } else {
     grid = grid_sorted(ws, n_rows);
     hipLaunchKernelGGL(dm_ref_sorted_kernel, dim3(grid), dim3(SRT_THREADS), sizeof(srt_lds_r), s, train, ref, n_rows, prm,

@@ -49,9 +49,12 @@ __global__ __launch_bounds__(BEAR_THREADS) void dm_prior_kernel(const uint32_t *
                                                                  const double *__restrict__ prior,
                                                                  uint64_t n_rows, bear_params prm,
                                                                  double *__restrict__ grad_prior,
+                                                                 const double2 *__restrict__ logtab_g,
                                                                  double *__restrict__ partials) {
   __shared__ __attribute__((aligned(16))) uint32_t s_cnt[BEAR_TILE_ROWS * 5];
   __shared__ __attribute__((aligned(16))) double s_pri[BEAR_TILE_ROWS * 5];
+  __shared__ double2 s_log[BEAR_LOGTAB_N];
+  if (threadIdx.x < BEAR_LOGTAB_N) s_log[threadIdx.x] = logtab_g[threadIdx.x];
   const uint64_t n_tiles = (n_rows + BEAR_TILE_ROWS - 1) / BEAR_TILE_ROWS;
   double acc[2] = {0.0, 0.0};
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(BEAR_THREADS) void dm_prior_kernel(const uint32_t *
         for (int b = 0; b < 5; ++b) {
           double p = f[b] + prm.eps;
           double cb = (double)c[b];
-          if (c[b] != 0) acc[0] += cb * bear_log(p);
+          if (c[b] != 0) acc[0] += cb * (p > 0.0 ? bear_log_tab(p, s_log) : bear_log(p));
           if (GRAD) grad_prior[(row0 + r) * 5 + b] = c[b] != 0 ? cb * bear_rcp(p) : 0.0;
         }
       } else {
@@ -105,7 +108,10 @@ template <bool AR>
 __global__ __launch_bounds__(BEAR_THREADS) void dm_ref_kernel(const uint32_t *__restrict__ train,
                                                                const uint32_t *__restrict__ ref,
                                                                uint64_t n_rows, bear_params prm,
+                                                               const double2 *__restrict__ logtab_g,
                                                                double *__restrict__ partials) {
+  __shared__ double2 s_log[BEAR_LOGTAB_N];
+  if (threadIdx.x < BEAR_LOGTAB_N) s_log[threadIdx.x] = logtab_g[threadIdx.x];
   __shared__ __attribute__((aligned(16))) uint32_t s_trn[BEAR_TILE_ROWS * 5];
   __shared__ __attribute__((aligned(16))) uint32_t s_ref[BEAR_TILE_ROWS * 5];
   const uint64_t n_tiles = (n_rows + BEAR_TILE_ROWS - 1) / BEAR_TILE_ROWS;
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(BEAR_THREADS) void dm_ref_kernel(const uint32_t *__
           double cb = (double)c[b];
           dLdf[b] = 0.0;
           if (c[b] != 0) {
-            acc[0] += cb * bear_log(p);
+            acc[0] += cb * (p > 0.0 ? bear_log_tab(p, s_log) : bear_log(p));
             dLdf[b] = cb * bear_rcp(p);
           }
         }

@@ -153,3 +153,19 @@ def bmm_likelihood(data, alpha, dtype=torch.float64, device=None):
             res, _ = kernels.dm_prior(data.device_column(d, device), prior, 0.0, eps=0.0)
             out[d, j] = res[0].item()
     return out.to(dtype)
+
+
+def write_counts_tsv(path, kmers, counts):
+    """Writes a dense count table in the summarize.py row format (summarize.py:429-449):
+    ``kmer \\t [[g0 A,C,G,T,$],[g1 ...],...]``.  kmers: sequence of str/bytes or uint8 [N, lag];
+    counts: integer array [num_ds, N, 5] (planar, as CountDataset.counts) or [N, num_ds, 5]."""
+    counts = np.asarray(counts)
+    if isinstance(kmers, np.ndarray) and kmers.dtype == np.uint8:
+        kmers = [bytes(r).decode() for r in kmers]
+    else:
+        kmers = [k.decode() if isinstance(k, bytes) else str(k) for k in kmers]
+    if counts.shape[0] != len(kmers):
+        counts = counts.transpose(1, 0, 2)
+    with open(path, "w") as fh:
+        for k, rows in zip(kmers, counts):
+            fh.write(k + "\t[[" + "],[".join(",".join(str(int(v)) for v in g) for g in rows) + "]]\n")

@@ -92,6 +92,8 @@ int bear_dm_ref_f64(bear_ws *ws, const uint32_t *train, const uint32_t *ref, uin
  * A plan holds what depends on the counts only -- per 512-context tile the (context, column) work
  * items sorted by count, as uint16 offsets, plus global lists of the rare large-count items -- so
  * the per-step kernels do no sorting.  Results are identical to the unplanned entry points.
+ *   The plan is a lossless sorted sparse encoding of the counts: the planned step kernels read it INSTEAD of the
+ *   count rows (the `counts` / `train` arguments of the planned entries only identify the table).
  *   bear_plan_create: synchronous; `ncol` = 5 for bear_dm_prior_plan_f64 (all columns are items),
  *     4 for bear_dm_ref_plan_f64 (the stop column has a context-independent concentration).
  *     The plan is valid for exactly the buffer contents it was built from; rebuild after any change.

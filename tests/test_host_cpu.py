@@ -113,3 +113,18 @@ def test_training_needs_a_device():
         pytest.skip("a device is present")
     with pytest.raises(RuntimeError):
         _train.require_device()
+
+
+def test_count_table_writer_round_trip(tmp_path):
+    """summarize.py row format (summarize.py:429-449): the writer's output is byte-identical to the bundled
+    table and parses back to the same arrays."""
+    data = dataloader.dataloader(YSD1, "dna", 100, 3)
+    out = tmp_path / "copy.tsv"
+    dataloader.write_counts_tsv(out, data.kmers, data.counts)
+    assert open(out, "rb").read() == open(YSD1, "rb").read()
+    back = dataloader.dataloader(str(out), "dna", 100, 3)
+    assert np.array_equal(back.counts, data.counts) and np.array_equal(back.kmers, data.kmers)
+    rng = np.random.default_rng(0)
+    c = rng.integers(0, 4_000_000_000, size=(2, 7, 5), dtype=np.uint64).astype(np.uint32)
+    dataloader.write_counts_tsv(tmp_path / "r.tsv", ["[[ACG"] * 7, c)
+    assert np.array_equal(dataloader.dataloader(str(tmp_path / "r.tsv"), "dna", 3, 2).counts, c)
