@@ -82,6 +82,12 @@ int bear_ws_create(int device, bear_ws **out) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
       if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_g));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_g));
+      if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
       if (e == hipSuccess)
@@ -420,6 +426,44 @@ int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *c
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
   HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
+                                uint64_t n_rows, double h_signed, double eps, int prior_normalized, double *out,
+                                double *grad_prior, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!plan || !out || !grad_prior || (n_rows && (!counts || !prior))) return BEAR_ERR_INVALID_ARG;
+  if (plan->ncol != 5 || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
+    return BEAR_ERR_INVALID_ARG;
+  if (misaligned(prior) || misaligned(grad_prior) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bear_params prm;
+  memset(&prm, 0, sizeof(prm));
+  prm.inv_h = 1.0 / exp(h_signed);
+  prm.eps = eps;
+  const int grid = grid_plan(ws, plan->n_tiles);
+  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  const pln_view pv = plan_view(plan);
+  if (prior_normalized)
+    hipLaunchKernelGGL(dm_prior_plan_grad_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
+                       grad_prior, ws->partials);
+  else
+    hipLaunchKernelGGL(dm_prior_plan_grad_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
+                       grad_prior, ws->partials);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
+  HIP_TRY(hipGetLastError());
+  if (pv.n_heavy_col + pv.n_heavy_row) {
+    const uint64_t nh = pv.n_heavy_col + pv.n_heavy_row;
+    const int g2 = (int)((nh + 255) / 256 < (uint64_t)ws->num_cu * 4 ? (nh + 255) / 256 : (uint64_t)ws->num_cu * 4);
+    if (prior_normalized)
+      hipLaunchKernelGGL(dm_prior_grad_fixup_kernel<true>, dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior);
+    else
+      hipLaunchKernelGGL(dm_prior_grad_fixup_kernel<false>, dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior);
+    HIP_TRY(hipGetLastError());
+  }
   return BEAR_OK;
 }
 

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
           c[k][b] = counts[r * 5 + b];
           n += (double)c[k][b];
         }
-        nrow[lr] = (n >= 1.0 && n <= (double)SRT_CL) ? (uint8_t)n : (uint8_t)0;
+        nrow[lr] = n < 1.0 ? (uint8_t)0 : (n <= (double)SRT_CL ? (uint8_t)n : (uint8_t)255);  // 255: large total
         if (n > (double)SRT_CL) {
           const uint32_t k2 = hr_cap ? atomicAdd(&s_hr, 1u) : 0xffffffffu;
           if (k2 < hr_cap) {  // evaluated inside the tile (prior row already in LDS)
@@ -482,7 +482,8 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
 #pragma unroll
       for (int b = 0; b < 5; ++b) f[b] = B.pri[rr * 5 + b];
       const double S5 = ((f[0] + f[1]) + (f[2] + f[3])) + f[4];
-      const uint32_t n = row < rows ? (uint32_t)nrow[rr] : 0u;  // 0: empty context, or a total beyond SRT_CL (heavy list)
+      uint32_t n = row < rows ? (uint32_t)nrow[rr] : 0u;  // 0: empty context; 255: total beyond SRT_CL (heavy lists)
+      if (n == 255u) n = 0u;
       const bool shared = __builtin_fabs(S5 - 1.0) <= SRT_SUM1_TOL;
       if (n != 0 && shared) {
         acc[0] -= S.tabD[n - 1];
@@ -702,4 +703,188 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
   }
   __syncthreads();
   block_store_partials<4>(acc, partials);
+}
+
+// ---- mode N with gradient rows --------------------------------------------------------------
+// d sum LL / d prior_ib = u (P_ib - P_n,i)  (bear_net.py:193: what the tape hands back to ar_func).  The rows
+// are assembled in LDS next to the prior tile -- context chunks write the base -u P_n into all five cells, the
+// item units add u P_b into their own cell (every cell belongs to at most one item) -- and leave as one
+// coalesced stream of 16-byte lane stores.  No prefetch here: with 40 B written per context on top of the 44 B
+// read the kernel is bound by HBM traffic either way.  Items that overflowed to the plan's global lists are
+// applied by dm_prior_grad_fixup_kernel (stream-ordered after this kernel).
+struct pln_lds_g {
+  double pri[PLN_RMAX * 5 + 2];
+  double grad[PLN_RMAX * 5 + 2];
+  __attribute__((aligned(16))) unsigned char blk[PLN_BLOCK_MAX];
+  double2 logtab[BEAR_LOGTAB_N];
+  double tabD[SRT_NKEY];
+  double tabP[SRT_NKEY];
+  uint32_t ticket;
+};
+
+template <bool NORM>
+__global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad_kernel(const double *__restrict__ prior,
+                                                                                         bear_params prm, pln_view pv,
+                                                                                         const double2 *__restrict__ logtab_g,
+                                                                                         double *__restrict__ grad_out,
+                                                                                         double *__restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
+  pln_lds_g &S = *reinterpret_cast<pln_lds_g *>(srt_smem);
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
+  const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
+  double acc[2] = {0.0, 0.0};
+  if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
+  if (tid < SRT_NKEY) {
+    const bear_dp o = srt_general_fast(u + eps5, (double)(tid + 1), logtab_g);
+    S.tabD[tid] = o.D;
+    S.tabP[tid] = o.P;
+  }
+  if (tid == 0) {
+    S.pri[PLN_SENTINEL] = 1.0;
+    S.ticket = 0;
+  }
+  for (uint64_t t = blockIdx.x; t < pv.n_tiles; t += gridDim.x) {
+    const pln_tile cur = pln_load_tile(pv, t);
+    const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
+    const uint32_t hc = cur.hc_hr >> 16, hr = cur.hc_hr & 0xffffu;
+    const pln_layout L = pln_block_layout(rows, n_light, hc, hr);
+    __syncthreads();  // previous tile written out (plain stores: vmcnt(0) inside __syncthreads is what we want here)
+    {
+      const uint32_t pbytes = rows * 40u;
+      pln_dma(S.pri, prior + cur.row0 * 5, pbytes & ~15u, wave, lane, 0);
+      if (pbytes & 15u) {
+        const __attribute__((address_space(4))) double *tail =
+            (const __attribute__((address_space(4))) double *)(uintptr_t)(prior + (cur.row0 + rows) * 5 - 1);
+        const double v = *tail;
+        if (tid == 0) S.pri[rows * 5 - 1] = v;
+      }
+      pln_dma(S.blk, pv.stream + (size_t)cur.off16 * 16, cur.blk16 * 16u, wave, lane, (pbytes + 1023u) >> 10);
+    }
+    if (tid == 0) S.ticket = 0;
+    srt_wait_dma();
+    srt_sync();
+    const uint16_t *E = reinterpret_cast<const uint16_t *>(S.blk);
+    const uint8_t *nrow = S.blk + L.nrow;
+    const uint16_t *items = reinterpret_cast<const uint16_t *>(S.blk + L.items);
+    // ---- 1: context chunks: context terms and the base -u P_n of all five cells
+    for (uint32_t row = tid; row < rows; row += PLN_THREADS) {
+      double f[5];
+#pragma unroll
+      for (int b = 0; b < 5; ++b) f[b] = S.pri[row * 5 + b];
+      const double S5 = ((f[0] + f[1]) + (f[2] + f[3])) + f[4];
+      uint32_t n = nrow[row];
+      if (n == 255u) n = 0u;  // large totals: step 2 / fix-up kernel
+      const bool shared = NORM || __builtin_fabs(S5 - 1.0) <= SRT_SUM1_TOL;
+      double Pn = 0.0;
+      if (n != 0 && shared) {
+        Pn = S.tabP[n - 1];
+        acc[0] -= S.tabD[n - 1];
+        acc[1] = __builtin_fma(u, Pn, acc[1]);
+      }
+      if (n != 0 && !shared) {  // own A: rare (general concentrations), evaluated lane by lane
+        const double A = __builtin_fma(S5, u, eps5);
+        const bear_dp o = srt_general_fast(A, (double)n, S.logtab);
+        Pn = o.P;
+        acc[0] -= o.D;
+        acc[1] = __builtin_fma(A - eps5, o.P, acc[1]);
+      }
+      const double base = -u * Pn;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) S.grad[row * 5 + b] = base;
+    }
+    srt_sync();
+    // ---- 2: contexts of this tile with a large total overwrite their base
+    for (uint32_t i = tid; i < hr; i += PLN_THREADS) {
+      const uint32_t row = reinterpret_cast<const uint16_t *>(S.blk + L.hrow)[i];
+      const double *f = &S.pri[row * 5u];
+      const double A = NORM ? u + eps5 : __builtin_fma(((f[0] + f[1]) + (f[2] + f[3])) + f[4], u, eps5);
+      const bear_dp o = srt_general_fast(A, reinterpret_cast<const double *>(S.blk + L.hn)[i], S.logtab);
+      acc[0] -= o.D;
+      acc[1] = __builtin_fma(A - eps5, o.P, acc[1]);
+#pragma unroll
+      for (int b = 0; b < 5; ++b) S.grad[row * 5 + b] = -u * o.P;
+    }
+    srt_sync();
+    // ---- 3: item units (tickets, dearest first): ELBO, d/dh, and u P_b into the item's own cell
+    const uint32_t n_hcu = (hc + 63u) >> 6, n_units = (n_light + 63u) >> 6;
+    for (uint32_t w = pln_ticket(&S.ticket, lane); w < n_hcu + n_units; w = pln_ticket(&S.ticket, lane)) {
+      if (w < n_hcu) {
+        const uint32_t i = w * 64u + lane;
+        if (i < hc) {
+          const uint32_t off = reinterpret_cast<const uint16_t *>(S.blk + L.hoff)[i];
+          const double x = __builtin_fma(S.pri[off], u, eps);
+          const bear_dp o = srt_general_fast(x, (double)reinterpret_cast<const uint32_t *>(S.blk + L.hcnt)[i], S.logtab);
+          acc[0] += o.D;
+          acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
+          S.grad[off] = __builtin_fma(u, o.P, S.grad[off]);
+        }
+        continue;
+      }
+      const uint32_t un = n_hcu + n_units - 1u - w;
+      uint32_t cmin, cmax;
+      const uint32_t ci[1] = {pln_unit_counts(E, n_light, un, lane, &cmin, &cmax)};
+      const uint32_t off = items[un * 64u + lane];
+      const double x[1] = {__builtin_fma(S.pri[off], u, eps)};
+      bear_dp o[1];
+      srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
+      acc[0] += o[0].D;
+      acc[1] = __builtin_fma(eps - x[0], o[0].P, acc[1]);
+      if (ci[0] != 0) S.grad[off] = __builtin_fma(u, o[0].P, S.grad[off]);
+    }
+    __syncthreads();
+    // ---- 4: the tile's gradient rows leave as one coalesced stream
+    {
+      const uint32_t n_dw = rows * 10u;  // dwords
+      const uint4 *src = reinterpret_cast<const uint4 *>(S.grad);
+      uint4 *dst = reinterpret_cast<uint4 *>(grad_out + cur.row0 * 5);
+      for (uint32_t i = tid; i < (n_dw >> 2); i += PLN_THREADS) dst[i] = src[i];
+      if ((n_dw & 3u) && tid == 0) grad_out[(cur.row0 + rows) * 5 - 1] = S.grad[rows * 5 - 1];  // odd row count
+    }
+  }
+  // ---- ELBO / d/dh of the items that overflowed to the global lists (their gradient cells: fix-up kernel)
+  __syncthreads();
+  const uint64_t gtid = (uint64_t)blockIdx.x * PLN_THREADS + tid, gsz = (uint64_t)gridDim.x * PLN_THREADS;
+  for (uint64_t i = gtid; i < pv.n_heavy_col; i += gsz) {
+    const pln_heavy_col h = pv.heavy_col[i];
+    const double x = __builtin_fma(prior[h.off], u, eps);
+    const bear_dp o = srt_general_fast(x, (double)h.c, S.logtab);
+    acc[0] += o.D;
+    acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
+  }
+  for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
+    const pln_heavy_row h = pv.heavy_row[i];
+    const double *f = prior + h.row * 5;
+    const double A = NORM ? u + eps5 : __builtin_fma(((f[0] + f[1]) + (f[2] + f[3])) + f[4], u, eps5);
+    const bear_dp o = srt_general_fast(A, h.n, S.logtab);
+    acc[0] -= o.D;
+    acc[1] = __builtin_fma(A - eps5, o.P, acc[1]);
+  }
+  __syncthreads();
+  block_store_partials<2>(acc, partials);
+}
+
+// Gradient cells of the items in the plan's global overflow lists (very dense tiles only).  A cell can be hit by
+// a column item and by its context, hence the fp64 atomics (rare path).
+template <bool NORM>
+__global__ __launch_bounds__(256) void dm_prior_grad_fixup_kernel(const double *__restrict__ prior, bear_params prm, pln_view pv,
+                                                                   const double2 *__restrict__ logtab_g,
+                                                                   double *__restrict__ grad_out) {
+  __shared__ double2 logtab[BEAR_LOGTAB_N];
+  if (threadIdx.x < BEAR_LOGTAB_N) logtab[threadIdx.x] = logtab_g[threadIdx.x];
+  __syncthreads();
+  const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
+  const uint64_t gtid = (uint64_t)blockIdx.x * 256 + threadIdx.x, gsz = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = gtid; i < pv.n_heavy_col; i += gsz) {
+    const pln_heavy_col h = pv.heavy_col[i];
+    const double x = __builtin_fma(prior[h.off], u, eps);
+    const bear_dp o = srt_general_fast(x, (double)h.c, logtab);
+    atomicAdd(&grad_out[h.off], u * o.P);
+  }
+  for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
+    const pln_heavy_row h = pv.heavy_row[i];
+    const double *f = prior + h.row * 5;
+    const double A = NORM ? u + eps5 : __builtin_fma(((f[0] + f[1]) + (f[2] + f[3])) + f[4], u, eps5);
+    const bear_dp o = srt_general_fast(A, h.n, logtab);
+    for (int b = 0; b < 5; ++b) atomicAdd(&grad_out[h.row * 5 + b], -u * o.P);
+  }
 }

@@ -133,15 +133,24 @@ class Plan:
                 pass
 
 
-def dm_prior_planned(plan, prior, h_signed, eps=EPSILON, out=None, normalized=False):
-    """Planned twin of dm_prior (BEAR mode, no gradient rows): [sum LL, d/dh_signed].
-    normalized=True asserts that every prior row sums to one (any softmax output)."""
+def dm_prior_planned(plan, prior, h_signed, eps=EPSILON, out=None, normalized=False, want_grad=False):
+    """Planned twin of dm_prior (BEAR mode): [sum LL, d/dh_signed]; with want_grad also the gradient rows
+    d sum LL / d prior, returned as (out, grad).  normalized=True asserts that every prior row sums to one
+    (any softmax output)."""
     counts = plan.counts
     _check_rows(prior, torch.float64, "prior")
     if prior.data_ptr() % 16 or prior.shape[0] != counts.shape[0] or plan.ncol != 5:
         raise ValueError("prior must be 16-byte aligned with one row per planned context (plan ncol=5)")
     if out is None:
         out = torch.empty(2, dtype=torch.float64, device=counts.device)
+    if want_grad:
+        grad = torch.empty_like(prior)
+        with torch.cuda.device(counts.device):
+            st = _lib.lib().bear_dm_prior_plan_grad_f64(plan.ws.handle, plan._h, _ptr(counts), _ptr(prior), counts.shape[0],
+                                                        float(h_signed), float(eps), int(bool(normalized)), _ptr(out),
+                                                        _ptr(grad), _stream())
+        _lib.check(st, "bear_dm_prior_plan_grad_f64")
+        return out, grad
     with torch.cuda.device(counts.device):
         st = _lib.lib().bear_dm_prior_plan_f64(plan.ws.handle, plan._h, _ptr(counts), _ptr(prior), counts.shape[0],
                                                float(h_signed), float(eps), int(bool(normalized)), _ptr(out), _stream())

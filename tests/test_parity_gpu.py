@@ -256,6 +256,13 @@ def test_planned_kernels_parity(case, dev, ysd1):
         got = kernels.dm_prior_planned(plan_n, _to_dev(f, dev), h_s).cpu().numpy()
         _close(got[0], want[0], ELBO_RTOL)
         _close(got[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
+        wantg = co.dm_prior(tr, f, h_s, want_grad=True, nthreads=4)[1]
+        for norm in ([False, True] if seed != 3 else [False]):   # planned kernel that also writes the gradient rows
+            got, g = kernels.dm_prior_planned(plan_n, _to_dev(f, dev), h_s, normalized=norm, want_grad=True)
+            got, g = got.cpu().numpy(), g.cpu().numpy()
+            _close(got[0], want[0], ELBO_RTOL)
+            _close(got[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
+            assert np.allclose(g, wantg, rtol=1e-9, atol=1e-9 * np.abs(wantg).max()), (case, seed, np.abs(g - wantg).max())
         if seed != 3:  # rows sum to one: the caller may assert it (context terms from the plan's histogram)
             got = kernels.dm_prior_planned(plan_n, _to_dev(f, dev), h_s, normalized=True).cpu().numpy()
             _close(got[0], want[0], ELBO_RTOL)
