@@ -296,3 +296,46 @@ def test_planned_full_size_chunks(dev):
         pn2 = kernels.Plan(other, 5)
         pn2.counts = t["train"]  # wrong buffer for this plan
         kernels.dm_prior_planned(pn2, f, 0.0)
+
+
+def test_planned_randomized_shapes(dev):
+    """Randomized tables (sizes around the tile / unit boundaries; sparse, dense, mostly-empty, mixed and
+    single-column tables; normalised and un-normalised prior rows): planned kernels == oracle."""
+    from bear_amd import kernels
+    rng = np.random.default_rng(2024)
+    for it in range(24):
+        n = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 1663, 1664, 1665, 4096, 10007, 50021]))
+        kind = it % 5
+        if kind == 0:
+            tr, _, rf = sparse_table(n, int(rng.integers(1e9)), lam_scale=float(rng.choice([0.05, 0.3, 1, 4, 20])))
+        elif kind == 1:
+            tr, rf = dense_table(n, int(rng.integers(1e9)))
+        elif kind == 2:
+            tr, _, rf = sparse_table(n, int(rng.integers(1e9)))
+            tr[rng.random(n) < 0.5] = 0
+        elif kind == 3:
+            tr, _, rf = sparse_table(n, int(rng.integers(1e9)))
+            d, _ = dense_table(n, 7)
+            m = rng.random(n) < 0.1
+            tr[m] = d[m]
+        else:
+            tr, rf = np.zeros((n, 5), np.uint32), np.zeros((n, 5), np.uint32)
+            tr[:, int(rng.integers(5))] = rng.integers(0, 60, n)
+        f = prior_rows(n, int(rng.integers(1e9)), float(rng.choice([0.2, 1, 5])))
+        if it % 3 == 0:
+            f = f * rng.uniform(0.5, 2.0, size=(n, 1))
+        h = float(rng.uniform(-4, 3))
+        args = (h, float(rng.uniform(-5, 1)), float(rng.uniform(-6, 1)))
+        d_tr, d_rf, d_f = _to_dev(tr, dev), _to_dev(rf, dev), _to_dev(f, dev)
+        wr = co.dm_ref(tr, rf, *args, nthreads=4)
+        wn, wg = co.dm_prior(tr, f, h, want_grad=True, nthreads=4)
+        gr = kernels.dm_ref_planned(kernels.Plan(d_tr, 4), d_rf, *args).cpu().numpy()
+        pn = kernels.Plan(d_tr, 5)
+        gn = kernels.dm_prior_planned(pn, d_f, h).cpu().numpy()
+        gg, g = kernels.dm_prior_planned(pn, d_f, h, want_grad=True)
+        assert abs(gr[0] - wr[0]) <= ELBO_RTOL * abs(wr[0]) + 1e-300, (it, n, kind)
+        assert np.all(np.abs(gr[1:] - wr[1:]) <= GRAD_RTOL * (np.abs(wr[1:]).max() + abs(wr[0]) * 1e-3 + 1e-300)), (it, n, kind)
+        for got in (gn, gg.cpu().numpy()):
+            assert abs(got[0] - wn[0]) <= ELBO_RTOL * abs(wn[0]) + 1e-300, (it, n, kind)
+            assert abs(got[1] - wn[1]) <= GRAD_RTOL * (abs(wn[1]) + abs(wn[0]) * 1e-3 + 1e-300), (it, n, kind)
+        assert np.allclose(g.cpu().numpy(), wg, rtol=1e-9, atol=1e-9 * (np.abs(wg).max() + 1e-300)), (it, n, kind)
