@@ -56,9 +56,9 @@ def _load():
     L.bear_plan_destroy.argtypes = [vp]
     L.bear_plan_bytes.argtypes = [vp]
     L.bear_plan_bytes.restype = u64
-    L.bear_dm_prior_plan_f64.argtypes = [vp, vp, vp, vp, u64, dbl, dbl, cint, vp, vp]
-    L.bear_dm_prior_plan_grad_f64.argtypes = [vp, vp, vp, vp, u64, dbl, dbl, cint, vp, vp, vp]
-    L.bear_dm_ref_plan_f64.argtypes = [vp, vp, vp, vp, u64, dbl, dbl, dbl, dbl, vp, vp]
+    L.bear_dm_prior_plan_f64.argtypes = [vp, vp, vp, vp, u64, dbl, dbl, cint, cint, vp, vp]
+    L.bear_dm_prior_plan_grad_f64.argtypes = [vp, vp, vp, vp, u64, dbl, dbl, cint, cint, vp, vp, vp]
+    L.bear_dm_ref_plan_f64.argtypes = [vp, vp, vp, vp, u64, dbl, dbl, dbl, dbl, cint, vp, vp]
     L.bear_dm_items_f64.argtypes = [vp, vp, vp, u64, cint, vp, vp, vp]
     L.bear_synth_counts_u32.argtypes = [u64, u64, u64, cint, vp, vp, vp, vp]
     L.bear_synth_prior_f64.argtypes = [u64, u64, u64, vp, vp]

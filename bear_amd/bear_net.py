@@ -58,14 +58,12 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
             if e["rows"]:
                 prior = ar_func(e["codes"]).expand(e["rows"], alphabet_size + 1).contiguous()
                 need_rows = prior.requires_grad
-                if train_ar:
-                    _, grad_rows = kernels.dm_prior(e["train"], prior.detach(), h_signed.item(), train_ar=True,
-                                                    want_grad=need_rows, out=out)
-                elif need_rows:   # planned kernel, gradient rows assembled in LDS
+                if need_rows:     # planned kernel, gradient rows assembled in LDS
                     _, grad_rows = kernels.dm_prior_planned(res.plan(k, "train", 5), prior.detach(), h_signed.item(), out=out,
-                                                            want_grad=True)
+                                                            want_grad=True, train_ar=train_ar)
                 else:             # parameter-free AR function (stop): nothing to feed back
-                    kernels.dm_prior_planned(res.plan(k, "train", 5), prior.detach(), h_signed.item(), out=out)
+                    kernels.dm_prior_planned(res.plan(k, "train", 5), prior.detach(), h_signed.item(), out=out,
+                                             train_ar=train_ar)
                     grad_rows = None
                 if need_rows:
                     prior.backward(scale * grad_rows)                  # d loss / d AR parameters

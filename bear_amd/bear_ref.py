@@ -87,10 +87,8 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
             hs, ts, ns = h_signed.item(), tau_signed.item(), nu_signed.item()
             if e["rows"] == 0:
                 out.zero_()
-            elif train_ar:
-                kernels.dm_ref(e["train"], e["ref"], hs, ts, ns, train_ar=True, out=out)
             else:
-                kernels.dm_ref_planned(res.plan(k, "train", 4), e["ref"], hs, ts, ns, out=out)
+                kernels.dm_ref_planned(res.plan(k, "train", 4), e["ref"], hs, ts, ns, out=out, train_ar=train_ar)
             dist.allreduce_sum_(out)                                   # replaces bear_ref.py:358 + the grad sum of :346-350
             scaled = (-(num_kmers / e["global_rows"]) * out).cpu()     # loss = -(num_kmers / B) sum LL, bear_ref.py:252-253
             loss += scaled[0].item()

@@ -79,20 +79,29 @@ int bear_ws_create(int device, bear_ws **out) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_sorted_kernel<9>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(srt_lds_n));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<false>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_kernel<false>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_kernel<false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_g));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_kernel<true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_kernel<true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_g));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_ref_plan_kernel),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_ref_plan_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_r));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_ref_plan_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_r));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_g));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_ref_sorted_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(srt_lds_r));
@@ -402,8 +411,8 @@ static int grid_plan(const bear_ws *ws, uint64_t n_tiles) {
 }
 
 int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
-                           uint64_t n_rows, double h_signed, double eps, int prior_normalized, double *out,
-                           void *stream) {
+                           uint64_t n_rows, double h_signed, double eps, int train_ar, int prior_normalized,
+                           double *out, void *stream) {
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
   if (!plan || !out || (n_rows && (!counts || !prior))) return BEAR_ERR_INVALID_ARG;
@@ -417,11 +426,14 @@ int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *c
   prm.eps = eps;
   const int grid = grid_plan(ws, plan->n_tiles);
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
-  if (prior_normalized)
-    hipLaunchKernelGGL(dm_prior_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
+  if (train_ar)
+    hipLaunchKernelGGL((dm_prior_plan_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
+                       plan_view(plan), lt, ws->partials);
+  else if (prior_normalized)
+    hipLaunchKernelGGL((dm_prior_plan_kernel<true, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
                        plan_view(plan), lt, ws->partials);
   else
-    hipLaunchKernelGGL(dm_prior_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
+    hipLaunchKernelGGL((dm_prior_plan_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
                        plan_view(plan), lt, ws->partials);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
@@ -430,8 +442,8 @@ int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *c
 }
 
 int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
-                                uint64_t n_rows, double h_signed, double eps, int prior_normalized, double *out,
-                                double *grad_prior, void *stream) {
+                                uint64_t n_rows, double h_signed, double eps, int train_ar, int prior_normalized,
+                                double *out, double *grad_prior, void *stream) {
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
   if (!plan || !out || !grad_prior || (n_rows && (!counts || !prior))) return BEAR_ERR_INVALID_ARG;
@@ -446,11 +458,14 @@ int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32
   const int grid = grid_plan(ws, plan->n_tiles);
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const pln_view pv = plan_view(plan);
-  if (prior_normalized)
-    hipLaunchKernelGGL(dm_prior_plan_grad_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
+  if (train_ar)
+    hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
+                       grad_prior, ws->partials);
+  else if (prior_normalized)
+    hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
                        grad_prior, ws->partials);
   else
-    hipLaunchKernelGGL(dm_prior_plan_grad_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
+    hipLaunchKernelGGL((dm_prior_plan_grad_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
                        grad_prior, ws->partials);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
@@ -458,10 +473,12 @@ int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32
   if (pv.n_heavy_col + pv.n_heavy_row) {
     const uint64_t nh = pv.n_heavy_col + pv.n_heavy_row;
     const int g2 = (int)((nh + 255) / 256 < (uint64_t)ws->num_cu * 4 ? (nh + 255) / 256 : (uint64_t)ws->num_cu * 4);
-    if (prior_normalized)
-      hipLaunchKernelGGL(dm_prior_grad_fixup_kernel<true>, dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior);
+    if (train_ar)
+      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, true>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior);
+    else if (prior_normalized)
+      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior);
     else
-      hipLaunchKernelGGL(dm_prior_grad_fixup_kernel<false>, dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior);
+      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<false, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior);
     HIP_TRY(hipGetLastError());
   }
   return BEAR_OK;
@@ -469,7 +486,7 @@ int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32
 
 int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref,
                          uint64_t n_rows, double h_signed, double tau_signed, double nu_signed, double eps,
-                         double *out, void *stream) {
+                         int train_ar, double *out, void *stream) {
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
   if (!plan || !out || (n_rows && (!train || !ref))) return BEAR_ERR_INVALID_ARG;
@@ -487,8 +504,12 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
   prm.V = 1.0 / (nw + 1.0);
   prm.nw = nw;
   const int grid = grid_plan(ws, plan->n_tiles);
-  hipLaunchKernelGGL(dm_ref_plan_kernel, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan),
-                     reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
+  if (train_ar)
+    hipLaunchKernelGGL(dm_ref_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan),
+                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
+  else
+    hipLaunchKernelGGL(dm_ref_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan),
+                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 4, out);
   HIP_TRY(hipGetLastError());

@@ -356,7 +356,9 @@ struct pln_lds_n {
 // NORM: the caller asserts that every prior row sums to one (true for every ar_func of the reference,
 // all of which end in a softmax, ar_funcs.py:44,97,121-126).  Then A = u + 5 eps for every context
 // and the context terms collapse to the plan's histogram over n: no per-context pass at all.
-template <bool NORM>
+// AR: multinomial mode (train_ar, core.py:138-139 with probs = prior + eps, bear_net.py:68): sum LL =
+// sum over cells c log(prior + eps); no context terms, no h gradient.
+template <bool NORM, bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kernel(const double *__restrict__ prior,
                                                                                     uint64_t n_rows, bear_params prm,
                                                                                     pln_view pv,
@@ -436,18 +438,23 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
     // Work list of the tile, dearest first: the large-count column items and contexts (Stirling path), the
     // item units from the sorted tail down (long loops), then the 64-context chunks of the context terms.
     // Waves draw tickets until the list is exhausted.
-    const uint32_t n_hcu = (hc + 63u) >> 6, n_hru = (hr + 63u) >> 6, n_heavy = n_hcu + n_hru;
+    const uint32_t n_hcu = (hc + 63u) >> 6, n_hru = AR ? 0u : (hr + 63u) >> 6, n_heavy = n_hcu + n_hru;
     const uint32_t n_units = (n_light + 63u) >> 6;
-    const uint32_t n_work = n_heavy + n_units + (NORM ? 0u : (rows + 63u) >> 6);
+    const uint32_t n_work = n_heavy + n_units + ((NORM || AR) ? 0u : (rows + 63u) >> 6);
     for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_work; w = pln_ticket(&S.ticket[slot], lane)) {
       if (w < n_hcu) {  // large-count column items of this tile
         const uint32_t i = w * 64u + lane;
         if (i < hc) {
           const uint32_t off = reinterpret_cast<const uint16_t *>(B.blk + L.hoff)[i];
-          const double x = __builtin_fma(B.pri[off], u, eps);
-          const bear_dp o = srt_general_fast(x, (double)reinterpret_cast<const uint32_t *>(B.blk + L.hcnt)[i], S.logtab);
-          acc[0] += o.D;
-          acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
+          const double cnt = (double)reinterpret_cast<const uint32_t *>(B.blk + L.hcnt)[i];
+          if (AR) {
+            acc[0] = __builtin_fma(cnt, bear_log_tab(B.pri[off] + eps, S.logtab), acc[0]);
+          } else {
+            const double x = __builtin_fma(B.pri[off], u, eps);
+            const bear_dp o = srt_general_fast(x, cnt, S.logtab);
+            acc[0] += o.D;
+            acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
+          }
         }
         continue;
       }
@@ -462,12 +469,16 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
         }
         continue;
       }
-      if (NORM || w < n_heavy + n_units) {
+      if (NORM || AR || w < n_heavy + n_units) {
         // ---- D: one unit of column items
         const uint32_t un = n_heavy + n_units - 1u - w;
         uint32_t cmin, cmax;
         const uint32_t ci[1] = {pln_unit_counts(E, n_light, un, lane, &cmin, &cmax)};
         const uint32_t off = items[un * 64u + lane];
+        if (AR) {
+          acc[0] = __builtin_fma((double)ci[0], bear_log_tab(B.pri[off] + eps, S.logtab), acc[0]);
+          continue;
+        }
         const double x[1] = {__builtin_fma(B.pri[off], u, eps)};
         bear_dp o[1];
         srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
@@ -512,12 +523,16 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
   const uint64_t gtid = (uint64_t)blockIdx.x * PLN_THREADS + tid, gsz = (uint64_t)gridDim.x * PLN_THREADS;
   for (uint64_t i = gtid; i < pv.n_heavy_col; i += gsz) {
     const pln_heavy_col h = pv.heavy_col[i];
+    if (AR) {
+      acc[0] = __builtin_fma((double)h.c, bear_log_tab(prior[h.off] + eps, S.logtab), acc[0]);
+      continue;
+    }
     const double x = __builtin_fma(prior[h.off], u, eps);
     const bear_dp o = srt_general_fast(x, (double)h.c, S.logtab);
     acc[0] += o.D;
     acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
   }
-  for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
+  for (uint64_t i = gtid; !AR && i < pv.n_heavy_row; i += gsz) {
     const pln_heavy_row h = pv.heavy_row[i];
     const double *f = prior + h.row * 5;
     const double A = __builtin_fma(((f[0] + f[1]) + (f[2] + f[3])) + f[4], u, eps5);
@@ -525,7 +540,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
     acc[0] -= o.D;
     acc[1] = __builtin_fma(A - eps5, o.P, acc[1]);
   }
-  if (NORM && blockIdx.x == 0 && tid < SRT_CL) {  // context terms with the shared A, weighted by their multiplicity
+  if (NORM && !AR && blockIdx.x == 0 && tid < SRT_CL) {  // context terms with the shared A, weighted by their multiplicity
     const double m = (double)pv.hist[tid];
     acc[0] -= m * S.tabD[tid];
     acc[1] = __builtin_fma(u * m, S.tabP[tid], acc[1]);
@@ -547,6 +562,8 @@ struct pln_lds_r {
   uint32_t ticket[PLN_NBUF];
 };
 
+// AR: multinomial mode of bear_ref (train_ar): sum LL = sum c log(f + eps); gradients w.r.t. tau_s, nu_s only.
+template <bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel(const uint32_t *__restrict__ ref,
                                                                                   uint64_t n_rows, bear_params prm,
                                                                                   pln_view pv,
@@ -605,6 +622,16 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
     acc[2] = __builtin_fma(__builtin_fma(-tau, x, w2c), o.P, acc[2]);
     acc[3] = __builtin_fma(nwV * w1, o.P, acc[3]);
   };
+  // AR mode: item (ref count rb, row total R, count c): f = (1/4 + E dev) V, dLL/df = c / (f + eps)
+  auto accumulate_ar = [&](double rb, double R, double c) {
+    const double dev = __builtin_fma(rb + eps, bear_rcp(R), -0.25);
+    const double f = __builtin_fma(prm.E, dev, 0.25) * prm.V;
+    const double p = f + eps;
+    const double dLdf = c * bear_rcp(p);
+    acc[0] = __builtin_fma(c, bear_log_tab(p, S.logtab), acc[0]);
+    acc[2] = __builtin_fma(dLdf, -prm.tauE * dev * prm.V, acc[2]);  // d f / d tau_s
+    acc[3] = __builtin_fma(dLdf, -nwV * f, acc[3]);                 // d f / d nu_s (net function is 0 here)
+  };
 
   const uint64_t G = gridDim.x;
   uint64_t t = blockIdx.x;
@@ -653,8 +680,13 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
           const uint32_t off = reinterpret_cast<const uint16_t *>(B.blk + L.hoff)[i];
           const uint32_t *rr = &B.ref[((off * 52429u) >> 18) * 5u];
           const double R = (double)(((uint64_t)rr[0] + rr[1]) + ((uint64_t)rr[2] + rr[3])) + 4.0 * eps;
-          const double x = alpha_from((double)B.ref[off], R);
-          accumulate(x, srt_general_fast(x, (double)reinterpret_cast<const uint32_t *>(B.blk + L.hcnt)[i], S.logtab));
+          const double cnt = (double)reinterpret_cast<const uint32_t *>(B.blk + L.hcnt)[i];
+          if (AR) {
+            accumulate_ar((double)B.ref[off], R, cnt);
+          } else {
+            const double x = alpha_from((double)B.ref[off], R);
+            accumulate(x, srt_general_fast(x, cnt, S.logtab));
+          }
         }
         continue;
       }
@@ -664,6 +696,10 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
       const uint32_t off = items[un * 64u + lane];
       const uint32_t *rr = &B.ref[((off * 52429u) >> 18) * 5u];  // row start: 5 * (off / 5), off < 2^16
       const double R = (double)(((uint64_t)rr[0] + rr[1]) + ((uint64_t)rr[2] + rr[3])) + 4.0 * eps;  // bear_ref.py:335-337, 30
+      if (AR) {
+        accumulate_ar((double)B.ref[off], R, (double)ci[0]);
+        continue;
+      }
       const double x[1] = {alpha_from((double)B.ref[off], R)};
       bear_dp o[1];
       srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
@@ -678,8 +714,24 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
     const pln_heavy_col h = pv.heavy_col[i];
     const uint32_t *rr = ref + (h.off / 5) * 5;
     const double R = (double)(((uint64_t)rr[0] + rr[1]) + ((uint64_t)rr[2] + rr[3])) + 4.0 * eps;
+    if (AR) {
+      accumulate_ar((double)ref[h.off], R, (double)h.c);
+      continue;
+    }
     const double x = alpha_from((double)ref[h.off], R);
     accumulate(x, srt_general_fast(x, (double)h.c, S.logtab));
+  }
+  if (AR) {
+    // stop column: f_4 = nw V for every context, so its term is (sum of all stop counts) log(f_4 + eps)
+    const double f4 = nwV, p4 = f4 + eps;
+    double c4sum = 0.0;
+    if (blockIdx.x == 0 && tid < SRT_CL) c4sum = (double)(tid + 1) * (double)pv.hist[SRT_NKEY + tid];
+    for (uint64_t i = gtid; i < pv.n_heavy_stop; i += gsz) c4sum += (double)pv.heavy_stop[i];
+    acc[0] = __builtin_fma(c4sum, bear_log_tab(p4, S.logtab), acc[0]);
+    acc[3] = __builtin_fma(c4sum * bear_rcp(p4), nwV * (1.0 - f4), acc[3]);  // d f_4 / d nu_s = nw V (1 - f_4)
+    __syncthreads();
+    block_store_partials<4>(acc, partials);
+    return;
   }
   for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
     const bear_dp o = srt_general_fast(A, pv.heavy_row[i].n, S.logtab);
@@ -722,7 +774,7 @@ struct pln_lds_g {
   uint32_t ticket;
 };
 
-template <bool NORM>
+template <bool NORM, bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad_kernel(const double *__restrict__ prior,
                                                                                          bear_params prm, pln_view pv,
                                                                                          const double2 *__restrict__ logtab_g,
@@ -766,8 +818,12 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
     const uint16_t *E = reinterpret_cast<const uint16_t *>(S.blk);
     const uint8_t *nrow = S.blk + L.nrow;
     const uint16_t *items = reinterpret_cast<const uint16_t *>(S.blk + L.items);
-    // ---- 1: context chunks: context terms and the base -u P_n of all five cells
-    for (uint32_t row = tid; row < rows; row += PLN_THREADS) {
+    // ---- 1: context chunks: context terms and the base -u P_n of all five cells (AR mode: zeros)
+    for (uint32_t row = tid; AR && row < rows; row += PLN_THREADS) {
+#pragma unroll
+      for (int b = 0; b < 5; ++b) S.grad[row * 5 + b] = 0.0;
+    }
+    for (uint32_t row = tid; !AR && row < rows; row += PLN_THREADS) {
       double f[5];
 #pragma unroll
       for (int b = 0; b < 5; ++b) f[b] = S.pri[row * 5 + b];
@@ -794,7 +850,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
     }
     srt_sync();
     // ---- 2: contexts of this tile with a large total overwrite their base
-    for (uint32_t i = tid; i < hr; i += PLN_THREADS) {
+    for (uint32_t i = tid; !AR && i < hr; i += PLN_THREADS) {
       const uint32_t row = reinterpret_cast<const uint16_t *>(S.blk + L.hrow)[i];
       const double *f = &S.pri[row * 5u];
       const double A = NORM ? u + eps5 : __builtin_fma(((f[0] + f[1]) + (f[2] + f[3])) + f[4], u, eps5);
@@ -812,11 +868,18 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
         const uint32_t i = w * 64u + lane;
         if (i < hc) {
           const uint32_t off = reinterpret_cast<const uint16_t *>(S.blk + L.hoff)[i];
-          const double x = __builtin_fma(S.pri[off], u, eps);
-          const bear_dp o = srt_general_fast(x, (double)reinterpret_cast<const uint32_t *>(S.blk + L.hcnt)[i], S.logtab);
-          acc[0] += o.D;
-          acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
-          S.grad[off] = __builtin_fma(u, o.P, S.grad[off]);
+          const double cnt = (double)reinterpret_cast<const uint32_t *>(S.blk + L.hcnt)[i];
+          if (AR) {
+            const double pp = S.pri[off] + eps;
+            acc[0] = __builtin_fma(cnt, bear_log_tab(pp, S.logtab), acc[0]);
+            S.grad[off] = cnt * bear_rcp(pp);
+          } else {
+            const double x = __builtin_fma(S.pri[off], u, eps);
+            const bear_dp o = srt_general_fast(x, cnt, S.logtab);
+            acc[0] += o.D;
+            acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
+            S.grad[off] = __builtin_fma(u, o.P, S.grad[off]);
+          }
         }
         continue;
       }
@@ -824,6 +887,12 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
       uint32_t cmin, cmax;
       const uint32_t ci[1] = {pln_unit_counts(E, n_light, un, lane, &cmin, &cmax)};
       const uint32_t off = items[un * 64u + lane];
+      if (AR) {
+        const double pp = S.pri[off] + eps;
+        acc[0] = __builtin_fma((double)ci[0], bear_log_tab(pp, S.logtab), acc[0]);
+        if (ci[0] != 0) S.grad[off] = (double)ci[0] * bear_rcp(pp);
+        continue;
+      }
       const double x[1] = {__builtin_fma(S.pri[off], u, eps)};
       bear_dp o[1];
       srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
@@ -846,12 +915,16 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
   const uint64_t gtid = (uint64_t)blockIdx.x * PLN_THREADS + tid, gsz = (uint64_t)gridDim.x * PLN_THREADS;
   for (uint64_t i = gtid; i < pv.n_heavy_col; i += gsz) {
     const pln_heavy_col h = pv.heavy_col[i];
+    if (AR) {
+      acc[0] = __builtin_fma((double)h.c, bear_log_tab(prior[h.off] + eps, S.logtab), acc[0]);
+      continue;
+    }
     const double x = __builtin_fma(prior[h.off], u, eps);
     const bear_dp o = srt_general_fast(x, (double)h.c, S.logtab);
     acc[0] += o.D;
     acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
   }
-  for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
+  for (uint64_t i = gtid; !AR && i < pv.n_heavy_row; i += gsz) {
     const pln_heavy_row h = pv.heavy_row[i];
     const double *f = prior + h.row * 5;
     const double A = NORM ? u + eps5 : __builtin_fma(((f[0] + f[1]) + (f[2] + f[3])) + f[4], u, eps5);
@@ -865,7 +938,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
 
 // Gradient cells of the items in the plan's global overflow lists (very dense tiles only).  A cell can be hit by
 // a column item and by its context, hence the fp64 atomics (rare path).
-template <bool NORM>
+template <bool NORM, bool AR>
 __global__ __launch_bounds__(256) void dm_prior_grad_fixup_kernel(const double *__restrict__ prior, bear_params prm, pln_view pv,
                                                                    const double2 *__restrict__ logtab_g,
                                                                    double *__restrict__ grad_out) {
@@ -876,11 +949,15 @@ __global__ __launch_bounds__(256) void dm_prior_grad_fixup_kernel(const double *
   const uint64_t gtid = (uint64_t)blockIdx.x * 256 + threadIdx.x, gsz = (uint64_t)gridDim.x * 256;
   for (uint64_t i = gtid; i < pv.n_heavy_col; i += gsz) {
     const pln_heavy_col h = pv.heavy_col[i];
+    if (AR) {
+      atomicAdd(&grad_out[h.off], (double)h.c * bear_rcp(prior[h.off] + eps));
+      continue;
+    }
     const double x = __builtin_fma(prior[h.off], u, eps);
     const bear_dp o = srt_general_fast(x, (double)h.c, logtab);
     atomicAdd(&grad_out[h.off], u * o.P);
   }
-  for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
+  for (uint64_t i = gtid; !AR && i < pv.n_heavy_row; i += gsz) {
     const pln_heavy_row h = pv.heavy_row[i];
     const double *f = prior + h.row * 5;
     const double A = NORM ? u + eps5 : __builtin_fma(((f[0] + f[1]) + (f[2] + f[3])) + f[4], u, eps5);

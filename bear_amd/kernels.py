@@ -133,7 +133,7 @@ class Plan:
                 pass
 
 
-def dm_prior_planned(plan, prior, h_signed, eps=EPSILON, out=None, normalized=False, want_grad=False):
+def dm_prior_planned(plan, prior, h_signed, eps=EPSILON, out=None, normalized=False, want_grad=False, train_ar=False):
     """Planned twin of dm_prior (BEAR mode): [sum LL, d/dh_signed]; with want_grad also the gradient rows
     d sum LL / d prior, returned as (out, grad).  normalized=True asserts that every prior row sums to one
     (any softmax output)."""
@@ -147,18 +147,19 @@ def dm_prior_planned(plan, prior, h_signed, eps=EPSILON, out=None, normalized=Fa
         grad = torch.empty_like(prior)
         with torch.cuda.device(counts.device):
             st = _lib.lib().bear_dm_prior_plan_grad_f64(plan.ws.handle, plan._h, _ptr(counts), _ptr(prior), counts.shape[0],
-                                                        float(h_signed), float(eps), int(bool(normalized)), _ptr(out),
-                                                        _ptr(grad), _stream())
+                                                        float(h_signed), float(eps), int(bool(train_ar)), int(bool(normalized)),
+                                                        _ptr(out), _ptr(grad), _stream())
         _lib.check(st, "bear_dm_prior_plan_grad_f64")
         return out, grad
     with torch.cuda.device(counts.device):
         st = _lib.lib().bear_dm_prior_plan_f64(plan.ws.handle, plan._h, _ptr(counts), _ptr(prior), counts.shape[0],
-                                               float(h_signed), float(eps), int(bool(normalized)), _ptr(out), _stream())
+                                               float(h_signed), float(eps), int(bool(train_ar)), int(bool(normalized)), _ptr(out),
+                                               _stream())
     _lib.check(st, "bear_dm_prior_plan_f64")
     return out
 
 
-def dm_ref_planned(plan, ref, h_signed, tau_signed, nu_signed, eps=EPSILON, out=None):
+def dm_ref_planned(plan, ref, h_signed, tau_signed, nu_signed, eps=EPSILON, out=None, train_ar=False):
     """Planned twin of dm_ref (BEAR mode): [sum LL, d/dh_signed, d/dtau_signed, d/dnet_weight_signed]."""
     train = plan.counts
     _check_rows(ref, torch.int32, "ref")
@@ -168,7 +169,7 @@ def dm_ref_planned(plan, ref, h_signed, tau_signed, nu_signed, eps=EPSILON, out=
         out = torch.empty(4, dtype=torch.float64, device=train.device)
     with torch.cuda.device(train.device):
         st = _lib.lib().bear_dm_ref_plan_f64(plan.ws.handle, plan._h, _ptr(train), _ptr(ref), train.shape[0], float(h_signed),
-                                             float(tau_signed), float(nu_signed), float(eps), _ptr(out), _stream())
+                                             float(tau_signed), float(nu_signed), float(eps), int(bool(train_ar)), _ptr(out), _stream())
     _lib.check(st, "bear_dm_ref_plan_f64")
     return out
 

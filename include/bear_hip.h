@@ -110,16 +110,16 @@ uint64_t bear_plan_bytes(const bear_plan *plan);
  * come from the plan's histogram of totals; with 0 the kernel sums each row and uses the shared A
  * only where the sum is 1 to 2 ulp. */
 int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
-                           uint64_t n_rows, double h_signed, double eps, int prior_normalized, double *out,
-                           void *stream);
+                           uint64_t n_rows, double h_signed, double eps, int train_ar, int prior_normalized,
+                           double *out, void *stream);
 /* The same with the gradient rows: grad_prior [dev] double [n_rows, 5] = d sum LL / d prior (BEAR mode), what
  * grad_tape.gradient hands back to ar_func (bear_model/bear_net.py:193). */
 int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
-                                uint64_t n_rows, double h_signed, double eps, int prior_normalized, double *out,
-                                double *grad_prior, void *stream);
+                                uint64_t n_rows, double h_signed, double eps, int train_ar, int prior_normalized,
+                                double *out, double *grad_prior, void *stream);
 int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref,
                          uint64_t n_rows, double h_signed, double tau_signed, double nu_signed, double eps,
-                         double *out, void *stream);
+                         int train_ar, double *out, void *stream);
 
 /*
  * The primitive underneath both entry points, item by item (tests / diagnostics): for x > 0 and

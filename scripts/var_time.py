@@ -10,7 +10,7 @@ f = kernels.synth_prior(20211012, 0, N, dev)
 args = (0.0, float(np.log(1 / 30)), float(-np.log(100)))
 plan_r = kernels.Plan(t["train"], 4); plan_n = kernels.Plan(t["train"], 5)
 res = []
-for name, fn in [("ref", lambda: kernels.dm_ref_planned(plan_r, t["ref"], *args)), ("net", lambda: kernels.dm_prior_planned(plan_n, f, 0.0)), ("net_norm", lambda: kernels.dm_prior_planned(plan_n, f, 0.0, normalized=True)), ("net_grad", lambda: kernels.dm_prior_planned(plan_n, f, 0.0, want_grad=True)[0])]:
+for name, fn in [("ref", lambda: kernels.dm_ref_planned(plan_r, t["ref"], *args)), ("net", lambda: kernels.dm_prior_planned(plan_n, f, 0.0)), ("net_norm", lambda: kernels.dm_prior_planned(plan_n, f, 0.0, normalized=True)), ("net_grad", lambda: kernels.dm_prior_planned(plan_n, f, 0.0, want_grad=True)[0]), ("ref_ar", lambda: kernels.dm_ref_planned(plan_r, t["ref"], *args, train_ar=True)), ("net_ar", lambda: kernels.dm_prior_planned(plan_n, f, 0.0, train_ar=True)), ("net_ar_grad", lambda: kernels.dm_prior_planned(plan_n, f, 0.0, want_grad=True, train_ar=True)[0])]:
     fn(); torch.cuda.synchronize()
     best = 1e9
     for _ in range(3):

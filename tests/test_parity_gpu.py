@@ -269,6 +269,39 @@ def test_planned_kernels_parity(case, dev, ysd1):
             _close(got[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
 
 
+@pytest.mark.parametrize("case", ["ysd1", "sparse", "sparse_hot", "dense", "edge", "one_row"])
+def test_planned_ar_mode_parity(case, dev, ysd1):
+    """train_ar (multinomial, core.py:138-139) on the plan: sum c log(f + eps), gradients w.r.t. tau_s, nu_s
+    (mode R) and the prior rows (mode N) against the oracle."""
+    from bear_amd import kernels
+    if case == "ysd1":
+        tr, rf = ysd1[1][:, 0].astype(np.uint32), ysd1[1][:, 2].astype(np.uint32)
+    else:
+        tr, rf = CASES_REF[case]()
+    d_tr, d_rf = _to_dev(tr, dev), _to_dev(rf, dev)
+    plan_r, plan_n = kernels.Plan(d_tr, 4), kernels.Plan(d_tr, 5)
+    for args in PARAMS:
+        want = co.dm_ref(tr, rf, *args, train_ar=True, nthreads=4)
+        got = kernels.dm_ref_planned(plan_r, d_rf, *args, train_ar=True).cpu().numpy()
+        _close(got[0], want[0], ELBO_RTOL)
+        assert got[1] == 0.0 and want[1] == 0.0          # no h in the multinomial
+        scale = np.abs(want[2:]).max() + abs(want[0]) * 1e-3
+        for k in (2, 3):
+            _close(got[k], want[k], GRAD_RTOL, scale)
+    n = len(tr)
+    for seed, conc in [(1, 1.0), (2, 0.2), (3, 5.0)]:
+        f = prior_rows(n, seed, conc)
+        if seed == 3:
+            f = f * np.linspace(0.5, 3.0, n)[:, None]
+        want, wantg = co.dm_prior(tr, f, 0.3, train_ar=True, want_grad=True, nthreads=4)
+        got = kernels.dm_prior_planned(plan_n, _to_dev(f, dev), 0.3, train_ar=True).cpu().numpy()
+        _close(got[0], want[0], ELBO_RTOL)
+        assert got[1] == 0.0
+        got, g = kernels.dm_prior_planned(plan_n, _to_dev(f, dev), 0.3, train_ar=True, want_grad=True)
+        _close(got.cpu().numpy()[0], want[0], ELBO_RTOL)
+        assert np.allclose(g.cpu().numpy(), wantg, rtol=1e-12, atol=1e-12 * (np.abs(wantg).max() + 1e-300)), case
+
+
 def test_planned_full_size_chunks(dev):
     """Bench-scale table: planned == unplanned on the whole table; planned on sampled chunks ==
     oracle; a plan refuses a different buffer."""
