@@ -68,7 +68,7 @@ class ResidentBatches:
         for a, b in data.batch_bounds():
             lo, hi = dist.shard_rows(b - a)
             lo, hi = a + lo, a + hi
-            entry = {"global_rows": b - a, "rows": hi - lo}
+            entry = {"global_rows": b - a, "rows": hi - lo, "row0": lo}
             for name, col in columns.items():
                 entry[name] = torch.from_numpy(np.ascontiguousarray(data.counts[col, lo:hi]).view(np.int32)).to(device)
             if codes is not None:
@@ -89,37 +89,34 @@ def counts_f64(t):
     return torch.where(t < 0, t.to(torch.float64) + 4294967296.0, t.to(torch.float64))
 
 
-def evaluation_sums(test, prior, h, van_reg, train=None, eps=epsilon, generator=None):
-    """The 7 partial sums of ``_evaluation_step`` (bear_net.py:323-371) for this rank's rows.
+MAX_EVAL_MODELS = 64   # EVL_MAX_MODELS of kernels_eval.h: h values + van_reg values per launch
+
+
+def evaluation_sums(test, prior, h, van_reg, train=None, eps=epsilon, noise_seed=0, row_base=0):
+    """The 7 partial sums of ``_evaluation_step`` (bear_net.py:323-371) for this rank's rows: one launch of
+    ``bear_eval_f64`` (all h values, the AR model and all van_reg values in a single pass over the rows).
     test / train: uint32 [n,5] device slabs; prior: float64 [n,5] = ar_func rows; h: float or 1-D sequence
-    (h_scan, bear_net.py:523).  Every log-likelihood is one launch of the DM kernels on a prepared
-    concentration / probability slab; the arg-max bookkeeping is elementwise torch."""
-    dev = test.device
-    ct = counts_f64(test)
-    ctr = counts_f64(train) if train is not None else None
-    hs = [float(x) for x in np.atleast_1d(np.asarray(h, dtype=np.float64))]
-    van = [float(v) for v in np.atleast_1d(np.asarray(van_reg, dtype=np.float64))]
-    n = test.shape[0]
-
-    def noisy_correct(values, scale):
-        noise = scale * torch.randn(values.shape, dtype=values.dtype, device=dev, generator=generator)
-        idx = torch.argmax(values + noise, dim=-1, keepdim=True)
-        return torch.gather(ct, 1, idx).sum().item()
-
+    (h_scan, bear_net.py:523).  ``row_base`` is the global index of row 0, so the arg-max noise stream
+    does not depend on how the rows are sharded."""
+    hs = np.atleast_1d(np.asarray(h, dtype=np.float64)).reshape(-1)
+    van = np.atleast_1d(np.asarray(van_reg, dtype=np.float64)).reshape(-1)
+    if van.size >= MAX_EVAL_MODELS:
+        raise ValueError(f"at most {MAX_EVAL_MODELS - 1} van_reg values")
     ll_ear, cor_ear = [], []
-    for hv in hs:
-        conc = prior / hv + (ctr if ctr is not None else 0.0)                       # bear_net.py:43, :335-337
-        ll_ear.append(kernels.dm_prior(test, conc.contiguous(), 0.0, eps=eps)[0][0].item() if n else 0.0)
-        cor_ear.append(noisy_correct(conc + eps, 100 * eps) if n else 0.0)
-    ll_arm = kernels.dm_prior(test, prior.contiguous(), 0.0, eps=eps, train_ar=True)[0][0].item() if n else 0.0
-    cor_arm = noisy_correct(prior + eps, eps) if n else 0.0                         # core.py:134-136
-    ll_van, cor_van = [], []
-    for v in van:
-        conc = (ctr + v) if ctr is not None else torch.full((n, 5), v, dtype=torch.float64, device=dev)
-        ll_van.append(kernels.dm_prior(test, conc.contiguous(), 0.0, eps=eps)[0][0].item() if n else 0.0)
-        cor_van.append(noisy_correct(conc + eps, 100 * eps) if n else 0.0)
-    total_len = ct.sum().item()
-    return (np.array(ll_ear), ll_arm, np.array(ll_van), np.array(cor_ear), cor_arm, np.array(cor_van), total_len)
+    rest = None
+    step = MAX_EVAL_MODELS - van.size
+    for k in range(0, max(hs.size, 1), step):        # more h values than fit one launch: chunks, noise stream seed + k
+        hk = hs[k:k + step]
+        first = k == 0
+        out = kernels.evaluate(test, prior, hk, van if first else None, train, eps=eps, with_ar=first,
+                               noise_seed=noise_seed + k, row_base=row_base).cpu().numpy()
+        H, V = hk.size, van.size if first else 0
+        ll_ear.append(out[:H])
+        cor_ear.append(out[H + V + 1:2 * H + V + 1])
+        if first:
+            rest = (out[H], out[H + 1:H + 1 + V], out[2 * H + V + 1], out[2 * H + V + 2:2 * H + 2 * V + 2], out[-1])
+    ll_arm, ll_van, cor_arm, cor_van, total_len = rest
+    return (np.concatenate(ll_ear), ll_arm, ll_van, np.concatenate(cor_ear), cor_arm, cor_van, total_len)
 
 
 def reduce_evaluation(parts, device, scalar_h):

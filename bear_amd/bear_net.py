@@ -90,7 +90,7 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
     return params, h_signed, ar_func
 
 
-def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype, generator):
+def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype, seed):
     device = _train.require_device()
     use_train = ds_loc_train >= 0
     cols = {"test": ds_loc_test}
@@ -101,21 +101,21 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
     with torch.no_grad():
         for e in res.batches:
             prior = ar_func(e["codes"]).expand(e["rows"], 5).contiguous() if e["rows"] else torch.zeros((0, 5), dtype=dtype, device=device)
-            part = _train.evaluation_sums(e["test"], prior, h, van_reg, e.get("train"), generator=generator)
+            part = _train.evaluation_sums(e["test"], prior, h, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"])
             total = part if total is None else tuple(a + b for a, b in zip(total, part))
     return total, device
 
 
-def evaluation(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype=torch.float64, generator=None):
+def evaluation(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype=torch.float64, seed=0):
     """bear_net.evaluation (bear_net.py:387-463) -> the reference's 9-tuple."""
     hv = float(torch.as_tensor(h).detach().cpu().item())
-    total, device = _eval(data, ds_loc_train, ds_loc_test, alphabet, hv, ar_func, van_reg, dtype, generator)
+    total, device = _eval(data, ds_loc_train, ds_loc_test, alphabet, hv, ar_func, van_reg, dtype, seed)
     return _train.reduce_evaluation(total, device, True)
 
 
-def h_scan(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, dtype=torch.float64, generator=None):
+def h_scan(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, dtype=torch.float64, seed=0):
     """bear_net.h_scan (bear_net.py:465-531): BEAR log-likelihood, perplexity and accuracy for a vector of h."""
     hs = torch.as_tensor(h).detach().cpu().numpy().reshape(-1)
-    total, device = _eval(data, ds_loc_train, ds_loc_test, alphabet, hs, ar_func, np.ones(1), dtype, generator)
+    total, device = _eval(data, ds_loc_train, ds_loc_test, alphabet, hs, ar_func, np.ones(1), dtype, seed)
     r = _train.reduce_evaluation(total, device, False)
     return r[0], r[3], r[6]

@@ -107,7 +107,7 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
 
 
 def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func, van_reg, dtype=torch.float64,
-               generator=None):
+               seed=0):
     """bear_ref.evaluation (bear_ref.py:453-539) -> (ll_ear, ll_arm, ll_van, perp_ear, perp_arm, perp_van,
     acc_ear, acc_arm, acc_van).  ``ds_loc_train = -1``: no conditioning on training counts.  The training
     column is used for conditioning (the reference reads the reference column there by mistake,
@@ -124,6 +124,6 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
         for e in res.batches:
             prior = ar_func(e["codes"], _ref_input(e["ref"], dtype)) if e["rows"] else torch.zeros((0, 5), dtype=dtype, device=device)
             prior = prior.expand(e["rows"], 5).contiguous()
-            part = _train.evaluation_sums(e["test"], prior, hv, van_reg, e.get("train"), generator=generator)
+            part = _train.evaluation_sums(e["test"], prior, hv, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"])
             total = part if total is None else tuple(a + b for a, b in zip(total, part))
     return _train.reduce_evaluation(total, device, np.ndim(hv) == 0)

@@ -31,6 +31,9 @@ struct bear_ws {
   double *partials;  // [max_blocks][BEAR_MAX_OUT]
   double *logtab;    // [BEAR_LOGTAB_N][2] = {r_i, -log r_i} (bear_math.h, bear_log_tab)
   unsigned long long *dbg;  // developer timing buffer [max_blocks][8][6]
+  double *eval_partials;    // [eval_blocks][EVL_MAX_OUT] (kernels_eval.h)
+  double *eval_out;         // [EVL_MAX_OUT] scratch result vector (bear_bmm_f64)
+  int eval_blocks;
 };
 
 struct bear_params {

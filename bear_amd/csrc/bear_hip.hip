@@ -13,6 +13,7 @@
 
 #include "bear_common.h"
 #include "kernels_rows.h"
+#include "kernels_eval.h"
 #include "kernels_sorted.h"
 #include "kernels_plan.h"
 #include "kernels_synth.h"
@@ -59,6 +60,9 @@ int bear_ws_create(int device, bear_ws **out) {
       e = hipMalloc(&ws->partials, sizeof(double) * BEAR_MAX_OUT * (size_t)ws->max_blocks);
       if (e == hipSuccess) e = hipMalloc(&ws->logtab, sizeof(double) * 2 * BEAR_LOGTAB_N);
       if (e == hipSuccess) e = hipMalloc(&ws->dbg, sizeof(unsigned long long) * 48 * (size_t)ws->max_blocks);
+      ws->eval_blocks = ws->num_cu * 8;
+      if (e == hipSuccess) e = hipMalloc(&ws->eval_partials, sizeof(double) * EVL_MAX_OUT * (size_t)ws->eval_blocks);
+      if (e == hipSuccess) e = hipMalloc(&ws->eval_out, sizeof(double) * EVL_MAX_OUT);
       if (e == hipSuccess) {
         // {r_i, -log r_i}: r_i = 1 / midpoint of the i-th mantissa cell of [0.5, 1) (bear_log_tab)
         double tab[2 * BEAR_LOGTAB_N];
@@ -128,6 +132,8 @@ int bear_ws_destroy(bear_ws *ws) {
   (void)hipFree(ws->partials);
   (void)hipFree(ws->logtab);
   (void)hipFree(ws->dbg);
+  (void)hipFree(ws->eval_partials);
+  (void)hipFree(ws->eval_out);
   (void)hipSetDevice(prev);
   delete ws;
   return BEAR_OK;
@@ -527,6 +533,69 @@ int bear_dm_items_f64(bear_ws *ws, const double *x, const uint32_t *c, uint64_t 
   hipLaunchKernelGGL(dm_items_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, c, n, path,
                      reinterpret_cast<const double2 *>(ws->logtab), D, P);
   HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+// ---- held-out evaluation / BMM marginal (kernels_eval.h) ------------------------------------------------
+static int launch_eval(bear_ws *ws, const uint32_t *test, const uint32_t *train, const double *prior, uint64_t n_rows,
+                       const evl_args &A, double *out, hipStream_t s) {
+  const int n_out = 2 * (A.n_h + A.n_van) + 3;
+  const uint64_t tiles = (n_rows + EVL_THREADS - 1) / EVL_THREADS;
+  const int grid = (int)(tiles < (uint64_t)ws->eval_blocks ? (tiles ? tiles : 1) : (uint64_t)ws->eval_blocks);
+  hipLaunchKernelGGL(eval_kernel, dim3(grid), dim3(EVL_THREADS), 0, s, test, train, prior, n_rows, A,
+                     reinterpret_cast<const double2 *>(ws->logtab), ws->eval_partials);
+  hipLaunchKernelGGL(eval_finalize_kernel, dim3(1), dim3(256), 0, s, ws->eval_partials, grid, n_out, out);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_eval_f64(bear_ws *ws, const uint32_t *test, const uint32_t *train, const double *prior, uint64_t n_rows,
+                  const double *h, int n_h, int with_ar, const double *van_reg, int n_van, double eps,
+                  uint64_t noise_seed, uint64_t row_base, double *out, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!out || n_h < 0 || n_van < 0 || n_h + n_van > EVL_MAX_MODELS || (n_h && !h) || (n_van && !van_reg))
+    return BEAR_ERR_INVALID_ARG;
+  if ((n_h || with_ar) && !prior && n_rows) return BEAR_ERR_INVALID_ARG;
+  if (n_rows && !test) return BEAR_ERR_INVALID_ARG;
+  if (misaligned(test) || misaligned(train) || misaligned(prior)) return BEAR_ERR_INVALID_ARG;
+  if (!(eps >= 0.0)) return BEAR_ERR_INVALID_ARG;
+  evl_args A;
+  memset(&A, 0, sizeof(A));
+  A.n_h = n_h;
+  A.n_van = n_van;
+  A.arm = with_ar ? 1 : 0;
+  A.has_train = train ? 1 : 0;
+  A.has_prior = prior ? 1 : 0;
+  A.eps = eps;
+  A.seed = noise_seed;
+  A.row_base = row_base;
+  for (int j = 0; j < n_h; ++j) {
+    if (!(h[j] > 0.0)) return BEAR_ERR_INVALID_ARG;
+    A.inv_h[j] = 1.0 / h[j];
+  }
+  for (int k = 0; k < n_van; ++k) A.inv_h[n_h + k] = van_reg[k];
+  return launch_eval(ws, test, train, prior, n_rows, A, out, static_cast<hipStream_t>(stream));
+}
+
+int bear_bmm_f64(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, const double *alpha, int n_alpha, double *out,
+                 void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!out || !alpha || n_alpha <= 0 || n_alpha > EVL_MAX_MODELS || (n_rows && !counts) || misaligned(counts))
+    return BEAR_ERR_INVALID_ARG;
+  evl_args A;
+  memset(&A, 0, sizeof(A));
+  A.n_van = n_alpha;
+  for (int k = 0; k < n_alpha; ++k) {
+    if (!(alpha[k] > 0.0)) return BEAR_ERR_INVALID_ARG;
+    A.inv_h[k] = alpha[k];
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  st = launch_eval(ws, counts, nullptr, nullptr, n_rows, A, ws->eval_out, s);
+  if (st != BEAR_OK) return st;
+  // result vector layout: [ll_arm (unused), ll_van[n_alpha], ...]
+  HIP_TRY(hipMemcpyAsync(out, ws->eval_out + 1, sizeof(double) * (size_t)n_alpha, hipMemcpyDeviceToDevice, s));
   return BEAR_OK;
 }
 

@@ -139,19 +139,17 @@ def sparse_dataloader(file, alphabet, batch_size, num_ds, cache=False, header=Tr
 
 def bmm_likelihood(data, alpha, dtype=torch.float64, device=None):
     """dataloader.py:120-147: BMM marginal ``sum_i lbeta(c_i + alpha) - lbeta(alpha)`` for every dataset
-    column and every alpha -> [num_ds, len(alpha)].  Each (column, alpha) is one launch of the DM kernel
-    with the constant prior alpha (h = 1, eps = 0)."""
+    column and every alpha -> [num_ds, len(alpha)].  One launch of ``bear_bmm_f64`` per column (all alphas
+    in a single pass over the rows)."""
     if not isinstance(data, CountDataset):
         raise TypeError("bmm_likelihood expects the CountDataset returned by dataloader()")
     device = torch.device(device or "cuda")
     alpha = np.atleast_1d(np.asarray(alpha, dtype=np.float64))
     out = torch.zeros((data.num_ds, len(alpha)), dtype=torch.float64)
-    n = data.num_rows
-    for j, a in enumerate(alpha):
-        prior = torch.full((n, 5), float(a), dtype=torch.float64, device=device)
-        for d in range(data.num_ds):
-            res, _ = kernels.dm_prior(data.device_column(d, device), prior, 0.0, eps=0.0)
-            out[d, j] = res[0].item()
+    for d in range(data.num_ds):
+        col = data.device_column(d, device)
+        for k in range(0, len(alpha), 64):
+            out[d, k:k + 64] = kernels.bmm(col, alpha[k:k + 64]).cpu()
     return out.to(dtype)
 
 

@@ -2,6 +2,7 @@
 current torch stream).  Tensors are passed as raw device pointers; nothing here computes."""
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -185,6 +186,46 @@ def dm_items(x, c, path=0, ws=None):
         st = _lib.lib().bear_dm_items_f64(ws.handle, _ptr(x), _ptr(c), x.shape[0], int(path), _ptr(D), _ptr(P), _stream())
     _lib.check(st, "bear_dm_items_f64")
     return D, P
+
+
+def _host_f64(values):
+    a = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64)))
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def evaluate(test, prior, h, van_reg, train=None, eps=EPSILON, with_ar=True, noise_seed=0, row_base=0, ws=None):
+    """One launch of ``bear_eval_f64``: the 7 partial sums of ``_evaluation_step`` (bear_net.py:323-371).
+    Returns a device float64 vector {ll_ear[H], ll_arm, ll_van[V], cor_ear[H], cor_arm, cor_van[V], total_len}."""
+    test = _check_rows(test, torch.int32, "test")
+    n = test.shape[0]
+    if train is not None:
+        train = _check_rows(train, torch.int32, "train")
+    if prior is not None:
+        prior = _check_rows(prior, torch.float64, "prior")
+    for t in (train, prior):
+        if t is not None and t.shape[0] != n:
+            raise ValueError("test, train and prior must have the same number of rows")
+    hs, hp = _host_f64(h) if h is not None else (np.zeros(0), ctypes.c_void_p(0))
+    vs, vp = _host_f64(van_reg) if van_reg is not None else (np.zeros(0), ctypes.c_void_p(0))
+    ws = ws or default_workspace(test.device)
+    out = torch.empty(2 * (hs.size + vs.size) + 3, dtype=torch.float64, device=test.device)
+    with torch.cuda.device(test.device):
+        st = _lib.lib().bear_eval_f64(ws.handle, _ptr(test), _ptr(train), _ptr(prior), n, hp, hs.size, int(bool(with_ar)), vp,
+                                      vs.size, float(eps), int(noise_seed), int(row_base), _ptr(out), _stream())
+    _lib.check(st, "bear_eval_f64")
+    return out
+
+
+def bmm(counts, alpha, ws=None):
+    """sum_i lbeta(counts_i + alpha_k) - lbeta(alpha_k) for every alpha_k (dataloader.py:111-118): device [V]."""
+    counts = _check_rows(counts, torch.int32, "counts")
+    al, ap = _host_f64(alpha)
+    ws = ws or default_workspace(counts.device)
+    out = torch.empty(al.size, dtype=torch.float64, device=counts.device)
+    with torch.cuda.device(counts.device):
+        st = _lib.lib().bear_bmm_f64(ws.handle, _ptr(counts), counts.shape[0], ap, al.size, _ptr(out), _stream())
+    _lib.check(st, "bear_bmm_f64")
+    return out
 
 
 def synth_counts(seed, row0, n_rows, device, dense=False, want=("train", "test", "ref")):

@@ -122,6 +122,30 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
                          int train_ar, double *out, void *stream);
 
 /*
+ * Held-out evaluation, one pass over a row range: replaces _evaluation_step of bear_model/bear_net.py:323-371
+ * (and its bear_ref twin, bear_ref.py:391-446, with prior = the reference-mixed AR rows) and, with n_h > 1,
+ * one batch of h_scan (bear_net.py:465-531).
+ *   test   [dev] uint32 [n_rows,5]  held-out transition counts
+ *   train  [dev] uint32 [n_rows,5]  or NULL (use_train = False)
+ *   prior  [dev] double [n_rows,5]  ar_func rows (NULL only when n_h == 0 and with_ar == 0)
+ *   h      [host] n_h > 0 values (not log-transformed); van_reg [host] n_van pseudo-counts; n_h + n_van <= 64
+ *   out    [dev] double [2 (n_h + n_van) + 3] =
+ *          { ll_ear[n_h], ll_arm, ll_van[n_van], correct_ear[n_h], correct_arm, correct_van[n_van], total_len }
+ * The arg-max noise of core.py:69-71,134-136 is a counter-based hash of (noise_seed, model, row_base + row,
+ * letter) -- the same sequence for any sharding of the rows -- restated in oracle/bear_oracle.py:eval_noise.
+ */
+int bear_eval_f64(bear_ws *ws, const uint32_t *test, const uint32_t *train, const double *prior, uint64_t n_rows,
+                  const double *h, int n_h, int with_ar, const double *van_reg, int n_van, double eps,
+                  uint64_t noise_seed, uint64_t row_base, double *out, void *stream);
+
+/*
+ * BMM marginal likelihood of one dataset column: replaces _marginal_step of bear_model/dataloader.py:111-118,
+ *   out[k] = sum_i lbeta(counts_i + alpha_k) - lbeta(alpha_k 1_5),   alpha [host] n_alpha <= 64, out [dev].
+ */
+int bear_bmm_f64(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, const double *alpha, int n_alpha, double *out,
+                 void *stream);
+
+/*
  * The primitive underneath both entry points, item by item (tests / diagnostics): for x > 0 and
  * integer c >= 0,  D[i] = lgamma(x+c) - lgamma(x)  and  P[i] = digamma(x+c) - digamma(x)
  * -- the two quantities TFP's lbeta and its autodiff yield in bear_model/core.py:73-74.

@@ -259,14 +259,56 @@ def _ml_output(values, noise_scale, rng):
     return np.argmax(values + noise_scale * rng.standard_normal(values.shape), axis=-1)
 
 
+def _mix64(z):
+    z = np.asarray(z, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def _u01(hash64):
+    return ((hash64 >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+EVAL_ID_ARM, EVAL_ID_VAN = 1000, 2000
+
+
+def eval_noise(seed, model, rows, width=5):
+    """The counter-based N(0,1) stream the evaluation entry point uses in place of tf.random.normal
+    (core.py:69-71, 134-136): one Box-Muller draw per (seed, model id, global row, letter).  Model ids:
+    j for the j-th h, EVAL_ID_ARM for the AR model, EVAL_ID_VAN + k for the k-th van_reg."""
+    rows = np.asarray(rows, dtype=np.uint64)
+    cell = rows[:, None] * np.uint64(width) + np.arange(width, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        key = _mix64(_mix64(np.uint64(seed) + np.uint64(model)) ^ cell)
+        u1 = _u01(_mix64(key))
+        u2 = _u01(_mix64(key ^ np.uint64(0x5851F42D4C957F2D)))
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586 * u2)
+
+
+class HashNoise:
+    """rng stand-in for evaluation_step: hands out eval_noise streams by model id."""
+
+    def __init__(self, seed, row_base, n_rows):
+        self.seed, self.rows = seed, np.arange(row_base, row_base + n_rows, dtype=np.uint64)
+
+    def normal(self, model):
+        return eval_noise(self.seed, model, self.rows)
+
+
 def evaluation_step(test_counts, prior, h, van_reg, train_counts=None, eps=EPSILON, rng=None):
     """bear_net._evaluation_step (bear_net.py:323-371) on one batch.
 
     prior [B, A+1] = ar_func(...) rows; ``h`` scalar or [H] (h_scan, bear_net.py:523).
     With rng=None ties are broken by first index (deterministic oracle); accuracy
-    parity on tied rows is statistical in the reference.
+    parity on tied rows is statistical in the reference.  With rng a
+    ``HashNoise`` the tie-breaking noise is the counter-based stream of ``eval_noise``.
     Returns the 7 partial sums of bear_net.py:370-371.
     """
+    if isinstance(rng, HashNoise):
+        return _evaluation_step_hash(test_counts, prior, h, van_reg, train_counts, eps, rng)
     ct = np.asarray(test_counts, dtype=np.float64)
     f = np.broadcast_to(np.asarray(prior, dtype=np.float64), ct.shape)
     van = np.asarray(van_reg, dtype=np.float64)
@@ -297,6 +339,36 @@ def evaluation_step(test_counts, prior, h, van_reg, train_counts=None, eps=EPSIL
     if np.ndim(h) == 0:
         ll_ear, cor_ear = ll_ear[0], cor_ear[0]
     return ll_ear, ll_arm, ll_van, cor_ear, cor_arm, cor_van, total_len
+
+
+def _evaluation_step_hash(test_counts, prior, h, van_reg, train_counts, eps, noise):
+    """evaluation_step with the HashNoise streams (same arithmetic, per-model noise lookup)."""
+    ct = np.asarray(test_counts, dtype=np.float64)
+    f = np.broadcast_to(np.asarray(prior, dtype=np.float64), ct.shape)
+    hs = np.atleast_1d(np.asarray(h, dtype=np.float64))
+    van = np.atleast_1d(np.asarray(van_reg, dtype=np.float64))
+    ctr = np.asarray(train_counts, dtype=np.float64) if train_counts is not None else np.zeros_like(ct)
+
+    def correct(values, scale, model):
+        idx = np.argmax(values + scale * noise.normal(model), axis=-1)
+        return np.take_along_axis(ct, idx[:, None], -1).sum()
+
+    ll_ear, cor_ear, ll_van, cor_van = [], [], [], []
+    for j, hv in enumerate(hs):
+        conc = f / hv + ctr + eps
+        ll_ear.append(dm_counts_log_prob(conc, ct).sum())
+        cor_ear.append(correct(conc, 100 * eps, j))
+    probs = f + eps
+    ll_arm = multinomial_counts_log_prob(probs, ct).sum()
+    cor_arm = correct(probs, eps, EVAL_ID_ARM)
+    for k, v in enumerate(van):
+        conc = ctr + v + eps
+        ll_van.append(dm_counts_log_prob(conc, ct).sum())
+        cor_van.append(correct(conc, 100 * eps, EVAL_ID_VAN + k))
+    ll_ear, cor_ear = np.array(ll_ear), np.array(cor_ear)
+    if np.ndim(h) == 0:
+        ll_ear, cor_ear = ll_ear[0], cor_ear[0]
+    return ll_ear, ll_arm, np.array(ll_van), cor_ear, cor_arm, np.array(cor_van), ct.sum()
 
 
 # --------------------------------------------------------------------------- count-table text format

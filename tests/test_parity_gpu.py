@@ -302,6 +302,61 @@ def test_planned_ar_mode_parity(case, dev, ysd1):
         assert np.allclose(g.cpu().numpy(), wantg, rtol=1e-12, atol=1e-12 * (np.abs(wantg).max() + 1e-300)), case
 
 
+@pytest.mark.parametrize("case", ["ysd1", "sparse", "ties", "edge"])
+def test_eval_kernel_parity(case, dev, ysd1):
+    """bear_eval_f64 (bear_net.py:323-371 in one pass): log-likelihoods within ELBO_RTOL of the oracle, the
+    correct-transition counts and total length exactly (same hashed arg-max noise), for any row sharding."""
+    from bear_amd import kernels
+    rng = np.random.default_rng(5)
+    if case == "ysd1":
+        tr, te = ysd1[1][:, 0].astype(np.uint32), ysd1[1][:, 1].astype(np.uint32)
+    elif case == "sparse":
+        tr, te, _ = sparse_table(20011, 3)
+    elif case == "ties":    # uniform prior, no evidence: every arg-max is decided by the noise stream
+        te, _, _ = sparse_table(5000, 9)
+        tr = np.zeros_like(te)
+    else:
+        tr, _ = CASES_REF["edge"]()
+        te = tr[::-1].copy()
+    n = len(te)
+    f = prior_rows(n, 4, 1.0) if case != "ties" else np.full((n, 5), 0.2)
+    hs, van = np.array([0.05, 1.0, 37.0]), np.array([0.1, 1.0, 10.0])
+    d_te, d_tr, d_f = _to_dev(te, dev), _to_dev(tr, dev), _to_dev(f, dev)
+    for use_train in (True, False):
+        want = o.evaluation_step(te, f, hs, van, tr if use_train else None, rng=o.HashNoise(77, 1000, n))
+        got = kernels.evaluate(d_te, d_f, hs, van, d_tr if use_train else None, noise_seed=77, row_base=1000).cpu().numpy()
+        H, V = 3, 3
+        parts = (got[:H], got[H], got[H + 1:H + 1 + V], got[H + V + 1:2 * H + V + 1], got[2 * H + V + 1],
+                 got[2 * H + V + 2:2 * H + 2 * V + 2], got[-1])
+        for k in (0, 1, 2):
+            assert np.allclose(parts[k], want[k], rtol=ELBO_RTOL, atol=0), (case, k, parts[k], want[k])
+        for k in (3, 4, 5, 6):
+            assert np.array_equal(np.asarray(parts[k]), np.asarray(want[k])), (case, k, parts[k], want[k])
+        # sharding: two launches with the matching row_base add up (integers exactly, sums to rounding)
+        cut = (n // 3) // 4 * 4
+        a = kernels.evaluate(d_te[:cut], d_f[:cut], hs, van, d_tr[:cut] if use_train else None, noise_seed=77, row_base=1000)
+        b = kernels.evaluate(d_te[cut:], d_f[cut:], hs, van, d_tr[cut:] if use_train else None, noise_seed=77,
+                             row_base=1000 + cut)
+        both = (a + b).cpu().numpy()
+        assert np.array_equal(both[H + V + 1:], got[H + V + 1:])
+        assert np.allclose(both[:H + V + 1], got[:H + V + 1], rtol=1e-12)
+    # the BMM marginal entry is the vanilla model without training counts at eps = 0 (dataloader.py:111-118)
+    alpha = np.array([0.1, 1.0, 10.0])
+    wantb = np.array([o.dm_counts_log_prob(np.full(5, a), te.astype(np.float64)).sum() for a in alpha])
+    assert np.allclose(kernels.bmm(d_te, alpha).cpu().numpy(), wantb, rtol=ELBO_RTOL)
+
+
+def test_eval_kernel_degenerate(dev):
+    import torch
+    from bear_amd import kernels
+    e = torch.zeros((0, 5), dtype=torch.int32, device=dev)
+    out = kernels.evaluate(e, torch.zeros((0, 5), dtype=torch.float64, device=dev), [1.0], [1.0]).cpu().numpy()
+    assert out.shape == (7,) and np.all(out == 0)
+    with pytest.raises(Exception):
+        kernels.evaluate(e, None, [1.0], [1.0])
+        kernels.evaluate(torch.zeros((4, 5), dtype=torch.int32, device=dev), None, [1.0], [1.0])
+
+
 def test_planned_full_size_chunks(dev):
     """Bench-scale table: planned == unplanned on the whole table; planned on sampled chunks ==
     oracle; a plan refuses a different buffer."""
