@@ -43,6 +43,7 @@ def make_ar_func_linear(lag, alphabet_size, dtype=torch.float64, device=None, ge
         else:
             z = torch.einsum("...jk,jkl->...l", kmers, mat)
         return torch.softmax(z, dim=-1)
+    ar_func.linear_mat = mat      # bear_net.train: whole step fused in one kernel (bear_dm_linear_f64)
     return ar_func, [mat]
 
 

@@ -49,13 +49,23 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
     acc = [torch.zeros_like(p) for p in params]
     loss, step = 0.0, 1
     out = torch.zeros(2, dtype=torch.float64, device=device)
+    # linear AR function on a DNA/RNA-sized alphabet: forward, ELBO and all gradients in one launch per batch
+    fused_mat = getattr(ar_func, "linear_mat", None)
+    if fused_mat is not None and not (alphabet_size == 4 and lag <= kernels.LINEAR_MAX_LAG and fused_mat is ar_params[0]):
+        fused_mat = None
     for _ in range(data.repeats):
         for k in range(n_batches):
             e = res.batches[k]
             scale = -(num_kmers / e["global_rows"])                    # bear_net.py:190-191 with the global batch
             for p in ar_params:
                 p.grad = None
-            if e["rows"]:
+            if e["rows"] and fused_mat is not None:
+                if "packed" not in e:
+                    e["packed"] = kernels.pack_kmers(e["codes"].contiguous())
+                _, gmat = kernels.dm_linear(res.plan(k, "train", 5), e["packed"], fused_mat.detach(), h_signed.item(),
+                                            train_ar=train_ar, out=out)
+                fused_mat.grad = scale * gmat
+            elif e["rows"]:
                 prior = ar_func(e["codes"]).expand(e["rows"], alphabet_size + 1).contiguous()
                 need_rows = prior.requires_grad
                 if need_rows:     # planned kernel, gradient rows assembled in LDS

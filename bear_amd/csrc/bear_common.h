@@ -34,6 +34,7 @@ struct bear_ws {
   double *eval_partials;    // [eval_blocks][EVL_MAX_OUT] (kernels_eval.h)
   double *eval_out;         // [EVL_MAX_OUT] scratch result vector (bear_bmm_f64)
   int eval_blocks;
+  double *lin_partials;     // [num_cu][LIN_MAX_GRAD] d/d mat partials (kernels_linear.h)
 };
 
 struct bear_params {

@@ -17,6 +17,7 @@
 #include "kernels_sorted.h"
 #include "kernels_plan.h"
 #include "kernels_synth.h"
+#include "kernels_linear.h"
 
 // ------------------------------------------------------------------ C ABI
 extern "C" {
@@ -63,6 +64,13 @@ int bear_ws_create(int device, bear_ws **out) {
       ws->eval_blocks = ws->num_cu * 8;
       if (e == hipSuccess) e = hipMalloc(&ws->eval_partials, sizeof(double) * EVL_MAX_OUT * (size_t)ws->eval_blocks);
       if (e == hipSuccess) e = hipMalloc(&ws->eval_out, sizeof(double) * EVL_MAX_OUT);
+      if (e == hipSuccess) e = hipMalloc(&ws->lin_partials, sizeof(double) * LIN_MAX_GRAD * (size_t)ws->num_cu);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_linear_plan_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_lin));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_linear_plan_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_lin));
       if (e == hipSuccess) {
         // {r_i, -log r_i}: r_i = 1 / midpoint of the i-th mantissa cell of [0.5, 1) (bear_log_tab)
         double tab[2 * BEAR_LOGTAB_N];
@@ -134,6 +142,7 @@ int bear_ws_destroy(bear_ws *ws) {
   (void)hipFree(ws->dbg);
   (void)hipFree(ws->eval_partials);
   (void)hipFree(ws->eval_out);
+  (void)hipFree(ws->lin_partials);
   (void)hipSetDevice(prev);
   delete ws;
   return BEAR_OK;
@@ -532,6 +541,50 @@ int bear_dm_items_f64(bear_ws *ws, const double *x, const uint32_t *c, uint64_t 
   if (blocks > 0x7fffffffull) return BEAR_ERR_INVALID_ARG;
   hipLaunchKernelGGL(dm_items_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, c, n, path,
                      reinterpret_cast<const double2 *>(ws->logtab), D, P);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+// ---- fused linear AR head (kernels_linear.h) -----------------------------------------------------------
+int bear_pack_kmers_u64(const int8_t *codes, uint64_t n_rows, int lag, uint64_t *packed, void *stream) {
+  if (lag < 1 || lag > LIN_MAX_LAG) return BEAR_ERR_INVALID_ARG;
+  if (n_rows == 0) return BEAR_OK;
+  if (!codes || !packed) return BEAR_ERR_INVALID_ARG;
+  const uint64_t blocks = (n_rows + 255) / 256;
+  if (blocks > 0x7fffffffull) return BEAR_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(pack_kmers_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), codes, n_rows, lag,
+                     reinterpret_cast<unsigned long long *>(packed));
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code,
+                       const double *mat, int lag, uint64_t n_rows, double h_signed, double eps, int train_ar,
+                       double *out, double *grad_mat, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!plan || !out || !grad_mat || !mat || lag < 1 || lag > LIN_MAX_LAG) return BEAR_ERR_INVALID_ARG;
+  if (plan->counts != counts || plan->n_rows != n_rows || plan->ncol != 5 || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
+  if ((n_rows && !kmer_code) || misaligned(kmer_code) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  if (!(eps >= 0.0) || !isfinite(h_signed)) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bear_params prm;
+  memset(&prm, 0, sizeof(prm));
+  prm.inv_h = 1.0 / exp(h_signed);
+  prm.eps = eps;
+  const int grid = grid_plan(ws, plan->n_tiles);
+  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  if (train_ar)
+    hipLaunchKernelGGL(dm_linear_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
+                       reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, prm, plan_view(plan), lt, ws->partials,
+                       ws->lin_partials);
+  else
+    hipLaunchKernelGGL(dm_linear_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
+                       reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, prm, plan_view(plan), lt, ws->partials,
+                       ws->lin_partials);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
+  hipLaunchKernelGGL(linear_finalize_kernel, dim3((lag * 25 + 255) / 256), dim3(256), 0, s, ws->lin_partials, grid, lag * 25,
+                     grad_mat);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }

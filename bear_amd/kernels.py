@@ -188,6 +188,41 @@ def dm_items(x, c, path=0, ws=None):
     return D, P
 
 
+LINEAR_MAX_LAG = 21   # LIN_MAX_LAG of kernels_linear.h (3 bits per letter in one 64-bit word)
+
+
+def pack_kmers(codes):
+    """int8 code matrix [n, lag] (core.encode_kmers) -> packed contexts, int64 storage [n] (3 bits per letter)."""
+    if not (codes.is_cuda and codes.dtype == torch.int8 and codes.dim() == 2 and codes.is_contiguous()):
+        raise ValueError("codes must be a contiguous CUDA int8 tensor [n, lag]")
+    out = torch.empty(codes.shape[0], dtype=torch.int64, device=codes.device)
+    with torch.cuda.device(codes.device):
+        st = _lib.lib().bear_pack_kmers_u64(_ptr(codes), codes.shape[0], codes.shape[1], _ptr(out), _stream())
+    _lib.check(st, "bear_pack_kmers_u64")
+    return out
+
+
+def dm_linear(plan, kmer_code, mat, h_signed, eps=EPSILON, train_ar=False, out=None):
+    """One launch of ``bear_dm_linear_f64``: the bear_net step with the linear AR function fused on the plan.
+    Returns (out[2] = {sum LL, d/dh_signed}, grad_mat [lag,5,5] = d sum LL / d mat)."""
+    n = plan.counts.shape[0]
+    if not (kmer_code.is_cuda and kmer_code.dtype == torch.int64 and kmer_code.dim() == 1 and kmer_code.is_contiguous()
+            and kmer_code.shape[0] == n):
+        raise ValueError("kmer_code must be a contiguous CUDA int64 tensor [n_rows] (pack_kmers)")
+    if kmer_code.data_ptr() % 16:
+        kmer_code = kmer_code.clone()
+    if not (mat.is_cuda and mat.dtype == torch.float64 and mat.dim() == 3 and mat.shape[1:] == (5, 5) and mat.is_contiguous()):
+        raise ValueError("mat must be a contiguous CUDA float64 tensor [lag, 5, 5]")
+    if out is None:
+        out = torch.empty(2, dtype=torch.float64, device=mat.device)
+    grad = torch.empty_like(mat)
+    with torch.cuda.device(mat.device):
+        st = _lib.lib().bear_dm_linear_f64(plan.ws.handle, plan._h, _ptr(plan.counts), _ptr(kmer_code), _ptr(mat), mat.shape[0], n,
+                                           float(h_signed), float(eps), int(bool(train_ar)), _ptr(out), _ptr(grad), _stream())
+    _lib.check(st, "bear_dm_linear_f64")
+    return out, grad
+
+
 def _host_f64(values):
     a = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64)))
     return a, a.ctypes.data_as(ctypes.c_void_p)

@@ -122,6 +122,24 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
                          int train_ar, double *out, void *stream);
 
 /*
+ * The whole bear_net training step for the linear AR function, fused on a plan: replaces
+ * ar_func = make_ar_func_linear(...) (bear_model/ar_funcs.py:23-46), _train_step's forward and
+ * grad_tape.gradient(loss, [h_signed, mat]) (bear_model/bear_net.py:146-197).
+ *   kmer_code [dev] uint64 [n_rows]   packed contexts, letter l in bits [3l, 3l+3): 0..3 letters, 4 = start
+ *                                     symbol '[', 5 = any other character (all-zero one-hot row, core.py:173);
+ *                                     positions >= lag hold 5.  bear_pack_kmers_u64 builds it from the int8
+ *                                     code matrix [n_rows, lag] (values outside 0..4 -> 5).  lag <= 21.
+ *   mat       [dev] double [lag,5,5]  the AR parameter
+ *   out       [dev] double [2]        { sum LL, d sum LL / d h_signed }
+ *   grad_mat  [dev] double [lag,5,5]  d sum LL / d mat (overwritten)
+ * Reads 8 bytes per context plus the plan; writes nothing per context.
+ */
+int bear_pack_kmers_u64(const int8_t *codes, uint64_t n_rows, int lag, uint64_t *packed, void *stream);
+int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code,
+                       const double *mat, int lag, uint64_t n_rows, double h_signed, double eps, int train_ar,
+                       double *out, double *grad_mat, void *stream);
+
+/*
  * Held-out evaluation, one pass over a row range: replaces _evaluation_step of bear_model/bear_net.py:323-371
  * (and its bear_ref twin, bear_ref.py:391-446, with prior = the reference-mixed AR rows) and, with n_h > 1,
  * one batch of h_scan (bear_net.py:465-531).

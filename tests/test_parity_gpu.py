@@ -357,6 +357,51 @@ def test_eval_kernel_degenerate(dev):
         kernels.evaluate(torch.zeros((4, 5), dtype=torch.int32, device=dev), None, [1.0], [1.0])
 
 
+def _linear_oracle(tr, codes, mat, h_s, train_ar):
+    """sum LL, d/dh_s and d/d mat through the oracle: prior rows from ar_func_linear, gradient rows from the C
+    oracle, softmax + einsum backward in NumPy (ar_funcs.py:41-45)."""
+    lag = codes.shape[1]
+    onehot = np.zeros((len(codes), lag, 5))
+    for l in range(lag):
+        ok = codes[:, l] >= 0
+        onehot[np.nonzero(ok)[0], l, codes[ok, l]] = 1.0
+    f = o.ar_func_linear(onehot, mat)
+    out, G = co.dm_prior(tr, f, h_s, train_ar=train_ar, want_grad=True, nthreads=4)
+    gz = f * (G - (f * G).sum(-1, keepdims=True))
+    return out, np.einsum("njk,nl->jkl", onehot, gz)
+
+
+@pytest.mark.parametrize("case", ["sparse", "sparse_hot", "dense", "edge", "ysd1"])
+@pytest.mark.parametrize("lag", [5, 13, 21])
+def test_fused_linear_head_parity(case, lag, dev, ysd1):
+    """bear_dm_linear_f64: ELBO, d/dh and d/d mat of the whole linear-head step against the oracle chain
+    (ar_func_linear -> DM gradient rows -> softmax/einsum backward), BEAR and multinomial mode, incl. unknown
+    letters and the start symbol."""
+    import torch
+    from bear_amd import kernels
+    if case == "ysd1":
+        tr = ysd1[1][:, 0].astype(np.uint32)
+    else:
+        tr = CASES_REF[case]()[0]
+    n = len(tr)
+    rng = np.random.default_rng(lag * 7 + n)
+    codes = rng.integers(0, 4, size=(n, lag)).astype(np.int8)
+    codes[rng.random((n, lag)) < 0.03] = 4        # start symbol
+    codes[rng.random((n, lag)) < 0.02] = -1       # unknown letter: all-zero one-hot row (core.py:173)
+    mat = rng.normal(size=(lag, 5, 5)) * 0.4
+    d_tr = _to_dev(tr, dev)
+    plan = kernels.Plan(d_tr, 5)
+    packed = kernels.pack_kmers(torch.from_numpy(codes).to(dev))
+    d_mat = torch.from_numpy(mat).to(dev)
+    for h_s, ar in [(0.0, False), (-2.5, False), (1.5, False), (0.3, True)]:
+        want, wantg = _linear_oracle(tr, codes, mat, h_s, ar)
+        got, g = kernels.dm_linear(plan, packed, d_mat, h_s, train_ar=ar)
+        got, g = got.cpu().numpy(), g.cpu().numpy()
+        _close(got[0], want[0], ELBO_RTOL)
+        _close(got[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
+        assert np.allclose(g, wantg, rtol=1e-9, atol=1e-9 * np.abs(wantg).max()), (case, lag, h_s, ar, np.abs(g - wantg).max())
+
+
 def test_planned_full_size_chunks(dev):
     """Bench-scale table: planned == unplanned on the whole table; planned on sampled chunks ==
     oracle; a plan refuses a different buffer."""
