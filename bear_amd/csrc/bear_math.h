@@ -185,6 +185,25 @@ __device__ __forceinline__ bear_dp bear_dm_item_fast(double x, double c, const d
   return o;
 }
 
+// ---- exp(z) for z <= 0 on a 128-entry table -----------------------------------------
+// z = k ln2/128 + r, |r| <= ln2/256: exp(z) = 2^(k >> 7) * tab[k & 127] * (1 + r + ... + r^5/120); tab[j] = 2^(j/128).
+// Two-term Cody-Waite reduction (fdlibm's ln2 split, scaled by 1/128).  ~1 ulp; flushes to 0 below -700.
+#define BEAR_EXPTAB_N 128
+__device__ __forceinline__ double bear_exp_tab(double z, const double *__restrict__ tab) {
+  if (z < -700.0) return 0.0;
+  const double kf = __builtin_rint(z * 184.66496523378731);  // 128 / ln 2
+  double r = __builtin_fma(kf, -0x1.62e42fee00000p-8, z);
+  r = __builtin_fma(kf, -0x1.a39ef35793c76p-40, r);
+  const int ki = (int)kf;
+  const double t = tab[ki & (BEAR_EXPTAB_N - 1)];
+  double p = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = __builtin_fma(r, p, 1.0 / 6.0);
+  p = __builtin_fma(r, p, 0.5);
+  p = __builtin_fma(r, p, 1.0);
+  const double v = __builtin_fma(t, r * p, t);
+  return __longlong_as_double(__double_as_longlong(v) + ((long long)(ki >> 7) << 52));
+}
+
 // ---- reductions -----------------------------------------------------------------
 __device__ __forceinline__ double bear_wave_sum(double v) {
 #pragma unroll

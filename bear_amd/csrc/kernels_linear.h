@@ -16,6 +16,8 @@
 //   C  one thread per context with s != 0: -f_b s into the gradient pair tables (LDS fp64 atomics).
 // The context terms -D(A, n) come from the plan's histogram (A = u + 5 eps: softmax rows are normalised).
 // After the last tile the pair tables fold into d/d mat partials; a finalize kernel sums the blocks in fixed order.
+// Measured at 1e8 contexts, lag 13 (3.9 ms): pass C 1.6 ms and the item scatter 0.6 ms run at the LDS fp64-atomic
+// rate (~2.5 lane-atomics per clock per CU, scripts/dev/lds_atomic_bench.hip), the softmax exponentials 0.2 ms.
 // Note: LDS floating-point atomics make the summation order inside a block run-dependent (last-bit jitter in
 // grad_mat); the ELBO and d/dh sums keep the fixed-order reduction of the other kernels.
 #pragma once
@@ -40,6 +42,7 @@ struct pln_lds_lin {
   double2 logtab[BEAR_LOGTAB_N];
   double tabD[SRT_NKEY];
   double tabP[SRT_NKEY];
+  double exptab[BEAR_EXPTAB_N];
   uint32_t ticket[2];
 };
 static_assert(sizeof(pln_lds_lin) <= 160 * 1024, "linear-head kernel: LDS budget");
@@ -66,7 +69,7 @@ __device__ __forceinline__ uint32_t lin_combo(unsigned long long code, int g) {
 }
 
 // softmax row of one context from the pair tables
-__device__ __forceinline__ void lin_row(const double *T, unsigned long long code, int ng, double (&f)[5]) {
+__device__ __forceinline__ void lin_row(const double *T, const double *exptab, unsigned long long code, int ng, double (&f)[5]) {
   double z[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int g = 0; g < ng; ++g) {
     const double *t = T + g * LIN_GSTRIDE + lin_combo(code, g) * 5u;
@@ -79,10 +82,10 @@ __device__ __forceinline__ void lin_row(const double *T, unsigned long long code
   double s = 0.0;
 #pragma unroll
   for (int b = 0; b < 5; ++b) {
-    f[b] = exp(z[b] - m);
+    f[b] = bear_exp_tab(z[b] - m, exptab);
     s += f[b];
   }
-  const double r = 1.0 / s;
+  const double r = bear_rcp(s);
 #pragma unroll
   for (int b = 0; b < 5; ++b) f[b] *= r;
 }
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     S.ticket[0] = 0;
     S.ticket[1] = 0;
   }
+  if (tid < BEAR_EXPTAB_N) S.exptab[tid] = exp2((double)tid * (1.0 / BEAR_EXPTAB_N));
   // pair tables: T[g][a * 6 + a'][b] = mat[2g][a][b] (a < 5) + mat[2g+1][a'][b] (a' < 5, position inside the lag)
   for (int k = tid; k < ng * LIN_GSTRIDE; k += PLN_THREADS) {
     const int g = k / LIN_GSTRIDE, r = k - g * LIN_GSTRIDE, combo = r / 5, b = r - combo * 5;
@@ -138,7 +142,10 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   // Lanes walk the groups in rotated order (lane i starts at group i mod ng): at any moment the 64 atomics of
   // a wave spread over all ng tables instead of colliding inside one.
   const int g_rot = (int)(lane % (uint32_t)ng);
+  // Only letters b < 4 are accumulated: the softmax gradient of a context sums to zero over b, so the last
+  // column is minus the sum of the others (restored in the fold below).
   auto scatter1 = [&](unsigned long long code, uint32_t b, double w) {
+    if (b == 4u) return;
     int g = g_rot;
     for (int k = 0; k < ng; ++k) {
       atomicAdd(&S.GT[g * LIN_GSTRIDE + lin_combo(code, g) * 5u + b], w);
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     // ---- A: softmax rows of the tile
     for (uint32_t row = tid; row < rows; row += PLN_THREADS) {
       double f[5];
-      lin_row(S.T, B.codes[row], ng, f);
+      lin_row(S.T, S.exptab, B.codes[row], ng, f);
 #pragma unroll
       for (int b = 0; b < 5; ++b) S.pri[row * 5 + b] = f[b];
       S.srow[row] = 0.0;
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
         for (int k = 0; k < ng; ++k) {
           double *gt = &S.GT[g * LIN_GSTRIDE + lin_combo(code, g) * 5u];
 #pragma unroll
-          for (int b = 0; b < 5; ++b) atomicAdd(&gt[b], fs[b]);
+          for (int b = 0; b < 4; ++b) atomicAdd(&gt[b], fs[b]);
           g = g + 1 == ng ? 0 : g + 1;
         }
       }
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     const uint32_t b = (uint32_t)(h.off - row * 5u);
     const unsigned long long code = kmer_code[row];
     double f[5];
-    lin_row(S.T, code, ng, f);
+    lin_row(S.T, S.exptab, code, ng, f);
     double q;
     if (AR) {
       const double pp = f[b] + eps;
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     for (int g = 0; g < ng; ++g) {
       double *gt = &S.GT[g * LIN_GSTRIDE + lin_combo(code, g) * 5u];
 #pragma unroll
-      for (int bb = 0; bb < 5; ++bb) atomicAdd(&gt[bb], (bb == (int)b ? w : 0.0) - f[bb] * w);
+      for (int bb = 0; bb < 4; ++bb) atomicAdd(&gt[bb], (bb == (int)b ? w : 0.0) - f[bb] * w);
     }
   }
   for (uint64_t i = gtid; !AR && i < pv.n_heavy_row; i += gsz) {
@@ -293,7 +300,8 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     double s = 0.0;
     for (int p = 0; p < 6; ++p) {
       const int combo = (l & 1) ? p * 6 + a : a * 6 + p;
-      s += S.GT[g * LIN_GSTRIDE + combo * 5 + b];
+      const double *gt = &S.GT[g * LIN_GSTRIDE + combo * 5];
+      s += b < 4 ? gt[b] : -((gt[0] + gt[1]) + (gt[2] + gt[3]));
     }
     grad_partials[(size_t)blockIdx.x * LIN_MAX_GRAD + k] = s;
   }
