@@ -583,7 +583,7 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
                        reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, prm, plan_view(plan), lt, ws->partials,
                        ws->lin_partials);
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
-  hipLaunchKernelGGL(linear_finalize_kernel, dim3((lag * 25 + 255) / 256), dim3(256), 0, s, ws->lin_partials, grid, lag * 25,
+  hipLaunchKernelGGL(linear_finalize_kernel, dim3((lag * 25 + 3) / 4), dim3(256), 0, s, ws->lin_partials, grid, lag * 25,
                      grad_mat);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
@@ -597,7 +597,7 @@ static int launch_eval(bear_ws *ws, const uint32_t *test, const uint32_t *train,
   const int grid = (int)(tiles < (uint64_t)ws->eval_blocks ? (tiles ? tiles : 1) : (uint64_t)ws->eval_blocks);
   hipLaunchKernelGGL(eval_kernel, dim3(grid), dim3(EVL_THREADS), 0, s, test, train, prior, n_rows, A,
                      reinterpret_cast<const double2 *>(ws->logtab), ws->eval_partials);
-  hipLaunchKernelGGL(eval_finalize_kernel, dim3(1), dim3(256), 0, s, ws->eval_partials, grid, n_out, out);
+  hipLaunchKernelGGL(eval_finalize_kernel, dim3((n_out + 3) / 4), dim3(256), 0, s, ws->eval_partials, grid, n_out, out);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }

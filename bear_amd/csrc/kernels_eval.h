@@ -151,12 +151,13 @@ __global__ __launch_bounds__(EVL_THREADS) void eval_kernel(const uint32_t *__res
     partials[(size_t)blockIdx.x * EVL_MAX_OUT + k] = (s_acc[0][k] + s_acc[1][k]) + (s_acc[2][k] + s_acc[3][k]);
 }
 
-// fixed-order sum of the block partials, one thread per output
+// fixed-order sum of the block partials: one wave per output (lane-strided partial sums, then the shuffle tree)
 __global__ __launch_bounds__(256) void eval_finalize_kernel(const double *__restrict__ partials, int n_blocks, int n_out,
                                                             double *__restrict__ out) {
-  for (int k = threadIdx.x; k < n_out; k += 256) {
-    double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += partials[(size_t)b * EVL_MAX_OUT + k];
-    out[k] = s;
-  }
+  const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n_out) return;
+  double s = 0.0;
+  for (int b = lane; b < n_blocks; b += 64) s += partials[(size_t)b * EVL_MAX_OUT + k];
+  s = bear_wave_sum(s);
+  if (lane == 0) out[k] = s;
 }

@@ -308,12 +308,13 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   block_store_partials<2>(acc, partials);
 }
 
-// fixed-order sum of the per-block d/d mat partials
+// fixed-order sum of the per-block d/d mat partials: one wave per entry
 __global__ __launch_bounds__(256) void linear_finalize_kernel(const double *__restrict__ grad_partials, int n_blocks, int n_grad,
                                                               double *__restrict__ grad_mat) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (k >= n_grad) return;
   double s = 0.0;
-  for (int b = 0; b < n_blocks; ++b) s += grad_partials[(size_t)b * LIN_MAX_GRAD + k];
-  grad_mat[k] = s;
+  for (int b = lane; b < n_blocks; b += 64) s += grad_partials[(size_t)b * LIN_MAX_GRAD + k];
+  s = bear_wave_sum(s);
+  if (lane == 0) grad_mat[k] = s;
 }

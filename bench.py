@@ -137,6 +137,36 @@ def main():
         torch.cuda.synchronize()
         norm_ms = e0.elapsed_time(e1) / 10
 
+    extra = {}
+    if rank == 0 and world == 1:  # the rows of SURVEY 8f built on the same kernels: kernel-only times, 1 GPU
+        def timed(fn, reps):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        ms = timed(lambda: kernels.dm_prior_planned(plans["net"], prior, h_s, want_grad=True), 5)
+        extra["net_with_gradient_rows"] = {"kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3)}
+        ms = timed(lambda: kernels.dm_prior_planned(plans["net"], prior, h_s, train_ar=True), 5)
+        extra["net_multinomial_mode"] = {"kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3)}
+        lag = 13
+        mat = 0.05 * torch.randn(lag, 5, 5, dtype=torch.float64, device=dev, generator=torch.Generator(dev).manual_seed(10))
+        packed = kernels.pack_kmers(torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev,
+                                                  generator=torch.Generator(dev).manual_seed(SEED)))
+        ms = timed(lambda: kernels.dm_linear(plans["net"], packed, mat, h_s), 5)
+        extra["linear_head_fused_step"] = {"lag": lag, "kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3),
+                                           "note": "forward + ELBO + d/dh + d/dmat from 8-byte packed k-mers"}
+        del packed
+        m = min(n, 20_000_000)
+        test = kernels.synth_counts(SEED, row0, m, dev, want=("test",))["test"]
+        ms = timed(lambda: kernels.evaluate(test, prior[:m], [1.0], [0.1, 1.0, 10.0], t["train"][:m]), 2)
+        extra["heldout_evaluation"] = {"contexts": m, "models": "1 h + AR + 3 van_reg", "kernel_ms": ms,
+                                       "contexts_per_s": m / (ms * 1e-3)}
+        del test
+
     total = n * world
     value = total * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
@@ -200,6 +230,7 @@ def main():
                 },
                 "net_prior_normalized_asserted": None if norm_ms is None else {
                     "kernel_ms": norm_ms, "contexts_per_s_per_gpu": n / (norm_ms * 1e-3)},
+                **extra,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

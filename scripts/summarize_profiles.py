@@ -17,6 +17,16 @@ if ks:
         out_md.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['Percentage']} |")
     out_md.append("")
 traffic = {}
+def kernel_key(k):
+    """bench.py workload name of a planned kernel instantiation."""
+    if "eval_kernel" in k: return "heldout_eval"
+    if "dm_linear" in k: return "linear_head"
+    if "plan_grad_kernel" in k: return "net_grad"
+    if "dm_ref" in k: return "ref_ar" if "<true>" in k else "ref"
+    if "<true, true>" in k: return "net_ar"
+    if "<true, false>" in k: return "net_norm"
+    if "<false, false>" in k: return "net"
+    return k[:24]
 def pmc(kind):
     fs = glob.glob(os.path.join(src, f"{tag}_{kind}", "**", "*_counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -29,10 +39,10 @@ for kind in ("fetch", "write", "sq"):
     if not agg: continue
     out_md += [f"## PMC pass: {kind}", "", "| kernel | counter | mean per launch |", "|---|---|---|"]
     for k, v in agg.items():
-        if "plan_kernel" not in k and "sorted" not in k: continue
+        if "plan_kernel" not in k and "plan_grad_kernel" not in k and "sorted" not in k and "eval_kernel" not in k: continue
         for c, x in v.items():
             out_md.append(f"| `{k[:40]}` | {c} | {sum(x)/len(x):.0f} |")
-            name = "ref" if "dm_ref" in k else ("net_norm" if "true>" in k else "net")
+            name = kernel_key(k)
             if c == "FETCH_SIZE":
                 # FETCH_SIZE is in KiB and, on gfx950, counts a wide coalesced stream at half its bytes
                 # (MI355X_MICROARCH.md, HBM): bytes = FETCH_SIZE * 1024 * 2
@@ -42,7 +52,8 @@ for kind in ("fetch", "write", "sq"):
     out_md.append("")
 for name, d in traffic.items():
     d["bytes_per_launch"] = d.get("fetch_bytes_per_launch", 0) + d.get("write_bytes_per_launch", 0)
-    d["contexts_per_launch"] = 100000000  # bench.py default (--contexts 1e8); bench.py scales linearly for other sizes
+    # bench.py defaults (--contexts 1e8; the evaluation extra runs on the first 2e7); bench.py scales linearly for other sizes
+    d["contexts_per_launch"] = 20000000 if name == "heldout_eval" else 100000000
 if traffic:
     json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
