@@ -35,11 +35,13 @@ def make_ar_func_linear(lag, alphabet_size, dtype=torch.float64, device=None, ge
 
     def ar_func(kmers):
         if _is_codes(kmers):
+            # sum_l mat[l, a_l]: an embedding-bag over the flattened [lag * (A+1), A+1] table (unknown letters
+            # carry weight 0) -- no [.., lag, A+1] intermediate, and a dense scatter-add backward
             idx = kmers.long()
-            pos = torch.arange(lag, device=idx.device)
-            rows = mat[pos, idx.clamp(min=0)]                        # [..., lag, A+1]
-            rows = rows * (idx >= 0).unsqueeze(-1).to(rows.dtype)
-            z = rows.sum(-2)
+            flat = idx.clamp(min=0) + (alphabet_size + 1) * torch.arange(lag, device=idx.device)
+            z = F.embedding_bag(flat.reshape(-1, lag), mat.reshape(lag * (alphabet_size + 1), alphabet_size + 1), mode="sum",
+                                per_sample_weights=(idx >= 0).to(mat.dtype).reshape(-1, lag))
+            z = z.reshape(idx.shape[:-1] + (alphabet_size + 1,))
         else:
             z = torch.einsum("...jk,jkl->...l", kmers, mat)
         return torch.softmax(z, dim=-1)
@@ -67,14 +69,14 @@ def make_ar_func_cnn(lag, alphabet_size, filter_width=8, num_filters=30, kmer_la
 
     def conv(data):
         if _is_codes(data):
+            # conv1d VALID over a one-hot input = for every output position the sum of filter_width rows of the
+            # flattened [filter_width * (A+1), nf] filter table: one embedding-bag (dense scatter-add backward)
             idx = data.long()
-            valid = (idx >= 0).to(filters.dtype)
-            idx = idx.clamp(min=0)
-            out = 0
-            for w in range(filter_width):   # conv1d VALID over a one-hot input = gather-sum
-                sl = idx[..., w:w + P]
-                out = out + filters[w][sl] * valid[..., w:w + P].unsqueeze(-1)
-            return out                                   # [..., P, nf]
+            win = idx.unfold(-1, filter_width, 1)                                  # [..., P, fw] windows
+            flat = win.clamp(min=0) + A1 * torch.arange(filter_width, device=idx.device)
+            out = F.embedding_bag(flat.reshape(-1, filter_width), filters.reshape(filter_width * A1, num_filters), mode="sum",
+                                  per_sample_weights=(win >= 0).to(filters.dtype).reshape(-1, filter_width))
+            return out.reshape(idx.shape[:-1] + (P, num_filters))                 # [..., P, nf]
         x = data.reshape((-1,) + data.shape[-2:]).transpose(1, 2)          # [B, A1, lag]
         y = F.conv1d(x, filters.permute(2, 1, 0))                          # [B, nf, P]
         return y.transpose(1, 2).reshape(data.shape[:-2] + (P, num_filters))

@@ -71,11 +71,11 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
         params, h_signed, ar_func = _create_params(lag, alphabet_size, make_ar_func, af_kwargs, dtype, device)
     else:
         params, h_signed, ar_func = change_scope_params(lag, alphabet_size, make_ar_func, af_kwargs, params_restart, dtype, device)
-    if not ar_func.net_is_stop:
-        raise NotImplementedError("bear_ref on MI355X currently fuses the stop net function (bear_stop_*.cfg); "
-                                  "other net functions are a next row of SURVEY.md section 8f")
     tau_signed, nu_signed = params[1], params[2]
     optimizer = _train.make_optimizer(optimizer_name, params, learning_rate)
+    if not ar_func.net_is_stop:
+        return _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_ar, acc_steps, writer, loss_save,
+                              ds_loc, ds_loc_ref, device)
     res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device)
     n_batches = len(res.batches)
     acc = torch.zeros(3, dtype=torch.float64)
@@ -101,6 +101,52 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
                 grads = [None if train_ar else acc[0].clone(), acc[1].clone(), acc[2].clone()]  # AR mode: h gets no gradient
                 optimizer.apply_gradients(grads)
                 acc.zero_()
+                loss = 0.0
+            step += 1
+    return params, h_signed, ar_func
+
+
+def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_ar, acc_steps, writer, loss_save,
+                   ds_loc, ds_loc_ref, device):
+    """bear_ref.train with a parametrised net function (linear, cnn; bear_ref.py:63-68): the mixed prior rows
+    ``(nw net(kmers) + jukes_cantor(ref, tau)) / (nw + 1)`` are formed by torch ops, the planned kernel returns
+    the ELBO, d/dh and the gradient rows, and autograd carries the rows back to tau, the net weight and the
+    net parameters -- the same loop as bear_net.train with two more parameters."""
+    rest = params[1:]
+    res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device, want_codes=True)
+    acc = [torch.zeros_like(p) for p in params]
+    loss, step = 0.0, 1
+    out = torch.zeros(2, dtype=torch.float64, device=device)
+    for _ in range(data.repeats):
+        for k, e in enumerate(res.batches):
+            scale = -(num_kmers / e["global_rows"])
+            for p in rest:
+                p.grad = None
+            if e["rows"]:
+                if "ref_in" not in e:
+                    e["ref_in"] = _ref_input(e["ref"])
+                prior = ar_func(e["codes"], e["ref_in"]).contiguous()
+                _, grad_rows = kernels.dm_prior_planned(res.plan(k, "train", 5), prior.detach(), h_signed.item(), out=out,
+                                                        want_grad=True, train_ar=train_ar)
+                prior.backward(scale * grad_rows)
+            else:
+                out.zero_()
+            flat, unpack = dist.pack([out] + [p.grad if p.grad is not None else torch.zeros_like(p) for p in rest])
+            dist.allreduce_sum_(flat)
+            parts = unpack(flat)
+            loss += scale * parts[0][0].item()
+            if not train_ar:
+                acc[0] += scale * parts[0][1]
+            for a, g in zip(acc[1:], parts[1:]):
+                a += g.to(a.dtype)
+            if step % acc_steps == 0:
+                if writer is not None:
+                    writer.add_scalar("elbo", -loss / acc_steps, step)
+                if loss_save is not None:
+                    loss_save.append(-loss / acc_steps)
+                optimizer.apply_gradients([None if train_ar else acc[0]] + acc[1:])
+                for a in acc:
+                    a.zero_()
                 loss = 0.0
             step += 1
     return params, h_signed, ar_func

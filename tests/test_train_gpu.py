@@ -58,6 +58,53 @@ def test_bear_ref_train_matches_oracle_loop(train_ar, ysd1):
     assert np.allclose(ar_func(oh, ref_in).detach().cpu().numpy(), want, rtol=1e-12)
 
 
+@pytest.mark.parametrize("train_ar", [False, True])
+def test_bear_ref_linear_net_matches_oracle_loop(train_ar, ysd1):
+    """bear_ref.train with a parametrised net function (bear_ref.py:63-68 with make_ar_func_linear): losses and
+    parameters against a CPU replica (torch autograd through the same mixing formula, likelihood and gradient
+    rows from the oracle)."""
+    _, counts = ysd1
+    data = dataloader.dataloader(YSD1, "dna", 700, 3)
+    torch.manual_seed(5)
+    _, init = ar_funcs.make_ar_func_linear(5, 4)
+    mat0 = init[0].detach().numpy().copy()
+    restart = [np.array(0.2), np.array(np.log(1 / 30)), np.array(-1.0), mat0]
+    loss_save = []
+    params, h_signed, ar_func = bear_ref.train(data.repeat(2), 1365, 2, 0, 2, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01,
+                                               "Adam", train_ar, params_restart=restart, loss_save=loss_save)
+    f_cpu, (mat,) = ar_funcs.make_ar_func_linear(5, 4)
+    with torch.no_grad():
+        mat.copy_(torch.as_tensor(mat0))
+    tau_s = torch.tensor(np.log(1 / 30), dtype=torch.float64, requires_grad=True)
+    nu_s = torch.tensor(-1.0, dtype=torch.float64, requires_grad=True)
+    h = np.array(0.2)
+    flat = [h, tau_s.detach().numpy(), nu_s.detach().numpy(), mat.detach().numpy()]
+    ms, vs = [np.zeros_like(x) for x in flat], [np.zeros_like(x) for x in flat]
+    codes = torch.as_tensor(data.codes())
+    want_loss, t = [], 0
+    for _ in range(2):
+        for a in range(0, 1365, 700):
+            b = min(a + 700, 1365)
+            for q in (tau_s, nu_s, mat):
+                q.grad = None
+            ref_in = torch.as_tensor(o.ref_input(counts[a:b, 2]))
+            nw, tau = torch.exp(nu_s), torch.exp(tau_s)
+            prior = (nw * f_cpu(codes[a:b]) + bear_ref._counts_to_probs(ref_in, tau, 4)) / (nw + 1)
+            r = o.bear_net_step(counts[a:b, 0], prior.detach().numpy(), float(h), train_ar=train_ar)
+            scale = -(1365 / (b - a))
+            prior.backward(torch.as_tensor(scale * r["d_prior"]))
+            want_loss.append(-scale * r["ll"])
+            t += 1
+            if not train_ar:
+                keras_adam_np(h, np.array(scale * r["d_h_signed"]), ms[0], vs[0], t)
+            for i, q in enumerate((tau_s, nu_s, mat)):
+                keras_adam_np(q.detach().numpy(), q.grad.numpy(), ms[i + 1], vs[i + 1], t)
+    assert np.allclose(loss_save, want_loss, rtol=1e-9)
+    assert np.isclose(params[0].item(), float(h), rtol=1e-7, atol=1e-9)
+    for got, want in zip(params[1:], (tau_s, nu_s, mat)):
+        assert np.allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-6, atol=1e-8)
+
+
 @pytest.mark.parametrize("name,kw,train_ar", [("linear", {}, False), ("linear", {}, True), ("cnn", {"filter_width": 3, "num_filters": 5}, False)])
 def test_bear_net_train_matches_oracle_loop(name, kw, train_ar, ysd1):
     _, counts = ysd1
