@@ -19,6 +19,12 @@
 #include "kernels_synth.h"
 #include "kernels_linear.h"
 
+#ifdef PLN_STAMPS  // developer build: per-wave phase timers of dm_prior_plan_kernel land in ws->dbg
+#define PLN_DBG_ARG , ws->dbg
+#else
+#define PLN_DBG_ARG
+#endif
+
 // ------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -361,7 +367,9 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   p->n_tiles = tiles.size();
   const uint64_t stream_bytes = off16 * 16 + 1024;  // slack: a DMA piece may be issued for a partial KiB
   for (int k = 0; k < 3; ++k) p->n_heavy[k] = h_cnt[k];
-  if (e == hipSuccess) e = hipMalloc(&p->tiles, sizeof(pln_tile) * (tiles.size() + 1));
+  // + PLN_DESC_PAD zeroed descriptors: the kernels fetch descriptors 32 at a time (1 KiB LDS-DMA pieces)
+  if (e == hipSuccess) e = hipMalloc(&p->tiles, sizeof(pln_tile) * (tiles.size() + PLN_DESC_PAD));
+  if (e == hipSuccess) e = hipMemset(p->tiles, 0, sizeof(pln_tile) * (tiles.size() + PLN_DESC_PAD));
   if (e == hipSuccess) e = hipMalloc(&p->stream, stream_bytes);
   if (e == hipSuccess) e = hipMemset(p->stream, 0, stream_bytes);
   if (e == hipSuccess && h_cnt[0]) e = hipMalloc(&p->heavy_col, sizeof(pln_heavy_col) * h_cnt[0]);
@@ -443,13 +451,13 @@ int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *c
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   if (train_ar)
     hipLaunchKernelGGL((dm_prior_plan_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
-                       plan_view(plan), lt, ws->partials);
+                       plan_view(plan), lt, ws->partials PLN_DBG_ARG);
   else if (prior_normalized)
     hipLaunchKernelGGL((dm_prior_plan_kernel<true, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
-                       plan_view(plan), lt, ws->partials);
+                       plan_view(plan), lt, ws->partials PLN_DBG_ARG);
   else
     hipLaunchKernelGGL((dm_prior_plan_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
-                       plan_view(plan), lt, ws->partials);
+                       plan_view(plan), lt, ws->partials PLN_DBG_ARG);
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
   HIP_TRY(hipGetLastError());

@@ -54,6 +54,11 @@ struct pln_tile {
   uint64_t pad;
 };
 static_assert(sizeof(pln_tile) == 32, "tile descriptors are fetched with one s_load_dwordx8");
+#ifndef PLN_DMA_WAVES
+#define PLN_DMA_WAVES 2                     // waves of each block that only stream tiles into LDS (see dm_prior_plan_kernel)
+#endif
+#define PLN_DESC_CHUNK 32                   // descriptors per 1 KiB LDS-DMA piece
+#define PLN_DESC_PAD (2 * PLN_DESC_CHUNK)   // zeroed descriptors behind the last tile (plan allocation)
 
 struct pln_layout {  // byte offsets inside a tile's block (all multiples of 16)
   uint32_t nrow, items, hoff, hcnt, hrow, hn, end;
@@ -280,6 +285,14 @@ __device__ __forceinline__ uint32_t pln_dma(void *lds, const void *src, uint32_t
   return issued;
 }
 
+// One 1 KiB piece (`piece` = KiB index inside a slab of `bytes` bytes, multiple of 16) as a single DMA instruction.
+__device__ __forceinline__ void pln_dma_piece(void *lds, const void *src, uint32_t bytes, uint32_t piece, uint32_t lane) {
+  const uint32_t m = srt_uniform((uint32_t)(uintptr_t)lds + (piece << 10));
+  const unsigned char *g = static_cast<const unsigned char *>(src) + (piece << 10) + lane * 16u;
+  if ((piece << 10) + lane * 16u < bytes)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m) : "memory", "m0");
+}
+
 // Waits until at most `younger` of this wave's vector-memory operations are outstanding (vmcnt is an
 // immediate, hence the ladder; a wave issues at most 3 DMA pieces per tile).
 __device__ __forceinline__ void pln_wait_all_but(uint32_t younger) {
@@ -351,7 +364,29 @@ struct pln_lds_n {
   double tabD[SRT_NKEY];  // D(u + 5 eps, j + 1)
   double tabP[SRT_NKEY];
   uint32_t ticket[PLN_NBUF];  // per ring slot; zeroed one tile ahead
+  __attribute__((aligned(16))) pln_tile desc[2][PLN_DESC_CHUNK];  // descriptors of this block's tile range, 2 x 32
 };
+
+// Tile descriptor j of the block's range from the LDS ring (wave-uniform: every lane reads the same address).
+__device__ __forceinline__ pln_tile pln_desc(const pln_tile (*ring)[PLN_DESC_CHUNK], uint64_t j, uint64_t count) {
+  pln_tile ti;
+  ti.row0 = 0;
+  ti.rows_items = 0;
+  ti.off16 = 0;
+  ti.hc_hr = 0;
+  ti.blk16 = 0;
+  ti.pad = 0;
+  if (j < count) {
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(&ring[(j >> 5) & 1u][j & 31u]);
+    const uint32_t lo = srt_uniform(d[0]), hi = srt_uniform(d[1]);
+    ti.row0 = ((uint64_t)hi << 32) | lo;
+    ti.rows_items = srt_uniform(d[2]);
+    ti.off16 = srt_uniform(d[3]);
+    ti.hc_hr = srt_uniform(d[4]);
+    ti.blk16 = srt_uniform(d[5]);
+  }
+  return ti;
+}
 
 // NORM: the caller asserts that every prior row sums to one (true for every ar_func of the reference,
 // all of which end in a softmax, ar_funcs.py:44,97,121-126).  Then A = u + 5 eps for every context
@@ -363,7 +398,11 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
                                                                                     uint64_t n_rows, bear_params prm,
                                                                                     pln_view pv,
                                                                                     const double2 *__restrict__ logtab_g,
-                                                                                    double *__restrict__ partials) {
+                                                                                    double *__restrict__ partials
+#ifdef PLN_STAMPS
+                                                                                    , unsigned long long *__restrict__ dbg
+#endif
+                                                                                    ) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_n &S = *reinterpret_cast<pln_lds_n *>(srt_smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
@@ -381,51 +420,79 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
     S.ticket[tid] = 0;
   }
 
-  // Streams tile `ti` into ring slot `b`; returns the number of DMA instructions this wave issued.
-  auto stage = [&](const pln_tile &ti, uint32_t b) -> uint32_t {
+  // One wave of the block (the last) is the DMA wave: it streams the tiles into the LDS ring and never computes.
+  // Measured on MI355X (scripts/dev/dma_issue_bench.hip): with HBM saturated every vector-memory instruction
+  // blocks its wave for ~700 clocks at issue -- spread over all waves that was 20-25 % of the kernel -- while a
+  // single wave per CU with <= 24 pieces in flight already sustains 5.8 TB/s.
+  const bool dma_wave = wave >= PLN_WAVES - PLN_DMA_WAVES;
+  const uint32_t dw = wave - (PLN_WAVES - PLN_DMA_WAVES);  // index among the DMA waves
+  auto stage = [&](const pln_tile &ti, uint32_t b) {  // DMA wave only: every piece of tile `ti` into ring slot `b`
     const uint32_t rows = ti.rows_items >> 16;
-    if (rows == 0) return 0u;
-    const uint32_t pbytes = rows * 40u;
-    uint32_t k = pln_dma(S.buf[b].pri, prior + ti.row0 * 5, pbytes & ~15u, wave, lane, 0);
-    if (pbytes & 15u) {  // odd row count (last tile only): the trailing 8 bytes through the SCALAR path --
-      // a vector load here would be followed by s_waitcnt vmcnt(0), which drains the DMA ring
+    if (rows == 0) return;
+    const uint32_t pbytes = (rows * 40u) & ~15u, bbytes = ti.blk16 * 16u;
+    const unsigned char *psrc = reinterpret_cast<const unsigned char *>(prior + ti.row0 * 5);
+    const unsigned char *bsrc = pv.stream + (size_t)ti.off16 * 16;
+    for (uint32_t pc = dw; (pc << 10) < bbytes; pc += PLN_DMA_WAVES) pln_dma_piece(S.buf[b].blk, bsrc, bbytes, pc, lane);
+    for (uint32_t pc = dw; (pc << 10) < pbytes; pc += PLN_DMA_WAVES) pln_dma_piece(S.buf[b].pri, psrc, pbytes, pc, lane);
+    if (dw == 0 && ((rows * 40u) & 15u)) {  // odd row count (last tile only): the trailing 8 bytes through the SCALAR path --
+      // a vector load here would be followed by s_waitcnt vmcnt(0), which drains the DMA queue
       const __attribute__((address_space(4))) double *tail =
           (const __attribute__((address_space(4))) double *)(uintptr_t)(prior + (ti.row0 + rows) * 5 - 1);
       const double v = *tail;
-      if (tid == 0) S.buf[b].pri[rows * 5 - 1] = v;
+      if (lane == 0) S.buf[b].pri[rows * 5 - 1] = v;
     }
-    k += pln_dma(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, ti.blk16 * 16u, wave, lane, (pbytes + 1023u) >> 10);
-    return k;
   };
 
-  const uint64_t G = gridDim.x;
-  uint64_t t = blockIdx.x;
-  pln_tile ring[PLN_NBUF];  // descriptors of tiles t, t+G, ... ; ring[0] is the current one
-  uint32_t inflight[PLN_NBUF];
-#pragma unroll
-  for (int k = 0; k < PLN_NBUF; ++k) {
-    ring[k] = pln_load_tile(pv, t + (uint64_t)k * G);
-    inflight[k] = 0;
+#ifdef PLN_STAMPS
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+  int prev_kind = 0;
+#define PLN_STAMP(k)                                              \
+  {                                                               \
+    const unsigned long long now = __builtin_amdgcn_s_memtime();  \
+    tph[k] += now - t_prev;                                       \
+    t_prev = now;                                                 \
   }
-#pragma unroll
-  for (int k = 0; k < PLN_NBUF - 1; ++k) inflight[k] = srt_uniform(stage(ring[k], k));
+#else
+#define PLN_STAMP(k)
+#endif
+  // Each block owns a contiguous range of tiles; their descriptors come through LDS, 32 per DMA piece (no scalar
+  // global loads in the loop: they would sit in lgkmcnt in front of every LDS access).
+  static_assert(PLN_NBUF == 2, "the DMA-wave protocol below is written for a two-slot ring");
+  const uint64_t G = gridDim.x;
+  const uint64_t first = (pv.n_tiles * (uint64_t)blockIdx.x) / G, count = (pv.n_tiles * ((uint64_t)blockIdx.x + 1)) / G - first;
+  auto fetch_desc = [&](uint64_t j0) {  // DMA wave: descriptors [j0, j0 + 32) of the range -> ring half (j0 / 32) & 1
+    if (dw == 0 && j0 < count)
+      pln_dma_piece(S.desc[(j0 >> 5) & 1u], pv.tiles + first + j0, PLN_DESC_CHUNK * (uint32_t)sizeof(pln_tile), 0u, lane);
+  };
+  if (dma_wave) {
+    __builtin_amdgcn_s_setprio(3);  // its few instructions per piece go ahead of the compute waves of the same SIMD
+    fetch_desc(0);
+    fetch_desc(PLN_DESC_CHUNK);
+    srt_wait_dma();
+  }
+  __syncthreads();
+  pln_tile cur = pln_desc(S.desc, 0, count), nxt = pln_desc(S.desc, 1, count);
+  if (dma_wave) stage(cur, 0);
   uint32_t slot = 0;
-  for (; t < pv.n_tiles; t += G) {
-    // wait for the current tile: everything except the DMA pieces of the younger tiles in flight
-    uint32_t younger = 0;
-#pragma unroll
-    for (int k = 1; k < PLN_NBUF - 1; ++k) younger += inflight[k];
-    pln_wait_all_but(srt_uniform(younger));  // scalar waits ignore EXEC: the selector must be provably wave-uniform
-    srt_sync();  // everybody's pieces have landed; the previous tile's slot is fully consumed
-    const uint32_t free_slot = (slot + PLN_NBUF - 1) % PLN_NBUF;
-    const uint32_t issued = srt_uniform(stage(ring[PLN_NBUF - 1], free_slot));  // refill it with the tile PLN_NBUF - 1 ahead
-    const pln_tile cur = ring[0];
-#pragma unroll
-    for (int k = 0; k < PLN_NBUF - 1; ++k) {
-      ring[k] = ring[k + 1];
-      inflight[k] = k + 1 < PLN_NBUF - 1 ? inflight[k + 1] : issued;
+  for (uint64_t j = 0; j < count; ++j) {
+#ifdef PLN_STAMPS
+    PLN_STAMP(prev_kind)  // last work item of the previous tile + the failed ticket draw
+    prev_kind = 4;        // slot 4: first ticket draw of a tile
+#endif
+    if (dma_wave) srt_wait_dma();  // tile j has landed
+    PLN_STAMP(1)
+    srt_sync();  // ... and every compute wave is done with tile j - 1: its slot is free
+    PLN_STAMP(2)  // barrier
+    const pln_tile nn = pln_desc(S.desc, j + 2, count);
+    if (dma_wave) {
+      if ((j & (PLN_DESC_CHUNK - 1)) == 0 && j != 0) fetch_desc(j + PLN_DESC_CHUNK);  // the ring half just left behind
+      stage(nxt, slot ^ 1u);
+      cur = nxt;
+      nxt = nn;
+      slot ^= 1u;
+      continue;
     }
-    ring[PLN_NBUF - 1] = pln_load_tile(pv, t + (uint64_t)PLN_NBUF * G);
+    PLN_STAMP(3)
 
     const pln_buf_n &B = S.buf[slot];
     const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
@@ -440,8 +507,20 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
     // Waves draw tickets until the list is exhausted.
     const uint32_t n_hcu = (hc + 63u) >> 6, n_hru = AR ? 0u : (hr + 63u) >> 6, n_heavy = n_hcu + n_hru;
     const uint32_t n_units = (n_light + 63u) >> 6;
+#ifdef PLN_NOWORK
+    const uint32_t n_work = 0;
+#else
     const uint32_t n_work = n_heavy + n_units + ((NORM || AR) ? 0u : (rows + 63u) >> 6);
+#endif
     for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_work; w = pln_ticket(&S.ticket[slot], lane)) {
+#ifdef PLN_STAMPS
+      {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        tph[prev_kind] += now - t_prev;  // the previous work item incl. the ticket draw that followed it
+        t_prev = now;
+        prev_kind = w < n_heavy ? 5 : (w < n_heavy + n_units ? 6 : 7);
+      }
+#endif
       if (w < n_hcu) {  // large-count column items of this tile
         const uint32_t i = w * 64u + lane;
         if (i < hc) {
@@ -516,9 +595,16 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
         acc[1] = __builtin_fma(xa[0] - eps5, o[0].P, acc[1]);
       }
     }
-    slot = (slot + 1) % PLN_NBUF;
+    cur = nxt;
+    nxt = nn;
+    slot ^= 1u;
   }
   srt_wait_dma();
+#ifdef PLN_STAMPS
+  if (lane == 0 && dbg) {
+    for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * PLN_WAVES + wave) * 8 + k] = tph[k];
+  }
+#endif
   // ---- Stirling-path items of the whole table, densely packed over the grid
   const uint64_t gtid = (uint64_t)blockIdx.x * PLN_THREADS + tid, gsz = (uint64_t)gridDim.x * PLN_THREADS;
   for (uint64_t i = gtid; i < pv.n_heavy_col; i += gsz) {
@@ -560,6 +646,7 @@ struct pln_lds_r {
   double tabD[2][SRT_NKEY];  // [0]: context term (x = A), [1]: stop column (x = x4)
   double tabP[2][SRT_NKEY];
   uint32_t ticket[PLN_NBUF];
+  __attribute__((aligned(16))) pln_tile desc[2][PLN_DESC_CHUNK];
 };
 
 // AR: multinomial mode of bear_ref (train_ar): sum LL = sum c log(f + eps); gradients w.r.t. tau_s, nu_s only.
@@ -591,24 +678,28 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
   if (tid < PLN_NBUF) S.ticket[tid] = 0;
   if (tid < 4 * PLN_NBUF) S.buf[tid >> 2].ref[PLN_SENTINEL + (tid & 3)] = 0;  // neutral cell: reference row of zeros
 
-  auto stage = [&](const pln_tile &ti, uint32_t b) -> uint32_t {
+  // Same streaming protocol as dm_prior_plan_kernel: the last PLN_DMA_WAVES waves only move data.
+  const bool dma_wave = wave >= PLN_WAVES - PLN_DMA_WAVES;
+  const uint32_t dw = wave - (PLN_WAVES - PLN_DMA_WAVES);
+  auto stage = [&](const pln_tile &ti, uint32_t b) {
     const uint32_t rows = ti.rows_items >> 16;
-    if (rows == 0) return 0u;
-    const uint32_t rbytes = rows * 20u;
-    uint32_t k = pln_dma(S.buf[b].ref, ref + ti.row0 * 5, rbytes & ~15u, wave, lane, 0);
-    if (rbytes & 15u) {  // row count not a multiple of 4 (last tile only): trailing dwords through the SCALAR path
-      const uint32_t w0 = (rbytes & ~15u) >> 2, nw = (rbytes & 15u) >> 2;
+    if (rows == 0) return;
+    const uint32_t rbytes = rows * 20u, rb16 = rbytes & ~15u, bbytes = ti.blk16 * 16u;
+    const unsigned char *rsrc = reinterpret_cast<const unsigned char *>(ref + ti.row0 * 5);
+    const unsigned char *bsrc = pv.stream + (size_t)ti.off16 * 16;
+    for (uint32_t pc = dw; (pc << 10) < bbytes; pc += PLN_DMA_WAVES) pln_dma_piece(S.buf[b].blk, bsrc, bbytes, pc, lane);
+    for (uint32_t pc = dw; (pc << 10) < rb16; pc += PLN_DMA_WAVES) pln_dma_piece(S.buf[b].ref, rsrc, rb16, pc, lane);
+    if (dw == 0 && (rbytes & 15u)) {  // row count not a multiple of 4 (last tile only): trailing dwords, SCALAR path
+      const uint32_t w0 = rb16 >> 2, nw = (rbytes & 15u) >> 2;
       const __attribute__((address_space(4))) uint32_t *tail =
           (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)(ref + ti.row0 * 5 + w0);
       const uint32_t v0 = tail[0], v1 = nw > 1 ? tail[1] : 0u, v2 = nw > 2 ? tail[2] : 0u;
-      if (tid == 0) {
+      if (lane == 0) {
         S.buf[b].ref[w0] = v0;
         if (nw > 1) S.buf[b].ref[w0 + 1] = v1;
         if (nw > 2) S.buf[b].ref[w0 + 2] = v2;
       }
     }
-    k += pln_dma(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, ti.blk16 * 16u, wave, lane, (rbytes + 1023u) >> 10);
-    return k;
   };
   // bear_ref.py:30-33 (Jukes-Cantor on the L1-normalised reference row), :63-68 (mix), bear_ref.py:106
   auto alpha_from = [&](double rb, double R) {
@@ -634,32 +725,33 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
   };
 
   const uint64_t G = gridDim.x;
-  uint64_t t = blockIdx.x;
-  pln_tile ring[PLN_NBUF];
-  uint32_t inflight[PLN_NBUF];
-#pragma unroll
-  for (int k = 0; k < PLN_NBUF; ++k) {
-    ring[k] = pln_load_tile(pv, t + (uint64_t)k * G);
-    inflight[k] = 0;
+  const uint64_t first = (pv.n_tiles * (uint64_t)blockIdx.x) / G, count = (pv.n_tiles * ((uint64_t)blockIdx.x + 1)) / G - first;
+  auto fetch_desc = [&](uint64_t j0) {
+    if (dw == 0 && j0 < count)
+      pln_dma_piece(S.desc[(j0 >> 5) & 1u], pv.tiles + first + j0, PLN_DESC_CHUNK * (uint32_t)sizeof(pln_tile), 0u, lane);
+  };
+  if (dma_wave) {
+    __builtin_amdgcn_s_setprio(3);
+    fetch_desc(0);
+    fetch_desc(PLN_DESC_CHUNK);
+    srt_wait_dma();
   }
-#pragma unroll
-  for (int k = 0; k < PLN_NBUF - 1; ++k) inflight[k] = srt_uniform(stage(ring[k], k));
+  __syncthreads();
+  pln_tile cur = pln_desc(S.desc, 0, count), nxt = pln_desc(S.desc, 1, count);
+  if (dma_wave) stage(cur, 0);
   uint32_t slot = 0;
-  for (; t < pv.n_tiles; t += G) {
-    uint32_t younger = 0;
-#pragma unroll
-    for (int k = 1; k < PLN_NBUF - 1; ++k) younger += inflight[k];
-    pln_wait_all_but(srt_uniform(younger));  // scalar waits ignore EXEC: the selector must be provably wave-uniform
+  for (uint64_t j = 0; j < count; ++j) {
+    if (dma_wave) srt_wait_dma();
     srt_sync();
-    const uint32_t free_slot = (slot + PLN_NBUF - 1) % PLN_NBUF;
-    const uint32_t issued = srt_uniform(stage(ring[PLN_NBUF - 1], free_slot));
-    const pln_tile cur = ring[0];
-#pragma unroll
-    for (int k = 0; k < PLN_NBUF - 1; ++k) {
-      ring[k] = ring[k + 1];
-      inflight[k] = k + 1 < PLN_NBUF - 1 ? inflight[k + 1] : issued;
+    const pln_tile nn = pln_desc(S.desc, j + 2, count);
+    if (dma_wave) {
+      if ((j & (PLN_DESC_CHUNK - 1)) == 0 && j != 0) fetch_desc(j + PLN_DESC_CHUNK);
+      stage(nxt, slot ^ 1u);
+      cur = nxt;
+      nxt = nn;
+      slot ^= 1u;
+      continue;
     }
-    ring[PLN_NBUF - 1] = pln_load_tile(pv, t + (uint64_t)PLN_NBUF * G);
 
     const pln_buf_r &B = S.buf[slot];
     const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
@@ -705,7 +797,9 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
       srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
       accumulate(x[0], o[0]);
     }
-    slot = (slot + 1) % PLN_NBUF;
+    cur = nxt;
+    nxt = nn;
+    slot ^= 1u;
   }
   srt_wait_dma();
   // ---- Stirling-path items of the whole table
