@@ -54,6 +54,9 @@ struct pln_tile {
   uint64_t pad;
 };
 static_assert(sizeof(pln_tile) == 32, "tile descriptors are fetched with one s_load_dwordx8");
+#ifndef PLN_CHUNK
+#define PLN_CHUNK 128                       // contexts per context-term ticket (multiple of 64)
+#endif
 #ifndef PLN_DMA_WAVES
 #define PLN_DMA_WAVES 2                     // waves of each block that only stream tiles into LDS (see dm_prior_plan_kernel)
 #endif
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
 #ifdef PLN_NOWORK
     const uint32_t n_work = 0;
 #else
-    const uint32_t n_work = n_heavy + n_units + ((NORM || AR) ? 0u : (rows + 63u) >> 6);
+    const uint32_t n_work = n_heavy + n_units + ((NORM || AR) ? 0u : (rows + PLN_CHUNK - 1u) / PLN_CHUNK);
 #endif
     for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_work; w = pln_ticket(&S.ticket[slot], lane)) {
 #ifdef PLN_STAMPS
@@ -565,34 +568,45 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
         acc[1] = __builtin_fma(eps - x[0], o[0].P, acc[1]);
         continue;
       }
-      // ---- A: context terms  -D(A, n), (A - 5 eps) P(A, n)   with A = S u + 5 eps
-      const uint32_t row = (w - n_heavy - n_units) * 64u + lane;
-      const uint32_t rr = row < rows ? row : rows - 1;
-      double f[5];
+      // ---- A: context terms  -D(A, n), (A - 5 eps) P(A, n)   with A = S u + 5 eps; PLN_CHUNK contexts per ticket,
+      // PLN_CHUNK / 64 per lane so that their LDS reads are in flight together
+      const uint32_t row0c = (w - n_heavy - n_units) * PLN_CHUNK + lane;
+      double S5[PLN_CHUNK / 64];
+      uint32_t nn_[PLN_CHUNK / 64];
 #pragma unroll
-      for (int b = 0; b < 5; ++b) f[b] = B.pri[rr * 5 + b];
-      const double S5 = ((f[0] + f[1]) + (f[2] + f[3])) + f[4];
-      uint32_t n = row < rows ? (uint32_t)nrow[rr] : 0u;  // 0: empty context; 255: total beyond SRT_CL (heavy lists)
-      if (n == 255u) n = 0u;
-      const bool shared = __builtin_fabs(S5 - 1.0) <= SRT_SUM1_TOL;
-      if (n != 0 && shared) {
-        acc[0] -= S.tabD[n - 1];
-        acc[1] = __builtin_fma(u, S.tabP[n - 1], acc[1]);
+      for (int q = 0; q < PLN_CHUNK / 64; ++q) {
+        const uint32_t row = row0c + 64u * q;
+        const uint32_t rr = row < rows ? row : rows - 1;
+        double f[5];
+#pragma unroll
+        for (int b = 0; b < 5; ++b) f[b] = B.pri[rr * 5 + b];
+        S5[q] = ((f[0] + f[1]) + (f[2] + f[3])) + f[4];
+        uint32_t n = row < rows ? (uint32_t)nrow[rr] : 0u;  // 0: empty context; 255: total beyond SRT_CL (heavy lists)
+        nn_[q] = n == 255u ? 0u : n;
       }
-      const uint32_t own = (n != 0 && !shared) ? n : 0u;  // general concentrations: own A
-      if (__builtin_amdgcn_ballot_w64(own != 0)) {
-        uint32_t cm = own;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-          const uint32_t o2 = (uint32_t)__shfl_xor((int)cm, off, 64);
-          cm = o2 > cm ? o2 : cm;
+      for (int q = 0; q < PLN_CHUNK / 64; ++q) {
+        const uint32_t n = nn_[q];
+        const bool shared = __builtin_fabs(S5[q] - 1.0) <= SRT_SUM1_TOL;
+        if (n != 0 && shared) {
+          acc[0] -= S.tabD[n - 1];
+          acc[1] = __builtin_fma(u, S.tabP[n - 1], acc[1]);
         }
-        const double xa[1] = {own ? __builtin_fma(S5, u, eps5) : 1.0};
-        const uint32_t ca[1] = {own};
-        bear_dp o[1];
-        srt_light<1>(xa, ca, 0u, srt_uniform(cm), S.logtab, o);
-        acc[0] -= o[0].D;
-        acc[1] = __builtin_fma(xa[0] - eps5, o[0].P, acc[1]);
+        const uint32_t own = (n != 0 && !shared) ? n : 0u;  // general concentrations: own A
+        if (__builtin_amdgcn_ballot_w64(own != 0)) {
+          uint32_t cm = own;
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t o2 = (uint32_t)__shfl_xor((int)cm, off, 64);
+            cm = o2 > cm ? o2 : cm;
+          }
+          const double xa[1] = {own ? __builtin_fma(S5[q], u, eps5) : 1.0};
+          const uint32_t ca[1] = {own};
+          bear_dp o[1];
+          srt_light<1>(xa, ca, 0u, srt_uniform(cm), S.logtab, o);
+          acc[0] -= o[0].D;
+          acc[1] = __builtin_fma(xa[0] - eps5, o[0].P, acc[1]);
+        }
       }
     }
     cur = nxt;
