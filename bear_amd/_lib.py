@@ -19,7 +19,7 @@ SYMBOLS = [
     "bear_abi_version", "bear_strerror", "bear_last_hip_error", "bear_ws_create", "bear_ws_destroy",
     "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_dm_items_f64", "bear_eval_f64", "bear_bmm_f64", "bear_pack_kmers_u64", "bear_dm_linear_f64",
     "bear_plan_create", "bear_plan_destroy", "bear_plan_bytes", "bear_dm_prior_plan_f64", "bear_dm_prior_plan_grad_f64", "bear_dm_ref_plan_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
-    "bear_count_rows", "bear_parse_counts_tsv",
+    "bear_count_rows", "bear_parse_counts_tsv", "bear_log_gamma_f64", "bear_logdir_sample_f64",
 ]
 
 
@@ -66,6 +66,8 @@ def _load():
     L.bear_dm_items_f64.argtypes = [vp, vp, vp, u64, cint, vp, vp, vp]
     L.bear_synth_counts_u32.argtypes = [u64, u64, u64, cint, vp, vp, vp, vp]
     L.bear_synth_prior_f64.argtypes = [u64, u64, u64, vp, vp]
+    L.bear_log_gamma_f64.argtypes = [vp, u64, u64, u64, vp, vp]
+    L.bear_logdir_sample_f64.argtypes = [vp, vp, u64, vp, cint, cint, vp, cint, cint, cint, u64, u64, vp, vp]
     L.bear_count_rows.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]
     L.bear_parse_counts_tsv.argtypes = [ctypes.c_char_p, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
     for name in SYMBOLS:

@@ -18,6 +18,7 @@
 #include "kernels_plan.h"
 #include "kernels_synth.h"
 #include "kernels_linear.h"
+#include "kernels_sample.h"
 
 #ifdef PLN_STAMPS  // developer build: per-wave phase timers of dm_prior_plan_kernel land in ws->dbg
 #define PLN_DBG_ARG , ws->dbg
@@ -676,6 +677,55 @@ int bear_debug_occupancy(int which) {
       ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dm_prior_sorted_kernel<0>, SRT_THREADS, sizeof(srt_lds_n))
       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dm_ref_sorted_kernel, SRT_THREADS, sizeof(srt_lds_r));
   return e == hipSuccess ? nb : -1000 - (int)e;
+}
+
+int bear_log_gamma_f64(const double *conc, uint64_t n, uint64_t n_samples, uint64_t seed, double *out, void *stream) {
+  if (n == 0 || n_samples == 0) return BEAR_OK;
+  if (!conc || !out) return BEAR_ERR_INVALID_ARG;
+  if (n_samples > (~0ull) / n) return BEAR_ERR_INVALID_ARG;
+  const uint64_t total = n * n_samples;
+  uint64_t blocks = (total + SMP_THREADS - 1) / SMP_THREADS;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(log_gamma_kernel, dim3((unsigned)blocks), dim3(SMP_THREADS), 0, static_cast<hipStream_t>(stream), conc, n,
+                     n_samples, seed, out);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_logdir_sample_f64(const uint32_t *counts, const double *prior, uint64_t n_rows, const double *h, int n_h,
+                           int with_ar, const double *van, int n_van, int mc_samples, int map, uint64_t seed,
+                           uint64_t row_base, double *out, void *stream) {
+  if (n_h < 0 || n_van < 0 || n_h + n_van > SMP_MAX_MODELS || (n_h && !h) || (n_van && !van)) return BEAR_ERR_INVALID_ARG;
+  if (with_ar && !map) return BEAR_ERR_INVALID_ARG;   // the AR model enters only the MAP table (get_var_probs.py:150-153)
+  if (map) mc_samples = 1;                            // get_var_probs.py:131-132
+  if (mc_samples <= 0) return BEAR_ERR_INVALID_ARG;
+  const int M = (with_ar ? 1 : 0) + n_h + n_van;
+  if (n_rows == 0 || M == 0) return BEAR_OK;
+  if (!out || ((n_h || with_ar) && !prior)) return BEAR_ERR_INVALID_ARG;
+  smp_args A;
+  memset(&A, 0, sizeof(A));
+  A.n_h = n_h;
+  A.n_van = n_van;
+  A.arm = with_ar ? 1 : 0;
+  A.has_counts = counts ? 1 : 0;
+  A.has_prior = prior ? 1 : 0;
+  A.map = map ? 1 : 0;
+  A.mc = (uint32_t)mc_samples;
+  A.seed = seed;
+  A.row_base = row_base;
+  for (int j = 0; j < n_h; ++j) {
+    if (!(h[j] > 0.0)) return BEAR_ERR_INVALID_ARG;
+    A.w[j] = 1.0 / h[j];
+  }
+  for (int k = 0; k < n_van; ++k) A.w[n_h + k] = van[k];
+  const uint64_t per_row = (uint64_t)M * (uint64_t)mc_samples;
+  if (per_row > 0xffffffffull || n_rows > (~0ull) / (5 * per_row)) return BEAR_ERR_INVALID_ARG;
+  uint64_t blocks = (n_rows * per_row + SMP_THREADS - 1) / SMP_THREADS;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(logdir_sample_kernel, dim3((unsigned)blocks), dim3(SMP_THREADS), 0, static_cast<hipStream_t>(stream), counts,
+                     prior, n_rows, A, out);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
 }
 
 int bear_synth_counts_u32(uint64_t seed, uint64_t row0, uint64_t n_rows, int dense, uint32_t *train,

@@ -279,3 +279,39 @@ def synth_prior(seed, row0, n_rows, device):
         st = _lib.lib().bear_synth_prior_f64(int(seed), int(row0), int(n_rows), _ptr(prior), _stream())
     _lib.check(st, "bear_synth_prior_f64")
     return prior
+
+
+def log_gamma(conc, n_samples, seed):
+    """One launch of ``bear_log_gamma_f64``: device float64 [n_samples, n] of log Gamma(conc[i], 1) draws."""
+    if not (conc.is_cuda and conc.dtype == torch.float64 and conc.dim() == 1 and conc.is_contiguous()):
+        raise ValueError("conc must be a contiguous CUDA float64 vector")
+    out = torch.empty((int(n_samples), conc.shape[0]), dtype=torch.float64, device=conc.device)
+    with torch.cuda.device(conc.device):
+        st = _lib.lib().bear_log_gamma_f64(_ptr(conc), conc.shape[0], int(n_samples), int(seed) & (2 ** 64 - 1), _ptr(out), _stream())
+    _lib.check(st, "bear_log_gamma_f64")
+    return out
+
+
+def logdir_sample(counts, prior, h, vans, mc_samples, get_map=False, with_ar=False, seed=0, row_base=0, n_rows=None,
+                  device=None):
+    """One launch of ``bear_logdir_sample_f64``: normalised log transition probabilities
+    [n_rows, 5, n_models, mc_samples] (get_var_probs.get_pdf, output='numpy').  counts None = all-zero rows."""
+    n = None
+    for t, dt, name in ((counts, torch.int32, "counts"), (prior, torch.float64, "prior")):
+        if t is not None:
+            _check_rows(t, dt, name)
+            if n is not None and t.shape[0] != n:
+                raise ValueError("counts and prior must have the same number of rows")
+            n, device = t.shape[0], t.device
+    if n is None:
+        n, device = int(n_rows), torch.device(device or "cuda")
+    hs, hp = _host_f64(h) if h is not None and np.size(h) else (np.zeros(0), ctypes.c_void_p(0))
+    vs, vp = _host_f64(vans) if vans is not None and np.size(vans) else (np.zeros(0), ctypes.c_void_p(0))
+    mc = 1 if get_map else int(mc_samples)
+    M = int(bool(with_ar)) + hs.size + vs.size
+    out = torch.empty((n, 5, M, mc), dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        st = _lib.lib().bear_logdir_sample_f64(_ptr(counts), _ptr(prior), n, hp, hs.size, int(bool(with_ar)), vp, vs.size, mc,
+                                               int(bool(get_map)), int(seed) & (2 ** 64 - 1), int(row_base), _ptr(out), _stream())
+    _lib.check(st, "bear_logdir_sample_f64")
+    return out

@@ -176,6 +176,30 @@ int bear_dm_items_f64(bear_ws *ws, const double *x, const uint32_t *c, uint64_t 
                       double *P, void *stream);
 
 /*
+ * Posterior sampling of transition probabilities (inference apps).
+ *
+ * bear_log_gamma_f64 replaces log_gamma.log_gamma(concs, size) (bear_model/log_gamma.py:17-76):
+ *   conc [dev] double [n] > 0;  out [dev] double [n_samples, n],  out[s, i] ~ log Gamma(conc[i], 1)
+ *   -- accurate for tiny concentrations, where exp(out) underflows.  The reference draws from numpy's global
+ *   generator; here a draw is a pure function of (seed, s, i), restated in oracle/bear_oracle.py:log_gamma_hash.
+ *
+ * bear_logdir_sample_f64 replaces the concentration assembly + sampling (or MAP) of get_var_probs.get_pdf
+ * (bear_model/get_var_probs.py:128-183), output='numpy' layout:
+ *   counts [dev, nullable] uint32 [n_rows,5]  training-column counts (NULL = unseen k-mers, all zero, :441-444)
+ *   prior  [dev, nullable] double [n_rows,5]  ar_func rows (required when n_h > 0 or with_ar)
+ *   h [host] n_h values; van [host] n_van values; n_h + n_van <= 64
+ *   model order: (AR if with_ar) , BEAR h_0.., vanilla van_0..   (get_var_probs.py:146-153)
+ *   map != 0: log(conc / sum conc), mc_samples forced to 1; with_ar requires map
+ *   out [dev] double [n_rows, 5, n_models, mc_samples]  normalised log transition probabilities
+ *   a draw is a pure function of (seed, model, sample, row_base + row, letter): any sharding of the rows
+ *   reproduces the same table.
+ */
+int bear_log_gamma_f64(const double *conc, uint64_t n, uint64_t n_samples, uint64_t seed, double *out, void *stream);
+int bear_logdir_sample_f64(const uint32_t *counts, const double *prior, uint64_t n_rows, const double *h, int n_h,
+                           int with_ar, const double *van, int n_van, int mc_samples, int map, uint64_t seed,
+                           uint64_t row_base, double *out, void *stream);
+
+/*
  * Synthetic "k=13 sparse" count table for measurement: rows
  * [row0, row0 + n_rows) of a table defined by a counter-based hash of (seed, row), so any
  * shard of the same table can be generated independently on any GPU.

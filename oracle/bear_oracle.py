@@ -388,3 +388,101 @@ def parse_counts_tsv(path, num_ds):
     arr = np.asarray(rows, dtype=np.float64)
     assert arr.shape[1] == num_ds
     return kmers, arr
+
+
+# --------------------------------------------------------------------------- posterior sampling
+SMP_MAX_ROUNDS = 64
+
+
+def _gauss_key(key):
+    """N(0,1) from a 64-bit counter, the same Box-Muller pair as eval_noise."""
+    with np.errstate(over="ignore"):
+        u1 = _u01(_mix64(key))
+        u2 = _u01(_mix64(key ^ np.uint64(0x5851F42D4C957F2D)))
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586 * u2)
+
+
+def log_gamma_keys(concs, keys):
+    """One log Gamma(conc, 1) draw per element from its 64-bit counter key: the distribution sampled by
+    log_gamma.log_gamma (log_gamma.py:17-76 -- log of a standard gamma, computed so that tiny concentrations
+    do not underflow).  The reference uses vectorised rejection rounds on numpy's global generator
+    (log_gamma.py:47-75); a counter-based restatement cannot share that stream, so this follows the HIP
+    kernel's scheme (kernels_sample.h:smp_log_gamma): Marsaglia-Tsang for shape >= 1 and, below 1, the boost
+    log G_a = log G_{a+1} + log(U)/a.  Pinned to the reference distributionally (tests/test_sampling_*.py)."""
+    a = np.asarray(concs, dtype=np.float64).reshape(-1)
+    keys = np.asarray(keys, dtype=np.uint64).reshape(-1)
+    small = a < 1.0
+    a1 = np.where(small, a + 1.0, a)
+    d = a1 - 1.0 / 3.0
+    c = 1.0 / np.sqrt(9.0 * d)
+    ld = np.log(d)
+    lg = ld.copy()
+    live = np.ones(a.shape, dtype=bool)
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        for t in range(SMP_MAX_ROUNDS):
+            if not live.any():
+                break
+            idx = np.nonzero(live)[0]
+            k = keys[idx]
+            x = _gauss_key(k + np.uint64(2 * t + 1))
+            u = _u01(_mix64(k + np.uint64(2 * t + 2)))
+            w = c[idx] * x + 1.0          # fma(c, x, 1): the product c*x is exact to 1 ulp of a sub-unit term
+            pos = w > 0.0
+            v = w * w * w
+            lv = np.log(np.where(pos, v, 1.0))
+            lg[idx[pos]] = ld[idx[pos]] + lv[pos]
+            acc = pos & (np.log(u) < (0.5 * x * x + d[idx]) - d[idx] * v + d[idx] * lv)
+            live[idx[acc]] = False
+        boost = np.log(_u01(_mix64(keys))) / a
+    return np.where(small, lg + boost, lg)
+
+
+def _cell_key(seed, model, sample, cell):
+    with np.errstate(over="ignore"):
+        return _mix64(_mix64(_mix64(np.uint64(seed) + np.asarray(model, dtype=np.uint64)) + np.asarray(sample, dtype=np.uint64))
+                      ^ np.asarray(cell, dtype=np.uint64))
+
+
+def log_gamma_hash(concs, size, seed):
+    """log_gamma.log_gamma(concs, size) (log_gamma.py:17-76) on the counter stream of bear_log_gamma_f64:
+    out[s, i] keyed by (seed, model 0, sample s, element i); shape = size + concs.shape (log_gamma.py:31, 76)."""
+    concs = np.asarray(concs, dtype=np.float64)
+    n_s = int(np.prod(size)) if len(size) else 1
+    flat = concs.reshape(-1)
+    s = np.repeat(np.arange(n_s, dtype=np.uint64), flat.size)
+    i = np.tile(np.arange(flat.size, dtype=np.uint64), n_s)
+    out = log_gamma_keys(np.tile(flat, n_s), _cell_key(seed, 0, s, i))
+    return out.reshape(tuple(int(v) for v in size) + concs.shape)
+
+
+def get_pdf_concs(counts, ar_vals, h, vans, get_map):
+    """Concentrations of get_var_probs.get_pdf (get_var_probs.py:134-153): [num_models, K, A+1] in the order
+    (AR if get_map and an AR function is present), BEAR h_0.., vanilla van_0..  counts: training column [K, A+1]."""
+    counts = np.asarray(counts, dtype=np.float64)
+    parts = []
+    if ar_vals is not None:
+        parts.append(np.asarray(ar_vals)[None, :, :] / np.asarray(h, dtype=np.float64)[:, None, None])
+    if len(vans) > 0:
+        parts.append(np.asarray(vans, dtype=np.float64)[:, None, None] * np.ones(counts.shape)[None, ...])
+    concs = np.concatenate(parts, axis=0) + counts[None, :, :]
+    if ar_vals is not None and get_map:
+        concs = np.concatenate([np.asarray(ar_vals)[None, ...], concs], axis=0)
+    return concs
+
+
+def get_pdf_numpy(counts, ar_vals, h, vans, mc_samples, get_map, seed=0, row_base=0):
+    """get_var_probs.get_pdf(..., output='numpy') (get_var_probs.py:128-183): normalised log transition
+    probabilities [K, A+1, num_models, mc_samples]; sampling on the counter stream of bear_logdir_sample_f64
+    (key = (seed, model, sample, (row_base + k) * 5 + letter))."""
+    concs = get_pdf_concs(counts, ar_vals, h, vans, get_map)
+    M, K, A1 = concs.shape
+    if get_map:
+        lp = np.log(concs / np.sum(concs, axis=-1)[..., None]).reshape(1, M, K, A1)      # :174-175
+        return np.transpose(lp, [2, 3, 1, 0])
+    s, m, k, b = np.meshgrid(np.arange(mc_samples, dtype=np.uint64), np.arange(M, dtype=np.uint64),
+                             np.arange(K, dtype=np.uint64), np.arange(A1, dtype=np.uint64), indexing="ij")
+    keys = _cell_key(seed, m, s, (np.uint64(row_base) + k) * np.uint64(A1) + b)
+    g = log_gamma_keys(np.broadcast_to(concs[None], s.shape).reshape(-1), keys.reshape(-1)).reshape(s.shape)
+    mx = g.max(axis=-1, keepdims=True)
+    lse = mx + np.log(np.exp(g - mx).sum(axis=-1, keepdims=True))                        # :177-178
+    return np.transpose(g - lse, [2, 3, 1, 0])                                           # :181-183
