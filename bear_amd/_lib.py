@@ -20,6 +20,7 @@ SYMBOLS = [
     "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_dm_items_f64", "bear_eval_f64", "bear_bmm_f64", "bear_pack_kmers_u64", "bear_dm_linear_f64",
     "bear_plan_create", "bear_plan_destroy", "bear_plan_bytes", "bear_dm_prior_plan_f64", "bear_dm_prior_plan_grad_f64", "bear_dm_ref_plan_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
     "bear_count_rows", "bear_parse_counts_tsv", "bear_log_gamma_f64", "bear_logdir_sample_f64",
+    "bear_stat_source", "bear_cache_write", "bear_cache_info", "bear_cache_read", "bear_shuffle_rows", "bear_shuffle_source_row",
 ]
 
 
@@ -68,11 +69,20 @@ def _load():
     L.bear_synth_prior_f64.argtypes = [u64, u64, u64, vp, vp]
     L.bear_log_gamma_f64.argtypes = [vp, u64, u64, u64, vp, vp]
     L.bear_logdir_sample_f64.argtypes = [vp, vp, u64, vp, cint, cint, vp, cint, cint, cint, u64, u64, vp, vp]
+    i64 = ctypes.c_int64
+    L.bear_stat_source.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64), ctypes.POINTER(i64)]
+    L.bear_cache_write.argtypes = [ctypes.c_char_p, vp, vp, u64, cint, cint, u64, i64]
+    L.bear_cache_info.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64), ctypes.POINTER(cint), ctypes.POINTER(cint),
+                                  ctypes.POINTER(u64), ctypes.POINTER(i64)]
+    L.bear_cache_read.argtypes = [ctypes.c_char_p, u64, u64, vp, vp]
+    L.bear_shuffle_rows.argtypes = [vp, vp, u64, ctypes.c_uint32, u64, vp]
+    L.bear_shuffle_source_row.argtypes = [u64, u64, u64]
+    L.bear_shuffle_source_row.restype = u64
     L.bear_count_rows.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]
     L.bear_parse_counts_tsv.argtypes = [ctypes.c_char_p, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name == "bear_plan_bytes":
+        if name in ("bear_plan_bytes", "bear_shuffle_source_row"):
             continue
         if fn.restype is ctypes.c_int and name not in ("bear_abi_version", "bear_last_hip_error"):
             fn.restype = cint

@@ -65,16 +65,30 @@ class ResidentBatches:
         self.data, self.device = data, device
         self.batches = []
         codes = data.codes() if want_codes else None
+        shuffled = {}
+        if data.shuffle_seed is not None and data.num_rows:
+            # whole columns go up once, are permuted by one gather pass each (same seed: columns stay aligned), and the
+            # batches below are slices of the permuted slabs
+            for name, col in columns.items():
+                up = torch.from_numpy(np.ascontiguousarray(data.counts[col]).view(np.int32)).to(device)
+                shuffled[name] = kernels.shuffle_rows(up, data.shuffle_seed)
+                del up
+            if codes is not None:
+                shuffled["codes"] = kernels.shuffle_rows(torch.from_numpy(np.ascontiguousarray(codes)).to(device), data.shuffle_seed)
         for a, b in data.batch_bounds():
             lo, hi = dist.shard_rows(b - a)
             lo, hi = a + lo, a + hi
             entry = {"global_rows": b - a, "rows": hi - lo, "row0": lo}
             for name, col in columns.items():
-                entry[name] = torch.from_numpy(np.ascontiguousarray(data.counts[col, lo:hi]).view(np.int32)).to(device)
+                if shuffled:
+                    entry[name] = shuffled[name][lo:hi].clone()
+                else:
+                    entry[name] = torch.from_numpy(np.ascontiguousarray(data.counts[col, lo:hi]).view(np.int32)).to(device)
             if codes is not None:
-                entry["codes"] = torch.from_numpy(np.ascontiguousarray(codes[lo:hi])).to(device)
+                entry["codes"] = shuffled["codes"][lo:hi].clone() if shuffled else torch.from_numpy(np.ascontiguousarray(codes[lo:hi])).to(device)
             entry["plans"] = {}
             self.batches.append(entry)
+        del shuffled
 
     def plan(self, k, column, ncol):
         e = self.batches[k]

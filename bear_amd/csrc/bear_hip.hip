@@ -19,6 +19,7 @@
 #include "kernels_synth.h"
 #include "kernels_linear.h"
 #include "kernels_sample.h"
+#include "kernels_shuffle.h"
 
 #ifdef PLN_STAMPS  // developer build: per-wave phase timers of dm_prior_plan_kernel land in ws->dbg
 #define PLN_DBG_ARG , ws->dbg
@@ -726,6 +727,29 @@ int bear_logdir_sample_f64(const uint32_t *counts, const double *prior, uint64_t
                      prior, n_rows, A, out);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
+}
+
+int bear_shuffle_rows(const void *src, void *dst, uint64_t n_rows, uint32_t row_bytes, uint64_t seed, void *stream) {
+  if (n_rows == 0 || row_bytes == 0) return BEAR_OK;
+  if (!src || !dst || src == dst) return BEAR_ERR_INVALID_ARG;
+  if (n_rows > (1ull << 62) / row_bytes) return BEAR_ERR_INVALID_ARG;
+  const uint32_t hb = shf_half_bits(n_rows);
+  const bool words = (row_bytes % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) % 4 == 0);
+  const uint64_t total = words ? n_rows * (row_bytes / 4) : n_rows * (uint64_t)row_bytes;
+  uint64_t blocks = (total + 255) / 256;
+  if (blocks > 1u << 20) blocks = 1u << 20;
+  if (words)
+    hipLaunchKernelGGL(shuffle_words_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint32_t *>(src), static_cast<uint32_t *>(dst), n_rows, row_bytes / 4, hb, seed);
+  else
+    hipLaunchKernelGGL(shuffle_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint8_t *>(src), static_cast<uint8_t *>(dst), n_rows, row_bytes, hb, seed);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+uint64_t bear_shuffle_source_row(uint64_t i, uint64_t n_rows, uint64_t seed) {
+  return (n_rows == 0 || i >= n_rows) ? i : shf_perm(i, n_rows, shf_half_bits(n_rows), seed);
 }
 
 int bear_synth_counts_u32(uint64_t seed, uint64_t row0, uint64_t n_rows, int dense, uint32_t *train,

@@ -4,6 +4,7 @@
 // output planar by dataset column as uint32 so each column can be uploaded as one [N,5] slab.
 #include <fcntl.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -109,4 +110,126 @@ extern "C" int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint
   }
   *n_rows_out = row;
   return BEAR_OK;
+}
+
+// ------------------------------------------------------------------ binary cache of a parsed table
+// The reference decodes the text of every file again in every process and keeps the tensors in host RAM
+// (dataloader.py:47-48, `.cache()`); at 1e9 rows the text is 60-80 GB and decoding it is the first-epoch cost.
+// The cache is the parsed table as it is uploaded: header, k-mer bytes, planar uint32 slabs.
+namespace {
+struct cache_header {
+  char magic[8];          // "BEARCT01"
+  uint64_t n_rows;
+  uint32_t lag, num_ds;
+  uint64_t src_size;      // size and mtime of the text file the cache was parsed from (staleness check)
+  int64_t src_mtime_ns;
+  uint64_t kmers_offset, counts_offset;
+  uint64_t reserved[1];
+};
+static_assert(sizeof(cache_header) == 64, "cache header is 64 bytes");
+const char CACHE_MAGIC[8] = {'B', 'E', 'A', 'R', 'C', 'T', '0', '1'};
+
+bool write_all(int fd, const void *buf, size_t n) {
+  const char *p = static_cast<const char *>(buf);
+  while (n) {
+    ssize_t w = ::write(fd, p, n > (1u << 30) ? (1u << 30) : n);
+    if (w <= 0) return false;
+    p += w;
+    n -= (size_t)w;
+  }
+  return true;
+}
+bool read_all(int fd, void *buf, size_t n, uint64_t off) {
+  char *p = static_cast<char *>(buf);
+  while (n) {
+    ssize_t r = ::pread(fd, p, n > (1u << 30) ? (1u << 30) : n, (off_t)off);
+    if (r <= 0) return false;
+    p += r;
+    off += (uint64_t)r;
+    n -= (size_t)r;
+  }
+  return true;
+}
+int read_header(int fd, cache_header *h) {
+  if (!read_all(fd, h, sizeof(*h), 0)) return BEAR_ERR_PARSE;
+  if (memcmp(h->magic, CACHE_MAGIC, 8) != 0) return BEAR_ERR_PARSE;
+  struct stat st;
+  if (fstat(fd, &st) != 0) return BEAR_ERR_IO;
+  const uint64_t need = h->counts_offset + (uint64_t)h->num_ds * h->n_rows * BEAR_ROW_WIDTH * 4;
+  if (h->kmers_offset < sizeof(*h) || h->counts_offset < h->kmers_offset + h->n_rows * h->lag || (uint64_t)st.st_size < need)
+    return BEAR_ERR_PARSE;
+  return BEAR_OK;
+}
+}  // namespace
+
+extern "C" int bear_stat_source(const char *path, uint64_t *size_out, int64_t *mtime_ns_out) {
+  if (!path || !size_out || !mtime_ns_out) return BEAR_ERR_INVALID_ARG;
+  struct stat st;
+  if (stat(path, &st) != 0) return BEAR_ERR_IO;
+  *size_out = (uint64_t)st.st_size;
+  *mtime_ns_out = (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec;
+  return BEAR_OK;
+}
+
+extern "C" int bear_cache_write(const char *path, const char *kmers, const uint32_t *counts, uint64_t n_rows, int lag,
+                                int num_ds, uint64_t src_size, int64_t src_mtime_ns) {
+  if (!path || !counts || (!kmers && lag > 0 && n_rows) || lag < 0 || num_ds < 1) return BEAR_ERR_INVALID_ARG;
+  cache_header h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, CACHE_MAGIC, 8);
+  h.n_rows = n_rows;
+  h.lag = (uint32_t)lag;
+  h.num_ds = (uint32_t)num_ds;
+  h.src_size = src_size;
+  h.src_mtime_ns = src_mtime_ns;
+  h.kmers_offset = sizeof(h);
+  h.counts_offset = (h.kmers_offset + n_rows * (uint64_t)lag + 63) & ~63ull;
+  // write to a temporary name and rename: a reader never sees a half-written cache
+  char tmp[4096];
+  if (snprintf(tmp, sizeof(tmp), "%s.tmp.%d", path, (int)getpid()) >= (int)sizeof(tmp)) return BEAR_ERR_INVALID_ARG;
+  int fd = ::open(tmp, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return BEAR_ERR_IO;
+  static const char zeros[64] = {0};
+  bool ok = write_all(fd, &h, sizeof(h)) && write_all(fd, kmers, n_rows * (uint64_t)lag) &&
+            write_all(fd, zeros, h.counts_offset - (h.kmers_offset + n_rows * (uint64_t)lag)) &&
+            write_all(fd, counts, (uint64_t)num_ds * n_rows * BEAR_ROW_WIDTH * 4);
+  ok = (::close(fd) == 0) && ok;
+  if (!ok || ::rename(tmp, path) != 0) {
+    ::unlink(tmp);
+    return BEAR_ERR_IO;
+  }
+  return BEAR_OK;
+}
+
+extern "C" int bear_cache_info(const char *path, uint64_t *n_rows, int *lag, int *num_ds, uint64_t *src_size,
+                               int64_t *src_mtime_ns) {
+  if (!path) return BEAR_ERR_INVALID_ARG;
+  int fd = ::open(path, O_RDONLY);
+  if (fd < 0) return BEAR_ERR_IO;
+  cache_header h;
+  int st = read_header(fd, &h);
+  ::close(fd);
+  if (st != BEAR_OK) return st;
+  if (n_rows) *n_rows = h.n_rows;
+  if (lag) *lag = (int)h.lag;
+  if (num_ds) *num_ds = (int)h.num_ds;
+  if (src_size) *src_size = h.src_size;
+  if (src_mtime_ns) *src_mtime_ns = h.src_mtime_ns;
+  return BEAR_OK;
+}
+
+extern "C" int bear_cache_read(const char *path, uint64_t row0, uint64_t n_rows, char *kmers, uint32_t *counts) {
+  if (!path || !counts) return BEAR_ERR_INVALID_ARG;
+  int fd = ::open(path, O_RDONLY);
+  if (fd < 0) return BEAR_ERR_IO;
+  cache_header h;
+  int st = read_header(fd, &h);
+  if (st == BEAR_OK && (row0 > h.n_rows || n_rows > h.n_rows - row0)) st = BEAR_ERR_INVALID_ARG;
+  if (st == BEAR_OK && kmers && !read_all(fd, kmers, n_rows * h.lag, h.kmers_offset + row0 * h.lag)) st = BEAR_ERR_IO;
+  for (uint32_t d = 0; st == BEAR_OK && d < h.num_ds; ++d)
+    if (!read_all(fd, counts + (uint64_t)d * n_rows * BEAR_ROW_WIDTH, n_rows * BEAR_ROW_WIDTH * 4,
+                  h.counts_offset + ((uint64_t)d * h.n_rows + row0) * BEAR_ROW_WIDTH * 4))
+      st = BEAR_ERR_IO;
+  ::close(fd);
+  return st;
 }

@@ -10,6 +10,7 @@ dataloader.py:35-46) into k-mer bytes and planar ``uint32 [num_ds, N, 5]`` slabs
 """
 import ctypes
 import json
+import os
 
 import numpy as np
 import torch
@@ -20,7 +21,8 @@ from . import _lib, core, kernels
 class CountDataset:
     """Parsed count table: ``kmers`` uint8 [N, lag] (ASCII), ``counts`` uint32 [num_ds, N, A+1]."""
 
-    def __init__(self, kmers, counts, alphabet, batch_size, dtype=torch.float64, repeats=1):
+    def __init__(self, kmers, counts, alphabet, batch_size, dtype=torch.float64, repeats=1, shuffle_seed=None):
+        self.shuffle_seed = shuffle_seed   # None: file order; else rows are permuted on the device at upload
         self.kmers = kmers
         self.counts = counts
         self.alphabet = alphabet
@@ -59,7 +61,14 @@ class CountDataset:
 
     def repeat(self, epochs):
         """tf.data ``.repeat(epochs)`` (models/train_bear_net.py:88)."""
-        return CountDataset(self.kmers, self.counts, self.alphabet, self.batch_size, self.dtype, self.repeats * int(epochs))
+        return CountDataset(self.kmers, self.counts, self.alphabet, self.batch_size, self.dtype, self.repeats * int(epochs),
+                            self.shuffle_seed)
+
+    def shuffle(self, seed):
+        """The `shuf` step of docs/usage.rst:191-200 without rewriting the file: training and evaluation see the rows
+        in the order ``perm_seed`` (one gather pass on the device at upload, ``bear_shuffle_rows``).  Iterating the
+        dataset on the host still yields file order."""
+        return CountDataset(self.kmers, self.counts, self.alphabet, self.batch_size, self.dtype, self.repeats, int(seed))
 
     # ---- packed device view --------------------------------------------------------------------
     def codes(self):
@@ -94,12 +103,46 @@ def _sniff_lag(file, header, delim):
     return 0
 
 
-def dataloader(file, alphabet, batch_size, num_ds, cache=True, header=False, n_par=1, dtype=torch.float64):
+def cache_path_for(file, binary_cache):
+    """Where the binary cache of ``file`` lives: next to it (``True``), or inside a directory."""
+    if binary_cache is True:
+        return str(file) + ".bearcache"
+    return os.path.join(str(binary_cache), os.path.basename(str(file)) + ".bearcache")
+
+
+def _load_cache(path, file, num_ds, rows=None):
+    """The parsed table from a valid, fresh binary cache, or None."""
+    L = _lib.lib()
+    n, lag, nds, ssz, smt = ctypes.c_uint64(), ctypes.c_int(), ctypes.c_int(), ctypes.c_uint64(), ctypes.c_int64()
+    if not os.path.exists(path) or L.bear_cache_info(path.encode(), ctypes.byref(n), ctypes.byref(lag), ctypes.byref(nds),
+                                                     ctypes.byref(ssz), ctypes.byref(smt)) != 0:
+        return None
+    fsz, fmt = ctypes.c_uint64(), ctypes.c_int64()
+    if L.bear_stat_source(str(file).encode(), ctypes.byref(fsz), ctypes.byref(fmt)) != 0:
+        return None
+    if (fsz.value, fmt.value) != (ssz.value, smt.value) or nds.value != num_ds:
+        return None      # stale (source rewritten) or parsed with another num_ds
+    a, b = rows if rows is not None else (0, n.value)
+    kmers = np.zeros((b - a, lag.value), dtype=np.uint8)
+    counts = np.zeros((num_ds, b - a, 5), dtype=np.uint32)
+    _lib.check(L.bear_cache_read(path.encode(), a, b - a, kmers.ctypes.data, counts.ctypes.data), "bear_cache_read")
+    return kmers, counts
+
+
+def dataloader(file, alphabet, batch_size, num_ds, cache=True, header=False, n_par=1, dtype=torch.float64,
+               binary_cache=None):
     """dataloader.py:6-50.  ``cache`` / ``n_par`` are accepted for signature compatibility: the table
-    is always parsed once and kept."""
+    is always parsed once and kept.  ``binary_cache`` (``True``: next to the file; or a directory; default: the
+    ``BEAR_AMD_CACHE_DIR`` environment variable) keeps the parsed table on disk so later runs skip the text."""
     if header:
         raise NotImplementedError("dense count tables written by summarize.py have no header")
     L = _lib.lib()
+    if binary_cache is None:
+        binary_cache = os.environ.get("BEAR_AMD_CACHE_DIR") or None
+    if binary_cache:
+        hit = _load_cache(cache_path_for(file, binary_cache), file, num_ds)
+        if hit is not None:
+            return CountDataset(hit[0], hit[1], alphabet, batch_size, dtype)
     n = ctypes.c_uint64()
     _lib.check(L.bear_count_rows(str(file).encode(), ctypes.byref(n)), "bear_count_rows")
     lag = _sniff_lag(file, header, b"\t")
@@ -112,6 +155,13 @@ def dataloader(file, alphabet, batch_size, num_ds, cache=True, header=False, n_p
     _lib.check(L.bear_parse_counts_tsv(str(file).encode(), int(num_ds), int(lag), n.value, kmers.ctypes.data,
                                        counts.ctypes.data, ctypes.byref(got)), "bear_parse_counts_tsv")
     assert got.value == n.value
+    if binary_cache:
+        fsz, fmt = ctypes.c_uint64(), ctypes.c_int64()
+        _lib.check(L.bear_stat_source(str(file).encode(), ctypes.byref(fsz), ctypes.byref(fmt)), "bear_stat_source")
+        path = cache_path_for(file, binary_cache)
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        _lib.check(L.bear_cache_write(path.encode(), kmers.ctypes.data, counts.ctypes.data, n.value, int(lag), int(num_ds),
+                                      fsz.value, fmt.value), "bear_cache_write")
     return CountDataset(kmers, counts, alphabet, batch_size, dtype)
 
 

@@ -315,3 +315,21 @@ def logdir_sample(counts, prior, h, vans, mc_samples, get_map=False, with_ar=Fal
                                                int(bool(get_map)), int(seed) & (2 ** 64 - 1), int(row_base), _ptr(out), _stream())
     _lib.check(st, "bear_logdir_sample_f64")
     return out
+
+
+def shuffle_rows(src, seed):
+    """One launch of ``bear_shuffle_rows``: a new tensor with ``dst[i] = src[perm_seed(i)]`` along dim 0."""
+    if not (src.is_cuda and src.is_contiguous() and src.dim() >= 1):
+        raise ValueError("src must be a contiguous CUDA tensor")
+    dst = torch.empty_like(src)
+    n = src.shape[0]
+    row_bytes = src.element_size() * (src.numel() // n) if n else 0
+    with torch.cuda.device(src.device):
+        st = _lib.lib().bear_shuffle_rows(_ptr(src), _ptr(dst), n, row_bytes, int(seed) & (2 ** 64 - 1), _stream())
+    _lib.check(st, "bear_shuffle_rows")
+    return dst
+
+
+def shuffle_source_row(i, n_rows, seed):
+    """Host evaluation of the permutation: the source row of shuffled row i."""
+    return int(_lib.lib().bear_shuffle_source_row(int(i), int(n_rows), int(seed) & (2 ** 64 - 1)))

@@ -225,6 +225,32 @@ int bear_count_rows(const char *path, uint64_t *n_rows_out);
 int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint64_t max_rows, char *kmers,
                           uint32_t *counts, uint64_t *n_rows_out);
 
+/*
+ * Binary cache of a parsed count table: what bear_parse_counts_tsv produced, stored as it is uploaded,
+ * so later runs / other ranks skip the text decode (the reference re-decodes per process and caches in RAM only,
+ * bear_model/dataloader.py:47-48).  File: 64-byte header {"BEARCT01", n_rows, lag, num_ds, size and mtime of the
+ * source text, offsets}, k-mer bytes [n_rows, lag], uint32 counts [num_ds, n_rows, 5].
+ *   bear_stat_source: size / mtime (ns) of a text file, the staleness key stored in the header.
+ *   bear_cache_write: atomic (temporary file + rename).
+ *   bear_cache_read:  rows [row0, row0 + n_rows) into kmers [host, nullable] char [n_rows, lag] and
+ *                     counts [host] uint32 [num_ds, n_rows, 5] -- a rank reads only its shard.
+ */
+int bear_stat_source(const char *path, uint64_t *size_out, int64_t *mtime_ns_out);
+int bear_cache_write(const char *path, const char *kmers, const uint32_t *counts, uint64_t n_rows, int lag, int num_ds,
+                     uint64_t src_size, int64_t src_mtime_ns);
+int bear_cache_info(const char *path, uint64_t *n_rows, int *lag, int *num_ds, uint64_t *src_size, int64_t *src_mtime_ns);
+int bear_cache_read(const char *path, uint64_t row0, uint64_t n_rows, char *kmers, uint32_t *counts);
+
+/*
+ * On-device shuffle of resident rows (replaces the `shuf` step the reference asks for before training,
+ * docs/usage.rst:191-200): dst[i] = src[perm(i)], perm a keyed bijection of [0, n_rows) (4-round Feistel network with
+ * cycle walking; bear_shuffle_source_row evaluates it on the host, oracle/bear_oracle.py:shuffle_perm restates it).
+ *   src, dst [dev] n_rows rows of row_bytes bytes (20: a count slab; 8: packed k-mers; lag: k-mer bytes); dst != src.
+ * Calling it with the same seed on every column of a table keeps the columns aligned.
+ */
+int bear_shuffle_rows(const void *src, void *dst, uint64_t n_rows, uint32_t row_bytes, uint64_t seed, void *stream);
+uint64_t bear_shuffle_source_row(uint64_t i, uint64_t n_rows, uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

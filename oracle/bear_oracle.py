@@ -486,3 +486,29 @@ def get_pdf_numpy(counts, ar_vals, h, vans, mc_samples, get_map, seed=0, row_bas
     mx = g.max(axis=-1, keepdims=True)
     lse = mx + np.log(np.exp(g - mx).sum(axis=-1, keepdims=True))                        # :177-178
     return np.transpose(g - lse, [2, 3, 1, 0])                                           # :181-183
+
+
+# --------------------------------------------------------------------------- row shuffle
+def shuffle_perm(n, seed):
+    """Source row of every shuffled row, ``dst[i] = src[perm[i]]``: the keyed bijection of bear_shuffle_rows
+    (kernels_shuffle.h) -- a 4-round Feistel network on 2*half_bits >= log2(n) bits, cycle-walked into [0, n).
+    Stands in for the `shuf` of docs/usage.rst:191-200 (any uniform-looking permutation serves that purpose)."""
+    n = int(n)
+    hb = 1
+    while hb < 32 and (1 << (2 * hb)) < n:
+        hb += 1
+    mask = np.uint64((1 << hb) - 1)
+    x = np.arange(n, dtype=np.uint64)
+    todo = np.ones(n, dtype=bool)
+    with np.errstate(over="ignore"):
+        while todo.any():
+            idx = np.nonzero(todo)[0]
+            v = x[idx]
+            l, r = v >> np.uint64(hb), v & mask
+            for k in range(4):
+                f = _mix64(np.uint64(seed) ^ (r + np.uint64((k + 1) << 58))) & mask
+                l, r = r, l ^ f
+            v = (l << np.uint64(hb)) | r
+            x[idx] = v
+            todo[idx] = v >= np.uint64(n)
+    return x.astype(np.int64)

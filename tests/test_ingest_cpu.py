@@ -1,0 +1,61 @@
+"""CPU tests of the ingestion add-ons: the binary cache of a parsed table and the shuffle
+permutation (host evaluation through the C ABI against the oracle restatement)."""
+import ctypes
+import os
+import shutil
+
+import numpy as np
+
+import bear_oracle as o
+from conftest import YSD1
+
+
+def test_binary_cache_roundtrip_and_staleness(tmp_path, ysd1):
+    from bear_amd import _lib, dataloader
+    src = tmp_path / "table.tsv"
+    shutil.copy(YSD1, src)
+    cdir = tmp_path / "cache"
+    d0 = dataloader.dataloader(str(src), "dna", 500, 3, binary_cache=str(cdir))
+    cpath = dataloader.cache_path_for(str(src), str(cdir))
+    assert os.path.exists(cpath)
+    kmers, counts = ysd1                                         # oracle parse of the same file
+    assert np.array_equal(d0.counts, counts.transpose(1, 0, 2).astype(np.uint32))
+    # second load: served from the cache (the text is not needed any more -> make it unparsable but same size/mtime)
+    st = os.stat(src)
+    raw = src.read_bytes()
+    src.write_bytes(b"#" * len(raw))
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns))
+    d1 = dataloader.dataloader(str(src), "dna", 500, 3, binary_cache=str(cdir))
+    assert np.array_equal(d1.counts, d0.counts) and np.array_equal(d1.kmers, d0.kmers)
+    assert [bytes(r).decode() for r in d1.kmers[:3]] == list(kmers[:3])
+    # a rank reads only its shard
+    L = _lib.lib()
+    km = np.zeros((100, 5), dtype=np.uint8)
+    cn = np.zeros((3, 100, 5), dtype=np.uint32)
+    assert L.bear_cache_read(cpath.encode(), 200, 100, km.ctypes.data, cn.ctypes.data) == 0
+    assert np.array_equal(cn, d0.counts[:, 200:300]) and np.array_equal(km, d0.kmers[200:300])
+    assert L.bear_cache_read(cpath.encode(), 1300, 100, km.ctypes.data, cn.ctypes.data) == -1   # beyond the table
+    # stale: source rewritten with different content -> cache ignored and rebuilt
+    src.write_bytes(raw[: raw.index(b"\n", 2000) + 1])
+    d2 = dataloader.dataloader(str(src), "dna", 500, 3, binary_cache=str(cdir))
+    assert d2.num_rows < d0.num_rows and np.array_equal(d2.counts, d0.counts[:, :d2.num_rows])
+    n = ctypes.c_uint64()
+    assert L.bear_cache_info(cpath.encode(), ctypes.byref(n), None, None, None, None) == 0 and n.value == d2.num_rows
+    # a corrupt cache is rejected, not trusted
+    with open(cpath, "r+b") as fh:
+        fh.write(b"XXXX")
+    assert L.bear_cache_info(cpath.encode(), ctypes.byref(n), None, None, None, None) == -7
+    d3 = dataloader.dataloader(str(src), "dna", 500, 3, binary_cache=str(cdir))
+    assert np.array_equal(d3.counts, d2.counts)
+
+
+def test_shuffle_permutation_is_a_bijection_and_matches_the_abi():
+    from bear_amd import kernels
+    for n in [1, 2, 3, 5, 16, 17, 1365, 4097, 100003]:
+        p = o.shuffle_perm(n, 20211012)
+        assert np.array_equal(np.sort(p), np.arange(n))
+        for i in {0, n // 3, n - 1}:
+            assert kernels.shuffle_source_row(i, n, 20211012) == p[i]
+    # different seeds give different orders; fixed points are rare
+    a, b = o.shuffle_perm(10000, 1), o.shuffle_perm(10000, 2)
+    assert (a != b).mean() > 0.99 and (a == np.arange(10000)).mean() < 0.01

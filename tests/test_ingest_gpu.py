@@ -1,0 +1,44 @@
+"""GPU tests of the ingestion add-ons: bear_shuffle_rows against the oracle permutation (bit exact)
+and training on a device-shuffled table against the oracle loop run on the permuted rows."""
+import numpy as np
+import pytest
+import torch
+
+import bear_oracle as o
+from bear_amd import ar_funcs, bear_ref, dataloader, kernels
+from conftest import YSD1
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1365, 100003])
+def test_shuffle_rows_matches_oracle_permutation(n):
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(n)
+    perm = o.shuffle_perm(n, 99)
+    for shape, dtype in (((n, 5), np.int32), ((n, 13), np.int8), ((n,), np.int64), ((n, 5), np.float64)):
+        a = rng.integers(-100, 100, size=shape).astype(dtype)
+        got = kernels.shuffle_rows(torch.from_numpy(a).to(dev), 99).cpu().numpy()
+        assert np.array_equal(got, a[perm]), (shape, dtype)
+
+
+def test_training_on_shuffled_table_matches_oracle_on_permuted_rows(ysd1):
+    _, counts = ysd1
+    perm = o.shuffle_perm(1365, 5)
+    data = dataloader.dataloader(YSD1, "dna", 500, 3).shuffle(5)
+    loss_save = []
+    bear_ref.train(data.repeat(1), 1365, 1, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False,
+                   loss_save=loss_save)
+    c = counts[perm]
+    p = np.array([0.0, np.log(1 / 30), -np.log(100)])
+    r = o.bear_ref_step(c[:500, 0], c[:500, 2], *p)
+    assert np.isclose(loss_save[0], (1365 / 500) * r["ll"], rtol=1e-11)
+    # the batches differ from file order (that is the point), the table total does not
+    r_file = o.bear_ref_step(counts[:500, 0], counts[:500, 2], *p)
+    assert not np.isclose(r["ll"], r_file["ll"], rtol=1e-6)
+    full = dataloader.dataloader(YSD1, "dna", 1365, 3)
+    l0, l1 = [], []
+    bear_ref.train(full.repeat(1), 1365, 1, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False, loss_save=l0)
+    bear_ref.train(full.shuffle(11).repeat(1), 1365, 1, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False,
+                   loss_save=l1)
+    assert np.isclose(l0[0], l1[0], rtol=1e-12)
