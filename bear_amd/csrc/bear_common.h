@@ -35,6 +35,8 @@ struct bear_ws {
   double *eval_out;         // [EVL_MAX_OUT] scratch result vector (bear_bmm_f64)
   int eval_blocks;
   double *lin_partials;     // [num_cu][LIN_MAX_GRAD] d/d mat partials (kernels_linear.h)
+  double *cnn_partials;     // [cnn_blocks][cnn total] parameter-gradient partials (kernels_cnn.h), grown on demand
+  size_t cnn_partials_cap;  // doubles
 };
 
 struct bear_params {

@@ -20,6 +20,7 @@
 #include "kernels_linear.h"
 #include "kernels_sample.h"
 #include "kernels_shuffle.h"
+#include "kernels_cnn.h"
 
 #ifdef PLN_STAMPS  // developer build: per-wave phase timers of dm_prior_plan_kernel land in ws->dbg
 #define PLN_DBG_ARG , ws->dbg
@@ -151,6 +152,7 @@ int bear_ws_destroy(bear_ws *ws) {
   (void)hipFree(ws->eval_partials);
   (void)hipFree(ws->eval_out);
   (void)hipFree(ws->lin_partials);
+  if (ws->cnn_partials) (void)hipFree(ws->cnn_partials);
   (void)hipSetDevice(prev);
   delete ws;
   return BEAR_OK;
@@ -750,6 +752,66 @@ int bear_shuffle_rows(const void *src, void *dst, uint64_t n_rows, uint32_t row_
 
 uint64_t bear_shuffle_source_row(uint64_t i, uint64_t n_rows, uint64_t seed) {
   return (n_rows == 0 || i >= n_rows) ? i : shf_perm(i, n_rows, shf_half_bits(n_rows), seed);
+}
+
+static int cnn_check(const bear_ws *ws, int lag, int fw, int nf, int l1) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (lag < 1 || lag > CNN_MAX_LAG || fw < 1 || fw > lag || nf != CNN_NF || l1 != CNN_L1) return BEAR_ERR_INVALID_ARG;
+  return BEAR_OK;
+}
+
+int bear_cnn_param_count(int lag, int filter_width, int num_filters, int layer1_width) {
+  if (lag < 1 || lag > CNN_MAX_LAG || filter_width < 1 || filter_width > lag || num_filters != CNN_NF || layer1_width != CNN_L1)
+    return BEAR_ERR_INVALID_ARG;
+  return cnn_make_dims(lag, filter_width).total;
+}
+
+int bear_cnn_forward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows, int lag, int filter_width, int num_filters,
+                         int layer1_width, const double *params, double *prior, double *t1_save, void *stream) {
+  int st = cnn_check(ws, lag, filter_width, num_filters, layer1_width);
+  if (st != BEAR_OK) return st;
+  if (n_rows == 0) return BEAR_OK;
+  if (!kmer_code || !params || !prior || misaligned(t1_save) || (reinterpret_cast<uintptr_t>(prior) & 7u)) return BEAR_ERR_INVALID_ARG;
+  const cnn_dims D = cnn_make_dims(lag, filter_width);
+  const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF);
+  uint64_t blocks = (n_rows + CNN_THREADS - 1) / CNN_THREADS;
+  if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
+  hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), lds, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, prior, t1_save);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_cnn_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows, int lag, int filter_width, int num_filters,
+                          int layer1_width, const double *params, const double *t1_save, const double *prior,
+                          const double *grad_prior, double *grad_params, void *stream) {
+  int st = cnn_check(ws, lag, filter_width, num_filters, layer1_width);
+  if (st != BEAR_OK) return st;
+  if (!params || !grad_params) return BEAR_ERR_INVALID_ARG;
+  if (n_rows && (!kmer_code || !t1_save || !prior || !grad_prior || misaligned(t1_save))) return BEAR_ERR_INVALID_ARG;
+  const cnn_dims D = cnn_make_dims(lag, filter_width);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint64_t blocks = (n_rows + CNN_THREADS - 1) / CNN_THREADS;
+  if (blocks > (uint64_t)ws->num_cu * 2) blocks = (uint64_t)ws->num_cu * 2;
+  if (blocks == 0) blocks = 1;
+  const size_t need = (size_t)blocks * D.total;
+  if (ws->cnn_partials_cap < need) {
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ws->cnn_partials) (void)hipFree(ws->cnn_partials);
+    ws->cnn_partials = nullptr;
+    ws->cnn_partials_cap = 0;
+    HIP_TRY(hipMalloc(&ws->cnn_partials, sizeof(double) * need));
+    ws->cnn_partials_cap = need;
+  }
+  const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (size_t)D.total);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(cnn_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(cnn_backward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), lds, s,
+                     reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, t1_save, prior, grad_prior,
+                     ws->cnn_partials);
+  hipLaunchKernelGGL(cnn_finalize_kernel, dim3((D.total + 3) / 4), dim3(256), 0, s, ws->cnn_partials, (int)blocks, D.total, grad_params);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
 }
 
 int bear_synth_counts_u32(uint64_t seed, uint64_t row0, uint64_t n_rows, int dense, uint32_t *train,

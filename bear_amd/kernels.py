@@ -333,3 +333,56 @@ def shuffle_rows(src, seed):
 def shuffle_source_row(i, n_rows, seed):
     """Host evaluation of the permutation: the source row of shuffled row i."""
     return int(_lib.lib().bear_shuffle_source_row(int(i), int(n_rows), int(seed) & (2 ** 64 - 1)))
+
+
+CNN_NUM_FILTERS, CNN_LAYER1_WIDTH, CNN_MAX_LAG = 30, 16, 21   # CNN_NF / CNN_L1 / CNN_MAX_LAG of kernels_cnn.h
+
+
+def cnn_supported(lag, alphabet_size, filter_width, num_filters, kmer_layer1_width):
+    return (alphabet_size == 4 and num_filters == CNN_NUM_FILTERS and kmer_layer1_width == CNN_LAYER1_WIDTH
+            and 1 <= filter_width <= lag <= CNN_MAX_LAG)
+
+
+def cnn_param_count(lag, filter_width):
+    n = _lib.lib().bear_cnn_param_count(int(lag), int(filter_width), CNN_NUM_FILTERS, CNN_LAYER1_WIDTH)
+    _lib.check(min(n, 0), "bear_cnn_param_count")
+    return n
+
+
+def _check_codes(kmer_code):
+    if not (kmer_code.is_cuda and kmer_code.dtype == torch.int64 and kmer_code.dim() == 1 and kmer_code.is_contiguous()):
+        raise ValueError("kmer_code must be a contiguous CUDA int64 tensor [n_rows] (pack_kmers)")
+
+
+def cnn_forward(kmer_code, flat_params, lag, filter_width, save=True, ws=None):
+    """One launch of ``bear_cnn_forward_f64``: (prior [n,5], t1 [n,16] or None)."""
+    _check_codes(kmer_code)
+    n = kmer_code.shape[0]
+    if not (flat_params.is_cuda and flat_params.dtype == torch.float64 and flat_params.is_contiguous()
+            and flat_params.numel() == cnn_param_count(lag, filter_width)):
+        raise ValueError("flat_params must be the contiguous CUDA float64 parameter vector of bear_cnn_param_count elements")
+    ws = ws or default_workspace(kmer_code.device)
+    prior = torch.empty((n, 5), dtype=torch.float64, device=kmer_code.device)
+    t1 = torch.empty((n, CNN_LAYER1_WIDTH), dtype=torch.float64, device=kmer_code.device) if save else None
+    with torch.cuda.device(kmer_code.device):
+        st = _lib.lib().bear_cnn_forward_f64(ws.handle, _ptr(kmer_code), n, int(lag), int(filter_width), CNN_NUM_FILTERS,
+                                             CNN_LAYER1_WIDTH, _ptr(flat_params), _ptr(prior), _ptr(t1), _stream())
+    _lib.check(st, "bear_cnn_forward_f64")
+    return prior, t1
+
+
+def cnn_backward(kmer_code, flat_params, lag, filter_width, t1, prior, grad_prior, ws=None):
+    """One launch of ``bear_cnn_backward_f64``: d L / d flat_params."""
+    _check_codes(kmer_code)
+    n = kmer_code.shape[0]
+    for t, w in ((t1, CNN_LAYER1_WIDTH), (prior, 5), (grad_prior, 5)):
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.shape == (n, w)):
+            raise ValueError("t1 [n,16], prior [n,5] and grad_prior [n,5] must be contiguous CUDA float64 tensors")
+    ws = ws or default_workspace(kmer_code.device)
+    grad = torch.empty_like(flat_params)
+    with torch.cuda.device(kmer_code.device):
+        st = _lib.lib().bear_cnn_backward_f64(ws.handle, _ptr(kmer_code), n, int(lag), int(filter_width), CNN_NUM_FILTERS,
+                                              CNN_LAYER1_WIDTH, _ptr(flat_params), _ptr(t1), _ptr(prior), _ptr(grad_prior),
+                                              _ptr(grad), _stream())
+    _lib.check(st, "bear_cnn_backward_f64")
+    return grad

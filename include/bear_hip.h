@@ -140,6 +140,26 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
                        double *out, double *grad_mat, void *stream);
 
 /*
+ * The convolutional AR function of bear_net, forward and backward (replaces make_ar_func_cnn's ar_func,
+ * bear_model/ar_funcs.py:49-99, and grad_tape.gradient through it, bear_model/bear_net.py:193) for 4-letter alphabets,
+ * num_filters = 30 and kmer_layer1_width = 16 (every reference config), lag <= 21, filter_width <= lag.
+ *   kmer_code [dev] uint64 [n_rows]      packed contexts (bear_pack_kmers_u64)
+ *   params    [dev] double [bear_cnn_param_count(...)]  the parameters flattened and concatenated in the reference's
+ *             order (ar_funcs.py:98-99): filters [fw,5,nf], intercept0 [P,nf], weights1 [P,nf,l1], intercept1 [l1],
+ *             weights2 [l1,5], intercept2 [5], scale0 [P,nf], scale1 [l1];  P = lag - fw + 1
+ *   forward:  prior [dev] double [n_rows,5] = ar_func rows; t1_save [dev, nullable] double [n_rows,16] = the layer-1
+ *             pre-normalisation sums, which the backward entry takes instead of redoing the first tensordot
+ *   backward: grad_prior [dev] double [n_rows,5] = d L / d prior (e.g. from bear_dm_prior_plan_grad_f64);
+ *             grad_params [dev] double [param_count] = d L / d params (overwritten), same layout as params.
+ */
+int bear_cnn_param_count(int lag, int filter_width, int num_filters, int layer1_width);
+int bear_cnn_forward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows, int lag, int filter_width, int num_filters,
+                         int layer1_width, const double *params, double *prior, double *t1_save, void *stream);
+int bear_cnn_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows, int lag, int filter_width, int num_filters,
+                          int layer1_width, const double *params, const double *t1_save, const double *prior,
+                          const double *grad_prior, double *grad_params, void *stream);
+
+/*
  * Held-out evaluation, one pass over a row range: replaces _evaluation_step of bear_model/bear_net.py:323-371
  * (and its bear_ref twin, bear_ref.py:391-446, with prior = the reference-mixed AR rows) and, with n_h > 1,
  * one batch of h_scan (bear_net.py:465-531).

@@ -1,0 +1,99 @@
+"""GPU parity tests of the fused convolutional AR function (bear_cnn_forward_f64 / bear_cnn_backward_f64, through the
+C ABI): forward against the oracle's restatement of ar_funcs.py:91-97, backward against torch fp64 autograd of the
+same formulas (the torch reference kept for this floating-point kernel).  Tolerances: rows 1e-12 relative; parameter
+gradients 1e-10 of the gradient's largest entry per tensor."""
+import numpy as np
+import pytest
+import torch
+
+import bear_oracle as o
+from bear_amd import ar_funcs, core, kernels
+
+pytestmark = pytest.mark.gpu
+
+ROW_RTOL = 1e-12
+GRAD_RTOL = 1e-10
+
+
+def _random_kmers(n, lag, rng, with_specials=True):
+    letters = np.array(list("ACGT"))
+    km = ["".join(rng.choice(letters, size=lag)) for _ in range(n)]
+    if with_specials and n >= 8:
+        km[0] = "[" * lag
+        km[1] = "[" * (lag - 1) + "A"
+        km[2] = "N" + km[2][1:]            # unknown letter: all-zero one-hot row (core.py:173)
+        km[3] = km[3][:-1] + "x"
+    return km
+
+
+def _make(lag, fw, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    ar_func, params = ar_funcs.make_ar_func_cnn(lag, 4, filter_width=fw, device=dev, generator=g)
+    with torch.no_grad():                 # move every parameter off its initial value (ones / zeros)
+        for p in params:
+            p.add_(0.3 * torch.randn(p.shape, dtype=p.dtype, device=dev, generator=g))
+    return ar_func, params
+
+
+@pytest.mark.parametrize("lag,fw,n", [(13, 8, 1000), (5, 3, 300), (21, 21, 130), (4, 1, 70), (1, 1, 5)])
+def test_cnn_forward_matches_oracle(lag, fw, n):
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(lag * 100 + fw)
+    kmers = _random_kmers(n, lag, rng)
+    ar_func, params = _make(lag, fw, dev, 3)
+    codes = torch.from_numpy(core.encode_kmers(kmers, "dna")).to(dev)
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+    assert flat.numel() == kernels.cnn_param_count(lag, fw)
+    prior, t1 = kernels.cnn_forward(kernels.pack_kmers(codes), flat, lag, fw)
+    want = o.ar_func_cnn(o.one_hot(kmers, "dna"), [p.detach().cpu().numpy() for p in params])
+    assert np.allclose(prior.cpu().numpy(), want, rtol=ROW_RTOL, atol=1e-300)
+    assert t1.shape == (n, 16)
+
+
+@pytest.mark.parametrize("lag,fw,n", [(13, 8, 3000), (5, 3, 1365), (7, 7, 64), (2, 1, 3)])
+def test_cnn_backward_matches_torch_autograd(lag, fw, n):
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(lag * 7 + fw)
+    kmers = _random_kmers(n, lag, rng)
+    ar_func, params = _make(lag, fw, dev, 5)
+    codes = torch.from_numpy(core.encode_kmers(kmers, "dna")).to(dev)
+    packed = kernels.pack_kmers(codes)
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+    prior, t1 = kernels.cnn_forward(packed, flat, lag, fw)
+    grad_rows = torch.from_numpy(rng.standard_normal((n, 5)) * np.exp(rng.normal(size=(n, 1)))).to(dev)
+    got = kernels.cnn_backward(packed, flat, lag, fw, t1, prior, grad_rows)
+    # torch reference: the one-hot formulation (conv1d / tensordot), autograd
+    rows = ar_func(core.tf_one_hot(kmers, "dna", device=dev))
+    assert torch.allclose(rows, prior, rtol=1e-11, atol=0)
+    rows.backward(grad_rows)
+    k = 0
+    for p in params:
+        want = p.grad.reshape(-1)
+        g = got[k:k + want.numel()]
+        k += want.numel()
+        assert (g - want).abs().max().item() <= GRAD_RTOL * max(want.abs().max().item(), 1e-30), (p.shape,)
+    assert k == got.numel()
+
+
+def test_cnn_backward_is_linear_and_shard_additive():
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0)
+    lag, fw, n = 13, 8, 5000
+    codes = torch.from_numpy(rng.integers(0, 4, size=(n, lag)).astype(np.int8)).to(dev)
+    packed = kernels.pack_kmers(codes)
+    _, params = _make(lag, fw, dev, 1)
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+    prior, t1 = kernels.cnn_forward(packed, flat, lag, fw)
+    g = torch.from_numpy(rng.standard_normal((n, 5))).to(dev)
+    full = kernels.cnn_backward(packed, flat, lag, fw, t1, prior, g)
+    a = kernels.cnn_backward(packed[:2000].contiguous(), flat, lag, fw, t1[:2000].contiguous(), prior[:2000].contiguous(),
+                             g[:2000].contiguous())
+    b = kernels.cnn_backward(packed[2000:].contiguous(), flat, lag, fw, t1[2000:].contiguous(), prior[2000:].contiguous(),
+                             g[2000:].contiguous())
+    scale = full.abs().max().item()
+    assert (full - (a + b)).abs().max().item() <= 1e-12 * scale
+    twice = kernels.cnn_backward(packed, flat, lag, fw, t1, prior, 2.0 * g)
+    assert (twice - 2.0 * full).abs().max().item() <= 1e-12 * scale
+    empty = kernels.cnn_backward(packed[:0].contiguous(), flat, lag, fw, t1[:0].contiguous(), prior[:0].contiguous(),
+                                 g[:0].contiguous())
+    assert torch.count_nonzero(empty).item() == 0
