@@ -792,8 +792,14 @@ int bear_cnn_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_row
   if (n_rows && (!kmer_code || !t1_save || !prior || !grad_prior || misaligned(t1_save))) return BEAR_ERR_INVALID_ARG;
   const cnn_dims D = cnn_make_dims(lag, filter_width);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  uint64_t blocks = (n_rows + CNN_THREADS - 1) / CNN_THREADS;
-  if (blocks > (uint64_t)ws->num_cu * 2) blocks = (uint64_t)ws->num_cu * 2;
+  // one block per CU; as many waves per block as the LDS holds (gradient image + per-wave staging)
+  const size_t fixed = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (size_t)((D.total + 1) & ~1));
+  int waves = 4;
+  while (waves > 1 && fixed + (size_t)waves * CNN_WAVE_DOUBLES * sizeof(double) > 160u * 1024u) waves >>= 1;
+  const size_t lds = fixed + (size_t)waves * CNN_WAVE_DOUBLES * sizeof(double);
+  if (lds > 160u * 1024u) return BEAR_ERR_INVALID_ARG;
+  uint64_t blocks = (n_rows + 64 * waves - 1) / (64 * waves);
+  if (blocks > (uint64_t)ws->num_cu) blocks = (uint64_t)ws->num_cu;
   if (blocks == 0) blocks = 1;
   const size_t need = (size_t)blocks * D.total;
   if (ws->cnn_partials_cap < need) {
@@ -804,9 +810,8 @@ int bear_cnn_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_row
     HIP_TRY(hipMalloc(&ws->cnn_partials, sizeof(double) * need));
     ws->cnn_partials_cap = need;
   }
-  const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (size_t)D.total);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(cnn_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(cnn_backward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), lds, s,
+  hipLaunchKernelGGL(cnn_backward_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, s,
                      reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, t1_save, prior, grad_prior,
                      ws->cnn_partials);
   hipLaunchKernelGGL(cnn_finalize_kernel, dim3((D.total + 3) / 4), dim3(256), 0, s, ws->cnn_partials, (int)blocks, D.total, grad_params);

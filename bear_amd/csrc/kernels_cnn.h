@@ -15,8 +15,9 @@
 // position's 30 filter responses in registers, takes the filter rows from an LDS table (6 rows per tap: A, C, G, T,
 // '[' and a zero row for any other character) and every other weight from SGPRs (uniform scalar loads), and
 // writes its 5 prior rows plus the 16 pre-normalisation layer-1 sums t1 (so that the backward kernel does not redo
-// the first tensordot).  Backward recomputes the cheap per-position quantities and accumulates the parameter
-// gradients per block (LDS), one partial vector per block, fixed-order finalize.
+// the first tensordot).  Backward recomputes the cheap per-position quantities; sums over contexts go through LDS
+// staging into fp64 MFMA products / column sums (see the backward section), one partial vector per block, fixed-order
+// finalize.
 //
 // Packed parameter vector (doubles), the reference's parameter order (ar_funcs.py:98-99):
 //   filters [fw][5][nf] | intercept0 [P][nf] | weights1 [P][nf][l1] | intercept1 [l1] | weights2 [l1][5] |
@@ -61,8 +62,23 @@ __device__ __forceinline__ void cnn_stage_filters(double *Fs, const double *__re
 }
 
 // elu(y) and its derivative: y > 0 ? (y, 1) : (exp(y) - 1, exp(y))     (tf.nn.elu, alpha = 1)
+__device__ __forceinline__ double cnn_exp_neg(double z, const double *__restrict__ tab) {   // bear_exp_tab without its branch
+  z = z > -700.0 ? z : -700.0;
+  const double kf = __builtin_rint(z * 184.66496523378731);
+  double r = __builtin_fma(kf, -0x1.62e42fee00000p-8, z);
+  r = __builtin_fma(kf, -0x1.a39ef35793c76p-40, r);
+  const int ki = (int)kf;
+  const double t = tab[ki & (BEAR_EXPTAB_N - 1)];
+  double p = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = __builtin_fma(r, p, 1.0 / 6.0);
+  p = __builtin_fma(r, p, 0.5);
+  p = __builtin_fma(r, p, 1.0);
+  const double v = __builtin_fma(t, r * p, t);
+  return __longlong_as_double(__double_as_longlong(v) + ((long long)(ki >> 7) << 52));
+}
+
 __device__ __forceinline__ double cnn_elu(double y, const double *exptab, double &deriv) {
-  const double ex = bear_exp_tab(y < 0.0 ? y : 0.0, exptab);
+  const double ex = cnn_exp_neg(y < 0.0 ? y : 0.0, exptab);
   deriv = y > 0.0 ? 1.0 : ex;
   return y > 0.0 ? y : ex - 1.0;
 }
@@ -149,12 +165,29 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_forward_kernel(const unsigned
       cnn_conv_norm(Fs, code, p, D.fw, x);
       const double *__restrict__ s0 = params + D.os0 + p * CNN_NF, *__restrict__ b0 = params + D.ob0 + p * CNN_NF;
       const double *__restrict__ W1 = params + D.oW1 + p * CNN_NF * CNN_L1;
+      // weights of filter f+1 are fetched (uniform scalar loads) while filter f is consumed; the scheduling barrier keeps
+      // the compiler from hoisting all 480 loads of a position at once (that spilled ~1100 SGPRs)
+      double wc[CNN_L1], wn[CNN_L1], sc = s0[0], bc = b0[0], sn = 0.0, bn = 0.0;
+#pragma unroll
+      for (int j = 0; j < CNN_L1; ++j) wc[j] = W1[j];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int f = 0; f < CNN_NF; ++f) {
-        double dv;
-        const double e = cnn_elu(__builtin_fma(s0[f], x[f], b0[f]), exptab, dv);
+        if (f + 1 < CNN_NF) {
+          sn = s0[f + 1];
+          bn = b0[f + 1];
 #pragma unroll
-        for (int j = 0; j < CNN_L1; ++j) t1[j] = __builtin_fma(e, W1[f * CNN_L1 + j], t1[j]);
+          for (int j = 0; j < CNN_L1; ++j) wn[j] = W1[(f + 1) * CNN_L1 + j];
+        }
+        double dv;
+        const double e = cnn_elu(__builtin_fma(sc, x[f], bc), exptab, dv);
+#pragma unroll
+        for (int j = 0; j < CNN_L1; ++j) t1[j] = __builtin_fma(e, wc[j], t1[j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < CNN_L1; ++j) wc[j] = wn[j];
+        sc = sn;
+        bc = bn;
       }
     }
     double n1[CNN_L1], e1[CNN_L1], d1[CNN_L1];
@@ -188,9 +221,37 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_forward_kernel(const unsigned
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// grad_prior [n,5] = d loss / d prior rows (what the DM kernel returns, already scaled by the caller or not: linear).
-// Accumulates d loss / d params: per block in LDS (fp64 LDS atomics), one partial vector per block.
+// grad_prior [n,5] = d L / d prior rows (what the DM kernel returns).  A wave owns a tile of 64 contexts (lane = context)
+// and everything summed over contexts leaves the lanes through LDS staging, never through same-address atomics
+// (64 lanes adding to one LDS address serialise: the first version of this kernel ran 80x slower):
+//   * d/d weights1[p] = E0_p^T dT1 and d/d filters = OneHot_p^T dConv_p are 16x16x4 fp64 MFMA products whose K
+//     dimension is the tile's 64 contexts (operands staged [feature][context], row stride 68 doubles: conflict-free
+//     lane=context writes, 2-way -- the minimum for 8-byte reads -- operand reads);
+//   * the per-feature sums (scale / intercept gradients, weights2) are staged with row stride 65 and summed by
+//     (column, half) lanes;
+//   * the tile results are added to the block's gradient image in LDS with one fp64 LDS atomic per lane and value,
+//     all lanes on distinct addresses;  d e0 = W1 dT1 stays on the VALU with SGPR weights (as the forward pass).
+typedef double cnn_d4 __attribute__((ext_vector_type(4)));
+#define CNN_ES 68            // operand staging: row stride in doubles
+#define CNN_CS 65            // column-sum staging: row stride in doubles
+#define CNN_E_DOUBLES (32 * CNN_ES)
+#define CNN_T_DOUBLES (16 * CNN_ES)
+#define CNN_WAVE_DOUBLES (CNN_E_DOUBLES + CNN_T_DOUBLES + 64)
+
 __device__ __forceinline__ void cnn_lds_add(double *addr, double v) { atomicAdd(addr, v); }
+
+// sums 32 staged columns (layout [column][context], stride CNN_CS) over the 64 contexts; lane (c = lane & 31, half) adds
+// its half-sum to dst[col0 + c] when col0 + c < n_cols
+__device__ __forceinline__ void cnn_colsum_add(const double *E, double *dst, int n_cols, uint32_t lane) {
+  const double *src = E + (lane & 31u) * CNN_CS + (lane >> 5) * 32u;
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 32; r += 2) {
+    s0 += src[r];
+    s1 += src[r + 1];
+  }
+  if ((int)(lane & 31u) < n_cols) cnn_lds_add(dst + (lane & 31u), s0 + s1);
+}
 
 __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigned long long *__restrict__ codes, uint64_t n_rows,
                                                                     cnn_dims D, const double *__restrict__ params,
@@ -201,17 +262,40 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
   extern __shared__ __attribute__((aligned(16))) double cnn_lds[];
   double *exptab = cnn_lds;
   double *Fs = cnn_lds + BEAR_EXPTAB_N;
-  double *G = Fs + D.fw * 6 * CNN_NF;             // [total] block gradient accumulators, parameter layout
+  double *G = Fs + D.fw * 6 * CNN_NF;             // [total] block gradient image, parameter layout
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  double *E = G + ((D.total + 1) & ~1) + wave * CNN_WAVE_DOUBLES;   // [32][CNN_ES] staging
+  double *T = E + CNN_E_DOUBLES;                                    // [16][CNN_ES] dT1
+  unsigned long long *Cw = reinterpret_cast<unsigned long long *>(T + CNN_T_DOUBLES);   // [64] packed contexts
   if (threadIdx.x < BEAR_EXPTAB_N) exptab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / BEAR_EXPTAB_N));
-  cnn_stage_filters(Fs, params, D);
-  for (int k = threadIdx.x; k < D.total; k += CNN_THREADS) G[k] = 0.0;
+  for (int k = threadIdx.x; k < D.fw * 6 * CNN_NF; k += blockDim.x) {
+    const int w = k / (6 * CNN_NF), r = k - w * 6 * CNN_NF, a = r / CNN_NF, f = r - a * CNN_NF;
+    Fs[k] = a < 5 ? params[D.oF + (w * 5 + a) * CNN_NF + f] : 0.0;
+  }
+  for (int k = threadIdx.x; k < D.total; k += blockDim.x) G[k] = 0.0;
   __syncthreads();
-  for (uint64_t base = (uint64_t)blockIdx.x * CNN_THREADS; base < n_rows; base += (uint64_t)gridDim.x * CNN_THREADS) {
-    const uint64_t i = base + threadIdx.x;
-    if (i >= n_rows) continue;
-    const unsigned long long code = codes[i];
+  const uint64_t n_tiles = (n_rows + 63) / 64;
+  const uint32_t lq = lane >> 4, lr = lane & 15u;     // MFMA lane coordinates: k / row-group index, row / column index
+  const int n_mt = (4 * D.fw + 15) / 16;              // M tiles of the one-hot operand: rows (tap w, letter a < 4)
+  for (uint64_t tile = (uint64_t)blockIdx.x * n_waves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * n_waves) {
+    const uint64_t i = tile * 64 + lane;
+    const bool live = i < n_rows;
+    // dead lanes: every letter "other" and a zero gradient row -> all their contributions are exact zeros
+    unsigned long long code = 0;
+#pragma unroll
+    for (int l = 0; l < 21; ++l) code |= 5ull << (3 * l);
+    if (live) code = codes[i];
+    Cw[lane] = code;
     double t1[CNN_L1], n1[CNN_L1], e1[CNN_L1], d1[CNN_L1];
-    {
+#pragma unroll
+    for (int j = 0; j < CNN_L1; ++j) t1[j] = 0.0;
+    double pr[5], gp[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      pr[b] = 0.2;
+      gp[b] = 0.0;
+    }
+    if (live) {
       const double2 *src = reinterpret_cast<const double2 *>(t1_save + i * CNN_L1);
 #pragma unroll
       for (int j = 0; j < CNN_L1 / 2; ++j) {
@@ -219,86 +303,177 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
         t1[2 * j] = v.x;
         t1[2 * j + 1] = v.y;
       }
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        pr[b] = prior[i * 5 + b];
+        gp[b] = grad_prior[i * 5 + b];
+      }
     }
     const double r1 = cnn_layer1(t1, params, D, exptab, n1, e1, d1);
     // softmax backward
     double dz[5], sg = 0.0;
 #pragma unroll
-    for (int b = 0; b < 5; ++b) {
-      dz[b] = prior[i * 5 + b];
-      sg = __builtin_fma(dz[b], grad_prior[i * 5 + b], sg);
+    for (int b = 0; b < 5; ++b) sg = __builtin_fma(pr[b], gp[b], sg);
+#pragma unroll
+    for (int b = 0; b < 5; ++b) dz[b] = pr[b] * (gp[b] - sg);
+    // layer 2 / layer-1 norm backward; the 117 small gradient columns leave through four 32-column rounds:
+    //   round 0: d weights2[j][b], j < 6 (30 columns) ; round 1: j in [6,12) ; round 2: j in [12,16) + d intercept2 (25)
+    //   round 3: d scale1 (16) + d intercept1 (16)
+    double dy1[CNN_L1];
+    {
+      double ma = 0.0, mb = 0.0;
+#pragma unroll
+      for (int j = 0; j < CNN_L1; ++j) {
+        double de = 0.0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) de = __builtin_fma(params[D.oW2 + j * 5 + b], dz[b], de);
+        dy1[j] = de * d1[j];
+        const double dn = dy1[j] * params[D.os1 + j];
+        t1[j] = dn;
+        ma += dn;
+        mb = __builtin_fma(dn, n1[j], mb);
+      }
+      ma *= 1.0 / CNN_L1;
+      mb *= 1.0 / CNN_L1;
+#pragma unroll
+      for (int j = 0; j < CNN_L1; ++j) t1[j] = r1 * (t1[j] - ma - n1[j] * mb);     // dT1
     }
 #pragma unroll
-    for (int b = 0; b < 5; ++b) {
-      dz[b] *= grad_prior[i * 5 + b] - sg;
-      cnn_lds_add(G + D.ob2 + b, dz[b]);
+    for (int rd = 0; rd < 3; ++rd) {
+#pragma unroll
+      for (int c = 0; c < 30; ++c) {
+        const int j = rd * 6 + c / 5, b = c % 5;
+        if (j < CNN_L1) E[c * CNN_CS + lane] = e1[j] * dz[b];
+        else if (j == CNN_L1) E[c * CNN_CS + lane] = dz[b];       // round 2, columns 20..24: d intercept2
+      }
+      // weights2 [16][5] and intercept2 [5] are adjacent in the parameter vector: columns map to oW2 + 30 rd + c
+      cnn_colsum_add(E, G + D.oW2 + 30 * rd, rd < 2 ? 30 : 25, lane);
     }
-    // layer 2 / layer-1 norm backward -> dt1 (kept in t1)
-    double ma = 0.0, mb = 0.0;
 #pragma unroll
     for (int j = 0; j < CNN_L1; ++j) {
-      double de = 0.0;
-#pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        de = __builtin_fma(params[D.oW2 + j * 5 + b], dz[b], de);
-        cnn_lds_add(G + D.oW2 + j * 5 + b, e1[j] * dz[b]);
-      }
-      const double dy = de * d1[j];
-      cnn_lds_add(G + D.os1 + j, dy * n1[j]);
-      cnn_lds_add(G + D.ob1 + j, dy);
-      const double dn = dy * params[D.os1 + j];
-      t1[j] = dn;
-      ma += dn;
-      mb = __builtin_fma(dn, n1[j], mb);
+      E[j * CNN_CS + lane] = dy1[j] * n1[j];
+      E[(16 + j) * CNN_CS + lane] = dy1[j];
     }
-    ma *= 1.0 / CNN_L1;
-    mb *= 1.0 / CNN_L1;
+    {
+      const double *src = E + (lane & 31u) * CNN_CS + (lane >> 5) * 32u;
+      double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < CNN_L1; ++j) t1[j] = r1 * (t1[j] - ma - n1[j] * mb);
+      for (int r = 0; r < 32; r += 2) {
+        s0 += src[r];
+        s1 += src[r + 1];
+      }
+      cnn_lds_add(G + ((lane & 31u) < 16u ? D.os1 + (int)(lane & 31u) : D.ob1 + (int)(lane & 31u) - 16), s0 + s1);
+    }
+#pragma unroll
+    for (int j = 0; j < CNN_L1; ++j) T[j * CNN_ES + lane] = t1[j];
     // positions
     for (int p = 0; p < D.P; ++p) {
-      double x[CNN_NF], dn0[CNN_NF];
+      double x[CNN_NF], dy[CNN_NF];
       const double r0 = cnn_conv_norm(Fs, code, p, D.fw, x);
       const double *__restrict__ s0 = params + D.os0 + p * CNN_NF, *__restrict__ b0 = params + D.ob0 + p * CNN_NF;
       const double *__restrict__ W1 = params + D.oW1 + p * CNN_NF * CNN_L1;
-      double *gW1 = G + D.oW1 + p * CNN_NF * CNN_L1, *gs0 = G + D.os0 + p * CNN_NF, *gb0 = G + D.ob0 + p * CNN_NF;
       double a0 = 0.0, a1 = 0.0;
+      {
+        double wc[CNN_L1], wn[CNN_L1], sc = s0[0], bc = b0[0], sn = 0.0, bn = 0.0;
 #pragma unroll
-      for (int f = 0; f < CNN_NF; ++f) {
-        double dv;
-        const double e = cnn_elu(__builtin_fma(s0[f], x[f], b0[f]), exptab, dv);
-        double de = 0.0;
+        for (int j = 0; j < CNN_L1; ++j) wc[j] = W1[j];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < CNN_L1; ++j) {
-          de = __builtin_fma(W1[f * CNN_L1 + j], t1[j], de);
-          cnn_lds_add(gW1 + f * CNN_L1 + j, e * t1[j]);
+        for (int f = 0; f < CNN_NF; ++f) {
+          if (f + 1 < CNN_NF) {
+            sn = s0[f + 1];
+            bn = b0[f + 1];
+#pragma unroll
+            for (int j = 0; j < CNN_L1; ++j) wn[j] = W1[(f + 1) * CNN_L1 + j];
+          }
+          double dv;
+          const double e = cnn_elu(__builtin_fma(sc, x[f], bc), exptab, dv);
+          E[f * CNN_ES + lane] = e;                                   // A operand of d weights1[p]
+          double de = 0.0;
+#pragma unroll
+          for (int j = 0; j < CNN_L1; ++j) de = __builtin_fma(wc[j], t1[j], de);
+          dy[f] = de * dv;
+          const double dn = dy[f] * sc;
+          a0 += dn;
+          a1 = __builtin_fma(dn, x[f], a1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < CNN_L1; ++j) wc[j] = wn[j];
+          sc = sn;
+          bc = bn;
         }
-        const double dy = de * dv;
-        cnn_lds_add(gs0 + f, dy * x[f]);
-        cnn_lds_add(gb0 + f, dy);
-        const double dn = dy * s0[f];
-        dn0[f] = dn;
-        a0 += dn;
-        a1 = __builtin_fma(dn, x[f], a1);
       }
       a0 *= 1.0 / CNN_NF;
       a1 *= 1.0 / CNN_NF;
+      // d weights1[p][f][j] += sum_ctx e0[ctx][f] dT1[ctx][j]
 #pragma unroll
-      for (int f = 0; f < CNN_NF; ++f) dn0[f] = r0 * (dn0[f] - a0 - x[f] * a1);
-      unsigned long long c = code >> (3 * p);
-      for (int w = 0; w < D.fw; ++w) {
-        const int a = (int)(c & 7ull);
-        c >>= 3;
-        if (a < 5) {
-          double *gF = G + D.oF + (w * 5 + a) * CNN_NF;
+      for (int mt = 0; mt < 2; ++mt) {
+        cnn_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int f = 0; f < CNN_NF; ++f) cnn_lds_add(gF + f, dn0[f]);
+        for (int ks = 0; ks < 16; ++ks)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(E[(mt * 16 + lr) * CNN_ES + 4 * ks + lq], T[lr * CNN_ES + 4 * ks + lq], acc, 0, 0, 0);
+        double *g = G + D.oW1 + p * CNN_NF * CNN_L1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = mt * 16 + (int)lq + 4 * r;
+          if (f < CNN_NF) cnn_lds_add(g + f * CNN_L1 + lr, acc[r]);
+        }
+      }
+      // d scale0[p], d intercept0[p]: column sums of dy * n0 and dy
+#pragma unroll
+      for (int f = 0; f < CNN_NF; ++f) E[f * CNN_CS + lane] = dy[f] * x[f];
+      cnn_colsum_add(E, G + D.os0 + p * CNN_NF, CNN_NF, lane);
+#pragma unroll
+      for (int f = 0; f < CNN_NF; ++f) E[f * CNN_CS + lane] = dy[f];
+      cnn_colsum_add(E, G + D.ob0 + p * CNN_NF, CNN_NF, lane);
+      // layer-norm backward -> d conv[p][f], staged as the B operand of d filters
+      {
+        unsigned long long c = code >> (3 * p);
+        bool any_start = false;
+        for (int w = 0; w < D.fw; ++w) any_start |= ((c >> (3 * w)) & 7ull) == 4ull;
+#pragma unroll
+        for (int f = 0; f < CNN_NF; ++f) {
+          const double dc = r0 * (dy[f] * s0[f] - a0 - x[f] * a1);
+          E[f * CNN_ES + lane] = dc;
+          dy[f] = dc;
+        }
+        if (any_start) {   // the start symbol '[' (rare: only contexts at a sequence start) bypasses the MFMA rows
+          for (int w = 0; w < D.fw; ++w)
+            if (((c >> (3 * w)) & 7ull) == 4ull) {
+              double *gF = G + D.oF + (w * 5 + 4) * CNN_NF;
+#pragma unroll
+              for (int f = 0; f < CNN_NF; ++f) cnn_lds_add(gF + f, dy[f]);
+            }
+        }
+      }
+      // d filters[w][a][f] += sum_ctx [letter_{p+w}(ctx) == a] d conv[ctx][f],  rows (w, a < 4), two column tiles of f
+      for (int mt = 0; mt < n_mt; ++mt) {
+        cnn_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const int row = mt * 16 + (int)lr, w = row >> 2;
+        const unsigned long long want = (unsigned long long)(row & 3);
+        const int sh = 3 * (p + w);
+        const bool row_ok = w < D.fw;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const unsigned long long cc = Cw[4 * ks + lq];
+          const double a = (row_ok && ((cc >> sh) & 7ull) == want) ? 1.0 : 0.0;
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, E[lr * CNN_ES + 4 * ks + lq], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, E[(16 + lr) * CNN_ES + 4 * ks + lq], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int orow = mt * 16 + (int)lq + 4 * r, ow = orow >> 2, oa = orow & 3;
+          if (ow < D.fw) {
+            double *gF = G + D.oF + (ow * 5 + oa) * CNN_NF;
+            cnn_lds_add(gF + lr, acc0[r]);
+            if (lr < CNN_NF - 16) cnn_lds_add(gF + 16 + lr, acc1[r]);
+          }
         }
       }
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < D.total; k += CNN_THREADS) partials[(size_t)blockIdx.x * D.total + k] = G[k];
+  for (int k = threadIdx.x; k < D.total; k += blockDim.x) partials[(size_t)blockIdx.x * D.total + k] = G[k];
 }
 
 // fixed-order sum of the block partial vectors: one wave per parameter (lane-strided partial sums, then the shuffle tree)
