@@ -5,8 +5,10 @@ reference (selected with ``getattr(ar_funcs, 'make_ar_func_' + name)``, models/t
 ``ar_func`` maps contexts to transition-probability rows ``[..., alphabet_size + 1]`` (the "prior rows"
 of the DM kernels).  Contexts are accepted in the reference's one-hot form ``[..., lag, A+1]`` or, to
 avoid materialising 5.2 GB of one-hot at 1e7 contexts, as integer codes ``[..., lag]``
-(-1 = unknown letter = all-zero one-hot row).  Parameters are torch tensors with ``requires_grad``; the
-small dense algebra (K <= 330) stays in PyTorch-ROCm ops, the DM kernels consume the rows.
+(-1 = unknown letter = all-zero one-hot row).  Parameters are torch tensors with ``requires_grad``.  On
+integer codes the linear function is fused into the DM step (``bear_dm_linear_f64``) and the convolutional one
+runs as ``bear_cnn_forward_f64`` / ``bear_cnn_backward_f64`` behind torch autograd; one-hot input (and shapes the
+kernels do not cover) takes the PyTorch-ROCm formulation, the DM kernels consume the rows either way.
 """
 import numpy as np
 import torch
@@ -15,6 +17,36 @@ import torch.nn.functional as F
 
 def _is_codes(x):
     return not x.dtype.is_floating_point
+
+
+class _FusedCnn(torch.autograd.Function):
+    """The convolutional AR function on integer context codes as one HIP launch per direction
+    (``bear_cnn_forward_f64`` / ``bear_cnn_backward_f64``, kernels_cnn.h) behind torch autograd, so that
+    ``prior = ar_func(codes); prior.backward(grad_rows)`` in bear_net.train / bear_ref.train runs fused."""
+
+    @staticmethod
+    def forward(ctx, codes, lag, filter_width, *params):
+        from . import kernels
+        lead = codes.shape[:-1]
+        packed = kernels.pack_kmers(codes.reshape(-1, lag).to(torch.int8).contiguous())
+        flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+        need = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        prior, t1 = kernels.cnn_forward(packed, flat, lag, filter_width, save=True)
+        ctx.lag, ctx.fw, ctx.shapes = lag, filter_width, [p.shape for p in params]
+        ctx.save_for_backward(packed, flat, t1, prior)
+        return prior.reshape(lead + (5,))
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        from . import kernels
+        packed, flat, t1, prior = ctx.saved_tensors
+        g = kernels.cnn_backward(packed, flat, ctx.lag, ctx.fw, t1, prior, grad_rows.reshape(-1, 5).to(torch.float64).contiguous())
+        out, k = [], 0
+        for shp in ctx.shapes:
+            n = int(np.prod(shp))
+            out.append(g[k:k + n].reshape(shp))
+            k += n
+        return (None, None, None) + tuple(out)
 
 
 def _l2_normalize(x, dims):
@@ -81,14 +113,25 @@ def make_ar_func_cnn(lag, alphabet_size, filter_width=8, num_filters=30, kmer_la
         y = F.conv1d(x, filters.permute(2, 1, 0))                          # [B, nf, P]
         return y.transpose(1, 2).reshape(data.shape[:-2] + (P, num_filters))
 
+    params = [filters, kmer_intercept0, kmer_weights1, kmer_intercept1, kmer_weights2, kmer_intercept2,
+              kmer_scale0, kmer_scale1]
+    from . import kernels
+    fused_ok = dtype == torch.float64 and kernels.cnn_supported(lag, alphabet_size, filter_width, num_filters, kmer_layer1_width)
+
     def ar_func(data):
+        if fused_ok and _is_codes(data) and data.is_cuda and data.shape[-1] == lag:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                return _FusedCnn.apply(data, lag, filter_width, *params)
+            flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+            packed = kernels.pack_kmers(data.reshape(-1, lag).to(torch.int8).contiguous())
+            return kernels.cnn_forward(packed, flat, lag, filter_width, save=False)[0].reshape(data.shape[:-1] + (A1,))
         nn0 = kmer_scale0 * _normalize_layer(conv(data)) + kmer_intercept0
         t1 = torch.tensordot(F.elu(nn0), kmer_weights1, dims=([-2, -1], [0, 1]))
         nn1 = kmer_scale1 * _normalize_layer(t1) + kmer_intercept1
         nn2 = torch.tensordot(F.elu(nn1), kmer_weights2, dims=([-1], [0])) + kmer_intercept2
         return torch.softmax(nn2, dim=-1)
-    return ar_func, [filters, kmer_intercept0, kmer_weights1, kmer_intercept1, kmer_weights2, kmer_intercept2,
-                     kmer_scale0, kmer_scale1]
+    ar_func.fused = fused_ok       # integer codes on the device take the fused kernels; one-hot input the torch ops
+    return ar_func, params
 
 
 def make_ar_func_stop(lag, alphabet_size, dtype=torch.float64, device=None, generator=None):

@@ -105,7 +105,11 @@ def test_bear_ref_linear_net_matches_oracle_loop(train_ar, ysd1):
         assert np.allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-6, atol=1e-8)
 
 
-@pytest.mark.parametrize("name,kw,train_ar", [("linear", {}, False), ("linear", {}, True), ("cnn", {"filter_width": 3, "num_filters": 5}, False)])
+CNN_CFG = {"num_filters": 30, "filter_width": 3, "kmer_layer1_width": 16}     # models/config_files/bear_cnn_bear.cfg:65 -> fused kernels
+
+
+@pytest.mark.parametrize("name,kw,train_ar", [("linear", {}, False), ("linear", {}, True), ("cnn", {"filter_width": 3, "num_filters": 5}, False),
+                                              ("cnn", CNN_CFG, False), ("cnn", CNN_CFG, True)])
 def test_bear_net_train_matches_oracle_loop(name, kw, train_ar, ysd1):
     _, counts = ysd1
     data = dataloader.dataloader(YSD1, "dna", 700, 3)          # 2 batches (700 + 665)
