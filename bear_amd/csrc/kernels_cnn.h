@@ -104,16 +104,18 @@ __device__ __forceinline__ double cnn_conv_norm(const double *Fs, unsigned long 
       x[2 * f2 + 1] += v.y;
     }
   }
-  double mu = 0.0;
+  // sums in six independent chains: one wave per SIMD has no other wave to hide a 30-long dependent chain behind
+  double m6[6] = {x[0], x[1], x[2], x[3], x[4], x[5]};
 #pragma unroll
-  for (int f = 0; f < CNN_NF; ++f) mu += x[f];
-  mu *= 1.0 / CNN_NF;
-  double var = 0.0;
+  for (int f = 6; f < CNN_NF; ++f) m6[f % 6] += x[f];
+  const double mu = (((m6[0] + m6[1]) + (m6[2] + m6[3])) + (m6[4] + m6[5])) * (1.0 / CNN_NF);
+  double v6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int f = 0; f < CNN_NF; ++f) {
     x[f] -= mu;
-    var = __builtin_fma(x[f], x[f], var);
+    v6[f % 6] = __builtin_fma(x[f], x[f], v6[f % 6]);
   }
+  const double var = ((v6[0] + v6[1]) + (v6[2] + v6[3])) + (v6[4] + v6[5]);
   const double r = cnn_rsqrt(var * (1.0 / CNN_NF) + CNN_LN_EPS);
 #pragma unroll
   for (int f = 0; f < CNN_NF; ++f) x[f] *= r;
@@ -244,13 +246,10 @@ __device__ __forceinline__ void cnn_lds_add(double *addr, double v) { atomicAdd(
 // its half-sum to dst[col0 + c] when col0 + c < n_cols
 __device__ __forceinline__ void cnn_colsum_add(const double *E, double *dst, int n_cols, uint32_t lane) {
   const double *src = E + (lane & 31u) * CNN_CS + (lane >> 5) * 32u;
-  double s0 = 0.0, s1 = 0.0;
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int r = 0; r < 32; r += 2) {
-    s0 += src[r];
-    s1 += src[r + 1];
-  }
-  if ((int)(lane & 31u) < n_cols) cnn_lds_add(dst + (lane & 31u), s0 + s1);
+  for (int r = 0; r < 32; ++r) s4[r & 3] += src[r];
+  if ((int)(lane & 31u) < n_cols) cnn_lds_add(dst + (lane & 31u), (s4[0] + s4[1]) + (s4[2] + s4[3]));
 }
 
 __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigned long long *__restrict__ codes, uint64_t n_rows,
@@ -356,62 +355,42 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
     }
     {
       const double *src = E + (lane & 31u) * CNN_CS + (lane >> 5) * 32u;
-      double s0 = 0.0, s1 = 0.0;
+      double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int r = 0; r < 32; r += 2) {
-        s0 += src[r];
-        s1 += src[r + 1];
-      }
-      cnn_lds_add(G + ((lane & 31u) < 16u ? D.os1 + (int)(lane & 31u) : D.ob1 + (int)(lane & 31u) - 16), s0 + s1);
+      for (int r = 0; r < 32; ++r) s4[r & 3] += src[r];
+      cnn_lds_add(G + ((lane & 31u) < 16u ? D.os1 + (int)(lane & 31u) : D.ob1 + (int)(lane & 31u) - 16),
+                  (s4[0] + s4[1]) + (s4[2] + s4[3]));
     }
 #pragma unroll
     for (int j = 0; j < CNN_L1; ++j) T[j * CNN_ES + lane] = t1[j];
+    double tb[16], tb2[4][4];     // dT1 as the B operand of d weights1 (K = contexts) and of d e0 (K = j), the same for every position
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) tb[ks] = T[lr * CNN_ES + 4 * ks + lq];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) tb2[ks][nt] = T[(4 * ks + lq) * CNN_ES + nt * 16 + lr];
     // positions
     for (int p = 0; p < D.P; ++p) {
-      double x[CNN_NF], dy[CNN_NF];
+      double x[CNN_NF], dy[CNN_NF], dn[CNN_NF];
       const double r0 = cnn_conv_norm(Fs, code, p, D.fw, x);
       const double *__restrict__ s0 = params + D.os0 + p * CNN_NF, *__restrict__ b0 = params + D.ob0 + p * CNN_NF;
       const double *__restrict__ W1 = params + D.oW1 + p * CNN_NF * CNN_L1;
-      double a0 = 0.0, a1 = 0.0;
-      {
-        double wc[CNN_L1], wn[CNN_L1], sc = s0[0], bc = b0[0], sn = 0.0, bn = 0.0;
+      double a0[2] = {0.0, 0.0}, a1[2] = {0.0, 0.0};
+      // pass A: activations e0 (staged as the A operand of d weights1[p]) and elu'; dy holds elu' until pass B
 #pragma unroll
-        for (int j = 0; j < CNN_L1; ++j) wc[j] = W1[j];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int f = 0; f < CNN_NF; ++f) {
-          if (f + 1 < CNN_NF) {
-            sn = s0[f + 1];
-            bn = b0[f + 1];
-#pragma unroll
-            for (int j = 0; j < CNN_L1; ++j) wn[j] = W1[(f + 1) * CNN_L1 + j];
-          }
-          double dv;
-          const double e = cnn_elu(__builtin_fma(sc, x[f], bc), exptab, dv);
-          E[f * CNN_ES + lane] = e;                                   // A operand of d weights1[p]
-          double de = 0.0;
-#pragma unroll
-          for (int j = 0; j < CNN_L1; ++j) de = __builtin_fma(wc[j], t1[j], de);
-          dy[f] = de * dv;
-          const double dn = dy[f] * sc;
-          a0 += dn;
-          a1 = __builtin_fma(dn, x[f], a1);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < CNN_L1; ++j) wc[j] = wn[j];
-          sc = sn;
-          bc = bn;
-        }
+      for (int f = 0; f < CNN_NF; ++f) {
+        double dv;
+        E[f * CNN_ES + lane] = cnn_elu(__builtin_fma(s0[f], x[f], b0[f]), exptab, dv);
+        dy[f] = dv;
       }
-      a0 *= 1.0 / CNN_NF;
-      a1 *= 1.0 / CNN_NF;
       // d weights1[p][f][j] += sum_ctx e0[ctx][f] dT1[ctx][j]
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         cnn_d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(E[(mt * 16 + lr) * CNN_ES + 4 * ks + lq], T[lr * CNN_ES + 4 * ks + lq], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(E[(mt * 16 + lr) * CNN_ES + 4 * ks + lq], tb[ks], acc, 0, 0, 0);
         double *g = G + D.oW1 + p * CNN_NF * CNN_L1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -419,6 +398,47 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
           if (f < CNN_NF) cnn_lds_add(g + f * CNN_L1 + lr, acc[r]);
         }
       }
+      // pass B: d e0[f][ctx] = sum_j weights1[p][f][j] dT1[ctx][j] as MFMA products (rows f, columns ctx, K = j), the
+      // result handed back to the context lanes through the staging buffer
+      {
+        double wa[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const int f = mt * 16 + (int)lr;
+            wa[mt][ks] = f < CNN_NF ? W1[f * CNN_L1 + 4 * ks + (int)lq] : 0.0;
+          }
+        cnn_d4 c[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) c[mt][nt] = cnn_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) c[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[mt][ks], tb2[ks][nt], c[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int f = mt * 16 + (int)lq + 4 * r;
+            if (f < CNN_NF) {
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) E[f * CNN_ES + nt * 16 + lr] = c[mt][nt][r];
+            }
+          }
+      }
+#pragma unroll
+      for (int f = 0; f < CNN_NF; ++f) {
+        dy[f] *= E[f * CNN_ES + lane];
+        dn[f] = dy[f] * s0[f];
+        a0[f & 1] += dn[f];
+        a1[f & 1] = __builtin_fma(dn[f], x[f], a1[f & 1]);
+      }
+      const double ma0 = (a0[0] + a0[1]) * (1.0 / CNN_NF), ma1 = (a1[0] + a1[1]) * (1.0 / CNN_NF);
       // d scale0[p], d intercept0[p]: column sums of dy * n0 and dy
 #pragma unroll
       for (int f = 0; f < CNN_NF; ++f) E[f * CNN_CS + lane] = dy[f] * x[f];
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
         for (int w = 0; w < D.fw; ++w) any_start |= ((c >> (3 * w)) & 7ull) == 4ull;
 #pragma unroll
         for (int f = 0; f < CNN_NF; ++f) {
-          const double dc = r0 * (dy[f] * s0[f] - a0 - x[f] * a1);
+          const double dc = r0 * (dn[f] - ma0 - x[f] * ma1);
           E[f * CNN_ES + lane] = dc;
           dy[f] = dc;
         }
@@ -447,28 +467,40 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
         }
       }
       // d filters[w][a][f] += sum_ctx [letter_{p+w}(ctx) == a] d conv[ctx][f],  rows (w, a < 4), two column tiles of f
-      for (int mt = 0; mt < n_mt; ++mt) {
-        cnn_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        const int row = mt * 16 + (int)lr, w = row >> 2;
-        const unsigned long long want = (unsigned long long)(row & 3);
-        const int sh = 3 * (p + w);
-        const bool row_ok = w < D.fw;
+      for (int mt = 0; mt < n_mt; mt += 2) {      // two row tiles per pass share the B operand reads
+        cnn_d4 acc[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
+        int sh[2];
+        unsigned long long want[2];
+        bool row_ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = (mt + u) * 16 + (int)lr, w = row >> 2;
+          want[u] = (unsigned long long)(row & 3);
+          row_ok[u] = w < D.fw;
+          sh[u] = row_ok[u] ? 3 * (p + w) : 0;
+        }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           const unsigned long long cc = Cw[4 * ks + lq];
-          const double a = (row_ok && ((cc >> sh) & 7ull) == want) ? 1.0 : 0.0;
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, E[lr * CNN_ES + 4 * ks + lq], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, E[(16 + lr) * CNN_ES + 4 * ks + lq], acc1, 0, 0, 0);
-        }
+          const double b0v = E[lr * CNN_ES + 4 * ks + lq], b1v = E[(16 + lr) * CNN_ES + 4 * ks + lq];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int orow = mt * 16 + (int)lq + 4 * r, ow = orow >> 2, oa = orow & 3;
-          if (ow < D.fw) {
-            double *gF = G + D.oF + (ow * 5 + oa) * CNN_NF;
-            cnn_lds_add(gF + lr, acc0[r]);
-            if (lr < CNN_NF - 16) cnn_lds_add(gF + 16 + lr, acc1[r]);
+          for (int u = 0; u < 2; ++u) {
+            const double a = (row_ok[u] && ((cc >> sh[u]) & 7ull) == want[u]) ? 1.0 : 0.0;
+            acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0v, acc[u][0], 0, 0, 0);
+            acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1v, acc[u][1], 0, 0, 0);
           }
         }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int orow = (mt + u) * 16 + (int)lq + 4 * r, ow = orow >> 2, oa = orow & 3;
+            if (ow < D.fw) {
+              double *gF = G + D.oF + (ow * 5 + oa) * CNN_NF;
+              cnn_lds_add(gF + lr, acc[u][0][r]);
+              if (lr < CNN_NF - 16) cnn_lds_add(gF + 16 + lr, acc[u][1][r]);
+            }
+          }
       }
     }
   }
