@@ -159,7 +159,19 @@ def main():
         ms = timed(lambda: kernels.dm_linear(plans["net"], packed, mat, h_s), 5)
         extra["linear_head_fused_step"] = {"lag": lag, "kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3),
                                            "note": "forward + ELBO + d/dh + d/dmat from 8-byte packed k-mers"}
-        del packed
+        # BASELINE configs[4]: the convolutional AR function, forward + DM step with gradient rows + backward
+        from bear_amd import ar_funcs
+        fw = 8
+        _, cnn_params = ar_funcs.make_ar_func_cnn(lag, 4, filter_width=fw, device=dev, generator=torch.Generator(dev).manual_seed(10))
+        flat = torch.cat([q.detach().reshape(-1) for q in cnn_params]).contiguous()
+        f_ms = timed(lambda: kernels.cnn_forward(packed, flat, lag, fw), 3)
+        pr_c, t1_c = kernels.cnn_forward(packed, flat, lag, fw)
+        _, g_c = kernels.dm_prior_planned(plans["net"], pr_c, h_s, want_grad=True)
+        b_ms = timed(lambda: kernels.cnn_backward(packed, flat, lag, fw, t1_c, pr_c, g_c), 3)
+        extra["cnn_head"] = {"lag": lag, "filter_width": fw, "forward_ms": f_ms, "backward_ms": b_ms,
+                             "step_contexts_per_s": n / ((f_ms + b_ms + extra["net_with_gradient_rows"]["kernel_ms"]) * 1e-3),
+                             "note": "bear_cnn_forward_f64 + planned DM kernel with gradient rows + bear_cnn_backward_f64"}
+        del packed, pr_c, t1_c, g_c
         m = min(n, 20_000_000)
         test = kernels.synth_counts(SEED, row0, m, dev, want=("test",))["test"]
         ms = timed(lambda: kernels.evaluate(test, prior[:m], [1.0], [0.1, 1.0, 10.0], t["train"][:m]), 2)
