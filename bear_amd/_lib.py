@@ -22,6 +22,7 @@ SYMBOLS = [
     "bear_count_rows", "bear_parse_counts_tsv", "bear_log_gamma_f64", "bear_logdir_sample_f64",
     "bear_stat_source", "bear_cache_write", "bear_cache_info", "bear_cache_read", "bear_shuffle_rows", "bear_shuffle_source_row",
     "bear_cnn_param_count", "bear_cnn_forward_f64", "bear_cnn_backward_f64",
+    "bear_kmer_sort_create", "bear_kmer_sort_reduce", "bear_kmer_sort_destroy", "bear_count_last_hip_error", "bear_write_counts_tsv",
 ]
 
 
@@ -82,6 +83,10 @@ def _load():
     L.bear_cnn_param_count.argtypes = [cint, cint, cint, cint]
     L.bear_cnn_forward_f64.argtypes = [vp, vp, u64, cint, cint, cint, cint, vp, vp, vp, vp]
     L.bear_cnn_backward_f64.argtypes = [vp, vp, u64, cint, cint, cint, cint, vp, vp, vp, vp, vp, vp]
+    L.bear_kmer_sort_create.argtypes = [vp, vp, u64, cint, ctypes.POINTER(vp), ctypes.POINTER(u64), vp]
+    L.bear_kmer_sort_reduce.argtypes = [vp, cint, vp, vp, vp, vp]
+    L.bear_kmer_sort_destroy.argtypes = [vp]
+    L.bear_write_counts_tsv.argtypes = [ctypes.c_char_p, vp, vp, u64, cint, cint, u64, u64, cint]
     L.bear_count_rows.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]
     L.bear_parse_counts_tsv.argtypes = [ctypes.c_char_p, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
     for name in SYMBOLS:

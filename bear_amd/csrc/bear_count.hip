@@ -1,0 +1,203 @@
+// bear_count.hip -- k-mer transition counting on the device: the count table of summarize.py built straight from the
+// sequences.
+//
+// The reference gets there in three stages (bear_model/summarize.py): (1) write prefix / suffix / full FASTQ files per
+// input, (2) run the external KMC counter on each, (3) heap-merge the sorted KMC dumps into rows
+// `kmer \t [[A,C,G,T,$ per group]...]` (Register / Consolidate, summarize.py:380-622).  What the three stages compute is
+// stated by the reference's own test (bear_model/tests/test_summarize.py:88-115): for every sequence and lag L,
+//     full = '[' * L + seq + ']' ;  for j in [L, len(full)):  counts[full[j-L:j]][group][full[j]] += 1 .
+// On an MI355X that is one pass per lag over the resident text: every transition becomes a (context code, group * 5 +
+// next letter) pair, the pairs are radix-sorted by context (rocPRIM via hipCUB: a library sort is the right tool for
+// the sort itself), and a run-length pass turns runs of equal contexts into rows and scatters the pair values into the
+// planar uint32 [group][row][5] slabs the training kernels consume -- no KMC, no intermediate files, and the table can
+// go to training without ever being text.
+//
+// Text layout [dev]: per sequence  5 (start marker), letters 0..3 (6 = any other character), 4 (stop).  A transition sits
+// at every position holding 0..4; its context is the L codes before it, read back until the start marker, the rest
+// filled with the start symbol.  Transitions whose context or next letter contains a 6 are dropped (KMC drops k-mers
+// with non-ACGT letters likewise).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include "../../include/bear_hip.h"
+
+namespace {
+thread_local int g_count_hip_error = 0;
+#define CNT_TRY(expr)                    \
+  do {                                   \
+    hipError_t _e = (expr);              \
+    if (_e != hipSuccess) {              \
+      g_count_hip_error = (int)_e;       \
+      st = BEAR_ERR_HIP;                 \
+      goto done;                         \
+    }                                    \
+  } while (0)
+
+constexpr uint64_t CNT_INVALID = ~0ull;
+
+// key: the context as the packed k-mer code of bear_pack_kmers_u64 (letter l of the k-mer in bits [3l, 3l+3); 4 = '[')
+__global__ __launch_bounds__(256) void cnt_emit_kernel(const uint8_t *__restrict__ text, const uint8_t *__restrict__ grp,
+                                                       uint64_t n_pos, int lag, uint64_t *__restrict__ keys,
+                                                       uint32_t *__restrict__ vals) {
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n_pos; t += (uint64_t)gridDim.x * 256) {
+    const uint32_t nx = text[t];
+    uint64_t key = CNT_INVALID;
+    if (nx <= 4u) {
+      key = 0;
+      bool started = false, bad = false;
+      for (int i = 1; i <= lag; ++i) {                 // letter lag - i of the k-mer
+        uint32_t c = 4u;
+        if (!started) {
+          c = (t >= (uint64_t)i) ? text[t - i] : 5u;
+          if (c == 5u) {
+            started = true;
+            c = 4u;
+          }
+        }
+        bad |= c > 4u;
+        key |= (uint64_t)c << (3 * (lag - i));
+      }
+      if (bad) key = CNT_INVALID;
+    }
+    keys[t] = key;
+    vals[t] = (uint32_t)grp[t] * 5u + (nx <= 4u ? nx : 0u);
+  }
+}
+
+__global__ __launch_bounds__(256) void cnt_flag_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ flags) {
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (uint64_t)gridDim.x * 256) {
+    const uint64_t k = keys[t];
+    flags[t] = (k != CNT_INVALID && (t == 0 || keys[t - 1] != k)) ? 1u : 0u;
+  }
+}
+
+// rows: inclusive scan of the run-start flags (row index + 1).  One thread per sorted pair.
+__global__ __launch_bounds__(256) void cnt_scatter_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                          const uint32_t *__restrict__ rows, uint64_t n, uint64_t n_rows, int lag,
+                                                          uint32_t n_groups, uint8_t *__restrict__ kmers, uint64_t *__restrict__ codes,
+                                                          uint32_t *__restrict__ counts) {
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (uint64_t)gridDim.x * 256) {
+    const uint64_t k = keys[t];
+    if (k == CNT_INVALID) continue;
+    const uint64_t row = (uint64_t)rows[t] - 1u;
+    const uint32_t v = vals[t];
+    if (v / 5u < n_groups) atomicAdd(&counts[((uint64_t)(v / 5u) * n_rows + row) * 5u + (v % 5u)], 1u);   // group ids beyond n_groups are ignored
+    if (t == 0 || keys[t - 1] != k) {                // run start: name the row
+      if (codes) {
+        uint64_t packed = k;
+        for (int l = lag; l < 21; ++l) packed |= 5ull << (3 * l);     // positions >= lag hold 5 (bear_pack_kmers_u64)
+        codes[row] = packed;
+      }
+      if (kmers)
+        for (int l = 0; l < lag; ++l) kmers[row * (uint64_t)lag + l] = (uint8_t)("ACGT["[(k >> (3 * l)) & 7ull]);
+    }
+  }
+}
+
+unsigned grid_for(uint64_t n) {
+  uint64_t b = (n + 255) / 256;
+  return (unsigned)(b > (1u << 20) ? (1u << 20) : (b ? b : 1));
+}
+}  // namespace
+
+struct bear_kmer_sort {
+  uint64_t n_pos, n_rows;
+  int lag;
+  uint64_t *keys;   // sorted
+  uint32_t *vals;   // sorted with the keys
+  uint32_t *rows;   // inclusive scan of run starts
+};
+
+extern "C" {
+
+int bear_count_last_hip_error(void) { return g_count_hip_error; }
+
+int bear_kmer_sort_create(const uint8_t *text, const uint8_t *group, uint64_t n_pos, int lag, bear_kmer_sort **out,
+                          uint64_t *n_rows_out, void *stream) {
+  if (!out || !n_rows_out || lag < 1 || lag > 21) return BEAR_ERR_INVALID_ARG;
+  *out = nullptr;
+  *n_rows_out = 0;
+  if (n_pos && (!text || !group)) return BEAR_ERR_INVALID_ARG;
+  if (n_pos >= 0xffffffffull) return BEAR_ERR_INVALID_ARG;   // row indices are 32-bit: shard the text above 4e9 positions
+  int st = BEAR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bear_kmer_sort *h = new (std::nothrow) bear_kmer_sort();
+  if (!h) return BEAR_ERR_NOMEM;
+  h->n_pos = n_pos;
+  h->lag = lag;
+  uint64_t *keys_in = nullptr;
+  uint32_t *vals_in = nullptr, *flags = nullptr;
+  void *temp = nullptr;
+  size_t tb_sort = 0, tb_scan = 0;
+  uint32_t last = 0;
+  if (n_pos == 0) {
+    *out = h;
+    return BEAR_OK;
+  }
+  CNT_TRY(hipMalloc(&keys_in, n_pos * 8));
+  CNT_TRY(hipMalloc(&vals_in, n_pos * 4));
+  CNT_TRY(hipMalloc(&h->keys, n_pos * 8));
+  CNT_TRY(hipMalloc(&h->vals, n_pos * 4));
+  hipLaunchKernelGGL(cnt_emit_kernel, dim3(grid_for(n_pos)), dim3(256), 0, s, text, group, n_pos, lag, keys_in, vals_in);
+  CNT_TRY(hipGetLastError());
+  // all 64 key bits take part so that the invalid marker (all ones) sorts last
+  CNT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb_sort, keys_in, h->keys, vals_in, h->vals, n_pos, 0, 64, s));
+  CNT_TRY(hipMalloc(&temp, tb_sort ? tb_sort : 8));
+  CNT_TRY(hipcub::DeviceRadixSort::SortPairs(temp, tb_sort, keys_in, h->keys, vals_in, h->vals, n_pos, 0, 64, s));
+  CNT_TRY(hipStreamSynchronize(s));
+  (void)hipFree(temp);
+  temp = nullptr;
+  (void)hipFree(keys_in);
+  keys_in = nullptr;
+  flags = vals_in;   // reuse
+  vals_in = nullptr;
+  CNT_TRY(hipMalloc(&h->rows, n_pos * 4));
+  hipLaunchKernelGGL(cnt_flag_kernel, dim3(grid_for(n_pos)), dim3(256), 0, s, h->keys, n_pos, flags);
+  CNT_TRY(hipGetLastError());
+  CNT_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb_scan, flags, h->rows, n_pos, s));
+  CNT_TRY(hipMalloc(&temp, tb_scan ? tb_scan : 8));
+  CNT_TRY(hipcub::DeviceScan::InclusiveSum(temp, tb_scan, flags, h->rows, n_pos, s));
+  CNT_TRY(hipMemcpyAsync(&last, h->rows + (n_pos - 1), 4, hipMemcpyDeviceToHost, s));
+  CNT_TRY(hipStreamSynchronize(s));
+  h->n_rows = last;
+done:
+  if (temp) (void)hipFree(temp);
+  if (keys_in) (void)hipFree(keys_in);
+  if (vals_in) (void)hipFree(vals_in);
+  if (flags) (void)hipFree(flags);
+  if (st != BEAR_OK) {
+    if (h->keys) (void)hipFree(h->keys);
+    if (h->vals) (void)hipFree(h->vals);
+    if (h->rows) (void)hipFree(h->rows);
+    delete h;
+    return st;
+  }
+  *out = h;
+  *n_rows_out = h->n_rows;
+  return BEAR_OK;
+}
+
+int bear_kmer_sort_reduce(const bear_kmer_sort *h, int n_groups, uint8_t *kmers, uint64_t *kmer_code, uint32_t *counts,
+                          void *stream) {
+  if (!h || n_groups < 1 || n_groups > 255) return BEAR_ERR_INVALID_ARG;
+  if (h->n_rows == 0) return BEAR_OK;
+  if (!counts) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(counts, 0, (size_t)n_groups * h->n_rows * 5 * 4, s) != hipSuccess) return BEAR_ERR_HIP;
+  hipLaunchKernelGGL(cnt_scatter_kernel, dim3(grid_for(h->n_pos)), dim3(256), 0, s, h->keys, h->vals, h->rows, h->n_pos, h->n_rows,
+                     h->lag, (uint32_t)n_groups, kmers, kmer_code, counts);
+  if (hipGetLastError() != hipSuccess) return BEAR_ERR_HIP;
+  return BEAR_OK;
+}
+
+int bear_kmer_sort_destroy(bear_kmer_sort *h) {
+  if (!h) return BEAR_OK;
+  if (h->keys) (void)hipFree(h->keys);
+  if (h->vals) (void)hipFree(h->vals);
+  if (h->rows) (void)hipFree(h->rows);
+  delete h;
+  return BEAR_OK;
+}
+
+}  // extern "C"

@@ -5,6 +5,7 @@
 #include <fcntl.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -232,4 +233,54 @@ extern "C" int bear_cache_read(const char *path, uint64_t row0, uint64_t n_rows,
       st = BEAR_ERR_IO;
   ::close(fd);
   return st;
+}
+
+// ------------------------------------------------------------------ count-table writer (summarize.py:429-449 row format)
+// Rows row_begin, row_begin + row_step, ... of a planar table:  kmer \t [[g0 A,C,G,T,$],[g1 ...],...] \n
+extern "C" int bear_write_counts_tsv(const char *path, const char *kmers, const uint32_t *counts, uint64_t n_rows, int lag,
+                                     int num_ds, uint64_t row_begin, uint64_t row_step, int append) {
+  if (!path || !counts || (!kmers && lag > 0 && n_rows) || lag < 0 || num_ds < 1 || row_step == 0) return BEAR_ERR_INVALID_ARG;
+  FILE *fh = fopen(path, append ? "ab" : "wb");
+  if (!fh) return BEAR_ERR_IO;
+  static const size_t BUF = 1u << 20;
+  char *buf = static_cast<char *>(malloc(BUF + 64 + (size_t)lag + (size_t)num_ds * 64));
+  if (!buf) {
+    fclose(fh);
+    return BEAR_ERR_NOMEM;
+  }
+  size_t fill = 0;
+  bool ok = true;
+  for (uint64_t r = row_begin; r < n_rows && ok; r += row_step) {
+    memcpy(buf + fill, kmers + r * (uint64_t)lag, (size_t)lag);
+    fill += (size_t)lag;
+    buf[fill++] = '\t';
+    buf[fill++] = '[';
+    for (int d = 0; d < num_ds; ++d) {
+      buf[fill++] = d ? ',' : '[';
+      if (d) buf[fill++] = '[';
+      const uint32_t *c = counts + ((uint64_t)d * n_rows + r) * BEAR_ROW_WIDTH;
+      for (int b = 0; b < BEAR_ROW_WIDTH; ++b) {
+        if (b) buf[fill++] = ',';
+        char tmp[12];
+        int k = 0;
+        uint32_t v = c[b];
+        do {
+          tmp[k++] = (char)('0' + v % 10);
+          v /= 10;
+        } while (v);
+        while (k) buf[fill++] = tmp[--k];
+      }
+      buf[fill++] = ']';
+    }
+    buf[fill++] = ']';
+    buf[fill++] = '\n';
+    if (fill >= BUF) {
+      ok = fwrite(buf, 1, fill, fh) == fill;
+      fill = 0;
+    }
+  }
+  if (ok && fill) ok = fwrite(buf, 1, fill, fh) == fill;
+  free(buf);
+  ok = (fclose(fh) == 0) && ok;
+  return ok ? BEAR_OK : BEAR_ERR_IO;
 }

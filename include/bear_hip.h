@@ -271,6 +271,30 @@ int bear_cache_read(const char *path, uint64_t row0, uint64_t n_rows, char *kmer
 int bear_shuffle_rows(const void *src, void *dst, uint64_t n_rows, uint32_t row_bytes, uint64_t seed, void *stream);
 uint64_t bear_shuffle_source_row(uint64_t i, uint64_t n_rows, uint64_t seed);
 
+/*
+ * k-mer transition counting on the device: the rows summarize.py produces through KMC and its stage-3
+ * heap merge (bear_model/summarize.py:380-622), computed from the sequences as bear_model/tests/test_summarize.py:88-115
+ * defines them.  Per lag: emit (context, group*5 + next letter) per transition, radix sort by context, run-length reduce.
+ *   text  [dev] uint8 [n_pos]  per sequence: 5 (start), letters 0..3 (6 = any other character), 4 (stop); n_pos < 2^32
+ *   group [dev] uint8 [n_pos]  group id of the sequence each position belongs to
+ *   bear_kmer_sort_create: synchronous; *n_rows_out = number of distinct contexts (rows of the lag-`lag` table).
+ *   bear_kmer_sort_reduce: kmers [dev, nullable] uint8 [n_rows, lag] ASCII ('[' padded as summarize.py:442);
+ *                          kmer_code [dev, nullable] uint64 [n_rows] (bear_pack_kmers_u64 form);
+ *                          counts [dev] uint32 [n_groups, n_rows, 5] (planar, the layout of bear_parse_counts_tsv).
+ *   Rows come out sorted by packed context code; shuffle with bear_shuffle_rows before training.
+ * bear_write_counts_tsv [host]: rows row_begin, row_begin + row_step, ... in the summarize.py text format
+ *   (summarize.py:429-449), e.g. step = number of output bins.
+ */
+typedef struct bear_kmer_sort bear_kmer_sort;
+int bear_kmer_sort_create(const uint8_t *text, const uint8_t *group, uint64_t n_pos, int lag, bear_kmer_sort **out,
+                          uint64_t *n_rows_out, void *stream);
+int bear_kmer_sort_reduce(const bear_kmer_sort *h, int n_groups, uint8_t *kmers, uint64_t *kmer_code, uint32_t *counts,
+                          void *stream);
+int bear_kmer_sort_destroy(bear_kmer_sort *h);
+int bear_count_last_hip_error(void);
+int bear_write_counts_tsv(const char *path, const char *kmers, const uint32_t *counts, uint64_t n_rows, int lag, int num_ds,
+                          uint64_t row_begin, uint64_t row_step, int append);
+
 #ifdef __cplusplus
 }
 #endif

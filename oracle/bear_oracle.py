@@ -512,3 +512,25 @@ def shuffle_perm(n, seed):
             x[idx] = v
             todo[idx] = v >= np.uint64(n)
     return x.astype(np.int64)
+
+
+# --------------------------------------------------------------------------- summarize
+def count_transitions(seqs, groups, max_lag, reverse=False):
+    """The k-mer transition counts summarize.py produces, as its own test computes them in memory
+    (bear_model/tests/test_summarize.py:88-115; check_summarize.py:36-66): for every lag L and sequence,
+    ``full = '[' * L + seq + ']'`` and ``counts[full[j-L:j]][group][full[j]] += 1``; with ``reverse`` the reverse
+    complement of every sequence is counted as well.  Returns a list (index L-1) of dicts kmer -> int array [n_groups, 5]."""
+    letters = {"A": 0, "C": 1, "G": 2, "T": 3, "]": 4}            # summarize.py:380
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    n_groups = max(groups) + 1
+    out = [dict() for _ in range(max_lag)]
+    for li in range(max_lag):
+        lag = li + 1
+        for seq, g in zip(seqs, groups):
+            variants = [seq] + (["".join(comp[c] for c in reversed(seq))] if reverse else [])
+            for s in variants:
+                full = "[" * lag + s + "]"
+                for j in range(lag, len(full)):
+                    row = out[li].setdefault(full[j - lag:j], np.zeros((n_groups, 5), dtype=np.int64))
+                    row[g, letters[full[j]]] += 1
+    return out

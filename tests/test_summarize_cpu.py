@@ -1,0 +1,60 @@
+"""CPU tests of the summarize path: the oracle's in-memory count (bear_model/tests/test_summarize.py:88-115) against the
+reference pipeline's own output files for the ex_seqs sequences (bear_model/data/kmaps/ex_seqs_lag_*_file_0.tsv), and
+the host pieces of bear_amd.summarize (sequence readers, text encoding, bin sizing, the C++ table writer)."""
+import io
+import os
+
+import numpy as np
+
+import bear_oracle as o
+from conftest import GOLDEN
+
+SUM = os.path.join(GOLDEN, "summarize")
+
+
+def test_oracle_count_matches_reference_pipeline_files():
+    want_seqs = ["TTTAT", "TTCTT", "TTTTT", "TTTTT"]              # tests/test_var_prob.py:13
+    got = o.count_transitions(want_seqs, [0] * 4, 3)
+    for lag in (1, 2, 3):
+        kmers, counts = o.parse_counts_tsv(os.path.join(SUM, f"ex_seqs_lag_{lag}_file_0.tsv"), 1)
+        assert set(kmers) == set(got[lag - 1])
+        for k, c in zip(kmers, counts):
+            assert np.array_equal(c.astype(np.int64), got[lag - 1][k]), (lag, k)
+
+
+def test_sequence_readers_and_encoding():
+    from bear_amd import summarize
+    fa = io.StringIO(">a desc\nACG\nTTA\n>b\nGG\n")
+    assert list(summarize.load_input(fa, "fa")) == [("a desc", "ACGTTA"), ("b", "GG")]
+    fq = io.StringIO("@r1\nACGT\n+\nFFFF\n@r2\nTT\n+\nFF\n")
+    assert list(summarize.load_input(fq, "fq")) == [("r1", "ACGT"), ("r2", "TT")]
+    with open(os.path.join(SUM, "infile_1.fq")) as fh:
+        assert [s for _, s in summarize.load_input(fh, "fq")][0] == "AATCCGTAGCCGTTT"
+    text, grp = summarize.encode_sequences(["ACGT", "nA"], [0, 3])
+    assert text.tolist() == [5, 0, 1, 2, 3, 4, 5, 6, 0, 4] and grp.tolist() == [0] * 6 + [3] * 4
+    text, _ = summarize.encode_sequences(["AACG"], [1], reverse=True)           # reverse complement CGTT follows
+    assert text.tolist() == [5, 0, 0, 1, 2, 4, 5, 1, 2, 3, 3, 4]
+    assert summarize.compute_n_bin_bits(3e9, 2, 0.1) == 6 and summarize.compute_n_bin_bits(10, 1, 0.1) == 0
+
+
+def test_table_writer_roundtrip(tmp_path, ysd1):
+    from bear_amd import dataloader
+    kmers, counts = ysd1
+    km = np.frombuffer("".join(kmers).encode(), dtype=np.uint8).reshape(len(kmers), 5).copy()
+    d = dataloader.CountDataset(km, np.ascontiguousarray(counts.transpose(1, 0, 2).astype(np.uint32)), "dna", 500)
+    # the bundled table (lag 5, 3 groups) split over 4 bins
+    from bear_amd import _lib
+    L = _lib.lib()
+    seen = {}
+    for b in range(4):
+        path = str(tmp_path / f"t_lag_5_file_{b}.tsv")
+        assert L.bear_write_counts_tsv(path.encode(), d.kmers.ctypes.data, d.counts.ctypes.data, d.num_rows, 5, 3, b, 4, 0) == 0
+        k2, c2 = o.parse_counts_tsv(path, 3)
+        assert len(k2) == len(range(b, d.num_rows, 4))
+        seen.update({k: c for k, c in zip(k2, c2)})
+    assert len(seen) == len(kmers)
+    for k, c in zip(kmers, counts):
+        assert np.array_equal(seen[k], c)
+    # byte-identical to the reference's row format on the first row (summarize.py:429-449)
+    first = open(tmp_path / "t_lag_5_file_0.tsv").readline()
+    assert first == open(os.path.join(GOLDEN, "ysd1_lag_5_file_0_preshuf.tsv")).readline()
