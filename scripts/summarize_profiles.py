@@ -20,6 +20,8 @@ traffic = {}
 def kernel_key(k):
     """bench.py workload name of a planned kernel instantiation."""
     if "eval_kernel" in k: return "heldout_eval"
+    if "cnn_forward" in k: return "cnn_forward"
+    if "cnn_backward" in k: return "cnn_backward"
     if "dm_linear" in k: return "linear_head"
     if "plan_grad_kernel" in k: return "net_grad"
     if "dm_ref" in k: return "ref_ar" if "<true>" in k else "ref"
@@ -39,7 +41,7 @@ for kind in ("fetch", "write", "sq"):
     if not agg: continue
     out_md += [f"## PMC pass: {kind}", "", "| kernel | counter | mean per launch |", "|---|---|---|"]
     for k, v in agg.items():
-        if "plan_kernel" not in k and "plan_grad_kernel" not in k and "sorted" not in k and "eval_kernel" not in k: continue
+        if "plan_kernel" not in k and "plan_grad_kernel" not in k and "sorted" not in k and "eval_kernel" not in k and "cnn_" not in k: continue
         for c, x in v.items():
             out_md.append(f"| `{k[:40]}` | {c} | {sum(x)/len(x):.0f} |")
             name = kernel_key(k)
