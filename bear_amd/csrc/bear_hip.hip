@@ -604,16 +604,35 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
 // ---- held-out evaluation / BMM marginal (kernels_eval.h) ------------------------------------------------
 static int launch_eval(bear_ws *ws, const uint32_t *test, const uint32_t *train, const double *prior, uint64_t n_rows,
                        const evl_args &A, double *out, hipStream_t s) {
-  const int n_out = 2 * (A.n_h + A.n_van) + 3;
-  const uint64_t tiles = (n_rows + EVL_THREADS - 1) / EVL_THREADS;
+  // sorted formulation (kernels_eval.h): at most EVS_CHUNK DM models per launch; the first launch also carries the AR
+  // model and the total length.  Output slots: ll_ear[n_h], ll_arm, ll_van[n_van], cor_ear[n_h], cor_arm, cor_van[n_van], total
+  const int n_models = A.n_h + A.n_van;
+  const uint64_t tiles = (n_rows + EVS_THREADS - 1) / EVS_THREADS;
   const int grid = (int)(tiles < (uint64_t)ws->eval_blocks ? (tiles ? tiles : 1) : (uint64_t)ws->eval_blocks);
-  hipLaunchKernelGGL(eval_kernel, dim3(grid), dim3(EVL_THREADS), 0, s, test, train, prior, n_rows, A,
-                     reinterpret_cast<const double2 *>(ws->logtab), ws->eval_partials);
-  hipLaunchKernelGGL(eval_finalize_kernel, dim3((n_out + 3) / 4), dim3(256), 0, s, ws->eval_partials, grid, n_out, out);
+  static_assert(EVS_NOUT <= EVL_MAX_OUT, "compact partials fit the evaluation partial buffer");
+  for (int m0 = 0; m0 == 0 || m0 < n_models; m0 += EVS_CHUNK) {
+    const int m_cnt = n_models - m0 < EVS_CHUNK ? n_models - m0 : EVS_CHUNK;
+    const int common = m0 == 0;
+    evs_slots S;
+    for (int k = 0; k < EVS_NOUT; ++k) S.slot[k] = -1;
+    for (int k = 0; k < m_cnt; ++k) {
+      const int m = m0 + k;
+      const int ll_slot = m < A.n_h ? m : m + 1;                 // ll_arm sits between the BEAR and vanilla blocks
+      S.slot[k] = ll_slot;
+      S.slot[EVS_CHUNK + k] = n_models + 1 + ll_slot;
+    }
+    if (common) {
+      S.slot[2 * EVS_CHUNK] = A.n_h;
+      S.slot[2 * EVS_CHUNK + 1] = n_models + 1 + A.n_h;
+      S.slot[2 * EVS_CHUNK + 2] = 2 * n_models + 2;
+    }
+    hipLaunchKernelGGL(eval_sorted_kernel, dim3(grid), dim3(EVS_THREADS), 0, s, test, train, prior, n_rows, A, m0, m_cnt, common,
+                       reinterpret_cast<const double2 *>(ws->logtab), ws->eval_partials);
+    hipLaunchKernelGGL(eval_sorted_finalize_kernel, dim3((EVS_NOUT + 3) / 4), dim3(256), 0, s, ws->eval_partials, grid, S, out);
+  }
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
-
 int bear_eval_f64(bear_ws *ws, const uint32_t *test, const uint32_t *train, const double *prior, uint64_t n_rows,
                   const double *h, int n_h, int with_ar, const double *van_reg, int n_van, double eps,
                   uint64_t noise_seed, uint64_t row_base, double *out, void *stream) {
