@@ -838,6 +838,16 @@ int bear_cnn_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_row
   return BEAR_OK;
 }
 
+int bear_stream_read(bear_ws *ws, const void *src, uint64_t n_bytes, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!src || misaligned(src)) return BEAR_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(stream_read_kernel, dim3(ws->num_cu * 16), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const uint4 *>(src), n_bytes / 16, reinterpret_cast<uint32_t *>(ws->dbg));
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
 int bear_synth_counts_u32(uint64_t seed, uint64_t row0, uint64_t n_rows, int dense, uint32_t *train,
                           uint32_t *test, uint32_t *ref, void *stream) {
   if (n_rows == 0) return BEAR_OK;

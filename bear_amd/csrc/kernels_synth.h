@@ -70,3 +70,14 @@ __global__ void synth_prior_kernel(uint64_t seed, uint64_t row0, uint64_t n_rows
   for (int b = 0; b < 5; ++b) prior[i * 5 + b] = e[b] / s;
 }
 
+
+// ------------------------------------------------------------------ read-only stream (measurement)
+// What a pure read of `n16` 16-byte words costs on this device: the measured ceiling next to the 8 TB/s spec peak.
+__global__ __launch_bounds__(256) void stream_read_kernel(const uint4 *__restrict__ src, uint64_t n16, uint32_t *__restrict__ sink) {
+  uint32_t acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) {
+    const uint4 v = src[i];
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9E3779B9u) sink[0] = acc;   // never true in practice: keeps the loads alive without a store per thread
+}

@@ -386,3 +386,11 @@ def cnn_backward(kmer_code, flat_params, lag, filter_width, t1, prior, grad_prio
                                               _ptr(grad), _stream())
     _lib.check(st, "bear_cnn_backward_f64")
     return grad
+
+
+def stream_read(t, ws=None):
+    """One launch of ``bear_stream_read`` over tensor ``t`` (measurement helper: a pure HBM read)."""
+    ws = ws or default_workspace(t.device)
+    with torch.cuda.device(t.device):
+        st = _lib.lib().bear_stream_read(ws.handle, _ptr(t), t.numel() * t.element_size(), _stream())
+    _lib.check(st, "bear_stream_read")

@@ -137,6 +137,17 @@ def main():
         torch.cuda.synchronize()
         norm_ms = e0.elapsed_time(e1) / 10
 
+    stream_gbps = None
+    if rank == 0:   # measured read-only stream over the same prior rows (4 GB): the practical ceiling under the spec peak
+        kernels.stream_read(prior)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            kernels.stream_read(prior)
+        e1.record()
+        torch.cuda.synchronize()
+        stream_gbps = prior.numel() * 8 / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9
+
     extra = {}
     if rank == 0 and world == 1:  # the rows of SURVEY 8f built on the same kernels: kernel-only times, 1 GPU
         def timed(fn, reps):
@@ -229,6 +240,7 @@ def main():
                 "traffic": traffic,
                 "kernel": "dm_prior_plan_kernel" if primary == "net" else "dm_ref_plan_kernel",
                 "kernel_ms": k_ms,
+                "measured_stream_read_GBps": stream_gbps,
             },
             "plan_build_s": plan_build_s,
             "plan_bytes_per_context": plans[primary].nbytes / n,

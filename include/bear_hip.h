@@ -228,6 +228,9 @@ int bear_logdir_sample_f64(const uint32_t *counts, const double *prior, uint64_t
  */
 int bear_synth_counts_u32(uint64_t seed, uint64_t row0, uint64_t n_rows, int dense, uint32_t *train,
                           uint32_t *test, uint32_t *ref, void *stream);
+/* Read-only pass over n_bytes of device memory (16-byte lane loads, nothing written): the measured HBM read ceiling that
+ * bench.py reports next to the 8 TB/s spec peak. */
+int bear_stream_read(bear_ws *ws, const void *src, uint64_t n_bytes, void *stream);
 /* prior [dev] double [n_rows, 5]: positive rows summing to 1 (softmax of hashed logits). */
 int bear_synth_prior_f64(uint64_t seed, uint64_t row0, uint64_t n_rows, double *prior, void *stream);
 
