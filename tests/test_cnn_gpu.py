@@ -97,3 +97,29 @@ def test_cnn_backward_is_linear_and_shard_additive():
     empty = kernels.cnn_backward(packed[:0].contiguous(), flat, lag, fw, t1[:0].contiguous(), prior[:0].contiguous(),
                                  g[:0].contiguous())
     assert torch.count_nonzero(empty).item() == 0
+
+
+def test_cnn_full_size_properties():
+    """BASELINE configs[2]/[4] size (1e7 contexts, lag 13): size-independent properties -- rows sum to one, the intercept2
+    gradient sums to zero (softmax), shard additivity of the backward pass, forward independent of sharding."""
+    dev = torch.device("cuda", 0)
+    lag, fw, n = 13, 8, 10_000_000
+    g = torch.Generator(device=dev).manual_seed(2)
+    codes = torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev, generator=g)
+    codes[:1000, :3] = 4                                   # some start contexts
+    packed = kernels.pack_kmers(codes)
+    _, params = _make(lag, fw, dev, 9)
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+    prior, t1 = kernels.cnn_forward(packed, flat, lag, fw)
+    assert (prior.sum(1) - 1.0).abs().max().item() < 1e-14 and prior.min().item() > 0.0
+    cut = 3_333_333
+    pa, _ = kernels.cnn_forward(packed[:cut].contiguous(), flat, lag, fw)
+    assert torch.equal(pa, prior[:cut])
+    grad = torch.randn(n, 5, dtype=torch.float64, device=dev, generator=g)
+    full = kernels.cnn_backward(packed, flat, lag, fw, t1, prior, grad)
+    parts = [kernels.cnn_backward(packed[a:b].contiguous(), flat, lag, fw, t1[a:b].contiguous(), prior[a:b].contiguous(),
+                                  grad[a:b].contiguous()) for a, b in ((0, cut), (cut, n))]
+    scale = full.abs().max().item()
+    assert (full - (parts[0] + parts[1])).abs().max().item() <= 1e-11 * scale
+    off = 8 * 5 * 30 + 6 * 30 + 6 * 30 * 16 + 16 + 16 * 5          # intercept2 sits after filters, intercept0, weights1, intercept1, weights2
+    assert abs(full[off:off + 5].sum().item()) <= 1e-9 * full[off:off + 5].abs().sum().item()

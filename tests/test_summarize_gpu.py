@@ -110,3 +110,33 @@ def test_random_sequences_many_bins_and_invalid_letters(tmp_path):
     # totals: one transition per letter plus one stop per sequence
     kmers, counts = summarize.count_transitions(*summarize.encode_sequences([s for s, _ in clean], [g for _, g in clean]), 3, 4)
     assert counts.sum() == sum(len(s) + 1 for s, _ in clean)
+
+
+def test_full_size_count_conservation():
+    """1e7 positions at lag 13: every letter and every stop is exactly one transition, rows are distinct, and the lag-13
+    table folds onto the lag-5 table (marginalising the 8 leading letters preserves each 5-mer's counts)."""
+    import torch
+    from bear_amd import summarize
+    dev = torch.device("cuda", 0)
+    reads, rl = 66_000, 150
+    g = torch.Generator(device=dev).manual_seed(3)
+    body = torch.randint(0, 4, (reads, rl), dtype=torch.uint8, device=dev, generator=g)
+    text = torch.cat([torch.full((reads, 1), 5, dtype=torch.uint8, device=dev), body,
+                      torch.full((reads, 1), 4, dtype=torch.uint8, device=dev)], 1).reshape(-1).contiguous()
+    grp = (torch.arange(reads, device=dev) % 3).to(torch.uint8).repeat_interleave(rl + 2).contiguous()
+    k13, c13 = summarize.count_transitions(text, grp, 13, 3)
+    k5, c5 = summarize.count_transitions(text, grp, 5, 3)
+    assert int(c13.sum()) == int(c5.sum()) == reads * (rl + 1)
+    assert len({bytes(r) for r in k13[:200000]}) == 200000 and c13.shape == (3, k13.shape[0], 5)
+    per_group = np.bincount(np.arange(reads) % 3, minlength=3) * (rl + 1)
+    assert np.array_equal(c13.sum(axis=(1, 2)), per_group)
+    # fold: suffix of length 5 of every 13-mer context
+    fold = {}
+    suf = k13[:, 8:]
+    keys = (suf.astype(np.uint64) * (256 ** np.arange(5, dtype=np.uint64))).sum(1)
+    order = np.argsort(keys, kind="stable")
+    uk, start = np.unique(keys[order], return_index=True)
+    folded = np.add.reduceat(c13[:, order].astype(np.int64), start, axis=1)
+    k5keys = (k5.astype(np.uint64) * (256 ** np.arange(5, dtype=np.uint64))).sum(1)
+    o5 = np.argsort(k5keys)
+    assert np.array_equal(uk, k5keys[o5]) and np.array_equal(folded, c5[:, o5].astype(np.int64))
