@@ -9,8 +9,9 @@ log-Gamma draws of ``log_gamma.log_gamma`` and their normalisation, or the MAP t
 reference (string windows, a lookup table indexed by k+1-mer).
 
 Differences a user can see: draws come from a counter-based stream (``seed`` argument; ``None`` takes a fresh
-seed from numpy's global generator) instead of numpy's Mersenne twister, and the KMC look-up
-(``make_kmc_genome_counter``, :213-290) needs the external ``py_kmc_api`` module exactly as the reference.
+seed from numpy's global generator) instead of numpy's Mersenne twister, and the KMC database look-up
+(``make_kmc_genome_counter``, :213-290, external ``py_kmc_api``) is replaced by ``make_sequence_counter``: the same counts
+from the sequence files themselves, counted on the device and passed as ``counter=``.
 """
 import configparser
 import json
@@ -168,13 +169,45 @@ def get_pdf(kmers, counts, h, ar_func, mc_samples, vans, train_col, alphabet_nam
 
 def make_kmc_genome_counter(path, lag, reverse=True, no_end=False):
     """get_var_probs.py:213-290 looks counts up in KMC databases through ``py_kmc_api`` (an external binary
-    module, imported lazily by the reference too).  Not part of this build: pass ``data`` instead."""
+    module, imported lazily by the reference too).  This build has no KMC: use ``make_sequence_counter`` (the same
+    counts from the sequence files, counted on the device) and pass it as ``counter=``."""
     try:
         import py_kmc_api  # noqa: F401
     except ImportError as e:
-        raise ImportError("make_kmc_genome_counter needs the external py_kmc_api module (KMC); "
-                          "use the count-table path (data=...) instead") from e
-    raise NotImplementedError("KMC database look-ups are outside this build (SURVEY.md 8f.2: KMC stays external)")
+        raise ImportError("make_kmc_genome_counter needs the external py_kmc_api module (KMC); build the counter "
+                          "with make_sequence_counter(...) and pass it as counter=, or use the count-table path (data=...)") from e
+    raise NotImplementedError("KMC database look-ups are outside this build; use make_sequence_counter")
+
+
+def make_sequence_counter(seqs, lag, reverse=True, no_end=False, device=None):
+    """The counter of ``make_kmc_genome_counter`` (get_var_probs.py:213-290: k-mer strings -> transition counts
+    ``[..., alphabet_size + 1]``) without KMC: the lag-``lag`` transition table of the sequences, counted on the device
+    (``bear_amd.summarize``), as a look-up.  ``seqs``: sequences (list of str) or a summarize-style csv of
+    ``FILE, GROUP, TYPE`` rows (all groups are pooled, as one KMC database is).  ``reverse`` adds the counts of the reverse
+    complements (:246-248, 271-278); ``no_end`` drops the stop counts and serves only full-length contexts (:240-252)."""
+    from . import summarize
+    if isinstance(seqs, str):
+        seqs, _ = summarize._load_sequences(seqs)
+    seqs = [str(s) for s in seqs]
+    text, grp = summarize.encode_sequences(seqs, [0] * len(seqs), reverse=reverse)
+    kmers, counts = summarize.count_transitions(text, grp, lag, 1, device=device)
+    table = {bytes(k).decode(): counts[0, i].astype(np.float64) for i, k in enumerate(kmers)}
+    A1 = counts.shape[-1]
+
+    def counter(kmers):
+        kmers = np.asarray(kmers)
+        out = np.zeros((kmers.size, A1))
+        for i, k in enumerate(kmers.reshape(-1).tolist()):
+            k = k.decode() if isinstance(k, bytes) else str(k)
+            if no_end and "[" in k:
+                continue
+            row = table.get(k)
+            if row is not None:
+                out[i] = row
+        if no_end:
+            out[:, -1] = 0
+        return out.reshape(kmers.shape + (A1,))
+    return counter
 
 
 # ------------------------------------------------------------------------------------------- variants
@@ -233,7 +266,7 @@ def _scan(data, all_kmers, add, make_pdf, alphabet_size, train_col):
             all_kmers[unseen].astype(str))
 
 
-def _setup(bear_path, lag, alphabet_name, h, data, vans, kmc_path):
+def _setup(bear_path, lag, alphabet_name, h, data, vans, kmc_path, counter=None):
     if bear_path is not None:
         lag, alphabet_name, h_bear, ar_func, data = load_bear(bear_path)
         if h is None:
@@ -241,19 +274,19 @@ def _setup(bear_path, lag, alphabet_name, h, data, vans, kmc_path):
         len_h = len(h)
     else:
         assert ((lag is not None and alphabet_name is not None)
-                and ((data is not None or kmc_path is not None) and len(vans) > 0))
+                and ((data is not None or kmc_path is not None or counter is not None) and len(vans) > 0))
         len_h, ar_func = 0, None
-    if kmc_path is not None:
+    if kmc_path is not None and counter is None:
         make_kmc_genome_counter(kmc_path, lag)
     return lag, alphabet_name, h, ar_func, data, len_h
 
 
 def get_bear_probs(bear_path, wt_seq, vars_, train_col, mc_samples=41, vans=[0.1, 1, 10], get_map=False,
                    lag=None, alphabet_name=None, h=None, data=None, kmc_path=None, kmc_reverse=False,
-                   kmc_no_end=False, seed=None):
+                   kmc_no_end=False, seed=None, counter=None):
     """get_var_probs.get_bear_probs (get_var_probs.py:346-452): posterior predictive log-probability ratios of
     variants -> [num variants, num models, mc_samples] ([num variants, num models] with ``get_map``)."""
-    lag, alphabet_name, h, ar_func, data, len_h = _setup(bear_path, lag, alphabet_name, h, data, vans, kmc_path)
+    lag, alphabet_name, h, ar_func, data, len_h = _setup(bear_path, lag, alphabet_name, h, data, vans, kmc_path, counter)
     alphabet_size = len(core.alphabets_en[alphabet_name]) - 1
     wt_seq = lag * "[" + wt_seq + "]"
     vars_ = [parse_var(v) for v in vars_]
@@ -269,7 +302,10 @@ def get_bear_probs(bear_path, wt_seq, vars_, train_col, mc_samples=41, vans=[0.1
 
     def add(pdf, seen):
         _add_kmer_probs_vars(vars_, scores, wt_seq, pdf, lag, seen)
-    _scan(data, all_kmers, add, make_pdf, alphabet_size, train_col)
+    if counter is not None:     # get_var_probs.py:411-420: counts looked up per k-mer instead of scanning the table
+        add(make_pdf(all_kmers, counter(all_kmers)[:, None, :], 0), all_kmers)
+    else:
+        _scan(data, all_kmers, add, make_pdf, alphabet_size, train_col)
     return scores[..., 0] if get_map else scores
 
 
@@ -305,10 +341,10 @@ def _get_all_kmers_seqs(seqs, lag):
 
 def get_bear_probs_seqs(bear_path, seqs, train_col, mc_samples=41, vans=[0.1, 1, 10], get_map=False, get_marg=False,
                         lag=None, alphabet_name=None, h=None, data=None, kmc_path=None, kmc_reverse=False,
-                        no_ends=False, seed=None):
+                        no_ends=False, seed=None, counter=None):
     """get_var_probs.get_bear_probs_seqs (get_var_probs.py:511-631): log-probabilities of whole sequences ->
     [num sequences, num models, mc_samples] (last axis dropped with ``get_map`` / ``get_marg``)."""
-    lag, alphabet_name, h, ar_func, data, len_h = _setup(bear_path, lag, alphabet_name, h, data, vans, kmc_path)
+    lag, alphabet_name, h, ar_func, data, len_h = _setup(bear_path, lag, alphabet_name, h, data, vans, kmc_path, counter)
     alphabet = core.alphabets_en[alphabet_name]
     alphabet_size = len(alphabet) - 1
     if not no_ends:
@@ -326,5 +362,8 @@ def get_bear_probs_seqs(bear_path, seqs, train_col, mc_samples=41, vans=[0.1, 1,
 
     def add(pdf, seen):
         _add_kmer_probs_seqs(seqs, scores, pdf, lag, seen, get_marg, alphabet)
-    _scan(data, all_kmers, add, make_pdf, alphabet_size, train_col)
+    if counter is not None:     # get_var_probs.py:585-597
+        add(make_pdf(all_kmers, counter(all_kmers)[:, None, :], 0), all_kmers)
+    else:
+        _scan(data, all_kmers, add, make_pdf, alphabet_size, train_col)
     return scores[..., 0] if (get_map or get_marg) else scores

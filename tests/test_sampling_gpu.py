@@ -194,3 +194,36 @@ def test_get_pdf_with_ar_func_outputs(dev):
     assert np.allclose(arr, want, rtol=DRAW_RTOL, atol=1e-11)
     m = get_var_probs.get_pdf(kmers, counts, h, ar_func, 6, vans, 0, "dna", True, output="numpy")
     assert m.shape == (4, 5, 4, 1) and np.allclose(np.exp(m[:, :, 0, 0]), f, rtol=1e-12)
+
+
+EX_SEQS_LIST = ["TTTAT", "TTCTT", "TTTTT", "TTTTT"]          # bear_model/tests/test_var_prob.py:13
+
+
+def test_sequence_counter_reference_values(dev):
+    """bear_model/tests/test_var_prob.py:9-21 (test_kmc_counter) with the device-built table in place of the KMC databases."""
+    from bear_amd import get_var_probs
+    counter = get_var_probs.make_sequence_counter(EX_SEQS_LIST, 3, reverse=False, no_end=False)
+    assert np.all(counter(np.array(["TTT", "TTA", "[[T"])) == [[1, 0, 0, 4, 2], [0, 0, 0, 1, 0], [0, 0, 0, 4, 0]])
+    counter = get_var_probs.make_sequence_counter(EX_SEQS_LIST, 3, reverse=True, no_end=False)
+    assert np.all(counter(np.array(["TTT", "[AT", "AAA"])) == [[1, 0, 0, 4, 2], [1, 0, 0, 0, 0], [4, 0, 0, 0, 3]])
+    counter = get_var_probs.make_sequence_counter(EX_SEQS_LIST, 3, reverse=False, no_end=True)
+    assert np.all(counter(np.array([["TTT", "[[T"]])) == [[[1, 0, 0, 4, 0], [0, 0, 0, 0, 0]]])
+    assert np.all(counter(np.array(["GGG"])) == 0)
+
+
+def test_get_bear_probs_through_the_sequence_counter(dev):
+    """test_var_prob.py:31-33, 53-55, 60-61: the counter path gives the same scores as scanning the table."""
+    from bear_amd import get_var_probs
+    vans = np.array([0.1, 1, 10])
+    counter = get_var_probs.make_sequence_counter(EX_SEQS_LIST, 3, reverse=False)
+    kw = dict(vans=vans, lag=3, alphabet_name="dna")
+    a = get_var_probs.get_bear_probs(None, "TTTAT", np.array(["A3T", "T2C"]), 0, data=_data(), get_map=True, **kw)
+    b = get_var_probs.get_bear_probs(None, "TTTAT", np.array(["A3T", "T2C"]), 0, counter=counter, get_map=True, **kw)
+    assert np.allclose(a, b)
+    seqs = ["TTTAT", "TTCAT", "TTTTTTTTTT"]
+    a = get_var_probs.get_bear_probs_seqs(None, seqs, 0, data=_data(), get_marg=True, **kw)
+    b = get_var_probs.get_bear_probs_seqs(None, seqs, 0, counter=counter, get_marg=True, **kw)
+    assert np.allclose(a, b, rtol=1e-12)
+    m = get_var_probs.get_bear_probs_seqs(None, seqs, 0, counter=counter, mc_samples=20000, seed=4, **kw)
+    n = get_var_probs.get_bear_probs_seqs(None, seqs, 0, data=_data(), mc_samples=20000, seed=5, **kw)
+    assert np.all(np.abs((m.mean(-1) - n.mean(-1)) / n.mean(-1)) < 0.01)
