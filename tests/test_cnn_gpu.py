@@ -50,7 +50,7 @@ def test_cnn_forward_matches_oracle(lag, fw, n):
     assert t1.shape == (n, 16)
 
 
-@pytest.mark.parametrize("lag,fw,n", [(13, 8, 3000), (5, 3, 1365), (7, 7, 64), (2, 1, 3)])
+@pytest.mark.parametrize("lag,fw,n", [(13, 8, 3000), (5, 3, 1365), (7, 7, 64), (2, 1, 3), (21, 1, 500), (21, 16, 200)])
 def test_cnn_backward_matches_torch_autograd(lag, fw, n):
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(lag * 7 + fw)
