@@ -5,6 +5,9 @@
 #include <fcntl.h>
 #include <stdint.h>
 #include <stdio.h>
+
+#include <thread>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
@@ -60,17 +63,13 @@ extern "C" int bear_count_rows(const char *path, uint64_t *n_rows_out) {
   return BEAR_OK;
 }
 
-extern "C" int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint64_t max_rows, char *kmers,
-                                     uint32_t *counts, uint64_t *n_rows_out) {
-  if (!path || !counts || !n_rows_out || num_ds < 1 || lag < 0) return BEAR_ERR_INVALID_ARG;
-  *n_rows_out = 0;
-  mapped_file f;
-  int st = f.open_ro(path);
-  if (st != BEAR_OK) return st;
-  const char *p = f.data, *end = f.data + f.size;
-  uint64_t row = 0;
+namespace {
+// Parses the lines of [p, end) into rows row .. ; returns the status and the number of rows written.
+int parse_range(const char *p, const char *end, int num_ds, int lag, uint64_t max_rows, uint64_t row, uint64_t row_limit,
+                char *kmers, uint32_t *counts, uint64_t *rows_done) {
   const int per_row = num_ds * BEAR_ROW_WIDTH;
-  while (p < end && row < max_rows) {
+  const uint64_t row_begin = row;
+  while (p < end && row < row_limit) {
     const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
     const char *le = nl ? nl : end;
     if (blank_line(p, le)) {
@@ -109,7 +108,78 @@ extern "C" int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint
     ++row;
     p = le + 1;
   }
-  *n_rows_out = row;
+  *rows_done = row - row_begin;
+  return BEAR_OK;
+}
+
+uint64_t count_lines(const char *p, const char *end) {
+  uint64_t n = 0;
+  while (p < end) {
+    const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+    const char *le = nl ? nl : end;
+    if (!blank_line(p, le)) ++n;
+    p = le + 1;
+  }
+  return n;
+}
+}  // namespace
+
+// Text decoding is the first-epoch cost of a large table (~60-80 GB of text at 1e9 rows), so the file is
+// cut at line boundaries into one chunk per hardware thread: pass 1 counts the rows of each chunk, a prefix sum gives
+// every chunk its first row, pass 2 parses the chunks in place into the shared output arrays.
+extern "C" int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint64_t max_rows, char *kmers,
+                                     uint32_t *counts, uint64_t *n_rows_out) {
+  if (!path || !counts || !n_rows_out || num_ds < 1 || lag < 0) return BEAR_ERR_INVALID_ARG;
+  *n_rows_out = 0;
+  mapped_file f;
+  int st = f.open_ro(path);
+  if (st != BEAR_OK) return st;
+  const char *base = f.data, *end = f.data + f.size;
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *env = getenv("BEAR_PARSE_THREADS")) nt = (unsigned)atoi(env);
+  if (nt < 1) nt = 1;
+  if (nt > 64) nt = 64;
+  if (f.size < (size_t)(1u << 20)) nt = 1;           // small files: not worth the threads
+  // chunk boundaries at line starts
+  std::vector<const char *> cut(nt + 1);
+  cut[0] = base;
+  cut[nt] = end;
+  for (unsigned k = 1; k < nt; ++k) {
+    const char *p = base + (f.size / nt) * k;
+    const char *nl = p < end ? static_cast<const char *>(memchr(p, '\n', (size_t)(end - p))) : nullptr;
+    cut[k] = nl ? nl + 1 : end;
+    if (cut[k] < cut[k - 1]) cut[k] = cut[k - 1];
+  }
+  std::vector<uint64_t> first(nt + 1, 0), done(nt, 0);
+  std::vector<int> status(nt, BEAR_OK);
+  if (nt == 1) {
+    st = parse_range(base, end, num_ds, lag, max_rows, 0, max_rows, kmers, counts, &done[0]);
+    if (st != BEAR_OK) return st;
+    *n_rows_out = done[0];
+    return BEAR_OK;
+  }
+  {
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; ++k) th.emplace_back([&, k] { first[k + 1] = count_lines(cut[k], cut[k + 1]); });
+    for (auto &t : th) t.join();
+  }
+  for (unsigned k = 0; k < nt; ++k) first[k + 1] += first[k];
+  {
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; ++k)
+      th.emplace_back([&, k] {
+        const uint64_t lim = first[k + 1] < max_rows ? first[k + 1] : max_rows;
+        if (first[k] >= lim) return;
+        status[k] = parse_range(cut[k], cut[k + 1], num_ds, lag, max_rows, first[k], lim, kmers, counts, &done[k]);
+      });
+    for (auto &t : th) t.join();
+  }
+  uint64_t total = 0;
+  for (unsigned k = 0; k < nt; ++k) {
+    if (status[k] != BEAR_OK) return status[k];
+    total += done[k];
+  }
+  *n_rows_out = total;
   return BEAR_OK;
 }
 

@@ -59,3 +59,40 @@ def test_shuffle_permutation_is_a_bijection_and_matches_the_abi():
     # different seeds give different orders; fixed points are rare
     a, b = o.shuffle_perm(10000, 1), o.shuffle_perm(10000, 2)
     assert (a != b).mean() > 0.99 and (a == np.arange(10000)).mean() < 0.01
+
+
+def test_threaded_parser_matches_single_thread(tmp_path):
+    """A table above the 1 MiB threshold is cut at line boundaries and parsed by several threads: same result as one
+    thread, including blank lines and an error in the middle of the file."""
+    from bear_amd import _lib, dataloader
+    rng = np.random.default_rng(1)
+    n, lag = 60000, 7
+    letters = np.frombuffer(b"ACGT[", dtype=np.uint8)
+    kmers = letters[rng.integers(0, 5, size=(n, lag))]
+    counts = rng.integers(0, 5, size=(2, n, 5)).astype(np.uint32)
+    counts[0, ::97, 0] = 4000000000
+    path = tmp_path / "big.tsv"
+    L = _lib.lib()
+    assert L.bear_write_counts_tsv(str(path).encode(), kmers.ctypes.data, counts.ctypes.data, n, lag, 2, 0, 1, 0) == 0
+    text = path.read_bytes()
+    assert len(text) > (1 << 20)
+    lines = text.split(b"\n")
+    lines.insert(20000, b"")                       # blank lines are skipped (dataloader.py: CsvDataset ignores them too)
+    lines.insert(45000, b"   ")
+    path.write_bytes(b"\n".join(lines))
+    results = []
+    for threads in ("1", "8", "3"):
+        os.environ["BEAR_PARSE_THREADS"] = threads
+        d = dataloader.dataloader(str(path), "dna", 1000, 2)
+        results.append(d)
+        assert d.num_rows == n and np.array_equal(d.counts, counts) and np.array_equal(d.kmers, kmers)
+    # a malformed row in the middle fails loudly whichever thread meets it
+    bad = lines[:]
+    bad[30000] = bad[30000].replace(b"[[", b"[[x")
+    path.write_bytes(b"\n".join(bad))
+    import pytest
+    for threads in ("1", "8"):
+        os.environ["BEAR_PARSE_THREADS"] = threads
+        with pytest.raises(_lib.BearError):
+            dataloader.dataloader(str(path), "dna", 1000, 2)
+    os.environ.pop("BEAR_PARSE_THREADS")
