@@ -64,7 +64,14 @@ class ResidentBatches:
             raise TypeError("train / evaluation expect the CountDataset returned by bear_amd.dataloader")
         self.data, self.device = data, device
         self.batches = []
-        codes = data.codes() if want_codes else None
+        # k-mer letter codes: the ASCII bytes go up as they were parsed and are encoded on the device
+        fast_codes = want_codes and data.alphabet in ("dna", "rna") and data.lag > 0
+        codes = data.codes() if (want_codes and not fast_codes) else None
+
+        def device_codes(lo, hi):
+            if fast_codes:
+                return kernels.encode_kmers(torch.from_numpy(np.ascontiguousarray(data.kmers[lo:hi])).to(device), data.alphabet)
+            return torch.from_numpy(np.ascontiguousarray(codes[lo:hi])).to(device)
         shuffled = {}
         if data.shuffle_seed is not None and data.num_rows:
             # whole columns go up once, are permuted by one gather pass each (same seed: columns stay aligned), and the
@@ -73,8 +80,8 @@ class ResidentBatches:
                 up = torch.from_numpy(np.ascontiguousarray(data.counts[col]).view(np.int32)).to(device)
                 shuffled[name] = kernels.shuffle_rows(up, data.shuffle_seed)
                 del up
-            if codes is not None:
-                shuffled["codes"] = kernels.shuffle_rows(torch.from_numpy(np.ascontiguousarray(codes)).to(device), data.shuffle_seed)
+            if want_codes:
+                shuffled["codes"] = kernels.shuffle_rows(device_codes(0, data.num_rows), data.shuffle_seed)
         for a, b in data.batch_bounds():
             lo, hi = dist.shard_rows(b - a)
             lo, hi = a + lo, a + hi
@@ -84,8 +91,8 @@ class ResidentBatches:
                     entry[name] = shuffled[name][lo:hi].clone()
                 else:
                     entry[name] = torch.from_numpy(np.ascontiguousarray(data.counts[col, lo:hi]).view(np.int32)).to(device)
-            if codes is not None:
-                entry["codes"] = shuffled["codes"][lo:hi].clone() if shuffled else torch.from_numpy(np.ascontiguousarray(codes[lo:hi])).to(device)
+            if want_codes:
+                entry["codes"] = shuffled["codes"][lo:hi].clone() if shuffled else device_codes(lo, hi)
             entry["plans"] = {}
             self.batches.append(entry)
         del shuffled

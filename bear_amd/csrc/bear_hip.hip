@@ -570,6 +570,19 @@ int bear_pack_kmers_u64(const int8_t *codes, uint64_t n_rows, int lag, uint64_t 
   return BEAR_OK;
 }
 
+int bear_encode_kmers_i8(const uint8_t *ascii, uint64_t n_rows, int lag, int rna, int8_t *codes, void *stream) {
+  if (lag < 1) return BEAR_ERR_INVALID_ARG;
+  if (n_rows == 0) return BEAR_OK;
+  if (!ascii || !codes) return BEAR_ERR_INVALID_ARG;
+  const uint64_t n_bytes = n_rows * (uint64_t)lag;
+  uint64_t blocks = (n_bytes + 255) / 256;
+  if (blocks > 1u << 20) blocks = 1u << 20;
+  hipLaunchKernelGGL(encode_kmers_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), ascii, n_bytes, rna,
+                     codes);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
 int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code,
                        const double *mat, int lag, uint64_t n_rows, double h_signed, double eps, int train_ar,
                        double *out, double *grad_mat, void *stream) {

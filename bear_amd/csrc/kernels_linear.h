@@ -63,6 +63,21 @@ __global__ void pack_kmers_kernel(const int8_t *__restrict__ codes, uint64_t n, 
   out[i] = w;
 }
 
+// ASCII k-mers as they sit in the count file -> int8 letter codes (core.tf_one_hot's alphabet order, core.py:146-153:
+// 0..3 letters, 4 = start symbol '[', -1 = anything else) -- the host LUT of a 1e9-row table took longer than an epoch.
+__global__ void encode_kmers_kernel(const uint8_t *__restrict__ ascii, uint64_t n_bytes, int rna, int8_t *__restrict__ codes) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bytes; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint8_t ch = ascii[i];
+    int8_t c = -1;
+    if (ch == 'A') c = 0;
+    else if (ch == 'C') c = 1;
+    else if (ch == 'G') c = 2;
+    else if (ch == (rna ? 'U' : 'T')) c = 3;
+    else if (ch == '[') c = 4;
+    codes[i] = c;
+  }
+}
+
 __device__ __forceinline__ uint32_t lin_combo(unsigned long long code, int g) {
   const uint32_t field = (uint32_t)(code >> (6 * g)) & 63u;
   return (field & 7u) * 6u + (field >> 3);

@@ -394,3 +394,18 @@ def stream_read(t, ws=None):
     with torch.cuda.device(t.device):
         st = _lib.lib().bear_stream_read(ws.handle, _ptr(t), t.numel() * t.element_size(), _stream())
     _lib.check(st, "bear_stream_read")
+
+
+def encode_kmers(ascii_kmers, alphabet="dna"):
+    """One launch of ``bear_encode_kmers_i8``: device uint8 [n, lag] ASCII k-mers -> int8 letter codes [n, lag]
+    (the device twin of ``core.encode_kmers``)."""
+    if not (ascii_kmers.is_cuda and ascii_kmers.dtype == torch.uint8 and ascii_kmers.dim() == 2 and ascii_kmers.is_contiguous()):
+        raise ValueError("ascii_kmers must be a contiguous CUDA uint8 tensor [n, lag]")
+    if alphabet not in ("dna", "rna"):
+        raise NotImplementedError("device encoding covers the 4-letter alphabets")
+    codes = torch.empty(ascii_kmers.shape, dtype=torch.int8, device=ascii_kmers.device)
+    with torch.cuda.device(ascii_kmers.device):
+        st = _lib.lib().bear_encode_kmers_i8(_ptr(ascii_kmers), ascii_kmers.shape[0], ascii_kmers.shape[1], int(alphabet == "rna"),
+                                             _ptr(codes), _stream())
+    _lib.check(st, "bear_encode_kmers_i8")
+    return codes

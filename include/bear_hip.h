@@ -135,6 +135,9 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
  * Reads 8 bytes per context plus the plan; writes nothing per context.
  */
 int bear_pack_kmers_u64(const int8_t *codes, uint64_t n_rows, int lag, uint64_t *packed, void *stream);
+/* ASCII k-mer bytes as parsed from the count file [dev] uint8 [n_rows, lag] -> int8 letter codes [dev] [n_rows, lag]:
+ * 0..3 = A, C, G, T (U when rna != 0), 4 = '[', -1 = anything else (the all-zero one-hot row of core.py:173). */
+int bear_encode_kmers_i8(const uint8_t *ascii, uint64_t n_rows, int lag, int rna, int8_t *codes, void *stream);
 int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code,
                        const double *mat, int lag, uint64_t n_rows, double h_signed, double eps, int train_ar,
                        double *out, double *grad_mat, void *stream);

@@ -42,3 +42,14 @@ def test_training_on_shuffled_table_matches_oracle_on_permuted_rows(ysd1):
     bear_ref.train(full.shuffle(11).repeat(1), 1365, 1, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False,
                    loss_save=l1)
     assert np.isclose(l0[0], l1[0], rtol=1e-12)
+
+
+def test_device_kmer_encoding_matches_host():
+    from bear_amd import core
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0)
+    ascii_ = rng.integers(32, 127, size=(5000, 13)).astype(np.uint8)
+    ascii_[:4000] = np.frombuffer(b"ACGTU[acgtN]", dtype=np.uint8)[rng.integers(0, 12, size=(4000, 13))]
+    for alphabet in ("dna", "rna"):
+        got = kernels.encode_kmers(torch.from_numpy(ascii_).to(dev), alphabet).cpu().numpy()
+        assert np.array_equal(got, core.encode_kmers(ascii_, alphabet))
