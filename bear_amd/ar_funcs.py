@@ -78,6 +78,7 @@ def make_ar_func_linear(lag, alphabet_size, dtype=torch.float64, device=None, ge
             z = torch.einsum("...jk,jkl->...l", kmers, mat)
         return torch.softmax(z, dim=-1)
     ar_func.linear_mat = mat      # bear_net.train: whole step fused in one kernel (bear_dm_linear_f64)
+    ar_func.normalized_rows = True   # softmax output: the DM kernels may take the shared concentration total (prior_normalized)
     return ar_func, [mat]
 
 
@@ -131,6 +132,7 @@ def make_ar_func_cnn(lag, alphabet_size, filter_width=8, num_filters=30, kmer_la
         nn2 = torch.tensordot(F.elu(nn1), kmer_weights2, dims=([-1], [0])) + kmer_intercept2
         return torch.softmax(nn2, dim=-1)
     ar_func.fused = fused_ok       # integer codes on the device take the fused kernels; one-hot input the torch ops
+    ar_func.normalized_rows = True
     return ar_func, params
 
 
@@ -142,4 +144,5 @@ def make_ar_func_stop(lag, alphabet_size, dtype=torch.float64, device=None, gene
     def ar_func(y):
         return stop
     ar_func.is_stop = True  # lets bear_ref pick the fused reference-prior kernels
+    ar_func.normalized_rows = True
     return ar_func, []

@@ -53,6 +53,7 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
     fused_mat = getattr(ar_func, "linear_mat", None)
     if fused_mat is not None and not (alphabet_size == 4 and lag <= kernels.LINEAR_MAX_LAG and fused_mat is ar_params[0]):
         fused_mat = None
+    normalized = bool(getattr(ar_func, "normalized_rows", False))   # every reference AR function ends in a softmax
     for _ in range(data.repeats):
         for k in range(n_batches):
             e = res.batches[k]
@@ -70,10 +71,10 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
                 need_rows = prior.requires_grad
                 if need_rows:     # planned kernel, gradient rows assembled in LDS
                     _, grad_rows = kernels.dm_prior_planned(res.plan(k, "train", 5), prior.detach(), h_signed.item(), out=out,
-                                                            want_grad=True, train_ar=train_ar)
+                                                            want_grad=True, train_ar=train_ar, normalized=normalized)
                 else:             # parameter-free AR function (stop): nothing to feed back
                     kernels.dm_prior_planned(res.plan(k, "train", 5), prior.detach(), h_signed.item(), out=out,
-                                             train_ar=train_ar)
+                                             train_ar=train_ar, normalized=normalized)
                     grad_rows = None
                 if need_rows:
                     prior.backward(scale * grad_rows)                  # d loss / d AR parameters
