@@ -22,7 +22,7 @@ SYMBOLS = [
     "bear_count_rows", "bear_parse_counts_tsv", "bear_log_gamma_f64", "bear_logdir_sample_f64",
     "bear_stat_source", "bear_cache_write", "bear_cache_info", "bear_cache_read", "bear_shuffle_rows", "bear_shuffle_source_row",
     "bear_stream_read", "bear_encode_kmers_i8", "bear_cnn_param_count", "bear_cnn_forward_f64", "bear_cnn_backward_f64",
-    "bear_kmer_sort_create", "bear_kmer_sort_reduce", "bear_kmer_sort_destroy", "bear_count_last_hip_error", "bear_write_counts_tsv",
+    "bear_kmer_sort_create", "bear_kmer_sort_reduce", "bear_kmer_sort_destroy", "bear_count_last_hip_error", "bear_write_counts_tsv", "bear_fastx_size", "bear_fastx_encode",
 ]
 
 
@@ -89,6 +89,8 @@ def _load():
     L.bear_write_counts_tsv.argtypes = [ctypes.c_char_p, vp, vp, u64, cint, cint, u64, u64, cint]
     L.bear_stream_read.argtypes = [vp, vp, u64, vp]
     L.bear_encode_kmers_i8.argtypes = [vp, u64, cint, cint, vp, vp]
+    L.bear_fastx_size.argtypes = [ctypes.c_char_p, cint, cint, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.bear_fastx_encode.argtypes = [ctypes.c_char_p, cint, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
     L.bear_count_rows.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]
     L.bear_parse_counts_tsv.argtypes = [ctypes.c_char_p, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
     for name in SYMBOLS:

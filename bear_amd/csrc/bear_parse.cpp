@@ -354,3 +354,122 @@ extern "C" int bear_write_counts_tsv(const char *path, const char *kmers, const 
   ok = (fclose(fh) == 0) && ok;
   return ok ? BEAR_OK : BEAR_ERR_IO;
 }
+
+// ------------------------------------------------------------------ FASTA / FASTQ -> device code text (summarize path)
+// Replaces summarize.py's stage 1 readers (Biopython SimpleFastaParser / FastqGeneralIterator, summarize.py:96-100) for
+// the device pipeline: per sequence  5 (start marker), letters A,C,G,T -> 0..3 (any other character 6), 4 (stop); with
+// `reverse` every sequence is followed by its reverse complement (summarize.py:202-207).  Two calls: size, then fill.
+namespace {
+inline uint8_t letter_code(unsigned char ch) {
+  switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 6;
+  }
+}
+
+// Calls emit(begin, end) for every sequence line-segment and flush() at the end of each record.
+template <class Seg, class End>
+int walk_fastx(const mapped_file &f, int fastq, Seg seg, End end_record) {
+  const char *p = f.data, *end = f.data + f.size;
+  auto next_line = [&](const char *&b, const char *&e) {
+    if (p >= end) return false;
+    const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+    b = p;
+    e = nl ? nl : end;
+    p = e + 1;
+    if (e > b && e[-1] == '\r') --e;
+    return true;
+  };
+  const char *b, *e;
+  if (fastq) {
+    while (next_line(b, e)) {
+      if (b == e) continue;
+      if (*b != '@') return BEAR_ERR_PARSE;
+      if (!next_line(b, e)) return BEAR_ERR_PARSE;
+      seg(b, e);
+      end_record();
+      const char *b2, *e2;
+      if (!next_line(b2, e2) || b2 == e2 || *b2 != '+') return BEAR_ERR_PARSE;
+      if (!next_line(b2, e2)) return BEAR_ERR_PARSE;
+    }
+  } else {
+    bool open = false;
+    while (next_line(b, e)) {
+      if (b < e && *b == '>') {
+        if (open) end_record();
+        open = true;
+      } else if (open) {
+        while (b < e && (*b == ' ' || *b == '\t')) ++b;
+        while (e > b && (e[-1] == ' ' || e[-1] == '\t')) --e;
+        seg(b, e);
+      }
+    }
+    if (open) end_record();
+  }
+  return BEAR_OK;
+}
+}  // namespace
+
+extern "C" int bear_fastx_size(const char *path, int fastq, int reverse, uint64_t *n_pos_out, uint64_t *n_seqs_out) {
+  if (!path || !n_pos_out) return BEAR_ERR_INVALID_ARG;
+  mapped_file f;
+  int st = f.open_ro(path);
+  if (st != BEAR_OK) return st;
+  uint64_t letters = 0, seqs = 0;
+  st = walk_fastx(f, fastq, [&](const char *b, const char *e) { letters += (uint64_t)(e - b); }, [&] { ++seqs; });
+  if (st != BEAR_OK) return st;
+  const uint64_t mult = reverse ? 2 : 1;
+  *n_pos_out = mult * (letters + 2 * seqs);
+  if (n_seqs_out) *n_seqs_out = mult * seqs;
+  return BEAR_OK;
+}
+
+extern "C" int bear_fastx_encode(const char *path, int fastq, int reverse, int group, uint64_t capacity, uint8_t *text,
+                                 uint8_t *group_out, uint64_t *n_pos_out) {
+  if (!path || !text || !n_pos_out || group < 0 || group > 254) return BEAR_ERR_INVALID_ARG;
+  mapped_file f;
+  int st = f.open_ro(path);
+  if (st != BEAR_OK) return st;
+  uint64_t pos = 0, start = 0;
+  bool overflow = false, in_seq = false;
+  auto put = [&](uint8_t v) {
+    if (pos < capacity) text[pos] = v;
+    else overflow = true;
+    ++pos;
+  };
+  st = walk_fastx(
+      f, fastq,
+      [&](const char *b, const char *e) {
+        if (!in_seq) {
+          start = pos;
+          put(5);
+          in_seq = true;
+        }
+        for (const char *q = b; q < e; ++q) put(letter_code((unsigned char)*q));
+      },
+      [&] {
+        if (!in_seq) {   // empty record: start + stop
+          start = pos;
+          put(5);
+        }
+        put(4);
+        in_seq = false;
+        if (reverse && !overflow) {
+          const uint64_t first = start + 1, last = pos - 1;   // letters in [first, last)
+          put(5);
+          for (uint64_t q = last; q > first; --q) {
+            const uint8_t c = text[q - 1];
+            put(c < 4 ? (uint8_t)(3 - c) : c);
+          }
+          put(4);
+        }
+      });
+  if (st != BEAR_OK) return st;
+  if (overflow) return BEAR_ERR_INVALID_ARG;
+  if (group_out) memset(group_out, group, (size_t)pos);
+  *n_pos_out = pos;
+  return BEAR_OK;
+}

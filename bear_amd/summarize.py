@@ -127,11 +127,32 @@ def _load_sequences(seq_list_file):
     return seqs, groups
 
 
+def load_text(seq_list_file, reverse=False):
+    """Every file of the list as the device code text (C++ readers, ``bear_fastx_encode``): ``(text, group, n_groups)``."""
+    L = _lib.lib()
+    parts, gparts, groups = [], [], []
+    for path, group, ftype in read_file_list(seq_list_file):
+        if ftype not in ("fa", "fq"):
+            raise ValueError("file type must be 'fa' or 'fq'")
+        n = ctypes.c_uint64()
+        _lib.check(L.bear_fastx_size(path.encode(), int(ftype == "fq"), int(bool(reverse)), ctypes.byref(n), None), "bear_fastx_size")
+        text = np.empty(n.value, dtype=np.uint8)
+        grp = np.empty(n.value, dtype=np.uint8)
+        got = ctypes.c_uint64()
+        _lib.check(L.bear_fastx_encode(path.encode(), int(ftype == "fq"), int(bool(reverse)), int(group), n.value, text.ctypes.data,
+                                       grp.ctypes.data, ctypes.byref(got)), "bear_fastx_encode")
+        assert got.value == n.value
+        parts.append(text)
+        gparts.append(grp)
+        groups.append(group)
+    if not parts:
+        return np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.uint8), 1
+    return np.concatenate(parts), np.concatenate(gparts), max(groups) + 1
+
+
 def count_tables(seq_list_file, max_lag, reverse=False, batch_size=1 << 30, device=None):
     """The tables of every lag 1..max_lag as ``CountDataset`` objects (index L-1), never written as text."""
-    seqs, groups = _load_sequences(seq_list_file)
-    n_groups = max(groups) + 1 if groups else 1
-    text, grp = encode_sequences(seqs, groups, reverse)
+    text, grp, n_groups = load_text(seq_list_file, reverse)
     device = torch.device(device or "cuda")
     t, g = torch.from_numpy(text).to(device), torch.from_numpy(grp).to(device)
     out = []

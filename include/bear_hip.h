@@ -290,7 +290,13 @@ uint64_t bear_shuffle_source_row(uint64_t i, uint64_t n_rows, uint64_t seed);
  *   Rows come out sorted by packed context code; shuffle with bear_shuffle_rows before training.
  * bear_write_counts_tsv [host]: rows row_begin, row_begin + row_step, ... in the summarize.py text format
  *   (summarize.py:429-449), e.g. step = number of output bins.
+ * bear_fastx_size / bear_fastx_encode [host]: a FASTA (fastq == 0) or FASTQ file as that code text (replacing the Biopython
+ *   readers of summarize.py:96-100); reverse != 0 appends every sequence's reverse complement (summarize.py:202-207);
+ *   group_out [nullable] receives `group` at every position.  Size first, then fill (`capacity` positions).
  */
+int bear_fastx_size(const char *path, int fastq, int reverse, uint64_t *n_pos_out, uint64_t *n_seqs_out);
+int bear_fastx_encode(const char *path, int fastq, int reverse, int group, uint64_t capacity, uint8_t *text,
+                      uint8_t *group_out, uint64_t *n_pos_out);
 typedef struct bear_kmer_sort bear_kmer_sort;
 int bear_kmer_sort_create(const uint8_t *text, const uint8_t *group, uint64_t n_pos, int lag, bear_kmer_sort **out,
                           uint64_t *n_rows_out, void *stream);

@@ -58,3 +58,23 @@ def test_table_writer_roundtrip(tmp_path, ysd1):
     # byte-identical to the reference's row format on the first row (summarize.py:429-449)
     first = open(tmp_path / "t_lag_5_file_0.tsv").readline()
     assert first == open(os.path.join(GOLDEN, "ysd1_lag_5_file_0_preshuf.tsv")).readline()
+
+
+def test_cpp_sequence_reader_matches_python_encoding(tmp_path):
+    """bear_fastx_encode against load_input + encode_sequences on the reference's example inputs, multi-line FASTA with
+    CRLF / blank / lower-case / N, empty records, forward and with reverse complements."""
+    from bear_amd import summarize
+    fa = tmp_path / "m.fa"
+    fa.write_bytes(b">a x\r\nACGT\r\nacgn\r\n>b\n\n>c\nTTTT\nGG\n")
+    fq = tmp_path / "m.fq"
+    fq.write_bytes(b"@r1\nACGTA\n+\nFFFFF\n@r2\nNNA\n+r2\nFFF\n")
+    lst = tmp_path / "l.csv"
+    rows = [(str(fa), 2, "fa"), (str(fq), 0, "fq")] + [(os.path.join(SUM, f"infile_{j}.{t}"), g, t)
+                                                         for j, (g, t) in enumerate([(0, "fa"), (0, "fq"), (2, "fq"), (1, "fa"), (1, "fq")])]
+    lst.write_text("".join(f"{p},{g},{t}\n" for p, g, t in rows))
+    for reverse in (False, True):
+        seqs, groups = summarize._load_sequences(str(lst))
+        assert seqs[:3] == ["ACGTacgn", "", "TTTTGG"]
+        want_text, want_grp = summarize.encode_sequences(seqs, groups, reverse)
+        text, grp, n_groups = summarize.load_text(str(lst), reverse)
+        assert n_groups == 3 and np.array_equal(text, want_text) and np.array_equal(grp, want_grp)
