@@ -80,7 +80,7 @@ __device__ __noinline__ int evl_argmax_noisy(const double (&a)[5], double sigma,
       }
     }
   }
-  return i1;
+  return i1 < 0 ? 0 : i1;   // no contender only when the concentrations are NaN: index 0, as argmax of NaNs does
 }
 
 // ------------------------------------------------------------------------------------------------ sorted formulation
