@@ -123,3 +123,34 @@ def test_cnn_full_size_properties():
     assert (full - (parts[0] + parts[1])).abs().max().item() <= 1e-11 * scale
     off = 8 * 5 * 30 + 6 * 30 + 6 * 30 * 16 + 16 + 16 * 5          # intercept2 sits after filters, intercept0, weights1, intercept1, weights2
     assert abs(full[off:off + 5].sum().item()) <= 1e-9 * full[off:off + 5].abs().sum().item()
+
+
+def test_cnn_saturating_parameters():
+    """Large weights: logits far apart (probabilities down to 1e-60), first-layer pre-activations far below zero (elu at
+    its floor): rows still positive, normalised and equal to the oracle's; gradients against torch autograd."""
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(8)
+    lag, fw, n = 13, 8, 600
+    kmers = _random_kmers(n, lag, rng)
+    ar_func, params = _make(lag, fw, dev, 6)
+    with torch.no_grad():
+        params[4].mul_(60.0)          # weights2
+        params[1].sub_(6.0)           # intercept0: most first-layer units saturate at -1
+        params[6].mul_(5.0)           # scale0
+    codes = torch.from_numpy(core.encode_kmers(kmers, "dna")).to(dev)
+    packed = kernels.pack_kmers(codes)
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+    prior, t1 = kernels.cnn_forward(packed, flat, lag, fw)
+    want = o.ar_func_cnn(o.one_hot(kmers, "dna"), [p.detach().cpu().numpy() for p in params])
+    got = prior.cpu().numpy()
+    assert got.min() > 0.0 and want.min() < 1e-20
+    assert np.allclose(np.log(got), np.log(want), rtol=0, atol=1e-10) and np.allclose(got.sum(1), 1.0, rtol=1e-14)
+    grad_rows = torch.from_numpy(rng.standard_normal((n, 5))).to(dev)
+    g = kernels.cnn_backward(packed, flat, lag, fw, t1, prior, grad_rows)
+    rows = ar_func(core.tf_one_hot(kmers, "dna", device=dev))
+    rows.backward(grad_rows)
+    k = 0
+    for p in params:
+        w = p.grad.reshape(-1)
+        assert (g[k:k + w.numel()] - w).abs().max().item() <= 1e-9 * max(w.abs().max().item(), 1e-30), p.shape
+        k += w.numel()

@@ -472,3 +472,22 @@ def test_planned_randomized_shapes(dev):
             assert abs(got[0] - wn[0]) <= ELBO_RTOL * abs(wn[0]) + 1e-300, (it, n, kind)
             assert abs(got[1] - wn[1]) <= GRAD_RTOL * (abs(wn[1]) + abs(wn[0]) * 1e-3 + 1e-300), (it, n, kind)
         assert np.allclose(g.cpu().numpy(), wg, rtol=1e-9, atol=1e-9 * (np.abs(wg).max() + 1e-300)), (it, n, kind)
+
+
+def test_eval_many_models_across_launch_chunks(dev):
+    """20 h values + 5 van_reg values = 25 DM models = four launches of at most 8 models (kernels_eval.h): every slot of the
+    output vector against the oracle, accuracies exactly."""
+    from bear_amd import kernels
+    tr, te, _ = sparse_table(7001, 11)
+    n = len(te)
+    f = prior_rows(n, 12, 0.8)
+    hs, van = np.geomspace(1e-3, 1e2, 20), np.array([0.05, 0.3, 1.0, 4.0, 25.0])
+    want = o.evaluation_step(te, f, hs, van, tr, rng=o.HashNoise(5, 0, n))
+    got = kernels.evaluate(_to_dev(te, dev), _to_dev(f, dev), hs, van, _to_dev(tr, dev), noise_seed=5).cpu().numpy()
+    H, V = 20, 5
+    parts = (got[:H], got[H], got[H + 1:H + 1 + V], got[H + V + 1:2 * H + V + 1], got[2 * H + V + 1],
+             got[2 * H + V + 2:2 * H + 2 * V + 2], got[-1])
+    for k in (0, 1, 2):
+        assert np.allclose(parts[k], want[k], rtol=ELBO_RTOL, atol=0), k
+    for k in (3, 4, 5, 6):
+        assert np.array_equal(np.asarray(parts[k]), np.asarray(want[k])), k
