@@ -59,9 +59,17 @@ def main(config, kind):
     epochs = int(epochs[:-1]) // (1 + num_kmers // kmer_batch_size) + 1 if epochs[-1] == "s" else int(epochs)
     num_ds = int(config["data"]["num_ds"])
     load = dataloader.sparse_dataloader if config["data"]["sparse"] == "True" else dataloader.dataloader
-    parts = [load(f, config["data"]["alphabet"], kmer_batch_size, num_ds, cache=config["train"]["cache"] == "True", dtype=dtype)
-             for f in files]
+    # two optional keys beyond the reference's: [data] binary_cache (True or a directory: parsed tables are kept on disk,
+    # dense format only) and [data] shuffle_seed (rows are permuted on the device at upload instead of `shuf`-ing the file)
+    extra_kw = {}
+    if config["data"].get("binary_cache") and load is dataloader.dataloader:
+        bc = config["data"]["binary_cache"]
+        extra_kw["binary_cache"] = True if bc == "True" else bc
+    parts = [load(f, config["data"]["alphabet"], kmer_batch_size, num_ds, cache=config["train"]["cache"] == "True", dtype=dtype,
+                  **extra_kw) for f in files]
     data = parts[0] if len(parts) == 1 else dataloader.concatenate(parts)
+    if config["data"].get("shuffle_seed"):
+        data = data.shuffle(int(config["data"]["shuffle_seed"]))
     data_train = data.repeat(epochs)
 
     result_file = os.path.join(out_folder, "results.pickle")

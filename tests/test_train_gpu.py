@@ -244,3 +244,26 @@ def test_core_distributions_reference_tests():
     d2 = core.tfpDirichletMultinomialPerm(torch.tensor([1.0], device="cuda"), torch.tensor([1.0, 0.5, 1.0], device="cuda"))
     seen = {int(d2.ml_output().item()) for _ in range(200)}
     assert seen == {0, 2}
+
+
+def test_driver_optional_cache_and_shuffle_keys(tmp_path, ysd1):
+    """[data] binary_cache / shuffle_seed (beyond the reference's keys): the run goes through, a cache file appears, and the
+    table-level BMM results do not depend on the row order."""
+    from bear_amd.models import train_bear_ref
+    import shutil
+    src = tmp_path / "data"
+    src.mkdir()
+    shutil.copy(YSD1, src / "tab_lag_5_file_0.tsv")
+    config = configparser.ConfigParser()
+    config.read(os.path.join(ROOT, "bear_amd", "models", "config_files", "bear_test.cfg"))
+    config["model"]["ar_func_name"] = "stop"
+    config["general"]["out_folder"] = str(tmp_path / "out") + "*"
+    config["data"]["files_path"] = str(src)
+    config["data"]["start_token"] = "tab_lag_5"
+    config["data"]["binary_cache"] = str(tmp_path / "cache")
+    config["data"]["shuffle_seed"] = "7"
+    exit_code, ll_van, _ = train_bear_ref.main(config)
+    assert exit_code == 1 and os.path.exists(tmp_path / "cache" / "tab_lag_5_file_0.tsv.bearcache")
+    assert np.allclose(ll_van, [-152712571.34208858, -152709051.39618373, -152745386.28243095], rtol=1e-12)
+    exit_code, ll_van2, _ = train_bear_ref.main(config)          # second run: served from the cache
+    assert np.allclose(ll_van2, ll_van, rtol=1e-13)
