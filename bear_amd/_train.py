@@ -66,18 +66,26 @@ class ResidentBatches:
         self.batches = []
         # k-mer letter codes: the ASCII bytes go up as they were parsed and are encoded on the device
         fast_codes = want_codes and data.alphabet in ("dna", "rna") and data.lag > 0
+        on_dev = getattr(data, "counts_dev", None) is not None       # DeviceCountDataset: the table is in HBM already
         codes = data.codes() if (want_codes and not fast_codes) else None
+
+        def device_column(col, lo, hi):
+            if on_dev:
+                return data.counts_dev[col, lo:hi].to(device).contiguous().clone()
+            return torch.from_numpy(np.ascontiguousarray(data.counts[col, lo:hi]).view(np.int32)).to(device)
 
         def device_codes(lo, hi):
             if fast_codes:
-                return kernels.encode_kmers(torch.from_numpy(np.ascontiguousarray(data.kmers[lo:hi])).to(device), data.alphabet)
+                km = data.kmers_dev[lo:hi].to(device).contiguous() if on_dev else \
+                    torch.from_numpy(np.ascontiguousarray(data.kmers[lo:hi])).to(device)
+                return kernels.encode_kmers(km, data.alphabet)
             return torch.from_numpy(np.ascontiguousarray(codes[lo:hi])).to(device)
         shuffled = {}
         if data.shuffle_seed is not None and data.num_rows:
             # whole columns go up once, are permuted by one gather pass each (same seed: columns stay aligned), and the
             # batches below are slices of the permuted slabs
             for name, col in columns.items():
-                up = torch.from_numpy(np.ascontiguousarray(data.counts[col]).view(np.int32)).to(device)
+                up = device_column(col, 0, data.num_rows)
                 shuffled[name] = kernels.shuffle_rows(up, data.shuffle_seed)
                 del up
             if want_codes:
@@ -90,7 +98,7 @@ class ResidentBatches:
                 if shuffled:
                     entry[name] = shuffled[name][lo:hi].clone()
                 else:
-                    entry[name] = torch.from_numpy(np.ascontiguousarray(data.counts[col, lo:hi]).view(np.int32)).to(device)
+                    entry[name] = device_column(col, lo, hi)
             if want_codes:
                 entry["codes"] = shuffled["codes"][lo:hi].clone() if shuffled else device_codes(lo, hi)
             entry["plans"] = {}

@@ -85,6 +85,41 @@ class CountDataset:
         return t
 
 
+class DeviceCountDataset(CountDataset):
+    """A count table that already lives in HBM (e.g. built by ``bear_amd.summarize`` on the device): ``kmers_dev`` uint8
+    [N, lag] and ``counts_dev`` int32-storage uint32 [num_ds, N, 5].  Training and evaluation use the device tensors
+    directly (no upload); the host views ``kmers`` / ``counts`` are downloaded on first use."""
+
+    def __init__(self, kmers_dev, counts_dev, alphabet, batch_size, dtype=torch.float64, repeats=1, shuffle_seed=None):
+        self.kmers_dev, self.counts_dev = kmers_dev.contiguous(), counts_dev.contiguous()
+        self._host = None
+        self.shuffle_seed = shuffle_seed
+        self.alphabet, self.batch_size, self.dtype, self.repeats = alphabet, int(batch_size), dtype, int(repeats)
+        self._device_cache = {}
+
+    def _download(self):
+        if self._host is None:
+            self._host = (self.kmers_dev.cpu().numpy(), self.counts_dev.cpu().numpy().view(np.uint32))
+        return self._host
+
+    kmers = property(lambda self: self._download()[0])
+    counts = property(lambda self: self._download()[1])
+    num_rows = property(lambda self: self.counts_dev.shape[1])
+    num_ds = property(lambda self: self.counts_dev.shape[0])
+    lag = property(lambda self: self.kmers_dev.shape[1])
+
+    def repeat(self, epochs):
+        return DeviceCountDataset(self.kmers_dev, self.counts_dev, self.alphabet, self.batch_size, self.dtype,
+                                  self.repeats * int(epochs), self.shuffle_seed)
+
+    def shuffle(self, seed):
+        return DeviceCountDataset(self.kmers_dev, self.counts_dev, self.alphabet, self.batch_size, self.dtype, self.repeats, int(seed))
+
+    def device_column(self, ds_loc, device, rows=None):
+        a, b = rows if rows is not None else (0, self.num_rows)
+        return self.counts_dev[ds_loc, a:b].to(device)
+
+
 def concatenate(datasets):
     """Several count files of one table (models/train_bear_net.py:79-87 interleaves them; rows are
     independent and pre-shuffled, so concatenation is an equivalent batch stream)."""

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .dataloader import CountDataset
+from .dataloader import CountDataset, DeviceCountDataset
 
 alphabet = {"A": 0, "C": 1, "G": 2, "T": 3, "]": 4}     # summarize.py:380
 
@@ -89,9 +89,10 @@ def encode_sequences(seqs, groups, reverse=False):
     return np.concatenate(parts), np.concatenate(gparts)
 
 
-def count_transitions(text, group, lag, n_groups, device=None):
+def count_transitions(text, group, lag, n_groups, device=None, on_device=False):
     """One lag on the device.  text / group: uint8 arrays or CUDA tensors.  Returns
-    ``(kmers uint8 [n_rows, lag] ASCII, counts uint32 [n_groups, n_rows, 5])`` as numpy arrays."""
+    ``(kmers uint8 [n_rows, lag] ASCII, counts uint32 [n_groups, n_rows, 5])`` as numpy arrays, or with ``on_device`` as
+    CUDA tensors (counts in int32 storage)."""
     if not torch.cuda.is_available():
         raise RuntimeError("bear_amd counts on an MI355X only (libbear_hip.so has no CPU fallback)")
     device = torch.device(device or "cuda")
@@ -114,6 +115,8 @@ def count_transitions(text, group, lag, n_groups, device=None):
             torch.cuda.current_stream().synchronize()
         finally:
             L.bear_kmer_sort_destroy(h)
+    if on_device:
+        return kmers, counts
     return kmers.cpu().numpy(), counts.cpu().numpy().view(np.uint32)
 
 
@@ -150,15 +153,16 @@ def load_text(seq_list_file, reverse=False):
     return np.concatenate(parts), np.concatenate(gparts), max(groups) + 1
 
 
-def count_tables(seq_list_file, max_lag, reverse=False, batch_size=1 << 30, device=None):
-    """The tables of every lag 1..max_lag as ``CountDataset`` objects (index L-1), never written as text."""
+def count_tables(seq_list_file, max_lag, reverse=False, batch_size=1 << 30, device=None, on_device=False):
+    """The tables of every lag 1..max_lag as ``CountDataset`` objects (index L-1), never written as text; with
+    ``on_device`` as ``DeviceCountDataset`` objects that never leave HBM (count -> shuffle -> plan -> train)."""
     text, grp, n_groups = load_text(seq_list_file, reverse)
     device = torch.device(device or "cuda")
     t, g = torch.from_numpy(text).to(device), torch.from_numpy(grp).to(device)
     out = []
     for lag in range(1, max_lag + 1):
-        kmers, counts = count_transitions(t, g, lag, n_groups)
-        out.append(CountDataset(kmers, counts, "dna", batch_size))
+        kmers, counts = count_transitions(t, g, lag, n_groups, on_device=on_device)
+        out.append(DeviceCountDataset(kmers, counts, "dna", batch_size) if on_device else CountDataset(kmers, counts, "dna", batch_size))
     return out
 
 
