@@ -15,3 +15,7 @@ torch.cuda.synchronize(); t = time.time()
 kmers, counts = summarize.count_transitions(text, grp, lag, 1)
 dt = time.time() - t
 print("lag %d: %d positions -> %d rows in %.3f s (%.2e transitions/s incl. download of the table)" % (lag, text.numel(), kmers.shape[0], dt, text.numel() / dt))
+torch.cuda.synchronize(); t = time.time()
+kd, cd = summarize.count_transitions(text, grp, lag, 1, on_device=True)
+torch.cuda.synchronize(); dt = time.time() - t
+print("      on the device only: %.3f s (%.2e transitions/s)" % (dt, text.numel() / dt))
