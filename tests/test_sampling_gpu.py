@@ -227,3 +227,43 @@ def test_get_bear_probs_through_the_sequence_counter(dev):
     m = get_var_probs.get_bear_probs_seqs(None, seqs, 0, counter=counter, mc_samples=20000, seed=4, **kw)
     n = get_var_probs.get_bear_probs_seqs(None, seqs, 0, data=_data(), mc_samples=20000, seed=5, **kw)
     assert np.all(np.abs((m.mean(-1) - n.mean(-1)) / n.mean(-1)) < 0.01)
+
+
+def test_trained_model_folder_restart_and_variant_scores(dev, tmp_path):
+    """The reference's workflow across modules: train_bear_net writes config.cfg + results.pickle (models/train_bear_net.py:
+    142-149), a second run restarts from them (:113-118), get_var_probs.load_bear reads the folder (get_var_probs.py:58-82)
+    and get_bear_probs scores variants with the BEAR model next to the BMMs (MAP: closed form)."""
+    import configparser
+    from conftest import ROOT
+    from bear_amd import get_var_probs
+    from bear_amd.models import train_bear_net
+    config = configparser.ConfigParser()
+    config.read(os.path.join(ROOT, "bear_amd", "models", "config_files", "bear_lin_bear.cfg"))
+    config["train"]["epochs"] = "30"
+    config["train"]["batch_size"] = "1500"
+    config["general"]["out_folder"] = str(tmp_path / "m1") + "*"
+    config["test"]["test"] = "False"
+    config["test"]["train_test"] = "False"
+    assert train_bear_net.main(config) == 1
+    h1 = float(config["results"]["h"])
+    # restart from the saved parameters: h continues from where the first run stopped
+    config2 = configparser.ConfigParser()
+    config2.read(str(tmp_path / "m1" / "config.cfg"))
+    config2["general"]["out_folder"] = str(tmp_path / "m2") + "*"
+    config2["train"]["restart"] = "True"
+    config2["train"]["restart_path"] = str(tmp_path / "m1")
+    config2["train"]["epochs"] = "1"
+    assert train_bear_net.main(config2) == 1
+    assert abs(np.log(float(config2["results"]["h"])) - np.log(h1)) < 0.05
+    # variant scores from the trained folder
+    lag, alphabet, h, ar_func, data = get_var_probs.load_bear(str(tmp_path / "m1"))
+    assert lag == 5 and alphabet == "dna" and np.isclose(h, h1) and data.num_rows == 1365
+    wt = "ACGTACGTTAGC"
+    vars_ = np.array(["G2T", "T7A"])
+    vans = np.array([1.0])
+    s_map = get_var_probs.get_bear_probs(str(tmp_path / "m1"), wt, vars_, 0, get_map=True, vans=vans)
+    assert s_map.shape == (2, 3) and np.all(np.isfinite(s_map))            # models: AR (MAP only), BEAR h, BMM
+    s_mc = get_var_probs.get_bear_probs(str(tmp_path / "m1"), wt, vars_, 0, mc_samples=4000, vans=vans, seed=2)
+    assert s_mc.shape == (2, 2, 4000) and np.all(np.isfinite(s_mc))
+    # with lots of data per k-mer (lag 5, 1e8 transitions) posterior samples concentrate on the MAP values
+    assert np.all(np.abs(s_mc.mean(-1) - s_map[:, 1:]) < 0.02 * np.abs(s_map[:, 1:]) + 0.02)
