@@ -59,6 +59,11 @@ class CountDataset:
                 km = np.array([bytes(r) for r in self.kmers[a:b]])
                 yield km, torch.from_numpy(self.counts[:, a:b].transpose(1, 0, 2).astype(np_dtype))
 
+    def map(self, fn):
+        """tf.data ``.map(fn)`` as the reference's callers use it (``data.map(lambda kmers, counts: counts)`` in front of
+        ``bmm_likelihood``, tests/test_dataloader.py:48): a lazily mapped view that remembers its source table."""
+        return MappedDataset(self, fn)
+
     def repeat(self, epochs):
         """tf.data ``.repeat(epochs)`` (models/train_bear_net.py:88)."""
         return CountDataset(self.kmers, self.counts, self.alphabet, self.batch_size, self.dtype, self.repeats * int(epochs),
@@ -83,6 +88,17 @@ class CountDataset:
             t = torch.from_numpy(np.ascontiguousarray(self.counts[ds_loc, a:b]).view(np.int32)).to(device)
             self._device_cache[key] = t
         return t
+
+
+class MappedDataset:
+    """``CountDataset.map(fn)``: iterating yields ``fn(kmers, counts)`` per batch; ``source`` is the table."""
+
+    def __init__(self, source, fn):
+        self.source, self.fn = source, fn
+
+    def __iter__(self):
+        for kmers, counts in self.source:
+            yield self.fn(kmers, counts)
 
 
 class DeviceCountDataset(CountDataset):
@@ -226,8 +242,10 @@ def bmm_likelihood(data, alpha, dtype=torch.float64, device=None):
     """dataloader.py:120-147: BMM marginal ``sum_i lbeta(c_i + alpha) - lbeta(alpha)`` for every dataset
     column and every alpha -> [num_ds, len(alpha)].  One launch of ``bear_bmm_f64`` per column (all alphas
     in a single pass over the rows)."""
+    if isinstance(data, MappedDataset):      # the reference passes data.map(lambda kmers, counts: counts)
+        data = data.source
     if not isinstance(data, CountDataset):
-        raise TypeError("bmm_likelihood expects the CountDataset returned by dataloader()")
+        raise TypeError("bmm_likelihood expects the CountDataset returned by dataloader() (or its .map(...) view)")
     device = torch.device(device or "cuda")
     alpha = np.atleast_1d(np.asarray(alpha, dtype=np.float64))
     out = torch.zeros((data.num_ds, len(alpha)), dtype=torch.float64)

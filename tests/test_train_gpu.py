@@ -222,6 +222,11 @@ def test_bmm_likelihood_reference_test(ysd1):
                        - (np.sum(loggamma(0 * counts[:, :, None, :] + alpha[:, None]), axis=-1)
                           - loggamma(np.sum(0 * counts[:, :, None, :] + alpha[:, None], axis=-1))), axis=0)
     assert np.allclose(true_liks, dataloader.bmm_likelihood(data, alpha).numpy(), rtol=1e-12)
+    # exactly as the reference test calls it (test_dataloader.py:48)
+    calc_liks = dataloader.bmm_likelihood(data.map(lambda kmers, counts: counts), alpha)
+    assert np.allclose(true_liks, calc_liks.numpy(), rtol=1e-12)
+    first = next(iter(data.map(lambda kmers, counts: counts)))
+    assert tuple(first.shape) == (1365, 3, 5)
 
 
 def test_core_distributions_reference_tests():
