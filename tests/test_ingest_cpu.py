@@ -96,3 +96,27 @@ def test_threaded_parser_matches_single_thread(tmp_path):
         with pytest.raises(_lib.BearError):
             dataloader.dataloader(str(path), "dna", 1000, 2)
     os.environ.pop("BEAR_PARSE_THREADS")
+
+
+def test_parser_fuzz_against_oracle(tmp_path):
+    """Seeded random tables in the summarize.py row format, with the separators the reference's json.loads accepts
+    (spaces after commas): the C++ reader and the oracle's parser agree on every one."""
+    from bear_amd import dataloader
+    rng = np.random.default_rng(11)
+    for trial in range(20):
+        n, lag, num_ds = int(rng.integers(1, 40)), int(rng.integers(1, 9)), int(rng.integers(1, 4))
+        kmers = ["".join(rng.choice(list("ACGT["), size=lag)) for _ in range(n)]
+        counts = rng.integers(0, 10 ** rng.integers(1, 10), size=(n, num_ds, 5))
+        sep = ", " if trial % 2 else ","
+        path = tmp_path / f"t{trial}.tsv"
+        with open(path, "w") as fh:
+            for k, rows in zip(kmers, counts):
+                fh.write(k + "\t[[" + "],[".join(sep.join(str(int(v)) for v in g) for g in rows) + "]]\n")
+                if trial % 5 == 0:
+                    fh.write("\n")
+        want_k, want_c = o.parse_counts_tsv(str(path), num_ds)
+        d = dataloader.dataloader(str(path), "dna", 7, num_ds)
+        assert [bytes(r).decode() for r in d.kmers] == list(want_k)
+        assert np.array_equal(d.counts.transpose(1, 0, 2), want_c.astype(np.uint32))
+        batches = list(d)
+        assert sum(len(b[0]) for b in batches) == n and batches[0][1].shape[1:] == (num_ds, 5)

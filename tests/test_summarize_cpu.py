@@ -78,3 +78,24 @@ def test_cpp_sequence_reader_matches_python_encoding(tmp_path):
         want_text, want_grp = summarize.encode_sequences(seqs, groups, reverse)
         text, grp, n_groups = summarize.load_text(str(lst), reverse)
         assert n_groups == 3 and np.array_equal(text, want_text) and np.array_equal(grp, want_grp)
+
+
+def test_sequence_reader_errors(tmp_path):
+    import ctypes
+    from bear_amd import _lib
+    L = _lib.lib()
+    n = ctypes.c_uint64()
+    bad = tmp_path / "bad.fq"
+    bad.write_text("@r1\nACGT\nFFFF\n")                      # separator line missing
+    assert L.bear_fastx_size(str(bad).encode(), 1, 0, ctypes.byref(n), None) == -7
+    assert L.bear_fastx_size(str(tmp_path / "missing.fa").encode(), 0, 0, ctypes.byref(n), None) == -6
+    ok = tmp_path / "ok.fa"
+    ok.write_text(">a\nACGT\n")
+    assert L.bear_fastx_size(str(ok).encode(), 0, 1, ctypes.byref(n), None) == 0 and n.value == 12
+    text = np.zeros(6, dtype=np.uint8)
+    got = ctypes.c_uint64()
+    assert L.bear_fastx_encode(str(ok).encode(), 0, 1, 0, 6, text.ctypes.data, None, ctypes.byref(got)) == -1   # capacity too small
+    text = np.zeros(12, dtype=np.uint8)
+    assert L.bear_fastx_encode(str(ok).encode(), 0, 1, 300, 12, text.ctypes.data, None, ctypes.byref(got)) == -1  # group id out of range
+    assert L.bear_fastx_encode(str(ok).encode(), 0, 1, 3, 12, text.ctypes.data, None, ctypes.byref(got)) == 0
+    assert text.tolist() == [5, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4]                                                   # ACGT is its own reverse complement
