@@ -24,6 +24,7 @@ static thread_local int g_last_hip_error = 0;
     }                                      \
   } while (0)
 
+struct bear_params;
 struct bear_ws {
   int device;
   int num_cu;
@@ -35,6 +36,7 @@ struct bear_ws {
   double *eval_out;         // [EVL_MAX_OUT] scratch result vector (bear_bmm_f64)
   int eval_blocks;
   double *lin_partials;     // [num_cu][LIN_MAX_GRAD] d/d mat partials (kernels_linear.h)
+  struct bear_params *ref_prm;     // device copy of the mode-R constants (bear_ref_train_step_f64: graph replay)
   double *cnn_partials;     // [cnn_blocks][cnn total] parameter-gradient partials (kernels_cnn.h), grown on demand
   size_t cnn_partials_cap;  // doubles
 };

@@ -74,6 +74,7 @@ int bear_ws_create(int device, bear_ws **out) {
       if (e == hipSuccess) e = hipMalloc(&ws->eval_partials, sizeof(double) * EVL_MAX_OUT * (size_t)ws->eval_blocks);
       if (e == hipSuccess) e = hipMalloc(&ws->eval_out, sizeof(double) * EVL_MAX_OUT);
       if (e == hipSuccess) e = hipMalloc(&ws->lin_partials, sizeof(double) * LIN_MAX_GRAD * (size_t)ws->num_cu);
+      if (e == hipSuccess) e = hipMalloc(&ws->ref_prm, sizeof(bear_params));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_linear_plan_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_lin));
@@ -153,6 +154,7 @@ int bear_ws_destroy(bear_ws *ws) {
   (void)hipFree(ws->eval_out);
   (void)hipFree(ws->lin_partials);
   if (ws->cnn_partials) (void)hipFree(ws->cnn_partials);
+  if (ws->ref_prm) (void)hipFree(ws->ref_prm);
   (void)hipSetDevice(prev);
   delete ws;
   return BEAR_OK;
@@ -533,12 +535,39 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
   const int grid = grid_plan(ws, plan->n_tiles);
   if (train_ar)
     hipLaunchKernelGGL(dm_ref_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan),
-                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
+                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials, static_cast<const bear_params *>(nullptr));
   else
     hipLaunchKernelGGL(dm_ref_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan),
-                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials);
+                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials, static_cast<const bear_params *>(nullptr));
   HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 4, out);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
+                            double *theta, double *adam_m, double *adam_v, double *adam_t, double eps, int train_ar,
+                            double learning_rate, double scale, double *out, double *loss_buf, uint64_t loss_cap, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!plan || !out || !theta || !adam_m || !adam_v || !adam_t || !n_rows || !train || !ref) return BEAR_ERR_INVALID_ARG;
+  if (plan->ncol != 4 || plan->n_rows != n_rows || plan->counts != train || plan->device != ws->device)
+    return BEAR_ERR_INVALID_ARG;
+  if (misaligned(ref) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bear_params dummy;
+  memset(&dummy, 0, sizeof(dummy));
+  const int grid = grid_plan(ws, plan->n_tiles);
+  hipLaunchKernelGGL(ref_params_kernel, dim3(1), dim3(64), 0, s, theta, eps, ws->ref_prm);
+  if (train_ar)
+    hipLaunchKernelGGL(dm_ref_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, dummy, plan_view(plan),
+                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials, static_cast<const bear_params *>(ws->ref_prm));
+  else
+    hipLaunchKernelGGL(dm_ref_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, dummy, plan_view(plan),
+                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials, static_cast<const bear_params *>(ws->ref_prm));
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 4, out);
+  hipLaunchKernelGGL(adam_ref_kernel, dim3(1), dim3(64), 0, s, theta, out, adam_m, adam_v, adam_t, learning_rate, scale, train_ar,
+                     loss_buf, (unsigned long long)loss_cap);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }

@@ -666,12 +666,15 @@ struct pln_lds_r {
 // AR: multinomial mode of bear_ref (train_ar): sum LL = sum c log(f + eps); gradients w.r.t. tau_s, nu_s only.
 template <bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel(const uint32_t *__restrict__ ref,
-                                                                                  uint64_t n_rows, bear_params prm,
+                                                                                  uint64_t n_rows, bear_params prm_arg,
                                                                                   pln_view pv,
                                                                                   const double2 *__restrict__ logtab_g,
-                                                                                  double *__restrict__ partials) {
+                                                                                  double *__restrict__ partials,
+                                                                                  const bear_params *__restrict__ prm_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_r &S = *reinterpret_cast<pln_lds_r *>(srt_smem);
+  // parameters by value, or -- for a step that is replayed from a HIP graph while the optimizer moves them -- from device memory
+  const bear_params prm = prm_dev ? *prm_dev : prm_arg;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps;
   const double A = u + 5.0 * eps;              // sum_b alpha_b
@@ -1072,4 +1075,46 @@ __global__ __launch_bounds__(256) void dm_prior_grad_fixup_kernel(const double *
     const bear_dp o = srt_general_fast(A, h.n, logtab);
     for (int b = 0; b < 5; ++b) atomicAdd(&grad_out[h.row * 5 + b], -u * o.P);
   }
+}
+
+
+// ---- the bear_ref optimizer step on the device (HIP-graph replay) ---------------------------------------------
+// theta = (h_signed, tau_signed, net_weight_signed).  ref_params_kernel derives the kernel constants from theta (what
+// bear_dm_ref_plan_f64 does on the host); adam_ref_kernel applies tf.keras.optimizers.Adam's update (defaults beta 0.9 /
+// 0.999, epsilon 1e-7; bear_model/bear_ref.py:312-313, 346-350) to the gradients the DM kernel left in out[1..3].
+__global__ void ref_params_kernel(const double *__restrict__ theta, double eps, bear_params *__restrict__ prm) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double tau = exp(theta[1]), nw = exp(theta[2]);
+  bear_params p;
+  p.inv_h = 1.0 / exp(theta[0]);
+  p.eps = eps;
+  p.E = exp(-tau);
+  p.tauE = tau * p.E;
+  p.tau = tau;
+  p.V = 1.0 / (nw + 1.0);
+  p.nw = nw;
+  *prm = p;
+}
+
+__global__ void adam_ref_kernel(double *__restrict__ theta, const double *__restrict__ out4, double *__restrict__ m,
+                                double *__restrict__ v, double *__restrict__ t_state, double lr, double scale, int train_ar,
+                                double *__restrict__ loss_buf, unsigned long long loss_cap) {
+  if (blockIdx.x != 0 || threadIdx.x >= 3) return;
+  const int k = threadIdx.x;
+  const double t = t_state[0] + 1.0;
+  const double b1 = 0.9, b2 = 0.999, aeps = 1e-7;
+  const double lr_t = lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
+  if (!(train_ar && k == 0)) {      // AR mode: h_signed gets no gradient (bear_ref.py:256-258)
+    const double g = scale * out4[1 + k];
+    const double mk = b1 * m[k] + (1.0 - b1) * g, vk = b2 * v[k] + (1.0 - b2) * g * g;
+    m[k] = mk;
+    v[k] = vk;
+    theta[k] -= lr_t * mk / (sqrt(vk) + aeps);
+  }
+  if (k == 0) {
+    const unsigned long long step = (unsigned long long)t_state[0];
+    if (loss_buf && step < loss_cap) loss_buf[step] = -scale * out4[0];
+  }
+  __syncthreads();
+  if (k == 0) t_state[0] = t;
 }

@@ -409,3 +409,21 @@ def encode_kmers(ascii_kmers, alphabet="dna"):
                                              _ptr(codes), _stream())
     _lib.check(st, "bear_encode_kmers_i8")
     return codes
+
+
+def ref_train_step(plan, ref, theta, adam_m, adam_v, adam_t, learning_rate, scale, out, loss_buf=None, eps=EPSILON, train_ar=False):
+    """Enqueues one ``bear_ref_train_step_f64`` (constants from theta, planned mode-R kernel, finalize, Adam on theta): no host
+    synchronisation, every argument device-resident -- capturable in a HIP graph (``torch.cuda.graph``)."""
+    train = plan.counts
+    _check_rows(ref, torch.int32, "ref")
+    for t, n in ((theta, 3), (adam_m, 3), (adam_v, 3), (adam_t, 1), (out, 4)):
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == n):
+            raise ValueError("theta / adam_m / adam_v [3], adam_t [1], out [4] must be contiguous CUDA float64 tensors")
+    if ref.data_ptr() % 16 or ref.shape[0] != train.shape[0] or plan.ncol != 4:
+        raise ValueError("ref must be 16-byte aligned with one row per planned context (plan ncol=4)")
+    with torch.cuda.device(train.device):
+        st = _lib.lib().bear_ref_train_step_f64(plan.ws.handle, plan._h, _ptr(train), _ptr(ref), train.shape[0], _ptr(theta), _ptr(adam_m),
+                                                _ptr(adam_v), _ptr(adam_t), float(eps), int(bool(train_ar)), float(learning_rate),
+                                                float(scale), _ptr(out), _ptr(loss_buf), 0 if loss_buf is None else loss_buf.numel(),
+                                                _stream())
+    _lib.check(st, "bear_ref_train_step_f64")

@@ -122,6 +122,21 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
                          int train_ar, double *out, void *stream);
 
 /*
+ * One bear_ref optimizer step with every moving quantity in device memory, so that the step can be captured in a HIP graph
+ * and replayed (the reference traces its step once with tf.function and re-runs the graph, bear_model/bear_ref.py:207;
+ * launch-bound on small tables: the bundled example is 10 000 steps over 1365 contexts).  Enqueues, without any host
+ * synchronisation: constants from theta -> the planned mode-R kernel -> finalize -> tf.keras Adam (beta 0.9 / 0.999,
+ * epsilon 1e-7; bear_ref.py:312-313, 346-350) on theta.
+ *   theta   [dev] double [3]  {h_signed, tau_signed, net_weight_signed}, updated in place
+ *   adam_m, adam_v [dev] double [3], adam_t [dev] double [1]  optimizer state (zero before the first step)
+ *   scale   the loss scale -(num_kmers / batch) (bear_ref.py:252-253);  out [dev] double [4] as bear_dm_ref_plan_f64
+ *   loss_buf [dev, nullable] double [loss_cap]: loss_buf[step] = -scale * sum LL  (the "elbo" the reference logs)
+ */
+int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
+                            double *theta, double *adam_m, double *adam_v, double *adam_t, double eps, int train_ar,
+                            double learning_rate, double scale, double *out, double *loss_buf, uint64_t loss_cap, void *stream);
+
+/*
  * The whole bear_net training step for the linear AR function, fused on a plan: replaces
  * ar_func = make_ar_func_linear(...) (bear_model/ar_funcs.py:23-46), _train_step's forward and
  * grad_tape.gradient(loss, [h_signed, mat]) (bear_model/bear_net.py:146-197).

@@ -272,3 +272,38 @@ def test_driver_optional_cache_and_shuffle_keys(tmp_path, ysd1):
     assert np.allclose(ll_van, [-152712571.34208858, -152709051.39618373, -152745386.28243095], rtol=1e-12)
     exit_code, ll_van2, _ = train_bear_ref.main(config)          # second run: served from the cache
     assert np.allclose(ll_van2, ll_van, rtol=1e-13)
+
+
+@pytest.mark.parametrize("train_ar", [False, True])
+def test_bear_ref_graph_replay_matches_oracle_loop(train_ar, ysd1):
+    """One resident batch: bear_ref.train replays the captured step (bear_ref_train_step_f64 in a HIP graph) -- losses and
+    parameters against the oracle loop, and against the eager path of the same build."""
+    _, counts = ysd1
+    data = dataloader.dataloader(YSD1, "dna", 1500, 3)           # one batch of 1365 rows per epoch
+    steps = 40
+    loss_save = []
+    params, h_signed, _ = bear_ref.train(data.repeat(steps), 1365, steps, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01,
+                                         "Adam", train_ar, loss_save=loss_save)
+    p = np.array([0.0, np.log(1 / 30), -np.log(100)])
+    m, v = np.zeros(3), np.zeros(3)
+    want_loss = []
+    for t in range(1, steps + 1):
+        r = o.bear_ref_step(counts[:, 0], counts[:, 2], *p, train_ar=train_ar)
+        want_loss.append(r["ll"])
+        g = -np.array([r["d_h_signed"], r["d_tau_signed"], r["d_nu_signed"]])
+        if train_ar:
+            keras_adam_np(p[1:], g[1:], m[1:], v[1:], t)
+        else:
+            keras_adam_np(p, g, m, v, t)
+    got = np.array([x.item() for x in params])
+    assert len(loss_save) == steps and np.allclose(loss_save, want_loss, rtol=1e-10)
+    assert np.allclose(got, p, rtol=1e-8, atol=1e-10) and h_signed is params[0]
+    os.environ["BEAR_AMD_NO_GRAPH"] = "1"
+    try:
+        loss_eager = []
+        params_e, _, _ = bear_ref.train(data.repeat(steps), 1365, steps, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01,
+                                        "Adam", train_ar, loss_save=loss_eager)
+    finally:
+        os.environ.pop("BEAR_AMD_NO_GRAPH")
+    assert np.allclose(loss_save, loss_eager, rtol=1e-12)
+    assert np.allclose(got, [x.item() for x in params_e], rtol=1e-10, atol=1e-12)
