@@ -6,6 +6,8 @@ AR rows come from the plugin (``ar_funcs``, PyTorch-ROCm ops with autograd), and
 log-likelihood, its gradient w.r.t. ``h_signed`` and w.r.t. the AR rows come from one launch of
 ``bear_dm_prior_f64``; the row gradient is fed back through ``ar_func`` by ``Tensor.backward``.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -54,6 +56,10 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
     if fused_mat is not None and not (alphabet_size == 4 and lag <= kernels.LINEAR_MAX_LAG and fused_mat is ar_params[0]):
         fused_mat = None
     normalized = bool(getattr(ar_func, "normalized_rows", False))   # every reference AR function ends in a softmax
+    if (fused_mat is not None and n_batches == 1 and acc_steps == 1 and optimizer_name == "Adam" and writer is None
+            and dist.world()[1] == 1 and res.batches[0]["rows"] > 0 and data.repeats > 1 and not os.environ.get("BEAR_AMD_NO_GRAPH")):
+        return _train_linear_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, fused_mat, lag, learning_rate, train_ar,
+                                   loss_save, device)
     for _ in range(data.repeats):
         for k in range(n_batches):
             e = res.batches[k]
@@ -98,6 +104,35 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
                     a.zero_()
                 loss = 0.0
             step += 1
+    return params, h_signed, ar_func
+
+
+def _train_linear_graph(res, steps, num_kmers, params, h_signed, ar_func, mat, lag, learning_rate, train_ar, loss_save, device):
+    """One resident batch, linear AR function, Adam, one GPU: the optimizer step (1/h from the device-resident parameters,
+    the fused linear-head kernel, both finalize kernels, Adam on {h_signed, mat}) is captured in a HIP graph once and replayed
+    ``steps`` times; parameters and losses come back at the end (see bear_ref._train_stop_graph)."""
+    e = res.batches[0]
+    plan = res.plan(0, "train", 5)
+    packed = kernels.pack_kmers(e["codes"].contiguous())
+    scale = -(num_kmers / e["global_rows"])
+    theta = torch.cat([h_signed.detach().reshape(1), mat.detach().reshape(-1)]).to(device=device, dtype=torch.float64).contiguous()
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    t = torch.zeros(1, dtype=torch.float64, device=device)
+    gmat = torch.zeros(lag * 25, dtype=torch.float64, device=device)
+    out = torch.zeros(2, dtype=torch.float64, device=device)
+    loss_buf = torch.zeros(steps, dtype=torch.float64, device=device)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        kernels.net_linear_train_step(plan, packed, lag, theta, m, v, t, gmat, learning_rate, scale, out, loss_buf, train_ar=train_ar)
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        h_signed.copy_(theta[0])
+        mat.copy_(theta[1:].reshape(mat.shape))
+    if loss_save is not None:
+        loss_save.extend(loss_buf.cpu().tolist())
     return params, h_signed, ar_func
 
 

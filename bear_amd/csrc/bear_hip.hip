@@ -631,11 +631,11 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
   if (train_ar)
     hipLaunchKernelGGL(dm_linear_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
                        reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, prm, plan_view(plan), lt, ws->partials,
-                       ws->lin_partials);
+                       ws->lin_partials, static_cast<const bear_params *>(nullptr));
   else
     hipLaunchKernelGGL(dm_linear_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
                        reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, prm, plan_view(plan), lt, ws->partials,
-                       ws->lin_partials);
+                       ws->lin_partials, static_cast<const bear_params *>(nullptr));
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
   hipLaunchKernelGGL(linear_finalize_kernel, dim3((lag * 25 + 3) / 4), dim3(256), 0, s, ws->lin_partials, grid, lag * 25,
                      grad_mat);
@@ -644,6 +644,41 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
 }
 
 // ---- held-out evaluation / BMM marginal (kernels_eval.h) ------------------------------------------------
+int bear_net_linear_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, int lag,
+                                   uint64_t n_rows, double *theta, double *adam_m, double *adam_v, double *adam_t, double *grad_mat,
+                                   double eps, int train_ar, double learning_rate, double scale, double *out, double *loss_buf,
+                                   uint64_t loss_cap, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!plan || !out || !theta || !adam_m || !adam_v || !adam_t || !grad_mat || lag < 1 || lag > LIN_MAX_LAG || !n_rows)
+    return BEAR_ERR_INVALID_ARG;
+  if (plan->counts != counts || plan->n_rows != n_rows || plan->ncol != 5 || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
+  if (!kmer_code || misaligned(kmer_code) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bear_params dummy;
+  memset(&dummy, 0, sizeof(dummy));
+  const int grid = grid_plan(ws, plan->n_tiles);
+  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  const double *mat = theta + 1;
+  hipLaunchKernelGGL(net_params_kernel, dim3(1), dim3(64), 0, s, theta, eps, ws->ref_prm);
+  if (train_ar)
+    hipLaunchKernelGGL(dm_linear_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
+                       reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, dummy, plan_view(plan), lt, ws->partials,
+                       ws->lin_partials, static_cast<const bear_params *>(ws->ref_prm));
+  else
+    hipLaunchKernelGGL(dm_linear_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
+                       reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, dummy, plan_view(plan), lt, ws->partials,
+                       ws->lin_partials, static_cast<const bear_params *>(ws->ref_prm));
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
+  hipLaunchKernelGGL(linear_finalize_kernel, dim3((lag * 25 + 3) / 4), dim3(256), 0, s, ws->lin_partials, grid, lag * 25, grad_mat);
+  const int n_rest = lag * 25;
+  hipLaunchKernelGGL(adam_vec_kernel, dim3((n_rest + 1 + 255) / 256), dim3(256), 0, s, theta, out, grad_mat, n_rest, adam_m, adam_v,
+                     adam_t, learning_rate, scale, train_ar, loss_buf, (unsigned long long)loss_cap);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, adam_t);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
 static int launch_eval(bear_ws *ws, const uint32_t *test, const uint32_t *train, const double *prior, uint64_t n_rows,
                        const evl_args &A, double *out, hipStream_t s) {
   // sorted formulation (kernels_eval.h): at most EVS_CHUNK DM models per launch; the first launch also carries the AR

@@ -107,10 +107,12 @@ __device__ __forceinline__ void lin_row(const double *T, const double *exptab, u
 
 template <bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_kernel(
-    const unsigned long long *__restrict__ kmer_code, const double *__restrict__ mat, int lag, bear_params prm, pln_view pv,
-    const double2 *__restrict__ logtab_g, double *__restrict__ partials, double *__restrict__ grad_partials) {
+    const unsigned long long *__restrict__ kmer_code, const double *__restrict__ mat, int lag, bear_params prm_arg, pln_view pv,
+    const double2 *__restrict__ logtab_g, double *__restrict__ partials, double *__restrict__ grad_partials,
+    const bear_params *__restrict__ prm_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_lin &S = *reinterpret_cast<pln_lds_lin *>(srt_smem);
+  const bear_params prm = prm_dev ? *prm_dev : prm_arg;   // device-resident parameters for HIP-graph replay (bear_net_linear_train_step_f64)
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
   const int ng = (lag + 1) >> 1;
@@ -332,4 +334,43 @@ __global__ __launch_bounds__(256) void linear_finalize_kernel(const double *__re
   for (int b = lane; b < n_blocks; b += 64) s += grad_partials[(size_t)b * LIN_MAX_GRAD + k];
   s = bear_wave_sum(s);
   if (lane == 0) grad_mat[k] = s;
+}
+
+
+// ---- the bear_net / linear optimizer step on the device (HIP-graph replay) ---------------------------------------
+// theta = {h_signed, mat[lag,5,5]} contiguous.  net_params_kernel derives 1/h; adam_vec_kernel is tf.keras Adam on the whole
+// vector with gradients grad[k] * scale (k = 0: d/dh from out[1], skipped in AR mode; k >= 1: d/d mat).
+__global__ void net_params_kernel(const double *__restrict__ theta, double eps, bear_params *__restrict__ prm) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  bear_params p;
+  p.inv_h = 1.0 / exp(theta[0]);
+  p.eps = eps;
+  p.E = p.tauE = p.tau = p.V = p.nw = 0.0;
+  *prm = p;
+}
+
+__global__ __launch_bounds__(256) void adam_vec_kernel(double *__restrict__ theta, const double *__restrict__ out2,
+                                                       const double *__restrict__ grad_rest, int n_rest, double *__restrict__ m,
+                                                       double *__restrict__ v, const double *__restrict__ t_state, double lr,
+                                                       double scale, int train_ar, double *__restrict__ loss_buf,
+                                                       unsigned long long loss_cap) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k > n_rest) return;
+  const double t = t_state[0] + 1.0;
+  const double b1 = 0.9, b2 = 0.999, aeps = 1e-7;
+  const double lr_t = lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
+  if (!(train_ar && k == 0)) {
+    const double g = scale * (k == 0 ? out2[1] : grad_rest[k - 1]);
+    const double mk = b1 * m[k] + (1.0 - b1) * g, vk = b2 * v[k] + (1.0 - b2) * g * g;
+    m[k] = mk;
+    v[k] = vk;
+    theta[k] -= lr_t * mk / (sqrt(vk) + aeps);
+  }
+  if (k == 0) {
+    const unsigned long long step = (unsigned long long)t_state[0];
+    if (loss_buf && step < loss_cap) loss_buf[step] = -scale * out2[0];
+  }
+}
+__global__ void adam_tick_kernel(double *__restrict__ t_state) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) t_state[0] += 1.0;
 }

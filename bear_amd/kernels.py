@@ -427,3 +427,22 @@ def ref_train_step(plan, ref, theta, adam_m, adam_v, adam_t, learning_rate, scal
                                                 float(scale), _ptr(out), _ptr(loss_buf), 0 if loss_buf is None else loss_buf.numel(),
                                                 _stream())
     _lib.check(st, "bear_ref_train_step_f64")
+
+
+def net_linear_train_step(plan, kmer_code, lag, theta, adam_m, adam_v, adam_t, grad_mat, learning_rate, scale, out, loss_buf=None,
+                          eps=EPSILON, train_ar=False):
+    """Enqueues one ``bear_net_linear_train_step_f64`` (HIP-graph capturable): theta = {h_signed, mat} on the device."""
+    n = plan.counts.shape[0]
+    size = 1 + lag * 25
+    for t, k in ((theta, size), (adam_m, size), (adam_v, size), (adam_t, 1), (grad_mat, lag * 25), (out, 2)):
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == k):
+            raise ValueError("theta / adam_m / adam_v [1 + lag*25], adam_t [1], grad_mat [lag*25], out [2]: contiguous CUDA float64")
+    if not (kmer_code.is_cuda and kmer_code.dtype == torch.int64 and kmer_code.is_contiguous() and kmer_code.shape == (n,)
+            and kmer_code.data_ptr() % 16 == 0):
+        raise ValueError("kmer_code must be a contiguous, 16-byte aligned CUDA int64 tensor [n_rows] (pack_kmers)")
+    with torch.cuda.device(theta.device):
+        st = _lib.lib().bear_net_linear_train_step_f64(plan.ws.handle, plan._h, _ptr(plan.counts), _ptr(kmer_code), int(lag), n, _ptr(theta),
+                                                       _ptr(adam_m), _ptr(adam_v), _ptr(adam_t), _ptr(grad_mat), float(eps),
+                                                       int(bool(train_ar)), float(learning_rate), float(scale), _ptr(out),
+                                                       _ptr(loss_buf), 0 if loss_buf is None else loss_buf.numel(), _stream())
+    _lib.check(st, "bear_net_linear_train_step_f64")

@@ -136,6 +136,13 @@ int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *
                             double *theta, double *adam_m, double *adam_v, double *adam_t, double eps, int train_ar,
                             double learning_rate, double scale, double *out, double *loss_buf, uint64_t loss_cap, void *stream);
 
+/* The same for bear_net with the linear AR function (bear_model/bear_net.py:146-197 + ar_funcs.py:23-46): theta [dev] double
+ * [1 + lag*25] = {h_signed, mat}; adam_m / adam_v the same size; grad_mat [dev] double [lag*25] scratch. */
+int bear_net_linear_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, int lag,
+                                   uint64_t n_rows, double *theta, double *adam_m, double *adam_v, double *adam_t, double *grad_mat,
+                                   double eps, int train_ar, double learning_rate, double scale, double *out, double *loss_buf,
+                                   uint64_t loss_cap, void *stream);
+
 /*
  * The whole bear_net training step for the linear AR function, fused on a plan: replaces
  * ar_func = make_ar_func_linear(...) (bear_model/ar_funcs.py:23-46), _train_step's forward and
