@@ -132,6 +132,7 @@ def make_ar_func_cnn(lag, alphabet_size, filter_width=8, num_filters=30, kmer_la
         nn2 = torch.tensordot(F.elu(nn1), kmer_weights2, dims=([-1], [0])) + kmer_intercept2
         return torch.softmax(nn2, dim=-1)
     ar_func.fused = fused_ok       # integer codes on the device take the fused kernels; one-hot input the torch ops
+    ar_func.cnn_params, ar_func.cnn_filter_width = params, filter_width
     ar_func.normalized_rows = True
     return ar_func, params
 

@@ -60,6 +60,11 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
             and dist.world()[1] == 1 and res.batches[0]["rows"] > 0 and data.repeats > 1 and not os.environ.get("BEAR_AMD_NO_GRAPH")):
         return _train_linear_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, fused_mat, lag, learning_rate, train_ar,
                                    loss_save, device)
+    cnn_ok = (getattr(ar_func, "fused", False) and alphabet_size == 4 and len(ar_params) == 8
+              and all(a is b for a, b in zip(getattr(ar_func, "cnn_params", []), ar_params)))
+    if (cnn_ok and n_batches == 1 and acc_steps == 1 and optimizer_name == "Adam" and writer is None
+            and dist.world()[1] == 1 and res.batches[0]["rows"] > 0 and data.repeats > 1 and not os.environ.get("BEAR_AMD_NO_GRAPH")):
+        return _train_cnn_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, lag, learning_rate, train_ar, loss_save, device)
     for _ in range(data.repeats):
         for k in range(n_batches):
             e = res.batches[k]
@@ -131,6 +136,39 @@ def _train_linear_graph(res, steps, num_kmers, params, h_signed, ar_func, mat, l
     with torch.no_grad():
         h_signed.copy_(theta[0])
         mat.copy_(theta[1:].reshape(mat.shape))
+    if loss_save is not None:
+        loss_save.extend(loss_buf.cpu().tolist())
+    return params, h_signed, ar_func
+
+
+def _train_cnn_graph(res, steps, num_kmers, params, h_signed, ar_func, lag, learning_rate, train_ar, loss_save, device):
+    """One resident batch, convolutional AR function, Adam, one GPU: forward, planned DM kernel with gradient rows, backward
+    and Adam on {h_signed, all eight parameter tensors} as one captured HIP graph, replayed ``steps`` times."""
+    e = res.batches[0]
+    plan = res.plan(0, "train", 5)
+    fw = ar_func.cnn_filter_width
+    packed = kernels.pack_kmers(e["codes"].contiguous())
+    scale = -(num_kmers / e["global_rows"])
+    ar_params = params[1:]
+    theta = torch.cat([h_signed.detach().reshape(1)] + [p.detach().reshape(-1) for p in ar_params]).to(device=device, dtype=torch.float64).contiguous()
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    t = torch.zeros(1, dtype=torch.float64, device=device)
+    out = torch.zeros(2, dtype=torch.float64, device=device)
+    loss_buf = torch.zeros(steps, dtype=torch.float64, device=device)
+    bufs = kernels.cnn_step_buffers(plan, lag, fw)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        kernels.net_cnn_train_step(plan, packed, lag, fw, theta, m, v, t, bufs, learning_rate, scale, out, loss_buf, train_ar=train_ar)
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        h_signed.copy_(theta[0])
+        k = 1
+        for p in ar_params:
+            p.copy_(theta[k:k + p.numel()].reshape(p.shape))
+            k += p.numel()
     if loss_save is not None:
         loss_save.extend(loss_buf.cpu().tolist())
     return params, h_signed, ar_func

@@ -470,6 +470,38 @@ int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *c
   return BEAR_OK;
 }
 
+static int launch_prior_plan_grad(bear_ws *ws, const bear_plan *plan, const double *prior, const bear_params &prm,
+                                  const bear_params *prm_dev, int train_ar, int prior_normalized, double *out, double *grad_prior,
+                                  hipStream_t s) {
+  const int grid = grid_plan(ws, plan->n_tiles);
+  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  const pln_view pv = plan_view(plan);
+  if (train_ar)
+    hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
+                       grad_prior, ws->partials, prm_dev);
+  else if (prior_normalized)
+    hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
+                       grad_prior, ws->partials, prm_dev);
+  else
+    hipLaunchKernelGGL((dm_prior_plan_grad_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
+                       grad_prior, ws->partials, prm_dev);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
+  HIP_TRY(hipGetLastError());
+  if (pv.n_heavy_col + pv.n_heavy_row) {
+    const uint64_t nh = pv.n_heavy_col + pv.n_heavy_row;
+    const int g2 = (int)((nh + 255) / 256 < (uint64_t)ws->num_cu * 4 ? (nh + 255) / 256 : (uint64_t)ws->num_cu * 4);
+    if (train_ar)
+      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, true>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, prm_dev);
+    else if (prior_normalized)
+      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, prm_dev);
+    else
+      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<false, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, prm_dev);
+    HIP_TRY(hipGetLastError());
+  }
+  return BEAR_OK;
+}
+
 int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
                                 uint64_t n_rows, double h_signed, double eps, int train_ar, int prior_normalized,
                                 double *out, double *grad_prior, void *stream) {
@@ -479,38 +511,12 @@ int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32
   if (plan->ncol != 5 || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
     return BEAR_ERR_INVALID_ARG;
   if (misaligned(prior) || misaligned(grad_prior) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
-  hipStream_t s = static_cast<hipStream_t>(stream);
   bear_params prm;
   memset(&prm, 0, sizeof(prm));
   prm.inv_h = 1.0 / exp(h_signed);
   prm.eps = eps;
-  const int grid = grid_plan(ws, plan->n_tiles);
-  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
-  const pln_view pv = plan_view(plan);
-  if (train_ar)
-    hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
-                       grad_prior, ws->partials);
-  else if (prior_normalized)
-    hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
-                       grad_prior, ws->partials);
-  else
-    hipLaunchKernelGGL((dm_prior_plan_grad_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
-                       grad_prior, ws->partials);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
-  HIP_TRY(hipGetLastError());
-  if (pv.n_heavy_col + pv.n_heavy_row) {
-    const uint64_t nh = pv.n_heavy_col + pv.n_heavy_row;
-    const int g2 = (int)((nh + 255) / 256 < (uint64_t)ws->num_cu * 4 ? (nh + 255) / 256 : (uint64_t)ws->num_cu * 4);
-    if (train_ar)
-      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, true>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior);
-    else if (prior_normalized)
-      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior);
-    else
-      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<false, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior);
-    HIP_TRY(hipGetLastError());
-  }
-  return BEAR_OK;
+  return launch_prior_plan_grad(ws, plan, prior, prm, nullptr, train_ar, prior_normalized, out, grad_prior,
+                                static_cast<hipStream_t>(stream));
 }
 
 int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref,
@@ -879,16 +885,10 @@ int bear_cnn_forward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows
   return BEAR_OK;
 }
 
-int bear_cnn_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows, int lag, int filter_width, int num_filters,
-                          int layer1_width, const double *params, const double *t1_save, const double *prior,
-                          const double *grad_prior, double *grad_params, void *stream) {
-  int st = cnn_check(ws, lag, filter_width, num_filters, layer1_width);
-  if (st != BEAR_OK) return st;
-  if (!params || !grad_params) return BEAR_ERR_INVALID_ARG;
-  if (n_rows && (!kmer_code || !t1_save || !prior || !grad_prior || misaligned(t1_save))) return BEAR_ERR_INVALID_ARG;
-  const cnn_dims D = cnn_make_dims(lag, filter_width);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  // one block per CU; as many waves per block as the LDS holds (gradient image + per-wave staging)
+// sizes the block-partial buffer of the CNN backward pass; returns the grid.  With may_alloc == 0 (inside a stream capture) a
+// buffer that is too small is an error: call bear_cnn_reserve first.
+static int cnn_backward_grid(bear_ws *ws, const cnn_dims &D, uint64_t n_rows, int filter_width, int *waves_out, size_t *lds_out,
+                             uint64_t *blocks_out, hipStream_t s, int may_alloc) {
   const size_t fixed = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (size_t)((D.total + 1) & ~1));
   int waves = 4;
   while (waves > 1 && fixed + (size_t)waves * CNN_WAVE_DOUBLES * sizeof(double) > 160u * 1024u) waves >>= 1;
@@ -899,6 +899,7 @@ int bear_cnn_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_row
   if (blocks == 0) blocks = 1;
   const size_t need = (size_t)blocks * D.total;
   if (ws->cnn_partials_cap < need) {
+    if (!may_alloc) return BEAR_ERR_INVALID_ARG;
     HIP_TRY(hipStreamSynchronize(s));
     if (ws->cnn_partials) (void)hipFree(ws->cnn_partials);
     ws->cnn_partials = nullptr;
@@ -906,11 +907,88 @@ int bear_cnn_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_row
     HIP_TRY(hipMalloc(&ws->cnn_partials, sizeof(double) * need));
     ws->cnn_partials_cap = need;
   }
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(cnn_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  *waves_out = waves;
+  *lds_out = lds;
+  *blocks_out = blocks;
+  return BEAR_OK;
+}
+
+static int launch_cnn_backward(bear_ws *ws, const cnn_dims &D, const uint64_t *kmer_code, uint64_t n_rows, int filter_width,
+                               const double *params, const double *t1_save, const double *prior, const double *grad_prior,
+                               double *grad_params, hipStream_t s, int may_alloc) {
+  int waves = 0;
+  size_t lds = 0;
+  uint64_t blocks = 0;
+  int st = cnn_backward_grid(ws, D, n_rows, filter_width, &waves, &lds, &blocks, s, may_alloc);
+  if (st != BEAR_OK) return st;
+  if (may_alloc)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(cnn_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(cnn_backward_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, s,
                      reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, t1_save, prior, grad_prior,
                      ws->cnn_partials);
   hipLaunchKernelGGL(cnn_finalize_kernel, dim3((D.total + 3) / 4), dim3(256), 0, s, ws->cnn_partials, (int)blocks, D.total, grad_params);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_cnn_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows, int lag, int filter_width, int num_filters,
+                          int layer1_width, const double *params, const double *t1_save, const double *prior,
+                          const double *grad_prior, double *grad_params, void *stream) {
+  int st = cnn_check(ws, lag, filter_width, num_filters, layer1_width);
+  if (st != BEAR_OK) return st;
+  if (!params || !grad_params) return BEAR_ERR_INVALID_ARG;
+  if (n_rows && (!kmer_code || !t1_save || !prior || !grad_prior || misaligned(t1_save))) return BEAR_ERR_INVALID_ARG;
+  const cnn_dims D = cnn_make_dims(lag, filter_width);
+  return launch_cnn_backward(ws, D, kmer_code, n_rows, filter_width, params, t1_save, prior, grad_prior, grad_params,
+                             static_cast<hipStream_t>(stream), 1);
+}
+
+int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, int num_filters, int layer1_width) {
+  int st = cnn_check(ws, lag, filter_width, num_filters, layer1_width);
+  if (st != BEAR_OK) return st;
+  const cnn_dims D = cnn_make_dims(lag, filter_width);
+  int waves = 0;
+  size_t lds = 0;
+  uint64_t blocks = 0;
+  st = cnn_backward_grid(ws, D, n_rows, filter_width, &waves, &lds, &blocks, nullptr, 1);
+  if (st != BEAR_OK) return st;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(cnn_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  return BEAR_OK;
+}
+
+int bear_net_cnn_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,
+                                int lag, int filter_width, int num_filters, int layer1_width, double *theta, double *adam_m,
+                                double *adam_v, double *adam_t, double *prior_buf, double *t1_buf, double *grad_rows_buf,
+                                double *grad_flat, double eps, int train_ar, double learning_rate, double scale, double *out,
+                                double *loss_buf, uint64_t loss_cap, void *stream) {
+  int st = cnn_check(ws, lag, filter_width, num_filters, layer1_width);
+  if (st != BEAR_OK) return st;
+  if (!plan || !out || !theta || !adam_m || !adam_v || !adam_t || !prior_buf || !t1_buf || !grad_rows_buf || !grad_flat || !n_rows ||
+      !kmer_code)
+    return BEAR_ERR_INVALID_ARG;
+  if (plan->counts != counts || plan->n_rows != n_rows || plan->ncol != 5 || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
+  if (misaligned(prior_buf) || misaligned(t1_buf) || misaligned(grad_rows_buf) || (reinterpret_cast<uintptr_t>(out) & 7u))
+    return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const cnn_dims D = cnn_make_dims(lag, filter_width);
+  const double *params = theta + 1;
+  hipLaunchKernelGGL(net_params_kernel, dim3(1), dim3(64), 0, s, theta, eps, ws->ref_prm);
+  {
+    const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF);
+    uint64_t blocks = (n_rows + CNN_THREADS - 1) / CNN_THREADS;
+    if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
+    hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), lds, s,
+                       reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, prior_buf, t1_buf);
+  }
+  bear_params dummy;
+  memset(&dummy, 0, sizeof(dummy));
+  st = launch_prior_plan_grad(ws, plan, prior_buf, dummy, ws->ref_prm, train_ar, 1, out, grad_rows_buf, s);   // softmax rows: normalised
+  if (st != BEAR_OK) return st;
+  st = launch_cnn_backward(ws, D, kmer_code, n_rows, filter_width, params, t1_buf, prior_buf, grad_rows_buf, grad_flat, s, 0);
+  if (st != BEAR_OK) return st;
+  hipLaunchKernelGGL(adam_vec_kernel, dim3((D.total + 1 + 255) / 256), dim3(256), 0, s, theta, out, grad_flat, D.total, adam_m, adam_v,
+                     adam_t, learning_rate, scale, train_ar, loss_buf, (unsigned long long)loss_cap);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, adam_t);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }

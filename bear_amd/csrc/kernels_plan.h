@@ -887,12 +887,14 @@ struct pln_lds_g {
 
 template <bool NORM, bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad_kernel(const double *__restrict__ prior,
-                                                                                         bear_params prm, pln_view pv,
+                                                                                         bear_params prm_arg, pln_view pv,
                                                                                          const double2 *__restrict__ logtab_g,
                                                                                          double *__restrict__ grad_out,
-                                                                                         double *__restrict__ partials) {
+                                                                                         double *__restrict__ partials,
+                                                                                         const bear_params *__restrict__ prm_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_g &S = *reinterpret_cast<pln_lds_g *>(srt_smem);
+  const bear_params prm = prm_dev ? *prm_dev : prm_arg;   // device-resident parameters for HIP-graph replay
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
   double acc[2] = {0.0, 0.0};
@@ -1050,9 +1052,11 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
 // Gradient cells of the items in the plan's global overflow lists (very dense tiles only).  A cell can be hit by
 // a column item and by its context, hence the fp64 atomics (rare path).
 template <bool NORM, bool AR>
-__global__ __launch_bounds__(256) void dm_prior_grad_fixup_kernel(const double *__restrict__ prior, bear_params prm, pln_view pv,
+__global__ __launch_bounds__(256) void dm_prior_grad_fixup_kernel(const double *__restrict__ prior, bear_params prm_arg, pln_view pv,
                                                                    const double2 *__restrict__ logtab_g,
-                                                                   double *__restrict__ grad_out) {
+                                                                   double *__restrict__ grad_out,
+                                                                   const bear_params *__restrict__ prm_dev) {
+  const bear_params prm = prm_dev ? *prm_dev : prm_arg;
   __shared__ double2 logtab[BEAR_LOGTAB_N];
   if (threadIdx.x < BEAR_LOGTAB_N) logtab[threadIdx.x] = logtab_g[threadIdx.x];
   __syncthreads();

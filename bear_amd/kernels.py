@@ -446,3 +446,28 @@ def net_linear_train_step(plan, kmer_code, lag, theta, adam_m, adam_v, adam_t, g
                                                        int(bool(train_ar)), float(learning_rate), float(scale), _ptr(out),
                                                        _ptr(loss_buf), 0 if loss_buf is None else loss_buf.numel(), _stream())
     _lib.check(st, "bear_net_linear_train_step_f64")
+
+
+def net_cnn_train_step(plan, kmer_code, lag, filter_width, theta, adam_m, adam_v, adam_t, bufs, learning_rate, scale, out, loss_buf=None,
+                       eps=EPSILON, train_ar=False):
+    """Enqueues one ``bear_net_cnn_train_step_f64`` (HIP-graph capturable): theta = {h_signed, flat CNN parameters} on the device;
+    ``bufs`` = (prior [n,5], t1 [n,16], grad_rows [n,5], grad_flat [param_count]) lent by the caller (``cnn_step_buffers``)."""
+    n = plan.counts.shape[0]
+    prior, t1, grad_rows, grad_flat = bufs
+    with torch.cuda.device(theta.device):
+        st = _lib.lib().bear_net_cnn_train_step_f64(plan.ws.handle, plan._h, _ptr(plan.counts), _ptr(kmer_code), n, int(lag), int(filter_width),
+                                                    CNN_NUM_FILTERS, CNN_LAYER1_WIDTH, _ptr(theta), _ptr(adam_m), _ptr(adam_v), _ptr(adam_t),
+                                                    _ptr(prior), _ptr(t1), _ptr(grad_rows), _ptr(grad_flat), float(eps), int(bool(train_ar)),
+                                                    float(learning_rate), float(scale), _ptr(out), _ptr(loss_buf),
+                                                    0 if loss_buf is None else loss_buf.numel(), _stream())
+    _lib.check(st, "bear_net_cnn_train_step_f64")
+
+
+def cnn_step_buffers(plan, lag, filter_width):
+    """Per-context scratch of the captured CNN step + the library-side reservation (``bear_cnn_reserve``)."""
+    n, dev = plan.counts.shape[0], plan.counts.device
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().bear_cnn_reserve(plan.ws.handle, n, int(lag), int(filter_width), CNN_NUM_FILTERS, CNN_LAYER1_WIDTH),
+                   "bear_cnn_reserve")
+    return (torch.empty((n, 5), dtype=torch.float64, device=dev), torch.empty((n, CNN_LAYER1_WIDTH), dtype=torch.float64, device=dev),
+            torch.empty((n, 5), dtype=torch.float64, device=dev), torch.empty(cnn_param_count(lag, filter_width), dtype=torch.float64, device=dev))

@@ -143,6 +143,16 @@ int bear_net_linear_train_step_f64(bear_ws *ws, const bear_plan *plan, const uin
                                    double eps, int train_ar, double learning_rate, double scale, double *out, double *loss_buf,
                                    uint64_t loss_cap, void *stream);
 
+/* And with the convolutional AR function: theta [dev] double [1 + bear_cnn_param_count(...)] = {h_signed, params}; the caller
+ * lends the per-context buffers prior_buf [n,5], t1_buf [n,16], grad_rows_buf [n,5] and grad_flat [param_count].  Call
+ * bear_cnn_reserve once before capturing (it sizes the library's block-partial buffer; nothing allocates inside the step). */
+int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, int num_filters, int layer1_width);
+int bear_net_cnn_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,
+                                int lag, int filter_width, int num_filters, int layer1_width, double *theta, double *adam_m,
+                                double *adam_v, double *adam_t, double *prior_buf, double *t1_buf, double *grad_rows_buf,
+                                double *grad_flat, double eps, int train_ar, double learning_rate, double scale, double *out,
+                                double *loss_buf, uint64_t loss_cap, void *stream);
+
 /*
  * The whole bear_net training step for the linear AR function, fused on a plan: replaces
  * ar_func = make_ar_func_linear(...) (bear_model/ar_funcs.py:23-46), _train_step's forward and

@@ -334,3 +334,28 @@ def test_bear_net_linear_graph_replay_matches_eager(train_ar, ysd1):
         assert np.allclose(a, b, rtol=1e-7, atol=1e-9)
     if train_ar:
         assert runs[0][1][0] == 0.1            # h_signed untouched in AR mode
+
+
+@pytest.mark.parametrize("train_ar", [False, True])
+def test_bear_net_cnn_graph_replay_matches_eager(train_ar, ysd1):
+    """One resident batch + the reference's cnn config: the captured step (bear_net_cnn_train_step_f64 in a HIP graph) against
+    the eager path (fused kernels behind torch autograd + host Adam, itself held to the CPU replica above)."""
+    data = dataloader.dataloader(YSD1, "dna", 1500, 3)
+    torch.manual_seed(6)
+    _, init = ar_funcs.make_ar_func_cnn(5, 4, **CNN_CFG)
+    restart = [np.array(0.1)] + [x.detach().numpy().copy() for x in init]
+    steps = 12
+    runs = []
+    for no_graph in (False, True):
+        if no_graph:
+            os.environ["BEAR_AMD_NO_GRAPH"] = "1"
+        try:
+            ls = []
+            params, _, _ = bear_net.train(data.repeat(steps), 1365, steps, 0, "dna", 5, ar_funcs.make_ar_func_cnn, CNN_CFG, 0.01,
+                                          "Adam", train_ar, params_restart=restart, loss_save=ls)
+        finally:
+            os.environ.pop("BEAR_AMD_NO_GRAPH", None)
+        runs.append((ls, [p.detach().cpu().numpy() for p in params]))
+    assert len(runs[0][0]) == steps and np.allclose(runs[0][0], runs[1][0], rtol=1e-8)
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-7)
