@@ -118,6 +118,7 @@ def counts_f64(t):
     return torch.where(t < 0, t.to(torch.float64) + 4294967296.0, t.to(torch.float64))
 
 
+GRAPH_MAX_BATCHES = 64    # an epoch of at most this many resident batches is captured as one HIP graph
 MAX_EVAL_MODELS = 64   # EVL_MAX_MODELS of kernels_eval.h: h values + van_reg values per launch
 
 

@@ -56,14 +56,15 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
     if fused_mat is not None and not (alphabet_size == 4 and lag <= kernels.LINEAR_MAX_LAG and fused_mat is ar_params[0]):
         fused_mat = None
     normalized = bool(getattr(ar_func, "normalized_rows", False))   # every reference AR function ends in a softmax
-    if (fused_mat is not None and n_batches == 1 and acc_steps == 1 and optimizer_name == "Adam" and writer is None
-            and dist.world()[1] == 1 and res.batches[0]["rows"] > 0 and data.repeats > 1 and not os.environ.get("BEAR_AMD_NO_GRAPH")):
+    graphable = (1 <= n_batches <= _train.GRAPH_MAX_BATCHES and acc_steps == 1 and optimizer_name == "Adam" and writer is None
+                 and dist.world()[1] == 1 and all(b["rows"] > 0 for b in res.batches) and data.repeats > 1
+                 and not os.environ.get("BEAR_AMD_NO_GRAPH"))
+    if fused_mat is not None and graphable:
         return _train_linear_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, fused_mat, lag, learning_rate, train_ar,
                                    loss_save, device)
     cnn_ok = (getattr(ar_func, "fused", False) and alphabet_size == 4 and len(ar_params) == 8
               and all(a is b for a, b in zip(getattr(ar_func, "cnn_params", []), ar_params)))
-    if (cnn_ok and n_batches == 1 and acc_steps == 1 and optimizer_name == "Adam" and writer is None
-            and dist.world()[1] == 1 and res.batches[0]["rows"] > 0 and data.repeats > 1 and not os.environ.get("BEAR_AMD_NO_GRAPH")):
+    if cnn_ok and graphable:
         return _train_cnn_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, lag, learning_rate, train_ar, loss_save, device)
     for _ in range(data.repeats):
         for k in range(n_batches):
@@ -113,23 +114,23 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
 
 
 def _train_linear_graph(res, steps, num_kmers, params, h_signed, ar_func, mat, lag, learning_rate, train_ar, loss_save, device):
-    """One resident batch, linear AR function, Adam, one GPU: the optimizer step (1/h from the device-resident parameters,
+    """Resident batches, linear AR function, Adam, one GPU: the optimizer step (1/h from the device-resident parameters,
     the fused linear-head kernel, both finalize kernels, Adam on {h_signed, mat}) is captured in a HIP graph once and replayed
     ``steps`` times; parameters and losses come back at the end (see bear_ref._train_stop_graph)."""
-    e = res.batches[0]
-    plan = res.plan(0, "train", 5)
-    packed = kernels.pack_kmers(e["codes"].contiguous())
-    scale = -(num_kmers / e["global_rows"])
+    plans = [res.plan(k, "train", 5) for k in range(len(res.batches))]
+    packed = [kernels.pack_kmers(e["codes"].contiguous()) for e in res.batches]
     theta = torch.cat([h_signed.detach().reshape(1), mat.detach().reshape(-1)]).to(device=device, dtype=torch.float64).contiguous()
     m, v = torch.zeros_like(theta), torch.zeros_like(theta)
     t = torch.zeros(1, dtype=torch.float64, device=device)
     gmat = torch.zeros(lag * 25, dtype=torch.float64, device=device)
     out = torch.zeros(2, dtype=torch.float64, device=device)
-    loss_buf = torch.zeros(steps, dtype=torch.float64, device=device)
+    loss_buf = torch.zeros(steps * len(res.batches), dtype=torch.float64, device=device)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        kernels.net_linear_train_step(plan, packed, lag, theta, m, v, t, gmat, learning_rate, scale, out, loss_buf, train_ar=train_ar)
+    with torch.cuda.graph(graph):                                            # one epoch: the batches in order, one optimizer step each
+        for e, plan, pk in zip(res.batches, plans, packed):
+            kernels.net_linear_train_step(plan, pk, lag, theta, m, v, t, gmat, learning_rate, -(num_kmers / e["global_rows"]), out,
+                                          loss_buf, train_ar=train_ar)
     for _ in range(steps):
         graph.replay()
     torch.cuda.synchronize()
@@ -142,24 +143,24 @@ def _train_linear_graph(res, steps, num_kmers, params, h_signed, ar_func, mat, l
 
 
 def _train_cnn_graph(res, steps, num_kmers, params, h_signed, ar_func, lag, learning_rate, train_ar, loss_save, device):
-    """One resident batch, convolutional AR function, Adam, one GPU: forward, planned DM kernel with gradient rows, backward
+    """Resident batches, convolutional AR function, Adam, one GPU: forward, planned DM kernel with gradient rows, backward
     and Adam on {h_signed, all eight parameter tensors} as one captured HIP graph, replayed ``steps`` times."""
-    e = res.batches[0]
-    plan = res.plan(0, "train", 5)
+    plans = [res.plan(k, "train", 5) for k in range(len(res.batches))]
     fw = ar_func.cnn_filter_width
-    packed = kernels.pack_kmers(e["codes"].contiguous())
-    scale = -(num_kmers / e["global_rows"])
+    packed = [kernels.pack_kmers(e["codes"].contiguous()) for e in res.batches]
     ar_params = params[1:]
     theta = torch.cat([h_signed.detach().reshape(1)] + [p.detach().reshape(-1) for p in ar_params]).to(device=device, dtype=torch.float64).contiguous()
     m, v = torch.zeros_like(theta), torch.zeros_like(theta)
     t = torch.zeros(1, dtype=torch.float64, device=device)
     out = torch.zeros(2, dtype=torch.float64, device=device)
-    loss_buf = torch.zeros(steps, dtype=torch.float64, device=device)
-    bufs = kernels.cnn_step_buffers(plan, lag, fw)
+    loss_buf = torch.zeros(steps * len(res.batches), dtype=torch.float64, device=device)
+    bufs = [kernels.cnn_step_buffers(plan, lag, fw) for plan in plans]
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        kernels.net_cnn_train_step(plan, packed, lag, fw, theta, m, v, t, bufs, learning_rate, scale, out, loss_buf, train_ar=train_ar)
+    with torch.cuda.graph(graph):                                            # one epoch: the batches in order, one optimizer step each
+        for e, plan, pk, bf in zip(res.batches, plans, packed, bufs):
+            kernels.net_cnn_train_step(plan, pk, lag, fw, theta, m, v, t, bf, learning_rate, -(num_kmers / e["global_rows"]), out,
+                                       loss_buf, train_ar=train_ar)
     for _ in range(steps):
         graph.replay()
     torch.cuda.synchronize()

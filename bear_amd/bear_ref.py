@@ -80,8 +80,9 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
                               ds_loc, ds_loc_ref, device)
     res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device)
     n_batches = len(res.batches)
-    if (n_batches == 1 and acc_steps == 1 and optimizer_name == "Adam" and writer is None and dist.world()[1] == 1
-            and res.batches[0]["rows"] > 0 and data.repeats > 1 and not os.environ.get("BEAR_AMD_NO_GRAPH")):
+    if (1 <= n_batches <= _train.GRAPH_MAX_BATCHES and acc_steps == 1 and optimizer_name == "Adam" and writer is None
+            and dist.world()[1] == 1 and all(b["rows"] > 0 for b in res.batches) and data.repeats > 1
+            and not os.environ.get("BEAR_AMD_NO_GRAPH")):
         return _train_stop_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, learning_rate, train_ar, loss_save, device)
     acc = torch.zeros(3, dtype=torch.float64)
     loss, step = 0.0, 1
@@ -112,22 +113,22 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
 
 
 def _train_stop_graph(res, steps, num_kmers, params, h_signed, ar_func, learning_rate, train_ar, loss_save, device):
-    """One resident batch, Adam, one GPU: the whole optimizer step (constants from the parameters, planned kernel,
+    """Resident batches, Adam, one GPU: the whole optimizer step (constants from the parameters, planned kernel,
     finalize, Adam) is enqueued once, captured in a HIP graph and replayed ``steps`` times -- no host round trip per step
     (the reference traces its step with tf.function, bear_ref.py:207; at 1365 contexts the eager loop is launch- and
     synchronisation-bound).  Parameters and optimizer state live in device memory; the losses come back once at the end."""
-    e = res.batches[0]
-    plan = res.plan(0, "train", 4)
-    scale = -(num_kmers / e["global_rows"])
+    plans = [res.plan(k, "train", 4) for k in range(len(res.batches))]       # built before the capture (plan creation allocates)
     theta = torch.stack([p.detach().reshape(()) for p in params[:3]]).to(device=device, dtype=torch.float64).contiguous()
     m, v = torch.zeros(3, dtype=torch.float64, device=device), torch.zeros(3, dtype=torch.float64, device=device)
     t = torch.zeros(1, dtype=torch.float64, device=device)
     out = torch.zeros(4, dtype=torch.float64, device=device)
-    loss_buf = torch.zeros(steps, dtype=torch.float64, device=device)
+    loss_buf = torch.zeros(steps * len(res.batches), dtype=torch.float64, device=device)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        kernels.ref_train_step(plan, e["ref"], theta, m, v, t, learning_rate, scale, out, loss_buf, train_ar=train_ar)
+    with torch.cuda.graph(graph):                                            # one epoch: the batches in order, one optimizer step each
+        for e, plan in zip(res.batches, plans):
+            kernels.ref_train_step(plan, e["ref"], theta, m, v, t, learning_rate, -(num_kmers / e["global_rows"]), out, loss_buf,
+                                   train_ar=train_ar)
     for _ in range(steps):
         graph.replay()
     torch.cuda.synchronize()
