@@ -56,16 +56,16 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
     if fused_mat is not None and not (alphabet_size == 4 and lag <= kernels.LINEAR_MAX_LAG and fused_mat is ar_params[0]):
         fused_mat = None
     normalized = bool(getattr(ar_func, "normalized_rows", False))   # every reference AR function ends in a softmax
-    graphable = (1 <= n_batches <= _train.GRAPH_MAX_BATCHES and acc_steps == 1 and optimizer_name == "Adam" and writer is None
+    graphable = (1 <= n_batches <= _train.GRAPH_MAX_BATCHES and acc_steps == 1 and optimizer_name == "Adam"
                  and dist.world()[1] == 1 and all(b["rows"] > 0 for b in res.batches) and data.repeats > 1
                  and not os.environ.get("BEAR_AMD_NO_GRAPH"))
     if fused_mat is not None and graphable:
         return _train_linear_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, fused_mat, lag, learning_rate, train_ar,
-                                   loss_save, device)
+                                   loss_save, device, writer)
     cnn_ok = (getattr(ar_func, "fused", False) and alphabet_size == 4 and len(ar_params) == 8
               and all(a is b for a, b in zip(getattr(ar_func, "cnn_params", []), ar_params)))
     if cnn_ok and graphable:
-        return _train_cnn_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, lag, learning_rate, train_ar, loss_save, device)
+        return _train_cnn_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, lag, learning_rate, train_ar, loss_save, device, writer)
     for _ in range(data.repeats):
         for k in range(n_batches):
             e = res.batches[k]
@@ -113,7 +113,7 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
     return params, h_signed, ar_func
 
 
-def _train_linear_graph(res, steps, num_kmers, params, h_signed, ar_func, mat, lag, learning_rate, train_ar, loss_save, device):
+def _train_linear_graph(res, steps, num_kmers, params, h_signed, ar_func, mat, lag, learning_rate, train_ar, loss_save, device, writer=None):
     """Resident batches, linear AR function, Adam, one GPU: the optimizer step (1/h from the device-resident parameters,
     the fused linear-head kernel, both finalize kernels, Adam on {h_signed, mat}) is captured in a HIP graph once and replayed
     ``steps`` times; parameters and losses come back at the end (see bear_ref._train_stop_graph)."""
@@ -137,12 +137,16 @@ def _train_linear_graph(res, steps, num_kmers, params, h_signed, ar_func, mat, l
     with torch.no_grad():
         h_signed.copy_(theta[0])
         mat.copy_(theta[1:].reshape(mat.shape))
+    losses = loss_buf.cpu().tolist()
     if loss_save is not None:
-        loss_save.extend(loss_buf.cpu().tolist())
+        loss_save.extend(losses)
+    if writer is not None:                       # the per-step scalars of bear_net.py:285-287 / bear_ref.py:353-355, written after the replay
+        for i, val in enumerate(losses):
+            writer.add_scalar("elbo", val, i + 1)
     return params, h_signed, ar_func
 
 
-def _train_cnn_graph(res, steps, num_kmers, params, h_signed, ar_func, lag, learning_rate, train_ar, loss_save, device):
+def _train_cnn_graph(res, steps, num_kmers, params, h_signed, ar_func, lag, learning_rate, train_ar, loss_save, device, writer=None):
     """Resident batches, convolutional AR function, Adam, one GPU: forward, planned DM kernel with gradient rows, backward
     and Adam on {h_signed, all eight parameter tensors} as one captured HIP graph, replayed ``steps`` times."""
     plans = [res.plan(k, "train", 5) for k in range(len(res.batches))]
@@ -170,8 +174,12 @@ def _train_cnn_graph(res, steps, num_kmers, params, h_signed, ar_func, lag, lear
         for p in ar_params:
             p.copy_(theta[k:k + p.numel()].reshape(p.shape))
             k += p.numel()
+    losses = loss_buf.cpu().tolist()
     if loss_save is not None:
-        loss_save.extend(loss_buf.cpu().tolist())
+        loss_save.extend(losses)
+    if writer is not None:                       # the per-step scalars of bear_net.py:285-287 / bear_ref.py:353-355, written after the replay
+        for i, val in enumerate(losses):
+            writer.add_scalar("elbo", val, i + 1)
     return params, h_signed, ar_func
 
 

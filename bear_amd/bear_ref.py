@@ -80,10 +80,10 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
                               ds_loc, ds_loc_ref, device)
     res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device)
     n_batches = len(res.batches)
-    if (1 <= n_batches <= _train.GRAPH_MAX_BATCHES and acc_steps == 1 and optimizer_name == "Adam" and writer is None
+    if (1 <= n_batches <= _train.GRAPH_MAX_BATCHES and acc_steps == 1 and optimizer_name == "Adam"
             and dist.world()[1] == 1 and all(b["rows"] > 0 for b in res.batches) and data.repeats > 1
             and not os.environ.get("BEAR_AMD_NO_GRAPH")):
-        return _train_stop_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, learning_rate, train_ar, loss_save, device)
+        return _train_stop_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, learning_rate, train_ar, loss_save, device, writer)
     acc = torch.zeros(3, dtype=torch.float64)
     loss, step = 0.0, 1
     out = torch.zeros(4, dtype=torch.float64, device=device)
@@ -112,7 +112,7 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
     return params, h_signed, ar_func
 
 
-def _train_stop_graph(res, steps, num_kmers, params, h_signed, ar_func, learning_rate, train_ar, loss_save, device):
+def _train_stop_graph(res, steps, num_kmers, params, h_signed, ar_func, learning_rate, train_ar, loss_save, device, writer=None):
     """Resident batches, Adam, one GPU: the whole optimizer step (constants from the parameters, planned kernel,
     finalize, Adam) is enqueued once, captured in a HIP graph and replayed ``steps`` times -- no host round trip per step
     (the reference traces its step with tf.function, bear_ref.py:207; at 1365 contexts the eager loop is launch- and
@@ -135,8 +135,12 @@ def _train_stop_graph(res, steps, num_kmers, params, h_signed, ar_func, learning
     with torch.no_grad():
         for p, val in zip(params[:3], theta.cpu()):
             p.copy_(val)
+    losses = loss_buf.cpu().tolist()
     if loss_save is not None:
-        loss_save.extend(loss_buf.cpu().tolist())
+        loss_save.extend(losses)
+    if writer is not None:                       # the per-step scalars of bear_net.py:285-287 / bear_ref.py:353-355, written after the replay
+        for i, val in enumerate(losses):
+            writer.add_scalar("elbo", val, i + 1)
     return params, h_signed, ar_func
 
 

@@ -359,3 +359,16 @@ def test_bear_net_cnn_graph_replay_matches_eager(train_ar, ysd1):
     assert len(runs[0][0]) == steps and np.allclose(runs[0][0], runs[1][0], rtol=1e-8)
     for a, b in zip(runs[0][1], runs[1][1]):
         assert np.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_graph_path_feeds_the_writer(ysd1):
+    class W:
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, name, value, step):
+            self.rows.append((name, value, step))
+    data = dataloader.dataloader(YSD1, "dna", 700, 3)
+    w, ls = W(), []
+    bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False, writer=w, loss_save=ls)
+    assert [r[2] for r in w.rows] == [1, 2, 3, 4, 5, 6] and [r[1] for r in w.rows] == ls and w.rows[0][0] == "elbo"
