@@ -7,6 +7,7 @@ log-likelihood, its gradient w.r.t. ``h_signed`` and w.r.t. the AR rows come fro
 ``bear_dm_prior_f64``; the row gradient is fed back through ``ar_func`` by ``Tensor.backward``.
 """
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -60,12 +61,19 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
                  and dist.world()[1] == 1 and all(b["rows"] > 0 for b in res.batches) and data.repeats > 1
                  and not os.environ.get("BEAR_AMD_NO_GRAPH"))
     if fused_mat is not None and graphable:
-        return _train_linear_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, fused_mat, lag, learning_rate, train_ar,
-                                   loss_save, device, writer)
+        try:
+            return _train_linear_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, fused_mat, lag, learning_rate, train_ar,
+                                       loss_save, device, writer)
+        except RuntimeError as err:     # stream capture unavailable: the eager loop below runs the same kernels
+            warnings.warn(f"HIP-graph capture of the training step failed ({err}); using the eager loop")
     cnn_ok = (getattr(ar_func, "fused", False) and alphabet_size == 4 and len(ar_params) == 8
               and all(a is b for a, b in zip(getattr(ar_func, "cnn_params", []), ar_params)))
     if cnn_ok and graphable:
-        return _train_cnn_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, lag, learning_rate, train_ar, loss_save, device, writer)
+        try:
+            return _train_cnn_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, lag, learning_rate, train_ar, loss_save, device,
+                                    writer)
+        except RuntimeError as err:
+            warnings.warn(f"HIP-graph capture of the training step failed ({err}); using the eager loop")
     for _ in range(data.repeats):
         for k in range(n_batches):
             e = res.batches[k]

@@ -6,6 +6,7 @@ Same entry points and argument meaning as the reference: ``train`` (bear_ref.py:
 launch of ``bear_dm_ref[_plan]_f64`` per batch shard plus one all-reduce of 4 doubles.
 """
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -83,7 +84,11 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
     if (1 <= n_batches <= _train.GRAPH_MAX_BATCHES and acc_steps == 1 and optimizer_name == "Adam"
             and dist.world()[1] == 1 and all(b["rows"] > 0 for b in res.batches) and data.repeats > 1
             and not os.environ.get("BEAR_AMD_NO_GRAPH")):
-        return _train_stop_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, learning_rate, train_ar, loss_save, device, writer)
+        try:
+            return _train_stop_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, learning_rate, train_ar, loss_save, device,
+                                     writer)
+        except RuntimeError as err:     # stream capture unavailable: the eager loop below runs the same kernels (parameters untouched so far)
+            warnings.warn(f"HIP-graph capture of the training step failed ({err}); using the eager loop")
     acc = torch.zeros(3, dtype=torch.float64)
     loss, step = 0.0, 1
     out = torch.zeros(4, dtype=torch.float64, device=device)
