@@ -22,6 +22,8 @@ SYMBOLS = [
     "bear_count_rows", "bear_parse_counts_tsv", "bear_log_gamma_f64", "bear_logdir_sample_f64",
     "bear_stat_source", "bear_cache_write", "bear_cache_info", "bear_cache_read", "bear_shuffle_rows", "bear_shuffle_source_row",
     "bear_stream_read", "bear_encode_kmers_i8", "bear_ref_train_step_f64", "bear_net_linear_train_step_f64", "bear_cnn_reserve", "bear_net_cnn_train_step_f64", "bear_cnn_param_count", "bear_cnn_forward_f64", "bear_cnn_backward_f64",
+    "bear_dm_prior_plan_dev_f64", "bear_train_apply_f64", "bear_ref_train_reduce_f64", "bear_net_linear_train_reduce_f64", "bear_net_cnn_train_reduce_f64",
+    "bear_shard_rows_count", "bear_parse_counts_tsv_shard",
     "bear_kmer_sort_create", "bear_kmer_sort_reduce", "bear_kmer_sort_destroy", "bear_count_last_hip_error", "bear_write_counts_tsv", "bear_fastx_size", "bear_fastx_encode",
 ]
 
@@ -92,10 +94,18 @@ def _load():
     L.bear_fastx_size.argtypes = [ctypes.c_char_p, cint, cint, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     L.bear_fastx_encode.argtypes = [ctypes.c_char_p, cint, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
     L.bear_ref_train_step_f64.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp, vp, dbl, cint, dbl, dbl, vp, vp, u64, vp]
-    L.bear_net_linear_train_step_f64.argtypes = [vp, vp, vp, vp, cint, u64, vp, vp, vp, vp, vp, dbl, cint, dbl, dbl, vp, vp, u64, vp]
+    L.bear_net_linear_train_step_f64.argtypes = [vp, vp, vp, vp, cint, u64, vp, vp, vp, vp, vp, dbl, cint, dbl, dbl, vp, u64, vp]
     L.bear_cnn_reserve.argtypes = [vp, u64, cint, cint, cint, cint]
     L.bear_net_cnn_train_step_f64.argtypes = [vp, vp, vp, vp, u64, cint, cint, cint, cint, vp, vp, vp, vp, vp, vp, vp, vp, dbl, cint, dbl,
-                                              dbl, vp, vp, u64, vp]
+                                              dbl, vp, u64, vp]
+    L.bear_dm_prior_plan_dev_f64.argtypes = [vp, vp, vp, vp, u64, vp, dbl, cint, cint, vp, vp, vp]
+    L.bear_train_apply_f64.argtypes = [vp, cint, vp, vp, vp, vp, dbl, dbl, cint, vp, u64, vp]
+    L.bear_ref_train_reduce_f64.argtypes = [vp, vp, vp, vp, u64, vp, dbl, cint, vp, vp]
+    L.bear_net_linear_train_reduce_f64.argtypes = [vp, vp, vp, vp, cint, u64, vp, dbl, cint, vp, vp]
+    L.bear_net_cnn_train_reduce_f64.argtypes = [vp, vp, vp, vp, u64, cint, cint, cint, cint, vp, vp, vp, vp, dbl, cint, vp, vp]
+    L.bear_shard_rows_count.argtypes = [u64, u64, u64, u64, cint, cint, ctypes.POINTER(u64)]
+    L.bear_parse_counts_tsv_shard.argtypes = [ctypes.c_char_p, cint, cint, u64, u64, u64, u64, cint, cint, u64, vp, vp, ctypes.POINTER(u64),
+                                              ctypes.POINTER(u64)]
     L.bear_count_rows.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]
     L.bear_parse_counts_tsv.argtypes = [ctypes.c_char_p, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
     for name in SYMBOLS:

@@ -1,11 +1,13 @@
 """Shared machinery of the bear_net / bear_ref drivers: resident shards, Keras-equivalent Adam,
 the per-step reduce, and the held-out evaluation built on the DM kernels."""
 import math
+import os
+import warnings
 
 import numpy as np
 import torch
 
-from . import core, dist, kernels
+from . import _lib, core, dist, kernels
 from .dataloader import CountDataset
 
 epsilon = core.epsilon
@@ -36,10 +38,26 @@ class KerasAdam:
             p.sub_(lr_t * m / (v.sqrt() + self.eps))
 
 
+# tf.keras optimizers reachable by name (bear_net.py:264-265 `getattr(tf.keras.optimizers, optimizer_name)(learning_rate)`) whose
+# update rule torch.optim reproduces exactly once Keras' defaults are passed explicitly (epsilon 1e-7 everywhere, RMSprop rho 0.9,
+# Adagrad initial accumulator 0.1, Adadelta rho 0.95).  Adam has its own class (Keras puts epsilon outside the bias correction).
+_KERAS_AS_TORCH = {
+    "SGD": (torch.optim.SGD, {}),
+    "RMSprop": (torch.optim.RMSprop, {"alpha": 0.9, "eps": 1e-7}),   # TF's kernel has epsilon inside the root: equal to O(1e-7)
+    "Adagrad": (torch.optim.Adagrad, {"initial_accumulator_value": 0.1, "eps": 1e-7}),
+    "Adadelta": (torch.optim.Adadelta, {"rho": 0.95, "eps": 1e-7}),
+}
+
+
 def make_optimizer(name, params, learning_rate):
     if name == "Adam":
         return KerasAdam(params, learning_rate)
-    opt = getattr(torch.optim, name)(params, lr=learning_rate)
+    if name not in _KERAS_AS_TORCH:
+        raise ValueError(f"optimizer_name {name!r}: supported are Adam, " + ", ".join(sorted(_KERAS_AS_TORCH))
+                         + " (tf.keras update rules with Keras defaults)")
+    cls, kw = _KERAS_AS_TORCH[name]
+    params = list(params)
+    opt = cls(params, lr=learning_rate, **kw)
 
     class _Wrap:
         def apply_gradients(self, grads):
@@ -85,15 +103,17 @@ class ResidentBatches:
             # whole columns go up once, are permuted by one gather pass each (same seed: columns stay aligned), and the
             # batches below are slices of the permuted slabs
             for name, col in columns.items():
-                up = device_column(col, 0, data.num_rows)
+                up = device_column(col, 0, data.local_rows)
                 shuffled[name] = kernels.shuffle_rows(up, data.shuffle_seed)
                 del up
             if want_codes:
-                shuffled["codes"] = kernels.shuffle_rows(device_codes(0, data.num_rows), data.shuffle_seed)
-        for a, b in data.batch_bounds():
-            lo, hi = dist.shard_rows(b - a)
-            lo, hi = a + lo, a + hi
-            entry = {"global_rows": b - a, "rows": hi - lo, "row0": lo}
+                shuffled["codes"] = kernels.shuffle_rows(device_codes(0, data.local_rows), data.shuffle_seed)
+        rank, world = dist.world()
+        if shuffled and data.shard is not None:
+            raise ValueError("a sharded table cannot be shuffled on the device")
+        for (a, b), (g0, g1, off) in zip(data.batch_bounds(), data.rank_pieces(rank, world)):
+            lo, hi = off, off + (g1 - g0)           # this rank's piece of the batch inside the dataset's arrays
+            entry = {"global_rows": b - a, "rows": hi - lo, "row0": g0}
             for name, col in columns.items():
                 if shuffled:
                     entry[name] = shuffled[name][lo:hi].clone()
@@ -111,6 +131,132 @@ class ResidentBatches:
         if key not in e["plans"]:
             e["plans"][key] = kernels.Plan(e[column], ncol)
         return e["plans"][key]
+
+
+def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimizer_name, train_ar, acc_steps, device):
+    """The optimizer loop with every moving quantity in device memory (bear_net.py:292-310 / bear_ref.py:360-381 without a host
+    round trip per step).  Per batch k: ``reduce_fns[k](packed)`` enqueues this rank's shard reduce into
+    ``packed = [sum LL, d/d theta]``; with several ranks ONE all-reduce of ``packed`` follows on the same stream (bear_net.py:278-290);
+    then the update: gradients ``scale_k * packed[1:]`` summed over ``acc_steps`` batches (bear_net.py:193-196: summed, not averaged),
+    applied by tf.keras Adam on the device (``bear_train_apply_f64``) or a Keras-equivalent torch optimizer.  With one rank, Adam
+    and no accumulation the epoch is captured in a HIP graph and replayed.  ``theta`` is updated in place; returns the logged
+    "elbo" of every optimizer step, ``-(sum of the scaled losses) / acc_steps`` (bear_net.py:303-305), read back once at the end."""
+    n_theta, n_batches = theta.numel(), len(reduce_fns)
+    world = dist.world()[1]
+    packed = torch.zeros(n_theta + 1, dtype=torch.float64, device=device)
+    n_steps = (repeats * n_batches) // acc_steps
+    loss_buf = torch.zeros(max(n_steps, 1), dtype=torch.float64, device=device)
+    adam = optimizer_name == "Adam"
+    if adam:
+        m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+        t = torch.zeros(1, dtype=torch.float64, device=device)
+
+        def update(vec, scale):
+            kernels.train_apply(theta, vec, m, v, t, learning_rate, scale, loss_buf, train_ar=train_ar)
+    else:
+        h_view, rest_view = theta[0:1], theta[1:]          # leaves sharing theta's storage: the optimizer updates theta in place
+        opt = make_optimizer(optimizer_name, [rest_view] if train_ar else [h_view, rest_view], learning_rate)
+        done = [0]
+
+        def update(vec, scale):
+            g = vec[1:] * scale
+            opt.apply_gradients([g[1:]] if train_ar else [g[0:1], g[1:]])      # AR mode: h_signed gets no gradient (bear_net.py:194-196)
+            loss_buf[done[0]:done[0] + 1] = -scale * vec[0:1]
+            done[0] += 1
+
+    def epoch():
+        for fn, scale in zip(reduce_fns, scales):
+            fn(packed)
+            kernels.train_apply(theta, packed, m, v, t, learning_rate, scale, loss_buf, train_ar=train_ar)
+
+    graph = None
+    if (adam and world == 1 and acc_steps == 1 and 1 <= n_batches <= GRAPH_MAX_BATCHES and repeats > 1
+            and not os.environ.get("BEAR_AMD_NO_GRAPH")):
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):        # one epoch: the batches in order, one optimizer step each; nothing runs yet
+                epoch()
+        except (_lib.BearError, torch.cuda.OutOfMemoryError):
+            raise
+        except RuntimeError as err:              # stream capture unavailable: the eager loop below enqueues the same kernels
+            warnings.warn(f"HIP-graph capture of the training step failed ({err}); using the eager loop")
+            graph = None
+    if graph is not None:
+        for _ in range(repeats):
+            graph.replay()
+    else:
+        acc = torch.zeros_like(packed) if acc_steps > 1 else None
+        step = 1
+        for _ in range(repeats):
+            for fn, scale in zip(reduce_fns, scales):
+                fn(packed)
+                dist.allreduce_sum_(packed)
+                if acc is None:
+                    update(packed, scale)
+                else:
+                    acc.add_(packed, alpha=scale)
+                    if step % acc_steps == 0:
+                        update(acc, 1.0)
+                        acc.zero_()
+                step += 1
+    torch.cuda.synchronize()
+    return (loss_buf[:n_steps] / acc_steps).cpu().tolist()
+
+
+def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, optimizer, train_ar, acc_steps, normalized, device):
+    """The optimizer loop for an AR function made of torch ops (any ``ar_funcs`` plugin; bear_net.py:292-310): per batch the
+    prior rows come from ``prior_fn(batch entry)`` with autograd, the planned kernel returns sum LL, d/dh and the gradient rows
+    (h_signed is read from the parameter tensor on the device), ``Tensor.backward`` carries the rows to the parameters, one
+    all-reduce sums the packed ``[sum LL, d/dh, parameter gradients]`` over the ranks, and the optimizer updates the (mirrored)
+    parameters.  No host round trip per step: the logged losses stay on the device until the loop is done."""
+    rest = params[1:]
+    acc = [torch.zeros_like(p) for p in params]
+    out = torch.zeros(2, dtype=torch.float64, device=device)
+    h_dev = h_signed.detach().reshape(1)                      # same storage as the parameter the optimizer updates
+    loss = torch.zeros((), dtype=torch.float64, device=device)
+    logged, step = [], 1
+    for _ in range(repeats):
+        for k, e in enumerate(res.batches):
+            scale = -(num_kmers / e["global_rows"])                    # bear_net.py:190-191 with the global batch
+            for p in rest:
+                p.grad = None
+            if e["rows"]:
+                prior = prior_fn(e)
+                need_rows = prior.requires_grad                        # parameter-free AR function (stop): nothing to feed back
+                r = kernels.dm_prior_planned_dev(res.plan(k, "train", 5), prior.detach(), h_dev, out=out, want_grad=need_rows,
+                                                 train_ar=train_ar, normalized=normalized)
+                if need_rows:
+                    prior.backward(scale * r[1])                       # d loss / d AR parameters
+            else:
+                out.zero_()
+            flat, unpack = dist.pack([out] + [p.grad if p.grad is not None else torch.zeros_like(p) for p in rest])
+            dist.allreduce_sum_(flat)                                  # one packed all-reduce: loss, d/dh, AR grads
+            parts = unpack(flat)
+            loss = loss + scale * parts[0][0]
+            if not train_ar:
+                acc[0] += scale * parts[0][1]                          # AR mode: h_signed gets no gradient (bear_net.py:194-196)
+            for a, g in zip(acc[1:], parts[1:]):
+                a += g.to(a.dtype)
+            if step % acc_steps == 0:
+                logged.append(-loss / acc_steps)
+                optimizer.apply_gradients([None if train_ar else acc[0]] + acc[1:])
+                for a in acc:
+                    a.zero_()
+                loss = torch.zeros((), dtype=torch.float64, device=device)
+            step += 1
+    torch.cuda.synchronize()
+    return torch.stack(logged).cpu().tolist() if logged else []
+
+
+def log_losses(losses, writer, loss_save, acc_steps=1):
+    """The per-step scalars of bear_net.py:303-307 (TensorBoard 'elbo' at batch step acc_steps, 2 acc_steps, ...; loss_save),
+    written once the device loop is done."""
+    if loss_save is not None:
+        loss_save.extend(losses)
+    if writer is not None:
+        for i, val in enumerate(losses):
+            writer.add_scalar("elbo", val, (i + 1) * acc_steps)
 
 
 def counts_f64(t):

@@ -5,9 +5,6 @@ Same entry points and argument meaning as the reference: ``train`` (bear_ref.py:
 (``ar_funcs.make_ar_func_stop``, the reference's bear_stop_*.cfg configurations) a training step is one
 launch of ``bear_dm_ref[_plan]_f64`` per batch shard plus one all-reduce of 4 doubles.
 """
-import os
-import warnings
-
 import numpy as np
 import torch
 
@@ -74,78 +71,29 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
         params, h_signed, ar_func = _create_params(lag, alphabet_size, make_ar_func, af_kwargs, dtype, device)
     else:
         params, h_signed, ar_func = change_scope_params(lag, alphabet_size, make_ar_func, af_kwargs, params_restart, dtype, device)
-    tau_signed, nu_signed = params[1], params[2]
-    optimizer = _train.make_optimizer(optimizer_name, params, learning_rate)
+    dist.broadcast_params(params)                    # mirrored variables: every rank starts from rank 0's values (bear_ref.py:310-321)
     if not ar_func.net_is_stop:
+        optimizer = _train.make_optimizer(optimizer_name, params, learning_rate)
         return _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_ar, acc_steps, writer, loss_save,
                               ds_loc, ds_loc_ref, device)
+    # stop net function: theta = (h_signed, tau_signed, net_weight_signed) lives on the device for the whole run; one step is
+    # constants-from-theta -> planned mode-R kernel -> finalize [-> all-reduce of 4 doubles] -> Adam, no host round trip
     res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device)
-    n_batches = len(res.batches)
-    if (1 <= n_batches <= _train.GRAPH_MAX_BATCHES and acc_steps == 1 and optimizer_name == "Adam"
-            and dist.world()[1] == 1 and all(b["rows"] > 0 for b in res.batches) and data.repeats > 1
-            and not os.environ.get("BEAR_AMD_NO_GRAPH")):
-        try:
-            return _train_stop_graph(res, data.repeats, num_kmers, params, h_signed, ar_func, learning_rate, train_ar, loss_save, device,
-                                     writer)
-        except RuntimeError as err:     # stream capture unavailable: the eager loop below runs the same kernels (parameters untouched so far)
-            warnings.warn(f"HIP-graph capture of the training step failed ({err}); using the eager loop")
-    acc = torch.zeros(3, dtype=torch.float64)
-    loss, step = 0.0, 1
-    out = torch.zeros(4, dtype=torch.float64, device=device)
-    for _ in range(data.repeats):
-        for k in range(n_batches):
-            e = res.batches[k]
-            hs, ts, ns = h_signed.item(), tau_signed.item(), nu_signed.item()
-            if e["rows"] == 0:
-                out.zero_()
-            else:
-                kernels.dm_ref_planned(res.plan(k, "train", 4), e["ref"], hs, ts, ns, out=out, train_ar=train_ar)
-            dist.allreduce_sum_(out)                                   # replaces bear_ref.py:358 + the grad sum of :346-350
-            scaled = (-(num_kmers / e["global_rows"]) * out).cpu()     # loss = -(num_kmers / B) sum LL, bear_ref.py:252-253
-            loss += scaled[0].item()
-            acc += scaled[1:]
-            if step % acc_steps == 0:
-                if writer is not None:
-                    writer.add_scalar("elbo", -loss / acc_steps, step)
-                if loss_save is not None:
-                    loss_save.append(-loss / acc_steps)
-                grads = [None if train_ar else acc[0].clone(), acc[1].clone(), acc[2].clone()]  # AR mode: h gets no gradient
-                optimizer.apply_gradients(grads)
-                acc.zero_()
-                loss = 0.0
-            step += 1
-    return params, h_signed, ar_func
-
-
-def _train_stop_graph(res, steps, num_kmers, params, h_signed, ar_func, learning_rate, train_ar, loss_save, device, writer=None):
-    """Resident batches, Adam, one GPU: the whole optimizer step (constants from the parameters, planned kernel,
-    finalize, Adam) is enqueued once, captured in a HIP graph and replayed ``steps`` times -- no host round trip per step
-    (the reference traces its step with tf.function, bear_ref.py:207; at 1365 contexts the eager loop is launch- and
-    synchronisation-bound).  Parameters and optimizer state live in device memory; the losses come back once at the end."""
-    plans = [res.plan(k, "train", 4) for k in range(len(res.batches))]       # built before the capture (plan creation allocates)
     theta = torch.stack([p.detach().reshape(()) for p in params[:3]]).to(device=device, dtype=torch.float64).contiguous()
-    m, v = torch.zeros(3, dtype=torch.float64, device=device), torch.zeros(3, dtype=torch.float64, device=device)
-    t = torch.zeros(1, dtype=torch.float64, device=device)
-    out = torch.zeros(4, dtype=torch.float64, device=device)
-    loss_buf = torch.zeros(steps * len(res.batches), dtype=torch.float64, device=device)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):                                            # one epoch: the batches in order, one optimizer step each
-        for e, plan in zip(res.batches, plans):
-            kernels.ref_train_step(plan, e["ref"], theta, m, v, t, learning_rate, -(num_kmers / e["global_rows"]), out, loss_buf,
-                                   train_ar=train_ar)
-    for _ in range(steps):
-        graph.replay()
-    torch.cuda.synchronize()
+
+    def reducer(k):
+        e = res.batches[k]
+        if e["rows"] == 0:
+            return lambda packed: packed.zero_()
+        plan = res.plan(k, "train", 4)               # built here, before any capture (plan creation allocates and synchronises)
+        return lambda packed: kernels.ref_train_reduce(plan, e["ref"], theta, packed, train_ar=train_ar)
+    reduce_fns = [reducer(k) for k in range(len(res.batches))]
+    scales = [-(num_kmers / e["global_rows"]) for e in res.batches]       # loss = -(num_kmers / B) sum LL, bear_ref.py:252-253
+    losses = _train.run_device_steps(reduce_fns, scales, theta, data.repeats, learning_rate, optimizer_name, train_ar, acc_steps, device)
     with torch.no_grad():
-        for p, val in zip(params[:3], theta.cpu()):
+        for p, val in zip(params[:3], theta):
             p.copy_(val)
-    losses = loss_buf.cpu().tolist()
-    if loss_save is not None:
-        loss_save.extend(losses)
-    if writer is not None:                       # the per-step scalars of bear_net.py:285-287 / bear_ref.py:353-355, written after the replay
-        for i, val in enumerate(losses):
-            writer.add_scalar("elbo", val, i + 1)
+    _train.log_losses(losses, writer, loss_save, acc_steps)
     return params, h_signed, ar_func
 
 
@@ -155,43 +103,15 @@ def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_
     ``(nw net(kmers) + jukes_cantor(ref, tau)) / (nw + 1)`` are formed by torch ops, the planned kernel returns
     the ELBO, d/dh and the gradient rows, and autograd carries the rows back to tau, the net weight and the
     net parameters -- the same loop as bear_net.train with two more parameters."""
-    rest = params[1:]
     res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device, want_codes=True)
-    acc = [torch.zeros_like(p) for p in params]
-    loss, step = 0.0, 1
-    out = torch.zeros(2, dtype=torch.float64, device=device)
-    for _ in range(data.repeats):
-        for k, e in enumerate(res.batches):
-            scale = -(num_kmers / e["global_rows"])
-            for p in rest:
-                p.grad = None
-            if e["rows"]:
-                if "ref_in" not in e:
-                    e["ref_in"] = _ref_input(e["ref"])
-                prior = ar_func(e["codes"], e["ref_in"]).contiguous()
-                _, grad_rows = kernels.dm_prior_planned(res.plan(k, "train", 5), prior.detach(), h_signed.item(), out=out,
-                                                        want_grad=True, train_ar=train_ar)
-                prior.backward(scale * grad_rows)
-            else:
-                out.zero_()
-            flat, unpack = dist.pack([out] + [p.grad if p.grad is not None else torch.zeros_like(p) for p in rest])
-            dist.allreduce_sum_(flat)
-            parts = unpack(flat)
-            loss += scale * parts[0][0].item()
-            if not train_ar:
-                acc[0] += scale * parts[0][1]
-            for a, g in zip(acc[1:], parts[1:]):
-                a += g.to(a.dtype)
-            if step % acc_steps == 0:
-                if writer is not None:
-                    writer.add_scalar("elbo", -loss / acc_steps, step)
-                if loss_save is not None:
-                    loss_save.append(-loss / acc_steps)
-                optimizer.apply_gradients([None if train_ar else acc[0]] + acc[1:])
-                for a in acc:
-                    a.zero_()
-                loss = 0.0
-            step += 1
+
+    def prior_fn(e):
+        if "ref_in" not in e:
+            e["ref_in"] = _ref_input(e["ref"])
+        return ar_func(e["codes"], e["ref_in"]).contiguous()
+    losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, optimizer, train_ar, acc_steps,
+                                       False, device)
+    _train.log_losses(losses, writer, loss_save, acc_steps)
     return params, h_signed, ar_func
 
 

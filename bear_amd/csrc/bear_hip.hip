@@ -439,6 +439,25 @@ static int grid_plan(const bear_ws *ws, uint64_t n_tiles) {
   return g < 1 ? 1 : (int)g;
 }
 
+static int launch_prior_plan(bear_ws *ws, const bear_plan *plan, const double *prior, uint64_t n_rows, const bear_params &prm,
+                             const bear_params *prm_dev, int train_ar, int prior_normalized, double *out, hipStream_t s) {
+  const int grid = grid_plan(ws, plan->n_tiles);
+  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  if (train_ar)
+    hipLaunchKernelGGL((dm_prior_plan_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
+                       plan_view(plan), lt, ws->partials, prm_dev PLN_DBG_ARG);
+  else if (prior_normalized)
+    hipLaunchKernelGGL((dm_prior_plan_kernel<true, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
+                       plan_view(plan), lt, ws->partials, prm_dev PLN_DBG_ARG);
+  else
+    hipLaunchKernelGGL((dm_prior_plan_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
+                       plan_view(plan), lt, ws->partials, prm_dev PLN_DBG_ARG);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
 int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
                            uint64_t n_rows, double h_signed, double eps, int train_ar, int prior_normalized,
                            double *out, void *stream) {
@@ -448,26 +467,11 @@ int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *c
   if (plan->ncol != 5 || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
     return BEAR_ERR_INVALID_ARG;
   if (misaligned(prior) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
-  hipStream_t s = static_cast<hipStream_t>(stream);
   bear_params prm;
   memset(&prm, 0, sizeof(prm));
   prm.inv_h = 1.0 / exp(h_signed);
   prm.eps = eps;
-  const int grid = grid_plan(ws, plan->n_tiles);
-  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
-  if (train_ar)
-    hipLaunchKernelGGL((dm_prior_plan_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
-                       plan_view(plan), lt, ws->partials PLN_DBG_ARG);
-  else if (prior_normalized)
-    hipLaunchKernelGGL((dm_prior_plan_kernel<true, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
-                       plan_view(plan), lt, ws->partials PLN_DBG_ARG);
-  else
-    hipLaunchKernelGGL((dm_prior_plan_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
-                       plan_view(plan), lt, ws->partials PLN_DBG_ARG);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
-  HIP_TRY(hipGetLastError());
-  return BEAR_OK;
+  return launch_prior_plan(ws, plan, prior, n_rows, prm, nullptr, train_ar, prior_normalized, out, static_cast<hipStream_t>(stream));
 }
 
 static int launch_prior_plan_grad(bear_ws *ws, const bear_plan *plan, const double *prior, const bear_params &prm,
@@ -519,6 +523,25 @@ int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32
                                 static_cast<hipStream_t>(stream));
 }
 
+// h_signed read from device memory (a parameter the optimizer updates on the device): the step is enqueued without the host
+// reading the parameter back.  grad_prior may be NULL (parameter-free ar_func: nothing to feed back).
+int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior, uint64_t n_rows,
+                               const double *h_signed_dev, double eps, int train_ar, int prior_normalized, double *out,
+                               double *grad_prior, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!plan || !out || !h_signed_dev || (n_rows && (!counts || !prior))) return BEAR_ERR_INVALID_ARG;
+  if (plan->ncol != 5 || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
+    return BEAR_ERR_INVALID_ARG;
+  if (misaligned(prior) || misaligned(grad_prior) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bear_params dummy;
+  memset(&dummy, 0, sizeof(dummy));
+  hipLaunchKernelGGL(net_params_kernel, dim3(1), dim3(64), 0, s, h_signed_dev, eps, ws->ref_prm);
+  if (grad_prior) return launch_prior_plan_grad(ws, plan, prior, dummy, ws->ref_prm, train_ar, prior_normalized, out, grad_prior, s);
+  return launch_prior_plan(ws, plan, prior, n_rows, dummy, ws->ref_prm, train_ar, prior_normalized, out, s);
+}
+
 int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref,
                          uint64_t n_rows, double h_signed, double tau_signed, double nu_signed, double eps,
                          int train_ar, double *out, void *stream) {
@@ -551,15 +574,33 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
   return BEAR_OK;
 }
 
-int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
-                            double *theta, double *adam_m, double *adam_v, double *adam_t, double eps, int train_ar,
-                            double learning_rate, double scale, double *out, double *loss_buf, uint64_t loss_cap, void *stream) {
+// ---- optimizer step in two halves: the shard's reduce (constants from theta -> planned kernel -> finalize into `packed`) and the
+// apply (tf.keras Adam on theta from packed).  One rank runs them back to back (bear_*_train_step_f64, graph-capturable);
+// several ranks put ONE all-reduce of `packed` between them (bear_net.py:278-290) -- no host round trip either way.
+static int launch_train_apply(double *theta, int n_theta, const double *packed, double *adam_m, double *adam_v, double *adam_t,
+                              double learning_rate, double scale, int train_ar, double *loss_buf, uint64_t loss_cap, hipStream_t s) {
+  hipLaunchKernelGGL(adam_vec_kernel, dim3((n_theta + 255) / 256), dim3(256), 0, s, theta, packed, packed + 2, n_theta - 1, adam_m, adam_v,
+                     adam_t, learning_rate, scale, train_ar, loss_buf, (unsigned long long)loss_cap);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, adam_t);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_train_apply_f64(double *theta, int n_theta, const double *packed, double *adam_m, double *adam_v, double *adam_t,
+                         double learning_rate, double scale, int train_ar, double *loss_buf, uint64_t loss_cap, void *stream) {
+  if (!theta || !packed || !adam_m || !adam_v || !adam_t || n_theta < 1) return BEAR_ERR_INVALID_ARG;
+  return launch_train_apply(theta, n_theta, packed, adam_m, adam_v, adam_t, learning_rate, scale, train_ar, loss_buf, loss_cap,
+                            static_cast<hipStream_t>(stream));
+}
+
+int bear_ref_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
+                              const double *theta, double eps, int train_ar, double *packed, void *stream) {
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
-  if (!plan || !out || !theta || !adam_m || !adam_v || !adam_t || !n_rows || !train || !ref) return BEAR_ERR_INVALID_ARG;
+  if (!plan || !packed || !theta || !n_rows || !train || !ref) return BEAR_ERR_INVALID_ARG;
   if (plan->ncol != 4 || plan->n_rows != n_rows || plan->counts != train || plan->device != ws->device)
     return BEAR_ERR_INVALID_ARG;
-  if (misaligned(ref) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  if (misaligned(ref) || (reinterpret_cast<uintptr_t>(packed) & 7u)) return BEAR_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   bear_params dummy;
   memset(&dummy, 0, sizeof(dummy));
@@ -571,11 +612,19 @@ int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *
   else
     hipLaunchKernelGGL(dm_ref_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, dummy, plan_view(plan),
                        reinterpret_cast<const double2 *>(ws->logtab), ws->partials, static_cast<const bear_params *>(ws->ref_prm));
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 4, out);
-  hipLaunchKernelGGL(adam_ref_kernel, dim3(1), dim3(64), 0, s, theta, out, adam_m, adam_v, adam_t, learning_rate, scale, train_ar,
-                     loss_buf, (unsigned long long)loss_cap);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 4, packed);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
+}
+
+int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
+                            double *theta, double *adam_m, double *adam_v, double *adam_t, double eps, int train_ar,
+                            double learning_rate, double scale, double *out, double *loss_buf, uint64_t loss_cap, void *stream) {
+  if (!adam_m || !adam_v || !adam_t) return BEAR_ERR_INVALID_ARG;
+  int st = bear_ref_train_reduce_f64(ws, plan, train, ref, n_rows, theta, eps, train_ar, out, stream);
+  if (st != BEAR_OK) return st;
+  return launch_train_apply(theta, 3, out, adam_m, adam_v, adam_t, learning_rate, scale, train_ar, loss_buf, loss_cap,
+                            static_cast<hipStream_t>(stream));
 }
 
 int bear_dm_items_f64(bear_ws *ws, const double *x, const uint32_t *c, uint64_t n, int path, double *D, double *P,
@@ -650,16 +699,13 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
 }
 
 // ---- held-out evaluation / BMM marginal (kernels_eval.h) ------------------------------------------------
-int bear_net_linear_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, int lag,
-                                   uint64_t n_rows, double *theta, double *adam_m, double *adam_v, double *adam_t, double *grad_mat,
-                                   double eps, int train_ar, double learning_rate, double scale, double *out, double *loss_buf,
-                                   uint64_t loss_cap, void *stream) {
+int bear_net_linear_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, int lag,
+                                     uint64_t n_rows, const double *theta, double eps, int train_ar, double *packed, void *stream) {
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
-  if (!plan || !out || !theta || !adam_m || !adam_v || !adam_t || !grad_mat || lag < 1 || lag > LIN_MAX_LAG || !n_rows)
-    return BEAR_ERR_INVALID_ARG;
+  if (!plan || !packed || !theta || lag < 1 || lag > LIN_MAX_LAG || !n_rows) return BEAR_ERR_INVALID_ARG;
   if (plan->counts != counts || plan->n_rows != n_rows || plan->ncol != 5 || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
-  if (!kmer_code || misaligned(kmer_code) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  if (!kmer_code || misaligned(kmer_code) || (reinterpret_cast<uintptr_t>(packed) & 7u)) return BEAR_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   bear_params dummy;
   memset(&dummy, 0, sizeof(dummy));
@@ -675,14 +721,21 @@ int bear_net_linear_train_step_f64(bear_ws *ws, const bear_plan *plan, const uin
     hipLaunchKernelGGL(dm_linear_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
                        reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, dummy, plan_view(plan), lt, ws->partials,
                        ws->lin_partials, static_cast<const bear_params *>(ws->ref_prm));
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
-  hipLaunchKernelGGL(linear_finalize_kernel, dim3((lag * 25 + 3) / 4), dim3(256), 0, s, ws->lin_partials, grid, lag * 25, grad_mat);
-  const int n_rest = lag * 25;
-  hipLaunchKernelGGL(adam_vec_kernel, dim3((n_rest + 1 + 255) / 256), dim3(256), 0, s, theta, out, grad_mat, n_rest, adam_m, adam_v,
-                     adam_t, learning_rate, scale, train_ar, loss_buf, (unsigned long long)loss_cap);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, adam_t);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, packed);
+  hipLaunchKernelGGL(linear_finalize_kernel, dim3((lag * 25 + 3) / 4), dim3(256), 0, s, ws->lin_partials, grid, lag * 25, packed + 2);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
+}
+
+int bear_net_linear_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, int lag,
+                                   uint64_t n_rows, double *theta, double *adam_m, double *adam_v, double *adam_t, double *packed,
+                                   double eps, int train_ar, double learning_rate, double scale, double *loss_buf,
+                                   uint64_t loss_cap, void *stream) {
+  if (!adam_m || !adam_v || !adam_t) return BEAR_ERR_INVALID_ARG;
+  int st = bear_net_linear_train_reduce_f64(ws, plan, counts, kmer_code, lag, n_rows, theta, eps, train_ar, packed, stream);
+  if (st != BEAR_OK) return st;
+  return launch_train_apply(theta, 1 + lag * 25, packed, adam_m, adam_v, adam_t, learning_rate, scale, train_ar, loss_buf, loss_cap,
+                            static_cast<hipStream_t>(stream));
 }
 
 static int launch_eval(bear_ws *ws, const uint32_t *test, const uint32_t *train, const double *prior, uint64_t n_rows,
@@ -956,18 +1009,14 @@ int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, in
   return BEAR_OK;
 }
 
-int bear_net_cnn_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,
-                                int lag, int filter_width, int num_filters, int layer1_width, double *theta, double *adam_m,
-                                double *adam_v, double *adam_t, double *prior_buf, double *t1_buf, double *grad_rows_buf,
-                                double *grad_flat, double eps, int train_ar, double learning_rate, double scale, double *out,
-                                double *loss_buf, uint64_t loss_cap, void *stream) {
+int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,
+                                  int lag, int filter_width, int num_filters, int layer1_width, const double *theta, double *prior_buf,
+                                  double *t1_buf, double *grad_rows_buf, double eps, int train_ar, double *packed, void *stream) {
   int st = cnn_check(ws, lag, filter_width, num_filters, layer1_width);
   if (st != BEAR_OK) return st;
-  if (!plan || !out || !theta || !adam_m || !adam_v || !adam_t || !prior_buf || !t1_buf || !grad_rows_buf || !grad_flat || !n_rows ||
-      !kmer_code)
-    return BEAR_ERR_INVALID_ARG;
+  if (!plan || !packed || !theta || !prior_buf || !t1_buf || !grad_rows_buf || !n_rows || !kmer_code) return BEAR_ERR_INVALID_ARG;
   if (plan->counts != counts || plan->n_rows != n_rows || plan->ncol != 5 || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
-  if (misaligned(prior_buf) || misaligned(t1_buf) || misaligned(grad_rows_buf) || (reinterpret_cast<uintptr_t>(out) & 7u))
+  if (misaligned(prior_buf) || misaligned(t1_buf) || misaligned(grad_rows_buf) || (reinterpret_cast<uintptr_t>(packed) & 7u))
     return BEAR_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const cnn_dims D = cnn_make_dims(lag, filter_width);
@@ -982,15 +1031,23 @@ int bear_net_cnn_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32
   }
   bear_params dummy;
   memset(&dummy, 0, sizeof(dummy));
-  st = launch_prior_plan_grad(ws, plan, prior_buf, dummy, ws->ref_prm, train_ar, 1, out, grad_rows_buf, s);   // softmax rows: normalised
+  st = launch_prior_plan_grad(ws, plan, prior_buf, dummy, ws->ref_prm, train_ar, 1, packed, grad_rows_buf, s);   // softmax rows: normalised
   if (st != BEAR_OK) return st;
-  st = launch_cnn_backward(ws, D, kmer_code, n_rows, filter_width, params, t1_buf, prior_buf, grad_rows_buf, grad_flat, s, 0);
+  return launch_cnn_backward(ws, D, kmer_code, n_rows, filter_width, params, t1_buf, prior_buf, grad_rows_buf, packed + 2, s, 0);
+}
+
+int bear_net_cnn_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,
+                                int lag, int filter_width, int num_filters, int layer1_width, double *theta, double *adam_m,
+                                double *adam_v, double *adam_t, double *prior_buf, double *t1_buf, double *grad_rows_buf,
+                                double *packed, double eps, int train_ar, double learning_rate, double scale, double *loss_buf,
+                                uint64_t loss_cap, void *stream) {
+  if (!adam_m || !adam_v || !adam_t) return BEAR_ERR_INVALID_ARG;
+  int st = bear_net_cnn_train_reduce_f64(ws, plan, counts, kmer_code, n_rows, lag, filter_width, num_filters, layer1_width, theta, prior_buf,
+                                         t1_buf, grad_rows_buf, eps, train_ar, packed, stream);
   if (st != BEAR_OK) return st;
-  hipLaunchKernelGGL(adam_vec_kernel, dim3((D.total + 1 + 255) / 256), dim3(256), 0, s, theta, out, grad_flat, D.total, adam_m, adam_v,
-                     adam_t, learning_rate, scale, train_ar, loss_buf, (unsigned long long)loss_cap);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, adam_t);
-  HIP_TRY(hipGetLastError());
-  return BEAR_OK;
+  const cnn_dims D = cnn_make_dims(lag, filter_width);
+  return launch_train_apply(theta, 1 + D.total, packed, adam_m, adam_v, adam_t, learning_rate, scale, train_ar, loss_buf, loss_cap,
+                            static_cast<hipStream_t>(stream));
 }
 
 int bear_stream_read(bear_ws *ws, const void *src, uint64_t n_bytes, void *stream) {

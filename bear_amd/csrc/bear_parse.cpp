@@ -65,14 +65,25 @@ extern "C" int bear_count_rows(const char *path, uint64_t *n_rows_out) {
 
 namespace {
 // Parses the lines of [p, end) into rows row .. ; returns the status and the number of rows written.
+// `keep(g)` (g = index of the line among the non-blank lines of [p, end), counted from g0) selects the lines that are decoded;
+// the others are skipped at memchr speed.  Kept lines fill consecutive rows.
+struct keep_all {
+  bool operator()(uint64_t) const { return true; }
+};
+template <class Keep>
 int parse_range(const char *p, const char *end, int num_ds, int lag, uint64_t max_rows, uint64_t row, uint64_t row_limit,
-                char *kmers, uint32_t *counts, uint64_t *rows_done) {
+                char *kmers, uint32_t *counts, uint64_t *rows_done, uint64_t g0 = 0, Keep keep = Keep()) {
   const int per_row = num_ds * BEAR_ROW_WIDTH;
   const uint64_t row_begin = row;
+  uint64_t g = g0;
   while (p < end && row < row_limit) {
     const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
     const char *le = nl ? nl : end;
     if (blank_line(p, le)) {
+      p = le + 1;
+      continue;
+    }
+    if (!keep(g++)) {
       p = le + 1;
       continue;
     }
@@ -153,7 +164,7 @@ extern "C" int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint
   std::vector<uint64_t> first(nt + 1, 0), done(nt, 0);
   std::vector<int> status(nt, BEAR_OK);
   if (nt == 1) {
-    st = parse_range(base, end, num_ds, lag, max_rows, 0, max_rows, kmers, counts, &done[0]);
+    st = parse_range<keep_all>(base, end, num_ds, lag, max_rows, 0, max_rows, kmers, counts, &done[0]);
     if (st != BEAR_OK) return st;
     *n_rows_out = done[0];
     return BEAR_OK;
@@ -170,7 +181,7 @@ extern "C" int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint
       th.emplace_back([&, k] {
         const uint64_t lim = first[k + 1] < max_rows ? first[k + 1] : max_rows;
         if (first[k] >= lim) return;
-        status[k] = parse_range(cut[k], cut[k + 1], num_ds, lag, max_rows, first[k], lim, kmers, counts, &done[k]);
+        status[k] = parse_range<keep_all>(cut[k], cut[k + 1], num_ds, lag, max_rows, first[k], lim, kmers, counts, &done[k]);
       });
     for (auto &t : th) t.join();
   }
@@ -180,6 +191,119 @@ extern "C" int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint
     total += done[k];
   }
   *n_rows_out = total;
+  return BEAR_OK;
+}
+
+// ------------------------------------------------------------------ one rank's rows of a row-sharded table
+// Training shards every batch over the ranks (bear_net.py:273 `experimental_distribute_dataset`): of batch k = global rows
+// [kB, min(kB + B, N)) with m rows, rank r owns the contiguous piece [lo, hi) with base = m / W, extra = m % W,
+// lo = r base + min(r, extra), hi = lo + base + (r < extra)  (bear_amd.dist.shard_rows).  A rank decodes only its own lines;
+// the other lines are stepped over at memchr speed, so W ranks decode 1/W of the text each.
+namespace {
+struct shard_map {
+  uint64_t B, N, W, r;
+  void piece(uint64_t m, uint64_t *lo, uint64_t *hi) const {
+    const uint64_t base = m / W, extra = m % W;
+    *lo = r * base + (r < extra ? r : extra);
+    *hi = *lo + base + (r < extra ? 1 : 0);
+  }
+  bool member(uint64_t g) const {
+    if (g >= N) return false;
+    const uint64_t a = (g / B) * B, m = (N - a < B) ? N - a : B;
+    uint64_t lo, hi;
+    piece(m, &lo, &hi);
+    return g - a >= lo && g - a < hi;
+  }
+  uint64_t below(uint64_t G) const {   // number of member rows with global index < G
+    if (G > N) G = N;
+    uint64_t lo, hi;
+    piece(B, &lo, &hi);
+    const uint64_t k = G / B, a = k * B;
+    uint64_t n = k * (hi - lo);
+    if (a < N) {
+      const uint64_t m = (N - a < B) ? N - a : B, off = G - a;
+      piece(m, &lo, &hi);
+      n += off <= lo ? 0 : (off >= hi ? hi - lo : off - lo);
+    }
+    return n;
+  }
+};
+struct keep_shard {
+  shard_map S;
+  uint64_t row_base;
+  bool operator()(uint64_t g) const { return S.member(row_base + g); }
+};
+}  // namespace
+
+extern "C" int bear_shard_rows_count(uint64_t row_base, uint64_t file_rows, uint64_t total_rows, uint64_t batch_rows, int rank,
+                                     int world, uint64_t *n_local_out) {
+  if (!n_local_out || batch_rows == 0 || world < 1 || rank < 0 || rank >= world || row_base + file_rows > total_rows)
+    return BEAR_ERR_INVALID_ARG;
+  const shard_map S{batch_rows, total_rows, (uint64_t)world, (uint64_t)rank};
+  *n_local_out = S.below(row_base + file_rows) - S.below(row_base);
+  return BEAR_OK;
+}
+
+extern "C" int bear_parse_counts_tsv_shard(const char *path, int num_ds, int lag, uint64_t skip_lines, uint64_t row_base,
+                                           uint64_t total_rows, uint64_t batch_rows, int rank, int world, uint64_t max_rows,
+                                           char *kmers, uint32_t *counts, uint64_t *n_local_out, uint64_t *n_file_rows_out) {
+  if (!path || !counts || !n_local_out || num_ds < 1 || lag < 0 || batch_rows == 0 || world < 1 || rank < 0 || rank >= world)
+    return BEAR_ERR_INVALID_ARG;
+  *n_local_out = 0;
+  mapped_file f;
+  int st = f.open_ro(path);
+  if (st != BEAR_OK) return st;
+  const char *base = f.data, *end = f.data + f.size;
+  for (uint64_t k = 0; k < skip_lines && base < end; ++k) {   // header lines (dataloader.py:7 `header`)
+    const char *nl = static_cast<const char *>(memchr(base, '\n', (size_t)(end - base)));
+    base = nl ? nl + 1 : end;
+  }
+  const size_t body = (size_t)(end - base);
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *env = getenv("BEAR_PARSE_THREADS")) nt = (unsigned)atoi(env);
+  if (nt < 1) nt = 1;
+  if (nt > 64) nt = 64;
+  if (body < (size_t)(1u << 20)) nt = 1;
+  std::vector<const char *> cut(nt + 1);
+  cut[0] = base;
+  cut[nt] = end;
+  for (unsigned k = 1; k < nt; ++k) {
+    const char *p = base + (body / nt) * k;
+    const char *nl = p < end ? static_cast<const char *>(memchr(p, '\n', (size_t)(end - p))) : nullptr;
+    cut[k] = nl ? nl + 1 : end;
+    if (cut[k] < cut[k - 1]) cut[k] = cut[k - 1];
+  }
+  std::vector<uint64_t> first(nt + 1, 0), done(nt, 0);
+  std::vector<int> status(nt, BEAR_OK);
+  {
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; ++k) th.emplace_back([&, k] { first[k + 1] = count_lines(cut[k], cut[k + 1]); });
+    for (auto &t : th) t.join();
+  }
+  for (unsigned k = 0; k < nt; ++k) first[k + 1] += first[k];
+  const uint64_t file_rows = first[nt];
+  if (n_file_rows_out) *n_file_rows_out = file_rows;
+  if (row_base + file_rows > total_rows) return BEAR_ERR_INVALID_ARG;   // the caller's row count does not match the file
+  const shard_map S{batch_rows, total_rows, (uint64_t)world, (uint64_t)rank};
+  const uint64_t l0 = S.below(row_base);
+  if (S.below(row_base + file_rows) - l0 > max_rows) return BEAR_ERR_INVALID_ARG;
+  {
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; ++k)
+      th.emplace_back([&, k] {
+        const uint64_t out0 = S.below(row_base + first[k]) - l0, out1 = S.below(row_base + first[k + 1]) - l0;
+        if (out0 >= out1) return;
+        status[k] = parse_range<keep_shard>(cut[k], cut[k + 1], num_ds, lag, max_rows, out0, out1, kmers, counts, &done[k], first[k],
+                                            keep_shard{S, row_base});
+      });
+    for (auto &t : th) t.join();
+  }
+  uint64_t total = 0;
+  for (unsigned k = 0; k < nt; ++k) {
+    if (status[k] != BEAR_OK) return status[k];
+    total += done[k];
+  }
+  *n_local_out = total;
   return BEAR_OK;
 }
 

@@ -282,7 +282,14 @@ __device__ __forceinline__ uint32_t pln_dma(void *lds, const void *src, uint32_t
     const unsigned char *g = s + (piece << 10);
     const uint32_t m = srt_uniform(d + (piece << 10));
     if ((piece << 10) + lane * 16u < bytes)
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m) : "memory", "m0");
+      {
+      // M0 is compiler-reserved: saved and restored inside the statement that uses it (no "m0" clobber: that is undefined behaviour)
+      uint32_t keep_m0;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0)
+                   : "v"(g), "s"(m)
+                   : "memory");
+    }
     ++issued;
   }
   return issued;
@@ -293,7 +300,14 @@ __device__ __forceinline__ void pln_dma_piece(void *lds, const void *src, uint32
   const uint32_t m = srt_uniform((uint32_t)(uintptr_t)lds + (piece << 10));
   const unsigned char *g = static_cast<const unsigned char *>(src) + (piece << 10) + lane * 16u;
   if ((piece << 10) + lane * 16u < bytes)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m) : "memory", "m0");
+    {
+      // M0 is compiler-reserved: saved and restored inside the statement that uses it (no "m0" clobber: that is undefined behaviour)
+      uint32_t keep_m0;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0)
+                   : "v"(g), "s"(m)
+                   : "memory");
+    }
 }
 
 // Waits until at most `younger` of this wave's vector-memory operations are outstanding (vmcnt is an
@@ -398,16 +412,18 @@ __device__ __forceinline__ pln_tile pln_desc(const pln_tile (*ring)[PLN_DESC_CHU
 // sum over cells c log(prior + eps); no context terms, no h gradient.
 template <bool NORM, bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kernel(const double *__restrict__ prior,
-                                                                                    uint64_t n_rows, bear_params prm,
+                                                                                    uint64_t n_rows, bear_params prm_arg,
                                                                                     pln_view pv,
                                                                                     const double2 *__restrict__ logtab_g,
-                                                                                    double *__restrict__ partials
+                                                                                    double *__restrict__ partials,
+                                                                                    const bear_params *__restrict__ prm_dev
 #ifdef PLN_STAMPS
                                                                                     , unsigned long long *__restrict__ dbg
 #endif
                                                                                     ) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_n &S = *reinterpret_cast<pln_lds_n *>(srt_smem);
+  const bear_params prm = prm_dev ? *prm_dev : prm_arg;   // device-resident parameters: steps enqueued without a host round trip
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
   double acc[2] = {0.0, 0.0};

@@ -76,7 +76,14 @@ __device__ __forceinline__ void srt_dma(void *lds, const void *src, uint32_t byt
   for (uint32_t piece = wave; piece < (bytes >> 10); piece += SRT_WAVES) {
     const unsigned char *g = s + (piece << 10);
     const uint32_t m = srt_uniform(d + (piece << 10));
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m) : "memory", "m0");
+    {
+      // M0 is compiler-reserved: saved and restored inside the statement that uses it (no "m0" clobber: that is undefined behaviour)
+      uint32_t keep_m0;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0)
+                   : "v"(g), "s"(m)
+                   : "memory");
+    }
   }
 }
 

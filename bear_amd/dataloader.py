@@ -19,9 +19,15 @@ from . import _lib, core, kernels
 
 
 class CountDataset:
-    """Parsed count table: ``kmers`` uint8 [N, lag] (ASCII), ``counts`` uint32 [num_ds, N, A+1]."""
+    """Parsed count table: ``kmers`` uint8 [rows, lag] (ASCII), ``counts`` uint32 [num_ds, rows, A+1].
 
-    def __init__(self, kmers, counts, alphabet, batch_size, dtype=torch.float64, repeats=1, shuffle_seed=None):
+    ``shard = (rank, world)``: the arrays hold only this rank's rows -- of every batch ``[a, b)`` of the table the contiguous
+    piece ``dist.shard_rows(b - a, rank, world)``, pieces in table order -- while ``num_rows`` / ``batch_bounds`` keep describing
+    the whole table (``total_rows`` rows).  That is the input sharding of ``strategy.experimental_distribute_dataset``
+    (bear_net.py:273) done at load time, so a rank never decodes or holds another rank's rows."""
+
+    def __init__(self, kmers, counts, alphabet, batch_size, dtype=torch.float64, repeats=1, shuffle_seed=None, shard=None,
+                 total_rows=None):
         self.shuffle_seed = shuffle_seed   # None: file order; else rows are permuted on the device at upload
         self.kmers = kmers
         self.counts = counts
@@ -29,12 +35,20 @@ class CountDataset:
         self.batch_size = int(batch_size)
         self.dtype = dtype
         self.repeats = int(repeats)
+        self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
+        self.total_rows = int(total_rows) if shard is not None else None
+        if self.shard is not None and self.local_rows != sum(hi - lo for lo, hi in self._pieces()):
+            raise ValueError("sharded CountDataset: the arrays do not hold exactly this rank's rows")
         self._device_cache = {}
 
     # ---- reference-shaped view -----------------------------------------------------------------
     @property
-    def num_rows(self):
+    def local_rows(self):
         return self.counts.shape[1]
+
+    @property
+    def num_rows(self):
+        return self.total_rows if self.shard is not None else self.counts.shape[1]
 
     @property
     def num_ds(self):
@@ -49,13 +63,40 @@ class CountDataset:
         B, N = self.batch_size, self.num_rows
         return [(a, min(a + B, N)) for a in range(0, N, B)]
 
+    def _pieces(self):
+        from . import dist
+        rank, world = self.shard
+        out = []
+        for a, b in self.batch_bounds():
+            lo, hi = dist.shard_rows(b - a, rank, world)
+            out.append((a + lo, a + hi))
+        return out
+
+    def rank_pieces(self, rank, world):
+        """Per batch: (global row range [g0, g1) of `rank`'s piece, offset of g0 in this dataset's arrays)."""
+        from . import dist
+        if self.shard is not None and self.shard != (rank, world):
+            raise ValueError(f"dataset was loaded for rank/world {self.shard}, asked for {(rank, world)}")
+        out, off = [], 0
+        for a, b in self.batch_bounds():
+            lo, hi = dist.shard_rows(b - a, rank, world)
+            out.append((a + lo, a + hi, off if self.shard is not None else a + lo))
+            off += hi - lo
+        return out
+
     def __len__(self):
         return len(self.batch_bounds()) * self.repeats
 
     def __iter__(self):
+        """The reference's batches ``(kmers [B], counts [B, num_ds, A+1])`` in file order; a sharded dataset yields this rank's
+        piece of every batch."""
         np_dtype = np.float64 if self.dtype == torch.float64 else np.float32
+        if self.shard is not None:
+            bounds = [(off, off + g1 - g0) for g0, g1, off in self.rank_pieces(*self.shard)]
+        else:
+            bounds = self.batch_bounds()
         for _ in range(self.repeats):
-            for a, b in self.batch_bounds():
+            for a, b in bounds:
                 km = np.array([bytes(r) for r in self.kmers[a:b]])
                 yield km, torch.from_numpy(self.counts[:, a:b].transpose(1, 0, 2).astype(np_dtype))
 
@@ -64,16 +105,24 @@ class CountDataset:
         ``bmm_likelihood``, tests/test_dataloader.py:48): a lazily mapped view that remembers its source table."""
         return MappedDataset(self, fn)
 
+    def _like(self, **kw):
+        args = dict(alphabet=self.alphabet, batch_size=self.batch_size, dtype=self.dtype, repeats=self.repeats,
+                    shuffle_seed=self.shuffle_seed, shard=self.shard, total_rows=self.total_rows)
+        args.update(kw)
+        return CountDataset(self.kmers, self.counts, **args)
+
     def repeat(self, epochs):
         """tf.data ``.repeat(epochs)`` (models/train_bear_net.py:88)."""
-        return CountDataset(self.kmers, self.counts, self.alphabet, self.batch_size, self.dtype, self.repeats * int(epochs),
-                            self.shuffle_seed)
+        return self._like(repeats=self.repeats * int(epochs))
 
     def shuffle(self, seed):
         """The `shuf` step of docs/usage.rst:191-200 without rewriting the file: training and evaluation see the rows
         in the order ``perm_seed`` (one gather pass on the device at upload, ``bear_shuffle_rows``).  Iterating the
         dataset on the host still yields file order."""
-        return CountDataset(self.kmers, self.counts, self.alphabet, self.batch_size, self.dtype, self.repeats, int(seed))
+        if self.shard is not None:
+            raise ValueError("the device shuffle permutes whole columns: load the table unsharded (or pre-shuffle the file, "
+                             "docs/usage.rst:191-200) to combine it with row sharding")
+        return self._like(shuffle_seed=int(seed))
 
     # ---- packed device view --------------------------------------------------------------------
     def codes(self):
@@ -84,7 +133,7 @@ class CountDataset:
         key = (int(ds_loc), str(device), rows)
         t = self._device_cache.get(key)
         if t is None:
-            a, b = rows if rows is not None else (0, self.num_rows)
+            a, b = rows if rows is not None else (0, self.local_rows)
             t = torch.from_numpy(np.ascontiguousarray(self.counts[ds_loc, a:b]).view(np.int32)).to(device)
             self._device_cache[key] = t
         return t
@@ -111,6 +160,7 @@ class DeviceCountDataset(CountDataset):
         self._host = None
         self.shuffle_seed = shuffle_seed
         self.alphabet, self.batch_size, self.dtype, self.repeats = alphabet, int(batch_size), dtype, int(repeats)
+        self.shard, self.total_rows = None, None      # a device-built table is whole; training slices this rank's rows from it
         self._device_cache = {}
 
     def _download(self):
@@ -121,6 +171,7 @@ class DeviceCountDataset(CountDataset):
     kmers = property(lambda self: self._download()[0])
     counts = property(lambda self: self._download()[1])
     num_rows = property(lambda self: self.counts_dev.shape[1])
+    local_rows = property(lambda self: self.counts_dev.shape[1])
     num_ds = property(lambda self: self.counts_dev.shape[0])
     lag = property(lambda self: self.kmers_dev.shape[1])
 
@@ -138,10 +189,13 @@ class DeviceCountDataset(CountDataset):
 
 def concatenate(datasets):
     """Several count files of one table (models/train_bear_net.py:79-87 interleaves them; rows are
-    independent and pre-shuffled, so concatenation is an equivalent batch stream)."""
+    independent and pre-shuffled, so concatenation is an equivalent batch stream).  Sharded parts must have been loaded
+    with consecutive ``row_base`` and the same ``total_rows``: their local rows concatenate to this rank's rows of the table."""
     d0 = datasets[0]
+    if any(d.shard != d0.shard or d.total_rows != d0.total_rows for d in datasets):
+        raise ValueError("cannot concatenate count tables with different sharding")
     return CountDataset(np.concatenate([d.kmers for d in datasets]), np.concatenate([d.counts for d in datasets], axis=1),
-                        d0.alphabet, d0.batch_size, d0.dtype)
+                        d0.alphabet, d0.batch_size, d0.dtype, shard=d0.shard, total_rows=d0.total_rows)
 
 
 def _sniff_lag(file, header, delim):
@@ -180,40 +234,122 @@ def _load_cache(path, file, num_ds, rows=None):
     return kmers, counts
 
 
+def _cache_meta(path, file, num_ds):
+    """(n_rows, lag) of a valid, fresh binary cache of `file`, or None."""
+    L = _lib.lib()
+    n, lag, nds, ssz, smt = ctypes.c_uint64(), ctypes.c_int(), ctypes.c_int(), ctypes.c_uint64(), ctypes.c_int64()
+    if not os.path.exists(path) or L.bear_cache_info(path.encode(), ctypes.byref(n), ctypes.byref(lag), ctypes.byref(nds),
+                                                     ctypes.byref(ssz), ctypes.byref(smt)) != 0:
+        return None
+    fsz, fmt = ctypes.c_uint64(), ctypes.c_int64()
+    if L.bear_stat_source(str(file).encode(), ctypes.byref(fsz), ctypes.byref(fmt)) != 0:
+        return None
+    if (fsz.value, fmt.value) != (ssz.value, smt.value) or nds.value != num_ds:
+        return None
+    return n.value, lag.value
+
+
+def count_rows(file, header=False):
+    """Number of table rows of a count file (non-empty lines, minus the header line)."""
+    n = ctypes.c_uint64()
+    _lib.check(_lib.lib().bear_count_rows(str(file).encode(), ctypes.byref(n)), "bear_count_rows")
+    return n.value - (1 if header and n.value else 0)
+
+
 def dataloader(file, alphabet, batch_size, num_ds, cache=True, header=False, n_par=1, dtype=torch.float64,
-               binary_cache=None):
+               binary_cache=None, shard=None, row_base=0, total_rows=None):
     """dataloader.py:6-50.  ``cache`` / ``n_par`` are accepted for signature compatibility: the table
     is always parsed once and kept.  ``binary_cache`` (``True``: next to the file; or a directory; default: the
-    ``BEAR_AMD_CACHE_DIR`` environment variable) keeps the parsed table on disk so later runs skip the text."""
-    if header:
-        raise NotImplementedError("dense count tables written by summarize.py have no header")
+    ``BEAR_AMD_CACHE_DIR`` environment variable) keeps the parsed table on disk so later runs skip the text.
+
+    ``shard=(rank, world)``: load only this rank's rows (see ``CountDataset``); ``shard="auto"`` takes them from the initialised
+    ``torch.distributed`` group.  ``row_base`` / ``total_rows`` place the file inside a table made of several files (the batches
+    -- and so the pieces -- are cut on the whole table); by default the file is the table."""
     L = _lib.lib()
+    A1 = len(core.alphabets_tf[alphabet])
+    if A1 != 5:
+        raise NotImplementedError("the HIP kernels are built for 4-letter alphabets (+ stop): dna / rna")
+    if shard == "auto":
+        from . import dist
+        shard = dist.world() if dist.world()[1] > 1 else None
     if binary_cache is None:
         binary_cache = os.environ.get("BEAR_AMD_CACHE_DIR") or None
+    if shard is not None:
+        return _load_shard(file, alphabet, int(batch_size), int(num_ds), header, dtype, binary_cache, shard, int(row_base), total_rows)
     if binary_cache:
         hit = _load_cache(cache_path_for(file, binary_cache), file, num_ds)
         if hit is not None:
             return CountDataset(hit[0], hit[1], alphabet, batch_size, dtype)
-    n = ctypes.c_uint64()
-    _lib.check(L.bear_count_rows(str(file).encode(), ctypes.byref(n)), "bear_count_rows")
+    n_rows = count_rows(file, header)
     lag = _sniff_lag(file, header, b"\t")
-    A1 = len(core.alphabets_tf[alphabet])
-    if A1 != 5:
-        raise NotImplementedError("the HIP kernels are built for 4-letter alphabets (+ stop): dna / rna")
-    kmers = np.zeros((n.value, lag), dtype=np.uint8)
-    counts = np.zeros((num_ds, n.value, A1), dtype=np.uint32)
+    kmers = np.zeros((n_rows, lag), dtype=np.uint8)
+    counts = np.zeros((num_ds, n_rows, A1), dtype=np.uint32)
     got = ctypes.c_uint64()
-    _lib.check(L.bear_parse_counts_tsv(str(file).encode(), int(num_ds), int(lag), n.value, kmers.ctypes.data,
-                                       counts.ctypes.data, ctypes.byref(got)), "bear_parse_counts_tsv")
-    assert got.value == n.value
+    if header:      # the sharded reader with one rank is the plain reader with a header line
+        _lib.check(L.bear_parse_counts_tsv_shard(str(file).encode(), int(num_ds), int(lag), 1, 0, n_rows, max(n_rows, 1), 0, 1, n_rows,
+                                                 kmers.ctypes.data, counts.ctypes.data, ctypes.byref(got), None), "bear_parse_counts_tsv_shard")
+    else:
+        _lib.check(L.bear_parse_counts_tsv(str(file).encode(), int(num_ds), int(lag), n_rows, kmers.ctypes.data,
+                                           counts.ctypes.data, ctypes.byref(got)), "bear_parse_counts_tsv")
+    assert got.value == n_rows
     if binary_cache:
         fsz, fmt = ctypes.c_uint64(), ctypes.c_int64()
         _lib.check(L.bear_stat_source(str(file).encode(), ctypes.byref(fsz), ctypes.byref(fmt)), "bear_stat_source")
         path = cache_path_for(file, binary_cache)
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        _lib.check(L.bear_cache_write(path.encode(), kmers.ctypes.data, counts.ctypes.data, n.value, int(lag), int(num_ds),
+        _lib.check(L.bear_cache_write(path.encode(), kmers.ctypes.data, counts.ctypes.data, n_rows, int(lag), int(num_ds),
                                       fsz.value, fmt.value), "bear_cache_write")
     return CountDataset(kmers, counts, alphabet, batch_size, dtype)
+
+
+def _load_shard(file, alphabet, batch_size, num_ds, header, dtype, binary_cache, shard, row_base, total_rows):
+    """This rank's rows of `file` (global rows [row_base, row_base + file rows) of a table of total_rows rows): from a fresh
+    binary cache when there is one (one ranged read per batch piece), else by the sharded text reader (every rank walks the
+    file, decodes 1 / world of the lines)."""
+    from . import dist
+    L = _lib.lib()
+    rank, world = int(shard[0]), int(shard[1])
+    meta = _cache_meta(cache_path_for(file, binary_cache), file, num_ds) if binary_cache else None
+    file_rows = meta[0] if meta else count_rows(file, header)
+    if total_rows is None:
+        total_rows = row_base + file_rows
+    n_local = ctypes.c_uint64()
+    _lib.check(L.bear_shard_rows_count(row_base, file_rows, int(total_rows), batch_size, rank, world, ctypes.byref(n_local)),
+               "bear_shard_rows_count")
+    lag = meta[1] if meta else _sniff_lag(file, header, b"\t")
+    kmers = np.zeros((n_local.value, lag), dtype=np.uint8)
+    counts = np.zeros((num_ds, n_local.value, 5), dtype=np.uint32)
+    if meta:
+        path, off = cache_path_for(file, binary_cache).encode(), 0
+        for a in range((row_base // batch_size) * batch_size, row_base + file_rows, batch_size):
+            b = min(a + batch_size, int(total_rows))
+            lo, hi = dist.shard_rows(b - a, rank, world)
+            g0, g1 = max(a + lo, row_base), min(a + hi, row_base + file_rows)      # the piece, clipped to this file
+            if g1 <= g0:
+                continue
+            n = g1 - g0
+            tmp = np.zeros((num_ds, n, 5), dtype=np.uint32)
+            _lib.check(L.bear_cache_read(path, g0 - row_base, n, kmers[off:off + n].ctypes.data, tmp.ctypes.data), "bear_cache_read")
+            counts[:, off:off + n] = tmp
+            off += n
+        assert off == n_local.value
+    else:
+        got, seen = ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(L.bear_parse_counts_tsv_shard(str(file).encode(), num_ds, int(lag), 1 if header else 0, row_base, int(total_rows),
+                                                 batch_size, rank, world, n_local.value, kmers.ctypes.data, counts.ctypes.data,
+                                                 ctypes.byref(got), ctypes.byref(seen)), "bear_parse_counts_tsv_shard")
+        assert got.value == n_local.value and seen.value == file_rows
+    if row_base == 0 and file_rows == total_rows:
+        return CountDataset(kmers, counts, alphabet, batch_size, dtype, shard=(rank, world), total_rows=total_rows)
+    return _ShardPart(kmers, counts, alphabet, batch_size, dtype, (rank, world), int(total_rows))
+
+
+class _ShardPart:
+    """One file's share of a sharded multi-file table: only ``concatenate`` makes a dataset of the parts."""
+
+    def __init__(self, kmers, counts, alphabet, batch_size, dtype, shard, total_rows):
+        self.kmers, self.counts, self.alphabet, self.batch_size, self.dtype = kmers, counts, alphabet, batch_size, dtype
+        self.shard, self.total_rows = shard, total_rows
 
 
 def sparse_dataloader(file, alphabet, batch_size, num_ds, cache=False, header=True, n_par=1, dtype=torch.float64):

@@ -1,11 +1,17 @@
-"""Row sharding and the one collective of a training step.
+"""Row sharding, process-group set-up and the one collective of a training step.
 
 K-mer contexts are independent, so a table shards by contiguous row ranges, one process per GPU; each
 step every rank reduces its shard to the packed fp64 vector ``[sum LL, grads...]`` and a single
 ``all_reduce(sum)`` combines them (RCCL over xGMI when the backend is "nccl"; "gloo" in the CPU tests).
-This replaces ``strategy.reduce`` (bear_net.py:290) and the cross-replica gradient sum inside
-``optimizer.apply_gradients`` (bear_net.py:278-282).
+This replaces ``tf.distribute.MirroredStrategy`` (bear_net.py:246): ``strategy.reduce`` (bear_net.py:290),
+the cross-replica gradient sum inside ``optimizer.apply_gradients`` (bear_net.py:278-282), the mirrored
+variables (``broadcast_params``) and ``experimental_distribute_dataset`` (bear_net.py:273; ``shard_rows``).
+
+Launch: ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+bear_amd/models/train_bear_ref.py config.cfg`` -- the drivers call ``init_from_env()`` before any GPU work.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -14,6 +20,39 @@ def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def init_from_env():
+    """One process per GPU: binds this process to its device and joins the process group when the launcher
+    (``torch.distributed.run``) exported WORLD_SIZE > 1.  Must run before anything touches the GPU.
+
+    Environment: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT from the launcher;
+    ``BEAR_AMD_DIST_BACKEND`` (default ``nccl`` = RCCL; ``gloo`` for tests that put several ranks on one GPU);
+    ``BEAR_AMD_DEVICE`` overrides the device index (default LOCAL_RANK).
+    Returns ``(rank, world_size)``."""
+    if dist.is_available() and dist.is_initialized():
+        return world()
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev_index = int(os.environ.get("BEAR_AMD_DEVICE", local_rank))
+    if torch.cuda.device_count() > dev_index:   # device_count() does not initialise the GPU on this image
+        torch.cuda.set_device(dev_index)
+    if world_size <= 1:
+        return 0, 1
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("BEAR_AMD_DIST_BACKEND", "nccl")
+    rank = int(os.environ["RANK"])
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world_size)
+    return world()
+
+
+def shutdown():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def shard_rows(n_rows, rank=None, world_size=None):
@@ -25,11 +64,54 @@ def shard_rows(n_rows, rank=None, world_size=None):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _via_host(t):
+    """gloo moves host memory: CUDA tensors are staged through the host for it (tests only; RCCL reduces in place)."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def allreduce_sum_(packed):
-    """In-place sum of the packed per-shard partials over all ranks (no-op for a single process)."""
+    """In-place sum of the packed per-shard partials over all ranks (no-op for a single process).  On RCCL this is
+    enqueued on the current stream: no host synchronisation."""
     if world()[1] > 1:
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        if _via_host(packed):
+            h = packed.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            packed.copy_(h)
+        else:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     return packed
+
+
+def allreduce_max_(t):
+    if world()[1] > 1:
+        if _via_host(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def broadcast_params(params, src=0):
+    """Mirrored variables: every rank starts from rank `src`'s parameter values (MirroredStrategy creates variables once
+    and mirrors them, bear_net.py:248-256; without this each rank would keep the draws of its own RNG)."""
+    if world()[1] <= 1:
+        return params
+    with torch.no_grad():
+        for p in params:
+            if _via_host(p):
+                h = p.detach().cpu()
+                dist.broadcast(h, src=src)
+                p.copy_(h)
+            else:
+                dist.broadcast(p.data, src=src)
+    return params
+
+
+def barrier():
+    if world()[1] > 1:
+        dist.barrier()
 
 
 def pack(tensors):

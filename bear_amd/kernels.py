@@ -411,6 +411,57 @@ def encode_kmers(ascii_kmers, alphabet="dna"):
     return codes
 
 
+def _f64_vec(t, n, name):
+    if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == n):
+        raise ValueError(f"{name} must be a contiguous CUDA float64 tensor of {n} elements")
+
+
+def dm_prior_planned_dev(plan, prior, h_signed_dev, eps=EPSILON, out=None, normalized=False, want_grad=False, train_ar=False):
+    """``bear_dm_prior_plan_dev_f64``: dm_prior_planned with h_signed read from a device tensor, so a training step is
+    enqueued without the host reading the parameter back.  Returns out, or (out, grad rows) with want_grad."""
+    counts = plan.counts
+    _check_rows(prior, torch.float64, "prior")
+    if prior.data_ptr() % 16 or prior.shape[0] != counts.shape[0] or plan.ncol != 5:
+        raise ValueError("prior must be 16-byte aligned with one row per planned context (plan ncol=5)")
+    _f64_vec(h_signed_dev, 1, "h_signed_dev")
+    if out is None:
+        out = torch.empty(2, dtype=torch.float64, device=counts.device)
+    grad = torch.empty_like(prior) if want_grad else None
+    with torch.cuda.device(counts.device):
+        st = _lib.lib().bear_dm_prior_plan_dev_f64(plan.ws.handle, plan._h, _ptr(counts), _ptr(prior), counts.shape[0], _ptr(h_signed_dev),
+                                                   float(eps), int(bool(train_ar)), int(bool(normalized)), _ptr(out), _ptr(grad), _stream())
+    _lib.check(st, "bear_dm_prior_plan_dev_f64")
+    return (out, grad) if want_grad else out
+
+
+def train_apply(theta, packed, adam_m, adam_v, adam_t, learning_rate, scale, loss_buf=None, train_ar=False):
+    """Enqueues ``bear_train_apply_f64``: tf.keras Adam on ``theta`` with the gradients ``scale * packed[1:]``;
+    ``loss_buf[step] = -scale * packed[0]``.  packed = [sum LL, d/d theta...] (after the all-reduce when rows are sharded)."""
+    n = theta.numel()
+    for t, k, name in ((theta, n, "theta"), (packed, n + 1, "packed"), (adam_m, n, "adam_m"), (adam_v, n, "adam_v"), (adam_t, 1, "adam_t")):
+        _f64_vec(t, k, name)
+    with torch.cuda.device(theta.device):
+        st = _lib.lib().bear_train_apply_f64(_ptr(theta), n, _ptr(packed), _ptr(adam_m), _ptr(adam_v), _ptr(adam_t), float(learning_rate),
+                                             float(scale), int(bool(train_ar)), _ptr(loss_buf),
+                                             0 if loss_buf is None else loss_buf.numel(), _stream())
+    _lib.check(st, "bear_train_apply_f64")
+
+
+def ref_train_reduce(plan, ref, theta, packed, eps=EPSILON, train_ar=False):
+    """Enqueues ``bear_ref_train_reduce_f64``: this shard's packed = [sum LL, d/dh_s, d/dtau_s, d/dnu_s] with the kernel constants
+    derived from the device-resident theta (no host round trip)."""
+    train = plan.counts
+    _check_rows(ref, torch.int32, "ref")
+    _f64_vec(theta, 3, "theta")
+    _f64_vec(packed, 4, "packed")
+    if ref.data_ptr() % 16 or ref.shape[0] != train.shape[0] or plan.ncol != 4:
+        raise ValueError("ref must be 16-byte aligned with one row per planned context (plan ncol=4)")
+    with torch.cuda.device(train.device):
+        st = _lib.lib().bear_ref_train_reduce_f64(plan.ws.handle, plan._h, _ptr(train), _ptr(ref), train.shape[0], _ptr(theta), float(eps),
+                                                  int(bool(train_ar)), _ptr(packed), _stream())
+    _lib.check(st, "bear_ref_train_reduce_f64")
+
+
 def ref_train_step(plan, ref, theta, adam_m, adam_v, adam_t, learning_rate, scale, out, loss_buf=None, eps=EPSILON, train_ar=False):
     """Enqueues one ``bear_ref_train_step_f64`` (constants from theta, planned mode-R kernel, finalize, Adam on theta): no host
     synchronisation, every argument device-resident -- capturable in a HIP graph (``torch.cuda.graph``)."""
@@ -429,45 +480,81 @@ def ref_train_step(plan, ref, theta, adam_m, adam_v, adam_t, learning_rate, scal
     _lib.check(st, "bear_ref_train_step_f64")
 
 
-def net_linear_train_step(plan, kmer_code, lag, theta, adam_m, adam_v, adam_t, grad_mat, learning_rate, scale, out, loss_buf=None,
-                          eps=EPSILON, train_ar=False):
-    """Enqueues one ``bear_net_linear_train_step_f64`` (HIP-graph capturable): theta = {h_signed, mat} on the device."""
+def _check_linear_step(plan, kmer_code, lag, theta, packed):
     n = plan.counts.shape[0]
-    size = 1 + lag * 25
-    for t, k in ((theta, size), (adam_m, size), (adam_v, size), (adam_t, 1), (grad_mat, lag * 25), (out, 2)):
-        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.numel() == k):
-            raise ValueError("theta / adam_m / adam_v [1 + lag*25], adam_t [1], grad_mat [lag*25], out [2]: contiguous CUDA float64")
+    _f64_vec(theta, 1 + lag * 25, "theta")
+    _f64_vec(packed, 2 + lag * 25, "packed")
     if not (kmer_code.is_cuda and kmer_code.dtype == torch.int64 and kmer_code.is_contiguous() and kmer_code.shape == (n,)
             and kmer_code.data_ptr() % 16 == 0):
         raise ValueError("kmer_code must be a contiguous, 16-byte aligned CUDA int64 tensor [n_rows] (pack_kmers)")
+    return n
+
+
+def net_linear_train_reduce(plan, kmer_code, lag, theta, packed, eps=EPSILON, train_ar=False):
+    """Enqueues ``bear_net_linear_train_reduce_f64``: packed = [sum LL, d/dh_s, d/d mat (lag*25)] of this shard, theta = {h_signed, mat}
+    device-resident."""
+    n = _check_linear_step(plan, kmer_code, lag, theta, packed)
+    with torch.cuda.device(theta.device):
+        st = _lib.lib().bear_net_linear_train_reduce_f64(plan.ws.handle, plan._h, _ptr(plan.counts), _ptr(kmer_code), int(lag), n, _ptr(theta),
+                                                         float(eps), int(bool(train_ar)), _ptr(packed), _stream())
+    _lib.check(st, "bear_net_linear_train_reduce_f64")
+
+
+def net_linear_train_step(plan, kmer_code, lag, theta, adam_m, adam_v, adam_t, packed, learning_rate, scale, loss_buf=None,
+                          eps=EPSILON, train_ar=False):
+    """Enqueues one ``bear_net_linear_train_step_f64`` (HIP-graph capturable): theta = {h_signed, mat} on the device."""
+    n = _check_linear_step(plan, kmer_code, lag, theta, packed)
+    size = 1 + lag * 25
+    for t, k in ((adam_m, size), (adam_v, size), (adam_t, 1)):
+        _f64_vec(t, k, "adam state")
     with torch.cuda.device(theta.device):
         st = _lib.lib().bear_net_linear_train_step_f64(plan.ws.handle, plan._h, _ptr(plan.counts), _ptr(kmer_code), int(lag), n, _ptr(theta),
-                                                       _ptr(adam_m), _ptr(adam_v), _ptr(adam_t), _ptr(grad_mat), float(eps),
-                                                       int(bool(train_ar)), float(learning_rate), float(scale), _ptr(out),
+                                                       _ptr(adam_m), _ptr(adam_v), _ptr(adam_t), _ptr(packed), float(eps),
+                                                       int(bool(train_ar)), float(learning_rate), float(scale),
                                                        _ptr(loss_buf), 0 if loss_buf is None else loss_buf.numel(), _stream())
     _lib.check(st, "bear_net_linear_train_step_f64")
 
 
-def net_cnn_train_step(plan, kmer_code, lag, filter_width, theta, adam_m, adam_v, adam_t, bufs, learning_rate, scale, out, loss_buf=None,
+def net_cnn_train_reduce(plan, kmer_code, lag, filter_width, theta, bufs, packed, eps=EPSILON, train_ar=False):
+    """Enqueues ``bear_net_cnn_train_reduce_f64``: forward, planned DM kernel with gradient rows, backward;
+    packed = [sum LL, d/dh_s, d/d params] of this shard.  ``bufs`` = (prior [n,5], t1 [n,16], grad_rows [n,5]) from ``cnn_step_buffers``."""
+    n = plan.counts.shape[0]
+    prior, t1, grad_rows = bufs
+    np_ = cnn_param_count(lag, filter_width)
+    _f64_vec(theta, 1 + np_, "theta")
+    _f64_vec(packed, 2 + np_, "packed")
+    with torch.cuda.device(theta.device):
+        st = _lib.lib().bear_net_cnn_train_reduce_f64(plan.ws.handle, plan._h, _ptr(plan.counts), _ptr(kmer_code), n, int(lag), int(filter_width),
+                                                      CNN_NUM_FILTERS, CNN_LAYER1_WIDTH, _ptr(theta), _ptr(prior), _ptr(t1), _ptr(grad_rows),
+                                                      float(eps), int(bool(train_ar)), _ptr(packed), _stream())
+    _lib.check(st, "bear_net_cnn_train_reduce_f64")
+
+
+def net_cnn_train_step(plan, kmer_code, lag, filter_width, theta, adam_m, adam_v, adam_t, bufs, packed, learning_rate, scale, loss_buf=None,
                        eps=EPSILON, train_ar=False):
     """Enqueues one ``bear_net_cnn_train_step_f64`` (HIP-graph capturable): theta = {h_signed, flat CNN parameters} on the device;
-    ``bufs`` = (prior [n,5], t1 [n,16], grad_rows [n,5], grad_flat [param_count]) lent by the caller (``cnn_step_buffers``)."""
+    ``bufs`` = (prior [n,5], t1 [n,16], grad_rows [n,5]) lent by the caller (``cnn_step_buffers``)."""
     n = plan.counts.shape[0]
-    prior, t1, grad_rows, grad_flat = bufs
+    prior, t1, grad_rows = bufs
+    np_ = cnn_param_count(lag, filter_width)
+    _f64_vec(theta, 1 + np_, "theta")
+    _f64_vec(packed, 2 + np_, "packed")
     with torch.cuda.device(theta.device):
         st = _lib.lib().bear_net_cnn_train_step_f64(plan.ws.handle, plan._h, _ptr(plan.counts), _ptr(kmer_code), n, int(lag), int(filter_width),
                                                     CNN_NUM_FILTERS, CNN_LAYER1_WIDTH, _ptr(theta), _ptr(adam_m), _ptr(adam_v), _ptr(adam_t),
-                                                    _ptr(prior), _ptr(t1), _ptr(grad_rows), _ptr(grad_flat), float(eps), int(bool(train_ar)),
-                                                    float(learning_rate), float(scale), _ptr(out), _ptr(loss_buf),
+                                                    _ptr(prior), _ptr(t1), _ptr(grad_rows), _ptr(packed), float(eps), int(bool(train_ar)),
+                                                    float(learning_rate), float(scale), _ptr(loss_buf),
                                                     0 if loss_buf is None else loss_buf.numel(), _stream())
     _lib.check(st, "bear_net_cnn_train_step_f64")
 
 
-def cnn_step_buffers(plan, lag, filter_width):
-    """Per-context scratch of the captured CNN step + the library-side reservation (``bear_cnn_reserve``)."""
-    n, dev = plan.counts.shape[0], plan.counts.device
-    with torch.cuda.device(dev):
-        _lib.check(_lib.lib().bear_cnn_reserve(plan.ws.handle, n, int(lag), int(filter_width), CNN_NUM_FILTERS, CNN_LAYER1_WIDTH),
+def cnn_step_buffers(n_rows, lag, filter_width, device, ws=None):
+    """Per-context scratch of the CNN step for (at most) ``n_rows`` contexts + the library-side reservation (``bear_cnn_reserve``):
+    (prior [n,5], t1 [n,16], grad_rows [n,5]).  Steps on one stream run one after the other, so one set sized for the largest
+    batch serves every batch."""
+    ws = ws or default_workspace(device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().bear_cnn_reserve(ws.handle, int(n_rows), int(lag), int(filter_width), CNN_NUM_FILTERS, CNN_LAYER1_WIDTH),
                    "bear_cnn_reserve")
-    return (torch.empty((n, 5), dtype=torch.float64, device=dev), torch.empty((n, CNN_LAYER1_WIDTH), dtype=torch.float64, device=dev),
-            torch.empty((n, 5), dtype=torch.float64, device=dev), torch.empty(cnn_param_count(lag, filter_width), dtype=torch.float64, device=dev))
+    return (torch.empty((n_rows, 5), dtype=torch.float64, device=device), torch.empty((n_rows, CNN_LAYER1_WIDTH), dtype=torch.float64, device=device),
+            torch.empty((n_rows, 5), dtype=torch.float64, device=device))

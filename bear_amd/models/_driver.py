@@ -31,8 +31,13 @@ def _writer(out_folder):
 
 def main(config, kind):
     """kind: 'net' or 'ref'.  Returns what the reference's main() returns (1, or (1, ll_van, perp_van)
-    when train_test is on, models/train_bear_net.py:197-200)."""
-    rank, _ = dist.world()
+    when train_test is on, models/train_bear_net.py:197-200).
+
+    Multi-GPU (replaces the MirroredStrategy of bear_net.py:246 / bear_ref.py:310): launched as one process per GPU --
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train_bear_ref.py cfg`` -- every
+    process binds to its GPU and joins the RCCL group here, before any GPU work; each rank loads only its rows of every batch,
+    rank 0 alone writes the output files."""
+    rank, world = dist.init_from_env()
     mod = bear_net if kind == "net" else bear_ref
     time_stamp = datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
     of = config["general"]["out_folder"]
@@ -42,7 +47,13 @@ def main(config, kind):
         out_folder = of[:-1]
     else:
         out_folder = os.path.join(of, "logs", time_stamp)
-    os.makedirs(out_folder, exist_ok=True)
+    if world > 1:       # one folder for the job: rank 0's time stamp
+        names = [out_folder]
+        torch.distributed.broadcast_object_list(names, src=0)
+        out_folder = names[0]
+    if rank == 0:
+        os.makedirs(out_folder, exist_ok=True)
+    dist.barrier()
     torch.manual_seed(int(config["general"]["seed"]))
     dtype = getattr(torch, config["general"]["precision"])
     writer = _writer(out_folder) if rank == 0 else None
@@ -52,24 +63,36 @@ def main(config, kind):
     else:
         fp = config["data"]["files_path"]
         files = sorted(os.path.join(fp, f) for f in os.listdir(fp) if f.startswith(config["data"]["start_token"]))
-    num_kmers = sum(_count_lines(f) for f in files)
+    sparse = config["data"]["sparse"] == "True"
+    num_kmers = sum(_count_lines(f) for f in files)          # `wc -l`, models/train_bear_net.py:52-55 (a sparse file's header included)
     kmer_batch_size = float(config["train"]["batch_size"])
     kmer_batch_size = int(num_kmers * kmer_batch_size) if kmer_batch_size <= 1 else int(kmer_batch_size)
     epochs = config["train"]["epochs"]
     epochs = int(epochs[:-1]) // (1 + num_kmers // kmer_batch_size) + 1 if epochs[-1] == "s" else int(epochs)
     num_ds = int(config["data"]["num_ds"])
-    load = dataloader.sparse_dataloader if config["data"]["sparse"] == "True" else dataloader.dataloader
+    load = dataloader.sparse_dataloader if sparse else dataloader.dataloader
     # two optional keys beyond the reference's: [data] binary_cache (True or a directory: parsed tables are kept on disk,
     # dense format only) and [data] shuffle_seed (rows are permuted on the device at upload instead of `shuf`-ing the file)
     extra_kw = {}
     if config["data"].get("binary_cache") and load is dataloader.dataloader:
         bc = config["data"]["binary_cache"]
         extra_kw["binary_cache"] = True if bc == "True" else bc
-    parts = [load(f, config["data"]["alphabet"], kmer_batch_size, num_ds, cache=config["train"]["cache"] == "True", dtype=dtype,
-                  **extra_kw) for f in files]
-    data = parts[0] if len(parts) == 1 else dataloader.concatenate(parts)
-    if config["data"].get("shuffle_seed"):
-        data = data.shuffle(int(config["data"]["shuffle_seed"]))
+    shuffle_seed = config["data"].get("shuffle_seed")
+    if world > 1 and load is dataloader.dataloader and not shuffle_seed:
+        # every rank decodes and holds only its pieces of the batches (the device shuffle needs whole columns: then, as for the
+        # small sparse format, each rank loads the table and slices its rows at upload)
+        file_rows = [dataloader.count_rows(f) for f in files]
+        total, base, parts = sum(file_rows), 0, []
+        for f, n in zip(files, file_rows):
+            parts.append(load(f, config["data"]["alphabet"], kmer_batch_size, num_ds, cache=config["train"]["cache"] == "True", dtype=dtype,
+                              shard=(rank, world), row_base=base, total_rows=total, **extra_kw))
+            base += n
+    else:
+        parts = [load(f, config["data"]["alphabet"], kmer_batch_size, num_ds, cache=config["train"]["cache"] == "True", dtype=dtype,
+                      **extra_kw) for f in files]
+    data = parts[0] if len(parts) == 1 and isinstance(parts[0], dataloader.CountDataset) else dataloader.concatenate(parts)
+    if shuffle_seed:
+        data = data.shuffle(int(shuffle_seed))
     data_train = data.repeat(epochs)
 
     result_file = os.path.join(out_folder, "results.pickle")
@@ -156,4 +179,5 @@ def main(config, kind):
             config["results"][name] = json.dumps(np.asarray(v).tolist()) if np.ndim(v) else str(float(v))
         save_config()
         ret = (1, np.asarray(r[2]), np.asarray(r[5]))
+    dist.barrier()
     return ret

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BEAR_ABI_VERSION 1
+#define BEAR_ABI_VERSION 2
 #define BEAR_ROW_WIDTH 5 /* alphabet_size + 1 for dna/rna */
 
 typedef enum bear_status {
@@ -121,37 +121,62 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
                          uint64_t n_rows, double h_signed, double tau_signed, double nu_signed, double eps,
                          int train_ar, double *out, void *stream);
 
+/* The same with h_signed read from device memory ([dev] double [1], e.g. a parameter tensor the optimizer updates in place): the
+ * step is enqueued without the host reading the parameter back (one sync fewer per step; needed for steps that are followed
+ * by an all-reduce on the same stream).  grad_prior [dev, nullable]: NULL = no gradient rows (parameter-free ar_func). */
+int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior, uint64_t n_rows,
+                               const double *h_signed_dev, double eps, int train_ar, int prior_normalized, double *out,
+                               double *grad_prior, void *stream);
+
 /*
- * One bear_ref optimizer step with every moving quantity in device memory, so that the step can be captured in a HIP graph
- * and replayed (the reference traces its step once with tf.function and re-runs the graph, bear_model/bear_ref.py:207;
- * launch-bound on small tables: the bundled example is 10 000 steps over 1365 contexts).  Enqueues, without any host
- * synchronisation: constants from theta -> the planned mode-R kernel -> finalize -> tf.keras Adam (beta 0.9 / 0.999,
- * epsilon 1e-7; bear_ref.py:312-313, 346-350) on theta.
- *   theta   [dev] double [3]  {h_signed, tau_signed, net_weight_signed}, updated in place
- *   adam_m, adam_v [dev] double [3], adam_t [dev] double [1]  optimizer state (zero before the first step)
- *   scale   the loss scale -(num_kmers / batch) (bear_ref.py:252-253);  out [dev] double [4] as bear_dm_ref_plan_f64
- *   loss_buf [dev, nullable] double [loss_cap]: loss_buf[step] = -scale * sum LL  (the "elbo" the reference logs)
+ * One optimizer step with every moving quantity in device memory, in two halves:
+ *
+ *   bear_*_train_reduce_f64  this rank's shard: kernel constants from theta -> planned kernel(s) -> finalize into
+ *                            packed [dev] double [1 + n_theta] = { sum LL, d sum LL / d theta[0..n_theta) }  (unscaled)
+ *   bear_train_apply_f64     tf.keras Adam (beta 0.9 / 0.999, epsilon 1e-7; bear_ref.py:312-313, 346-350) on theta with the
+ *                            gradients scale * packed[1..]; loss_buf[step] = -scale * packed[0] (the "elbo" the reference logs)
+ *
+ * Nothing synchronises with the host.  One rank enqueues them back to back (bear_*_train_step_f64 below: capturable in a
+ * HIP graph and replayed -- the reference traces its step once with tf.function, bear_model/bear_ref.py:207; the bundled
+ * example is 10 000 steps over 1365 contexts, launch-bound).  With the rows sharded over several ranks the caller puts ONE
+ * all-reduce(sum) of `packed` between the halves -- what strategy.reduce (bear_net.py:290) and the cross-replica gradient sum
+ * inside optimizer.apply_gradients (bear_net.py:278-282) do -- still without a host round trip.
+ *
+ *   theta    [dev] double [n_theta], updated in place by apply:
+ *            bear_ref / stop net function: {h_signed, tau_signed, net_weight_signed}           (n_theta = 3)
+ *            bear_net / linear:            {h_signed, mat[lag,5,5]}                            (n_theta = 1 + 25 lag)
+ *            bear_net / cnn:               {h_signed, params[bear_cnn_param_count(...)]}       (n_theta = 1 + param count)
+ *   adam_m, adam_v [dev] double [n_theta], adam_t [dev] double [1]: optimizer state, zero before the first step
+ *   scale    the loss scale -(num_kmers / global batch) (bear_ref.py:252-253); 1 when packed already holds scaled sums
+ *            (gradient accumulation: the caller adds scale_k * packed_k over acc_steps batches, bear_net.py:193-196)
+ *   train_ar != 0: theta[0] = h_signed gets no gradient (bear_net.py:194-196)
+ *   loss_buf [dev, nullable] double [loss_cap], indexed by the step counter adam_t
+ *   the cnn step borrows per-context buffers prior_buf [n,5], t1_buf [n,16], grad_rows_buf [n,5]; call bear_cnn_reserve once
+ *   before capturing (it sizes the library's block-partial buffer; nothing allocates inside a step).
  */
+int bear_train_apply_f64(double *theta, int n_theta, const double *packed, double *adam_m, double *adam_v, double *adam_t,
+                         double learning_rate, double scale, int train_ar, double *loss_buf, uint64_t loss_cap, void *stream);
+int bear_ref_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
+                              const double *theta, double eps, int train_ar, double *packed, void *stream);
+int bear_net_linear_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, int lag,
+                                     uint64_t n_rows, const double *theta, double eps, int train_ar, double *packed, void *stream);
+int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, int num_filters, int layer1_width);
+int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,
+                                  int lag, int filter_width, int num_filters, int layer1_width, const double *theta, double *prior_buf,
+                                  double *t1_buf, double *grad_rows_buf, double eps, int train_ar, double *packed, void *stream);
+/* reduce + apply in one call (single rank); `out` / `packed` as above. */
 int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
                             double *theta, double *adam_m, double *adam_v, double *adam_t, double eps, int train_ar,
                             double learning_rate, double scale, double *out, double *loss_buf, uint64_t loss_cap, void *stream);
-
-/* The same for bear_net with the linear AR function (bear_model/bear_net.py:146-197 + ar_funcs.py:23-46): theta [dev] double
- * [1 + lag*25] = {h_signed, mat}; adam_m / adam_v the same size; grad_mat [dev] double [lag*25] scratch. */
 int bear_net_linear_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, int lag,
-                                   uint64_t n_rows, double *theta, double *adam_m, double *adam_v, double *adam_t, double *grad_mat,
-                                   double eps, int train_ar, double learning_rate, double scale, double *out, double *loss_buf,
+                                   uint64_t n_rows, double *theta, double *adam_m, double *adam_v, double *adam_t, double *packed,
+                                   double eps, int train_ar, double learning_rate, double scale, double *loss_buf,
                                    uint64_t loss_cap, void *stream);
-
-/* And with the convolutional AR function: theta [dev] double [1 + bear_cnn_param_count(...)] = {h_signed, params}; the caller
- * lends the per-context buffers prior_buf [n,5], t1_buf [n,16], grad_rows_buf [n,5] and grad_flat [param_count].  Call
- * bear_cnn_reserve once before capturing (it sizes the library's block-partial buffer; nothing allocates inside the step). */
-int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, int num_filters, int layer1_width);
 int bear_net_cnn_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,
                                 int lag, int filter_width, int num_filters, int layer1_width, double *theta, double *adam_m,
                                 double *adam_v, double *adam_t, double *prior_buf, double *t1_buf, double *grad_rows_buf,
-                                double *grad_flat, double eps, int train_ar, double learning_rate, double scale, double *out,
-                                double *loss_buf, uint64_t loss_cap, void *stream);
+                                double *packed, double eps, int train_ar, double learning_rate, double scale, double *loss_buf,
+                                uint64_t loss_cap, void *stream);
 
 /*
  * The whole bear_net training step for the linear AR function, fused on a plan: replaces
@@ -282,6 +307,20 @@ int bear_synth_prior_f64(uint64_t seed, uint64_t row0, uint64_t n_rows, double *
 int bear_count_rows(const char *path, uint64_t *n_rows_out);
 int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint64_t max_rows, char *kmers,
                           uint32_t *counts, uint64_t *n_rows_out);
+/*
+ * One rank's rows of a row-sharded table (replaces strategy.experimental_distribute_dataset,
+ * bear_model/bear_net.py:273): the table of total_rows rows (this file holds global rows [row_base, row_base + file rows)) is
+ * cut into batches of batch_rows rows (last one short, dataloader.py:37) and every batch into `world` contiguous pieces,
+ * base = m / world rows each, the first m % world pieces one row longer; rank `rank` decodes only the lines of its pieces, in
+ * file order, into kmers [host] char [max_rows, lag] and counts [host] uint32 [num_ds, max_rows, 5]; the other lines are
+ * stepped over.  skip_lines header lines are ignored first (dataloader.py:7 `header`; world = 1 makes this the plain reader with
+ * a header).  bear_shard_rows_count gives the number of local rows (the size to allocate) from the row counts alone.
+ */
+int bear_shard_rows_count(uint64_t row_base, uint64_t file_rows, uint64_t total_rows, uint64_t batch_rows, int rank, int world,
+                          uint64_t *n_local_out);
+int bear_parse_counts_tsv_shard(const char *path, int num_ds, int lag, uint64_t skip_lines, uint64_t row_base, uint64_t total_rows,
+                                uint64_t batch_rows, int rank, int world, uint64_t max_rows, char *kmers, uint32_t *counts,
+                                uint64_t *n_local_out, uint64_t *n_file_rows_out);
 
 /*
  * Binary cache of a parsed count table: what bear_parse_counts_tsv produced, stored as it is uploaded,

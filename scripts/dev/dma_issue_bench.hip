@@ -17,7 +17,14 @@ __global__ __launch_bounds__(1024) void k_dma(const unsigned char *src, size_t s
     for (int p = 0; p < K; ++p) {
       const unsigned char *g = base + ((size_t)it * K + p) * 1024;
       const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds + (wave * K + p) * 1024);
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m) : "memory", "m0");
+      {
+      // M0 is compiler-reserved: saved and restored inside the statement that uses it (no "m0" clobber: that is undefined behaviour)
+      uint32_t keep_m0;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0)
+                   : "v"(g), "s"(m)
+                   : "memory");
+    }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -73,7 +80,14 @@ __global__ __launch_bounds__(1024) void k_few(const unsigned char *src, size_t b
   for (size_t p = wave; p < pieces; p += W, ++k) {
     const unsigned char *g = base + p * 1024;
     const uint32_t m = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds + (wave * 8 + (k & 7u)) * 1024);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m) : "memory", "m0");
+    {
+      // M0 is compiler-reserved: saved and restored inside the statement that uses it (no "m0" clobber: that is undefined behaviour)
+      uint32_t keep_m0;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0)
+                   : "v"(g), "s"(m)
+                   : "memory");
+    }
     asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -21,3 +21,14 @@ def ysd1():
     import bear_oracle as o
     kmers, counts = o.parse_counts_tsv(YSD1, 3)
     return kmers, counts
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests need a device: on a box without one they are skipped (never run on a fallback -- there is none)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X (no CPU fallback exists)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/bear_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == names
-    assert L.bear_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "bear_hip.h")).read()
+    assert L.bear_abi_version() == int(re.search(r"#define BEAR_ABI_VERSION (\d+)", hdr).group(1))
     assert L.bear_strerror(0) == b"ok"
 
 
@@ -79,3 +80,100 @@ def test_parser_errors(tmp_path):
     # wrong lag
     st = L.bear_parse_counts_tsv(str(ok).encode(), 2, 4, 4, None, counts.ctypes.data, ctypes.byref(n))
     assert st == -7
+
+
+def _write_table(path, n, rng, num_ds=3, lag=4, header=False):
+    kmers = ["".join(rng.choice(list("ACGT["), lag)) for _ in range(n)]
+    counts = rng.integers(0, 50, size=(n, num_ds, 5))
+    with open(path, "w") as fh:
+        if header:
+            fh.write("kmer\tcounts\n")
+        for k, rows in zip(kmers, counts):
+            fh.write(k + "\t[[" + "],[".join(",".join(str(int(v)) for v in g) for g in rows) + "]]\n")
+    return kmers, counts
+
+
+@pytest.mark.parametrize("n,batch,world", [(1000, 1000, 2), (1001, 250, 3), (37, 5, 8), (64, 100, 4), (5, 2, 8)])
+def test_sharded_reader_partitions_the_table(tmp_path, n, batch, world):
+    """bear_parse_counts_tsv_shard / dataloader(shard=...): the ranks' pieces are disjoint, cover the table, follow
+    dist.shard_rows per batch, and hold exactly the rows the plain reader returns (SURVEY 8e input sharding)."""
+    from bear_amd import dataloader, dist
+    rng = np.random.default_rng(n * 31 + world)
+    path = tmp_path / "t.tsv"
+    kmers, counts = _write_table(path, n, rng)
+    full = dataloader.dataloader(str(path), "dna", batch, 3)
+    assert full.num_rows == n and full.shard is None
+    assert np.array_equal(full.counts.transpose(1, 0, 2), counts)
+    seen = np.zeros(n, dtype=int)
+    for r in range(world):
+        part = dataloader.dataloader(str(path), "dna", batch, 3, shard=(r, world))
+        assert part.num_rows == n and part.shard == (r, world) and part.batch_bounds() == full.batch_bounds()
+        off = 0
+        for (a, b), (g0, g1, o) in zip(full.batch_bounds(), part.rank_pieces(r, world)):
+            lo, hi = dist.shard_rows(b - a, r, world)
+            assert (g0, g1, o) == (a + lo, a + hi, off)
+            assert np.array_equal(part.counts[:, o:o + g1 - g0], full.counts[:, g0:g1])
+            assert np.array_equal(part.kmers[o:o + g1 - g0], full.kmers[g0:g1])
+            seen[g0:g1] += 1
+            off += g1 - g0
+        assert off == part.local_rows
+        # the unsharded dataset describes the same pieces for a rank that slices at upload
+        assert [(g0, g1) for g0, g1, _ in full.rank_pieces(r, world)] == [(g0, g1) for g0, g1, _ in part.rank_pieces(r, world)]
+        with pytest.raises(ValueError):
+            part.rank_pieces((r + 1) % world, world)
+        with pytest.raises(ValueError):
+            part.shuffle(3)
+    assert np.all(seen == 1)
+
+
+def test_sharded_reader_multi_file_cache_and_header(tmp_path):
+    from bear_amd import dataloader
+    rng = np.random.default_rng(9)
+    sizes, batch, world = [130, 77, 201], 100, 3
+    tables = [_write_table(tmp_path / f"f{i}.tsv", n, rng) for i, n in enumerate(sizes)]
+    whole = np.concatenate([c for _, c in tables])
+    total = sum(sizes)
+    for use_cache in (False, True):
+        if use_cache:       # caches are written by an unsharded load, then served to the ranks by ranged reads
+            for i in range(len(sizes)):
+                dataloader.dataloader(str(tmp_path / f"f{i}.tsv"), "dna", batch, 3, binary_cache=str(tmp_path / "cache"))
+        seen = np.zeros(total, dtype=int)
+        for r in range(world):
+            parts, base = [], 0
+            for i, n in enumerate(sizes):
+                parts.append(dataloader.dataloader(str(tmp_path / f"f{i}.tsv"), "dna", batch, 3, shard=(r, world), row_base=base,
+                                                   total_rows=total, binary_cache=str(tmp_path / "cache") if use_cache else None))
+                base += n
+            data = dataloader.concatenate(parts)
+            assert data.num_rows == total and data.shard == (r, world)
+            for g0, g1, o in data.rank_pieces(r, world):
+                assert np.array_equal(data.counts[:, o:o + g1 - g0].transpose(1, 0, 2), whole[g0:g1])
+                seen[g0:g1] += 1
+        assert np.all(seen == 1)
+    # header=True (dataloader.py:7): the first line is skipped, sharded or not
+    kmers, counts = _write_table(tmp_path / "h.tsv", 50, rng, header=True)
+    d = dataloader.dataloader(str(tmp_path / "h.tsv"), "dna", 20, 3, header=True)
+    assert d.num_rows == 50 and np.array_equal(d.counts.transpose(1, 0, 2), counts) and bytes(d.kmers[0]).decode() == kmers[0]
+    p = dataloader.dataloader(str(tmp_path / "h.tsv"), "dna", 20, 3, header=True, shard=(1, 2))
+    g = p.rank_pieces(1, 2)
+    assert np.array_equal(p.counts[:, :g[0][1] - g[0][0]].transpose(1, 0, 2), counts[g[0][0]:g[0][1]])
+
+
+def test_sharded_reader_large_file_threads(tmp_path):
+    """> 1 MiB of text: the chunked, threaded path of the sharded reader agrees with the plain reader."""
+    from bear_amd import dataloader
+    rng = np.random.default_rng(4)
+    n = 40000
+    path = tmp_path / "big.tsv"
+    _write_table(path, n, rng, num_ds=2, lag=9)
+    assert os.path.getsize(path) > (1 << 20)
+    full = dataloader.dataloader(str(path), "dna", 7001, 2)
+    os.environ["BEAR_PARSE_THREADS"] = "7"
+    try:
+        for r in (0, 3, 4):
+            part = dataloader.dataloader(str(path), "dna", 7001, 2, shard=(r, 5))
+            for g0, g1, o in part.rank_pieces(r, 5):
+                assert np.array_equal(part.counts[:, o:o + g1 - g0], full.counts[:, g0:g1])
+                assert np.array_equal(part.kmers[o:o + g1 - g0], full.kmers[g0:g1])
+    finally:
+        os.environ.pop("BEAR_PARSE_THREADS")

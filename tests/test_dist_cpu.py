@@ -16,9 +16,24 @@ import numpy as np, torch, torch.distributed as dist
 import bear_oracle as o
 from bear_amd import dist as bdist
 from util import sparse_table, prior_rows
-dist.init_process_group("gloo")
-rank, world = bdist.world()
-assert world == 2
+rank, world = bdist.init_from_env()          # the product's own set-up (BEAR_AMD_DIST_BACKEND=gloo here, RCCL on the GPU node)
+assert world == 2 and bdist.world() == (rank, 2) and dist.get_backend() == "gloo"
+# mirrored variables: rank 1 draws other initial values, rank 0's win
+torch.manual_seed(10 + rank)
+ps = [torch.randn(3, 2, dtype=torch.float64), torch.randn((), dtype=torch.float64)]
+bdist.broadcast_params(ps)
+got = [None, None]
+dist.all_gather_object(got, [p.numpy().tolist() for p in ps])
+assert got[0] == got[1]
+# input sharding at load time: the two ranks' pieces of every batch tile the table
+from bear_amd import dataloader
+ysd1 = os.path.join(os.environ["BEAR_ROOT"], "tests", "golden", "ysd1_lag_5_file_0_preshuf.tsv")
+part = dataloader.dataloader(ysd1, "dna", 500, 3, shard="auto")
+assert part.shard == (rank, 2) and part.num_rows == 1365
+rows = [None, None]
+dist.all_gather_object(rows, [(g0, g1) for g0, g1, _ in part.rank_pieces(rank, 2)])
+assert rows[0] == [(0, 250), (500, 750), (1000, 1183)] and rows[1] == [(250, 500), (750, 1000), (1183, 1365)]
+assert part.local_rows == sum(b - a for a, b in rows[rank])
 train, _, ref = sparse_table(10007, 3)
 f = prior_rows(10007, 4)
 args = (0.2, np.log(1 / 30), -np.log(100))
@@ -44,14 +59,14 @@ num_kmers, B = 50000, len(train)
 assert np.isclose(-(num_kmers / B) * packed[0].item(), -(num_kmers / B) * full["ll"], rtol=1e-12)
 if rank == 0:
     print("DIST_OK")
-dist.destroy_process_group()
+bdist.shutdown()
 '''
 
 
 def test_two_rank_gloo_step(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, BEAR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    env = dict(os.environ, BEAR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", BEAR_AMD_DIST_BACKEND="gloo")
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]

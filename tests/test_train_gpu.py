@@ -372,3 +372,154 @@ def test_graph_path_feeds_the_writer(ysd1):
     w, ls = W(), []
     bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False, writer=w, loss_save=ls)
     assert [r[2] for r in w.rows] == [1, 2, 3, 4, 5, 6] and [r[1] for r in w.rows] == ls and w.rows[0][0] == "elbo"
+
+
+def _oracle_ref_loop(counts, batch, epochs, acc_steps, optimizer, train_ar, lr):
+    """bear_ref.train with the stop net function restated on the oracle: gradients SUMMED over acc_steps batches, the logged
+    ELBO averaged (bear_ref.py:256-258, 369-381)."""
+    p = np.array([0.0, np.log(1 / 30), -np.log(100)])
+    m, v = np.zeros(3), np.zeros(3)
+    acc, loss, step, t, logged = np.zeros(3), 0.0, 1, 0, []
+    n = len(counts)
+    for _ in range(epochs):
+        for a in range(0, n, batch):
+            b = min(a + batch, n)
+            r = o.bear_ref_step(counts[a:b, 0], counts[a:b, 2], *p, train_ar=train_ar)
+            scale = -(n / (b - a))
+            loss += scale * r["ll"]
+            acc += scale * np.array([r["d_h_signed"], r["d_tau_signed"], r["d_nu_signed"]])
+            if step % acc_steps == 0:
+                logged.append(-loss / acc_steps)
+                t += 1
+                k0 = 1 if train_ar else 0
+                if optimizer == "Adam":
+                    keras_adam_np(p[k0:], acc[k0:], m[k0:], v[k0:], t, lr=lr)
+                else:
+                    p[k0:] -= lr * acc[k0:]
+                acc[:] = 0.0
+                loss = 0.0
+            step += 1
+    return logged, p
+
+
+@pytest.mark.parametrize("optimizer,acc_steps,train_ar", [("Adam", 3, False), ("Adam", 2, True), ("SGD", 1, False), ("SGD", 3, False)])
+def test_accumulation_and_sgd_match_oracle_loop(optimizer, acc_steps, train_ar, ysd1):
+    """acc_steps > 1 (gradients summed, logged ELBO averaged: bear_net.py:193-196, 303-309) and a non-Adam optimizer, on the
+    device-resident loop of bear_ref.train; 3 batches per epoch x 3 epochs = 9 batch steps (a trailing partial accumulation
+    is dropped, as in the reference)."""
+    _, counts = ysd1
+    lr = 0.01 if optimizer == "Adam" else 1e-9      # plain SGD on a loss of order 1e8
+    data = dataloader.dataloader(YSD1, "dna", 500, 3)
+    ls = []
+    params, _, _ = bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, lr, optimizer, train_ar,
+                                  acc_steps=acc_steps, loss_save=ls)
+    want_loss, want_p = _oracle_ref_loop(counts, 500, 3, acc_steps, optimizer, train_ar, lr)
+    assert len(ls) == 9 // acc_steps and np.allclose(ls, want_loss, rtol=1e-10)
+    assert np.allclose([x.item() for x in params], want_p, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("name,kw", [("linear", {}), ("cnn", {"filter_width": 3, "num_filters": 5}), ("cnn", CNN_CFG)])
+def test_accumulation_through_every_bear_net_step(name, kw, ysd1):
+    """acc_steps = 2 through the three bear_net step implementations -- fused linear kernel and fused cnn kernels (device-resident
+    theta, _train.run_device_steps) and a torch-op AR function with autograd (num_filters = 5 is outside the fused kernel,
+    _train.run_autograd_steps) -- against a CPU replica: torch autograd through the plugin, likelihood and row gradients from the
+    oracle, gradients summed over two batches, logged ELBO averaged (bear_net.py:193-196, 303-309)."""
+    _, counts = ysd1
+    data = dataloader.dataloader(YSD1, "dna", 400, 3)             # 4 batches per epoch
+    make = getattr(ar_funcs, "make_ar_func_" + name)
+    torch.manual_seed(8)
+    _, init = make(5, 4, **kw)
+    init_np = [x.detach().numpy().copy() for x in init]
+    ls = []
+    params, _, _ = bear_net.train(data.repeat(2), 1365, 2, 0, "dna", 5, make, kw, 0.01, "Adam", False, acc_steps=2,
+                                  params_restart=[np.array(0.1)] + init_np, loss_save=ls)
+    f_cpu, p_cpu = make(5, 4, **kw)
+    with torch.no_grad():
+        for a, b in zip(p_cpu, init_np):
+            a.copy_(torch.as_tensor(b))
+    h = np.array(0.1)
+    arrs = [h] + [q.detach().numpy() for q in p_cpu]
+    ms, vs, acc = ([np.zeros_like(x) for x in arrs] for _ in range(3))
+    codes = torch.as_tensor(data.codes())
+    want, loss, step, t = [], 0.0, 1, 0
+    for _ in range(2):
+        for a in range(0, 1365, 400):
+            b = min(a + 400, 1365)
+            for q in p_cpu:
+                q.grad = None
+            prior = f_cpu(codes[a:b])
+            r = o.bear_net_step(counts[a:b, 0], prior.detach().numpy(), float(h))
+            scale = -(1365 / (b - a))
+            prior.backward(torch.as_tensor(scale * r["d_prior"]))
+            loss += scale * r["ll"]
+            acc[0] += scale * r["d_h_signed"]
+            for i, q in enumerate(p_cpu):
+                acc[i + 1] += q.grad.numpy()
+            if step % 2 == 0:
+                want.append(-loss / 2)
+                t += 1
+                for i in range(len(arrs)):
+                    keras_adam_np(arrs[i], acc[i], ms[i], vs[i], t)
+                    acc[i][...] = 0.0
+                loss = 0.0
+            step += 1
+    assert len(ls) == 4 and np.allclose(ls, want, rtol=1e-9)
+    assert np.isclose(params[0].item(), float(h), rtol=1e-7, atol=1e-9)
+    for got, w in zip(params[1:], arrs[1:]):
+        assert np.allclose(got.detach().cpu().numpy(), w, rtol=1e-6, atol=1e-8)
+
+
+def test_graph_capture_failure_falls_back_to_the_eager_loop(monkeypatch, ysd1):
+    """Stream capture unavailable -> the same kernels are enqueued eagerly (a warning, identical results); library errors
+    raised inside a capture are NOT swallowed."""
+    data = dataloader.dataloader(YSD1, "dna", 1500, 3)
+    args = (data.repeat(5), 1365, 5, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False)
+    ls_graph = []
+    p_graph, _, _ = bear_ref.train(*args, loss_save=ls_graph)
+
+    class Boom:
+        def __init__(self, *a, **k):
+            raise RuntimeError("capture refused (test)")
+    monkeypatch.setattr(torch.cuda, "graph", Boom)
+    ls = []
+    with pytest.warns(UserWarning, match="capture"):
+        p, _, _ = bear_ref.train(*args, loss_save=ls)
+    assert ls == ls_graph and [x.item() for x in p] == [x.item() for x in p_graph]
+    from bear_amd import _lib
+
+    class Bad:
+        def __init__(self, *a, **k):
+            raise _lib.BearError(-1, "test")
+    monkeypatch.setattr(torch.cuda, "graph", Bad)
+    with pytest.raises(_lib.BearError):
+        bear_ref.train(*args)
+
+
+def test_unsupported_optimizer_is_a_clear_error():
+    data = dataloader.dataloader(YSD1, "dna", 1500, 3)
+    with pytest.raises(ValueError, match="Ftrl"):
+        bear_ref.train(data.repeat(2), 1365, 2, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Ftrl", False)
+
+
+def test_c_example_compiles_and_runs(tmp_path):
+    """examples/ref_step.c: a plain-C caller of the ABI (no Python, no torch) -- compiled with gcc against include/bear_hip.h and
+    run; its sums are checked against the C oracle on the same synthetic table."""
+    import subprocess
+    import c_oracle as co
+    from bear_amd import kernels
+    exe = tmp_path / "ref_step"
+    cmd = ["gcc", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "ref_step.c"), "-L" + os.path.join(ROOT, "bear_amd"), "-lbear_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+           "-Wl,-rpath," + os.path.join(ROOT, "bear_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    n = 300_000
+    p = subprocess.run([str(exe), str(n)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    import re
+    vals = [float(x) for x in re.findall(r"= (-?\d\.\d+e[+-]\d+)", p.stdout)]
+    assert len(vals) == 4, p.stdout
+    t = kernels.synth_counts(20211012, 0, n, torch.device("cuda"), want=("train", "ref"))
+    want = co.dm_ref(t["train"].cpu().numpy().view(np.uint32), t["ref"].cpu().numpy().view(np.uint32), 0.0, np.log(1 / 30), -np.log(100))
+    assert np.isclose(vals[0], want[0], rtol=1e-11)            # printed with 12 digits
+    assert np.allclose(vals[1:], want[1:], rtol=1e-5)          # printed with 6 digits
