@@ -484,7 +484,8 @@ def test_graph_capture_failure_falls_back_to_the_eager_loop(monkeypatch, ysd1):
     ls = []
     with pytest.warns(UserWarning, match="capture"):
         p, _, _ = bear_ref.train(*args, loss_save=ls)
-    assert ls == ls_graph and [x.item() for x in p] == [x.item() for x in p_graph]
+    # same kernels, same order of steps; the ticketed work distribution inside a launch reorders the fp64 sums by an ulp
+    assert np.allclose(ls, ls_graph, rtol=1e-13) and np.allclose([x.item() for x in p], [x.item() for x in p_graph], rtol=1e-11)
     from bear_amd import _lib
 
     class Bad:
