@@ -23,6 +23,7 @@ SYMBOLS = [
     "bear_stat_source", "bear_cache_write", "bear_cache_info", "bear_cache_read", "bear_shuffle_rows", "bear_shuffle_source_row",
     "bear_stream_read", "bear_encode_kmers_i8", "bear_ref_train_step_f64", "bear_net_linear_train_step_f64", "bear_cnn_reserve", "bear_net_cnn_train_step_f64", "bear_cnn_param_count", "bear_cnn_forward_f64", "bear_cnn_backward_f64",
     "bear_dm_prior_plan_dev_f64", "bear_train_apply_f64", "bear_ref_train_reduce_f64", "bear_net_linear_train_reduce_f64", "bear_net_cnn_train_reduce_f64",
+    "bear_eval_plan_create", "bear_eval_plan_destroy", "bear_eval_plan_bytes", "bear_eval_plan_f64",
     "bear_shard_rows_count", "bear_parse_counts_tsv_shard",
     "bear_kmer_sort_create", "bear_kmer_sort_reduce", "bear_kmer_sort_destroy", "bear_count_last_hip_error", "bear_write_counts_tsv", "bear_fastx_size", "bear_fastx_encode",
 ]
@@ -106,11 +107,16 @@ def _load():
     L.bear_shard_rows_count.argtypes = [u64, u64, u64, u64, cint, cint, ctypes.POINTER(u64)]
     L.bear_parse_counts_tsv_shard.argtypes = [ctypes.c_char_p, cint, cint, u64, u64, u64, u64, cint, cint, u64, vp, vp, ctypes.POINTER(u64),
                                               ctypes.POINTER(u64)]
+    L.bear_eval_plan_create.argtypes = [vp, vp, u64, ctypes.POINTER(vp), vp]
+    L.bear_eval_plan_destroy.argtypes = [vp]
+    L.bear_eval_plan_bytes.argtypes = [vp]
+    L.bear_eval_plan_bytes.restype = u64
+    L.bear_eval_plan_f64.argtypes = [vp, vp, vp, vp, vp, u64, vp, cint, cint, vp, cint, dbl, u64, u64, vp, vp]
     L.bear_count_rows.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]
     L.bear_parse_counts_tsv.argtypes = [ctypes.c_char_p, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name in ("bear_plan_bytes", "bear_shuffle_source_row"):
+        if name in ("bear_plan_bytes", "bear_shuffle_source_row", "bear_eval_plan_bytes"):
             continue
         if fn.restype is ctypes.c_int and name not in ("bear_abi_version", "bear_last_hip_error"):
             fn.restype = cint

@@ -125,6 +125,14 @@ class ResidentBatches:
             self.batches.append(entry)
         del shuffled
 
+    def eval_plan(self, k, column="test"):
+        """Sorted plan of batch k's test column (built on first use, kept for later evaluations of the same shard)."""
+        e = self.batches[k]
+        key = ("eval", column)
+        if key not in e["plans"]:
+            e["plans"][key] = kernels.EvalPlan(e[column])
+        return e["plans"][key]
+
     def plan(self, k, column, ncol):
         e = self.batches[k]
         key = (column, ncol)
@@ -268,7 +276,7 @@ GRAPH_MAX_BATCHES = 64    # an epoch of at most this many resident batches is ca
 MAX_EVAL_MODELS = 64   # EVL_MAX_MODELS of kernels_eval.h: h values + van_reg values per launch
 
 
-def evaluation_sums(test, prior, h, van_reg, train=None, eps=epsilon, noise_seed=0, row_base=0):
+def evaluation_sums(test, prior, h, van_reg, train=None, eps=epsilon, noise_seed=0, row_base=0, plan=None):
     """The 7 partial sums of ``_evaluation_step`` (bear_net.py:323-371) for this rank's rows: one launch of
     ``bear_eval_f64`` (all h values, the AR model and all van_reg values in a single pass over the rows).
     test / train: uint32 [n,5] device slabs; prior: float64 [n,5] = ar_func rows; h: float or 1-D sequence
@@ -284,8 +292,12 @@ def evaluation_sums(test, prior, h, van_reg, train=None, eps=epsilon, noise_seed
     for k in range(0, max(hs.size, 1), step):        # more h values than fit one launch: chunks, noise stream seed + k
         hk = hs[k:k + step]
         first = k == 0
-        out = kernels.evaluate(test, prior, hk, van if first else None, train, eps=eps, with_ar=first,
-                               noise_seed=noise_seed + k, row_base=row_base).cpu().numpy()
+        if plan is not None:      # resident table: the sorted plan of the test column (kernels_evalplan.h)
+            out = kernels.evaluate_planned(plan, prior, hk, van if first else None, train, eps=eps, with_ar=first,
+                                           noise_seed=noise_seed + k, row_base=row_base).cpu().numpy()
+        else:
+            out = kernels.evaluate(test, prior, hk, van if first else None, train, eps=eps, with_ar=first,
+                                   noise_seed=noise_seed + k, row_base=row_base).cpu().numpy()
         H, V = hk.size, van.size if first else 0
         ll_ear.append(out[:H])
         cor_ear.append(out[H + V + 1:2 * H + V + 1])

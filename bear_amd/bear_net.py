@@ -99,9 +99,10 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
     res = _train.ResidentBatches(data, cols, device, want_codes=True)
     total = None
     with torch.no_grad():
-        for e in res.batches:
+        for k, e in enumerate(res.batches):
             prior = ar_func(e["codes"]).expand(e["rows"], 5).contiguous() if e["rows"] else torch.zeros((0, 5), dtype=dtype, device=device)
-            part = _train.evaluation_sums(e["test"], prior, h, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"])
+            part = _train.evaluation_sums(e["test"], prior, h, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"],
+                                           plan=res.eval_plan(k) if e["rows"] else None)
             total = part if total is None else tuple(a + b for a, b in zip(total, part))
     return total, device
 

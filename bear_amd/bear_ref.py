@@ -130,9 +130,10 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
     hv = float(torch.as_tensor(h).item()) if np.ndim(torch.as_tensor(h).detach().cpu().numpy()) == 0 else torch.as_tensor(h).detach().cpu().numpy()
     total = None
     with torch.no_grad():
-        for e in res.batches:
+        for k, e in enumerate(res.batches):
             prior = ar_func(e["codes"], _ref_input(e["ref"], dtype)) if e["rows"] else torch.zeros((0, 5), dtype=dtype, device=device)
             prior = prior.expand(e["rows"], 5).contiguous()
-            part = _train.evaluation_sums(e["test"], prior, hv, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"])
+            part = _train.evaluation_sums(e["test"], prior, hv, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"],
+                                           plan=res.eval_plan(k) if e["rows"] else None)
             total = part if total is None else tuple(a + b for a, b in zip(total, part))
     return _train.reduce_evaluation(total, device, np.ndim(hv) == 0)

@@ -21,6 +21,7 @@
 #include "kernels_sample.h"
 #include "kernels_shuffle.h"
 #include "kernels_cnn.h"
+#include "kernels_evalplan.h"
 
 #ifdef PLN_STAMPS  // developer build: per-wave phase timers of dm_prior_plan_kernel land in ws->dbg
 #define PLN_DBG_ARG , ws->dbg
@@ -127,6 +128,13 @@ int bear_ws_create(int device, bear_ws **out) {
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_ref_sorted_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(srt_lds_r));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_plan_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(evp_lds));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_plan_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(evp_lds));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_plan_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(evp_lds));
+
     }
   }
   (void)hipSetDevice(prev);
@@ -746,8 +754,8 @@ static int launch_eval(bear_ws *ws, const uint32_t *test, const uint32_t *train,
   const uint64_t tiles = (n_rows + EVS_THREADS - 1) / EVS_THREADS;
   const int grid = (int)(tiles < (uint64_t)ws->eval_blocks ? (tiles ? tiles : 1) : (uint64_t)ws->eval_blocks);
   static_assert(EVS_NOUT <= EVL_MAX_OUT, "compact partials fit the evaluation partial buffer");
-  for (int m0 = 0; m0 == 0 || m0 < n_models; m0 += EVS_CHUNK) {
-    const int m_cnt = n_models - m0 < EVS_CHUNK ? n_models - m0 : EVS_CHUNK;
+  for (int m0 = 0; m0 == 0 || m0 < n_models; m0 += EVP_MAXC) {
+    const int m_cnt = n_models - m0 < EVP_MAXC ? n_models - m0 : EVP_MAXC;
     const int common = m0 == 0;
     evs_slots S;
     for (int k = 0; k < EVS_NOUT; ++k) S.slot[k] = -1;
@@ -769,18 +777,16 @@ static int launch_eval(bear_ws *ws, const uint32_t *test, const uint32_t *train,
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
-int bear_eval_f64(bear_ws *ws, const uint32_t *test, const uint32_t *train, const double *prior, uint64_t n_rows,
-                  const double *h, int n_h, int with_ar, const double *van_reg, int n_van, double eps,
-                  uint64_t noise_seed, uint64_t row_base, double *out, void *stream) {
-  int st = check_ws(ws);
-  if (st != BEAR_OK) return st;
+static int eval_make_args(const uint32_t *test, const uint32_t *train, const double *prior, uint64_t n_rows, const double *h, int n_h,
+                          int with_ar, const double *van_reg, int n_van, double eps, uint64_t noise_seed, uint64_t row_base,
+                          const double *out, evl_args *Aout) {
   if (!out || n_h < 0 || n_van < 0 || n_h + n_van > EVL_MAX_MODELS || (n_h && !h) || (n_van && !van_reg))
     return BEAR_ERR_INVALID_ARG;
   if ((n_h || with_ar) && !prior && n_rows) return BEAR_ERR_INVALID_ARG;
   if (n_rows && !test) return BEAR_ERR_INVALID_ARG;
   if (misaligned(test) || misaligned(train) || misaligned(prior)) return BEAR_ERR_INVALID_ARG;
   if (!(eps >= 0.0)) return BEAR_ERR_INVALID_ARG;
-  evl_args A;
+  evl_args &A = *Aout;
   memset(&A, 0, sizeof(A));
   A.n_h = n_h;
   A.n_van = n_van;
@@ -795,7 +801,129 @@ int bear_eval_f64(bear_ws *ws, const uint32_t *test, const uint32_t *train, cons
     A.inv_h[j] = 1.0 / h[j];
   }
   for (int k = 0; k < n_van; ++k) A.inv_h[n_h + k] = van_reg[k];
+  return BEAR_OK;
+}
+
+int bear_eval_f64(bear_ws *ws, const uint32_t *test, const uint32_t *train, const double *prior, uint64_t n_rows,
+                  const double *h, int n_h, int with_ar, const double *van_reg, int n_van, double eps,
+                  uint64_t noise_seed, uint64_t row_base, double *out, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  evl_args A;
+  st = eval_make_args(test, train, prior, n_rows, h, n_h, with_ar, van_reg, n_van, eps, noise_seed, row_base, out, &A);
+  if (st != BEAR_OK) return st;
   return launch_eval(ws, test, train, prior, n_rows, A, out, static_cast<hipStream_t>(stream));
+}
+
+// ---- evaluation on a sorted plan of the test column (kernels_evalplan.h) ------------------------------------------------
+struct bear_eval_plan {
+  int device;
+  uint64_t n_rows, n_tiles;
+  const uint32_t *test;  // the buffer the plan was built from (identity check only)
+  uint16_t *items;       // [n_tiles][EVP_ITEMS_CAP]
+  uint32_t *tile_info;   // [n_tiles]
+  uint64_t bytes;
+};
+
+int bear_eval_plan_create(bear_ws *ws, const uint32_t *test, uint64_t n_rows, bear_eval_plan **out, void *stream) {
+  if (!out) return BEAR_ERR_INVALID_ARG;
+  *out = nullptr;
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if ((n_rows && !test) || misaligned(test)) return BEAR_ERR_INVALID_ARG;
+  bear_eval_plan *p = new (std::nothrow) bear_eval_plan();
+  if (!p) return BEAR_ERR_NOMEM;
+  memset(p, 0, sizeof(*p));
+  p->device = ws->device;
+  p->n_rows = n_rows;
+  p->test = test;
+  p->n_tiles = (n_rows + EVP_ROWS - 1) / EVP_ROWS;
+  if (p->n_tiles) {
+    // + 1 KiB: the last DMA piece of a tile's lists may be issued for a partial KiB
+    const size_t ibytes = sizeof(uint16_t) * EVP_ITEMS_CAP * (size_t)p->n_tiles + 1024;
+    hipError_t e = hipMalloc(&p->items, ibytes);
+    if (e == hipSuccess) e = hipMalloc(&p->tile_info, sizeof(uint32_t) * ((size_t)p->n_tiles + 2));
+    if (e == hipSuccess) e = hipMemsetAsync(p->tile_info, 0, sizeof(uint32_t) * ((size_t)p->n_tiles + 2), static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+      (void)hipFree(p->items);
+      (void)hipFree(p->tile_info);
+      delete p;
+      g_last_hip_error = (int)e;
+      return e == hipErrorOutOfMemory ? BEAR_ERR_NOMEM : BEAR_ERR_HIP;
+    }
+    const uint64_t cap = (uint64_t)ws->num_cu * 16;
+    const int grid = (int)(p->n_tiles < cap ? p->n_tiles : cap);
+    hipLaunchKernelGGL(evp_build_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), test, n_rows, p->n_tiles, p->items,
+                       p->tile_info);
+    e = hipGetLastError();
+    if (e != hipSuccess) {
+      (void)hipFree(p->items);
+      (void)hipFree(p->tile_info);
+      delete p;
+      g_last_hip_error = (int)e;
+      return BEAR_ERR_HIP;
+    }
+    p->bytes = ibytes + sizeof(uint32_t) * ((size_t)p->n_tiles + 2);
+  }
+  *out = p;
+  return BEAR_OK;
+}
+
+int bear_eval_plan_destroy(bear_eval_plan *plan) {
+  if (!plan) return BEAR_OK;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(plan->device);
+  (void)hipFree(plan->items);
+  (void)hipFree(plan->tile_info);
+  (void)hipSetDevice(prev);
+  delete plan;
+  return BEAR_OK;
+}
+
+uint64_t bear_eval_plan_bytes(const bear_eval_plan *plan) { return plan ? plan->bytes : 0; }
+
+int bear_eval_plan_f64(bear_ws *ws, const bear_eval_plan *plan, const uint32_t *test, const uint32_t *train, const double *prior,
+                       uint64_t n_rows, const double *h, int n_h, int with_ar, const double *van_reg, int n_van, double eps,
+                       uint64_t noise_seed, uint64_t row_base, double *out, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!plan || plan->test != test || plan->n_rows != n_rows || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
+  evl_args A;
+  st = eval_make_args(test, train, prior, n_rows, h, n_h, with_ar, van_reg, n_van, eps, noise_seed, row_base, out, &A);
+  if (st != BEAR_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int n_models = A.n_h + A.n_van;
+  const uint64_t nt = plan->n_tiles;
+  const int grid = (int)(nt < (uint64_t)ws->num_cu ? (nt ? nt : 1) : (uint64_t)ws->num_cu);   // one resident 1024-thread block per CU
+  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  for (int m0 = 0; m0 == 0 || m0 < n_models; m0 += EVP_MAXC) {
+    const int m_cnt = n_models - m0 < EVP_MAXC ? n_models - m0 : EVP_MAXC;
+    const int common = m0 == 0;
+    evs_slots S;
+    for (int k = 0; k < EVS_NOUT; ++k) S.slot[k] = -1;
+    for (int k = 0; k < m_cnt; ++k) {
+      const int m = m0 + k;
+      const int ll_slot = m < A.n_h ? m : m + 1;                 // ll_arm sits between the BEAR and vanilla blocks
+      S.slot[k] = ll_slot;
+      S.slot[EVS_CHUNK + k] = n_models + 1 + ll_slot;
+    }
+    if (common) {
+      S.slot[2 * EVS_CHUNK] = A.n_h;
+      S.slot[2 * EVS_CHUNK + 1] = n_models + 1 + A.n_h;
+      S.slot[2 * EVS_CHUNK + 2] = 2 * n_models + 2;
+    }
+#define EVP_LAUNCH(MC)                                                                                                              \
+  hipLaunchKernelGGL(eval_plan_kernel<MC>, dim3(grid), dim3(EVP_THREADS), sizeof(evp_lds), s, test, train, prior, n_rows, A, m0, m_cnt, \
+                     common, plan->items, plan->tile_info, nt, lt, ws->eval_partials)
+    if (m_cnt <= 1) EVP_LAUNCH(1);
+    else if (m_cnt <= 2) EVP_LAUNCH(2);
+    else EVP_LAUNCH(4);
+#undef EVP_LAUNCH
+    hipLaunchKernelGGL(eval_sorted_finalize_kernel, dim3((EVS_NOUT + 3) / 4), dim3(256), 0, s, ws->eval_partials, grid, S, out);
+  }
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
 }
 
 int bear_bmm_f64(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, const double *alpha, int n_alpha, double *out,

@@ -32,15 +32,23 @@ struct evl_args {
   double inv_h[EVL_MAX_MODELS];               // [0, n_h): 1 / h_j; [n_h, n_h + n_van): v_k
 };
 
-// The Box-Muller value of kernels_synth.h:gauss (= oracle eval_noise) on cheaper primitives: table log, hardware sqrt,
-// cospi (exact range reduction) -- the same number to a few ulp; an arg-max decision could only differ when two noisy
-// values agree to ~1e-15 of sigma.
+// Tie-breaking noise: one Box-Muller draw per (seed, model id, global row, letter) from ONE 64-bit hash word --
+//   k = mix64(mix64(seed + model) ^ (row * 5 + letter)),  u1 = (k >> 32 + 1/2) 2^-32,  u2 = (k & 0xffffffff + 1/2) 2^-32,
+//   z = sqrt(-2 ln u1) cos(2 pi u2)           (|z| < 6.8 for 32-bit uniforms; oracle/bear_oracle.py:eval_noise restates it)
+// evaluated on the table log, hardware sqrt and cospi (exact range reduction): the oracle's number to a few ulp; an arg-max
+// decision could only differ when two noisy values agree to ~1e-15 of sigma.
+__device__ __forceinline__ uint64_t evl_key(uint64_t model_base, uint64_t cell) { return mix64(model_base ^ cell); }
 __device__ __forceinline__ double evl_gauss(uint64_t k, const double2 *logtab) {
-  const double u1 = u01(mix64(k)), u2 = u01(mix64(k ^ 0x5851F42D4C957F2Dull));
+  const double u1 = ((double)(uint32_t)(k >> 32) + 0.5) * 0x1p-32, u2 = ((double)(uint32_t)k + 0.5) * 0x1p-32;
   return sqrt(-2.0 * bear_log_tab(u1, logtab)) * cospi(2.0 * u2);
 }
-__device__ __forceinline__ double evl_normal(uint64_t seed, uint32_t model, uint64_t cell, const double2 *logtab) {
-  return evl_gauss(mix64(mix64(seed + (uint64_t)model) ^ cell), logtab);
+// The same value in fp32 on the hardware transcendentals (v_log_f32, v_sqrt_f32, v_cos_f32: ~6 instructions instead of ~70).
+// |error| <= 1e-5 whenever -2 ln u1 >= 1e-4; `*tiny` reports the other case (probability 5e-5), where only the exact form counts.
+__device__ __forceinline__ float evl_gauss_f32(uint64_t k, bool *tiny) {
+  const float u1 = ((float)(uint32_t)(k >> 32) + 0.5f) * 0x1p-32f, u2 = ((float)(uint32_t)k + 0.5f) * 0x1p-32f;
+  const float r2 = -1.3862943611198906f * __builtin_amdgcn_logf(u1);     // -2 ln 2 log2(u1)
+  *tiny = !(r2 >= 1e-4f);
+  return __builtin_amdgcn_sqrtf(r2) * __builtin_amdgcn_cosf(u2);        // v_cos_f32 takes revolutions
 }
 
 // largest entry and whether it wins whatever the noise (|z| < 8.6: a gap above 17.5 sigma cannot be bridged)
@@ -61,26 +69,50 @@ __device__ __forceinline__ bool evl_argmax_clear(const double (&a)[5], double si
 }
 
 // arg-max of a[b] + sigma z_b over the letters that can still win (within 17.5 sigma of the largest entry); the noise of
-// the others is never formed.  First index on exact ties, as argmax does.
+// the others is never formed.  First index on exact ties, as argmax does.  A first pass in fp32 decides whenever the two
+// best noisy values are more than 2e-4 sigma apart (20x its error bound); the rest (~0.05 % of the calls) repeat in fp64.
 __device__ __noinline__ int evl_argmax_noisy(const double (&a)[5], double sigma, uint64_t seed, uint32_t model, uint64_t row,
                                                 const double2 *logtab) {
   double top = a[0];
 #pragma unroll
   for (int b = 1; b < 5; ++b) top = a[b] > top ? a[b] : top;
   const uint64_t base = mix64(seed + (uint64_t)model);
+  const double inv_sigma = 1.0 / sigma;
+  {
+    int i1 = -1;
+    float v1 = -INFINITY, v2 = -INFINITY;
+    bool unsure = false;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      if (top - a[b] <= 17.5 * sigma) {
+        bool tiny;
+        const float v = (float)((a[b] - top) * inv_sigma) + evl_gauss_f32(evl_key(base, row * 5 + b), &tiny);
+        unsure |= tiny;
+        if (v > v1) {
+          v2 = v1;
+          v1 = v;
+          i1 = b;
+        } else if (v > v2) {
+          v2 = v;
+        }
+      }
+    }
+    if (i1 < 0) return 0;   // no contender only when the concentrations are NaN: index 0, as argmax of NaNs does
+    if (!unsure && v1 - v2 > 2e-4f) return i1;
+  }
   int i1 = -1;
   double v1 = -INFINITY;
 #pragma unroll
   for (int b = 0; b < 5; ++b) {
     if (top - a[b] <= 17.5 * sigma) {
-      const double v = __builtin_fma(sigma, evl_gauss(mix64(base ^ (row * 5 + b)), logtab), a[b]);
+      const double v = __builtin_fma(sigma, evl_gauss(evl_key(base, row * 5 + b), logtab), a[b]);
       if (v > v1) {
         v1 = v;
         i1 = b;
       }
     }
   }
-  return i1 < 0 ? 0 : i1;   // no contender only when the concentrations are NaN: index 0, as argmax of NaNs does
+  return i1 < 0 ? 0 : i1;
 }
 
 // ------------------------------------------------------------------------------------------------ sorted formulation
@@ -148,7 +180,6 @@ __global__ __launch_bounds__(EVS_THREADS) void eval_sorted_kernel(const uint32_t
 #pragma unroll
     for (int b = 0; b < 5; ++b) t[b] = live ? (double)s_tst[tid * 5 + b] : 0.0;
     const double n = ((t[0] + t[1]) + (t[2] + t[3])) + t[4];
-    const uint64_t grow = A.row_base + row0 + tid;
     uint32_t rank[6], key[6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {

@@ -251,6 +251,54 @@ def evaluate(test, prior, h, van_reg, train=None, eps=EPSILON, with_ar=True, noi
     return out
 
 
+class EvalPlan:
+    """Sorted plan of a resident TEST column (``bear_eval_plan_create``): per tile the cells and row totals with a non-zero
+    count, sorted by count.  Keeps the count tensor alive; built asynchronously on the current stream."""
+
+    def __init__(self, test, ws=None):
+        test = _check_rows(test, torch.int32, "test")
+        self.test = test
+        self.ws = ws or default_workspace(test.device)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(test.device):
+            st = _lib.lib().bear_eval_plan_create(self.ws.handle, _ptr(test), test.shape[0], ctypes.byref(h), _stream())
+        _lib.check(st, "bear_eval_plan_create")
+        self._h = h
+
+    @property
+    def nbytes(self):
+        return int(_lib.lib().bear_eval_plan_bytes(self._h))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().bear_eval_plan_destroy(h)
+            except Exception:
+                pass
+
+
+def evaluate_planned(plan, prior, h, van_reg, train=None, eps=EPSILON, with_ar=True, noise_seed=0, row_base=0):
+    """One ``bear_eval_plan_f64`` call: ``evaluate`` on a sorted plan of the test column (same output vector)."""
+    test = plan.test
+    n = test.shape[0]
+    if train is not None:
+        _check_rows(train, torch.int32, "train")
+    if prior is not None:
+        _check_rows(prior, torch.float64, "prior")
+    for t in (train, prior):
+        if t is not None and (t.shape[0] != n or t.data_ptr() % 16):
+            raise ValueError("train and prior must be 16-byte aligned with one row per planned context")
+    hs, hp = _host_f64(h) if h is not None else (np.zeros(0), ctypes.c_void_p(0))
+    vs, vp = _host_f64(van_reg) if van_reg is not None else (np.zeros(0), ctypes.c_void_p(0))
+    out = torch.empty(2 * (hs.size + vs.size) + 3, dtype=torch.float64, device=test.device)
+    with torch.cuda.device(test.device):
+        st = _lib.lib().bear_eval_plan_f64(plan.ws.handle, plan._h, _ptr(test), _ptr(train), _ptr(prior), n, hp, hs.size, int(bool(with_ar)),
+                                           vp, vs.size, float(eps), int(noise_seed), int(row_base), _ptr(out), _stream())
+    _lib.check(st, "bear_eval_plan_f64")
+    return out
+
+
 def bmm(counts, alpha, ws=None):
     """sum_i lbeta(counts_i + alpha_k) - lbeta(alpha_k) for every alpha_k (dataloader.py:111-118): device [V]."""
     counts = _check_rows(counts, torch.int32, "counts")

@@ -237,6 +237,22 @@ int bear_eval_f64(bear_ws *ws, const uint32_t *test, const uint32_t *train, cons
                   uint64_t noise_seed, uint64_t row_base, double *out, void *stream);
 
 /*
+ * The same on a sorted plan of the TEST column, for a table that stays resident (a held-out evaluation after training, the
+ * train-set evaluation, every value of an h_scan): bear_eval_plan_create sorts, per tile of 704 contexts, the cells and the
+ * row totals with a non-zero test count by count (asynchronous on `stream`; ~12 B of plan per context); bear_eval_plan_f64
+ * then streams the three row slabs and the plan through LDS and evaluates wave-uniform units of equal counts -- rows without
+ * test transitions cost nothing.  Arguments, output vector and noise stream are those of bear_eval_f64 (identical results up to
+ * the order of the fp64 sums; accuracies exactly).  The plan is valid for exactly the buffer contents it was built from.
+ */
+typedef struct bear_eval_plan bear_eval_plan;
+int bear_eval_plan_create(bear_ws *ws, const uint32_t *test, uint64_t n_rows, bear_eval_plan **out, void *stream);
+int bear_eval_plan_destroy(bear_eval_plan *plan);
+uint64_t bear_eval_plan_bytes(const bear_eval_plan *plan);
+int bear_eval_plan_f64(bear_ws *ws, const bear_eval_plan *plan, const uint32_t *test, const uint32_t *train, const double *prior,
+                       uint64_t n_rows, const double *h, int n_h, int with_ar, const double *van_reg, int n_van, double eps,
+                       uint64_t noise_seed, uint64_t row_base, double *out, void *stream);
+
+/*
  * BMM marginal likelihood of one dataset column: replaces _marginal_step of bear_model/dataloader.py:111-118,
  *   out[k] = sum_i lbeta(counts_i + alpha_k) - lbeta(alpha_k 1_5),   alpha [host] n_alpha <= 64, out [dev].
  */

@@ -277,14 +277,15 @@ EVAL_ID_ARM, EVAL_ID_VAN = 1000, 2000
 
 def eval_noise(seed, model, rows, width=5):
     """The counter-based N(0,1) stream the evaluation entry point uses in place of tf.random.normal
-    (core.py:69-71, 134-136): one Box-Muller draw per (seed, model id, global row, letter).  Model ids:
-    j for the j-th h, EVAL_ID_ARM for the AR model, EVAL_ID_VAN + k for the k-th van_reg."""
+    (core.py:69-71, 134-136): one Box-Muller draw per (seed, model id, global row, letter), both uniforms from
+    one 64-bit hash word (32 bits each).  Model ids: j for the j-th h, EVAL_ID_ARM for the AR model,
+    EVAL_ID_VAN + k for the k-th van_reg."""
     rows = np.asarray(rows, dtype=np.uint64)
     cell = rows[:, None] * np.uint64(width) + np.arange(width, dtype=np.uint64)[None, :]
     with np.errstate(over="ignore"):
         key = _mix64(_mix64(np.uint64(seed) + np.uint64(model)) ^ cell)
-        u1 = _u01(_mix64(key))
-        u2 = _u01(_mix64(key ^ np.uint64(0x5851F42D4C957F2D)))
+    u1 = ((key >> np.uint64(32)).astype(np.float64) + 0.5) * 2.0 ** -32
+    u2 = ((key & np.uint64(0xFFFFFFFF)).astype(np.float64) + 0.5) * 2.0 ** -32
     return np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586 * u2)
 
 

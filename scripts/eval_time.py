@@ -1,25 +1,34 @@
-"""Dev helper: time bear_eval_f64 / bear_bmm_f64 on the synthetic table."""
+"""Held-out evaluation kernels on the synthetic k=13 table: planned (sorted test-column plan) vs unplanned, kernel-only times."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import time
+import torch
 from bear_amd import kernels
-N = int(float(os.environ.get("N", "1e8")))
-dev = torch.device("cuda", 0)
-t = kernels.synth_counts(20211012, 0, N, dev, want=("train", "test"))
-f = kernels.synth_prior(20211012, 0, N, dev)
-van = [0.1, 1.0, 10.0]
-res = []
-for name, fn in [("eval H=1 V=3", lambda: kernels.evaluate(t["test"], f, [1.0], van, t["train"])),
-                 ("eval H=1 V=3 no-train", lambda: kernels.evaluate(t["test"], f, [1.0], van, None)),
-                 ("h_scan H=16 V=1", lambda: kernels.evaluate(t["test"], f, np.geomspace(0.01, 100, 16), [1.0], t["train"], with_ar=False)),
-                 ("bmm V=3", lambda: kernels.bmm(t["train"], van))]:
-    fn(); torch.cuda.synchronize()
-    best = 1e9
-    for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5): out = fn()
-        e1.record(); torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / 5)
-    res.append(f"{name}: {best:.3f} ms ({N / best / 1e6:.1f} Gctx/s)")
-print(" | ".join(res))
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
+dev = torch.device("cuda")
+t = kernels.synth_counts(20211012, 0, n, dev, want=("train", "test"))
+f = kernels.synth_prior(20211012, 0, n, dev)
+torch.cuda.synchronize()
+t0 = time.time()
+plan = kernels.EvalPlan(t["test"])
+torch.cuda.synchronize()
+print(f"plan build {time.time() - t0:.4f} s, {plan.nbytes / n:.2f} B/context")
+
+
+def timed(fn, reps=5):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+for name, hs, van in (("1 h + AR + 3 van_reg", [1.0], [0.1, 1.0, 10.0]), ("1 h + AR", [1.0], None), ("AR + 3 van", None, [0.1, 1.0, 10.0]),
+                      ("h_scan 16", list(range(1, 17)), [1.0])):
+    ms_p = timed(lambda: kernels.evaluate_planned(plan, f, hs, van, t["train"]))
+    ms_u = timed(lambda: kernels.evaluate(t["test"], f, hs, van, t["train"]), 2)
+    print(f"{name:24s} planned {ms_p:8.3f} ms = {n / ms_p / 1e6:7.2f} Gctx/s ({80 * n / ms_p / 1e6 / 8000:.3f} of HBM peak) | unplanned {ms_u:8.3f} ms = {n / ms_u / 1e6:6.2f} Gctx/s")

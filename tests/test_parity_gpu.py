@@ -3,6 +3,7 @@ inputs.  Tolerance: north_star asks 1e-9 relative on the fp64 ELBO; we hold 1e-1
 ELBO and 1e-9 (relative to the L1 mass of the gradient terms) on gradients."""
 import numpy as np
 import pytest
+import torch
 
 import bear_oracle as o
 import c_oracle as co
@@ -491,3 +492,113 @@ def test_eval_many_models_across_launch_chunks(dev):
         assert np.allclose(parts[k], want[k], rtol=ELBO_RTOL, atol=0), k
     for k in (3, 4, 5, 6):
         assert np.array_equal(np.asarray(parts[k]), np.asarray(want[k])), k
+
+
+def _eval_parts(got, H, V):
+    return (got[:H], got[H], got[H + 1:H + 1 + V], got[H + V + 1:2 * H + V + 1], got[2 * H + V + 1],
+            got[2 * H + V + 2:2 * H + 2 * V + 2], got[-1])
+
+
+@pytest.mark.parametrize("case", ["ysd1", "sparse", "ties", "edge", "dense", "tiny", "empty_rows"])
+def test_eval_plan_kernel_parity(case, dev, ysd1):
+    """bear_eval_plan_f64 (sorted plan of the test column, kernels_evalplan.h): log-likelihoods within ELBO_RTOL of the oracle,
+    correct-transition counts and total length exactly, with and without training counts, for any row sharding; and equal to
+    the unplanned entry."""
+    from bear_amd import kernels
+    if case == "ysd1":
+        tr, te = ysd1[1][:, 0].astype(np.uint32), ysd1[1][:, 1].astype(np.uint32)
+    elif case == "sparse":
+        tr, te, _ = sparse_table(20011, 3)          # 29 tiles, the last one ragged
+    elif case == "ties":    # uniform prior, no evidence: every arg-max is decided by the noise stream
+        te, _, _ = sparse_table(5000, 9)
+        tr = np.zeros_like(te)
+    elif case == "dense":   # every cell on the Stirling path, every row heavy
+        tr, _ = dense_table(3000, 2)
+        te = (tr // 3).astype(np.uint32)
+    elif case == "tiny":    # fewer rows than one unit
+        tr, te, _ = sparse_table(37, 5, lam_scale=3.0)
+    elif case == "empty_rows":   # whole tiles without a test transition
+        tr, te, _ = sparse_table(4000, 6)
+        te[:2900] = 0
+    else:
+        tr, _ = CASES_REF["edge"]()
+        te = tr[::-1].copy()
+    n = len(te)
+    f = prior_rows(n, 4, 1.0) if case != "ties" else np.full((n, 5), 0.2)
+    hs, van = np.array([0.05, 1.0, 37.0]), np.array([0.1, 1.0, 10.0])
+    d_te, d_tr, d_f = _to_dev(te, dev), _to_dev(tr, dev), _to_dev(f, dev)
+    plan = kernels.EvalPlan(d_te)
+    assert plan.nbytes > 0
+    H, V = 3, 3
+    for use_train in (True, False):
+        want = o.evaluation_step(te, f, hs, van, tr if use_train else None, rng=o.HashNoise(77, 1000, n))
+        got = kernels.evaluate_planned(plan, d_f, hs, van, d_tr if use_train else None, noise_seed=77, row_base=1000).cpu().numpy()
+        parts = _eval_parts(got, H, V)
+        for k in (0, 1, 2):
+            assert np.allclose(parts[k], want[k], rtol=ELBO_RTOL, atol=0), (case, use_train, k, parts[k], want[k])
+        for k in (3, 4, 5, 6):
+            assert np.array_equal(np.asarray(parts[k]), np.asarray(want[k])), (case, use_train, k, parts[k], want[k])
+        old = kernels.evaluate(d_te, d_f, hs, van, d_tr if use_train else None, noise_seed=77, row_base=1000).cpu().numpy()
+        assert np.array_equal(old[H + V + 1:], got[H + V + 1:]) and np.allclose(old[:H + V + 1], got[:H + V + 1], rtol=1e-12)
+        if n >= 8:
+            cut = (n // 3) // 4 * 4
+            pa, pb = kernels.EvalPlan(d_te[:cut].clone()), kernels.EvalPlan(d_te[cut:].clone())
+            a = kernels.evaluate_planned(pa, d_f[:cut].clone(), hs, van, d_tr[:cut].clone() if use_train else None, noise_seed=77, row_base=1000)
+            b = kernels.evaluate_planned(pb, d_f[cut:].clone(), hs, van, d_tr[cut:].clone() if use_train else None, noise_seed=77,
+                                         row_base=1000 + cut)
+            both = (a + b).cpu().numpy()
+            assert np.array_equal(both[H + V + 1:], got[H + V + 1:])
+            assert np.allclose(both[:H + V + 1], got[:H + V + 1], rtol=1e-12)
+    # no AR model, vanilla models only, no prior at all (what bmm-style callers pass)
+    got = kernels.evaluate_planned(plan, None, None, van, d_tr, with_ar=False, noise_seed=3).cpu().numpy()
+    want = o.evaluation_step(te, np.full((n, 5), 0.2), 1.0, van, tr, rng=o.HashNoise(3, 0, n))
+    assert np.allclose(got[1:1 + V], want[2], rtol=ELBO_RTOL) and np.array_equal(got[V + 2:2 * V + 2], want[5]) and got[-1] == want[6]
+
+
+def test_eval_plan_many_models_and_zero_rows(dev):
+    """20 h values + 5 van_reg values = 25 DM models = seven launches of at most 4 models on one plan (an h_scan,
+    bear_net.py:465-531); an empty shard is a valid plan."""
+    from bear_amd import kernels
+    tr, te, _ = sparse_table(7001, 11)
+    n = len(te)
+    f = prior_rows(n, 12, 0.8)
+    hs, van = np.geomspace(1e-3, 1e2, 20), np.array([0.05, 0.3, 1.0, 4.0, 25.0])
+    want = o.evaluation_step(te, f, hs, van, tr, rng=o.HashNoise(5, 0, n))
+    plan = kernels.EvalPlan(_to_dev(te, dev))
+    got = kernels.evaluate_planned(plan, _to_dev(f, dev), hs, van, _to_dev(tr, dev), noise_seed=5).cpu().numpy()
+    parts = _eval_parts(got, 20, 5)
+    for k in (0, 1, 2):
+        assert np.allclose(parts[k], want[k], rtol=ELBO_RTOL, atol=0), k
+    for k in (3, 4, 5, 6):
+        assert np.array_equal(np.asarray(parts[k]), np.asarray(want[k])), k
+    empty = torch.zeros((0, 5), dtype=torch.int32, device=dev)
+    pe = kernels.EvalPlan(empty)
+    z = kernels.evaluate_planned(pe, torch.zeros((0, 5), dtype=torch.float64, device=dev), [1.0], [1.0], empty).cpu().numpy()
+    assert np.all(z == 0.0)
+
+
+def test_eval_plan_full_size_properties(dev):
+    """2e7 synthetic contexts (the shard size of BASELINE configs[4]): shard additivity of the planned evaluation, agreement
+    with the unplanned kernel (itself held to the oracle above), sampled-chunk oracle parity, accuracies exactly."""
+    from bear_amd import kernels
+    n = 20_000_000
+    t = kernels.synth_counts(20211012, 0, n, dev, want=("train", "test"))
+    f = kernels.synth_prior(20211012, 0, n, dev)
+    hs, van = [0.7], [0.1, 1.0, 10.0]
+    plan = kernels.EvalPlan(t["test"])
+    got = kernels.evaluate_planned(plan, f, hs, van, t["train"], noise_seed=9).cpu().numpy()
+    old = kernels.evaluate(t["test"], f, hs, van, t["train"], noise_seed=9).cpu().numpy()
+    assert np.array_equal(got[5:], old[5:]) and np.allclose(got[:5], old[:5], rtol=1e-12)
+    cut = 7_000_000 // 704 * 704 + 64          # not a tile boundary of the whole table
+    pa, pb = kernels.EvalPlan(t["test"][:cut]), kernels.EvalPlan(t["test"][cut:])
+    a = kernels.evaluate_planned(pa, f[:cut], hs, van, t["train"][:cut], noise_seed=9)
+    b = kernels.evaluate_planned(pb, f[cut:], hs, van, t["train"][cut:], noise_seed=9, row_base=cut)
+    both = (a + b).cpu().numpy()
+    assert np.array_equal(both[5:], got[5:]) and np.allclose(both[:5], got[:5], rtol=1e-12)
+    lo, m = 12_345_678 // 4 * 4, 30_000
+    ps = kernels.EvalPlan(t["test"][lo:lo + m].clone())
+    gs = kernels.evaluate_planned(ps, f[lo:lo + m].clone(), hs, van, t["train"][lo:lo + m].clone(), noise_seed=9, row_base=lo).cpu().numpy()
+    want = o.evaluation_step(t["test"][lo:lo + m].cpu().numpy().view(np.uint32), f[lo:lo + m].cpu().numpy(), 0.7, np.array(van),
+                             t["train"][lo:lo + m].cpu().numpy().view(np.uint32), rng=o.HashNoise(9, lo, m))
+    assert np.isclose(gs[0], want[0], rtol=ELBO_RTOL) and np.isclose(gs[1], want[1], rtol=ELBO_RTOL) and np.allclose(gs[2:5], want[2], rtol=ELBO_RTOL)
+    assert gs[5] == want[3] and gs[6] == want[4] and np.array_equal(gs[7:10], want[5]) and gs[10] == want[6]
