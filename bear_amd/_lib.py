@@ -107,7 +107,7 @@ def _load():
     L.bear_shard_rows_count.argtypes = [u64, u64, u64, u64, cint, cint, ctypes.POINTER(u64)]
     L.bear_parse_counts_tsv_shard.argtypes = [ctypes.c_char_p, cint, cint, u64, u64, u64, u64, cint, cint, u64, vp, vp, ctypes.POINTER(u64),
                                               ctypes.POINTER(u64)]
-    L.bear_eval_plan_create.argtypes = [vp, vp, u64, ctypes.POINTER(vp), vp]
+    L.bear_eval_plan_create.argtypes = [vp, vp, vp, u64, ctypes.POINTER(vp), vp]
     L.bear_eval_plan_destroy.argtypes = [vp]
     L.bear_eval_plan_bytes.argtypes = [vp]
     L.bear_eval_plan_bytes.restype = u64

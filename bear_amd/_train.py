@@ -125,12 +125,13 @@ class ResidentBatches:
             self.batches.append(entry)
         del shuffled
 
-    def eval_plan(self, k, column="test"):
-        """Sorted plan of batch k's test column (built on first use, kept for later evaluations of the same shard)."""
+    def eval_plan(self, k, column="test", train_column="train"):
+        """Sorted plan of batch k's test column given its conditioning column, if any (built on first use, kept for later
+        evaluations of the same shard)."""
         e = self.batches[k]
-        key = ("eval", column)
+        key = ("eval", column, train_column)
         if key not in e["plans"]:
-            e["plans"][key] = kernels.EvalPlan(e[column])
+            e["plans"][key] = kernels.EvalPlan(e[column], e.get(train_column))
         return e["plans"][key]
 
     def plan(self, k, column, ncol):
@@ -293,7 +294,7 @@ def evaluation_sums(test, prior, h, van_reg, train=None, eps=epsilon, noise_seed
         hk = hs[k:k + step]
         first = k == 0
         if plan is not None:      # resident table: the sorted plan of the test column (kernels_evalplan.h)
-            out = kernels.evaluate_planned(plan, prior, hk, van if first else None, train, eps=eps, with_ar=first,
+            out = kernels.evaluate_planned(plan, prior, hk, van if first else None, eps=eps, with_ar=first,
                                            noise_seed=noise_seed + k, row_base=row_base).cpu().numpy()
         else:
             out = kernels.evaluate(test, prior, hk, van if first else None, train, eps=eps, with_ar=first,

@@ -23,6 +23,11 @@
 #include "kernels_cnn.h"
 #include "kernels_evalplan.h"
 
+#ifdef EVP_STAMPS
+#define EVP_DBG_ARG , ws->dbg
+#else
+#define EVP_DBG_ARG
+#endif
 #ifdef PLN_STAMPS  // developer build: per-wave phase timers of dm_prior_plan_kernel land in ws->dbg
 #define PLN_DBG_ARG , ws->dbg
 #else
@@ -128,13 +133,12 @@ int bear_ws_create(int device, bear_ws **out) {
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_ref_sorted_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(srt_lds_r));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_plan_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(evp_lds));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_plan_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(evp_lds));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(eval_plan_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(evp_lds));
-
+      {
+        const void *evp[] = {reinterpret_cast<const void *>(eval_plan_kernel<0, 4>), reinterpret_cast<const void *>(eval_plan_kernel<1, 0>),
+                             reinterpret_cast<const void *>(eval_plan_kernel<1, 4>), reinterpret_cast<const void *>(eval_plan_kernel<4, 0>)};
+        for (const void *fn : evp)
+          if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(evp_lds));
+      }
     }
   }
   (void)hipSetDevice(prev);
@@ -754,8 +758,8 @@ static int launch_eval(bear_ws *ws, const uint32_t *test, const uint32_t *train,
   const uint64_t tiles = (n_rows + EVS_THREADS - 1) / EVS_THREADS;
   const int grid = (int)(tiles < (uint64_t)ws->eval_blocks ? (tiles ? tiles : 1) : (uint64_t)ws->eval_blocks);
   static_assert(EVS_NOUT <= EVL_MAX_OUT, "compact partials fit the evaluation partial buffer");
-  for (int m0 = 0; m0 == 0 || m0 < n_models; m0 += EVP_MAXC) {
-    const int m_cnt = n_models - m0 < EVP_MAXC ? n_models - m0 : EVP_MAXC;
+  for (int m0 = 0; m0 == 0 || m0 < n_models; m0 += EVS_CHUNK) {
+    const int m_cnt = n_models - m0 < EVS_CHUNK ? n_models - m0 : EVS_CHUNK;
     const int common = m0 == 0;
     evs_slots S;
     for (int k = 0; k < EVS_NOUT; ++k) S.slot[k] = -1;
@@ -819,24 +823,25 @@ int bear_eval_f64(bear_ws *ws, const uint32_t *test, const uint32_t *train, cons
 struct bear_eval_plan {
   int device;
   uint64_t n_rows, n_tiles;
-  const uint32_t *test;  // the buffer the plan was built from (identity check only)
+  const uint32_t *test, *train;  // the buffers the plan was built from (identity check only; train may be NULL)
   uint16_t *items;       // [n_tiles][EVP_ITEMS_CAP]
   uint32_t *tile_info;   // [n_tiles]
   uint64_t bytes;
 };
 
-int bear_eval_plan_create(bear_ws *ws, const uint32_t *test, uint64_t n_rows, bear_eval_plan **out, void *stream) {
+int bear_eval_plan_create(bear_ws *ws, const uint32_t *test, const uint32_t *train, uint64_t n_rows, bear_eval_plan **out, void *stream) {
   if (!out) return BEAR_ERR_INVALID_ARG;
   *out = nullptr;
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
-  if ((n_rows && !test) || misaligned(test)) return BEAR_ERR_INVALID_ARG;
+  if ((n_rows && !test) || misaligned(test) || misaligned(train)) return BEAR_ERR_INVALID_ARG;
   bear_eval_plan *p = new (std::nothrow) bear_eval_plan();
   if (!p) return BEAR_ERR_NOMEM;
   memset(p, 0, sizeof(*p));
   p->device = ws->device;
   p->n_rows = n_rows;
   p->test = test;
+  p->train = train;
   p->n_tiles = (n_rows + EVP_ROWS - 1) / EVP_ROWS;
   if (p->n_tiles) {
     // + 1 KiB: the last DMA piece of a tile's lists may be issued for a partial KiB
@@ -853,8 +858,8 @@ int bear_eval_plan_create(bear_ws *ws, const uint32_t *test, uint64_t n_rows, be
     }
     const uint64_t cap = (uint64_t)ws->num_cu * 16;
     const int grid = (int)(p->n_tiles < cap ? p->n_tiles : cap);
-    hipLaunchKernelGGL(evp_build_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), test, n_rows, p->n_tiles, p->items,
-                       p->tile_info);
+    hipLaunchKernelGGL(evp_build_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), test, train, n_rows, p->n_tiles,
+                       p->items, p->tile_info);
     e = hipGetLastError();
     if (e != hipSuccess) {
       (void)hipFree(p->items);
@@ -888,39 +893,55 @@ int bear_eval_plan_f64(bear_ws *ws, const bear_eval_plan *plan, const uint32_t *
                        uint64_t noise_seed, uint64_t row_base, double *out, void *stream) {
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
-  if (!plan || plan->test != test || plan->n_rows != n_rows || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
+  if (!plan || plan->test != test || plan->train != train || plan->n_rows != n_rows || plan->device != ws->device)
+    return BEAR_ERR_INVALID_ARG;
   evl_args A;
   st = eval_make_args(test, train, prior, n_rows, h, n_h, with_ar, van_reg, n_van, eps, noise_seed, row_base, out, &A);
   if (st != BEAR_OK) return st;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int n_models = A.n_h + A.n_van;
   const uint64_t nt = plan->n_tiles;
-  const int grid = (int)(nt < (uint64_t)ws->num_cu ? (nt ? nt : 1) : (uint64_t)ws->num_cu);   // one resident 1024-thread block per CU
+  const int grid = (int)(nt < (uint64_t)ws->num_cu ? (nt ? nt : 1) : (uint64_t)ws->num_cu);   // one resident 768-thread block per CU
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
-  for (int m0 = 0; m0 == 0 || m0 < n_models; m0 += EVP_MAXC) {
-    const int m_cnt = n_models - m0 < EVP_MAXC ? n_models - m0 : EVP_MAXC;
-    const int common = m0 == 0;
+  // launches: BEAR models (product path) four at a time, vanilla models (lgamma tables) four at a time -- a BEAR group and a
+  // vanilla group share a launch; the first launch also carries the AR model and the total length.
+  int h0 = 0, v0 = 0;
+  bool first = true;
+  while (first || h0 < A.n_h || v0 < A.n_van) {
+    const int nh = A.n_h - h0 < EVP_MAXH ? A.n_h - h0 : EVP_MAXH;
+    int nv = A.n_van - v0 < EVP_MAXV ? A.n_van - v0 : EVP_MAXV;
+    if (nh > 1) nv = 0;   // four BEAR models fill the register file (168 per lane at three waves per SIMD): the vanilla group follows
+    int common = first ? 1 : 0;
     evs_slots S;
     for (int k = 0; k < EVS_NOUT; ++k) S.slot[k] = -1;
-    for (int k = 0; k < m_cnt; ++k) {
-      const int m = m0 + k;
-      const int ll_slot = m < A.n_h ? m : m + 1;                 // ll_arm sits between the BEAR and vanilla blocks
-      S.slot[k] = ll_slot;
-      S.slot[EVS_CHUNK + k] = n_models + 1 + ll_slot;
+    for (int k = 0; k < nh; ++k) {            // output: ll_ear[n_h], ll_arm, ll_van[n_van], cor_ear[n_h], cor_arm, cor_van[n_van], total
+      S.slot[k] = h0 + k;
+      S.slot[EVS_CHUNK + k] = n_models + 1 + h0 + k;
+    }
+    for (int k = 0; k < nv; ++k) {
+      S.slot[EVP_SLOT_VAN + k] = A.n_h + 1 + v0 + k;
+      S.slot[EVS_CHUNK + EVP_SLOT_VAN + k] = n_models + 1 + A.n_h + 1 + v0 + k;
     }
     if (common) {
       S.slot[2 * EVS_CHUNK] = A.n_h;
       S.slot[2 * EVS_CHUNK + 1] = n_models + 1 + A.n_h;
       S.slot[2 * EVS_CHUNK + 2] = 2 * n_models + 2;
     }
-#define EVP_LAUNCH(MC)                                                                                                              \
-  hipLaunchKernelGGL(eval_plan_kernel<MC>, dim3(grid), dim3(EVP_THREADS), sizeof(evp_lds), s, test, train, prior, n_rows, A, m0, m_cnt, \
-                     common, plan->items, plan->tile_info, nt, lt, ws->eval_partials)
-    if (m_cnt <= 1) EVP_LAUNCH(1);
-    else if (m_cnt <= 2) EVP_LAUNCH(2);
-    else EVP_LAUNCH(4);
+#ifdef EVP_DEBUG_SWITCHES
+    if (const char *dbgs = getenv("BEAR_EVP_DEBUG")) common |= atoi(dbgs) << 4;
+#endif
+#define EVP_LAUNCH(NH_, NV_)                                                                                                        \
+  hipLaunchKernelGGL((eval_plan_kernel<NH_, NV_>), dim3(grid), dim3(EVP_THREADS), sizeof(evp_lds), s, test, train, prior, n_rows, A, \
+                     h0, nh, v0, nv, common, plan->items, plan->tile_info, nt, lt, ws->eval_partials EVP_DBG_ARG)
+    if (nh == 0) EVP_LAUNCH(0, 4);
+    else if (nh == 1 && nv == 0) EVP_LAUNCH(1, 0);
+    else if (nh == 1) EVP_LAUNCH(1, 4);
+    else EVP_LAUNCH(4, 0);
 #undef EVP_LAUNCH
     hipLaunchKernelGGL(eval_sorted_finalize_kernel, dim3((EVS_NOUT + 3) / 4), dim3(256), 0, s, ws->eval_partials, grid, S, out);
+    h0 += nh;
+    v0 += nv;
+    first = false;
   }
   HIP_TRY(hipGetLastError());
   return BEAR_OK;

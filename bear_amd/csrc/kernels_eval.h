@@ -51,6 +51,11 @@ __device__ __forceinline__ float evl_gauss_f32(uint64_t k, bool *tiny) {
   return __builtin_amdgcn_sqrtf(r2) * __builtin_amdgcn_cosf(u2);        // v_cos_f32 takes revolutions
 }
 
+// log of a probability that may be zero or (malformed prior rows) negative, on the table log
+__device__ __forceinline__ double evl_log_any(double p, const double2 *logtab) {
+  return p > 0.0 ? bear_log_tab(p, logtab) : (p == 0.0 ? -INFINITY : __builtin_nan(""));
+}
+
 // largest entry and whether it wins whatever the noise (|z| < 8.6: a gap above 17.5 sigma cannot be bridged)
 __device__ __forceinline__ bool evl_argmax_clear(const double (&a)[5], double sigma, int &i1) {
   i1 = 0;
@@ -71,35 +76,12 @@ __device__ __forceinline__ bool evl_argmax_clear(const double (&a)[5], double si
 // arg-max of a[b] + sigma z_b over the letters that can still win (within 17.5 sigma of the largest entry); the noise of
 // the others is never formed.  First index on exact ties, as argmax does.  A first pass in fp32 decides whenever the two
 // best noisy values are more than 2e-4 sigma apart (20x its error bound); the rest (~0.05 % of the calls) repeat in fp64.
-__device__ __noinline__ int evl_argmax_noisy(const double (&a)[5], double sigma, uint64_t seed, uint32_t model, uint64_t row,
-                                                const double2 *logtab) {
-  double top = a[0];
-#pragma unroll
-  for (int b = 1; b < 5; ++b) top = a[b] > top ? a[b] : top;
-  const uint64_t base = mix64(seed + (uint64_t)model);
-  const double inv_sigma = 1.0 / sigma;
-  {
-    int i1 = -1;
-    float v1 = -INFINITY, v2 = -INFINITY;
-    bool unsure = false;
-#pragma unroll
-    for (int b = 0; b < 5; ++b) {
-      if (top - a[b] <= 17.5 * sigma) {
-        bool tiny;
-        const float v = (float)((a[b] - top) * inv_sigma) + evl_gauss_f32(evl_key(base, row * 5 + b), &tiny);
-        unsure |= tiny;
-        if (v > v1) {
-          v2 = v1;
-          v1 = v;
-          i1 = b;
-        } else if (v > v2) {
-          v2 = v;
-        }
-      }
-    }
-    if (i1 < 0) return 0;   // no contender only when the concentrations are NaN: index 0, as argmax of NaNs does
-    if (!unsure && v1 - v2 > 2e-4f) return i1;
-  }
+// The fp64 form is out of line with its arguments BY VALUE (registers): inlined, the constants of its cospi / sqrt / log
+// expansions get hoisted into the caller's loops (60 registers, spilled); by reference the concentrations would travel through
+// scratch memory.
+__device__ __noinline__ int evl_argmax_exact(double a0, double a1, double a2, double a3, double a4, double top, double sigma,
+                                             uint64_t base, uint64_t row, const double2 *logtab) {
+  const double a[5] = {a0, a1, a2, a3, a4};
   int i1 = -1;
   double v1 = -INFINITY;
 #pragma unroll
@@ -113,6 +95,38 @@ __device__ __noinline__ int evl_argmax_noisy(const double (&a)[5], double sigma,
     }
   }
   return i1 < 0 ? 0 : i1;
+}
+__device__ __forceinline__ int evl_argmax_noisy(const double (&a)[5], double sigma, uint64_t seed, uint32_t model, uint64_t row,
+                                                const double2 *logtab) {
+  double top = a[0];
+#pragma unroll
+  for (int b = 1; b < 5; ++b) top = a[b] > top ? a[b] : top;
+  const uint64_t base = mix64(seed + (uint64_t)model);
+  const float inv_sigma = (float)(1.0 / sigma);
+  // branch-free: the five hash chains are independent and interleave; letters out of contention score -inf
+  float v[5];
+  bool unsure = false, any = false;
+#pragma unroll
+  for (int b = 0; b < 5; ++b) {
+    const bool cont = top - a[b] <= 17.5 * sigma;
+    bool tiny;
+    const float z = evl_gauss_f32(evl_key(base, row * 5 + b), &tiny);
+    v[b] = cont ? (float)(a[b] - top) * inv_sigma + z : -INFINITY;
+    unsure |= cont && tiny;
+    any |= cont;
+  }
+  if (!any) return 0;   // no contender only when the concentrations are NaN: index 0, as argmax of NaNs does
+  int i1 = 0;
+  float v1 = v[0], v2 = -INFINITY;
+#pragma unroll
+  for (int b = 1; b < 5; ++b) {
+    const bool gt = v[b] > v1;
+    v2 = gt ? v1 : (v[b] > v2 ? v[b] : v2);
+    i1 = gt ? b : i1;
+    v1 = gt ? v[b] : v1;
+  }
+  if (unsure || !(v1 - v2 > 2e-4f)) i1 = evl_argmax_exact(a[0], a[1], a[2], a[3], a[4], top, sigma, base, row, logtab);
+  return i1;
 }
 
 // ------------------------------------------------------------------------------------------------ sorted formulation
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(EVS_THREADS) void eval_sorted_kernel(const uint32_t
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
           p[b] = (live && A.has_prior ? s_pri[tid * 5 + b] : 1.0) + eps;
-          if (t[b] != 0.0) ll = __builtin_fma(t[b], p[b] > 0.0 ? bear_log_tab(p[b], s_log) : bear_log(p[b]), ll);
+          if (t[b] != 0.0) ll = __builtin_fma(t[b], evl_log_any(p[b], s_log), ll);
         }
         acc_arm += ll;
         if (n != 0.0) {
@@ -231,18 +245,13 @@ __global__ __launch_bounds__(EVS_THREADS) void eval_sorted_kernel(const uint32_t
     for (uint32_t i = tid; i < s_ntie; i += EVS_THREADS) {
       const uint32_t e = s_tie[i], row = e >> 4, slot = e & 15u;
       double a[5];
-      int im;
-      if (slot == (uint32_t)EVS_CHUNK) {
+      const bool is_arm = slot == (uint32_t)EVS_CHUNK;
+      const int m = is_arm ? 0 : m0 + (int)slot;
 #pragma unroll
-        for (int b = 0; b < 5; ++b) a[b] = (A.has_prior ? s_pri[row * 5 + b] : 1.0) + eps;
-        im = evl_argmax_noisy(a, eps, A.seed, EVL_ID_ARM, A.row_base + row0 + row, s_log);
-      } else {
-        const int m = m0 + (int)slot;
-#pragma unroll
-        for (int b = 0; b < 5; ++b) a[b] = conc(m, row, b);
-        im = evl_argmax_noisy(a, sig_dm, A.seed, m < A.n_h ? (uint32_t)m : EVL_ID_VAN + (uint32_t)(m - A.n_h),
-                              A.row_base + row0 + row, s_log);
-      }
+      for (int b = 0; b < 5; ++b) a[b] = is_arm ? (A.has_prior ? s_pri[row * 5 + b] : 1.0) + eps : conc(m, row, b);
+      const int im = evl_argmax_noisy(a, is_arm ? eps : sig_dm, A.seed,
+                                      is_arm ? EVL_ID_ARM : (m < A.n_h ? (uint32_t)m : EVL_ID_VAN + (uint32_t)(m - A.n_h)),
+                                      A.row_base + row0 + row, s_log);
       const double hit = (double)s_tst[row * 5 + im];
       if (slot == (uint32_t)EVS_CHUNK) acc_carm += hit;
 #pragma unroll

@@ -1,59 +1,82 @@
 // kernels_evalplan.h -- held-out evaluation (bear_net.py:323-371, bear_ref.py:391-446, one batch of h_scan :465-531) on a
 // sorted plan of the TEST column.
 //
-// The test counts of a resident table are as constant as its training counts, so -- as for the training step
-// (kernels_plan.h) -- everything that depends on them alone is done once, at load time (bear_eval_plan_create): per tile of
-// EVP_ROWS consecutive contexts two lists, sorted by count,
-//     cells   (row, letter) with a non-zero test count c      -> + D(conc_b, c) per DM model, c log(f_b + eps) for the AR model
-//     totals  rows with a non-zero total n = sum_b t_b         -> - D(sum_b conc_b, n) per DM model, and the arg-max accuracy
-// as uint16 offsets, each list padded to whole 64-lane units.  Rows without test transitions (52 % of the k=13 synthetic
-// table) appear in neither list and cost nothing.
+// The test (and training) counts of a resident table are constant, so -- as for the training step (kernels_plan.h) --
+// everything that depends on them alone is done once, at load time (bear_eval_plan_create): per tile of EVP_ROWS consecutive
+// contexts three lists of uint16 offsets, each padded to whole 64-lane units,
+//     cells   (row, letter) with a non-zero test count c, sorted by c  -> + D(conc_b, c) per DM model, c log(f_b + eps) (AR model)
+//     totals  rows with a non-zero total n = sum_b t_b, sorted by n    -> - D(sum_b conc_b, n) per DM model, the arg-max accuracy
+//     ties    those rows whose two largest TRAINING counts are equal   -> the vanilla models' arg-max is decided by the noise
+// Rows without test transitions (52 % of the k=13 synthetic table) appear in no list and cost nothing.
 //
-// Per launch: one 1024-thread block per CU owns a contiguous range of tiles; two of its 16 waves only stream -- by LDS-DMA --
-// the next tile's test, training and prior rows and its two lists into the other half of an LDS double buffer (see
-// dm_prior_plan_kernel for why dedicated DMA waves); the other 14 draw tickets from an LDS counter, ONE barrier per tile:
-//     total units first (lane = one row, sorted by n: the whole row from LDS, for every DM model of the launch the
-//       concentrations, -D(A, n) as a wave-uniform product loop + table log, and the arg-max; undecided (row, model) pairs --
-//       ties within 17.5 sigma, common on sparse tables because equal counts tie -- go to an LDS list),
-//     then cell units (lane = one cell, sorted by c: wave-uniform product loops for all models at once),
-//     then, once every total unit of the tile has been retired (an LDS counter, no barrier), the tie list, densely: the
-//       tie-breaking noise (core.py:69-71) is evaluated in fp32 on the hardware transcendentals and only repeated in fp64
-//       when the two best noisy values are closer than 20x the fp32 error bound.
+// Why the kernel looks the way it does (measured on MI355X, profiles/r02*): a unit of 64 items is one wave running one serial
+// fp64 dependency chain -- ~8 clocks per instruction, 2-4 us per unit -- so throughput is a matter of how many units are in
+// flight, not of instruction counts.  A first version kept kernels_plan.h's structure (two-slot ring, ONE workgroup barrier per
+// tile, a dynamic tie list resolved after the tile's totals): a tile of 704 rows holds only ~13 units for 10 compute waves, and
+// the waves spent 45 % of their time at the barrier or waiting for the slowest total unit (23 Gctx/s).  Hence:
+//   * NO barrier in the loop.  A three-slot LDS ring; per slot an arrival counter of the DMA waves (`landed`) and a departure
+//     counter of the compute waves (`left`).  A compute wave that finds a tile's tickets exhausted moves on to the next tile
+//     at once; a slot is refilled when every compute wave has left it.  Stragglers finish their unit while the others are
+//     already one or two tiles ahead.
+//   * ALL work static.  The vanilla models' ties depend on the training counts only (integers: the arg-max of r_b + v + eps is
+//     tied exactly when the two largest r_b are equal, whatever v), so the plan lists them and they are ordinary tickets; the
+//     rare ties of the BEAR / AR models (continuous concentrations) are resolved in place.
+//   * short units.  A row's work is split into an "H" unit (AR + BEAR models: needs the prior row) and a "V" unit (vanilla
+//     models: integer arg-max, lgamma tables); ties are (row, model) units.
+// Per launch: one 768-thread block per CU (168 registers per lane: no spills -- at 1024 threads the spilled loop state went
+// through scratch memory every tile); two of its 12 waves only stream, by LDS-DMA, the tiles' test / training / prior rows and
+// lists into the ring (see dm_prior_plan_kernel for why dedicated DMA waves), the other 10 draw tickets.
+//
+// The two model families cost very different amounts (measured: 854 VALU instructions per total unit when all four models of
+// the bench configuration went through the general product path):
+//     BEAR models   conc_b = f_b / h + r_b + eps: continuous -> wave-uniform product loop + table log per model;
+//     vanilla models conc_b = r_b + v + eps with INTEGER r_b: D(conc_b, c) = T[r_b + c] - T[r_b] with T[k] = lgamma(k + v + eps)
+//       from a per-launch LDS table (k < 128; larger counts take the general routine), and for the row total
+//       T5[N_r + n] - T5[N_r], T5[k] = lgamma(k + 5 (v + eps)): two LDS reads per model and item.
+// The tie-breaking noise (core.py:69-71) is evaluated in fp32 on the hardware transcendentals and only repeated in fp64 when
+// the two best noisy values are closer than 20x the fp32 error bound (kernels_eval.h).
 // Sums: per-thread fp64 accumulators -> wave shuffle -> LDS -> one partial per block -> fixed-order finalize kernel.
 #pragma once
 #include "kernels_eval.h"
 #include "kernels_plan.h"
 
-#define EVP_THREADS 1024
+#ifndef EVP_THREADS
+#define EVP_THREADS 768
+#endif
 #define EVP_WAVES (EVP_THREADS / 64)
 #define EVP_DMA_WAVES 2
+#define EVP_CWAVES (EVP_WAVES - EVP_DMA_WAVES)    // compute waves
+#define EVP_NSLOT 3                               // LDS ring: a tile being finished, the tile being worked on, a tile landing
 #ifndef EVP_ROWS
-#define EVP_ROWS 704                              // contexts per tile (multiple of 64; row0 * 20 B stays 16-byte aligned)
+#define EVP_ROWS 448                              // contexts per tile (multiple of 64; row0 * 20 B stays 16-byte aligned)
 #endif
 #define EVP_CELL_CAP (EVP_ROWS * 5)               // cells of a tile (multiple of 64)
-#define EVP_ITEMS_CAP (EVP_CELL_CAP + EVP_ROWS)   // uint16 entries per tile in the plan (fixed stride)
+#define EVP_ITEMS_CAP (EVP_CELL_CAP + 2 * EVP_ROWS)   // uint16 entries per tile in the plan (fixed stride): cells | totals | ties
 #define EVP_SENT_CELL (EVP_ROWS * 5)              // neutral cell: test count 0 (padding of the last unit)
 #define EVP_SENT_ROW EVP_ROWS                     // neutral row: no test transitions
-#define EVP_MAXC 4                                // DM models per launch (register accumulators; more models = more launches)
-#define EVP_TIECAP (EVP_ROWS * (EVP_MAXC + 1))    // undecided (row, model) pairs of a tile: every pair fits
-#define EVP_SLOT_ARM 15u                          // model slot of the AR model in a tie entry
-static_assert(EVP_ROWS % 64 == 0 && (EVP_ROWS * 20) % 16 == 0, "tile geometry");
-static_assert(EVP_ROWS * 16 + 15 < 65536, "tie entries are uint16: row * 16 + model slot");
+#define EVP_MAXH 4                                // BEAR models per launch (register accumulators; more models = more launches)
+#define EVP_MAXV 4                                // vanilla models per launch
+#define EVP_TABK 128                              // lgamma table length of the vanilla models
+#define EVP_SLOT_VAN 4u                           // partial slots: 0..3 BEAR, 4..7 vanilla
+static_assert(EVP_ROWS % 64 == 0 && (EVP_ROWS * 20) % 16 == 0 && EVP_ROWS * 5 < 4096 && EVP_ROWS < 1024, "tile geometry / info word");
+#define EVP_INFO(n_cells, n_tots, n_ties) ((n_cells) | ((n_tots) << 12) | ((n_ties) << 22))
 
 // ---------------------------------------------------------------------------------------------------- plan construction
 // One block per tile: counting sort of the tile's cells and totals by min(count, 32) (LDS histogram, rank = the atomic's
-// return value), lists written to the tile's fixed-stride slot; tile_info[t] = n_cells | n_totals << 16.
-__global__ __launch_bounds__(256) void evp_build_kernel(const uint32_t *__restrict__ test, uint64_t n_rows, uint64_t n_tiles,
-                                                        uint16_t *__restrict__ items, uint32_t *__restrict__ tile_info) {
+// return value), the tie rows in any order; lists written to the tile's fixed-stride slot; tile_info[t] = EVP_INFO(...).
+__global__ __launch_bounds__(256) void evp_build_kernel(const uint32_t *__restrict__ test, const uint32_t *__restrict__ train,
+                                                        uint64_t n_rows, uint64_t n_tiles, uint16_t *__restrict__ items,
+                                                        uint32_t *__restrict__ tile_info) {
   constexpr int RPT = (EVP_ROWS + 255) / 256;
-  __shared__ uint32_t hist[2][34], offs[2][34];
+  __shared__ uint32_t hist[2][34], offs[2][34], n_tie_s;
   const uint32_t tid = threadIdx.x;
   for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const uint64_t row0 = t * EVP_ROWS;
     const uint32_t rows = (uint32_t)(n_rows - row0 < EVP_ROWS ? n_rows - row0 : EVP_ROWS);
     if (tid < 68) (&hist[0][0])[tid] = 0;
+    if (tid == 0) n_tie_s = 0;
     __syncthreads();
-    uint32_t key[RPT][6], rank[RPT][6];
+    uint32_t key[RPT][6], rank[RPT][6], tie_at[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       const uint32_t lr = tid + 256u * k;
@@ -73,6 +96,21 @@ __global__ __launch_bounds__(256) void evp_build_kernel(const uint32_t *__restri
         key[k][b] = c > 32u ? 32u : c;
         rank[k][b] = key[k][b] ? atomicAdd(&hist[b == 5][key[k][b]], 1u) : 0u;
       }
+      tie_at[k] = 0xffffffffu;
+      if (lr < rows && nsat != 0) {   // a row with test transitions whose two largest training counts are equal
+        uint32_t rmax = 0, ntop = 5;  // no training column: all five concentrations equal
+        if (train) {
+          rmax = train[(row0 + lr) * 5];
+          ntop = 1;
+#pragma unroll
+          for (int b = 1; b < 5; ++b) {
+            const uint32_t r = train[(row0 + lr) * 5 + b];
+            ntop = r > rmax ? 1u : ntop + (r == rmax ? 1u : 0u);
+            rmax = r > rmax ? r : rmax;
+          }
+        }
+        if (ntop >= 2u) tie_at[k] = atomicAdd(&n_tie_s, 1u);
+      }
     }
     __syncthreads();
     if (tid < 2) {
@@ -84,8 +122,8 @@ __global__ __launch_bounds__(256) void evp_build_kernel(const uint32_t *__restri
       offs[tid][33] = run;
     }
     __syncthreads();
-    const uint32_t n_cells = offs[0][33], n_tots = offs[1][33];
-    const uint32_t pad_cells = (n_cells + 63u) & ~63u, pad_tots = (n_tots + 63u) & ~63u;
+    const uint32_t n_cells = offs[0][33], n_tots = offs[1][33], n_ties = n_tie_s;
+    const uint32_t pad_cells = (n_cells + 63u) & ~63u, pad_tots = (n_tots + 63u) & ~63u, pad_ties = (n_ties + 63u) & ~63u;
     uint16_t *dst = items + t * (uint64_t)EVP_ITEMS_CAP;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -94,10 +132,12 @@ __global__ __launch_bounds__(256) void evp_build_kernel(const uint32_t *__restri
       for (int b = 0; b < 5; ++b)
         if (key[k][b]) dst[offs[0][key[k][b]] + rank[k][b]] = (uint16_t)(lr * 5 + b);
       if (key[k][5]) dst[pad_cells + offs[1][key[k][5]] + rank[k][5]] = (uint16_t)lr;
+      if (tie_at[k] != 0xffffffffu) dst[pad_cells + pad_tots + tie_at[k]] = (uint16_t)lr;
     }
     for (uint32_t i = n_cells + tid; i < pad_cells; i += 256) dst[i] = (uint16_t)EVP_SENT_CELL;
     for (uint32_t i = n_tots + tid; i < pad_tots; i += 256) dst[pad_cells + i] = (uint16_t)EVP_SENT_ROW;
-    if (tid == 0) tile_info[t] = n_cells | (n_tots << 16);
+    for (uint32_t i = n_ties + tid; i < pad_ties; i += 256) dst[pad_cells + pad_tots + i] = (uint16_t)EVP_SENT_ROW;
+    if (tid == 0) tile_info[t] = EVP_INFO(n_cells, n_tots, n_ties);
     __syncthreads();
   }
 }
@@ -110,12 +150,15 @@ struct evp_buf {
   __attribute__((aligned(16))) uint16_t items[EVP_ITEMS_CAP];
 };
 struct evp_lds {
-  evp_buf buf[2];
+  evp_buf buf[EVP_NSLOT];
   double2 logtab[BEAR_LOGTAB_N];
+  double tabC[EVP_MAXV][EVP_TABK];   // lgamma(k + v + eps) - lgamma(v + eps)           (cells of the vanilla models)
+  double tabT[EVP_MAXV][EVP_TABK];   // lgamma(k + 5 (v + eps)) - lgamma(5 (v + eps))   (row totals)
   double red[EVP_WAVES][EVS_NOUT];
-  uint16_t tie[EVP_TIECAP];
-  uint32_t info[2];        // n_cells | n_totals << 16 of the tile in each slot (written by the DMA wave that staged it)
-  uint32_t ticket[2], tie_ticket[2], tot_done[2], n_tie[2];
+  uint32_t info[EVP_NSLOT];     // EVP_INFO of the tile in each slot (written by the DMA wave that staged it)
+  uint32_t ticket[EVP_NSLOT];   // work tickets of the tile in the slot
+  uint32_t landed[EVP_NSLOT];   // += 1 by the DMA wave that streamed a tile once it is in LDS: the slot's g-th tile is there at g + 1
+  uint32_t left[EVP_NSLOT];     // += 1 by each compute wave that has no more work in the slot's tile: free again at 10 (g + 1)
 };
 
 // D(x, c) for MC models at once on the product path (1 <= c <= SRT_CL; lanes with c == 0 yield 0), wave-uniform bounds.
@@ -172,268 +215,408 @@ __device__ __forceinline__ void evp_general_D(const double (&x)[MC], double c, b
   }
 }
 
-template <int MC>
+__device__ __forceinline__ uint32_t evp_peek(const uint32_t *p) {
+  return srt_uniform(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+
+// NH / NV: BEAR / vanilla models this instantiation carries (nh <= NH, nv <= NV of them are live: models h0 .. h0 + nh and
+// v0 .. v0 + nv of A; A.inv_h[j] = 1 / h_j for j < n_h, A.inv_h[n_h + k] = van_reg[k]).
+template <int NH, int NV>
 __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *__restrict__ test, const uint32_t *__restrict__ train,
-                                                                 const double *__restrict__ prior, uint64_t n_rows, evl_args A, int m0,
-                                                                 int m_cnt, int do_common, const uint16_t *__restrict__ plan_items,
+                                                                 const double *__restrict__ prior, uint64_t n_rows, evl_args A, int h0,
+                                                                 int nh, int v0, int nv, int do_common,
+                                                                 const uint16_t *__restrict__ plan_items,
                                                                  const uint32_t *__restrict__ tile_info, uint64_t n_tiles,
-                                                                 const double2 *__restrict__ logtab_g, double *__restrict__ partials) {
+                                                                 const double2 *__restrict__ logtab_g, double *__restrict__ partials
+#ifdef EVP_STAMPS
+                                                                 , unsigned long long *__restrict__ dbg
+#endif
+                                                                 ) {
+#ifdef EVP_STAMPS   // developer build: per-wave cycle totals by phase (0 wait for a tile, 1 H units, 2 cell units, 3 V units, 4 tie units, 5 ticket draws / rest, 6 DMA issue, 7 DMA wait)
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#define EVP_STAMP(k)                                              \
+  {                                                               \
+    const unsigned long long now = __builtin_amdgcn_s_memtime();  \
+    tph[k] += now - t_prev;                                       \
+    t_prev = now;                                                 \
+  }
+#else
+#define EVP_STAMP(k)
+#endif
+  constexpr int NHA = NH > 0 ? NH : 1, NVA = NV > 0 ? NV : 1;   // array extents (zero-length arrays are not C++)
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   evp_lds &S = *reinterpret_cast<evp_lds *>(srt_smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = srt_uniform(tid >> 6);
   const double eps = A.eps, sig_dm = 100.0 * A.eps;
-  double acc_ll[MC], acc_cor[MC], acc_arm = 0.0, acc_carm = 0.0, acc_tot = 0.0;
+#ifdef EVP_DEBUG_SWITCHES
+  const int dbg_flags = do_common >> 4;   // developer build: 2 = no tie units, 4 = no cell units, 8 = no H units, 16 = no V units
+  do_common &= 15;
+#endif
+  double accH_ll[NHA], accH_cor[NHA], accV_ll[NVA], accV_cor[NVA], acc_arm = 0.0, acc_carm = 0.0, acc_tot = 0.0;
 #pragma unroll
-  for (int k = 0; k < MC; ++k) acc_ll[k] = acc_cor[k] = 0.0;
+  for (int k = 0; k < NHA; ++k) accH_ll[k] = accH_cor[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < NVA; ++k) accV_ll[k] = accV_cor[k] = 0.0;
+  // the launch's model parameters, once (wave-uniform: SGPRs)
+  double wh[NHA], ve[NVA];
+#pragma unroll
+  for (int k = 0; k < NHA; ++k) wh[k] = (NH > 0 && k < nh) ? A.inv_h[h0 + k] : 1.0;
+#pragma unroll
+  for (int k = 0; k < NVA; ++k) ve[k] = (NV > 0 && k < nv) ? A.inv_h[A.n_h + v0 + k] + eps : 1.0;
 
   if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
-  for (uint32_t i = tid; i < 2u * (EVP_ROWS * 5 + 8); i += EVP_THREADS) {   // absent columns read as 0 / 1; sentinel rows
+  if (NV > 0) {
+    for (uint32_t i = tid; i < 2u * EVP_MAXV * EVP_TABK; i += EVP_THREADS) {
+      const uint32_t which = i / (EVP_MAXV * EVP_TABK), k = (i / EVP_TABK) % EVP_MAXV, j = i % EVP_TABK;
+      double val = 0.0;
+      if ((int)k < nv && j > 0) {
+        const double v1 = A.inv_h[A.n_h + v0 + (int)k] + eps;
+        val = srt_general_fast(which ? 5.0 * v1 : v1, (double)j, logtab_g).D;
+      }
+      (which ? S.tabT : S.tabC)[k][j] = val;
+    }
+  }
+  for (uint32_t i = tid; i < (uint32_t)EVP_NSLOT * (EVP_ROWS * 5 + 8); i += EVP_THREADS) {   // absent columns read as 0 / 1; sentinel rows
     const uint32_t b = i / (EVP_ROWS * 5 + 8), k = i % (EVP_ROWS * 5 + 8);
     if (!A.has_train || k >= EVP_ROWS * 5) S.buf[b].trn[k] = 0u;
     if (k >= EVP_ROWS * 5) S.buf[b].tst[k] = 0u;
   }
-  for (uint32_t i = tid; i < 2u * (EVP_ROWS * 5 + 6); i += EVP_THREADS) {
+  for (uint32_t i = tid; i < (uint32_t)EVP_NSLOT * (EVP_ROWS * 5 + 6); i += EVP_THREADS) {
     const uint32_t b = i / (EVP_ROWS * 5 + 6), k = i % (EVP_ROWS * 5 + 6);
     if (!A.has_prior || k >= EVP_ROWS * 5) S.buf[b].pri[k] = 1.0;
   }
-  if (tid < 2) S.ticket[tid] = S.tie_ticket[tid] = S.tot_done[tid] = S.n_tie[tid] = S.info[tid] = 0u;
+  if (tid < EVP_NSLOT) S.ticket[tid] = S.landed[tid] = S.left[tid] = S.info[tid] = 0u;
 
-  const bool dma_wave = wave >= EVP_WAVES - EVP_DMA_WAVES;
-  const uint32_t dw = wave - (EVP_WAVES - EVP_DMA_WAVES);
+  const bool dma_wave = wave >= EVP_CWAVES;
+  const uint32_t dw = wave - EVP_CWAVES;
   const uint64_t G = gridDim.x;
   const uint64_t first = (n_tiles * (uint64_t)blockIdx.x) / G, count = (n_tiles * ((uint64_t)blockIdx.x + 1)) / G - first;
-  const __attribute__((address_space(4))) uint32_t *info_c = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)tile_info;
+  __syncthreads();
 
-  // DMA waves: every piece of tile `t` (info word `inf`) into ring slot `b`.  Row slabs are rows * 20 (or 40) bytes: whole
-  // 16-byte words by LDS-DMA, the up-to-3 trailing dwords of the table's last tile through the scalar path (a vector load
-  // would be followed by s_waitcnt vmcnt(0), which drains the DMA queue).
-  auto stage = [&](uint64_t t, uint32_t inf, uint32_t b) {
-    const uint64_t row0 = t * EVP_ROWS;
-    const uint32_t rows = (uint32_t)(n_rows - row0 < EVP_ROWS ? n_rows - row0 : EVP_ROWS);
-    const uint32_t n_cells = inf & 0xffffu, n_tots = inf >> 16;
-    const uint32_t ibytes = (((n_cells + 63u) & ~63u) + ((n_tots + 63u) & ~63u)) * 2u;
-    const uint32_t cbytes = (rows * 20u) & ~15u, pbytes = rows * 40u;   // rows * 40 is a multiple of 8: & ~15 below
-    evp_buf &B = S.buf[b];
-    uint32_t pc = dw;   // pieces dealt round-robin over the DMA waves across the slabs
-    auto slab = [&](void *lds, const void *src, uint32_t bytes) {
-      const uint32_t np = (bytes + 1023u) >> 10;
-      for (; pc < np; pc += EVP_DMA_WAVES) pln_dma_piece(lds, src, bytes, pc, lane);
-      pc -= np;
-    };
-    slab(B.items, plan_items + t * (uint64_t)EVP_ITEMS_CAP, ibytes);
-    slab(B.tst, test + row0 * 5, cbytes);
-    if (A.has_train) slab(B.trn, train + row0 * 5, cbytes);
-    if (A.has_prior) slab(B.pri, prior + row0 * 5, pbytes & ~15u);
-    if (dw == 0) {
-      const uint32_t tail0 = cbytes >> 2, ndw = rows * 5u;
-      for (uint32_t q = tail0; q < ndw; ++q) {
-        const __attribute__((address_space(4))) uint32_t *tc = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)(test + row0 * 5 + q);
-        const uint32_t v = *tc;
-        uint32_t w = 0;
-        if (A.has_train) {
-          const __attribute__((address_space(4))) uint32_t *rc = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)(train + row0 * 5 + q);
-          w = *rc;
+  if (dma_wave) {
+    // ================================================================================================ the two streaming waves
+    // Tile j of this block's range goes to slot j % 3 once every compute wave has left tile j - 3.  The two waves take
+    // alternate tiles, each wave all pieces of its tile: a tile is published the moment it has landed, whether or not the slot
+    // of the next one is free yet -- so the compute waves may run up to two tiles ahead of the slowest of them -- and up to two
+    // tiles (~80 KB) are in flight per CU.
+    __builtin_amdgcn_s_setprio(3);
+    const __attribute__((address_space(4))) uint32_t *info_c = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)tile_info;
+    uint32_t inf = dw < count ? info_c[first + dw] : 0u;
+    for (uint64_t j = dw; j < count; j += EVP_DMA_WAVES) {
+      const uint32_t b = (uint32_t)(j % EVP_NSLOT), gen = (uint32_t)(j / EVP_NSLOT);
+      const uint32_t inf_next = j + EVP_DMA_WAVES < count ? info_c[first + j + EVP_DMA_WAVES] : 0u;   // used one iteration later
+      EVP_STAMP(5)
+      while (evp_peek(&S.left[b]) < (uint32_t)EVP_CWAVES * gen) __builtin_amdgcn_s_sleep(1);
+      EVP_STAMP(0)
+      const uint64_t t = first + j, row0 = t * EVP_ROWS;
+      const uint32_t rows = (uint32_t)(n_rows - row0 < EVP_ROWS ? n_rows - row0 : EVP_ROWS);
+      const uint32_t n_cells = inf & 0xfffu, n_tots = (inf >> 12) & 0x3ffu, n_ties = inf >> 22;
+      const uint32_t ibytes = (((n_cells + 63u) & ~63u) + ((n_tots + 63u) & ~63u) + ((n_ties + 63u) & ~63u)) * 2u;
+      const uint32_t cbytes = (rows * 20u) & ~15u, pbytes = rows * 40u;
+      evp_buf &B = S.buf[b];
+      auto slab = [&](void *lds, const void *src, uint32_t bytes) {
+        for (uint32_t pc = 0; (pc << 10) < bytes; ++pc) pln_dma_piece(lds, src, bytes, pc, lane);
+      };
+      slab(B.items, plan_items + t * (uint64_t)EVP_ITEMS_CAP, ibytes);
+      slab(B.tst, test + row0 * 5, cbytes);
+      if (A.has_train) slab(B.trn, train + row0 * 5, cbytes);
+      if (A.has_prior) slab(B.pri, prior + row0 * 5, pbytes & ~15u);
+      {
+        // the up-to-3 trailing dwords of the table's last tile through the scalar path (a vector load would be followed by
+        // s_waitcnt vmcnt(0) at its use)
+        const uint32_t tail0 = cbytes >> 2, ndw = rows * 5u;
+        for (uint32_t q = tail0; q < ndw; ++q) {
+          const __attribute__((address_space(4))) uint32_t *tc = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)(test + row0 * 5 + q);
+          const uint32_t v = *tc;
+          uint32_t w = 0;
+          if (A.has_train) {
+            const __attribute__((address_space(4))) uint32_t *rc = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)(train + row0 * 5 + q);
+            w = *rc;
+          }
+          if (lane == 0) {
+            B.tst[q] = v;
+            if (A.has_train) B.trn[q] = w;
+          }
+        }
+        if (A.has_prior && (pbytes & 15u)) {
+          const __attribute__((address_space(4))) double *pc8 = (const __attribute__((address_space(4))) double *)(uintptr_t)(prior + row0 * 5 + rows * 5 - 1);
+          const double v = *pc8;
+          if (lane == 0) B.pri[rows * 5 - 1] = v;
         }
         if (lane == 0) {
-          B.tst[q] = v;
-          if (A.has_train) B.trn[q] = w;
+          S.info[b] = inf;
+          S.ticket[b] = 0u;
         }
       }
-      if (A.has_prior && (pbytes & 15u)) {
-        const __attribute__((address_space(4))) double *pc8 = (const __attribute__((address_space(4))) double *)(uintptr_t)(prior + row0 * 5 + rows * 5 - 1);
-        const double v = *pc8;
-        if (lane == 0) B.pri[rows * 5 - 1] = v;
-      }
-      if (lane == 0) S.info[b] = inf;
+      EVP_STAMP(6)
+      srt_wait_dma();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) atomicAdd(&S.landed[b], 1u);
+      EVP_STAMP(7)
+      inf = inf_next;
     }
-  };
-  auto load_info = [&](uint64_t j) -> uint32_t { return j < count ? info_c[first + j] : 0u; };
-
-  __syncthreads();
-  uint32_t inf_next = 0;
-  if (dma_wave) {
-    __builtin_amdgcn_s_setprio(3);
-    if (count) stage(first, load_info(0), 0);
-    inf_next = load_info(1);
-  }
-  uint32_t slot = 0;
-  for (uint64_t j = 0; j < count; ++j) {
-    if (dma_wave) srt_wait_dma();   // tile j has landed (and S.info[slot] with it: lgkmcnt is waited inside srt_sync)
-    srt_sync();                     // ... and every compute wave is done with tile j - 1
-    if (dma_wave) {
-      if (j + 1 < count) stage(first + j + 1, inf_next, slot ^ 1u);
-      inf_next = load_info(j + 2);
-      slot ^= 1u;
-      continue;
-    }
-    const evp_buf &B = S.buf[slot];
-    const uint32_t par = slot;
-    if (tid == 0) {   // the other parity's counters: last used by tile j - 1, whose readers all passed the barrier above
-      S.ticket[par ^ 1u] = 0u;
-      S.tie_ticket[par ^ 1u] = 0u;
-      S.tot_done[par ^ 1u] = 0u;
-      S.n_tie[par ^ 1u] = 0u;
-    }
-    const uint64_t row0 = (first + j) * EVP_ROWS;
-    const uint32_t inf = srt_uniform(S.info[slot]);
-    const uint32_t n_cells = inf & 0xffffu, n_tots = inf >> 16;
-    const uint32_t n_cu = (n_cells + 63u) >> 6, n_tu = (n_tots + 63u) >> 6;
-    const uint32_t tot_base = n_cu * 64u;
-
-    // concentrations of DM model (m0 + mi) for one row's letters
-    auto resolve_tie = [&](uint32_t row, uint32_t slot_id) {
-      double a[5];
-      int im;
-      if (slot_id == EVP_SLOT_ARM) {
+  } else {
+    // ================================================================================================ the ten compute waves
+    for (uint64_t j = 0; j < count; ++j) {
+      const uint32_t b = (uint32_t)(j % EVP_NSLOT), gen = (uint32_t)(j / EVP_NSLOT);
+      EVP_STAMP(5)
+      while (evp_peek(&S.landed[b]) < gen + 1u) __builtin_amdgcn_s_sleep(1);
+      EVP_STAMP(0)
+      const evp_buf &B = S.buf[b];
+      const uint64_t row0 = (first + j) * EVP_ROWS;
+      const uint32_t inf = srt_uniform(S.info[b]);
+      const uint32_t n_cells = inf & 0xfffu, n_tots = (inf >> 12) & 0x3ffu, n_ties = inf >> 22;
+      const uint32_t n_cu = (n_cells + 63u) >> 6, n_tu = (n_tots + 63u) >> 6, n_ku = (n_ties + 63u) >> 6;
+      const uint32_t tot_base = n_cu * 64u, tie_base = tot_base + n_tu * 64u;
+      // work list, dearest first: H units (AR + BEAR models of the rows with transitions), tie units (one per vanilla model and
+      // 64 tied rows), V units (vanilla models of the rows), cell units
+      const uint32_t n_hu = (NH > 0 || (do_common && A.arm)) ? n_tu : 0u, n_ktu = NV > 0 ? n_ku * (uint32_t)nv : 0u;
+      const uint32_t n_vu = (NV > 0 || (do_common && n_hu == 0u)) ? n_tu : 0u;
+      const uint32_t w_k = n_hu, w_v = w_k + n_ktu, w_c = w_v + n_vu, n_work = w_c + n_cu;
+      const bool tot_in_h = n_hu != 0u;   // which unit kind carries the total length
+      for (uint32_t w = pln_ticket(&S.ticket[b], lane); w < n_work; w = pln_ticket(&S.ticket[b], lane)) {
+        if (w < w_k) {
+          // ---- H unit: 64 rows with test transitions, largest totals first: the AR model's and the BEAR models' arg-max,
+          //      the BEAR models' -D(A, n)
+#ifdef EVP_DEBUG_SWITCHES
+          if (dbg_flags & 8) continue;
+#endif
+          const uint32_t un = n_tu - 1u - w;
+          const uint32_t row = B.items[tot_base + un * 64u + lane];
+          uint32_t t[5], r[5];
+          double f[5];
 #pragma unroll
-        for (int b = 0; b < 5; ++b) a[b] = B.pri[row * 5 + b] + eps;
-        im = evl_argmax_noisy(a, eps, A.seed, EVL_ID_ARM, A.row_base + row0 + row, S.logtab);
-      } else {
-        const int m = m0 + (int)slot_id;
-        const double w = A.inv_h[m];
-#pragma unroll
-        for (int b = 0; b < 5; ++b) {
-          const double r = (double)B.trn[row * 5 + b];
-          a[b] = m < A.n_h ? __builtin_fma(B.pri[row * 5 + b], w, r) + eps : (r + w) + eps;
-        }
-        im = evl_argmax_noisy(a, sig_dm, A.seed, m < A.n_h ? (uint32_t)m : EVL_ID_VAN + (uint32_t)(m - A.n_h),
-                              A.row_base + row0 + row, S.logtab);
-      }
-      const double hit = (double)B.tst[row * 5 + im];
-      if (slot_id == EVP_SLOT_ARM) acc_carm += hit;
-#pragma unroll
-      for (int k = 0; k < MC; ++k)
-        if ((uint32_t)k == slot_id) acc_cor[k] += hit;
-    };
-    auto push_tie = [&](uint32_t row, uint32_t slot_id) { S.tie[atomicAdd(&S.n_tie[par], 1u)] = (uint16_t)(row * 16u + slot_id); };
-
-    for (uint32_t w = pln_ticket(&S.ticket[par], lane); w < n_tu + n_cu; w = pln_ticket(&S.ticket[par], lane)) {
-      if (w < n_tu) {
-        // ---- a unit of 64 rows with test transitions, largest totals first
-        const uint32_t un = n_tu - 1u - w;
-        const uint32_t row = B.items[tot_base + un * 64u + lane];
-        uint32_t t[5], r[5];
-        double f[5];
-#pragma unroll
-        for (int b = 0; b < 5; ++b) {
-          t[b] = B.tst[row * 5 + b];
-          r[b] = B.trn[row * 5 + b];
-          f[b] = B.pri[row * 5 + b];
-        }
-        const double n = (((double)t[0] + (double)t[1]) + ((double)t[2] + (double)t[3])) + (double)t[4];
-        const bool live = n != 0.0;   // false only for the padding of the last unit
-        // wave-uniform loop bounds: the list is sorted by min(n, 32) ascending, padding (n = 0) behind the largest
-        const uint32_t occ = (un + 1u) * 64u <= n_tots ? 64u : n_tots - un * 64u;
-        const uint32_t nn = n > 32.0 ? 33u : (uint32_t)n;
-        const uint32_t nmin = occ == 64u ? (uint32_t)__builtin_amdgcn_readlane((int)nn, 0) : 0u;
-        const uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)nn, (int)(occ - 1u));
-        const uint32_t lmin = nmin > SRT_CL ? SRT_CL : nmin, lmax = nmax > SRT_CL ? SRT_CL : nmax;
-        const bool heavy = n > (double)SRT_CL;
-        if (do_common) {
-          acc_tot += n;
-          if (A.arm && live) {
+          for (int q = 0; q < 5; ++q) {
+            t[q] = B.tst[row * 5 + q];
+            r[q] = B.trn[row * 5 + q];
+            f[q] = B.pri[row * 5 + q];
+          }
+          const double n = (((double)t[0] + (double)t[1]) + ((double)t[2] + (double)t[3])) + (double)t[4];
+          const bool live = n != 0.0;   // false only for the padding of the last unit
+          if (do_common && tot_in_h) acc_tot += n;
+          uint32_t undecided = 0;       // bit k: BEAR model k, bit NH: the AR model
+          if (do_common && A.arm && live) {
             double p[5];
 #pragma unroll
-            for (int b = 0; b < 5; ++b) p[b] = f[b] + eps;
+            for (int q = 0; q < 5; ++q) p[q] = f[q] + eps;
             int im;
             if (evl_argmax_clear(p, eps, im))
               acc_carm += (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
             else
-              push_tie(row, EVP_SLOT_ARM);
+              undecided |= 1u << NH;
           }
-        }
-        double xt[MC];
+          if (NH > 0) {
+            // wave-uniform loop bounds: the list is sorted by min(n, 32) ascending, padding (n = 0) behind the largest
+            const uint32_t occ = (un + 1u) * 64u <= n_tots ? 64u : n_tots - un * 64u;
+            const uint32_t nn = n > 32.0 ? 33u : (uint32_t)n;
+            const bool heavy = n > (double)SRT_CL;
+            const uint32_t nmin = occ == 64u ? (uint32_t)__builtin_amdgcn_readlane((int)nn, 0) : 0u;
+            const uint32_t nmax = (uint32_t)__builtin_amdgcn_readlane((int)nn, (int)(occ - 1u));
+            const uint32_t lmin = nmin > SRT_CL ? SRT_CL : nmin, lmax = nmax > SRT_CL ? SRT_CL : nmax;
+            const double Nr = (((double)r[0] + (double)r[1]) + ((double)r[2] + (double)r[3])) + (double)r[4];
+            const double Sf = ((f[0] + f[1]) + (f[2] + f[3])) + f[4];
+            double xt[NHA], D[NHA];
 #pragma unroll
-        for (int mi = 0; mi < MC; ++mi) {
-          xt[mi] = 1.0;
-          if (mi < m_cnt) {
-            const int m = m0 + mi;
-            const double w8 = A.inv_h[m];
+            for (int mi = 0; mi < NH; ++mi) {
+              xt[mi] = 1.0;
+              if (mi < nh) {
+                xt[mi] = __builtin_fma(Sf, wh[mi], Nr) + 5.0 * eps;
+                if (live) {
+                  double a[5];
+#pragma unroll
+                  for (int q = 0; q < 5; ++q) a[q] = __builtin_fma(f[q], wh[mi], (double)r[q]) + eps;
+                  int im;
+                  if (evl_argmax_clear(a, sig_dm, im))
+                    accH_cor[mi] += (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
+                  else
+                    undecided |= 1u << mi;
+                }
+              }
+            }
+            evp_light_D<NHA>(xt, (live && !heavy) ? nn : 0u, lmin, lmax, S.logtab, D);
+            evp_general_D<NHA>(xt, n, live, heavy, nh, S.logtab, D);
+#pragma unroll
+            for (int mi = 0; mi < NH; ++mi)
+              if (mi < nh) accH_ll[mi] -= D[mi];
+          }
+          // the rare ties of continuous concentrations (two letters within 17.5 sigma), in place, one model at a time
+          if (__builtin_amdgcn_ballot_w64(undecided != 0u)) {
+#pragma unroll 1
+            for (int sl = 0; sl <= NH; ++sl) {
+              if (!__builtin_amdgcn_ballot_w64((undecided >> sl) & 1u)) continue;
+              const bool is_arm = sl == NH;
+              const double wsl = is_arm ? 0.0 : A.inv_h[h0 + sl];
+              if ((undecided >> sl) & 1u) {
+                double a[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) a[q] = is_arm ? f[q] + eps : __builtin_fma(f[q], wsl, (double)r[q]) + eps;
+                const int im = evl_argmax_noisy(a, is_arm ? eps : sig_dm, A.seed, is_arm ? EVL_ID_ARM : (uint32_t)(h0 + sl),
+                                                A.row_base + row0 + row, S.logtab);
+                const double hit = (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
+                if (is_arm) acc_carm += hit;
+#pragma unroll
+                for (int k = 0; k < NH; ++k)
+                  if (k == sl) accH_cor[k] += hit;
+              }
+            }
+          }
+          EVP_STAMP(1)
+          continue;
+        }
+        if (w < w_v) {
+          // ---- tie unit: 64 rows whose largest training counts tie, one vanilla model: the noise decides among the tied letters
+#ifdef EVP_DEBUG_SWITCHES
+          if (dbg_flags & 2) continue;
+#endif
+          const uint32_t q0 = w - w_k, k = q0 / n_ku, un = q0 % n_ku;   // k: wave-uniform model index
+          const uint32_t row = B.items[tie_base + un * 64u + lane];
+          uint32_t t[5], r[5];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            t[q] = B.tst[row * 5 + q];
+            r[q] = B.trn[row * 5 + q];
+          }
+          if (row != (uint32_t)EVP_SENT_ROW) {
+            const double vk = A.inv_h[A.n_h + v0 + (int)k];
             double a[5];
 #pragma unroll
-            for (int b = 0; b < 5; ++b) a[b] = m < A.n_h ? __builtin_fma(f[b], w8, (double)r[b]) + eps : ((double)r[b] + w8) + eps;
-            xt[mi] = ((a[0] + a[1]) + (a[2] + a[3])) + a[4];
-            if (live) {
-              int im;
-              if (evl_argmax_clear(a, sig_dm, im))
-                acc_cor[mi] += (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
-              else
-                push_tie(row, (uint32_t)mi);
+            for (int q = 0; q < 5; ++q) a[q] = ((double)r[q] + vk) + eps;
+            const int im = evl_argmax_noisy(a, sig_dm, A.seed, EVL_ID_VAN + (uint32_t)(v0 + (int)k), A.row_base + row0 + row, S.logtab);
+            const double hit = (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
+#pragma unroll
+            for (int q = 0; q < NV; ++q)
+              if ((uint32_t)q == k) accV_cor[q] += hit;
+          }
+          EVP_STAMP(4)
+          continue;
+        }
+        if (w < w_c) {
+          // ---- V unit: 64 rows with test transitions: the vanilla models' arg-max (the largest training count, if it is
+          //      alone at the top) and -D(N_r + 5 (v + eps), n) from the table
+#ifdef EVP_DEBUG_SWITCHES
+          if (dbg_flags & 16) continue;
+#endif
+          const uint32_t un = n_tu - 1u - (w - w_v);
+          const uint32_t row = B.items[tot_base + un * 64u + lane];
+          uint32_t t[5], r[5];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            t[q] = B.tst[row * 5 + q];
+            r[q] = B.trn[row * 5 + q];
+          }
+          const double n = (((double)t[0] + (double)t[1]) + ((double)t[2] + (double)t[3])) + (double)t[4];
+          const bool live = n != 0.0;
+          if (do_common && !tot_in_h) acc_tot += n;
+          if (NV > 0) {
+            uint32_t rmax = r[0], im = 0, ntop = 1;
+#pragma unroll
+            for (int q = 1; q < 5; ++q) {
+              ntop = r[q] > rmax ? 1u : ntop + (r[q] == rmax ? 1u : 0u);
+              im = r[q] > rmax ? (uint32_t)q : im;
+              rmax = r[q] > rmax ? r[q] : rmax;
+            }
+            if (live && ntop == 1u) {   // tied rows are the tie units' (the plan lists them by the same rule)
+              const double hit = (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
+#pragma unroll
+              for (int k = 0; k < NV; ++k)
+                if (k < nv) accV_cor[k] += hit;
+            }
+            const double Nr = (((double)r[0] + (double)r[1]) + ((double)r[2] + (double)r[3])) + (double)r[4];
+            const bool in_tab = Nr + n < (double)EVP_TABK;
+            const uint32_t k0 = in_tab ? (uint32_t)Nr : 0u, k1 = in_tab ? (uint32_t)(Nr + n) : 0u;
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+              if (k < nv) accV_ll[k] -= S.tabT[k][k1] - S.tabT[k][k0];
+            if (__builtin_amdgcn_ballot_w64(live && !in_tab)) {
+#pragma unroll 1
+              for (int k = 0; k < nv; ++k) {
+                if (live && !in_tab) {
+                  const double d = srt_general_fast(Nr + 5.0 * (A.inv_h[A.n_h + v0 + k] + eps), n, S.logtab).D;
+#pragma unroll
+                  for (int q = 0; q < NV; ++q)
+                    if (q == k) accV_ll[q] -= d;
+                }
+              }
+            }
+          }
+          EVP_STAMP(3)
+          continue;
+        }
+        // ---- a unit of 64 cells, largest counts first
+#ifdef EVP_DEBUG_SWITCHES
+        if (dbg_flags & 4) continue;
+#endif
+        const uint32_t un = n_cu - 1u - (w - w_c);
+        const uint32_t idx = B.items[un * 64u + lane];
+        const uint32_t c = B.tst[idx], ru = B.trn[idx];
+        const double f = B.pri[idx];
+        const bool live = c != 0u, heavy = c > SRT_CL;
+        if (do_common && A.arm && live) acc_arm = __builtin_fma((double)c, evl_log_any(f + eps, S.logtab), acc_arm);
+        if (NV > 0) {
+          const bool in_tab = ru < (uint32_t)EVP_TABK && c < (uint32_t)EVP_TABK - ru;
+          const uint32_t k0 = in_tab ? ru : 0u, k1 = in_tab ? ru + c : 0u;
+#pragma unroll
+          for (int k = 0; k < NV; ++k)
+            if (k < nv) accV_ll[k] += S.tabC[k][k1] - S.tabC[k][k0];
+          if (__builtin_amdgcn_ballot_w64(live && !in_tab)) {
+#pragma unroll 1
+            for (int k = 0; k < nv; ++k) {
+              if (live && !in_tab) {
+                const double d = srt_general_fast(((double)ru + A.inv_h[A.n_h + v0 + k]) + eps, (double)c, S.logtab).D;
+#pragma unroll
+                for (int q = 0; q < NV; ++q)
+                  if (q == k) accV_ll[q] += d;
+              }
             }
           }
         }
-        {
-          double D[MC];
-          evp_light_D<MC>(xt, (live && !heavy) ? nn : 0u, lmin, lmax, S.logtab, D);
-          evp_general_D<MC>(xt, n, live, heavy, m_cnt, S.logtab, D);
+        if (NH > 0) {
+          const uint32_t occ = (un + 1u) * 64u <= n_cells ? 64u : n_cells - un * 64u;
+          const uint32_t cc = c > 32u ? 33u : c;
+          const uint32_t cmin = occ == 64u ? (uint32_t)__builtin_amdgcn_readlane((int)cc, 0) : 0u;
+          const uint32_t cmax = (uint32_t)__builtin_amdgcn_readlane((int)cc, (int)(occ - 1u));
+          const uint32_t lmin = cmin > SRT_CL ? SRT_CL : cmin, lmax = cmax > SRT_CL ? SRT_CL : cmax;
+          const double r = (double)ru;
+          double x[NHA], D[NHA];
 #pragma unroll
-          for (int mi = 0; mi < MC; ++mi)
-            if (mi < m_cnt) acc_ll[mi] -= D[mi];
+          for (int mi = 0; mi < NH; ++mi) x[mi] = mi < nh ? __builtin_fma(f, wh[mi], r) + eps : 1.0;
+          evp_light_D<NHA>(x, (live && !heavy) ? c : 0u, lmin, lmax, S.logtab, D);
+          evp_general_D<NHA>(x, (double)c, live, heavy, nh, S.logtab, D);
+#pragma unroll
+          for (int mi = 0; mi < NH; ++mi)
+            if (mi < nh) accH_ll[mi] += D[mi];
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's tie pushes are in LDS before the unit counts as retired
-        if (lane == 0) atomicAdd(&S.tot_done[par], 1u);
-        continue;
+        EVP_STAMP(2)
       }
-      // ---- a unit of 64 cells, largest counts first
-      const uint32_t un = n_cu - 1u - (w - n_tu);
-      const uint32_t idx = B.items[un * 64u + lane];
-      const uint32_t c = B.tst[idx];
-      const double r = (double)B.trn[idx], f = B.pri[idx];
-      const uint32_t occ = (un + 1u) * 64u <= n_cells ? 64u : n_cells - un * 64u;
-      const uint32_t cc = c > 32u ? 33u : c;
-      const uint32_t cmin = occ == 64u ? (uint32_t)__builtin_amdgcn_readlane((int)cc, 0) : 0u;
-      const uint32_t cmax = (uint32_t)__builtin_amdgcn_readlane((int)cc, (int)(occ - 1u));
-      const uint32_t lmin = cmin > SRT_CL ? SRT_CL : cmin, lmax = cmax > SRT_CL ? SRT_CL : cmax;
-      const bool live = c != 0u, heavy = c > SRT_CL;
-      if (do_common && A.arm && live) {
-        const double p = f + eps;
-        acc_arm = __builtin_fma((double)c, p > 0.0 ? bear_log_tab(p, S.logtab) : bear_log(p), acc_arm);
-      }
-      double x[MC], D[MC];
-#pragma unroll
-      for (int mi = 0; mi < MC; ++mi) {
-        x[mi] = 1.0;
-        if (mi < m_cnt) {
-          const int m = m0 + mi;
-          const double w8 = A.inv_h[m];
-          x[mi] = m < A.n_h ? __builtin_fma(f, w8, r) + eps : (r + w8) + eps;
-        }
-      }
-      evp_light_D<MC>(x, (live && !heavy) ? c : 0u, lmin, lmax, S.logtab, D);
-      evp_general_D<MC>(x, (double)c, live, heavy, m_cnt, S.logtab, D);
-#pragma unroll
-      for (int mi = 0; mi < MC; ++mi)
-        if (mi < m_cnt) acc_ll[mi] += D[mi];
+      EVP_STAMP(5)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are done before it counts as gone
+      if (lane == 0) atomicAdd(&S.left[b], 1u);
     }
-    // ---- the undecided arg-maxes, once every total unit of the tile is retired (they were drawn first: the wait is short)
-    if (n_tu) {
-      while (srt_uniform(__hip_atomic_load(&S.tot_done[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < n_tu)
-        __builtin_amdgcn_s_sleep(2);
-      const uint32_t n_tie = srt_uniform(__hip_atomic_load(&S.n_tie[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-      for (uint32_t k = pln_ticket(&S.tie_ticket[par], lane); k * 64u < n_tie; k = pln_ticket(&S.tie_ticket[par], lane)) {
-        const uint32_t i = k * 64u + lane;
-        if (i < n_tie) {
-          const uint32_t e = S.tie[i];
-          resolve_tie(e >> 4, e & 15u);
-        }
-      }
-    }
-    slot ^= 1u;
   }
-  srt_wait_dma();
-  static_assert(MC <= EVP_MAXC && EVP_MAXC <= EVS_CHUNK && EVP_SLOT_ARM >= EVP_MAXC, "model slots");
-  // ---- block reduction -> compact partial (the layout of eval_sorted_kernel: ll[8], cor[8], ll_arm, cor_arm, total_len)
+#ifdef EVP_STAMPS
+  if (lane == 0 && dbg)
+    for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * EVP_WAVES + wave) * 8 + k] = tph[k];
+#endif
+  (void)ve;
+  static_assert(NH <= EVP_MAXH && NV <= EVP_MAXV && EVP_SLOT_VAN >= EVP_MAXH && EVP_SLOT_VAN + EVP_MAXV <= EVS_CHUNK, "model slots");
+  // ---- block reduction -> compact partial: ll[8] = {BEAR 0..3, vanilla 0..3}, cor[8] likewise, ll_arm, cor_arm, total_len
   double vals[EVS_NOUT];
 #pragma unroll
   for (int k = 0; k < EVS_NOUT; ++k) vals[k] = 0.0;
 #pragma unroll
-  for (int k = 0; k < MC; ++k) {
-    vals[k] = acc_ll[k];
-    vals[EVS_CHUNK + k] = acc_cor[k];
+  for (int k = 0; k < NH; ++k) {
+    vals[k] = accH_ll[k];
+    vals[EVS_CHUNK + k] = accH_cor[k];
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    vals[EVP_SLOT_VAN + k] = accV_ll[k];
+    vals[EVS_CHUNK + EVP_SLOT_VAN + k] = accV_cor[k];
   }
   vals[2 * EVS_CHUNK] = acc_arm;
   vals[2 * EVS_CHUNK + 1] = acc_carm;
   vals[2 * EVS_CHUNK + 2] = acc_tot;
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < EVS_NOUT; ++k) {
     const double v = bear_wave_sum(vals[k]);

@@ -253,15 +253,20 @@ def evaluate(test, prior, h, van_reg, train=None, eps=EPSILON, with_ar=True, noi
 
 class EvalPlan:
     """Sorted plan of a resident TEST column (``bear_eval_plan_create``): per tile the cells and row totals with a non-zero
-    count, sorted by count.  Keeps the count tensor alive; built asynchronously on the current stream."""
+    count, sorted by count, and the rows whose largest counts in the conditioning column ``train`` tie.  Keeps the count
+    tensors alive; built asynchronously on the current stream."""
 
-    def __init__(self, test, ws=None):
+    def __init__(self, test, train=None, ws=None):
         test = _check_rows(test, torch.int32, "test")
-        self.test = test
+        if train is not None:
+            train = _check_rows(train, torch.int32, "train")
+            if train.shape[0] != test.shape[0]:
+                raise ValueError("test and train must have the same number of rows")
+        self.test, self.train = test, train
         self.ws = ws or default_workspace(test.device)
         h = ctypes.c_void_p()
         with torch.cuda.device(test.device):
-            st = _lib.lib().bear_eval_plan_create(self.ws.handle, _ptr(test), test.shape[0], ctypes.byref(h), _stream())
+            st = _lib.lib().bear_eval_plan_create(self.ws.handle, _ptr(test), _ptr(train), test.shape[0], ctypes.byref(h), _stream())
         _lib.check(st, "bear_eval_plan_create")
         self._h = h
 
@@ -278,17 +283,15 @@ class EvalPlan:
                 pass
 
 
-def evaluate_planned(plan, prior, h, van_reg, train=None, eps=EPSILON, with_ar=True, noise_seed=0, row_base=0):
-    """One ``bear_eval_plan_f64`` call: ``evaluate`` on a sorted plan of the test column (same output vector)."""
-    test = plan.test
+def evaluate_planned(plan, prior, h, van_reg, eps=EPSILON, with_ar=True, noise_seed=0, row_base=0):
+    """One ``bear_eval_plan_f64`` call: ``evaluate`` on a sorted plan of the test column (same output vector); the conditioning
+    column is the one the plan was built with."""
+    test, train = plan.test, plan.train
     n = test.shape[0]
-    if train is not None:
-        _check_rows(train, torch.int32, "train")
     if prior is not None:
         _check_rows(prior, torch.float64, "prior")
-    for t in (train, prior):
-        if t is not None and (t.shape[0] != n or t.data_ptr() % 16):
-            raise ValueError("train and prior must be 16-byte aligned with one row per planned context")
+        if prior.shape[0] != n or prior.data_ptr() % 16:
+            raise ValueError("prior must be 16-byte aligned with one row per planned context")
     hs, hp = _host_f64(h) if h is not None else (np.zeros(0), ctypes.c_void_p(0))
     vs, vp = _host_f64(van_reg) if van_reg is not None else (np.zeros(0), ctypes.c_void_p(0))
     out = torch.empty(2 * (hs.size + vs.size) + 3, dtype=torch.float64, device=test.device)

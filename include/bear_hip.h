@@ -238,14 +238,17 @@ int bear_eval_f64(bear_ws *ws, const uint32_t *test, const uint32_t *train, cons
 
 /*
  * The same on a sorted plan of the TEST column, for a table that stays resident (a held-out evaluation after training, the
- * train-set evaluation, every value of an h_scan): bear_eval_plan_create sorts, per tile of 704 contexts, the cells and the
- * row totals with a non-zero test count by count (asynchronous on `stream`; ~12 B of plan per context); bear_eval_plan_f64
- * then streams the three row slabs and the plan through LDS and evaluates wave-uniform units of equal counts -- rows without
- * test transitions cost nothing.  Arguments, output vector and noise stream are those of bear_eval_f64 (identical results up to
- * the order of the fp64 sums; accuracies exactly).  The plan is valid for exactly the buffer contents it was built from.
+ * train-set evaluation, every value of an h_scan): bear_eval_plan_create lists, per tile of 448 contexts, the cells and the rows
+ * with a non-zero test count sorted by count, and the rows whose largest TRAINING counts tie (their vanilla arg-max is decided
+ * by the noise) -- asynchronous on `stream`, ~13 B of plan per context.  `train` [dev, nullable] is the conditioning column the
+ * evaluations will use (NULL: none); bear_eval_plan_f64 must be given the same test / train buffers.  It streams the row slabs
+ * and the plan through a three-slot LDS ring and evaluates wave-uniform units of equal counts without a workgroup barrier --
+ * rows without test transitions cost nothing.  Arguments, output vector and noise stream are those of bear_eval_f64
+ * (identical results up to the order of the fp64 sums; accuracies exactly).  The plan is valid for exactly the buffer contents
+ * it was built from.
  */
 typedef struct bear_eval_plan bear_eval_plan;
-int bear_eval_plan_create(bear_ws *ws, const uint32_t *test, uint64_t n_rows, bear_eval_plan **out, void *stream);
+int bear_eval_plan_create(bear_ws *ws, const uint32_t *test, const uint32_t *train, uint64_t n_rows, bear_eval_plan **out, void *stream);
 int bear_eval_plan_destroy(bear_eval_plan *plan);
 uint64_t bear_eval_plan_bytes(const bear_eval_plan *plan);
 int bear_eval_plan_f64(bear_ws *ws, const bear_eval_plan *plan, const uint32_t *test, const uint32_t *train, const double *prior,

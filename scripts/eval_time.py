@@ -11,7 +11,7 @@ t = kernels.synth_counts(20211012, 0, n, dev, want=("train", "test"))
 f = kernels.synth_prior(20211012, 0, n, dev)
 torch.cuda.synchronize()
 t0 = time.time()
-plan = kernels.EvalPlan(t["test"])
+plan = kernels.EvalPlan(t["test"], t["train"])
 torch.cuda.synchronize()
 print(f"plan build {time.time() - t0:.4f} s, {plan.nbytes / n:.2f} B/context")
 
@@ -29,6 +29,6 @@ def timed(fn, reps=5):
 
 for name, hs, van in (("1 h + AR + 3 van_reg", [1.0], [0.1, 1.0, 10.0]), ("1 h + AR", [1.0], None), ("AR + 3 van", None, [0.1, 1.0, 10.0]),
                       ("h_scan 16", list(range(1, 17)), [1.0])):
-    ms_p = timed(lambda: kernels.evaluate_planned(plan, f, hs, van, t["train"]))
+    ms_p = timed(lambda: kernels.evaluate_planned(plan, f, hs, van))
     ms_u = timed(lambda: kernels.evaluate(t["test"], f, hs, van, t["train"]), 2)
     print(f"{name:24s} planned {ms_p:8.3f} ms = {n / ms_p / 1e6:7.2f} Gctx/s ({80 * n / ms_p / 1e6 / 8000:.3f} of HBM peak) | unplanned {ms_u:8.3f} ms = {n / ms_u / 1e6:6.2f} Gctx/s")

@@ -527,12 +527,12 @@ def test_eval_plan_kernel_parity(case, dev, ysd1):
     f = prior_rows(n, 4, 1.0) if case != "ties" else np.full((n, 5), 0.2)
     hs, van = np.array([0.05, 1.0, 37.0]), np.array([0.1, 1.0, 10.0])
     d_te, d_tr, d_f = _to_dev(te, dev), _to_dev(tr, dev), _to_dev(f, dev)
-    plan = kernels.EvalPlan(d_te)
-    assert plan.nbytes > 0
     H, V = 3, 3
     for use_train in (True, False):
+        plan = kernels.EvalPlan(d_te, d_tr if use_train else None)
+        assert plan.nbytes > 0
         want = o.evaluation_step(te, f, hs, van, tr if use_train else None, rng=o.HashNoise(77, 1000, n))
-        got = kernels.evaluate_planned(plan, d_f, hs, van, d_tr if use_train else None, noise_seed=77, row_base=1000).cpu().numpy()
+        got = kernels.evaluate_planned(plan, d_f, hs, van, noise_seed=77, row_base=1000).cpu().numpy()
         parts = _eval_parts(got, H, V)
         for k in (0, 1, 2):
             assert np.allclose(parts[k], want[k], rtol=ELBO_RTOL, atol=0), (case, use_train, k, parts[k], want[k])
@@ -542,15 +542,16 @@ def test_eval_plan_kernel_parity(case, dev, ysd1):
         assert np.array_equal(old[H + V + 1:], got[H + V + 1:]) and np.allclose(old[:H + V + 1], got[:H + V + 1], rtol=1e-12)
         if n >= 8:
             cut = (n // 3) // 4 * 4
-            pa, pb = kernels.EvalPlan(d_te[:cut].clone()), kernels.EvalPlan(d_te[cut:].clone())
-            a = kernels.evaluate_planned(pa, d_f[:cut].clone(), hs, van, d_tr[:cut].clone() if use_train else None, noise_seed=77, row_base=1000)
-            b = kernels.evaluate_planned(pb, d_f[cut:].clone(), hs, van, d_tr[cut:].clone() if use_train else None, noise_seed=77,
-                                         row_base=1000 + cut)
+            pa = kernels.EvalPlan(d_te[:cut].clone(), d_tr[:cut].clone() if use_train else None)
+            pb = kernels.EvalPlan(d_te[cut:].clone(), d_tr[cut:].clone() if use_train else None)
+            a = kernels.evaluate_planned(pa, d_f[:cut].clone(), hs, van, noise_seed=77, row_base=1000)
+            b = kernels.evaluate_planned(pb, d_f[cut:].clone(), hs, van, noise_seed=77, row_base=1000 + cut)
             both = (a + b).cpu().numpy()
             assert np.array_equal(both[H + V + 1:], got[H + V + 1:])
             assert np.allclose(both[:H + V + 1], got[:H + V + 1], rtol=1e-12)
     # no AR model, vanilla models only, no prior at all (what bmm-style callers pass)
-    got = kernels.evaluate_planned(plan, None, None, van, d_tr, with_ar=False, noise_seed=3).cpu().numpy()
+    plan = kernels.EvalPlan(d_te, d_tr)
+    got = kernels.evaluate_planned(plan, None, None, van, with_ar=False, noise_seed=3).cpu().numpy()
     want = o.evaluation_step(te, np.full((n, 5), 0.2), 1.0, van, tr, rng=o.HashNoise(3, 0, n))
     assert np.allclose(got[1:1 + V], want[2], rtol=ELBO_RTOL) and np.array_equal(got[V + 2:2 * V + 2], want[5]) and got[-1] == want[6]
 
@@ -564,16 +565,16 @@ def test_eval_plan_many_models_and_zero_rows(dev):
     f = prior_rows(n, 12, 0.8)
     hs, van = np.geomspace(1e-3, 1e2, 20), np.array([0.05, 0.3, 1.0, 4.0, 25.0])
     want = o.evaluation_step(te, f, hs, van, tr, rng=o.HashNoise(5, 0, n))
-    plan = kernels.EvalPlan(_to_dev(te, dev))
-    got = kernels.evaluate_planned(plan, _to_dev(f, dev), hs, van, _to_dev(tr, dev), noise_seed=5).cpu().numpy()
+    plan = kernels.EvalPlan(_to_dev(te, dev), _to_dev(tr, dev))
+    got = kernels.evaluate_planned(plan, _to_dev(f, dev), hs, van, noise_seed=5).cpu().numpy()
     parts = _eval_parts(got, 20, 5)
     for k in (0, 1, 2):
         assert np.allclose(parts[k], want[k], rtol=ELBO_RTOL, atol=0), k
     for k in (3, 4, 5, 6):
         assert np.array_equal(np.asarray(parts[k]), np.asarray(want[k])), k
     empty = torch.zeros((0, 5), dtype=torch.int32, device=dev)
-    pe = kernels.EvalPlan(empty)
-    z = kernels.evaluate_planned(pe, torch.zeros((0, 5), dtype=torch.float64, device=dev), [1.0], [1.0], empty).cpu().numpy()
+    pe = kernels.EvalPlan(empty, empty.clone())
+    z = kernels.evaluate_planned(pe, torch.zeros((0, 5), dtype=torch.float64, device=dev), [1.0], [1.0]).cpu().numpy()
     assert np.all(z == 0.0)
 
 
@@ -585,19 +586,19 @@ def test_eval_plan_full_size_properties(dev):
     t = kernels.synth_counts(20211012, 0, n, dev, want=("train", "test"))
     f = kernels.synth_prior(20211012, 0, n, dev)
     hs, van = [0.7], [0.1, 1.0, 10.0]
-    plan = kernels.EvalPlan(t["test"])
-    got = kernels.evaluate_planned(plan, f, hs, van, t["train"], noise_seed=9).cpu().numpy()
+    plan = kernels.EvalPlan(t["test"], t["train"])
+    got = kernels.evaluate_planned(plan, f, hs, van, noise_seed=9).cpu().numpy()
     old = kernels.evaluate(t["test"], f, hs, van, t["train"], noise_seed=9).cpu().numpy()
     assert np.array_equal(got[5:], old[5:]) and np.allclose(got[:5], old[:5], rtol=1e-12)
-    cut = 7_000_000 // 704 * 704 + 64          # not a tile boundary of the whole table
-    pa, pb = kernels.EvalPlan(t["test"][:cut]), kernels.EvalPlan(t["test"][cut:])
-    a = kernels.evaluate_planned(pa, f[:cut], hs, van, t["train"][:cut], noise_seed=9)
-    b = kernels.evaluate_planned(pb, f[cut:], hs, van, t["train"][cut:], noise_seed=9, row_base=cut)
+    cut = 7_000_000 // 448 * 448 + 64          # not a tile boundary of the whole table
+    pa, pb = kernels.EvalPlan(t["test"][:cut], t["train"][:cut]), kernels.EvalPlan(t["test"][cut:], t["train"][cut:])
+    a = kernels.evaluate_planned(pa, f[:cut], hs, van, noise_seed=9)
+    b = kernels.evaluate_planned(pb, f[cut:], hs, van, noise_seed=9, row_base=cut)
     both = (a + b).cpu().numpy()
     assert np.array_equal(both[5:], got[5:]) and np.allclose(both[:5], got[:5], rtol=1e-12)
     lo, m = 12_345_678 // 4 * 4, 30_000
-    ps = kernels.EvalPlan(t["test"][lo:lo + m].clone())
-    gs = kernels.evaluate_planned(ps, f[lo:lo + m].clone(), hs, van, t["train"][lo:lo + m].clone(), noise_seed=9, row_base=lo).cpu().numpy()
+    ps = kernels.EvalPlan(t["test"][lo:lo + m].clone(), t["train"][lo:lo + m].clone())
+    gs = kernels.evaluate_planned(ps, f[lo:lo + m].clone(), hs, van, noise_seed=9, row_base=lo).cpu().numpy()
     want = o.evaluation_step(t["test"][lo:lo + m].cpu().numpy().view(np.uint32), f[lo:lo + m].cpu().numpy(), 0.7, np.array(van),
                              t["train"][lo:lo + m].cpu().numpy().view(np.uint32), rng=o.HashNoise(9, lo, m))
     assert np.isclose(gs[0], want[0], rtol=ELBO_RTOL) and np.isclose(gs[1], want[1], rtol=ELBO_RTOL) and np.allclose(gs[2:5], want[2], rtol=ELBO_RTOL)
