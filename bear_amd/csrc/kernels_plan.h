@@ -670,14 +670,20 @@ struct pln_buf_r {
   uint32_t ref[PLN_RMAX * 5 + 4];  // [PLN_SENTINEL .. +3] = 0
   __attribute__((aligned(16))) unsigned char blk[PLN_BLOCK_MAX];
 };
+#define PLN_RSLOT 3   // mode R ring: a tile being finished, the tile being worked on, a tile landing (41 KB each)
 struct pln_lds_r {
-  pln_buf_r buf[PLN_NBUF];
+  pln_buf_r buf[PLN_RSLOT];
   double2 logtab[BEAR_LOGTAB_N];
   double tabD[2][SRT_NKEY];  // [0]: context term (x = A), [1]: stop column (x = x4)
   double tabP[2][SRT_NKEY];
-  uint32_t ticket[PLN_NBUF];
-  __attribute__((aligned(16))) pln_tile desc[2][PLN_DESC_CHUNK];
+  uint32_t meta[PLN_RSLOT][2];   // rows_items, hc_hr of the tile in each slot (written by the DMA wave that staged it)
+  uint32_t ticket[PLN_RSLOT];    // work tickets of the tile in the slot
+  uint32_t landed[PLN_RSLOT];    // += 1 by the DMA wave that streamed a tile once it is in LDS: the slot's g-th tile is there at g + 1
+  uint32_t left[PLN_RSLOT];      // += 1 by each compute wave that has no more work in the slot's tile: free again at 14 (g + 1)
 };
+__device__ __forceinline__ uint32_t pln_peek(const uint32_t *p) {
+  return srt_uniform(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
 
 // AR: multinomial mode of bear_ref (train_ar): sum LL = sum c log(f + eps); gradients w.r.t. tau_s, nu_s only.
 template <bool AR>
@@ -708,21 +714,26 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
     S.tabD[which][j] = o.D;
     S.tabP[which][j] = o.P;
   }
-  if (tid < PLN_NBUF) S.ticket[tid] = 0;
-  if (tid < 4 * PLN_NBUF) S.buf[tid >> 2].ref[PLN_SENTINEL + (tid & 3)] = 0;  // neutral cell: reference row of zeros
+  if (tid < PLN_RSLOT) S.ticket[tid] = S.landed[tid] = S.left[tid] = 0u;
+  if (tid < 4 * PLN_RSLOT) S.buf[tid >> 2].ref[PLN_SENTINEL + (tid & 3)] = 0;  // neutral cell: reference row of zeros
 
-  // Same streaming protocol as dm_prior_plan_kernel: the last PLN_DMA_WAVES waves only move data.
+  // Streaming protocol WITHOUT a workgroup barrier (measured: with dm_prior_plan_kernel's two-slot ring and one barrier per
+  // tile this kernel ran at the tile rate of the streaming skeleton -- 2.7 us per tile and CU, 3.5 TB/s -- because a tile is
+  // only 37 KB: one tile in flight per CU cannot cover the HBM latency).  Three slots; the last PLN_DMA_WAVES waves only move
+  // data, taking alternate tiles (each wave all pieces of its tile, published through `landed` the moment they are in LDS);
+  // a compute wave that finds a tile's tickets exhausted adds itself to `left` and moves on; a slot is refilled when all
+  // compute waves have left it.  Up to two tiles are in flight per CU and nobody waits for the slowest wave of a tile.
   const bool dma_wave = wave >= PLN_WAVES - PLN_DMA_WAVES;
   const uint32_t dw = wave - (PLN_WAVES - PLN_DMA_WAVES);
-  auto stage = [&](const pln_tile &ti, uint32_t b) {
+  constexpr uint32_t CWAVES = PLN_WAVES - PLN_DMA_WAVES;
+  auto stage = [&](const pln_tile &ti, uint32_t b) {   // a DMA wave: every piece of tile `ti` into ring slot `b`
     const uint32_t rows = ti.rows_items >> 16;
-    if (rows == 0) return;
     const uint32_t rbytes = rows * 20u, rb16 = rbytes & ~15u, bbytes = ti.blk16 * 16u;
     const unsigned char *rsrc = reinterpret_cast<const unsigned char *>(ref + ti.row0 * 5);
     const unsigned char *bsrc = pv.stream + (size_t)ti.off16 * 16;
-    for (uint32_t pc = dw; (pc << 10) < bbytes; pc += PLN_DMA_WAVES) pln_dma_piece(S.buf[b].blk, bsrc, bbytes, pc, lane);
-    for (uint32_t pc = dw; (pc << 10) < rb16; pc += PLN_DMA_WAVES) pln_dma_piece(S.buf[b].ref, rsrc, rb16, pc, lane);
-    if (dw == 0 && (rbytes & 15u)) {  // row count not a multiple of 4 (last tile only): trailing dwords, SCALAR path
+    for (uint32_t pc = 0; (pc << 10) < bbytes; ++pc) pln_dma_piece(S.buf[b].blk, bsrc, bbytes, pc, lane);
+    for (uint32_t pc = 0; (pc << 10) < rb16; ++pc) pln_dma_piece(S.buf[b].ref, rsrc, rb16, pc, lane);
+    if (rbytes & 15u) {  // row count not a multiple of 4 (last tile only): trailing dwords, SCALAR path
       const uint32_t w0 = rb16 >> 2, nw = (rbytes & 15u) >> 2;
       const __attribute__((address_space(4))) uint32_t *tail =
           (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)(ref + ti.row0 * 5 + w0);
@@ -732,6 +743,11 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
         if (nw > 1) S.buf[b].ref[w0 + 1] = v1;
         if (nw > 2) S.buf[b].ref[w0 + 2] = v2;
       }
+    }
+    if (lane == 0) {
+      S.meta[b][0] = ti.rows_items;
+      S.meta[b][1] = ti.hc_hr;
+      S.ticket[b] = 0u;
     }
   };
   // bear_ref.py:30-33 (Jukes-Cantor on the L1-normalised reference row), :63-68 (mix), bear_ref.py:106
@@ -759,45 +775,40 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
 
   const uint64_t G = gridDim.x;
   const uint64_t first = (pv.n_tiles * (uint64_t)blockIdx.x) / G, count = (pv.n_tiles * ((uint64_t)blockIdx.x + 1)) / G - first;
-  auto fetch_desc = [&](uint64_t j0) {
-    if (dw == 0 && j0 < count)
-      pln_dma_piece(S.desc[(j0 >> 5) & 1u], pv.tiles + first + j0, PLN_DESC_CHUNK * (uint32_t)sizeof(pln_tile), 0u, lane);
-  };
+  __syncthreads();
   if (dma_wave) {
     __builtin_amdgcn_s_setprio(3);
-    fetch_desc(0);
-    fetch_desc(PLN_DESC_CHUNK);
-    srt_wait_dma();
-  }
-  __syncthreads();
-  pln_tile cur = pln_desc(S.desc, 0, count), nxt = pln_desc(S.desc, 1, count);
-  if (dma_wave) stage(cur, 0);
-  uint32_t slot = 0;
-  for (uint64_t j = 0; j < count; ++j) {
-    if (dma_wave) srt_wait_dma();
-    srt_sync();
-    const pln_tile nn = pln_desc(S.desc, j + 2, count);
-    if (dma_wave) {
-      if ((j & (PLN_DESC_CHUNK - 1)) == 0 && j != 0) fetch_desc(j + PLN_DESC_CHUNK);
-      stage(nxt, slot ^ 1u);
-      cur = nxt;
-      nxt = nn;
-      slot ^= 1u;
-      continue;
+    pln_tile ti = pln_load_tile(pv, dw < count ? first + dw : pv.n_tiles);   // descriptors by scalar loads, one tile ahead
+    for (uint64_t j = dw; j < count; j += PLN_DMA_WAVES) {
+      const uint32_t b = (uint32_t)(j % PLN_RSLOT), gen = (uint32_t)(j / PLN_RSLOT);
+      const pln_tile ti_next = pln_load_tile(pv, j + PLN_DMA_WAVES < count ? first + j + PLN_DMA_WAVES : pv.n_tiles);
+      while (pln_peek(&S.left[b]) < CWAVES * gen) __builtin_amdgcn_s_sleep(1);
+      stage(ti, b);
+      srt_wait_dma();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) atomicAdd(&S.landed[b], 1u);
+      ti = ti_next;
     }
-
+  }
+  for (uint64_t j = 0; !dma_wave && j < count; ++j) {
+    const uint32_t slot = (uint32_t)(j % PLN_RSLOT), gen = (uint32_t)(j / PLN_RSLOT);
+    while (pln_peek(&S.landed[slot]) < gen + 1u) __builtin_amdgcn_s_sleep(1);
     const pln_buf_r &B = S.buf[slot];
-    const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
-    const uint32_t hc = cur.hc_hr >> 16;
-    const pln_layout L = pln_block_layout(rows, n_light, hc, cur.hc_hr & 0xffffu);
+    const uint32_t rows_items = srt_uniform(S.meta[slot][0]), hc_hr = srt_uniform(S.meta[slot][1]);
+    const uint32_t rows = rows_items >> 16, n_light = rows_items & 0xffffu;
+    const uint32_t hc = hc_hr >> 16;
+    const pln_layout L = pln_block_layout(rows, n_light, hc, hc_hr & 0xffffu);
     const uint16_t *E = reinterpret_cast<const uint16_t *>(B.blk);
     const uint16_t *items = reinterpret_cast<const uint16_t *>(B.blk + L.items);
-    if (tid == 0) S.ticket[(slot + 1) % PLN_NBUF] = 0;
     // The context term (x = A) and the stop column (x = x4) have the same concentration in every
     // context: their sums over the table are the plan's histograms times two small tables (added
     // once, after the loop).  Per tile only the column items b < 4 remain; waves draw units, dearest first.
     const uint32_t n_hcu = (hc + 63u) >> 6;
+#ifdef PLN_NOWORK
+    const uint32_t n_units = 0u * n_light;
+#else
     const uint32_t n_units = (n_light + 63u) >> 6;
+#endif
     for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_hcu + n_units; w = pln_ticket(&S.ticket[slot], lane)) {
       if (w < n_hcu) {  // large-count column items of this tile (Stirling path), first
         const uint32_t i = w * 64u + lane;
@@ -830,9 +841,8 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
       srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
       accumulate(x[0], o[0]);
     }
-    cur = nxt;
-    nxt = nn;
-    slot ^= 1u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are done before it counts as gone
+    if (lane == 0) atomicAdd(&S.left[slot], 1u);
   }
   srt_wait_dma();
   // ---- Stirling-path items of the whole table
