@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("BEAR_AMD_LIB") or os.path.join(_HERE, "libbear_hip.so
 SYMBOLS = [
     "bear_abi_version", "bear_strerror", "bear_last_hip_error", "bear_ws_create", "bear_ws_destroy",
     "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_dm_items_f64", "bear_eval_f64", "bear_bmm_f64", "bear_pack_kmers_u64", "bear_dm_linear_f64",
-    "bear_plan_create", "bear_plan_destroy", "bear_plan_bytes", "bear_dm_prior_plan_f64", "bear_dm_prior_plan_grad_f64", "bear_dm_ref_plan_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
+    "bear_plan_create", "bear_plan_create_ref", "bear_plan_destroy", "bear_plan_bytes", "bear_dm_prior_plan_f64", "bear_dm_prior_plan_grad_f64", "bear_dm_ref_plan_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
     "bear_count_rows", "bear_parse_counts_tsv", "bear_log_gamma_f64", "bear_logdir_sample_f64",
     "bear_stat_source", "bear_cache_write", "bear_cache_info", "bear_cache_read", "bear_shuffle_rows", "bear_shuffle_source_row",
     "bear_stream_read", "bear_encode_kmers_i8", "bear_ref_train_step_f64", "bear_net_linear_train_step_f64", "bear_cnn_reserve", "bear_net_cnn_train_step_f64", "bear_cnn_param_count", "bear_cnn_forward_f64", "bear_cnn_backward_f64",
@@ -59,6 +59,7 @@ def _load():
     L.bear_dm_prior_f64.argtypes = [vp, vp, vp, u64, dbl, dbl, cint, vp, vp, vp]
     L.bear_dm_ref_f64.argtypes = [vp, vp, vp, u64, dbl, dbl, dbl, dbl, cint, vp, vp]
     L.bear_plan_create.argtypes = [vp, vp, u64, cint, ctypes.POINTER(vp)]
+    L.bear_plan_create_ref.argtypes = [vp, vp, vp, u64, ctypes.POINTER(vp)]
     L.bear_plan_destroy.argtypes = [vp]
     L.bear_plan_bytes.argtypes = [vp]
     L.bear_plan_bytes.restype = u64

@@ -134,11 +134,13 @@ class ResidentBatches:
             e["plans"][key] = kernels.EvalPlan(e[column], e.get(train_column))
         return e["plans"][key]
 
-    def plan(self, k, column, ncol):
+    def plan(self, k, column, ncol, ref_column=None):
+        """Training plan of batch k (built on first use).  ref_column (ncol = 4): the reference column of bear_ref with the stop net
+        function -- the plan then folds the contexts without reference counts into a histogram (``bear_plan_create_ref``)."""
         e = self.batches[k]
-        key = (column, ncol)
+        key = (column, ncol, ref_column)
         if key not in e["plans"]:
-            e["plans"][key] = kernels.Plan(e[column], ncol)
+            e["plans"][key] = kernels.Plan(e[column], ncol, ref=None if ref_column is None else e[ref_column])
         return e["plans"][key]
 
 

@@ -85,7 +85,9 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
         e = res.batches[k]
         if e["rows"] == 0:
             return lambda packed: packed.zero_()
-        plan = res.plan(k, "train", 4)               # built here, before any capture (plan creation allocates and synchronises)
+        # built here, before any capture (plan creation allocates and synchronises); the reference column is resident too, so the
+        # plan folds the contexts without reference counts into a histogram and a step streams only the others' items
+        plan = res.plan(k, "train", 4, ref_column="ref")
         return lambda packed: kernels.ref_train_reduce(plan, e["ref"], theta, packed, train_ar=train_ar)
     reduce_fns = [reducer(k) for k in range(len(res.batches))]
     scales = [-(num_kmers / e["global_rows"]) for e in res.batches]       # loss = -(num_kmers / B) sum LL, bear_ref.py:252-253

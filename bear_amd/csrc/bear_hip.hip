@@ -22,6 +22,7 @@
 #include "kernels_shuffle.h"
 #include "kernels_cnn.h"
 #include "kernels_evalplan.h"
+#include "kernels_refplan.h"
 
 #ifdef EVP_STAMPS
 #define EVP_DBG_ARG , ws->dbg
@@ -288,6 +289,14 @@ struct bear_plan {
   uint64_t n_tiles;
   uint64_t n_heavy[3];
   uint64_t bytes;
+  // reference-aware extension (bear_plan_create_ref, kernels_refplan.h)
+  const uint32_t *ref;
+  rpl_item *ref_items;
+  uint64_t n_ref_items, n_heavy0;
+  unsigned long long *hist0;   // [RPL_NKEY], inside the allocation hist0_base
+  unsigned long long *hist0_base;
+  uint32_t *heavy0;
+  double *sum0;
 };
 
 static void plan_free(bear_plan *p) {
@@ -298,6 +307,10 @@ static void plan_free(bear_plan *p) {
   (void)hipFree(p->heavy_row);
   (void)hipFree(p->heavy_stop);
   (void)hipFree(p->hist);
+  (void)hipFree(p->ref_items);
+  (void)hipFree(p->hist0_base);
+  (void)hipFree(p->heavy0);
+  (void)hipFree(p->sum0);
   delete p;
 }
 
@@ -429,6 +442,60 @@ int bear_plan_destroy(bear_plan *plan) {
 
 uint64_t bear_plan_bytes(const bear_plan *plan) { return plan ? plan->bytes : 0; }
 
+int bear_plan_create_ref(bear_ws *ws, const uint32_t *train, const uint32_t *ref, uint64_t n_rows, bear_plan **out) {
+  if (!out) return BEAR_ERR_INVALID_ARG;
+  *out = nullptr;
+  if ((n_rows && !ref) || misaligned(ref)) return BEAR_ERR_INVALID_ARG;
+  bear_plan *p = nullptr;
+  int st = bear_plan_create(ws, train, n_rows, 4, &p);   // tiles, histograms of totals / stop counts, heavy lists
+  if (st != BEAR_OK) return st;
+  p->ref = ref;
+  unsigned long long *d_meta = nullptr;   // [0..31] bucket sizes / cursors, [32..63] hist0, [64] n_heavy0
+  hipError_t e = hipMalloc(&d_meta, sizeof(unsigned long long) * 72);
+  if (e == hipSuccess) e = hipMemset(d_meta, 0, sizeof(unsigned long long) * 72);
+  if (e == hipSuccess) e = hipMalloc(&p->sum0, sizeof(double));
+  if (e == hipSuccess) e = hipMemset(p->sum0, 0, sizeof(double));
+  p->hist0_base = d_meta;
+  unsigned long long h_meta[72];
+  memset(h_meta, 0, sizeof(h_meta));
+  const uint64_t chunks = (n_rows + 1023) / 1024;
+  const int grid = (int)(chunks < (uint64_t)ws->num_cu * 8 ? (chunks ? chunks : 1) : (uint64_t)ws->num_cu * 8);
+  if (e == hipSuccess && n_rows) {
+    hipLaunchKernelGGL(rpl_build_kernel, dim3(grid), dim3(256), 0, 0, train, ref, n_rows, 0, d_meta, d_meta + 32, d_meta + 64, p->sum0,
+                       static_cast<rpl_item *>(nullptr), static_cast<uint32_t *>(nullptr));
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(h_meta, d_meta, sizeof(h_meta), hipMemcpyDeviceToHost);
+  }
+  if (e == hipSuccess) {
+    unsigned long long run = 0, cur[RPL_NKEY];
+    for (int k = 0; k < RPL_NKEY; ++k) {
+      cur[k] = run;
+      run += h_meta[k];
+    }
+    p->n_ref_items = run;
+    p->n_heavy0 = h_meta[64];
+    if (run) e = hipMalloc(&p->ref_items, sizeof(rpl_item) * run);
+    if (e == hipSuccess && p->n_heavy0) e = hipMalloc(&p->heavy0, sizeof(uint32_t) * p->n_heavy0);
+    if (e == hipSuccess) e = hipMemcpy(d_meta, cur, sizeof(cur), hipMemcpyHostToDevice);      // sizes -> cursors
+    if (e == hipSuccess) e = hipMemset(d_meta + 64, 0, sizeof(unsigned long long));
+    if (e == hipSuccess && n_rows && (run || p->n_heavy0)) {
+      hipLaunchKernelGGL(rpl_build_kernel, dim3(grid), dim3(256), 0, 0, train, ref, n_rows, 1, d_meta, d_meta + 32, d_meta + 64, p->sum0,
+                         p->ref_items, p->heavy0);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    plan_free(p);
+    return e == hipErrorOutOfMemory ? BEAR_ERR_NOMEM : BEAR_ERR_HIP;
+  }
+  p->hist0 = d_meta + 32;
+  p->bytes += sizeof(rpl_item) * p->n_ref_items + sizeof(uint32_t) * p->n_heavy0 + sizeof(unsigned long long) * 72;
+  *out = p;
+  return BEAR_OK;
+}
+
 static pln_view plan_view(const bear_plan *p) {
   pln_view v;
   v.tiles = p->tiles;
@@ -554,6 +621,42 @@ int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_
   return launch_prior_plan(ws, plan, prior, n_rows, dummy, ws->ref_prm, train_ar, prior_normalized, out, s);
 }
 
+// The mode-R step on a plan: the reference-aware item stream when the plan was built with this reference column
+// (bear_plan_create_ref), the streaming kernel otherwise.  prm_dev != NULL: parameters from device memory.
+static int launch_ref_plan(bear_ws *ws, const bear_plan *plan, const uint32_t *ref, uint64_t n_rows, const bear_params &prm,
+                           const bear_params *prm_dev, int train_ar, double *out, hipStream_t s) {
+  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  int grid;
+  if (plan->ref) {
+    if (plan->ref != ref) return BEAR_ERR_INVALID_ARG;   // the plan is valid for the reference buffer it was built from
+    rpl_view rv;
+    rv.items = plan->ref_items;
+    rv.n_items = plan->n_ref_items;
+    rv.hist0 = plan->hist0;
+    rv.heavy0 = plan->heavy0;
+    rv.n_heavy0 = plan->n_heavy0;
+    rv.sum0 = plan->sum0;
+    const uint64_t units = (plan->n_ref_items + 63) / 64, want = (units + 3) / 4 + 2;   // 4 waves per block
+    grid = (int)(want < (uint64_t)ws->num_cu * 8 ? want : (uint64_t)ws->num_cu * 8);
+    if (train_ar)
+      hipLaunchKernelGGL(dm_ref_items_kernel<true>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, prm_dev);
+    else
+      hipLaunchKernelGGL(dm_ref_items_kernel<false>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, prm_dev);
+  } else {
+    grid = grid_plan(ws, plan->n_tiles);
+    if (train_ar)
+      hipLaunchKernelGGL(dm_ref_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan), lt,
+                         ws->partials, prm_dev);
+    else
+      hipLaunchKernelGGL(dm_ref_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan), lt,
+                         ws->partials, prm_dev);
+  }
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 4, out);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
 int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref,
                          uint64_t n_rows, double h_signed, double tau_signed, double nu_signed, double eps,
                          int train_ar, double *out, void *stream) {
@@ -573,17 +676,7 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
   prm.tau = tau;
   prm.V = 1.0 / (nw + 1.0);
   prm.nw = nw;
-  const int grid = grid_plan(ws, plan->n_tiles);
-  if (train_ar)
-    hipLaunchKernelGGL(dm_ref_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan),
-                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials, static_cast<const bear_params *>(nullptr));
-  else
-    hipLaunchKernelGGL(dm_ref_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan),
-                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials, static_cast<const bear_params *>(nullptr));
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 4, out);
-  HIP_TRY(hipGetLastError());
-  return BEAR_OK;
+  return launch_ref_plan(ws, plan, ref, n_rows, prm, nullptr, train_ar, out, s);
 }
 
 // ---- optimizer step in two halves: the shard's reduce (constants from theta -> planned kernel -> finalize into `packed`) and the
@@ -616,17 +709,8 @@ int bear_ref_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t
   hipStream_t s = static_cast<hipStream_t>(stream);
   bear_params dummy;
   memset(&dummy, 0, sizeof(dummy));
-  const int grid = grid_plan(ws, plan->n_tiles);
   hipLaunchKernelGGL(ref_params_kernel, dim3(1), dim3(64), 0, s, theta, eps, ws->ref_prm);
-  if (train_ar)
-    hipLaunchKernelGGL(dm_ref_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, dummy, plan_view(plan),
-                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials, static_cast<const bear_params *>(ws->ref_prm));
-  else
-    hipLaunchKernelGGL(dm_ref_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, dummy, plan_view(plan),
-                       reinterpret_cast<const double2 *>(ws->logtab), ws->partials, static_cast<const bear_params *>(ws->ref_prm));
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 4, packed);
-  HIP_TRY(hipGetLastError());
-  return BEAR_OK;
+  return launch_ref_plan(ws, plan, ref, n_rows, dummy, ws->ref_prm, train_ar, packed, s);
 }
 
 int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,

@@ -109,16 +109,27 @@ class Plan:
     """Count-dependent part of the hot path for a table that stays resident across optimizer steps
     (work items sorted by count; include/bear_hip.h "Planned variants").  Keeps the count tensor alive."""
 
-    def __init__(self, counts, ncol, ws=None):
+    def __init__(self, counts, ncol, ws=None, ref=None):
+        """ref (ncol = 4 only): the reference column the planned mode-R entries will be called with -- the plan then folds the
+        contexts without reference counts into a histogram (``bear_plan_create_ref``)."""
         counts = _check_rows(counts, torch.int32, "counts")
         self.counts = counts
         self.ncol = int(ncol)
+        self.ref = None
         self.ws = ws or default_workspace(counts.device)
         h = ctypes.c_void_p()
         with torch.cuda.device(counts.device):
             torch.cuda.current_stream().synchronize()  # plan construction runs on the default stream
-            st = _lib.lib().bear_plan_create(self.ws.handle, _ptr(counts), counts.shape[0], self.ncol, ctypes.byref(h))
-        _lib.check(st, "bear_plan_create")
+            if ref is not None:
+                ref = _check_rows(ref, torch.int32, "ref")
+                if self.ncol != 4 or ref.shape[0] != counts.shape[0] or ref.data_ptr() % 16:
+                    raise ValueError("a reference-aware plan needs ncol = 4 and a 16-byte aligned ref slab with one row per context")
+                self.ref = ref
+                st = _lib.lib().bear_plan_create_ref(self.ws.handle, _ptr(counts), _ptr(ref), counts.shape[0], ctypes.byref(h))
+                _lib.check(st, "bear_plan_create_ref")
+            else:
+                st = _lib.lib().bear_plan_create(self.ws.handle, _ptr(counts), counts.shape[0], self.ncol, ctypes.byref(h))
+                _lib.check(st, "bear_plan_create")
         self._h = h
 
     @property

@@ -104,6 +104,13 @@ typedef struct bear_plan bear_plan;
 int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int ncol, bear_plan **out);
 int bear_plan_destroy(bear_plan *plan);
 uint64_t bear_plan_bytes(const bear_plan *plan);
+/* A plan for bear_dm_ref_plan_f64 / bear_ref_train_*_f64 that also knows the REFERENCE column `ref` [dev] uint32 [n_rows, 5]
+ * -- as constant as the training column while a table is resident.  Contexts without reference counts (most k-mers of a read
+ * set that the reference genome does not contain) share one concentration per letter, so all their items collapse into a
+ * 24-bin histogram over the count, built here once; the step then streams only the items of contexts that do have reference
+ * counts, as 16-byte records {count, r_b, sum r} sorted by count.  Results are those of the streaming path (same arithmetic
+ * per item; the fp64 sums in another order).  The planned entries must be called with the same `train` and `ref` buffers. */
+int bear_plan_create_ref(bear_ws *ws, const uint32_t *train, const uint32_t *ref, uint64_t n_rows, bear_plan **out);
 /* prior_normalized != 0: the caller asserts that every row of `prior` sums to one -- true for each
  * ar_func of the reference, all of which end in a softmax (bear_model/ar_funcs.py:44,97,121-126).
  * The concentration total A = 1/h + 5 eps is then shared by all contexts and the context terms

@@ -603,3 +603,58 @@ def test_eval_plan_full_size_properties(dev):
                              t["train"][lo:lo + m].cpu().numpy().view(np.uint32), rng=o.HashNoise(9, lo, m))
     assert np.isclose(gs[0], want[0], rtol=ELBO_RTOL) and np.isclose(gs[1], want[1], rtol=ELBO_RTOL) and np.allclose(gs[2:5], want[2], rtol=ELBO_RTOL)
     assert gs[5] == want[3] and gs[6] == want[4] and np.array_equal(gs[7:10], want[5]) and gs[10] == want[6]
+
+
+@pytest.mark.parametrize("case", ["ysd1", "sparse", "sparse_hot", "dense", "edge", "one_row", "no_ref", "all_ref"])
+@pytest.mark.parametrize("train_ar", [False, True])
+def test_reference_aware_plan_parity(case, train_ar, dev, ysd1):
+    """bear_plan_create_ref (kernels_refplan.h): contexts without reference counts folded into a histogram, the others streamed
+    as sorted item records -- against the oracle and against the streaming plan, incl. tables where no / every context has
+    reference counts, Stirling-path items and uint32-range counts."""
+    from bear_amd import kernels
+    if case == "ysd1":
+        tr, rf = ysd1[1][:, 0].astype(np.uint32), ysd1[1][:, 2].astype(np.uint32)
+    elif case == "no_ref":
+        tr = sparse_table(5003, 21)[0]
+        rf = np.zeros_like(tr)
+    elif case == "all_ref":
+        tr, _, rf = sparse_table(5003, 22, lam_scale=4.0)
+        rf[:, :4] += 1
+    else:
+        tr, rf = CASES_REF[case]()
+    d_tr, d_rf = _to_dev(tr, dev), _to_dev(rf, dev)
+    plan = kernels.Plan(d_tr, 4, ref=d_rf)
+    stream = kernels.Plan(d_tr, 4)
+    assert plan.nbytes >= stream.nbytes
+    for args in PARAMS:
+        want = co.dm_ref(tr, rf, *args, train_ar=train_ar, nthreads=4)
+        got = kernels.dm_ref_planned(plan, d_rf, *args, train_ar=train_ar).cpu().numpy()
+        _close(got[0], want[0], ELBO_RTOL)
+        scale = np.abs(want[1:]).max() + abs(want[0]) * 1e-3
+        for k in range(1, 4):
+            _close(got[k], want[k], GRAD_RTOL, scale)
+        old = kernels.dm_ref_planned(stream, d_rf, *args, train_ar=train_ar).cpu().numpy()
+        assert np.allclose(got, old, rtol=1e-11, atol=1e-9 * scale)
+    other = d_rf.clone()
+    with pytest.raises(Exception):      # the plan is bound to the reference buffer it was built from
+        kernels.dm_ref_planned(plan, other, *PARAMS[0])
+
+
+def test_reference_aware_plan_full_size(dev):
+    """1e7 synthetic contexts (BASELINE configs[1]): reference-aware plan == streaming plan == unplanned kernel; shard additivity."""
+    from bear_amd import kernels
+    n = 10_000_000
+    t = kernels.synth_counts(20211012, 0, n, dev, want=("train", "ref"))
+    args = (0.0, float(np.log(1 / 30)), float(-np.log(100)))
+    a = kernels.dm_ref_planned(kernels.Plan(t["train"], 4, ref=t["ref"]), t["ref"], *args).cpu().numpy()
+    b = kernels.dm_ref_planned(kernels.Plan(t["train"], 4), t["ref"], *args).cpu().numpy()
+    c = kernels.dm_ref(t["train"], t["ref"], *args).cpu().numpy()
+    assert np.allclose(a, b, rtol=1e-12) and np.allclose(a, c, rtol=1e-12)
+    cut = 3_333_332
+    parts = sum(kernels.dm_ref_planned(kernels.Plan(t["train"][lo:hi], 4, ref=t["ref"][lo:hi]), t["ref"][lo:hi], *args).cpu().numpy()
+                for lo, hi in ((0, cut), (cut, n)))
+    assert np.allclose(parts, a, rtol=1e-12)
+    m = 40_000
+    want = co.dm_ref(t["train"][:m].cpu().numpy().view(np.uint32), t["ref"][:m].cpu().numpy().view(np.uint32), *args, nthreads=4)
+    got = kernels.dm_ref_planned(kernels.Plan(t["train"][:m].clone(), 4, ref=t["ref"][:m].clone()), t["ref"][:m].clone(), *args).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-10)
