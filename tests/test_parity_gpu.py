@@ -656,5 +656,6 @@ def test_reference_aware_plan_full_size(dev):
     assert np.allclose(parts, a, rtol=1e-12)
     m = 40_000
     want = co.dm_ref(t["train"][:m].cpu().numpy().view(np.uint32), t["ref"][:m].cpu().numpy().view(np.uint32), *args, nthreads=4)
-    got = kernels.dm_ref_planned(kernels.Plan(t["train"][:m].clone(), 4, ref=t["ref"][:m].clone()), t["ref"][:m].clone(), *args).cpu().numpy()
+    rf_m = t["ref"][:m].clone()
+    got = kernels.dm_ref_planned(kernels.Plan(t["train"][:m].clone(), 4, ref=rf_m), rf_m, *args).cpu().numpy()
     assert np.allclose(got, want, rtol=1e-10)
