@@ -77,7 +77,8 @@ def main():
     prior = kernels.synth_prior(SEED, row0, n, dev)
     torch.cuda.synchronize()
     t0 = time.time()
-    plans = {"net": kernels.Plan(t["train"], 5), "ref": kernels.Plan(t["train"], 4)}
+    # "ref": the product path of bear_ref.train -- a plan that also knows the (equally constant) reference column
+    plans = {"net": kernels.Plan(t["train"], 5), "ref": kernels.Plan(t["train"], 4, ref=t["ref"])}
     torch.cuda.synchronize()
     plan_build_s = time.time() - t0
 
@@ -159,6 +160,13 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
+        plan_stream = kernels.Plan(t["train"], 4)     # mode R with the reference rows streamed every step (plan from the training counts only)
+        ms = timed(lambda: kernels.dm_ref_planned(plan_stream, t["ref"], h_s, tau_s, nu_s), 10)
+        extra["ref_streaming_reference_rows"] = {"kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3), "achieved_GBps": n * 40 / (ms * 1e-3) / 1e9,
+                                                 "moved_bytes_per_context": 20 + plan_stream.nbytes / n,
+                                                 "note": "dm_ref_plan_kernel: 20 B reference row + plan per context; the 'ref' entry above is the "
+                                                         "reference-aware plan (bear_plan_create_ref), which streams only the items of contexts with reference counts"}
+        del plan_stream
         ms = timed(lambda: kernels.dm_prior_planned(plans["net"], prior, h_s, want_grad=True), 5)
         extra["net_with_gradient_rows"] = {"kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3)}
         ms = timed(lambda: kernels.dm_prior_planned(plans["net"], prior, h_s, train_ar=True), 5)
@@ -185,10 +193,16 @@ def main():
         del packed, pr_c, t1_c, g_c
         m = min(n, 20_000_000)
         test = kernels.synth_counts(SEED, row0, m, dev, want=("test",))["test"]
-        ms = timed(lambda: kernels.evaluate(test, prior[:m], [1.0], [0.1, 1.0, 10.0], t["train"][:m]), 2)
-        extra["heldout_evaluation"] = {"contexts": m, "models": "1 h + AR + 3 van_reg", "kernel_ms": ms,
-                                       "contexts_per_s": m / (ms * 1e-3)}
-        del test
+        tr_m, pr_m = t["train"][:m], prior[:m]
+        eplan = kernels.EvalPlan(test, tr_m)
+        ms = timed(lambda: kernels.evaluate_planned(eplan, pr_m, [1.0], [0.1, 1.0, 10.0]), 5)
+        ms_u = timed(lambda: kernels.evaluate(test, pr_m, [1.0], [0.1, 1.0, 10.0], tr_m), 2)
+        extra["heldout_evaluation"] = {"contexts": m, "models": "1 h + AR + 3 van_reg", "kernel": "eval_plan_kernel<1,4>", "kernel_ms": ms,
+                                       "contexts_per_s": m / (ms * 1e-3), "achieved_GBps": m * 80 / (ms * 1e-3) / 1e9,
+                                       "frac_of_hbm_peak": m * 80 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                       "plan_bytes_per_context": eplan.nbytes / m,
+                                       "unplanned_kernel_ms": ms_u, "unplanned_contexts_per_s": m / (ms_u * 1e-3)}
+        del test, eplan
 
     total = n * world
     value = total * args.steps / elapsed
@@ -198,7 +212,9 @@ def main():
 
     line = None
     if rank == 0:
-        traffic = None
+        # HBM bytes per launch as the PMC counters saw them (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate rocprofv3 --pmc
+        # passes of this command, scripts/profile_round.sh): NOT measured in this run -- read from the committed profile
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
@@ -207,8 +223,10 @@ def main():
                 traffic = ent.get("bytes_per_launch")
                 if traffic is not None:  # measured at ent["contexts_per_launch"]; traffic is linear in the shard size
                     traffic = traffic * n / float(ent.get("contexts_per_launch", n))
+                    traffic_source = "profiles/traffic_latest.json (%s): rocprofv3 --pmc passes of this command, not this run" % tj.get("tag", "?")
             except Exception:
                 traffic = None
+        moved = traffic if traffic is not None else n * (40 if primary == "net" else 0) + plans[primary].nbytes
         line = {
             "metric": "k-mer contexts/sec (DM-marginal+grad h), k=13",
             "value": value,
@@ -238,7 +256,11 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
-                "kernel": "dm_prior_plan_kernel" if primary == "net" else "dm_ref_plan_kernel",
+                "traffic_source": traffic_source,
+                # what the kernel actually moves (the plan replaces the 20 B count row by ~5 B): the HBM utilisation proper
+                "moved_bytes_per_context": moved / n,
+                "moved_bytes_frac": moved / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "kernel": "dm_prior_plan_kernel" if primary == "net" else "dm_ref_items_kernel",
                 "kernel_ms": k_ms,
                 "measured_stream_read_GBps": stream_gbps,
             },
@@ -258,7 +280,8 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"], line["elbo_rel_err_vs_cpu"] = cpu_baseline(kernels, t, prior, primary, (h_s, tau_s, nu_s), dev)
+            line["cpu_baseline"], line["elbo_rel_err_vs_cpu"], line["elbo_check"] = cpu_baseline(
+                t, prior, primary, (h_s, tau_s, nu_s), result)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
@@ -267,42 +290,31 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(kernels, t, prior, workload, params, dev):
-    """The oracle's C restatement (libm lgamma_r + series digamma, OpenMP over all host cores)
-    on a bounded sample of the same table; also the GPU-vs-CPU ELBO relative error on it."""
+def cpu_baseline(t, prior, workload, params, result):
+    """The oracle's C restatement (libm lgamma_r + series digamma, OpenMP over all host cores): timed on a bounded sample of the
+    same table (the reported baseline), then run over the WHOLE table to check the output of the launch that was timed."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle as co  # checker only: never on the measured or shipped path
 
     cores = os.cpu_count() or 1
     h_s, tau_s, nu_s = params
+    n = t["train"].shape[0]
+    tr = t["train"].cpu().numpy().view(np.uint32)
+    other = prior.cpu().numpy() if workload == "net" else t["ref"].cpu().numpy().view(np.uint32)
 
     def run(m):
-        tr = t["train"][:m].cpu().numpy().view(np.uint32)
-        if workload == "net":
-            f = prior[:m].cpu().numpy()
-            t0 = time.perf_counter()
-            out, _ = co.dm_prior(tr, f, h_s, nthreads=cores)
-            return time.perf_counter() - t0, out
-        rf = t["ref"][:m].cpu().numpy().view(np.uint32)
         t0 = time.perf_counter()
-        out = co.dm_ref(tr, rf, h_s, tau_s, nu_s, nthreads=cores)
-        return time.perf_counter() - t0, out
+        if workload == "net":
+            out, _ = co.dm_prior(tr[:m], other[:m], h_s, nthreads=cores)
+        else:
+            out = co.dm_ref(tr[:m], other[:m], h_s, tau_s, nu_s, nthreads=cores)
+        return time.perf_counter() - t0, np.asarray(out)
 
-    n = t["train"].shape[0]
     run(min(n, 200_000))  # thread start-up
     dt, _ = run(min(n, 2_000_000))
     rate = min(n, 2_000_000) / dt
     m = int(min(n, 30_000_000, max(2_000_000, rate * 12)))  # ~12 s of CPU work
-    dt, want = run(m)
-    if workload == "net":
-        got = kernels.dm_prior(t["train"][:m], prior[:m], h_s)[0].cpu().numpy()
-        p = kernels.Plan(t["train"][:m].clone(), 5)
-        got_p = kernels.dm_prior_planned(p, prior[:m].clone(), h_s).cpu().numpy()
-    else:
-        got = kernels.dm_ref(t["train"][:m], t["ref"][:m], h_s, tau_s, nu_s).cpu().numpy()
-        p = kernels.Plan(t["train"][:m].clone(), 4)
-        got_p = kernels.dm_ref_planned(p, t["ref"][:m].clone(), h_s, tau_s, nu_s).cpu().numpy()
-    rel = float(max(abs(got[0] - want[0]), abs(got_p[0] - want[0])) / abs(want[0]))
+    dt, _ = run(m)
     base = {
         "value": m / dt,
         "unit": "contexts/s",
@@ -311,7 +323,17 @@ def cpu_baseline(kernels, t, prior, workload, params, dev):
         "sample": f"first {m} contexts of the same synthetic table, oracle/bear_oracle.c (libm lgamma_r + series digamma, "
                   f"OpenMP x{cores}); TensorFlow is not installable here, so this restatement stands in for the TF-CPU path",
     }
-    return base, rel
+    # the timed launch's own result against the oracle on the full table (bounded: skipped above ~2 minutes of CPU)
+    check = {"contexts": 0, "note": "skipped: the full table would take %.0f s on this host" % (n / (m / dt))}
+    rel = None
+    if n / (m / dt) <= 120.0:
+        _, want = run(n)
+        k = want.size
+        rel = float(abs(result[0] - want[0]) / abs(want[0]))
+        scale = float(np.abs(want[1:]).max() + abs(want[0]) * 1e-3)
+        check = {"contexts": n, "elbo_rel_err": rel, "grad_abs_err_over_scale": float(np.abs(result[1:k] - want[1:]).max() / scale),
+                 "note": "output of the timed launch vs oracle/bear_oracle.c on the whole table"}
+    return base, rel, check
 
 
 if __name__ == "__main__":

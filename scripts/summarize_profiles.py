@@ -19,7 +19,10 @@ if ks:
 traffic = {}
 def kernel_key(k):
     """bench.py workload name of a planned kernel instantiation."""
-    if "eval_kernel" in k: return "heldout_eval"
+    if "eval_plan_kernel" in k: return "heldout_eval"
+    if "eval_sorted_kernel" in k: return "heldout_eval_unplanned"
+    if "dm_ref_items" in k: return "ref_ar" if "<true>" in k else "ref"
+    if "dm_ref_plan" in k: return "ref_stream_ar" if "<true>" in k else "ref_stream"
     if "cnn_forward" in k: return "cnn_forward"
     if "cnn_backward" in k: return "cnn_backward"
     if "dm_linear" in k: return "linear_head"
@@ -41,7 +44,7 @@ for kind in ("fetch", "write", "sq"):
     if not agg: continue
     out_md += [f"## PMC pass: {kind}", "", "| kernel | counter | mean per launch |", "|---|---|---|"]
     for k, v in agg.items():
-        if "plan_kernel" not in k and "plan_grad_kernel" not in k and "sorted" not in k and "eval_kernel" not in k and "cnn_" not in k: continue
+        if not any(x in k for x in ("plan_kernel", "plan_grad_kernel", "sorted", "eval_", "cnn_", "items_kernel")): continue
         for c, x in v.items():
             out_md.append(f"| `{k[:40]}` | {c} | {sum(x)/len(x):.0f} |")
             name = kernel_key(k)
@@ -52,11 +55,12 @@ for kind in ("fetch", "write", "sq"):
             if c == "WRITE_SIZE":
                 traffic.setdefault(name, {})["write_bytes_per_launch"] = sum(x) / len(x) * 1024
     out_md.append("")
-for name, d in traffic.items():
+for name, d in list(traffic.items()):
     d["bytes_per_launch"] = d.get("fetch_bytes_per_launch", 0) + d.get("write_bytes_per_launch", 0)
     # bench.py defaults (--contexts 1e8; the evaluation extra runs on the first 2e7); bench.py scales linearly for other sizes
-    d["contexts_per_launch"] = 20000000 if name == "heldout_eval" else 100000000
+    d["contexts_per_launch"] = 20000000 if name.startswith("heldout_eval") else 100000000
 if traffic:
+    traffic["tag"] = tag
     json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
     out_md += ["## HBM traffic per launch (corrected as MI355X_MICROARCH.md prescribes)", "", "```", json.dumps(traffic, indent=1), "```", ""]
