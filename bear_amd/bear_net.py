@@ -57,6 +57,20 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
         # fused kernels -> finalize [-> all-reduce of the packed vector] -> Adam, no host round trip (_train.run_device_steps)
         theta = torch.cat([h_signed.detach().reshape(1)] + [p.detach().reshape(-1) for p in ar_params]).to(
             device=device, dtype=torch.float64).contiguous()
+        if fused_mat is not None:
+            # the sums of a step do not depend on the order of a batch's rows: sorted by k-mer (first letter most significant),
+            # consecutive contexts share all but their last letters and the fused kernel adds whole waves / quads of them to
+            # d/d mat at once instead of one LDS atomic per context, letter and position (kernels_linear.h)
+            for e in res.batches:
+                if e["rows"] > 1:
+                    key = torch.zeros(e["rows"], dtype=torch.int64, device=device)
+                    for l in range(lag):
+                        c = e["codes"][:, l].to(torch.int64)
+                        key = key * 6 + torch.where((c >= 0) & (c <= 4), c, torch.full_like(c, 5))
+                    order = torch.argsort(key)
+                    e["train"] = e["train"][order].contiguous()
+                    e["codes"] = e["codes"][order].contiguous()
+                    del key, order
         packs = [kernels.pack_kmers(e["codes"].contiguous()) if e["rows"] else None for e in res.batches]
         if cnn_ok:
             fw = ar_func.cnn_filter_width

@@ -6,27 +6,41 @@
 //
 // Contexts arrive as packed k-mers (3 bits per letter: 0..A-1, A = start symbol, 5 = unknown letter = all-zero
 // one-hot row, core.py:173), 8 bytes per context instead of the 40-byte prior row, and nothing is written per
-// context.  Per tile of the plan:
-//   A  one thread per context: logits from PAIR tables T[g][a_2g, a_2g+1][b] = mat[2g][a][b] + mat[2g+1][a'][b]
-//      (7 LDS rows instead of 13 for lag 13), softmax, row into LDS;
-//   B  ticketed item units as in dm_prior_plan_kernel: D, P per item; with q = dLL/df at the item's cell and
-//      w = f q the softmax backward is  g_logit[b] = f_b (q_b - s),  s = sum over the context's items of w.
-//      The common base -u P(A,n) of all five cells drops out because the softmax row sums to one, so contexts
-//      only need s (LDS fp64 atomics per item) and the item adds +w to the gradient pair table at its own cell;
-//   C  one thread per context with s != 0: -f_b s into the gradient pair tables (LDS fp64 atomics).
+// context.  Per tile of the plan, two barriers:
+//   A  one thread per context (rows tid, tid + 1024): logits from PAIR tables T[g][a_2g, a_2g+1][b] = mat[2g][a][b] +
+//      mat[2g+1][a'][b] (7 LDS rows instead of 13 for lag 13), softmax; the row goes to LDS for the items AND stays in the
+//      thread's registers;
+//   B  ticketed item units as in dm_prior_plan_kernel: D, P per item; with q = dLL/df at the item's cell the item leaves
+//      -w = -f q in its own cell of the LDS row (a cell belongs to at most one item; f > 0, so the sign marks it);
+//   C  the same thread as in A reads its rows' cells back: w_b from the marked cells, s = sum_b w_b, and the softmax backward
+//      g_b = w_b - f_b s with f from its registers (the common base -u P(A,n) of the five cells drops out because the row
+//      sums to one).  d/d mat[l][a][:] = sum over contexts with letter a at position l of g: the 64 contexts of a wave are
+//      consecutive rows, and in a k-mer-sorted table (bear_net.train sorts a batch's rows by k-mer at upload: the sums do not
+//      depend on the order) they share all but the last few letters -- so per pair group the wave checks whether all its
+//      contexts agree (one wave-level sum of g, four lane-atomics per group), whether aligned quads agree (quad sums), and
+//      only otherwise falls back to one LDS fp64 atomic per context, letter and group (the round-1 formulation: 28 + 8 atomics
+//      per context at ~2.5 lane-atomics per clock and CU = 2.2 of its 3.85 ms; sorted tables need ~5).  The last group
+//      (6 combos) goes through 16 lane-indexed replicas so that the 64 atomics of a wave do not pile onto 5 addresses.
+//   C of tile t and A of tile t + 1 are one phase (a thread only touches its own row slots).
 // The context terms -D(A, n) come from the plan's histogram (A = u + 5 eps: softmax rows are normalised).
 // After the last tile the pair tables fold into d/d mat partials; a finalize kernel sums the blocks in fixed order.
-// Measured at 1e8 contexts, lag 13 (3.9 ms): pass C 1.6 ms and the item scatter 0.6 ms run at the LDS fp64-atomic
-// rate (~2.5 lane-atomics per clock per CU, scripts/dev/lds_atomic_bench.hip), the softmax exponentials 0.2 ms.
 // Note: LDS floating-point atomics make the summation order inside a block run-dependent (last-bit jitter in
 // grad_mat); the ELBO and d/dh sums keep the fixed-order reduction of the other kernels.
 #pragma once
 #include "kernels_plan.h"
+#ifndef LIN_DBG
+#define LIN_DBG 0   // developer cut-offs of phase C (results are then meaningless)
+#endif
 
 #define LIN_MAX_LAG 21
-#define LIN_MAX_GROUPS ((LIN_MAX_LAG + 1) / 2)
-#define LIN_COMBOS 36
-#define LIN_GSTRIDE (LIN_COMBOS * 5)
+// Letter groups: pairs over the leading letters, ONE triple over the last three (lag >= 3).  In a k-mer-sorted table the last
+// letters vary fastest: with them in a single group, the 64 consecutive contexts of a wave differ in that group only (plus,
+// now and then, the pair before it), so every other group takes one block-level add (see phase C).
+#define LIN_PAIR_COMBOS 36
+#define LIN_TRI_COMBOS 216
+#define LIN_PSTRIDE (LIN_PAIR_COMBOS * 5)
+#define LIN_MAX_PAIRS ((LIN_MAX_LAG - 3 + 1) / 2)
+#define LIN_TAB_DOUBLES (LIN_MAX_PAIRS * LIN_PSTRIDE + LIN_TRI_COMBOS * 5)
 #define LIN_MAX_GRAD (LIN_MAX_LAG * 25)
 
 struct lin_buf {
@@ -35,10 +49,9 @@ struct lin_buf {
 };
 struct pln_lds_lin {
   double pri[PLN_RMAX * 5 + 2];  // [PLN_SENTINEL] = 1.0
-  double srow[PLN_RMAX + 2];     // [PLN_RMAX] = sink of the sentinel lane
   lin_buf buf[2];
-  double T[LIN_MAX_GROUPS * LIN_GSTRIDE];
-  double GT[LIN_MAX_GROUPS * LIN_GSTRIDE];
+  double T[LIN_TAB_DOUBLES];     // [pair g][a * 6 + a'][b] ... | [triple][(a * 6 + a') * 6 + a''][b]
+  double GT[LIN_TAB_DOUBLES];
   double2 logtab[BEAR_LOGTAB_N];
   double tabD[SRT_NKEY];
   double tabP[SRT_NKEY];
@@ -46,6 +59,20 @@ struct pln_lds_lin {
   uint32_t ticket[2];
 };
 static_assert(sizeof(pln_lds_lin) <= 160 * 1024, "linear-head kernel: LDS budget");
+
+// group geometry of a lag: npair pair groups over letters [0, 2 npair) (the last pair may hold one letter), then the triple
+struct lin_geom {
+  int lag, npair, tri, ng;   // tri: first letter of the triple (-1: none); ng = npair + (tri >= 0)
+};
+__host__ __device__ inline lin_geom lin_make_geom(int lag) {
+  lin_geom G;
+  G.lag = lag;
+  G.tri = lag >= 3 ? lag - 3 : -1;
+  const int lead = lag >= 3 ? lag - 3 : lag;
+  G.npair = (lead + 1) / 2;
+  G.ng = G.npair + (G.tri >= 0 ? 1 : 0);
+  return G;
+}
 
 // int8 codes [n, lag] (core.encode_kmers: 0..A letters / start symbol, anything else unknown) -> packed words
 __global__ void pack_kmers_kernel(const int8_t *__restrict__ codes, uint64_t n, int lag, unsigned long long *__restrict__ out) {
@@ -78,16 +105,22 @@ __global__ void encode_kmers_kernel(const uint8_t *__restrict__ ascii, uint64_t 
   }
 }
 
-__device__ __forceinline__ uint32_t lin_combo(unsigned long long code, int g) {
-  const uint32_t field = (uint32_t)(code >> (6 * g)) & 63u;
-  return (field & 7u) * 6u + (field >> 3);
+// table offset (in doubles, letter b = 0) of group g's row for a context: pairs first, the triple last
+__device__ __forceinline__ uint32_t lin_row_off(unsigned long long code, int g, const lin_geom &G) {
+  if (g < G.npair) {
+    uint32_t field = (uint32_t)(code >> (6 * g)) & 63u;
+    if (2 * g + 1 >= (G.tri >= 0 ? G.tri : G.lag)) field &= 7u;   // a pair of one letter: its partner belongs to the triple
+    return (uint32_t)g * LIN_PSTRIDE + ((field & 7u) * 6u + (field >> 3)) * 5u;
+  }
+  const uint32_t f9 = (uint32_t)(code >> (3 * G.tri)) & 511u;
+  return (uint32_t)G.npair * LIN_PSTRIDE + (((f9 & 7u) * 6u + ((f9 >> 3) & 7u)) * 6u + (f9 >> 6)) * 5u;
 }
 
-// softmax row of one context from the pair tables
-__device__ __forceinline__ void lin_row(const double *T, const double *exptab, unsigned long long code, int ng, double (&f)[5]) {
+// softmax row of one context from the group tables
+__device__ __forceinline__ void lin_row(const double *T, const double *exptab, unsigned long long code, const lin_geom &G, double (&f)[5]) {
   double z[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int g = 0; g < ng; ++g) {
-    const double *t = T + g * LIN_GSTRIDE + lin_combo(code, g) * 5u;
+  for (int g = 0; g < G.ng; ++g) {
+    const double *t = T + lin_row_off(code, g, G);
 #pragma unroll
     for (int b = 0; b < 5; ++b) z[b] += t[b];
   }
@@ -105,6 +138,37 @@ __device__ __forceinline__ void lin_row(const double *T, const double *exptab, u
   for (int b = 0; b < 5; ++b) f[b] *= r;
 }
 
+// ---- cross-lane sums on DPP (a double = two 32-bit moves + one add per step; the generic __shfl_xor of a double costs
+// two ds_bpermute round trips: measured 0.76 ms per 1e8 contexts for the 24 of them a wave needs here)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double lin_dpp(double v) {
+  const long long q = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)q, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(q >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (uint32_t)lo);
+}
+// every lane gets the sum over its aligned quad / its row of 16
+__device__ __forceinline__ double lin_quad_sum(double v) {
+  v += lin_dpp<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += lin_dpp<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ double lin_row16_sum(double quad_sum) {
+  double v = quad_sum;
+  v += lin_dpp<0x141, 0xf>(v);   // row_half_mirror: the other quad pair of the half row (all four lanes of a quad agree)
+  v += lin_dpp<0x140, 0xf>(v);   // row_mirror: the other half row
+  return v;
+}
+// wave total from the row sums, as a wave-uniform value
+__device__ __forceinline__ double lin_wave_sum(double row_sum) {
+  double v = row_sum;
+  v += lin_dpp<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += lin_dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  const long long q = __double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | lo);
+}
+
 template <bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_kernel(
     const unsigned long long *__restrict__ kmer_code, const double *__restrict__ mat, int lag, bear_params prm_arg, pln_view pv,
@@ -115,7 +179,8 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   const bear_params prm = prm_dev ? *prm_dev : prm_arg;   // device-resident parameters for HIP-graph replay (bear_net_linear_train_step_f64)
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
-  const int ng = (lag + 1) >> 1;
+  const lin_geom G = lin_make_geom(lag);
+  const int ng = G.ng, n_tab = G.npair * LIN_PSTRIDE + (G.tri >= 0 ? LIN_TRI_COMBOS * 5 : 0);
   double acc[2] = {0.0, 0.0};
 
   if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
@@ -130,13 +195,22 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     S.ticket[1] = 0;
   }
   if (tid < BEAR_EXPTAB_N) S.exptab[tid] = exp2((double)tid * (1.0 / BEAR_EXPTAB_N));
-  // pair tables: T[g][a * 6 + a'][b] = mat[2g][a][b] (a < 5) + mat[2g+1][a'][b] (a' < 5, position inside the lag)
-  for (int k = tid; k < ng * LIN_GSTRIDE; k += PLN_THREADS) {
-    const int g = k / LIN_GSTRIDE, r = k - g * LIN_GSTRIDE, combo = r / 5, b = r - combo * 5;
-    const int a0 = combo / 6, a1 = combo - a0 * 6, l0 = 2 * g, l1 = 2 * g + 1;
+  // group tables: a row is the sum of mat[l][a_l][:] over the group's letters (letter values 5 = unknown and positions beyond
+  // the group contribute nothing)
+  for (int k = tid; k < n_tab; k += PLN_THREADS) {
     double v = 0.0;
-    if (a0 < 5) v += mat[(l0 * 5 + a0) * 5 + b];
-    if (a1 < 5 && l1 < lag) v += mat[(l1 * 5 + a1) * 5 + b];
+    if (k < G.npair * LIN_PSTRIDE) {
+      const int g = k / LIN_PSTRIDE, r = k - g * LIN_PSTRIDE, combo = r / 5, b = r - combo * 5;
+      const int a0 = combo / 6, a1 = combo - a0 * 6, l0 = 2 * g, l1 = 2 * g + 1, lead = G.tri >= 0 ? G.tri : lag;
+      if (a0 < 5 && l0 < lead) v += mat[(l0 * 5 + a0) * 5 + b];
+      if (a1 < 5 && l1 < lead) v += mat[(l1 * 5 + a1) * 5 + b];
+    } else {
+      const int r = k - G.npair * LIN_PSTRIDE, combo = r / 5, b = r - combo * 5;
+      const int a0 = combo / 36, a1 = (combo / 6) % 6, a2 = combo % 6;
+      if (a0 < 5) v += mat[((G.tri + 0) * 5 + a0) * 5 + b];
+      if (a1 < 5) v += mat[((G.tri + 1) * 5 + a1) * 5 + b];
+      if (a2 < 5) v += mat[((G.tri + 2) * 5 + a2) * 5 + b];
+    }
     S.T[k] = v;
     S.GT[k] = 0.0;
   }
@@ -155,29 +229,145 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     }
     pln_dma(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, ti.blk16 * 16u, wave, lane, (cbytes + 1023u) >> 10);
   };
-  // +w (item's own cell) or -f_b s (all cells of a context) into the gradient pair tables
-  // Lanes walk the groups in rotated order (lane i starts at group i mod ng): at any moment the 64 atomics of
-  // a wave spread over all ng tables instead of colliding inside one.
-  const int g_rot = (int)(lane % (uint32_t)ng);
-  // Only letters b < 4 are accumulated: the softmax gradient of a context sums to zero over b, so the last
-  // column is minus the sum of the others (restored in the fold below).
-  auto scatter1 = [&](unsigned long long code, uint32_t b, double w) {
-    if (b == 4u) return;
-    int g = g_rot;
-    for (int k = 0; k < ng; ++k) {
-      atomicAdd(&S.GT[g * LIN_GSTRIDE + lin_combo(code, g) * 5u + b], w);
-      g = g + 1 == ng ? 0 : g + 1;
+
+  // ---- phase A for the thread's rows of a tile: softmax rows into LDS and into fA (kept until phase C of the same tile)
+  constexpr int RPT = (PLN_RMAX + PLN_THREADS - 1) / PLN_THREADS;
+  double fA[RPT][5];
+  unsigned long long cA[RPT];
+  auto phase_a = [&](const lin_buf &B, uint32_t rows) {
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const uint32_t row = tid + PLN_THREADS * k;
+      cA[k] = 0ull;
+      if (row < rows) {
+        cA[k] = B.codes[row];
+        lin_row(S.T, S.exptab, cA[k], G, fA[k]);
+#pragma unroll
+        for (int b = 0; b < 5; ++b) S.pri[row * 5 + b] = fA[k][b];
+      }
+    }
+  };
+  // ---- phase C for the thread's rows: g_b = w_b - f_b s into the gradient tables, whole waves at a time.
+  // One LDS fp64 atomic wave-instruction costs ~20 clocks of CU time whatever the number of active lanes (measured,
+  // scripts/dev/lds_atomic_lanes.hip), so what counts is the number of INSTRUCTIONS: lanes are mapped to (group, letter) pairs
+  //   1. all groups whose row the whole wave shares: lane 4 g + b adds the wave's sum of g_b              (one instruction)
+  //   2. up to four groups that a lane's row of 16 shares: lane (slot, b) of each row adds the row's sum   (one instruction)
+  //   3. what is left (in a sorted table: the triple of the last letters): one add per context and letter (four per group)
+  auto phase_c = [&](uint32_t rows) {
+#ifdef LIN_SKIP_C
+    return;
+#endif
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const uint32_t row0w = (tid & ~63u) + PLN_THREADS * k;   // first row of this wave's 64 consecutive rows
+      if (row0w >= rows) continue;                             // wave-uniform
+      const uint32_t row = row0w + lane;
+      const bool live = row < rows;
+      double g[4] = {0.0, 0.0, 0.0, 0.0};
+      if (live) {
+        double w[5], sw = 0.0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          const double v = S.pri[row * 5 + b];
+          w[b] = v < 0.0 ? -v : 0.0;          // cells an item has marked hold -w; the others still hold f_b >= 0
+          sw += w[b];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) g[b] = __builtin_fma(-fA[k][b], sw, w[b]);
+      }
+      const bool nz = (g[0] != 0.0) | (g[1] != 0.0) | (g[2] != 0.0) | (g[3] != 0.0);
+      if (__builtin_amdgcn_ballot_w64(nz) == 0ull) continue;   // no item in these 64 contexts
+      // rows beyond the tile end take the code of the wave's first context: they add nothing and never break a run
+      const uint32_t c0lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cA[k]);
+      const uint32_t c0hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cA[k] >> 32));
+      const unsigned long long code0 = ((unsigned long long)c0hi << 32) | c0lo, code = live ? cA[k] : code0;
+      double th[4], tw[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        th[b] = lin_row16_sum(lin_quad_sum(g[b]));
+        tw[b] = lin_wave_sum(th[b]);
+      }
+      // which groups does the whole wave share, which does my row of 16 share
+      uint32_t wave_uniform = 0u, row_uniform = 0u;           // bit g; wave_uniform is wave-uniform, row_uniform per lane
+      for (int gq = 0; gq < ng; ++gq) {
+        const uint32_t off = lin_row_off(code, gq, G);
+        const uint32_t o0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+        if (__builtin_amdgcn_ballot_w64(off != o0) == 0ull) {
+          wave_uniform |= 1u << gq;
+          continue;
+        }
+        const uint32_t o16 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0x140, 0xf, 0xf, false);   // row_mirror: lane 15 - i
+        const uint32_t o8 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0x141, 0xf, 0xf, false);    // row_half_mirror: lane 7 - i
+        const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+        const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+        // a row of 16 agrees iff every lane equals its mirror images at all four levels
+        const unsigned long long bad = __builtin_amdgcn_ballot_w64(off != o16 || off != o8 || off != o1 || off != o2);
+        if (((bad >> (lane & ~15u)) & 0xffffull) == 0ull) row_uniform |= 1u << gq;
+      }
+#if LIN_DBG == 1
+      acc[1] += tw[0] * 1e-300 + th[1] * 1e-300 + (double)row_uniform * 1e-300;
+      continue;
+#endif
+      // 1. the groups the whole wave shares
+      {
+        const uint32_t gq = lane >> 2, b = lane & 3u;
+        if (gq < (uint32_t)ng && ((wave_uniform >> gq) & 1u)) {
+          const double v = b == 0 ? tw[0] : b == 1 ? tw[1] : b == 2 ? tw[2] : tw[3];
+          if (v != 0.0) atomicAdd(&S.GT[lin_row_off(code0, (int)gq, G) + b], v);
+        }
+      }
+#if LIN_DBG == 2
+      continue;
+#endif
+      // 2. groups a row of 16 shares (the wave does not): slot s of a row takes the s-th such group of that row
+      uint32_t rest = row_uniform;                              // per lane: groups still to be added at row level
+      const uint32_t not_wave = ~wave_uniform & ((1u << ng) - 1u);
+      if (__builtin_amdgcn_ballot_w64(rest != 0u)) {
+        const uint32_t slot = (lane & 15u) >> 2, b = lane & 3u;
+        uint32_t pick = 0xffffffffu, m = rest;
+        for (uint32_t s2 = 0; s2 <= slot; ++s2) {              // the slot-th set bit of the row's mask (same for all its lanes)
+          pick = m ? (uint32_t)__builtin_ctz(m) : 0xffffffffu;
+          m &= m - 1u;
+        }
+        if (pick != 0xffffffffu) {
+          const double v = b == 0 ? th[0] : b == 1 ? th[1] : b == 2 ? th[2] : th[3];
+          if (v != 0.0) atomicAdd(&S.GT[lin_row_off(code, (int)pick, G) + b], v);
+        }
+        // groups beyond the fourth of a row (unsorted tables only) stay for step 3
+        uint32_t done = 0u, m2 = rest;
+        for (int s2 = 0; s2 < 4 && m2; ++s2) {
+          done |= m2 & (0u - m2);
+          m2 &= m2 - 1u;
+        }
+        rest = done;
+      }
+#if LIN_DBG == 4
+      continue;
+#endif
+      // 3. one add per context and letter for every group not covered above
+      for (int gq = 0; gq < ng; ++gq) {
+        if (!((not_wave >> gq) & 1u)) continue;                 // wave-uniform test
+        const bool mine = !((rest >> gq) & 1u) && nz;
+        if (!__builtin_amdgcn_ballot_w64(mine)) continue;
+        if (mine) {
+          double *gt = &S.GT[lin_row_off(code, gq, G)];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) atomicAdd(&gt[b], g[b]);
+        }
+      }
     }
   };
 
-  const uint64_t G = gridDim.x;
-  pln_tile cur = pln_load_tile(pv, blockIdx.x), nxt = pln_load_tile(pv, blockIdx.x + G);
+  const uint64_t GR = gridDim.x;
+  pln_tile cur = pln_load_tile(pv, blockIdx.x), nxt = pln_load_tile(pv, blockIdx.x + GR);
   stage(cur, 0);
+  srt_wait_dma();
+  srt_sync();
+  phase_a(S.buf[0], cur.rows_items >> 16);
+  srt_sync();
+  stage(nxt, 1);
   uint32_t slot = 0;
-  for (uint64_t t = blockIdx.x; t < pv.n_tiles; t += G) {
-    srt_wait_dma();
-    srt_sync();  // current tile landed; previous tile fully consumed
-    stage(nxt, slot ^ 1u);
+  for (uint64_t t = blockIdx.x; t < pv.n_tiles; t += GR) {
     const lin_buf &B = S.buf[slot];
     const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
     const uint32_t hc = cur.hc_hr >> 16, hr = cur.hc_hr & 0xffffu;
@@ -185,18 +375,8 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     const uint16_t *E = reinterpret_cast<const uint16_t *>(B.blk);
     const uint16_t *items = reinterpret_cast<const uint16_t *>(B.blk + L.items);
     if (tid == 0) S.ticket[slot ^ 1u] = 0;
-    // ---- A: softmax rows of the tile
-    for (uint32_t row = tid; row < rows; row += PLN_THREADS) {
-      double f[5];
-      lin_row(S.T, S.exptab, B.codes[row], ng, f);
-#pragma unroll
-      for (int b = 0; b < 5; ++b) S.pri[row * 5 + b] = f[b];
-      S.srow[row] = 0.0;
-    }
-    srt_sync();
-    // ---- B: items (tickets, dearest first)
+    // ---- B: items (tickets, dearest first): ELBO / d/dh, and -w = -f q into the item's own cell
     auto item = [&](uint32_t off, double D, double P, double x, double cnt) {
-      // D, P of the item (AR: unused), x its concentration; accumulates ELBO / d/dh and the softmax backward
       const double fb = S.pri[off];
       double q;
       if (AR) {
@@ -208,15 +388,14 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
         acc[1] = __builtin_fma(eps - x, P, acc[1]);
         q = u * P;
       }
-      if (cnt != 0.0) {
-        const uint32_t row = off / 5u, b = off - row * 5u;
-        const double w = fb * q;
-        atomicAdd(&S.srow[row], w);
-        scatter1(B.codes[row], b, w);
-      }
+      if (cnt != 0.0) S.pri[off] = -(fb * q);
     };
     const uint32_t n_hcu = (hc + 63u) >> 6, n_hru = AR ? 0u : (hr + 63u) >> 6, n_units = (n_light + 63u) >> 6;
+#ifdef LIN_SKIP_B
+    const uint32_t n_work = 0u * (n_hcu + n_hru + n_units);
+#else
     const uint32_t n_work = n_hcu + n_hru + n_units;
+#endif
     for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_work; w = pln_ticket(&S.ticket[slot], lane)) {
       if (w < n_hcu) {
         const uint32_t i = w * 64u + lane;
@@ -246,28 +425,17 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
       const double x[1] = {__builtin_fma(S.pri[off], u, eps)};
       bear_dp o[1] = {{0.0, 0.0}};
       if (!AR) srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
-      item(off, o[0].D, o[0].P, x[0], (double)ci[0]);
+      if (off != (uint32_t)PLN_SENTINEL) item(off, o[0].D, o[0].P, x[0], (double)ci[0]);
     }
-    srt_sync();
-    // ---- C: contexts that own items: -f_b s into the gradient tables
-    for (uint32_t row = tid; row < rows; row += PLN_THREADS) {
-      const double s = S.srow[row];
-      if (s != 0.0) {
-        const unsigned long long code = B.codes[row];
-        double fs[5];
-#pragma unroll
-        for (int b = 0; b < 5; ++b) fs[b] = -S.pri[row * 5 + b] * s;
-        int g = g_rot;
-        for (int k = 0; k < ng; ++k) {
-          double *gt = &S.GT[g * LIN_GSTRIDE + lin_combo(code, g) * 5u];
-#pragma unroll
-          for (int b = 0; b < 4; ++b) atomicAdd(&gt[b], fs[b]);
-          g = g + 1 == ng ? 0 : g + 1;
-        }
-      }
-    }
+    srt_wait_dma();  // the next tile's codes and plan block (issued one phase ago)
+    srt_sync();      // ... and every item of this tile has left its mark
+    // ---- C of this tile, A of the next: a thread only touches its own row slots
+    phase_c(rows);
+    phase_a(S.buf[slot ^ 1u], nxt.rows_items >> 16);
+    srt_sync();      // nobody reads this tile's codes any more: its slot may be refilled
     cur = nxt;
-    nxt = pln_load_tile(pv, t + 2 * G);
+    nxt = pln_load_tile(pv, t + 2 * GR);
+    stage(nxt, slot);
     slot ^= 1u;
   }
   srt_wait_dma();
@@ -280,7 +448,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     const uint32_t b = (uint32_t)(h.off - row * 5u);
     const unsigned long long code = kmer_code[row];
     double f[5];
-    lin_row(S.T, S.exptab, code, ng, f);
+    lin_row(S.T, S.exptab, code, G, f);
     double q;
     if (AR) {
       const double pp = f[b] + eps;
@@ -295,7 +463,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     }
     const double w = f[b] * q;
     for (int g = 0; g < ng; ++g) {
-      double *gt = &S.GT[g * LIN_GSTRIDE + lin_combo(code, g) * 5u];
+      double *gt = &S.GT[lin_row_off(code, g, G)];
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) atomicAdd(&gt[bb], (bb == (int)b ? w : 0.0) - f[bb] * w);
     }
@@ -311,14 +479,23 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     acc[1] = __builtin_fma(u * m, S.tabP[tid], acc[1]);
   }
   __syncthreads();
-  // ---- fold the pair tables into d/d mat[l][a][b]
+  // ---- fold the group tables into d/d mat[l][a][b]: sum over the group's other letters; only b < 4 was accumulated (the softmax
+  // gradient of a context sums to zero over b: the last column is minus the sum of the others)
   for (int k = tid; k < lag * 25; k += PLN_THREADS) {
-    const int l = k / 25, r = k - l * 25, a = r / 5, b = r - a * 5, g = l >> 1;
+    const int l = k / 25, r = k - l * 25, a = r / 5, b = r - a * 5;
     double s = 0.0;
-    for (int p = 0; p < 6; ++p) {
-      const int combo = (l & 1) ? p * 6 + a : a * 6 + p;
-      const double *gt = &S.GT[g * LIN_GSTRIDE + combo * 5];
-      s += b < 4 ? gt[b] : -((gt[0] + gt[1]) + (gt[2] + gt[3]));
+    auto add = [&](const double *gt) { s += b < 4 ? gt[b] : -((gt[0] + gt[1]) + (gt[2] + gt[3])); };
+    if (G.tri >= 0 && l >= G.tri) {
+      const int pos = l - G.tri;
+      const double *base = &S.GT[G.npair * LIN_PSTRIDE];
+      for (int p = 0; p < 36; ++p) {
+        const int p0 = p / 6, p1 = p % 6;
+        const int combo = pos == 0 ? (a * 6 + p0) * 6 + p1 : pos == 1 ? (p0 * 6 + a) * 6 + p1 : (p0 * 6 + p1) * 6 + a;
+        add(base + combo * 5);
+      }
+    } else {
+      const int g = l >> 1;
+      for (int p = 0; p < 6; ++p) add(&S.GT[g * LIN_PSTRIDE + ((l & 1) ? p * 6 + a : a * 6 + p) * 5]);
     }
     grad_partials[(size_t)blockIdx.x * LIN_MAX_GRAD + k] = s;
   }

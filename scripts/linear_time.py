@@ -1,4 +1,4 @@
-"""Dev helper: the linear-head training step, fused kernel vs. torch ar_func + planned gradient-row kernel."""
+"""Dev helper: the fused linear-head training step (bear_dm_linear_f64) on random-order and on k-mer-sorted contexts."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -7,34 +7,43 @@ N = int(float(os.environ.get("N", "1e8")))
 LAG = int(os.environ.get("LAG", "13"))
 dev = torch.device("cuda", 0)
 t = kernels.synth_counts(20211012, 0, N, dev, want=("train",))
-codes = torch.randint(0, 4, (N, LAG), dtype=torch.int8, device=dev)
-packed = kernels.pack_kmers(codes)
-plan = kernels.Plan(t["train"], 5)
+codes = torch.randint(0, 4, (N, LAG), dtype=torch.int8, device=dev, generator=torch.Generator(dev).manual_seed(20211012))
 torch.manual_seed(0)
 f, (mat,) = ar_funcs.make_ar_func_linear(LAG, 4, device=dev)
-res = []
-def fused(ar=False):
-    return kernels.dm_linear(plan, packed, mat.detach(), 0.0, train_ar=ar)
-def unfused():
-    mat.grad = None
-    prior = f(codes)
-    out, g = kernels.dm_prior_planned(plan, prior.detach(), 0.0, want_grad=True)
-    prior.backward(g)
-    return out, mat.grad
-cases = [("fused", fused), ("fused_ar", lambda: fused(True))]
-if N <= 20_000_000:
-    cases.append(("torch+planned_grad", unfused))
-for name, fn in cases:
+
+
+def timed(fn, reps=5):
     fn(); torch.cuda.synchronize()
     best = 1e9
     for _ in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5): out = fn()
+        for _ in range(reps): fn()
         e1.record(); torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / 5)
-    res.append(f"{name}: {best:.3f} ms ({N / best / 1e6:.2f} Gctx/s)")
-print(f"N={N} lag={LAG} | " + " | ".join(res))
-if N <= 20_000_000:
-    a, b = fused(), unfused()
-    print("max |d mat| diff", (a[1] - b[1]).abs().max().item(), "of", b[1].abs().max().item(), "elbo", a[0][0].item(), b[0][0].item())
+        best = min(best, e0.elapsed_time(e1) / reps)
+    return best
+
+
+packed = kernels.pack_kmers(codes)
+plan = kernels.Plan(t["train"], 5)
+ref_out, ref_g = kernels.dm_linear(plan, packed, mat.detach(), 0.0)
+for ar in (False, True):
+    ms = timed(lambda: kernels.dm_linear(plan, packed, mat.detach(), 0.0, train_ar=ar))
+    print(f"random order  ar={ar}: {ms:.3f} ms ({N / ms / 1e6:.2f} Gctx/s)")
+# the same table with its rows sorted by k-mer (what bear_net.train does at upload)
+key = torch.zeros(N, dtype=torch.int64, device=dev)
+for l in range(LAG):
+    key = key * 6 + codes[:, l].to(torch.int64)
+order = torch.argsort(key)
+del key
+tr_s = t["train"][order].contiguous()
+packed_s = kernels.pack_kmers(codes[order].contiguous())
+del order
+plan_s = kernels.Plan(tr_s, 5)
+out_s, g_s = kernels.dm_linear(plan_s, packed_s, mat.detach(), 0.0)
+print("sorted vs random order: ELBO rel diff %.2e, d/dh rel diff %.2e, max |d mat| diff %.2e of %.2e" % (
+    abs((out_s[0] - ref_out[0]) / ref_out[0]).item(), abs((out_s[1] - ref_out[1]) / ref_out[1]).item(),
+    (g_s - ref_g).abs().max().item(), ref_g.abs().max().item()))
+for ar in (False, True):
+    ms = timed(lambda: kernels.dm_linear(plan_s, packed_s, mat.detach(), 0.0, train_ar=ar))
+    print(f"k-mer sorted  ar={ar}: {ms:.3f} ms ({N / ms / 1e6:.2f} Gctx/s)")
