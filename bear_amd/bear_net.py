@@ -72,6 +72,8 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
                     e["codes"] = e["codes"][order].contiguous()
                     del key, order
         packs = [kernels.pack_kmers(e["codes"].contiguous()) if e["rows"] else None for e in res.batches]
+        if fused_mat is not None:       # the linear head reads table-row words, not packed letters
+            packs = [kernels.linear_index(q, lag) if q is not None else None for q in packs]
         if cnn_ok:
             fw = ar_func.cnn_filter_width
             bufs = kernels.cnn_step_buffers(max(max(e["rows"] for e in res.batches), 1), lag, fw, device)   # one set, largest batch

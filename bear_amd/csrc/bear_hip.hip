@@ -286,6 +286,7 @@ struct bear_plan {
   pln_heavy_row *heavy_row;
   uint64_t *heavy_stop;
   unsigned long long *hist;  // [64]
+  uint16_t *live;            // five-column plans: per-tile lists of the contexts that hold counts (plan_live_kernel)
   uint64_t n_tiles;
   uint64_t n_heavy[3];
   uint64_t bytes;
@@ -307,6 +308,7 @@ static void plan_free(bear_plan *p) {
   (void)hipFree(p->heavy_row);
   (void)hipFree(p->heavy_stop);
   (void)hipFree(p->hist);
+  (void)hipFree(p->live);
   (void)hipFree(p->ref_items);
   (void)hipFree(p->hist0_base);
   (void)hipFree(p->heavy0);
@@ -414,6 +416,15 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
                        p->heavy_col, p->heavy_row, p->heavy_stop, d_cnt + 3);
     e = hipGetLastError();
   }
+  const uint64_t live_bytes = ncol == 5 ? sizeof(uint16_t) * PLN_LIVE_STRIDE * (tiles.size() + 1) : 0;   // + 1: DMA pieces are whole KiB
+  if (e == hipSuccess && live_bytes) e = hipMalloc(&p->live, live_bytes);
+  if (e == hipSuccess && live_bytes) e = hipMemset(p->live, 0, live_bytes);
+  if (e == hipSuccess && live_bytes) {
+    const uint64_t nt = tiles.size();
+    const int grid = (int)(nt < (uint64_t)ws->num_cu * 2 ? nt : (uint64_t)ws->num_cu * 2);
+    hipLaunchKernelGGL(plan_live_kernel, dim3(grid), dim3(1024), 0, 0, p->tiles, nt, p->stream, p->live);
+    e = hipGetLastError();
+  }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   unsigned long long h_used[3] = {0, 0, 0};  // entries that actually went to the global lists
   if (e == hipSuccess) e = hipMemcpy(h_used, d_cnt + 3, sizeof(h_used), hipMemcpyDeviceToHost);
@@ -424,7 +435,7 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
     plan_free(p);
     return e == hipErrorOutOfMemory ? BEAR_ERR_NOMEM : BEAR_ERR_HIP;
   }
-  p->bytes = stream_bytes + sizeof(pln_tile) * tiles.size() + sizeof(pln_heavy_col) * h_cnt[0] +
+  p->bytes = stream_bytes + live_bytes + sizeof(pln_tile) * tiles.size() + sizeof(pln_heavy_col) * h_cnt[0] +
              sizeof(pln_heavy_row) * h_cnt[1] + sizeof(uint64_t) * h_cnt[2];
   *out = p;
   return BEAR_OK;
@@ -504,6 +515,7 @@ static pln_view plan_view(const bear_plan *p) {
   v.heavy_row = p->heavy_row;
   v.heavy_stop = p->heavy_stop;
   v.hist = p->hist;
+  v.live = p->live;
   v.n_tiles = p->n_tiles;
   v.n_heavy_col = p->n_heavy[0];
   v.n_heavy_row = p->n_heavy[1];
@@ -746,6 +758,18 @@ int bear_pack_kmers_u64(const int8_t *codes, uint64_t n_rows, int lag, uint64_t 
   if (blocks > 0x7fffffffull) return BEAR_ERR_INVALID_ARG;
   hipLaunchKernelGGL(pack_kmers_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), codes, n_rows, lag,
                      reinterpret_cast<unsigned long long *>(packed));
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_linear_index_u64(const uint64_t *kmer_code, uint64_t n_rows, int lag, uint64_t *kmer_index, void *stream) {
+  if (lag < 1 || lag > LIN_MAX_LAG) return BEAR_ERR_INVALID_ARG;
+  if (n_rows == 0) return BEAR_OK;
+  if (!kmer_code || !kmer_index) return BEAR_ERR_INVALID_ARG;
+  uint64_t blocks = (n_rows + 255) / 256;
+  if (blocks > 1u << 20) blocks = 1u << 20;
+  hipLaunchKernelGGL(linear_index_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, lag, reinterpret_cast<unsigned long long *>(kmer_index));
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }

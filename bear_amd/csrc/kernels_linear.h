@@ -4,26 +4,29 @@
 //   sum LL, d sum LL / d h_signed                                   (bear_net.py:177-191, core.py:73-74)
 //   d sum LL / d mat[l, a, b]                                       (bear_net.py:193 through the softmax)
 //
-// Contexts arrive as packed k-mers (3 bits per letter: 0..A-1, A = start symbol, 5 = unknown letter = all-zero
-// one-hot row, core.py:173), 8 bytes per context instead of the 40-byte prior row, and nothing is written per
-// context.  Per tile of the plan, two barriers:
-//   A  one thread per context (rows tid, tid + 1024): logits from PAIR tables T[g][a_2g, a_2g+1][b] = mat[2g][a][b] +
-//      mat[2g+1][a'][b] (7 LDS rows instead of 13 for lag 13), softmax; the row goes to LDS for the items AND stays in the
+// Contexts arrive as one 64-bit word each (bear_linear_index_u64: the k-mer as row numbers of the letter-group tables below),
+// 8 bytes per context instead of the 40-byte prior row, and nothing is written per context.  Per tile of the plan, two barriers:
+//   A  one thread per LIVE context (entries tid, tid + 1024 of the plan's per-tile list of contexts that hold counts; ~30% of
+//      the rows of a count table hold none in the training column and are never looked at): logits from GROUP tables -- pairs
+//      of letters T[g][a, a'] = mat[2g][a] + mat[2g+1][a'] over the leading letters and one triple over the last three, rows of
+//      four doubles relative to the fifth letter's logit and in units of ln2/128 (6 table rows of 32 bytes for lag 13, read
+//      back to back: the group count is a template parameter) -- softmax; the row goes to LDS for the items AND stays in the
 //      thread's registers;
 //   B  ticketed item units as in dm_prior_plan_kernel: D, P per item; with q = dLL/df at the item's cell the item leaves
 //      -w = -f q in its own cell of the LDS row (a cell belongs to at most one item; f > 0, so the sign marks it);
 //   C  the same thread as in A reads its rows' cells back: w_b from the marked cells, s = sum_b w_b, and the softmax backward
 //      g_b = w_b - f_b s with f from its registers (the common base -u P(A,n) of the five cells drops out because the row
 //      sums to one).  d/d mat[l][a][:] = sum over contexts with letter a at position l of g: the 64 contexts of a wave are
-//      consecutive rows, and in a k-mer-sorted table (bear_net.train sorts a batch's rows by k-mer at upload: the sums do not
-//      depend on the order) they share all but the last few letters -- so per pair group the wave checks whether all its
-//      contexts agree (one wave-level sum of g, four lane-atomics per group), whether aligned quads agree (quad sums), and
-//      only otherwise falls back to one LDS fp64 atomic per context, letter and group (the round-1 formulation: 28 + 8 atomics
-//      per context at ~2.5 lane-atomics per clock and CU = 2.2 of its 3.85 ms; sorted tables need ~5).  The last group
-//      (6 combos) goes through 16 lane-indexed replicas so that the 64 atomics of a wave do not pile onto 5 addresses.
+//      consecutive live rows, and in a k-mer-sorted table (bear_net.train sorts a batch's rows by k-mer at upload: the sums do
+//      not depend on the order) they share all but the last few letters.  What an LDS fp64 atomic costs is its INSTRUCTION
+//      (~20 clocks of CU time whatever the number of active lanes, scripts/dev/lds_atomic_lanes.hip), so lanes are mapped to
+//      (group, letter) pairs: one instruction adds the wave's sums (DPP reductions) to every group the wave shares, one adds
+//      the row-of-16 sums to the groups a row of 16 shares, and only what is left (sorted: the triple) takes one add per
+//      context and letter, into letter-major tables so that the 64 adds of an instruction spread over all banks.  (Round 1:
+//      28 + 8 atomic instructions per 64 contexts = 2.2 of its 3.85 ms; now 6.)
 //   C of tile t and A of tile t + 1 are one phase (a thread only touches its own row slots).
 // The context terms -D(A, n) come from the plan's histogram (A = u + 5 eps: softmax rows are normalised).
-// After the last tile the pair tables fold into d/d mat partials; a finalize kernel sums the blocks in fixed order.
+// After the last tile the group tables fold into d/d mat partials; a finalize kernel sums the blocks in fixed order.
 // Note: LDS floating-point atomics make the summation order inside a block run-dependent (last-bit jitter in
 // grad_mat); the ELBO and d/dh sums keep the fixed-order reduction of the other kernels.
 #pragma once
@@ -33,25 +36,29 @@
 #endif
 
 #define LIN_MAX_LAG 21
-// Letter groups: pairs over the leading letters, ONE triple over the last three (lag >= 3).  In a k-mer-sorted table the last
-// letters vary fastest: with them in a single group, the 64 consecutive contexts of a wave differ in that group only (plus,
-// now and then, the pair before it), so every other group takes one block-level add (see phase C).
+// Letter groups: pairs over the leading letters, ONE triple over the last three.  In a k-mer-sorted table the last letters
+// vary fastest: with them in a single group, the 64 consecutive contexts of a wave differ in that group only (plus, now and
+// then, the pair before it), so every other group takes one block-level add (see phase C).
+// Table rows hold four doubles: the logits relative to the fifth letter's (a softmax does not see the shift), 32-byte aligned.
 #define LIN_PAIR_COMBOS 36
 #define LIN_TRI_COMBOS 216
-#define LIN_PSTRIDE (LIN_PAIR_COMBOS * 5)
+#define LIN_PSTRIDE (LIN_PAIR_COMBOS * 4)
 #define LIN_MAX_PAIRS ((LIN_MAX_LAG - 3 + 1) / 2)
-#define LIN_TAB_DOUBLES (LIN_MAX_PAIRS * LIN_PSTRIDE + LIN_TRI_COMBOS * 5)
+#define LIN_MAX_GROUPS (LIN_MAX_PAIRS + 1)
+#define LIN_TAB_DOUBLES (LIN_MAX_PAIRS * LIN_PSTRIDE + LIN_TRI_COMBOS * 4)
+#define LIN_GT_PLANE (LIN_TAB_DOUBLES / 4)   // rows of all group tables
 #define LIN_MAX_GRAD (LIN_MAX_LAG * 25)
 
 struct lin_buf {
   __attribute__((aligned(16))) unsigned long long codes[PLN_RMAX + 2];
   __attribute__((aligned(16))) unsigned char blk[PLN_BLOCK_MAX];
+  __attribute__((aligned(16))) uint16_t live[PLN_LIVE_STRIDE];   // the plan's list of contexts with counts: [0] = how many, then rows
 };
 struct pln_lds_lin {
   double pri[PLN_RMAX * 5 + 2];  // [PLN_SENTINEL] = 1.0
   lin_buf buf[2];
-  double T[LIN_TAB_DOUBLES];     // [pair g][a * 6 + a'][b] ... | [triple][(a * 6 + a') * 6 + a''][b]
-  double GT[LIN_TAB_DOUBLES];
+  __attribute__((aligned(32))) double T[LIN_TAB_DOUBLES];   // [pair g][a * 6 + a'][b < 4] ... | [triple][(a * 6 + a') * 6 + a''][b < 4]
+  double GT[LIN_TAB_DOUBLES];   // gradient tables, letter-major: [b < 4][row]: the 64 adds of a wave (one letter, 64 rows) spread over all banks
   double2 logtab[BEAR_LOGTAB_N];
   double tabD[SRT_NKEY];
   double tabP[SRT_NKEY];
@@ -60,17 +67,19 @@ struct pln_lds_lin {
 };
 static_assert(sizeof(pln_lds_lin) <= 160 * 1024, "linear-head kernel: LDS budget");
 
-// group geometry of a lag: npair pair groups over letters [0, 2 npair) (the last pair may hold one letter), then the triple
+// group geometry of a lag: npair pair groups over the letters before the triple (the last pair holds one letter when their
+// number is odd), then the triple over letters [tri, tri + 3) (positions >= lag hold the "unknown" letter: they add nothing)
 struct lin_geom {
-  int lag, npair, tri, ng;   // tri: first letter of the triple (-1: none); ng = npair + (tri >= 0)
+  int lag, npair, tri, ng;   // ng = npair + 1
+  uint32_t last_pair_mask;   // 7: the last pair holds one letter; 63: two
 };
 __host__ __device__ inline lin_geom lin_make_geom(int lag) {
   lin_geom G;
   G.lag = lag;
-  G.tri = lag >= 3 ? lag - 3 : -1;
-  const int lead = lag >= 3 ? lag - 3 : lag;
-  G.npair = (lead + 1) / 2;
-  G.ng = G.npair + (G.tri >= 0 ? 1 : 0);
+  G.tri = lag >= 3 ? lag - 3 : 0;
+  G.npair = (G.tri + 1) / 2;
+  G.ng = G.npair + 1;
+  G.last_pair_mask = (G.tri & 1) ? 7u : 63u;
   return G;
 }
 
@@ -105,32 +114,83 @@ __global__ void encode_kmers_kernel(const uint8_t *__restrict__ ascii, uint64_t 
   }
 }
 
-// table offset (in doubles, letter b = 0) of group g's row for a context: pairs first, the triple last
-__device__ __forceinline__ uint32_t lin_row_off(unsigned long long code, int g, const lin_geom &G) {
-  if (g < G.npair) {
-    uint32_t field = (uint32_t)(code >> (6 * g)) & 63u;
-    if (2 * g + 1 >= (G.tri >= 0 ? G.tri : G.lag)) field &= 7u;   // a pair of one letter: its partner belongs to the triple
-    return (uint32_t)g * LIN_PSTRIDE + ((field & 7u) * 6u + (field >> 3)) * 5u;
+// ---- group indices of a context.  The linear head does not read packed letters (3 bits each, bear_pack_kmers_u64) but one
+// word of table-row indices per context, built once per batch by bear_linear_index_u64: pair g at bits [6 g, 6 g + 6)
+// (a * 6 + a' < 36), the triple behind the pairs at bits [6 npair, 6 npair + 8) (< 216).  In the kernel the number of groups
+// NG = npair + 1 is a template parameter: every shift is a constant and the table reads of a context issue back to back.
+__host__ __device__ inline unsigned long long lin_index_word(unsigned long long raw, const lin_geom &G) {
+  unsigned long long cv = 0ull;
+  for (int g = 0; g < G.npair; ++g) {
+    uint32_t field = (uint32_t)(raw >> (6 * g)) & 63u;
+    if (g == G.npair - 1) field &= G.last_pair_mask;   // a pair of one letter: its partner belongs to the triple
+    cv |= (unsigned long long)((field & 7u) * 6u + (field >> 3)) << (6 * g);
   }
-  const uint32_t f9 = (uint32_t)(code >> (3 * G.tri)) & 511u;
-  return (uint32_t)G.npair * LIN_PSTRIDE + (((f9 & 7u) * 6u + ((f9 >> 3) & 7u)) * 6u + (f9 >> 6)) * 5u;
+  const uint32_t f9 = (uint32_t)(raw >> (3 * G.tri)) & 511u;
+  cv |= (unsigned long long)((f9 & 7u) * 36u + ((f9 >> 3) & 7u) * 6u + (f9 >> 6)) << (6 * G.npair);
+  return cv;
+}
+__global__ void linear_index_kernel(const unsigned long long *__restrict__ raw, uint64_t n, int lag, unsigned long long *__restrict__ out) {
+  const lin_geom G = lin_make_geom(lag);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    out[i] = lin_index_word(raw[i], G);
+}
+// offset (in doubles) of group g's table row; g a constant after unrolling
+template <int NG>
+__device__ __forceinline__ uint32_t lin_off(unsigned long long cv, int g) {
+  const uint32_t idx = (uint32_t)(cv >> (6 * g)) & (g == NG - 1 ? 255u : 63u);
+  return (uint32_t)g * LIN_PSTRIDE + idx * 4u;
+}
+// the same for a per-lane group number
+__device__ __forceinline__ uint32_t lin_off_any(unsigned long long cv, uint32_t g, uint32_t ng) {
+  const uint32_t idx = (uint32_t)(cv >> (6u * g)) & (g == ng - 1u ? 255u : 63u);
+  return g * LIN_PSTRIDE + idx * 4u;
 }
 
-// softmax row of one context from the group tables
-__device__ __forceinline__ void lin_row(const double *T, const double *exptab, unsigned long long code, const lin_geom &G, double (&f)[5]) {
-  double z[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int g = 0; g < G.ng; ++g) {
-    const double *t = T + lin_row_off(code, g, G);
+// exp(d ln2 / 128) for d <= 0: the tables hold logits in units of ln2 / 128, so the argument reduction of bear_exp_tab is a
+// rounding and an exact subtraction; 2^(j/128) from the table, degree-5 polynomial on |r| <= 1/2 unit, v_ldexp for the rest.
+#define LIN_EXP_UNIT 184.66496523378731    // 128 / ln 2
+__device__ __forceinline__ double lin_exp_units(double d, const double *__restrict__ tab) {
+  const double kf = __builtin_rint(d), r = d - kf;
+  const int ki = (int)kf;
+  const double t = tab[ki & (BEAR_EXPTAB_N - 1)];
+  constexpr double c1 = 0.0054152123481245727, c2 = c1 * c1 / 2.0, c3 = c1 * c1 * c1 / 6.0, c4 = c1 * c1 * c1 * c1 / 24.0,
+                   c5 = c1 * c1 * c1 * c1 * c1 / 120.0;
+  double p = __builtin_fma(r, c5, c4);
+  p = __builtin_fma(r, p, c3);
+  p = __builtin_fma(r, p, c2);
+  p = __builtin_fma(r, p, c1);
+  return __builtin_ldexp(__builtin_fma(t, r * p, t), ki >> 7);
+}
+
+// softmax row of one context from the group tables (the fifth logit is the zero the tables are relative to)
+template <int NG>
+__device__ __forceinline__ void lin_row(const double *T, const double *exptab, unsigned long long cv, double (&f)[5]) {
+  double z[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int CH = 4;   // table rows in flight (registers: 8 per row)
 #pragma unroll
-    for (int b = 0; b < 5; ++b) z[b] += t[b];
+  for (int g0 = 0; g0 < NG; g0 += CH) {
+    double2 lo[CH], hi[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      if (g0 + j < NG) {
+        const double2 *t = reinterpret_cast<const double2 *>(T + lin_off<NG>(cv, g0 + j));
+        lo[j] = t[0];
+        hi[j] = t[1];
+      }
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      if (g0 + j < NG) {
+        z[0] += lo[j].x;
+        z[1] += lo[j].y;
+        z[2] += hi[j].x;
+        z[3] += hi[j].y;
+      }
   }
-  double m = z[0];
-#pragma unroll
-  for (int b = 1; b < 5; ++b) m = z[b] > m ? z[b] : m;
+  const double m = __builtin_fmax(__builtin_fmax(__builtin_fmax(z[0], z[1]), __builtin_fmax(z[2], z[3])), 0.0);
   double s = 0.0;
 #pragma unroll
   for (int b = 0; b < 5; ++b) {
-    f[b] = bear_exp_tab(z[b] - m, exptab);
+    f[b] = lin_exp_units(__builtin_fmax((b < 4 ? z[b] : 0.0) - m, -700.0 * LIN_EXP_UNIT), exptab);
     s += f[b];
   }
   const double r = bear_rcp(s);
@@ -168,6 +228,160 @@ __device__ __forceinline__ double lin_wave_sum(double row_sum) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q >> 32), 63);
   return __longlong_as_double(((long long)hi << 32) | lo);
 }
+__device__ __forceinline__ unsigned long long lin_first_lane(unsigned long long v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+constexpr int LIN_RPT = (PLN_RMAX + PLN_THREADS - 1) / PLN_THREADS;   // contexts of a tile per thread
+
+// ---- phase A over the tile's live contexts (entry tid + 1024 k of the plan's list): softmax rows into LDS and into fA (kept
+// until phase C of the same tile).  Contexts without counts are never looked at: nothing reads their rows.
+template <int NG>
+__device__ __forceinline__ void lin_phase_a(pln_lds_lin &S, const lin_buf &B, uint32_t n_live, uint32_t tid, double (&fA)[LIN_RPT][5]) {
+#pragma unroll
+  for (int k = 0; k < LIN_RPT; ++k) {
+    const uint32_t j = tid + PLN_THREADS * k;
+    if (j < n_live) {
+      const uint32_t row = B.live[1 + j];
+      lin_row<NG>(S.T, S.exptab, B.codes[row], fA[k]);
+#pragma unroll
+      for (int b = 0; b < 5; ++b) S.pri[row * 5 + b] = fA[k][b];
+    }
+  }
+}
+
+// ---- phase C for the thread's rows: g_b = w_b - f_b s into the gradient tables, whole waves at a time.
+// One LDS fp64 atomic wave-instruction costs ~20 clocks of CU time whatever the number of active lanes (measured,
+// scripts/dev/lds_atomic_lanes.hip), so what counts is the number of INSTRUCTIONS: lanes are mapped to (group, letter) pairs
+//   1. all groups whose row the whole wave shares: lane 4 g + b adds the wave's sum of g_b              (one instruction)
+//   2. up to four groups that a lane's row of 16 shares: lane (slot, b) of each row adds the row's sum   (one instruction)
+//   3. what is left (in a sorted table: the triple of the last letters): one add per context and letter (four per group)
+template <int NG>
+__device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, const lin_buf &B, uint32_t n_live, uint32_t tid, uint32_t lane_in,
+                                            const double (&fA)[LIN_RPT][5], double (&acc)[2]) {
+  uint32_t lane = lane_in;
+#ifdef LIN_SKIP_C
+  return;
+#endif
+#pragma unroll
+  for (int k = 0; k < LIN_RPT; ++k) {
+    const uint32_t j0 = (tid & ~63u) + PLN_THREADS * k;      // first of this wave's 64 consecutive list entries
+    if (j0 >= n_live) continue;                              // wave-uniform
+    // keep LLVM from hoisting every lane-derived value of the ten NG variants out of the tile loop (that spilled 30 registers)
+    asm volatile("" : "+v"(lane));
+    const bool live = j0 + lane < n_live;
+    const uint32_t row = live ? (uint32_t)B.live[1 + j0 + lane] : 0u;   // the tile's buffers are still in place (refilled after this phase)
+    const unsigned long long code = B.codes[row];
+    double g[4] = {0.0, 0.0, 0.0, 0.0};
+    if (live) {
+      double w[5], sw = 0.0;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const double v = S.pri[row * 5 + b];
+        w[b] = v < 0.0 ? -v : 0.0;          // cells an item has marked hold -w; the others still hold f_b >= 0
+        sw += w[b];
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) g[b] = __builtin_fma(-fA[k][b], sw, w[b]);
+    }
+    const bool nz = (g[0] != 0.0) | (g[1] != 0.0) | (g[2] != 0.0) | (g[3] != 0.0);
+    if (__builtin_amdgcn_ballot_w64(nz) == 0ull) continue;   // no item in these 64 contexts
+    // entries beyond the list end take the indices of the wave's first context: they add nothing and never break a run
+    const unsigned long long cv0 = lin_first_lane(code), cv = live ? code : cv0, diff = cv ^ cv0;
+    double th[4], tw[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      th[b] = lin_row16_sum(lin_quad_sum(g[b]));
+      tw[b] = lin_wave_sum(th[b]);
+    }
+    // which groups does the whole wave share, which does my row of 16 share
+    uint32_t wave_uniform = 0u, row_uniform = 0u;           // bit g; wave_uniform is wave-uniform, row_uniform per lane
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+      const uint32_t d = (uint32_t)(diff >> (6 * gq)) & (gq == NG - 1 ? 255u : 63u);
+      if (__builtin_amdgcn_ballot_w64(d != 0u) == 0ull) {
+        wave_uniform |= 1u << gq;
+        continue;
+      }
+      const uint32_t d16 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x140, 0xf, 0xf, false);   // row_mirror: lane 15 - i
+      const uint32_t d8 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x141, 0xf, 0xf, false);    // row_half_mirror: lane 7 - i
+      const uint32_t d1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+      const uint32_t d2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+      // a row of 16 agrees iff every lane equals its mirror images at all four levels
+      const unsigned long long bad = __builtin_amdgcn_ballot_w64(d != d16 || d != d8 || d != d1 || d != d2);
+      if (((bad >> (lane & ~15u)) & 0xffffull) == 0ull) row_uniform |= 1u << gq;
+    }
+#if LIN_DBG == 1
+    acc[1] += tw[0] * 1e-300 + th[1] * 1e-300 + (double)row_uniform * 1e-300;
+    continue;
+#endif
+    // 1. the groups the whole wave shares
+    {
+      const uint32_t gq = lane >> 2, b = lane & 3u;
+      if (gq < (uint32_t)NG && ((wave_uniform >> gq) & 1u)) {
+        const double v = b == 0 ? tw[0] : b == 1 ? tw[1] : b == 2 ? tw[2] : tw[3];
+        if (v != 0.0) atomicAdd(&S.GT[b * LIN_GT_PLANE + (lin_off_any(cv0, gq, NG) >> 2)], v);
+      }
+    }
+#if LIN_DBG == 2
+    continue;
+#endif
+    if (wave_uniform == (1u << NG) - 1u) continue;
+    // 2. groups a row of 16 shares (the wave does not): slot s of a row takes the s-th such group of that row
+    uint32_t done = row_uniform;                              // per lane: groups added at row level
+    if (__builtin_amdgcn_ballot_w64(row_uniform != 0u)) {
+      const uint32_t slot = (lane & 15u) >> 2, b = lane & 3u;
+      uint32_t pick = 0xffffffffu, m = row_uniform;
+      for (uint32_t s2 = 0; s2 <= slot; ++s2) {              // the slot-th set bit of the row's mask (same for all its lanes)
+        pick = m ? (uint32_t)__builtin_ctz(m) : 0xffffffffu;
+        m &= m - 1u;
+      }
+      if (pick != 0xffffffffu) {
+        const double v = b == 0 ? th[0] : b == 1 ? th[1] : b == 2 ? th[2] : th[3];
+        if (v != 0.0) atomicAdd(&S.GT[b * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], v);
+      }
+      // groups beyond the fourth of a row (unsorted tables only) stay for step 3
+      uint32_t m2 = row_uniform;
+      done = 0u;
+      for (int s2 = 0; s2 < 4 && m2; ++s2) {
+        done |= m2 & (0u - m2);
+        m2 &= m2 - 1u;
+      }
+    }
+#if LIN_DBG == 4
+    continue;
+#endif
+    // 3. one add per context and letter for every group not covered above
+#pragma unroll
+    for (int gq = 0; gq < NG; ++gq) {
+      if ((wave_uniform >> gq) & 1u) continue;               // wave-uniform test
+      const bool mine = !((done >> gq) & 1u) && nz;
+      if (!__builtin_amdgcn_ballot_w64(mine)) continue;
+      if (mine) {
+        double *gt = &S.GT[lin_off<NG>(cv, gq) >> 2];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) atomicAdd(&gt[b * LIN_GT_PLANE], g[b]);
+      }
+    }
+  }
+}
+
+// compile-time group count from the run-time one
+#define LIN_FOR_NG(ng, CALL)                   \
+  switch (ng) {                                \
+    case 1: { constexpr int NG = 1; CALL; } break;   \
+    case 2: { constexpr int NG = 2; CALL; } break;   \
+    case 3: { constexpr int NG = 3; CALL; } break;   \
+    case 4: { constexpr int NG = 4; CALL; } break;   \
+    case 5: { constexpr int NG = 5; CALL; } break;   \
+    case 6: { constexpr int NG = 6; CALL; } break;   \
+    case 7: { constexpr int NG = 7; CALL; } break;   \
+    case 8: { constexpr int NG = 8; CALL; } break;   \
+    case 9: { constexpr int NG = 9; CALL; } break;   \
+    default: { constexpr int NG = LIN_MAX_GROUPS; CALL; } break; \
+  }
+static_assert(LIN_MAX_GROUPS == 10, "LIN_FOR_NG lists the group counts");
 
 template <bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_kernel(
@@ -180,7 +394,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
   const lin_geom G = lin_make_geom(lag);
-  const int ng = G.ng, n_tab = G.npair * LIN_PSTRIDE + (G.tri >= 0 ? LIN_TRI_COMBOS * 5 : 0);
+  const int ng = G.ng, n_tab = G.npair * LIN_PSTRIDE + LIN_TRI_COMBOS * 4;
   double acc[2] = {0.0, 0.0};
 
   if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
@@ -195,28 +409,30 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     S.ticket[1] = 0;
   }
   if (tid < BEAR_EXPTAB_N) S.exptab[tid] = exp2((double)tid * (1.0 / BEAR_EXPTAB_N));
-  // group tables: a row is the sum of mat[l][a_l][:] over the group's letters (letter values 5 = unknown and positions beyond
-  // the group contribute nothing)
+  // group tables: a row is the sum of mat[l][a_l][b] - mat[l][a_l][4] over the group's letters, in units of ln2 / 128
+  // (lin_exp_units); letter value 5 = unknown and positions beyond the group or the lag contribute nothing
   for (int k = tid; k < n_tab; k += PLN_THREADS) {
     double v = 0.0;
+    auto letter = [&](int l, int a2, int b) {
+      if (a2 < 5 && l < lag) v += (mat[(l * 5 + a2) * 5 + b] - mat[(l * 5 + a2) * 5 + 4]) * LIN_EXP_UNIT;
+    };
     if (k < G.npair * LIN_PSTRIDE) {
-      const int g = k / LIN_PSTRIDE, r = k - g * LIN_PSTRIDE, combo = r / 5, b = r - combo * 5;
-      const int a0 = combo / 6, a1 = combo - a0 * 6, l0 = 2 * g, l1 = 2 * g + 1, lead = G.tri >= 0 ? G.tri : lag;
-      if (a0 < 5 && l0 < lead) v += mat[(l0 * 5 + a0) * 5 + b];
-      if (a1 < 5 && l1 < lead) v += mat[(l1 * 5 + a1) * 5 + b];
+      const int g = k / LIN_PSTRIDE, r = k - g * LIN_PSTRIDE, combo = r >> 2, b = r & 3;
+      const int a0 = combo / 6, a1 = combo - a0 * 6;
+      letter(2 * g, a0, b);
+      if (2 * g + 1 < G.tri) letter(2 * g + 1, a1, b);
     } else {
-      const int r = k - G.npair * LIN_PSTRIDE, combo = r / 5, b = r - combo * 5;
-      const int a0 = combo / 36, a1 = (combo / 6) % 6, a2 = combo % 6;
-      if (a0 < 5) v += mat[((G.tri + 0) * 5 + a0) * 5 + b];
-      if (a1 < 5) v += mat[((G.tri + 1) * 5 + a1) * 5 + b];
-      if (a2 < 5) v += mat[((G.tri + 2) * 5 + a2) * 5 + b];
+      const int r = k - G.npair * LIN_PSTRIDE, combo = r >> 2, b = r & 3;
+      letter(G.tri, combo / 36, b);
+      letter(G.tri + 1, (combo / 6) % 6, b);
+      letter(G.tri + 2, combo % 6, b);
     }
     S.T[k] = v;
-    S.GT[k] = 0.0;
   }
+  for (int k = tid; k < LIN_TAB_DOUBLES; k += PLN_THREADS) S.GT[k] = 0.0;
   __syncthreads();
 
-  auto stage = [&](const pln_tile &ti, uint32_t b) {
+  auto stage = [&](const pln_tile &ti, uint64_t tile, uint32_t b) {
     const uint32_t rows = ti.rows_items >> 16;
     if (rows == 0) return;
     const uint32_t cbytes = rows * 8u;
@@ -228,144 +444,25 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
       if (tid == 0) S.buf[b].codes[rows - 1] = v;
     }
     pln_dma(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, ti.blk16 * 16u, wave, lane, (cbytes + 1023u) >> 10);
+    pln_dma(S.buf[b].live, pv.live + tile * PLN_LIVE_STRIDE, ((rows + 1u) * 2u + 15u) & ~15u, wave, lane, 7);
   };
 
-  // ---- phase A for the thread's rows of a tile: softmax rows into LDS and into fA (kept until phase C of the same tile)
-  constexpr int RPT = (PLN_RMAX + PLN_THREADS - 1) / PLN_THREADS;
-  double fA[RPT][5];
-  unsigned long long cA[RPT];
+  double fA[LIN_RPT][5];
+  uint32_t n_live = 0;   // of the tile whose phase A ran last
   auto phase_a = [&](const lin_buf &B, uint32_t rows) {
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      const uint32_t row = tid + PLN_THREADS * k;
-      cA[k] = 0ull;
-      if (row < rows) {
-        cA[k] = B.codes[row];
-        lin_row(S.T, S.exptab, cA[k], G, fA[k]);
-#pragma unroll
-        for (int b = 0; b < 5; ++b) S.pri[row * 5 + b] = fA[k][b];
-      }
-    }
+    n_live = rows ? srt_uniform((uint32_t)B.live[0]) : 0u;
+    LIN_FOR_NG(ng, lin_phase_a<NG>(S, B, n_live, tid, fA))
   };
-  // ---- phase C for the thread's rows: g_b = w_b - f_b s into the gradient tables, whole waves at a time.
-  // One LDS fp64 atomic wave-instruction costs ~20 clocks of CU time whatever the number of active lanes (measured,
-  // scripts/dev/lds_atomic_lanes.hip), so what counts is the number of INSTRUCTIONS: lanes are mapped to (group, letter) pairs
-  //   1. all groups whose row the whole wave shares: lane 4 g + b adds the wave's sum of g_b              (one instruction)
-  //   2. up to four groups that a lane's row of 16 shares: lane (slot, b) of each row adds the row's sum   (one instruction)
-  //   3. what is left (in a sorted table: the triple of the last letters): one add per context and letter (four per group)
-  auto phase_c = [&](uint32_t rows) {
-#ifdef LIN_SKIP_C
-    return;
-#endif
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      const uint32_t row0w = (tid & ~63u) + PLN_THREADS * k;   // first row of this wave's 64 consecutive rows
-      if (row0w >= rows) continue;                             // wave-uniform
-      const uint32_t row = row0w + lane;
-      const bool live = row < rows;
-      double g[4] = {0.0, 0.0, 0.0, 0.0};
-      if (live) {
-        double w[5], sw = 0.0;
-#pragma unroll
-        for (int b = 0; b < 5; ++b) {
-          const double v = S.pri[row * 5 + b];
-          w[b] = v < 0.0 ? -v : 0.0;          // cells an item has marked hold -w; the others still hold f_b >= 0
-          sw += w[b];
-        }
-#pragma unroll
-        for (int b = 0; b < 4; ++b) g[b] = __builtin_fma(-fA[k][b], sw, w[b]);
-      }
-      const bool nz = (g[0] != 0.0) | (g[1] != 0.0) | (g[2] != 0.0) | (g[3] != 0.0);
-      if (__builtin_amdgcn_ballot_w64(nz) == 0ull) continue;   // no item in these 64 contexts
-      // rows beyond the tile end take the code of the wave's first context: they add nothing and never break a run
-      const uint32_t c0lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cA[k]);
-      const uint32_t c0hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cA[k] >> 32));
-      const unsigned long long code0 = ((unsigned long long)c0hi << 32) | c0lo, code = live ? cA[k] : code0;
-      double th[4], tw[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        th[b] = lin_row16_sum(lin_quad_sum(g[b]));
-        tw[b] = lin_wave_sum(th[b]);
-      }
-      // which groups does the whole wave share, which does my row of 16 share
-      uint32_t wave_uniform = 0u, row_uniform = 0u;           // bit g; wave_uniform is wave-uniform, row_uniform per lane
-      for (int gq = 0; gq < ng; ++gq) {
-        const uint32_t off = lin_row_off(code, gq, G);
-        const uint32_t o0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
-        if (__builtin_amdgcn_ballot_w64(off != o0) == 0ull) {
-          wave_uniform |= 1u << gq;
-          continue;
-        }
-        const uint32_t o16 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0x140, 0xf, 0xf, false);   // row_mirror: lane 15 - i
-        const uint32_t o8 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0x141, 0xf, 0xf, false);    // row_half_mirror: lane 7 - i
-        const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
-        const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)off, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
-        // a row of 16 agrees iff every lane equals its mirror images at all four levels
-        const unsigned long long bad = __builtin_amdgcn_ballot_w64(off != o16 || off != o8 || off != o1 || off != o2);
-        if (((bad >> (lane & ~15u)) & 0xffffull) == 0ull) row_uniform |= 1u << gq;
-      }
-#if LIN_DBG == 1
-      acc[1] += tw[0] * 1e-300 + th[1] * 1e-300 + (double)row_uniform * 1e-300;
-      continue;
-#endif
-      // 1. the groups the whole wave shares
-      {
-        const uint32_t gq = lane >> 2, b = lane & 3u;
-        if (gq < (uint32_t)ng && ((wave_uniform >> gq) & 1u)) {
-          const double v = b == 0 ? tw[0] : b == 1 ? tw[1] : b == 2 ? tw[2] : tw[3];
-          if (v != 0.0) atomicAdd(&S.GT[lin_row_off(code0, (int)gq, G) + b], v);
-        }
-      }
-#if LIN_DBG == 2
-      continue;
-#endif
-      // 2. groups a row of 16 shares (the wave does not): slot s of a row takes the s-th such group of that row
-      uint32_t rest = row_uniform;                              // per lane: groups still to be added at row level
-      const uint32_t not_wave = ~wave_uniform & ((1u << ng) - 1u);
-      if (__builtin_amdgcn_ballot_w64(rest != 0u)) {
-        const uint32_t slot = (lane & 15u) >> 2, b = lane & 3u;
-        uint32_t pick = 0xffffffffu, m = rest;
-        for (uint32_t s2 = 0; s2 <= slot; ++s2) {              // the slot-th set bit of the row's mask (same for all its lanes)
-          pick = m ? (uint32_t)__builtin_ctz(m) : 0xffffffffu;
-          m &= m - 1u;
-        }
-        if (pick != 0xffffffffu) {
-          const double v = b == 0 ? th[0] : b == 1 ? th[1] : b == 2 ? th[2] : th[3];
-          if (v != 0.0) atomicAdd(&S.GT[lin_row_off(code, (int)pick, G) + b], v);
-        }
-        // groups beyond the fourth of a row (unsorted tables only) stay for step 3
-        uint32_t done = 0u, m2 = rest;
-        for (int s2 = 0; s2 < 4 && m2; ++s2) {
-          done |= m2 & (0u - m2);
-          m2 &= m2 - 1u;
-        }
-        rest = done;
-      }
-#if LIN_DBG == 4
-      continue;
-#endif
-      // 3. one add per context and letter for every group not covered above
-      for (int gq = 0; gq < ng; ++gq) {
-        if (!((not_wave >> gq) & 1u)) continue;                 // wave-uniform test
-        const bool mine = !((rest >> gq) & 1u) && nz;
-        if (!__builtin_amdgcn_ballot_w64(mine)) continue;
-        if (mine) {
-          double *gt = &S.GT[lin_row_off(code, gq, G)];
-#pragma unroll
-          for (int b = 0; b < 4; ++b) atomicAdd(&gt[b], g[b]);
-        }
-      }
-    }
-  };
+  auto phase_c = [&](const lin_buf &B) { LIN_FOR_NG(ng, lin_phase_c<NG>(S, B, n_live, tid, lane, fA, acc)) };
 
   const uint64_t GR = gridDim.x;
   pln_tile cur = pln_load_tile(pv, blockIdx.x), nxt = pln_load_tile(pv, blockIdx.x + GR);
-  stage(cur, 0);
+  stage(cur, blockIdx.x, 0);
   srt_wait_dma();
   srt_sync();
   phase_a(S.buf[0], cur.rows_items >> 16);
   srt_sync();
-  stage(nxt, 1);
+  stage(nxt, blockIdx.x + GR, 1);
   uint32_t slot = 0;
   for (uint64_t t = blockIdx.x; t < pv.n_tiles; t += GR) {
     const lin_buf &B = S.buf[slot];
@@ -430,12 +527,12 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     srt_wait_dma();  // the next tile's codes and plan block (issued one phase ago)
     srt_sync();      // ... and every item of this tile has left its mark
     // ---- C of this tile, A of the next: a thread only touches its own row slots
-    phase_c(rows);
+    phase_c(B);
     phase_a(S.buf[slot ^ 1u], nxt.rows_items >> 16);
     srt_sync();      // nobody reads this tile's codes any more: its slot may be refilled
     cur = nxt;
     nxt = pln_load_tile(pv, t + 2 * GR);
-    stage(nxt, slot);
+    stage(nxt, t + 2 * GR, slot);
     slot ^= 1u;
   }
   srt_wait_dma();
@@ -446,9 +543,10 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     const pln_heavy_col h = pv.heavy_col[i];
     const uint64_t row = h.off / 5u;
     const uint32_t b = (uint32_t)(h.off - row * 5u);
-    const unsigned long long code = kmer_code[row];
+    unsigned long long cv = 0ull;
     double f[5];
-    lin_row(S.T, S.exptab, code, G, f);
+    cv = kmer_code[row];
+    LIN_FOR_NG(ng, lin_row<NG>(S.T, S.exptab, cv, f))
     double q;
     if (AR) {
       const double pp = f[b] + eps;
@@ -463,9 +561,9 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     }
     const double w = f[b] * q;
     for (int g = 0; g < ng; ++g) {
-      double *gt = &S.GT[lin_row_off(code, g, G)];
+      double *gt = &S.GT[lin_off_any(cv, (uint32_t)g, (uint32_t)ng) >> 2];
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb) atomicAdd(&gt[bb], (bb == (int)b ? w : 0.0) - f[bb] * w);
+      for (int bb = 0; bb < 4; ++bb) atomicAdd(&gt[bb * LIN_GT_PLANE], (bb == (int)b ? w : 0.0) - f[bb] * w);
     }
   }
   for (uint64_t i = gtid; !AR && i < pv.n_heavy_row; i += gsz) {
@@ -484,18 +582,19 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   for (int k = tid; k < lag * 25; k += PLN_THREADS) {
     const int l = k / 25, r = k - l * 25, a = r / 5, b = r - a * 5;
     double s = 0.0;
-    auto add = [&](const double *gt) { s += b < 4 ? gt[b] : -((gt[0] + gt[1]) + (gt[2] + gt[3])); };
-    if (G.tri >= 0 && l >= G.tri) {
-      const int pos = l - G.tri;
-      const double *base = &S.GT[G.npair * LIN_PSTRIDE];
+    auto add = [&](int row) {
+      const double *gt = &S.GT[row];
+      s += b < 4 ? gt[b * LIN_GT_PLANE] : -((gt[0] + gt[LIN_GT_PLANE]) + (gt[2 * LIN_GT_PLANE] + gt[3 * LIN_GT_PLANE]));
+    };
+    if (l >= G.tri) {
+      const int pos = l - G.tri, base = G.npair * LIN_PAIR_COMBOS;
       for (int p = 0; p < 36; ++p) {
         const int p0 = p / 6, p1 = p % 6;
-        const int combo = pos == 0 ? (a * 6 + p0) * 6 + p1 : pos == 1 ? (p0 * 6 + a) * 6 + p1 : (p0 * 6 + p1) * 6 + a;
-        add(base + combo * 5);
+        add(base + (pos == 0 ? (a * 6 + p0) * 6 + p1 : pos == 1 ? (p0 * 6 + a) * 6 + p1 : (p0 * 6 + p1) * 6 + a));
       }
     } else {
       const int g = l >> 1;
-      for (int p = 0; p < 6; ++p) add(&S.GT[g * LIN_PSTRIDE + ((l & 1) ? p * 6 + a : a * 6 + p) * 5]);
+      for (int p = 0; p < 6; ++p) add(g * LIN_PAIR_COMBOS + ((l & 1) ? p * 6 + a : a * 6 + p));
     }
     grad_partials[(size_t)blockIdx.x * LIN_MAX_GRAD + k] = s;
   }

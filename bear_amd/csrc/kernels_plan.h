@@ -38,6 +38,7 @@
 #endif
 #define PLN_HCAP 128                          // large-count items / contexts evaluated inside a tile (rest: global lists)
 #define PLN_QUAD 4                            // tiles start on multiples of 4 contexts (16-byte aligned rows)
+#define PLN_LIVE_STRIDE (PLN_RMAX + 8)        // uint16 per tile of the live-context lists (a multiple of 8: 16-byte rows)
 #define PLN_SENTINEL (PLN_RMAX * 5)           // flat offset of the neutral cell (prior = 1 / ref row = 0)
 #ifndef PLN_NBUF
 #define PLN_NBUF 2                            // LDS ring depth: tiles in flight = PLN_NBUF - 1
@@ -259,6 +260,42 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
 // ---------------------------------------------------------------------------------------------
 // per-step evaluation
 // ---------------------------------------------------------------------------------------------
+// Per tile, the contexts that hold any count (nrow != 0), ascending, behind their number: kernels whose per-context work is
+// heavy (the linear head's softmax and its backward) run over this list instead of over all rows of the tile.
+__global__ __launch_bounds__(1024) void plan_live_kernel(const pln_tile *__restrict__ tiles, uint64_t n_tiles,
+                                                         const unsigned char *__restrict__ stream, uint16_t *__restrict__ live) {
+  constexpr int RPT = (PLN_RMAX + 1023) / 1024;
+  __shared__ uint32_t cnt[RPT * 16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const pln_tile ti = tiles[t];
+    const uint32_t rows = ti.rows_items >> 16;
+    const uint8_t *nrow = stream + (size_t)ti.off16 * 16 + 64;
+    uint16_t *out = live + t * PLN_LIVE_STRIDE;
+    unsigned long long mask[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const uint32_t lr = tid + 1024u * k;
+      mask[k] = __builtin_amdgcn_ballot_w64(lr < rows && nrow[lr] != 0);
+      if (lane == 0) cnt[k * 16 + wave] = (uint32_t)__builtin_popcountll(mask[k]);
+    }
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      uint32_t base = total;
+      for (int w = 0; w < 16; ++w) {
+        const uint32_t c = cnt[k * 16 + w];
+        if (w < (int)wave) base += c;
+        total += c;
+      }
+      if ((mask[k] >> lane) & 1ull) out[1 + base + (uint32_t)__builtin_popcountll(mask[k] & ((1ull << lane) - 1ull))] = (uint16_t)(tid + 1024u * k);
+    }
+    if (tid == 0) out[0] = (uint16_t)total;
+    __syncthreads();
+  }
+}
+
 struct pln_view {  // device-side view of a plan
   const pln_tile *tiles;
   const unsigned char *stream;
@@ -267,6 +304,7 @@ struct pln_view {  // device-side view of a plan
   const uint64_t *heavy_stop;
   const unsigned long long *hist;  // [0..31] contexts with total n = j+1, [32..63] with stop count j+1 (<= SRT_CL)
   uint64_t n_tiles, n_heavy_col, n_heavy_row, n_heavy_stop;
+  const uint16_t *live;            // [n_tiles][PLN_LIVE_STRIDE] (five-column plans): [0] = contexts with counts, then their rows, ascending
 };
 
 // DMA of `bytes` (multiple of 16) to LDS: 1 KiB pieces round-robin over the waves starting at wave

@@ -213,13 +213,27 @@ def pack_kmers(codes):
     return out
 
 
-def dm_linear(plan, kmer_code, mat, h_signed, eps=EPSILON, train_ar=False, out=None):
+def linear_index(kmer_code, lag):
+    """Packed contexts (``pack_kmers``) -> the table-row words the fused linear head reads (``bear_linear_index_u64``); once per
+    batch, the contexts do not change between steps."""
+    if not (kmer_code.is_cuda and kmer_code.dtype == torch.int64 and kmer_code.dim() == 1 and kmer_code.is_contiguous()):
+        raise ValueError("kmer_code must be a contiguous CUDA int64 tensor [n_rows] (pack_kmers)")
+    out = torch.empty_like(kmer_code)
+    with torch.cuda.device(kmer_code.device):
+        st = _lib.lib().bear_linear_index_u64(_ptr(kmer_code), kmer_code.shape[0], int(lag), _ptr(out), _stream())
+    _lib.check(st, "bear_linear_index_u64")
+    return out
+
+
+def dm_linear(plan, kmer_index, mat, h_signed, eps=EPSILON, train_ar=False, out=None):
     """One launch of ``bear_dm_linear_f64``: the bear_net step with the linear AR function fused on the plan.
+    ``kmer_index`` = ``linear_index(pack_kmers(codes), lag)``.
     Returns (out[2] = {sum LL, d/dh_signed}, grad_mat [lag,5,5] = d sum LL / d mat)."""
     n = plan.counts.shape[0]
+    kmer_code = kmer_index
     if not (kmer_code.is_cuda and kmer_code.dtype == torch.int64 and kmer_code.dim() == 1 and kmer_code.is_contiguous()
             and kmer_code.shape[0] == n):
-        raise ValueError("kmer_code must be a contiguous CUDA int64 tensor [n_rows] (pack_kmers)")
+        raise ValueError("kmer_index must be a contiguous CUDA int64 tensor [n_rows] (linear_index)")
     if kmer_code.data_ptr() % 16:
         kmer_code = kmer_code.clone()
     if not (mat.is_cuda and mat.dtype == torch.float64 and mat.dim() == 3 and mat.shape[1:] == (5, 5) and mat.is_contiguous()):
@@ -548,7 +562,7 @@ def _check_linear_step(plan, kmer_code, lag, theta, packed):
     _f64_vec(packed, 2 + lag * 25, "packed")
     if not (kmer_code.is_cuda and kmer_code.dtype == torch.int64 and kmer_code.is_contiguous() and kmer_code.shape == (n,)
             and kmer_code.data_ptr() % 16 == 0):
-        raise ValueError("kmer_code must be a contiguous, 16-byte aligned CUDA int64 tensor [n_rows] (pack_kmers)")
+        raise ValueError("kmer_index must be a contiguous, 16-byte aligned CUDA int64 tensor [n_rows] (linear_index)")
     return n
 
 

@@ -173,11 +173,21 @@ def main():
         extra["net_multinomial_mode"] = {"kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3)}
         lag = 13
         mat = 0.05 * torch.randn(lag, 5, 5, dtype=torch.float64, device=dev, generator=torch.Generator(dev).manual_seed(10))
-        packed = kernels.pack_kmers(torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev,
-                                                  generator=torch.Generator(dev).manual_seed(SEED)))
+        codes = torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev, generator=torch.Generator(dev).manual_seed(SEED))
+        packed = kernels.linear_index(kernels.pack_kmers(codes), lag)
+        ms_shuffled = timed(lambda: kernels.dm_linear(plans["net"], packed, mat, h_s), 5)
+        # bear_net.train sorts the rows of a batch by k-mer at upload; the synthetic counts are independent of the contexts, so
+        # sorting the contexts alone gives the same kind of table in that order
+        key = torch.zeros(n, dtype=torch.int64, device=dev)
+        for l in range(lag):
+            key = key * 6 + codes[:, l].to(torch.int64)
+        packed = kernels.linear_index(kernels.pack_kmers(codes[torch.argsort(key)].contiguous()), lag)
+        del key, codes
         ms = timed(lambda: kernels.dm_linear(plans["net"], packed, mat, h_s), 5)
         extra["linear_head_fused_step"] = {"lag": lag, "kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3),
-                                           "note": "forward + ELBO + d/dh + d/dmat from 8-byte packed k-mers"}
+                                           "kernel_ms_rows_in_random_order": ms_shuffled,
+                                           "note": "forward + ELBO + d/dh + d/dmat from 8-byte context words, rows in k-mer order "
+                                                   "(as bear_net.train uploads a batch)"}
         # BASELINE configs[4]: the convolutional AR function, forward + DM step with gradient rows + backward
         from bear_amd import ar_funcs
         fw = 8

@@ -165,7 +165,7 @@ int bear_train_apply_f64(double *theta, int n_theta, const double *packed, doubl
                          double learning_rate, double scale, int train_ar, double *loss_buf, uint64_t loss_cap, void *stream);
 int bear_ref_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
                               const double *theta, double eps, int train_ar, double *packed, void *stream);
-int bear_net_linear_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, int lag,
+int bear_net_linear_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_index, int lag,
                                      uint64_t n_rows, const double *theta, double eps, int train_ar, double *packed, void *stream);
 int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, int num_filters, int layer1_width);
 int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,
@@ -175,7 +175,7 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
 int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
                             double *theta, double *adam_m, double *adam_v, double *adam_t, double eps, int train_ar,
                             double learning_rate, double scale, double *out, double *loss_buf, uint64_t loss_cap, void *stream);
-int bear_net_linear_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, int lag,
+int bear_net_linear_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_index, int lag,
                                    uint64_t n_rows, double *theta, double *adam_m, double *adam_v, double *adam_t, double *packed,
                                    double eps, int train_ar, double learning_rate, double scale, double *loss_buf,
                                    uint64_t loss_cap, void *stream);
@@ -193,16 +193,24 @@ int bear_net_cnn_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32
  *                                     symbol '[', 5 = any other character (all-zero one-hot row, core.py:173);
  *                                     positions >= lag hold 5.  bear_pack_kmers_u64 builds it from the int8
  *                                     code matrix [n_rows, lag] (values outside 0..4 -> 5).  lag <= 21.
+ *   kmer_index [dev] uint64 [n_rows]  what the linear-head entry points read: the same contexts as row numbers of the
+ *                                     kernel's letter-group tables (pairs of letters in 6-bit fields, the last three
+ *                                     letters in an 8-bit field behind them), built ONCE per batch from kmer_code by
+ *                                     bear_linear_index_u64 (the contexts of a batch do not change between steps).
+ *                                     16-byte aligned.  Fastest when the rows of the batch are sorted by k-mer (first
+ *                                     letter most significant; the sums do not depend on the order): consecutive
+ *                                     contexts then share their leading groups and the backward pass adds once per wave.
  *   mat       [dev] double [lag,5,5]  the AR parameter
  *   out       [dev] double [2]        { sum LL, d sum LL / d h_signed }
  *   grad_mat  [dev] double [lag,5,5]  d sum LL / d mat (overwritten)
  * Reads 8 bytes per context plus the plan; writes nothing per context.
  */
 int bear_pack_kmers_u64(const int8_t *codes, uint64_t n_rows, int lag, uint64_t *packed, void *stream);
+int bear_linear_index_u64(const uint64_t *kmer_code, uint64_t n_rows, int lag, uint64_t *kmer_index, void *stream);
 /* ASCII k-mer bytes as parsed from the count file [dev] uint8 [n_rows, lag] -> int8 letter codes [dev] [n_rows, lag]:
  * 0..3 = A, C, G, T (U when rna != 0), 4 = '[', -1 = anything else (the all-zero one-hot row of core.py:173). */
 int bear_encode_kmers_i8(const uint8_t *ascii, uint64_t n_rows, int lag, int rna, int8_t *codes, void *stream);
-int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code,
+int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_index,
                        const double *mat, int lag, uint64_t n_rows, double h_signed, double eps, int train_ar,
                        double *out, double *grad_mat, void *stream);
 

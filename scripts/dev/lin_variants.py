@@ -12,7 +12,7 @@ key = torch.zeros(N, dtype=torch.int64, device=dev)
 for l in range(LAG):
     key = key * 6 + codes[:, l].to(torch.int64)
 order = torch.argsort(key); del key
-tr_s = t["train"][order].contiguous(); packed_s = kernels.pack_kmers(codes[order].contiguous()); del order
+tr_s = t["train"][order].contiguous(); packed_s = kernels.linear_index(kernels.pack_kmers(codes[order].contiguous()), LAG); del order
 plan_s = kernels.Plan(tr_s, 5)
 fn = lambda: kernels.dm_linear(plan_s, packed_s, mat.detach(), 0.0)
 fn(); torch.cuda.synchronize()

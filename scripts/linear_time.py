@@ -24,7 +24,7 @@ def timed(fn, reps=5):
     return best
 
 
-packed = kernels.pack_kmers(codes)
+packed = kernels.linear_index(kernels.pack_kmers(codes), LAG)
 plan = kernels.Plan(t["train"], 5)
 ref_out, ref_g = kernels.dm_linear(plan, packed, mat.detach(), 0.0)
 for ar in (False, True):
@@ -37,7 +37,7 @@ for l in range(LAG):
 order = torch.argsort(key)
 del key
 tr_s = t["train"][order].contiguous()
-packed_s = kernels.pack_kmers(codes[order].contiguous())
+packed_s = kernels.linear_index(kernels.pack_kmers(codes[order].contiguous()), LAG)
 del order
 plan_s = kernels.Plan(tr_s, 5)
 out_s, g_s = kernels.dm_linear(plan_s, packed_s, mat.detach(), 0.0)

@@ -392,7 +392,7 @@ def test_fused_linear_head_parity(case, lag, dev, ysd1):
     mat = rng.normal(size=(lag, 5, 5)) * 0.4
     d_tr = _to_dev(tr, dev)
     plan = kernels.Plan(d_tr, 5)
-    packed = kernels.pack_kmers(torch.from_numpy(codes).to(dev))
+    packed = kernels.linear_index(kernels.pack_kmers(torch.from_numpy(codes).to(dev)), lag)
     d_mat = torch.from_numpy(mat).to(dev)
     for h_s, ar in [(0.0, False), (-2.5, False), (1.5, False), (0.3, True)]:
         want, wantg = _linear_oracle(tr, codes, mat, h_s, ar)
