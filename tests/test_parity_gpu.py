@@ -403,6 +403,54 @@ def test_fused_linear_head_parity(case, lag, dev, ysd1):
         assert np.allclose(g, wantg, rtol=1e-9, atol=1e-9 * np.abs(wantg).max()), (case, lag, h_s, ar, np.abs(g - wantg).max())
 
 
+def test_fused_linear_head_full_size(dev):
+    """BASELINE configs[2] at size (1e7 contexts, lag 13, bear_dm_linear_f64): the sums of a k-mer-sorted table equal those of
+    the same rows in random order; a table's sums are the sums of its two halves (each with its own plan); every
+    d/d mat[l][a][:] sums to zero over the output letter (softmax backward); a sampled chunk equals the oracle chain."""
+    import torch
+    from bear_amd import kernels
+    N, lag = 10_000_019, 13
+    t = kernels.synth_counts(20211012, 0, N, dev, want=("train",))["train"]
+    gen = torch.Generator(dev).manual_seed(77)
+    codes = torch.randint(0, 4, (N, lag), dtype=torch.int8, device=dev, generator=gen)
+    codes[torch.rand(N, lag, device=dev, generator=gen) < 0.01] = 4      # start symbol
+    codes[torch.rand(N, lag, device=dev, generator=gen) < 0.005] = -1    # unknown letter
+    mat = (0.3 * torch.randn(lag, 5, 5, dtype=torch.float64, device=dev, generator=gen)).contiguous()
+
+    def step(tr, cd, h_s=-0.4, ar=False):
+        out, g = kernels.dm_linear(kernels.Plan(tr, 5), kernels.linear_index(kernels.pack_kmers(cd), lag), mat, h_s, train_ar=ar)
+        return out.cpu().numpy(), g.cpu().numpy()
+
+    out_r, g_r = step(t, codes)
+    key = torch.zeros(N, dtype=torch.int64, device=dev)
+    for l in range(lag):
+        c = codes[:, l].to(torch.int64)
+        key = key * 6 + torch.where(c >= 0, c, torch.full_like(c, 5))
+    order = torch.argsort(key)
+    del key
+    ts, cs = t[order].contiguous(), codes[order].contiguous()
+    del order
+    scale = np.abs(g_r).max()
+    for ar in (False, True):
+        o_r, gg_r = (out_r, g_r) if not ar else step(t, codes, ar=True)
+        o_s, gg_s = step(ts, cs, ar=ar)
+        assert np.allclose(o_s, o_r, rtol=1e-11), (ar, o_s, o_r)
+        assert np.allclose(gg_s, gg_r, rtol=0, atol=1e-10 * np.abs(gg_r).max())
+        assert np.abs(gg_s.sum(-1)).max() <= 1e-9 * np.abs(gg_r).max()
+    cut = 5_000_007
+    o_a, g_a = step(ts[:cut].clone(), cs[:cut].clone())
+    o_b, g_b = step(ts[cut:].clone(), cs[cut:].clone())
+    o_s, g_s = step(ts, cs)
+    assert np.allclose(o_a + o_b, o_s, rtol=1e-11)
+    assert np.allclose(g_a + g_b, g_s, rtol=0, atol=1e-10 * scale)
+    lo, hi = 6_000_001, 6_020_001
+    tr_c, cd_c = ts[lo:hi].clone(), cs[lo:hi].clone()
+    got, g = step(tr_c, cd_c, h_s=0.2)
+    want, wantg = _linear_oracle(tr_c.cpu().numpy().view(np.uint32), cd_c.cpu().numpy(), mat.cpu().numpy(), 0.2, False)
+    _close(got[0], want[0], ELBO_RTOL)
+    assert np.allclose(g, wantg, rtol=1e-9, atol=1e-9 * np.abs(wantg).max())
+
+
 def test_planned_full_size_chunks(dev):
     """Bench-scale table: planned == unplanned on the whole table; planned on sampled chunks ==
     oracle; a plan refuses a different buffer."""
