@@ -207,26 +207,37 @@ __device__ __forceinline__ double lin_dpp(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(q >> 32), CTRL, ROW_MASK, 0xf, false);
   return __longlong_as_double(((long long)hi << 32) | (uint32_t)lo);
 }
-// every lane gets the sum over its aligned quad / its row of 16
-__device__ __forceinline__ double lin_quad_sum(double v) {
-  v += lin_dpp<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
-  v += lin_dpp<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
-  return v;
+// Sums of the four gradient letters over quads, rows of 16 and the wave, TRANSPOSED: lane i ends up with the sums of ONE letter,
+// lin_letter(i) -- which is how the block-level adds want them (lane <-> (group, letter)).  A quad exchanges two letters, then
+// one (the other lane of a pair keeps the other half), and from there every level is one add: 33 instructions instead of the
+// 80 of four separate butterflies.
+__device__ __forceinline__ uint32_t lin_letter(uint32_t lane) { return ((lane & 1u) << 1) | ((lane >> 1) & 1u); }
+__device__ __forceinline__ double lin_quad_letter_sum(const double (&g)[4], uint32_t lane) {
+  const bool o1 = lane & 1u, o2 = lane & 2u;
+  double k0 = o1 ? g[2] : g[0], k1 = o1 ? g[3] : g[1];
+  k0 += lin_dpp<0xB1, 0xf>(o1 ? g[0] : g[2]);   // quad_perm [1,0,3,2]: the pair's sums of letters 2 o1, 2 o1 + 1
+  k1 += lin_dpp<0xB1, 0xf>(o1 ? g[1] : g[3]);
+  return (o2 ? k1 : k0) + lin_dpp<0x4E, 0xf>(o2 ? k0 : k1);   // quad_perm [2,3,0,1]
 }
 __device__ __forceinline__ double lin_row16_sum(double quad_sum) {
   double v = quad_sum;
-  v += lin_dpp<0x141, 0xf>(v);   // row_half_mirror: the other quad pair of the half row (all four lanes of a quad agree)
-  v += lin_dpp<0x140, 0xf>(v);   // row_mirror: the other half row
+  v += lin_dpp<0x124, 0xf>(v);   // row_ror:4: the same letter of the next quad
+  v += lin_dpp<0x128, 0xf>(v);   // row_ror:8
   return v;
 }
-// wave total from the row sums, as a wave-uniform value
+// v_permlane16_swap / v_permlane32_swap (gfx950) of a value with itself: every lane gets the value of the same lane of the
+// neighbouring row of 16 / of the other half of the wave in the second result
 __device__ __forceinline__ double lin_wave_sum(double row_sum) {
   double v = row_sum;
-  v += lin_dpp<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-  v += lin_dpp<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3: lane 63 holds the total
-  const long long q = __double_as_longlong(v);
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q >> 32), 63);
-  return __longlong_as_double(((long long)hi << 32) | lo);
+#pragma unroll
+  for (int step = 0; step < 2; ++step) {
+    const long long q = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
+    const auto a = step == 0 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false) : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto c = step == 0 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false) : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __longlong_as_double(((long long)c[0] << 32) | a[0]) + __longlong_as_double(((long long)c[1] << 32) | a[1]);
+  }
+  return v;
 }
 __device__ __forceinline__ unsigned long long lin_first_lane(unsigned long long v) {
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
@@ -289,12 +300,8 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, const lin_buf &B, ui
     if (__builtin_amdgcn_ballot_w64(nz) == 0ull) continue;   // no item in these 64 contexts
     // entries beyond the list end take the indices of the wave's first context: they add nothing and never break a run
     const unsigned long long cv0 = lin_first_lane(code), cv = live ? code : cv0, diff = cv ^ cv0;
-    double th[4], tw[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      th[b] = lin_row16_sum(lin_quad_sum(g[b]));
-      tw[b] = lin_wave_sum(th[b]);
-    }
+    const double th = lin_row16_sum(lin_quad_letter_sum(g, lane)), tw = lin_wave_sum(th);   // of letter lin_letter(lane)
+    const uint32_t bl = lin_letter(lane);
     // which groups does the whole wave share, which does my row of 16 share
     uint32_t wave_uniform = 0u, row_uniform = 0u;           // bit g; wave_uniform is wave-uniform, row_uniform per lane
 #pragma unroll
@@ -313,16 +320,13 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, const lin_buf &B, ui
       if (((bad >> (lane & ~15u)) & 0xffffull) == 0ull) row_uniform |= 1u << gq;
     }
 #if LIN_DBG == 1
-    acc[1] += tw[0] * 1e-300 + th[1] * 1e-300 + (double)row_uniform * 1e-300;
+    acc[1] += tw * 1e-300 + th * 1e-300 + (double)row_uniform * 1e-300;
     continue;
 #endif
     // 1. the groups the whole wave shares
     {
-      const uint32_t gq = lane >> 2, b = lane & 3u;
-      if (gq < (uint32_t)NG && ((wave_uniform >> gq) & 1u)) {
-        const double v = b == 0 ? tw[0] : b == 1 ? tw[1] : b == 2 ? tw[2] : tw[3];
-        if (v != 0.0) atomicAdd(&S.GT[b * LIN_GT_PLANE + (lin_off_any(cv0, gq, NG) >> 2)], v);
-      }
+      const uint32_t gq = lane >> 2;
+      if (gq < (uint32_t)NG && ((wave_uniform >> gq) & 1u) && tw != 0.0) atomicAdd(&S.GT[bl * LIN_GT_PLANE + (lin_off_any(cv0, gq, NG) >> 2)], tw);
     }
 #if LIN_DBG == 2
     continue;
@@ -331,16 +335,13 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, const lin_buf &B, ui
     // 2. groups a row of 16 shares (the wave does not): slot s of a row takes the s-th such group of that row
     uint32_t done = row_uniform;                              // per lane: groups added at row level
     if (__builtin_amdgcn_ballot_w64(row_uniform != 0u)) {
-      const uint32_t slot = (lane & 15u) >> 2, b = lane & 3u;
+      const uint32_t slot = (lane & 15u) >> 2;
       uint32_t pick = 0xffffffffu, m = row_uniform;
       for (uint32_t s2 = 0; s2 <= slot; ++s2) {              // the slot-th set bit of the row's mask (same for all its lanes)
         pick = m ? (uint32_t)__builtin_ctz(m) : 0xffffffffu;
         m &= m - 1u;
       }
-      if (pick != 0xffffffffu) {
-        const double v = b == 0 ? th[0] : b == 1 ? th[1] : b == 2 ? th[2] : th[3];
-        if (v != 0.0) atomicAdd(&S.GT[b * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], v);
-      }
+      if (pick != 0xffffffffu && th != 0.0) atomicAdd(&S.GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
       // groups beyond the fourth of a row (unsorted tables only) stay for step 3
       uint32_t m2 = row_uniform;
       done = 0u;
@@ -451,6 +452,9 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   uint32_t n_live = 0;   // of the tile whose phase A ran last
   auto phase_a = [&](const lin_buf &B, uint32_t rows) {
     n_live = rows ? srt_uniform((uint32_t)B.live[0]) : 0u;
+#ifdef LIN_SKIP_A
+    return;
+#endif
     LIN_FOR_NG(ng, lin_phase_a<NG>(S, B, n_live, tid, fA))
   };
   auto phase_c = [&](const lin_buf &B) { LIN_FOR_NG(ng, lin_phase_c<NG>(S, B, n_live, tid, lane, fA, acc)) };
