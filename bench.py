@@ -174,7 +174,8 @@ def main():
         lag = 13
         mat = 0.05 * torch.randn(lag, 5, 5, dtype=torch.float64, device=dev, generator=torch.Generator(dev).manual_seed(10))
         codes = torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev, generator=torch.Generator(dev).manual_seed(SEED))
-        packed = kernels.linear_index(kernels.pack_kmers(codes), lag)
+        packed_raw = kernels.pack_kmers(codes)          # 3 bits per letter: what the convolutional head reads
+        packed = kernels.linear_index(packed_raw, lag)   # table-row words: what the linear head reads
         ms_shuffled = timed(lambda: kernels.dm_linear(plans["net"], packed, mat, h_s), 5)
         # bear_net.train sorts the rows of a batch by k-mer at upload; the synthetic counts are independent of the contexts, so
         # sorting the contexts alone gives the same kind of table in that order
@@ -184,6 +185,7 @@ def main():
         packed = kernels.linear_index(kernels.pack_kmers(codes[torch.argsort(key)].contiguous()), lag)
         del key, codes
         ms = timed(lambda: kernels.dm_linear(plans["net"], packed, mat, h_s), 5)
+        del packed
         extra["linear_head_fused_step"] = {"lag": lag, "kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3),
                                            "kernel_ms_rows_in_random_order": ms_shuffled,
                                            "note": "forward + ELBO + d/dh + d/dmat from 8-byte context words, rows in k-mer order "
@@ -193,6 +195,7 @@ def main():
         fw = 8
         _, cnn_params = ar_funcs.make_ar_func_cnn(lag, 4, filter_width=fw, device=dev, generator=torch.Generator(dev).manual_seed(10))
         flat = torch.cat([q.detach().reshape(-1) for q in cnn_params]).contiguous()
+        packed = packed_raw
         f_ms = timed(lambda: kernels.cnn_forward(packed, flat, lag, fw), 3)
         pr_c, t1_c = kernels.cnn_forward(packed, flat, lag, fw)
         _, g_c = kernels.dm_prior_planned(plans["net"], pr_c, h_s, want_grad=True)
@@ -200,7 +203,7 @@ def main():
         extra["cnn_head"] = {"lag": lag, "filter_width": fw, "forward_ms": f_ms, "backward_ms": b_ms,
                              "step_contexts_per_s": n / ((f_ms + b_ms + extra["net_with_gradient_rows"]["kernel_ms"]) * 1e-3),
                              "note": "bear_cnn_forward_f64 + planned DM kernel with gradient rows + bear_cnn_backward_f64"}
-        del packed, pr_c, t1_c, g_c
+        del packed, packed_raw, pr_c, t1_c, g_c
         m = min(n, 20_000_000)
         test = kernels.synth_counts(SEED, row0, m, dev, want=("test",))["test"]
         tr_m, pr_m = t["train"][:m], prior[:m]
