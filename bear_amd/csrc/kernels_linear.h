@@ -64,6 +64,7 @@ struct pln_lds_lin {
   double tabP[SRT_NKEY];
   double exptab[BEAR_EXPTAB_N];
   uint32_t ticket[2];
+  uint32_t c_done;               // += 1 by every wave that has read its rows back in phase C (see the tile loop)
 };
 static_assert(sizeof(pln_lds_lin) <= 160 * 1024, "linear-head kernel: LDS budget");
 
@@ -246,16 +247,32 @@ __device__ __forceinline__ unsigned long long lin_first_lane(unsigned long long 
 
 constexpr int LIN_RPT = (PLN_RMAX + PLN_THREADS - 1) / PLN_THREADS;   // contexts of a tile per thread
 
-// ---- phase A over the tile's live contexts (entry tid + 1024 k of the plan's list): softmax rows into LDS and into fA (kept
-// until phase C of the same tile).  Contexts without counts are never looked at: nothing reads their rows.
+// ---- phase A over the tile's live contexts (entry tid + 1024 k of the plan's list): softmax rows into fA (kept until phase C
+// of the same tile) and, by lin_phase_a_store, into LDS for the items.  Contexts without counts are never looked at: nothing
+// reads their rows.  The two halves are separate because a thread's rows differ from tile to tile: the LDS rows may only be
+// overwritten once EVERY wave has read its rows of the previous tile back (phase C) -- the computation does not have to wait.
 template <int NG>
-__device__ __forceinline__ void lin_phase_a(pln_lds_lin &S, const lin_buf &B, uint32_t n_live, uint32_t tid, double (&fA)[LIN_RPT][5]) {
+__device__ __forceinline__ uint32_t lin_phase_a(pln_lds_lin &S, const lin_buf &B, uint32_t n_live, uint32_t tid_in, double (&fA)[LIN_RPT][5]) {
+  static_assert(LIN_RPT == 2 && PLN_RMAX < 0xffff, "two 16-bit row numbers in one register");
+  uint32_t rows = 0xffffffffu;     // 0xffff: no row
+  uint32_t tid = tid_in;
+  asm volatile("" : "+v"(tid));    // as in phase C: nothing derived from the thread number is worth a register across the tile loop
 #pragma unroll
   for (int k = 0; k < LIN_RPT; ++k) {
     const uint32_t j = tid + PLN_THREADS * k;
     if (j < n_live) {
       const uint32_t row = B.live[1 + j];
+      rows = k == 0 ? (rows & 0xffff0000u) | row : (rows & 0xffffu) | (row << 16);
       lin_row<NG>(S.T, S.exptab, B.codes[row], fA[k]);
+    }
+  }
+  return rows;
+}
+__device__ __forceinline__ void lin_phase_a_store(pln_lds_lin &S, const double (&fA)[LIN_RPT][5], uint32_t rows) {
+#pragma unroll
+  for (int k = 0; k < LIN_RPT; ++k) {
+    const uint32_t row = (rows >> (16 * k)) & 0xffffu;
+    if (row != 0xffffu) {
 #pragma unroll
       for (int b = 0; b < 5; ++b) S.pri[row * 5 + b] = fA[k][b];
     }
@@ -284,71 +301,81 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, const lin_buf &B, ui
     const bool live = j0 + lane < n_live;
     const uint32_t row = live ? (uint32_t)B.live[1 + j0 + lane] : 0u;   // the tile's buffers are still in place (refilled after this phase)
     const unsigned long long code = B.codes[row];
-    double g[4] = {0.0, 0.0, 0.0, 0.0};
+    double g[4] = {0.0, 0.0, 0.0, 0.0}, sw = 0.0;
     if (live) {
-      double w[5], sw = 0.0;
+      double w[5];
 #pragma unroll
       for (int b = 0; b < 5; ++b) {
         const double v = S.pri[row * 5 + b];
-        w[b] = v < 0.0 ? -v : 0.0;          // cells an item has marked hold -w; the others still hold f_b >= 0
+        w[b] = __builtin_fmax(-v, 0.0);     // cells an item has marked hold -w; the others still hold f_b >= 0
         sw += w[b];
       }
 #pragma unroll
       for (int b = 0; b < 4; ++b) g[b] = __builtin_fma(-fA[k][b], sw, w[b]);
     }
-    const bool nz = (g[0] != 0.0) | (g[1] != 0.0) | (g[2] != 0.0) | (g[3] != 0.0);
+    const bool nz = sw > 0.0;              // the context holds an item (w >= 0)
     if (__builtin_amdgcn_ballot_w64(nz) == 0ull) continue;   // no item in these 64 contexts
-    // entries beyond the list end take the indices of the wave's first context: they add nothing and never break a run
-    const unsigned long long cv0 = lin_first_lane(code), cv = live ? code : cv0, diff = cv ^ cv0;
+    // entries beyond the list end repeat its last context: they add nothing and never break a run
+    const uint32_t last = n_live - j0 < 64u ? n_live - j0 - 1u : 63u;   // wave-uniform
+    unsigned long long cv = code;
+    if (last != 63u) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)code, (int)last), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(code >> 32), (int)last);
+      if (!live) cv = ((unsigned long long)hi << 32) | lo;
+    }
     const double th = lin_row16_sum(lin_quad_letter_sum(g, lane)), tw = lin_wave_sum(th);   // of letter lin_letter(lane)
     const uint32_t bl = lin_letter(lane);
-    // which groups does the whole wave share, which does my row of 16 share
-    uint32_t wave_uniform = 0u, row_uniform = 0u;           // bit g; wave_uniform is wave-uniform, row_uniform per lane
-#pragma unroll
-    for (int gq = 0; gq < NG; ++gq) {
-      const uint32_t d = (uint32_t)(diff >> (6 * gq)) & (gq == NG - 1 ? 255u : 63u);
-      if (__builtin_amdgcn_ballot_w64(d != 0u) == 0ull) {
-        wave_uniform |= 1u << gq;
-        continue;
-      }
-      const uint32_t d16 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x140, 0xf, 0xf, false);   // row_mirror: lane 15 - i
-      const uint32_t d8 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x141, 0xf, 0xf, false);    // row_half_mirror: lane 7 - i
-      const uint32_t d1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
-      const uint32_t d2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
-      // a row of 16 agrees iff every lane equals its mirror images at all four levels
-      const unsigned long long bad = __builtin_amdgcn_ballot_w64(d != d16 || d != d8 || d != d1 || d != d2);
-      if (((bad >> (lane & ~15u)) & 0xffffull) == 0ull) row_uniform |= 1u << gq;
+    // How many LEADING groups does my row of 16 share (l_row), how many the whole wave (l_wave)?  In a sorted table the shared
+    // groups are the leading ones; anything else is merely handled one level lower than it could be.  e = my index word xor my
+    // predecessor's (wave_ror:1); a row shares the groups below the lowest set bit of the OR of e over its lanes 1..15, the
+    // wave those below the lowest set bit of the OR over all lanes (lane 0's e = word 0 xor word 63 is the xor of all the
+    // others: it cannot lower that bit).
+    const uint32_t clo = (uint32_t)cv, chi = (uint32_t)(cv >> 32);
+    const uint32_t elo = clo ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clo, 0x13C, 0xf, 0xf, false);
+    const uint32_t ehi = chi ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)chi, 0x13C, 0xf, 0xf, false);
+    const bool row_first = (lane & 15u) == 0u;
+    uint32_t rlo = row_first ? 0u : elo, rhi = row_first ? 0u : ehi;
+    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x121, 0xf, 0xf, false);   // row_ror:1, 2, 4, 8: OR over the row in every lane
+    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x121, 0xf, 0xf, false);
+    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x122, 0xf, 0xf, false);
+    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x122, 0xf, 0xf, false);
+    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x124, 0xf, 0xf, false);
+    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x124, 0xf, 0xf, false);
+    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x128, 0xf, 0xf, false);
+    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x128, 0xf, 0xf, false);
+    uint32_t wlo = rlo | elo, whi = rhi | ehi;                     // lanes 0, 16, 32, 48 carry the steps between rows
+    {
+      auto a = __builtin_amdgcn_permlane16_swap(wlo, wlo, false, false);
+      auto c = __builtin_amdgcn_permlane16_swap(whi, whi, false, false);
+      wlo = a[0] | a[1];
+      whi = c[0] | c[1];
+      a = __builtin_amdgcn_permlane32_swap(wlo, wlo, false, false);
+      c = __builtin_amdgcn_permlane32_swap(whi, whi, false, false);
+      wlo = a[0] | a[1];
+      whi = c[0] | c[1];
     }
+    const unsigned long long wave_or = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)whi) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)wlo);
+    const unsigned long long row_or = ((unsigned long long)rhi << 32) | rlo;
+    // group of bit position p: p / 6 (the last group is wider: clamp); 43 / 256 ~ 1 / 6 is exact for p < 64
+    const uint32_t l_wave = wave_or ? min((uint32_t)(__builtin_ctzll(wave_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG;
+    const uint32_t l_row = row_or ? min((uint32_t)(__builtin_ctzll(row_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG;   // >= l_wave
 #if LIN_DBG == 1
-    acc[1] += tw * 1e-300 + th * 1e-300 + (double)row_uniform * 1e-300;
+    acc[1] += tw * 1e-300 + th * 1e-300 + (double)l_row * 1e-300;
     continue;
 #endif
     // 1. the groups the whole wave shares
     {
       const uint32_t gq = lane >> 2;
-      if (gq < (uint32_t)NG && ((wave_uniform >> gq) & 1u) && tw != 0.0) atomicAdd(&S.GT[bl * LIN_GT_PLANE + (lin_off_any(cv0, gq, NG) >> 2)], tw);
+      if (gq < l_wave && tw != 0.0) atomicAdd(&S.GT[bl * LIN_GT_PLANE + (lin_off_any(cv, gq, NG) >> 2)], tw);
     }
 #if LIN_DBG == 2
     continue;
 #endif
-    if (wave_uniform == (1u << NG) - 1u) continue;
-    // 2. groups a row of 16 shares (the wave does not): slot s of a row takes the s-th such group of that row
-    uint32_t done = row_uniform;                              // per lane: groups added at row level
-    if (__builtin_amdgcn_ballot_w64(row_uniform != 0u)) {
-      const uint32_t slot = (lane & 15u) >> 2;
-      uint32_t pick = 0xffffffffu, m = row_uniform;
-      for (uint32_t s2 = 0; s2 <= slot; ++s2) {              // the slot-th set bit of the row's mask (same for all its lanes)
-        pick = m ? (uint32_t)__builtin_ctz(m) : 0xffffffffu;
-        m &= m - 1u;
-      }
-      if (pick != 0xffffffffu && th != 0.0) atomicAdd(&S.GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
-      // groups beyond the fourth of a row (unsorted tables only) stay for step 3
-      uint32_t m2 = row_uniform;
-      done = 0u;
-      for (int s2 = 0; s2 < 4 && m2; ++s2) {
-        done |= m2 & (0u - m2);
-        m2 &= m2 - 1u;
-      }
+    if (l_wave == (uint32_t)NG) continue;
+    // 2. the next (up to four) groups, shared by a row of 16: slot s of the row takes group l_wave + s
+    {
+      const uint32_t pick = l_wave + ((lane & 15u) >> 2);
+      if (pick < l_row && th != 0.0) atomicAdd(&S.GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
     }
 #if LIN_DBG == 4
     continue;
@@ -356,8 +383,8 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, const lin_buf &B, ui
     // 3. one add per context and letter for every group not covered above
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) {
-      if ((wave_uniform >> gq) & 1u) continue;               // wave-uniform test
-      const bool mine = !((done >> gq) & 1u) && nz;
+      if ((uint32_t)gq < l_wave) continue;                   // wave-uniform test
+      const bool mine = nz && ((uint32_t)gq >= l_row || (uint32_t)gq >= l_wave + 4u);
       if (!__builtin_amdgcn_ballot_w64(mine)) continue;
       if (mine) {
         double *gt = &S.GT[lin_off<NG>(cv, gq) >> 2];
@@ -408,6 +435,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     S.pri[PLN_SENTINEL] = 1.0;
     S.ticket[0] = 0;
     S.ticket[1] = 0;
+    S.c_done = 0;
   }
   if (tid < BEAR_EXPTAB_N) S.exptab[tid] = exp2((double)tid * (1.0 / BEAR_EXPTAB_N));
   // group tables: a row is the sum of mat[l][a_l][b] - mat[l][a_l][4] over the group's letters, in units of ln2 / 128
@@ -436,6 +464,8 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   auto stage = [&](const pln_tile &ti, uint64_t tile, uint32_t b) {
     const uint32_t rows = ti.rows_items >> 16;
     if (rows == 0) return;
+    uint32_t lane = tid & 63u;
+    asm volatile("" : "+v"(lane));   // no lane-derived addresses kept (and spilled) across the tile loop
     const uint32_t cbytes = rows * 8u;
     pln_dma(S.buf[b].codes, kmer_code + ti.row0, cbytes & ~15u, wave, lane, 0);
     if (cbytes & 15u) {  // odd row count: trailing word through the scalar path (see dm_prior_plan_kernel)
@@ -450,12 +480,14 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
 
   double fA[LIN_RPT][5];
   uint32_t n_live = 0;   // of the tile whose phase A ran last
+  uint32_t rowA = 0xffffffffu;
   auto phase_a = [&](const lin_buf &B, uint32_t rows) {
     n_live = rows ? srt_uniform((uint32_t)B.live[0]) : 0u;
+    rowA = 0xffffffffu;
 #ifdef LIN_SKIP_A
     return;
 #endif
-    LIN_FOR_NG(ng, lin_phase_a<NG>(S, B, n_live, tid, fA))
+    LIN_FOR_NG(ng, rowA = lin_phase_a<NG>(S, B, n_live, tid, fA))
   };
   auto phase_c = [&](const lin_buf &B) { LIN_FOR_NG(ng, lin_phase_c<NG>(S, B, n_live, tid, lane, fA, acc)) };
 
@@ -465,9 +497,10 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   srt_wait_dma();
   srt_sync();
   phase_a(S.buf[0], cur.rows_items >> 16);
+  lin_phase_a_store(S, fA, rowA);
   srt_sync();
   stage(nxt, blockIdx.x + GR, 1);
-  uint32_t slot = 0;
+  uint32_t slot = 0, c_target = 0;
   for (uint64_t t = blockIdx.x; t < pv.n_tiles; t += GR) {
     const lin_buf &B = S.buf[slot];
     const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
@@ -532,7 +565,12 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     srt_sync();      // ... and every item of this tile has left its mark
     // ---- C of this tile, A of the next: a thread only touches its own row slots
     phase_c(B);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of this tile's LDS rows have returned
+    if (lane == 0) atomicAdd(&S.c_done, 1u);
+    c_target += PLN_WAVES;
     phase_a(S.buf[slot ^ 1u], nxt.rows_items >> 16);
+    while (pln_peek(&S.c_done) < c_target) __builtin_amdgcn_s_sleep(1);   // every wave has: the rows may be overwritten
+    lin_phase_a_store(S, fA, rowA);
     srt_sync();      // nobody reads this tile's codes any more: its slot may be refilled
     cur = nxt;
     nxt = pln_load_tile(pv, t + 2 * GR);

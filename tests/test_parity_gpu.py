@@ -437,6 +437,14 @@ def test_fused_linear_head_full_size(dev):
         assert np.allclose(o_s, o_r, rtol=1e-11), (ar, o_s, o_r)
         assert np.allclose(gg_s, gg_r, rtol=0, atol=1e-10 * np.abs(gg_r).max())
         assert np.abs(gg_s.sum(-1)).max() <= 1e-9 * np.abs(gg_r).max()
+    # launches of the same step agree to rounding (LDS atomics reorder sums; a race between the waves of a block -- rows of
+    # the next tile written before every wave has read the previous tile's back -- would show as a lost contribution)
+    plan_s, idx_s = kernels.Plan(ts, 5), kernels.linear_index(kernels.pack_kmers(cs), lag)
+    runs = [kernels.dm_linear(plan_s, idx_s, mat, -0.4) for _ in range(6)]
+    for out_k, g_k in runs[1:]:
+        assert torch.allclose(out_k, runs[0][0], rtol=1e-13, atol=0)
+        assert float((g_k - runs[0][1]).abs().max()) <= 1e-11 * scale
+    del plan_s, idx_s, runs
     cut = 5_000_007
     o_a, g_a = step(ts[:cut].clone(), cs[:cut].clone())
     o_b, g_b = step(ts[cut:].clone(), cs[cut:].clone())
