@@ -252,7 +252,8 @@ constexpr int LIN_RPT = (PLN_RMAX + PLN_THREADS - 1) / PLN_THREADS;   // context
 // reads their rows.  The two halves are separate because a thread's rows differ from tile to tile: the LDS rows may only be
 // overwritten once EVERY wave has read its rows of the previous tile back (phase C) -- the computation does not have to wait.
 template <int NG>
-__device__ __forceinline__ uint32_t lin_phase_a(pln_lds_lin &S, const lin_buf &B, uint32_t n_live, uint32_t tid_in, double (&fA)[LIN_RPT][5]) {
+__device__ __forceinline__ uint32_t lin_phase_a(pln_lds_lin &S, const lin_buf &B, uint32_t n_live, uint32_t tid_in, double (&fA)[LIN_RPT][5],
+                                                unsigned long long (&cA)[LIN_RPT]) {
   static_assert(LIN_RPT == 2 && PLN_RMAX < 0xffff, "two 16-bit row numbers in one register");
   uint32_t rows = 0xffffffffu;     // 0xffff: no row
   uint32_t tid = tid_in;
@@ -263,7 +264,8 @@ __device__ __forceinline__ uint32_t lin_phase_a(pln_lds_lin &S, const lin_buf &B
     if (j < n_live) {
       const uint32_t row = B.live[1 + j];
       rows = k == 0 ? (rows & 0xffff0000u) | row : (rows & 0xffffu) | (row << 16);
-      lin_row<NG>(S.T, S.exptab, B.codes[row], fA[k]);
+      cA[k] = B.codes[row];
+      lin_row<NG>(S.T, S.exptab, cA[k], fA[k]);
     }
   }
   return rows;
@@ -286,8 +288,8 @@ __device__ __forceinline__ void lin_phase_a_store(pln_lds_lin &S, const double (
 //   2. up to four groups that a lane's row of 16 shares: lane (slot, b) of each row adds the row's sum   (one instruction)
 //   3. what is left (in a sorted table: the triple of the last letters): one add per context and letter (four per group)
 template <int NG>
-__device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, const lin_buf &B, uint32_t n_live, uint32_t tid, uint32_t lane_in,
-                                            const double (&fA)[LIN_RPT][5], double (&acc)[2]) {
+__device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uint32_t tid, uint32_t lane_in, const double (&fA)[LIN_RPT][5],
+                                            const unsigned long long (&cA)[LIN_RPT], uint32_t rowA, double (&acc)[2]) {
   uint32_t lane = lane_in;
 #ifdef LIN_SKIP_C
   return;
@@ -299,8 +301,8 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, const lin_buf &B, ui
     // keep LLVM from hoisting every lane-derived value of the ten NG variants out of the tile loop (that spilled 30 registers)
     asm volatile("" : "+v"(lane));
     const bool live = j0 + lane < n_live;
-    const uint32_t row = live ? (uint32_t)B.live[1 + j0 + lane] : 0u;   // the tile's buffers are still in place (refilled after this phase)
-    const unsigned long long code = B.codes[row];
+    const uint32_t row = live ? (rowA >> (16 * k)) & 0xffffu : 0u;      // row and index word from phase A's registers: the tile's
+    const unsigned long long code = cA[k];                               // buffers are being refilled already
     double g[4] = {0.0, 0.0, 0.0, 0.0}, sw = 0.0;
     if (live) {
       double w[5];
@@ -479,6 +481,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   };
 
   double fA[LIN_RPT][5];
+  unsigned long long cA[LIN_RPT] = {0ull, 0ull};
   uint32_t n_live = 0;   // of the tile whose phase A ran last
   uint32_t rowA = 0xffffffffu;
   auto phase_a = [&](const lin_buf &B, uint32_t rows) {
@@ -487,9 +490,9 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
 #ifdef LIN_SKIP_A
     return;
 #endif
-    LIN_FOR_NG(ng, rowA = lin_phase_a<NG>(S, B, n_live, tid, fA))
+    LIN_FOR_NG(ng, rowA = lin_phase_a<NG>(S, B, n_live, tid, fA, cA))
   };
-  auto phase_c = [&](const lin_buf &B) { LIN_FOR_NG(ng, lin_phase_c<NG>(S, B, n_live, tid, lane, fA, acc)) };
+  auto phase_c = [&]() { LIN_FOR_NG(ng, lin_phase_c<NG>(S, n_live, tid, lane, fA, cA, rowA, acc)) };
 
   const uint64_t GR = gridDim.x;
   pln_tile cur = pln_load_tile(pv, blockIdx.x), nxt = pln_load_tile(pv, blockIdx.x + GR);
@@ -561,20 +564,20 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
       if (!AR) srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
       if (off != (uint32_t)PLN_SENTINEL) item(off, o[0].D, o[0].P, x[0], (double)ci[0]);
     }
-    srt_wait_dma();  // the next tile's codes and plan block (issued one phase ago)
-    srt_sync();      // ... and every item of this tile has left its mark
-    // ---- C of this tile, A of the next: a thread only touches its own row slots
-    phase_c(B);
+    srt_wait_dma();  // the next tile's codes and plan block (issued a whole iteration ago)
+    srt_sync();      // ... and every item of this tile has left its mark: nobody reads this tile's buffers any more
+    cur = nxt;
+    nxt = pln_load_tile(pv, t + 2 * GR);
+    stage(nxt, t + 2 * GR, slot);   // the tile after next lands while phases C, A and the next tile's B run
+    // ---- C of this tile (rows, index words and softmax rows from phase A's registers), A of the next
+    phase_c();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of this tile's LDS rows have returned
     if (lane == 0) atomicAdd(&S.c_done, 1u);
     c_target += PLN_WAVES;
-    phase_a(S.buf[slot ^ 1u], nxt.rows_items >> 16);
+    phase_a(S.buf[slot ^ 1u], cur.rows_items >> 16);
     while (pln_peek(&S.c_done) < c_target) __builtin_amdgcn_s_sleep(1);   // every wave has: the rows may be overwritten
     lin_phase_a_store(S, fA, rowA);
-    srt_sync();      // nobody reads this tile's codes any more: its slot may be refilled
-    cur = nxt;
-    nxt = pln_load_tile(pv, t + 2 * GR);
-    stage(nxt, t + 2 * GR, slot);
+    srt_sync();      // the next tile's rows are in place for its items
     slot ^= 1u;
   }
   srt_wait_dma();
