@@ -194,6 +194,68 @@ extern "C" int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint
   return BEAR_OK;
 }
 
+// ------------------------------------------------------------------ the sparse row format
+// `kmer; [[ds, col], ...]; [value, ...]` (bear_model/dataloader.py:52-109: CsvDataset with ';' + two decode_json calls +
+// SparseTensor -> to_dense).  One pass over the mapped text; rows land in the same planar layout as the dense reader's.
+extern "C" int bear_parse_sparse_counts(const char *path, int num_ds, int width, int lag, uint64_t skip_lines, uint64_t max_rows,
+                                        char *kmers, uint32_t *counts, uint64_t *n_rows_out) {
+  if (!path || !n_rows_out || num_ds < 1 || width < 1 || lag < 0 || (max_rows && (!counts || (lag && !kmers)))) return BEAR_ERR_INVALID_ARG;
+  *n_rows_out = 0;
+  mapped_file f;
+  int st = f.open_ro(path);
+  if (st != BEAR_OK) return st;
+  if (max_rows) memset(counts, 0, sizeof(uint32_t) * (size_t)num_ds * max_rows * (size_t)width);
+  const char *p = f.data, *end = f.data + f.size;
+  uint64_t row = 0, line_no = 0;
+  std::vector<long long> pos;
+  while (p < end && row < max_rows) {
+    const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+    const char *le = nl ? nl : end;
+    const char *q = p;
+    p = le + 1;
+    if (line_no++ < skip_lines || blank_line(q, le)) continue;
+    const char *s1 = static_cast<const char *>(memchr(q, ';', (size_t)(le - q)));
+    const char *s2 = s1 ? static_cast<const char *>(memchr(s1 + 1, ';', (size_t)(le - s1 - 1))) : nullptr;
+    if (!s2) return BEAR_ERR_PARSE;
+    const char *kb = q, *ke = s1;
+    while (kb < ke && (*kb == ' ' || *kb == '\t')) ++kb;
+    while (ke > kb && (ke[-1] == ' ' || ke[-1] == '\t' || ke[-1] == '\r')) --ke;
+    if ((int)(ke - kb) != lag) return BEAR_ERR_PARSE;
+    memcpy(kmers + row * (size_t)lag, kb, (size_t)lag);
+    pos.clear();
+    for (const char *c = s1 + 1; c < s2;) {      // the integers of the index list, in order
+      if ((*c >= '0' && *c <= '9') || *c == '-') {
+        char *stop = nullptr;
+        pos.push_back(strtoll(c, &stop, 10));
+        c = stop;
+      } else {
+        ++c;
+      }
+    }
+    if (pos.size() & 1) return BEAR_ERR_PARSE;
+    size_t k = 0;
+    for (const char *c = s2 + 1; c < le;) {      // one value per index pair (the reference decodes them as floats)
+      if ((*c >= '0' && *c <= '9') || *c == '-' || *c == '.') {
+        char *stop = nullptr;
+        const double v = strtod(c, &stop);
+        if (stop == c) return BEAR_ERR_PARSE;
+        c = stop;
+        if (2 * k + 1 >= pos.size()) return BEAR_ERR_PARSE;
+        const long long d = pos[2 * k], col = pos[2 * k + 1];
+        if (d < 0 || d >= num_ds || col < 0 || col >= width || !(v >= 0.0) || v > 4294967295.0 || v != (double)(uint32_t)v) return BEAR_ERR_PARSE;
+        counts[((size_t)d * max_rows + row) * (size_t)width + (size_t)col] = (uint32_t)v;
+        ++k;
+      } else {
+        ++c;
+      }
+    }
+    if (2 * k != pos.size()) return BEAR_ERR_PARSE;
+    ++row;
+  }
+  *n_rows_out = row;
+  return BEAR_OK;
+}
+
 // ------------------------------------------------------------------ one rank's rows of a row-sharded table
 // Training shards every batch over the ranks (bear_net.py:273 `experimental_distribute_dataset`): of batch k = global rows
 // [kB, min(kB + B, N)) with m rows, rank r owns the contiguous piece [lo, hi) with base = m / W, extra = m % W,

@@ -9,7 +9,6 @@ dataloader.py:35-46) into k-mer bytes and planar ``uint32 [num_ds, N, 5]`` slabs
 ``bear_net.train`` / ``bear_ref.train`` upload once and keep resident.
 """
 import ctypes
-import json
 import os
 
 import numpy as np
@@ -355,22 +354,23 @@ class _ShardPart:
 def sparse_dataloader(file, alphabet, batch_size, num_ds, cache=False, header=True, n_par=1, dtype=torch.float64):
     """dataloader.py:52-109: ``kmer; [[ds, col], ...]; [vals]`` rows with a header line."""
     A1 = len(core.alphabets_tf[alphabet])
-    kmers, rows = [], []
-    with open(file) as fh:
+    n_rows = count_rows(file, header)
+    lag = 0
+    with open(file, "rb") as fh:       # the k-mer length from the first data line
         if header:
             fh.readline()
         for line in fh:
-            if not line.strip():
-                continue
-            k, pos, vals = [s.strip() for s in line.rstrip("\n").split(";")]
-            dense = np.zeros((num_ds, A1), dtype=np.uint32)
-            for (d, c), v in zip(json.loads(pos), json.loads(vals)):
-                dense[d, c] = v
-            kmers.append(k.encode())
-            rows.append(dense)
-    lag = len(kmers[0]) if kmers else 0
-    km = np.frombuffer(b"".join(kmers), dtype=np.uint8).reshape(len(kmers), lag).copy()
-    counts = np.stack(rows, axis=1) if rows else np.zeros((num_ds, 0, A1), dtype=np.uint32)
+            if line.strip():
+                lag = len(line.split(b";", 1)[0].strip())
+                break
+    km = np.empty((n_rows, lag), dtype=np.uint8)
+    counts = np.empty((num_ds, n_rows, A1), dtype=np.uint32)
+    got = ctypes.c_uint64()
+    st = _lib.lib().bear_parse_sparse_counts(os.fsencode(file), int(num_ds), A1, lag, 1 if header else 0, n_rows,
+                                             km.ctypes.data, counts.ctypes.data, ctypes.byref(got))
+    _lib.check(st, "bear_parse_sparse_counts")
+    if got.value != n_rows:
+        raise ValueError(f"{file}: {got.value} rows parsed, {n_rows} expected")
     return CountDataset(km, np.ascontiguousarray(counts), alphabet, batch_size, dtype)
 
 
@@ -397,12 +397,23 @@ def write_counts_tsv(path, kmers, counts):
     ``kmer \\t [[g0 A,C,G,T,$],[g1 ...],...]``.  kmers: sequence of str/bytes or uint8 [N, lag];
     counts: integer array [num_ds, N, 5] (planar, as CountDataset.counts) or [N, num_ds, 5]."""
     counts = np.asarray(counts)
-    if isinstance(kmers, np.ndarray) and kmers.dtype == np.uint8:
-        kmers = [bytes(r).decode() for r in kmers]
+    if isinstance(kmers, np.ndarray) and kmers.dtype == np.uint8 and kmers.ndim == 2:
+        km = np.ascontiguousarray(kmers)
     else:
-        kmers = [k.decode() if isinstance(k, bytes) else str(k) for k in kmers]
-    if counts.shape[0] != len(kmers):
+        rows = [k if isinstance(k, bytes) else str(k).encode() for k in kmers]
+        if len({len(r) for r in rows}) > 1:
+            raise ValueError("write_counts_tsv: k-mers of one table have one length")
+        km = np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(len(rows), len(rows[0]) if rows else 0).copy()
+    n = km.shape[0]
+    if counts.ndim != 3 or counts.shape[2] != 5:
+        raise ValueError("write_counts_tsv: counts must be [num_ds, N, 5] or [N, num_ds, 5]")
+    if counts.shape[0] == n:                          # [N, num_ds, 5] (takes precedence when both forms fit, as before) -> planar
         counts = counts.transpose(1, 0, 2)
-    with open(path, "w") as fh:
-        for k, rows in zip(kmers, counts):
-            fh.write(k + "\t[[" + "],[".join(",".join(str(int(v)) for v in g) for g in rows) + "]]\n")
+    if counts.shape[1] != n:
+        raise ValueError("write_counts_tsv: counts do not match the number of k-mers")
+    if counts.size and (counts.min() < 0 or counts.max() > 0xffffffff):
+        raise ValueError("write_counts_tsv: counts must fit uint32 (KMC's counter range, summarize.py:66-67)")
+    planar = np.ascontiguousarray(counts, dtype=np.uint32)
+    # the native writer of the summarize stage (csrc/bear_parse.cpp): formats in C++ instead of one Python call per number
+    st = _lib.lib().bear_write_counts_tsv(os.fsencode(path), km.ctypes.data, planar.ctypes.data, n, km.shape[1], planar.shape[0], 0, 1, 0)
+    _lib.check(st, "bear_write_counts_tsv")

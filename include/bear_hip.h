@@ -339,6 +339,10 @@ int bear_synth_prior_f64(uint64_t seed, uint64_t row0, uint64_t n_rows, double *
  *   *n_rows_out receives the number of rows parsed.
  */
 int bear_count_rows(const char *path, uint64_t *n_rows_out);
+/* The sparse row format of dataloader.sparse_dataloader (bear_model/dataloader.py:52-109): `kmer; [[ds, col], ...]; [value, ...]`,
+ * one line per k-mer behind `skip_lines` header lines.  counts [host] uint32 [num_ds, max_rows, width] (zeroed here, then filled). */
+int bear_parse_sparse_counts(const char *path, int num_ds, int width, int lag, uint64_t skip_lines, uint64_t max_rows,
+                             char *kmers, uint32_t *counts, uint64_t *n_rows_out);
 int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint64_t max_rows, char *kmers,
                           uint32_t *counts, uint64_t *n_rows_out);
 /*

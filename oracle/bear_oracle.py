@@ -395,6 +395,27 @@ def parse_counts_tsv(path, num_ds):
 SMP_MAX_ROUNDS = 64
 
 
+def parse_sparse_rows(path, num_ds, width, header=True):
+    """The sparse row format, ``kmer; [[ds, col], ...]; [value, ...]`` with a header line (bear_model/dataloader.py:52-109:
+    CsvDataset(field_delim=';'), the index / value lists through decode_json, SparseTensor -> to_dense).
+    -> (list of k-mer bytes, uint32 [N, num_ds, width])."""
+    import json
+    kmers, rows = [], []
+    with open(path) as fh:
+        if header:
+            fh.readline()
+        for line in fh:
+            if not line.strip():
+                continue
+            k, pos, vals = [t.strip() for t in line.rstrip("\n").split(";")]
+            dense = np.zeros((num_ds, width), dtype=np.uint32)
+            for (d, c), v in zip(json.loads(pos), json.loads(vals)):
+                dense[d, c] = v
+            kmers.append(k.encode())
+            rows.append(dense)
+    return kmers, (np.stack(rows) if rows else np.zeros((0, num_ds, width), dtype=np.uint32))
+
+
 def _gauss_key(key):
     """N(0,1) from a 64-bit counter, the same Box-Muller pair as eval_noise."""
     with np.errstate(over="ignore"):

@@ -1,5 +1,6 @@
 """CPU tests of the host logic: plugin surface, data plane, optimizer, sharding helpers, config semantics."""
 import configparser
+import json
 import os
 
 import numpy as np
@@ -63,6 +64,49 @@ def test_sparse_dataloader():
     assert s.num_rows == 9 and s.lag == 3 and s.num_ds == 1
     k, c = next(iter(s))
     assert k[0] == b"CTT" and c[0, 0].tolist() == [0, 0, 0, 0, 1] and c[2, 0].tolist() == [0, 0, 0, 1, 0]
+
+
+def test_sparse_dataloader_against_oracle_and_malformed_rows(tmp_path):
+    """Generated three-dataset sparse file: the native reader == the oracle's restatement of dataloader.py:52-109; rows it
+    cannot represent are refused, not guessed at."""
+    from oracle import bear_oracle as o
+    rng = np.random.default_rng(3)
+    path = tmp_path / "sparse.csv"
+    with open(path, "w") as fh:
+        fh.write("kmer; count_mat_indices; count_mat_values\n")
+        for i in range(500):
+            k = "".join(rng.choice(list("ACGT["), size=4))
+            cells = sorted({(int(rng.integers(0, 3)), int(rng.integers(0, 5))) for _ in range(int(rng.integers(0, 6)))})
+            vals = [int(rng.integers(1, 2 ** 32 - 1)) if j == 0 and i % 50 == 0 else int(rng.integers(1, 40)) for j in range(len(cells))]
+            fh.write(f"{k}; {json.dumps([list(c) for c in cells])}; {json.dumps(vals)}\n" if i % 7 else
+                     f" {k} ;[{','.join('[%d, %d]' % c for c in cells)}];[{', '.join(str(float(v)) if v < 100 else str(v) for v in vals)}]\n")
+        fh.write("\n")
+    d = dataloader.sparse_dataloader(str(path), "dna", 64, 3)
+    want_k, want_c = o.parse_sparse_rows(str(path), 3, 5)
+    assert d.num_rows == 500 and d.lag == 4 and [bytes(r) for r in d.kmers] == want_k
+    assert np.array_equal(d.counts, want_c.transpose(1, 0, 2))
+    for bad in ("ACGT; [[0,1]]\n", "ACGT; [[0,1],[1]]; [1,2]\n", "ACGT; [[3,1]]; [1]\n", "ACGT; [[0,5]]; [1]\n", "ACGT; [[0,1]]; [1.5]\n",
+                "ACGT; [[0,1]]; [-1]\n", "ACGT; [[0,1]]; [1,2]\n", "ACG; [[0,1]]; [1]\n"):
+        with open(path, "w") as fh:
+            fh.write("h\nACGT; [[0,1]]; [1]\n" + bad)
+        with pytest.raises(Exception):
+            dataloader.sparse_dataloader(str(path), "dna", 64, 3)
+
+
+def test_write_counts_tsv_native_round_trip(tmp_path):
+    """write_counts_tsv goes through the native writer; both count layouts; what it writes the dense reader reads back."""
+    rng = np.random.default_rng(5)
+    n, lag, nds = 300, 6, 3
+    km = np.frombuffer(b"ACGT[", dtype=np.uint8)[rng.integers(0, 5, size=(n, lag))]
+    counts = rng.integers(0, 2 ** 32, size=(nds, n, 5), dtype=np.uint64).astype(np.uint32)
+    counts[:, ::3] = 0
+    for form, kmers in ((counts, km), (counts.transpose(1, 0, 2), [bytes(r) for r in km])):
+        path = tmp_path / "t.tsv"
+        dataloader.write_counts_tsv(str(path), kmers, form)
+        back = dataloader.dataloader(str(path), "dna", 100, nds)
+        assert np.array_equal(back.kmers, km) and np.array_equal(back.counts, counts)
+    with pytest.raises(ValueError):
+        dataloader.write_counts_tsv(str(tmp_path / "x.tsv"), km, counts[:, :10])
 
 
 def test_keras_adam_update_rule():
