@@ -115,3 +115,31 @@ def test_config_driver_under_the_launcher(kind, tmp_path):
     assert np.allclose(res[0][1], res[1][1], rtol=1e-7, atol=1e-10)
     for key in ("h", "heldout_perplex_BEAR", "heldout_perplex_AR", "perplex_BEAR", "heldout_accuracy_BEAR"):
         assert np.allclose(json.loads(res[0][0][key]), json.loads(res[1][0][key]), rtol=1e-9), key
+
+
+def test_bench_under_the_launcher_two_ranks(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process; here both ranks on cuda:0 over
+    gloo): one JSON line from rank 0, whole-job value, weak scaling, and per-rank sums that the all-reduce has added up -- the
+    reduced ELBO equals the ELBO of the two row shards computed in this process."""
+    from bear_amd import kernels
+    n = 2_000_000
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", BEAR_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 31500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--contexts", str(n), "--backend", "gloo", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["unit"] == "contexts/s"
+    assert abs(d["value"] - 2 * n / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]          # whole job: both ranks' contexts
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is None
+    dev = torch.device("cuda", 0)
+    want = 0.0
+    for r in range(2):           # the shards bench.py gives rank r: rows [r n, (r + 1) n) of the global synthetic table
+        t = kernels.synth_counts(20211012, r * n, n, dev, want=("train",))["train"]
+        want += kernels.dm_prior_planned(kernels.Plan(t, 5), kernels.synth_prior(20211012, r * n, n, dev), 0.0).cpu().numpy()
+    # the bench re-reduces its output buffer at every step: after the last step it holds the all-reduced sums of that step
+    assert np.allclose(d["result"], want, rtol=1e-12), (d["result"], want)
