@@ -622,21 +622,24 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
         acc[1] = __builtin_fma(eps - x[0], o[0].P, acc[1]);
         continue;
       }
-      // ---- A: context terms  -D(A, n), (A - 5 eps) P(A, n)   with A = S u + 5 eps; PLN_CHUNK contexts per ticket,
-      // PLN_CHUNK / 64 per lane so that their LDS reads are in flight together
-      const uint32_t row0c = (w - n_heavy - n_units) * PLN_CHUNK + lane;
-      double S5[PLN_CHUNK / 64];
-      uint32_t nn_[PLN_CHUNK / 64];
+      // ---- A: context terms  -D(A, n), (A - 5 eps) P(A, n)   with A = S u + 5 eps; PLN_CHUNK contexts per ticket, a lane
+      // takes two ADJACENT contexts: their ten doubles are 80 contiguous, 16-byte aligned bytes = five 16-byte LDS reads
+      // (conflict-free at this stride) instead of ten 8-byte ones
+      static_assert(PLN_CHUNK == 128, "two adjacent contexts per lane");
+      const uint32_t row0c = (w - n_heavy - n_units) * PLN_CHUNK + 2u * lane;
+      double S5[2];
+      uint32_t nn_[2];
+      {
+        const uint32_t rr = row0c < rows ? row0c : 0u;          // rows is a multiple of 4 except in the table's last tile: a
+        const double2 *src = reinterpret_cast<const double2 *>(&B.pri[rr * 5]);   // pair may end one row past it (still inside pri)
+        const double2 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3], v4 = src[4];
+        S5[0] = ((v0.x + v0.y) + (v1.x + v1.y)) + v2.x;
+        S5[1] = ((v2.y + v3.x) + (v3.y + v4.x)) + v4.y;
 #pragma unroll
-      for (int q = 0; q < PLN_CHUNK / 64; ++q) {
-        const uint32_t row = row0c + 64u * q;
-        const uint32_t rr = row < rows ? row : rows - 1;
-        double f[5];
-#pragma unroll
-        for (int b = 0; b < 5; ++b) f[b] = B.pri[rr * 5 + b];
-        S5[q] = ((f[0] + f[1]) + (f[2] + f[3])) + f[4];
-        uint32_t n = row < rows ? (uint32_t)nrow[rr] : 0u;  // 0: empty context; 255: total beyond SRT_CL (heavy lists)
-        nn_[q] = n == 255u ? 0u : n;
+        for (int q = 0; q < 2; ++q) {
+          const uint32_t n = row0c + q < rows ? (uint32_t)nrow[rr + q] : 0u;  // 0: empty context; 255: total beyond SRT_CL (heavy lists)
+          nn_[q] = n == 255u ? 0u : n;
+        }
       }
 #pragma unroll
       for (int q = 0; q < PLN_CHUNK / 64; ++q) {

@@ -4,7 +4,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-out_md = [f"# rocprofv3 summary, round tag {tag}", "", "Command: `python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline` under",
+out_md = [f"# rocprofv3 summary, round tag {tag}", "", "Command: `python3 bench.py --steps 100 --warmup 60 --no-cpu-baseline` under",
           "`rocprofv3 --kernel-trace --stats` (kernel stats) and, in separate passes, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`,",
           "`--pmc SQ_*` (scripts/profile_round.sh).", ""]
 ks = glob.glob(os.path.join(src, f"{tag}_stats", "**", "*_kernel_stats.csv"), recursive=True)
@@ -16,6 +16,20 @@ if ks:
     for r in rows:
         out_md.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['Percentage']} |")
     out_md.append("")
+    # --stats averages ALL launches of a kernel, including the first ~30 after idle while the card ramps its clocks up
+    # (scripts/dev/ramp.py: 1.1 -> 0.79 ms for the headline kernel); the trace has every launch: steady state = the last half
+    kt = glob.glob(os.path.join(src, f"{tag}_stats", "**", "*_kernel_trace.csv"), recursive=True)
+    if kt:
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(kt[0])):
+            per[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        out_md += ["## the same trace, first launches apart (clock ramp after idle)", "",
+                   "| kernel | calls | avg ns, first quarter of the launches | avg ns, last half |", "|---|---|---|---|"]
+        for name, d in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            if len(d) >= 8 and any(t in name for t in ("dm_", "eval_", "cnn_", "stream_read")):
+                q, h = d[:len(d) // 4], d[len(d) // 2:]
+                out_md.append(f"| `{name[:70]}` | {len(d)} | {sum(q) / len(q):.0f} | {sum(h) / len(h):.0f} |")
+        out_md.append("")
 traffic = {}
 def kernel_key(k):
     """bench.py workload name of a planned kernel instantiation."""
