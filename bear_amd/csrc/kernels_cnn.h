@@ -252,6 +252,17 @@ __device__ __forceinline__ void cnn_colsum_add(const double *E, double *dst, int
   if ((int)(lane & 31u) < n_cols) cnn_lds_add(dst + (lane & 31u), (s4[0] + s4[1]) + (s4[2] + s4[3]));
 }
 
+#ifdef CNN_STAMPS   // developer build: clocks per phase of the backward tile loop, summed per wave (scripts/dev/cnn_stamps.py)
+__device__ unsigned long long cnn_stamp_sums[8];
+#define CNN_STAMP(k)                                              \
+  {                                                               \
+    const unsigned long long now = __builtin_amdgcn_s_memtime();  \
+    tph[k] += now - t_prev;                                       \
+    t_prev = now;                                                 \
+  }
+#else
+#define CNN_STAMP(k)
+#endif
 __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigned long long *__restrict__ codes, uint64_t n_rows,
                                                                     cnn_dims D, const double *__restrict__ params,
                                                                     const double *__restrict__ t1_save,
@@ -274,6 +285,9 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
   for (int k = threadIdx.x; k < D.total; k += blockDim.x) G[k] = 0.0;
   __syncthreads();
   const uint64_t n_tiles = (n_rows + 63) / 64;
+#ifdef CNN_STAMPS
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#endif
   const uint32_t lq = lane >> 4, lr = lane & 15u;     // MFMA lane coordinates: k / row-group index, row / column index
   const int n_mt = (4 * D.fw + 15) / 16;              // M tiles of the one-hot operand: rows (tap w, letter a < 4)
   for (uint64_t tile = (uint64_t)blockIdx.x * n_waves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * n_waves) {
@@ -370,6 +384,7 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) tb2[ks][nt] = T[(4 * ks + lq) * CNN_ES + nt * 16 + lr];
+    CNN_STAMP(6)
     // positions
     for (int p = 0; p < D.P; ++p) {
       double x[CNN_NF], dy[CNN_NF], dn[CNN_NF];
@@ -384,6 +399,7 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
         E[f * CNN_ES + lane] = cnn_elu(__builtin_fma(s0[f], x[f], b0[f]), exptab, dv);
         dy[f] = dv;
       }
+      CNN_STAMP(0)
       // d weights1[p][f][j] += sum_ctx e0[ctx][f] dT1[ctx][j]
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -398,6 +414,7 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
           if (f < CNN_NF) cnn_lds_add(g + f * CNN_L1 + lr, acc[r]);
         }
       }
+      CNN_STAMP(1)
       // pass B: d e0[f][ctx] = sum_j weights1[p][f][j] dT1[ctx][j] as MFMA products (rows f, columns ctx, K = j), the
       // result handed back to the context lanes through the staging buffer
       {
@@ -431,6 +448,7 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
             }
           }
       }
+      CNN_STAMP(2)
 #pragma unroll
       for (int f = 0; f < CNN_NF; ++f) {
         dy[f] *= E[f * CNN_ES + lane];
@@ -446,6 +464,7 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
 #pragma unroll
       for (int f = 0; f < CNN_NF; ++f) E[f * CNN_CS + lane] = dy[f];
       cnn_colsum_add(E, G + D.ob0 + p * CNN_NF, CNN_NF, lane);
+      CNN_STAMP(3)
       // layer-norm backward -> d conv[p][f], staged as the B operand of d filters
       {
         unsigned long long c = code >> (3 * p);
@@ -466,6 +485,7 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
             }
         }
       }
+      CNN_STAMP(4)
       // d filters[w][a][f] += sum_ctx [letter_{p+w}(ctx) == a] d conv[ctx][f],  rows (w, a < 4), two column tiles of f
       for (int mt = 0; mt < n_mt; mt += 2) {      // two row tiles per pass share the B operand reads
         cnn_d4 acc[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
@@ -502,8 +522,13 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
             }
           }
       }
+      CNN_STAMP(5)
     }
   }
+#ifdef CNN_STAMPS
+  if (lane == 0)
+    for (int k = 0; k < 8; ++k) atomicAdd(&cnn_stamp_sums[k], tph[k]);
+#endif
   __syncthreads();
   for (int k = threadIdx.x; k < D.total; k += blockDim.x) partials[(size_t)blockIdx.x * D.total + k] = G[k];
 }
