@@ -147,7 +147,7 @@ __device__ __forceinline__ uint32_t lin_off_any(unsigned long long cv, uint32_t 
   return g * LIN_PSTRIDE + idx * 4u;
 }
 
-// exp(d ln2 / 128) for d <= 0: the tables hold logits in units of ln2 / 128, so the argument reduction of bear_exp_tab is a
+// exp(d ln2 / 128): the tables hold logits in units of ln2 / 128, so the argument reduction of bear_exp_tab is a
 // rounding and an exact subtraction; 2^(j/128) from the table, degree-5 polynomial on |r| <= 1/2 unit, v_ldexp for the rest.
 #define LIN_EXP_UNIT 184.66496523378731    // 128 / ln 2
 __device__ __forceinline__ double lin_exp_units(double d, const double *__restrict__ tab) {
@@ -187,12 +187,26 @@ __device__ __forceinline__ void lin_row(const double *T, const double *exptab, u
         z[3] += hi[j].y;
       }
   }
-  const double m = __builtin_fmax(__builtin_fmax(__builtin_fmax(z[0], z[1]), __builtin_fmax(z[2], z[3])), 0.0);
-  double s = 0.0;
+  // Logits within +-600 (in natural units) for the whole wave -- anything a fitted model produces: no maximum to subtract and
+  // the fifth exponential is 1.  Otherwise the shifted form (a saturated softmax needs it).
+  const double za = __builtin_fmax(__builtin_fmax(__builtin_fabs(z[0]), __builtin_fabs(z[1])), __builtin_fmax(__builtin_fabs(z[2]), __builtin_fabs(z[3])));
+  double s;
+  if (__builtin_amdgcn_ballot_w64(!(za < 600.0 * LIN_EXP_UNIT)) == 0ull) {
+    s = 1.0;
+    f[4] = 1.0;
 #pragma unroll
-  for (int b = 0; b < 5; ++b) {
-    f[b] = lin_exp_units(__builtin_fmax((b < 4 ? z[b] : 0.0) - m, -700.0 * LIN_EXP_UNIT), exptab);
-    s += f[b];
+    for (int b = 0; b < 4; ++b) {
+      f[b] = lin_exp_units(z[b], exptab);
+      s += f[b];
+    }
+  } else {
+    const double m = __builtin_fmax(__builtin_fmax(__builtin_fmax(z[0], z[1]), __builtin_fmax(z[2], z[3])), 0.0);
+    s = 0.0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      f[b] = lin_exp_units(__builtin_fmax((b < 4 ? z[b] : 0.0) - m, -700.0 * LIN_EXP_UNIT), exptab);
+      s += f[b];
+    }
   }
   const double r = bear_rcp(s);
 #pragma unroll

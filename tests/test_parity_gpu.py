@@ -403,6 +403,29 @@ def test_fused_linear_head_parity(case, lag, dev, ysd1):
         assert np.allclose(g, wantg, rtol=1e-9, atol=1e-9 * np.abs(wantg).max()), (case, lag, h_s, ar, np.abs(g - wantg).max())
 
 
+def test_fused_linear_head_saturated_logits(dev):
+    """Logits of several hundred to thousands (a saturated softmax): the kernel leaves its un-shifted fast path (|logit| < 600
+    for the whole wave) for the max-shifted one; parity with the oracle chain either way, also with a mix inside one table."""
+    import torch
+    from bear_amd import kernels
+    tr = CASES_REF["sparse"]()[0]
+    n, lag = len(tr), 5
+    rng = np.random.default_rng(99)
+    codes = rng.integers(0, 4, size=(n, lag)).astype(np.int8)
+    plan = kernels.Plan(_to_dev(tr, dev), 5)
+    idx = kernels.linear_index(kernels.pack_kmers(torch.from_numpy(codes).to(dev)), lag)
+    for scale in (150.0, 400.0, 3000.0):
+        mat = rng.normal(size=(lag, 5, 5)) * scale
+        mat[0, 0] *= 0.001                      # contexts starting with letter 0 keep small logits from that position
+        for h_s, ar in [(0.0, False), (0.4, True)]:
+            want, wantg = _linear_oracle(tr, codes, mat, h_s, ar)
+            got, g = kernels.dm_linear(plan, idx, torch.from_numpy(mat).to(dev), h_s, train_ar=ar)
+            got, g = got.cpu().numpy(), g.cpu().numpy()
+            assert np.all(np.isfinite(got)) and np.all(np.isfinite(g))
+            _close(got[0], want[0], ELBO_RTOL)
+            assert np.allclose(g, wantg, rtol=1e-8, atol=1e-9 * max(np.abs(wantg).max(), 1e-300)), (scale, h_s, ar)
+
+
 def test_fused_linear_head_full_size(dev):
     """BASELINE configs[2] at size (1e7 contexts, lag 13, bear_dm_linear_f64): the sums of a k-mer-sorted table equal those of
     the same rows in random order; a table's sums are the sums of its two halves (each with its own plan); every
