@@ -760,6 +760,17 @@ extern "C" int bear_dbg_cnn_stamps(unsigned long long *host_out, int reset) {   
 }
 #endif
 
+#ifdef LIN_STAMPS
+extern "C" int bear_dbg_lin_stamps(unsigned long long *host_out, int reset) {   // developer build only
+  if (host_out) HIP_TRY(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lin_stamp_sums), sizeof(unsigned long long) * 8));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lin_stamp_sums), z, sizeof(z)));
+  }
+  return BEAR_OK;
+}
+#endif
+
 // ---- fused linear AR head (kernels_linear.h) -----------------------------------------------------------
 int bear_pack_kmers_u64(const int8_t *codes, uint64_t n_rows, int lag, uint64_t *packed, void *stream) {
   if (lag < 1 || lag > LIN_MAX_LAG) return BEAR_ERR_INVALID_ARG;

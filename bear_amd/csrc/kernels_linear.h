@@ -427,6 +427,17 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uin
   }
 static_assert(LIN_MAX_GROUPS == 10, "LIN_FOR_NG lists the group counts");
 
+#ifdef LIN_STAMPS   // developer build: clocks per section of the tile loop, summed over the waves (scripts/dev/lin_stamps.py)
+__device__ unsigned long long lin_stamp_sums[8];
+#define LIN_STAMP(k)                                              \
+  {                                                               \
+    const unsigned long long now = __builtin_amdgcn_s_memtime();  \
+    tph[k] += now - t_prev;                                       \
+    t_prev = now;                                                 \
+  }
+#else
+#define LIN_STAMP(k)
+#endif
 template <bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_kernel(
     const unsigned long long *__restrict__ kmer_code, const double *__restrict__ mat, int lag, bear_params prm_arg, pln_view pv,
@@ -477,21 +488,30 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   for (int k = tid; k < LIN_TAB_DOUBLES; k += PLN_THREADS) S.GT[k] = 0.0;
   __syncthreads();
 
+#ifndef LIN_DMA_WAVES
+#define LIN_DMA_WAVES 2              // waves that issue the tile DMA (the last ones of the block: they never hold a second batch of rows); measured 16 / 8 / 4 / 2 waves: 1.92 / 1.89 / 1.87 / 1.86 ms
+#endif
   auto stage = [&](const pln_tile &ti, uint64_t tile, uint32_t b) {
     const uint32_t rows = ti.rows_items >> 16;
     if (rows == 0) return;
+    if (wave < PLN_WAVES - LIN_DMA_WAVES) return;
     uint32_t lane = tid & 63u;
     asm volatile("" : "+v"(lane));   // no lane-derived addresses kept (and spilled) across the tile loop
-    const uint32_t cbytes = rows * 8u;
-    pln_dma(S.buf[b].codes, kmer_code + ti.row0, cbytes & ~15u, wave, lane, 0);
-    if (cbytes & 15u) {  // odd row count: trailing word through the scalar path (see dm_prior_plan_kernel)
+    // the three slabs of a tile as one sequence of 1 KiB pieces dealt round-robin to the issuing waves
+    const uint32_t dw = wave - (PLN_WAVES - LIN_DMA_WAVES);
+    const uint32_t cb = (rows * 8u) & ~15u, bb = ti.blk16 * 16u, lb = ((rows + 1u) * 2u + 15u) & ~15u;
+    const uint32_t pc = (cb + 1023u) >> 10, pb = (bb + 1023u) >> 10, pl = (lb + 1023u) >> 10;
+    for (uint32_t q = dw; q < pc + pb + pl; q += LIN_DMA_WAVES) {
+      if (q < pc) pln_dma_piece(S.buf[b].codes, kmer_code + ti.row0, cb, q, lane);
+      else if (q < pc + pb) pln_dma_piece(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, bb, q - pc, lane);
+      else pln_dma_piece(S.buf[b].live, pv.live + tile * PLN_LIVE_STRIDE, lb, q - pc - pb, lane);
+    }
+    if ((rows * 8u) & 15u) {  // odd row count: trailing word through the scalar path (see dm_prior_plan_kernel)
       const __attribute__((address_space(4))) unsigned long long *tail =
           (const __attribute__((address_space(4))) unsigned long long *)(uintptr_t)(kmer_code + ti.row0 + rows - 1);
       const unsigned long long v = *tail;
-      if (tid == 0) S.buf[b].codes[rows - 1] = v;
+      if (tid == PLN_THREADS - 64) S.buf[b].codes[rows - 1] = v;
     }
-    pln_dma(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, ti.blk16 * 16u, wave, lane, (cbytes + 1023u) >> 10);
-    pln_dma(S.buf[b].live, pv.live + tile * PLN_LIVE_STRIDE, ((rows + 1u) * 2u + 15u) & ~15u, wave, lane, 7);
   };
 
   double fA[LIN_RPT][5];
@@ -517,7 +537,11 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   lin_phase_a_store(S, fA, rowA);
   srt_sync();
   stage(nxt, blockIdx.x + GR, 1);
+  pln_tile nxt2 = pln_load_tile(pv, blockIdx.x + 2 * GR);   // descriptors by scalar loads, one iteration ahead of their use
   uint32_t slot = 0, c_target = 0;
+#ifdef LIN_STAMPS
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (uint64_t t = blockIdx.x; t < pv.n_tiles; t += GR) {
     const lin_buf &B = S.buf[slot];
     const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
@@ -578,22 +602,35 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
       if (!AR) srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
       if (off != (uint32_t)PLN_SENTINEL) item(off, o[0].D, o[0].P, x[0], (double)ci[0]);
     }
+    LIN_STAMP(0)     // B: items
     srt_wait_dma();  // the next tile's codes and plan block (issued a whole iteration ago)
+    LIN_STAMP(1)     // wait for the DMA
     srt_sync();      // ... and every item of this tile has left its mark: nobody reads this tile's buffers any more
+    LIN_STAMP(2)     // barrier after the items
     cur = nxt;
-    nxt = pln_load_tile(pv, t + 2 * GR);
+    nxt = nxt2;
     stage(nxt, t + 2 * GR, slot);   // the tile after next lands while phases C, A and the next tile's B run
+    nxt2 = pln_load_tile(pv, t + 3 * GR);
     // ---- C of this tile (rows, index words and softmax rows from phase A's registers), A of the next
+    LIN_STAMP(3)     // staging the tile after next
     phase_c();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of this tile's LDS rows have returned
+    LIN_STAMP(4)     // C
     if (lane == 0) atomicAdd(&S.c_done, 1u);
     c_target += PLN_WAVES;
     phase_a(S.buf[slot ^ 1u], cur.rows_items >> 16);
+    LIN_STAMP(5)     // A (compute)
     while (pln_peek(&S.c_done) < c_target) __builtin_amdgcn_s_sleep(1);   // every wave has: the rows may be overwritten
+    LIN_STAMP(6)     // wait for the other waves' read-backs
     lin_phase_a_store(S, fA, rowA);
     srt_sync();      // the next tile's rows are in place for its items
+    LIN_STAMP(7)     // row stores + barrier
     slot ^= 1u;
   }
+#ifdef LIN_STAMPS
+  if (lane == 0)
+    for (int k = 0; k < 8; ++k) atomicAdd(&lin_stamp_sums[k], tph[k]);
+#endif
   srt_wait_dma();
   __syncthreads();
   // ---- items / contexts that overflowed to the plan's global lists (very dense tiles): self-contained
