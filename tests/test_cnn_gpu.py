@@ -50,8 +50,13 @@ def test_cnn_forward_matches_oracle(lag, fw, n):
     assert t1.shape == (n, 16)
 
 
-@pytest.mark.parametrize("lag,fw,n", [(13, 8, 3000), (5, 3, 1365), (7, 7, 64), (2, 1, 3), (21, 1, 500), (21, 16, 200)])
-def test_cnn_backward_matches_torch_autograd(lag, fw, n):
+@pytest.mark.parametrize("form", ["32-context tiles, two waves per SIMD", "64-context tiles, one wave per SIMD"])
+@pytest.mark.parametrize("lag,fw,n", [(13, 8, 3000), (5, 3, 1365), (7, 7, 64), (2, 1, 3), (21, 1, 500), (21, 16, 200), (13, 8, 31), (13, 8, 33)])
+def test_cnn_backward_matches_torch_autograd(lag, fw, n, form, monkeypatch):
+    """Both tile forms of the backward kernel (the library picks the first when its LDS fits: not for (21, 16); BEAR_CNN_BACKWARD=1
+    forces the second)."""
+    if form.startswith("64"):
+        monkeypatch.setenv("BEAR_CNN_BACKWARD", "1")
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(lag * 7 + fw)
     kmers = _random_kmers(n, lag, rng)
