@@ -1222,21 +1222,21 @@ int bear_cnn_forward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows
 static int cnn_backward_grid(bear_ws *ws, const cnn_dims &D, uint64_t n_rows, int filter_width, int *waves_out, size_t *lds_out,
                              uint64_t *blocks_out, hipStream_t s, int may_alloc) {
   const size_t fixed = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (size_t)((D.total + 1) & ~1));
-  // eight waves of 32-context tiles (cnn_backward2_kernel: two waves per SIMD) when their staging fits next to the filter
-  // image and the gradient image -- every reference config; otherwise 64-context tiles, one wave per SIMD.  waves == 8 names
-  // the first form.  BEAR_CNN_BACKWARD=1 forces the second (developer A/B runs).
-  const size_t lds2 = fixed + sizeof(double) * ((size_t)(CNN2_THREADS / 64) * CNN2_WAVE_DOUBLES + 2 * CNN_L1 + CNN_L1 * 5 + 2 * (size_t)D.P * CNN_NF);
+  // cnn_backward_parts_kernel<2>: two lanes per context, eight waves of 32-context tiles (two per SIMD), when the staging fits
+  // next to the filter, parameter and gradient images (every reference config); otherwise 64-context tiles, one wave per SIMD.
+  // `waves` names the form (8 / <= 4).  BEAR_CNN_BACKWARD=1 forces the second form (developer A/B runs, tests).
+  const size_t lds2 = sizeof(double) * (cnnq_fixed_doubles(D) + (size_t)cnnq<2>::WAVES * cnnq<2>::WAVE_DOUBLES);
   const char *force = getenv("BEAR_CNN_BACKWARD");
-  const bool two_per_simd = lds2 <= 160u * 1024u && !(force && force[0] == '1');
   int waves = 4;
   while (waves > 1 && fixed + (size_t)waves * CNN_WAVE_DOUBLES * sizeof(double) > 160u * 1024u) waves >>= 1;
   size_t lds = fixed + (size_t)waves * CNN_WAVE_DOUBLES * sizeof(double);
-  if (two_per_simd) {
-    waves = CNN2_THREADS / 64;
+  uint64_t per_block = (uint64_t)64 * waves;
+  if (lds2 <= 160u * 1024u && !(force && force[0] == '1')) {
+    waves = cnnq<2>::WAVES;
     lds = lds2;
+    per_block = (uint64_t)cnnq<2>::TILE * waves;
   }
   if (lds > 160u * 1024u) return BEAR_ERR_INVALID_ARG;
-  const uint64_t per_block = two_per_simd ? (uint64_t)CNN2_TILE * waves : (uint64_t)64 * waves;
   uint64_t blocks = (n_rows + per_block - 1) / per_block;
   if (blocks > (uint64_t)ws->num_cu) blocks = (uint64_t)ws->num_cu;
   if (blocks == 0) blocks = 1;
@@ -1264,18 +1264,16 @@ static int launch_cnn_backward(bear_ws *ws, const cnn_dims &D, const uint64_t *k
   uint64_t blocks = 0;
   int st = cnn_backward_grid(ws, D, n_rows, filter_width, &waves, &lds, &blocks, s, may_alloc);
   if (st != BEAR_OK) return st;
-  const bool two_per_simd = waves == CNN2_THREADS / 64;
-  if (may_alloc)
-    HIP_TRY(hipFuncSetAttribute(two_per_simd ? reinterpret_cast<const void *>(cnn_backward2_kernel) : reinterpret_cast<const void *>(cnn_backward_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  if (two_per_simd)
-    hipLaunchKernelGGL(cnn_backward2_kernel, dim3((unsigned)blocks), dim3(CNN2_THREADS), lds, s,
-                       reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, t1_save, prior, grad_prior,
-                       ws->cnn_partials);
+  const bool parts2 = waves == cnnq<2>::WAVES;
+  const void *fn = parts2 ? reinterpret_cast<const void *>(cnn_backward_parts_kernel<2>) : reinterpret_cast<const void *>(cnn_backward_kernel);
+  if (may_alloc) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const unsigned long long *kc = reinterpret_cast<const unsigned long long *>(kmer_code);
+  if (parts2)
+    hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)blocks), dim3(64 * waves), lds, s, kc, n_rows, D, params, t1_save, prior,
+                       grad_prior, ws->cnn_partials);
   else
-    hipLaunchKernelGGL(cnn_backward_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, s,
-                       reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, t1_save, prior, grad_prior,
-                       ws->cnn_partials);
+    hipLaunchKernelGGL(cnn_backward_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, s, kc, n_rows, D, params, t1_save, prior,
+                       grad_prior, ws->cnn_partials);
   hipLaunchKernelGGL(cnn_finalize_kernel, dim3((D.total + 3) / 4), dim3(256), 0, s, ws->cnn_partials, (int)blocks, D.total, grad_params);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
@@ -1302,8 +1300,8 @@ int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, in
   uint64_t blocks = 0;
   st = cnn_backward_grid(ws, D, n_rows, filter_width, &waves, &lds, &blocks, nullptr, 1);
   if (st != BEAR_OK) return st;
-  HIP_TRY(hipFuncSetAttribute(waves == CNN2_THREADS / 64 ? reinterpret_cast<const void *>(cnn_backward2_kernel)
-                                                         : reinterpret_cast<const void *>(cnn_backward_kernel),
+  HIP_TRY(hipFuncSetAttribute(waves == cnnq<2>::WAVES ? reinterpret_cast<const void *>(cnn_backward_parts_kernel<2>)
+                                                      : reinterpret_cast<const void *>(cnn_backward_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return BEAR_OK;
 }

@@ -541,55 +541,80 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
 // real ones) and layer-1 units [8 half, 8 half + 8).  Per-context instruction counts stay what they were (a wave
 // instruction covers 32 contexts x 2 features instead of 64 x 1), the register arrays halve, the staging tile halves
 // (K = 32 contexts per MFMA product), and eight waves fit a CU: two per SIMD, each hiding the other's stalls.  Sums over a
-// context's filters / units cross the halves with v_permlane32_swap.  Parameters a lane needs for "its" filter are two uniform
-// scalar loads and a select.  Used when its LDS fits (it does for every reference config); otherwise the kernel above.
-#define CNN2_THREADS 512
-#define CNN2_TILE 32
-#define CNN2_ES 36            // operand staging: row stride in doubles ([feature][context])
-#define CNN2_CS 33            // column-sum staging: row stride in doubles ([column][context])
-#define CNN2_FH 16            // filters per lane half
-#define CNN2_JH 8             // layer-1 units per lane half
-#define CNN2_E_DOUBLES (CNN_NF * CNN2_ES)
-#define CNN2_T_DOUBLES (CNN_L1 * CNN2_ES)
-#define CNN2_WAVE_DOUBLES (CNN2_E_DOUBLES + CNN2_T_DOUBLES + CNN2_TILE)
-static_assert(32 * CNN2_CS <= CNN2_E_DOUBLES, "column-sum staging lives in the operand staging area");
-
-// v + (the value of v in lane ^ 32)
-__device__ __forceinline__ double cnn2_hsum(double v) {
-  const long long q = __double_as_longlong(v);
-  const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
-  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto c = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return __longlong_as_double(((long long)c[0] << 32) | a[0]) + __longlong_as_double(((long long)c[1] << 32) | a[1]);
+// context's filters / units cross the parts with v_permlane32_swap (/ v_permlane16_swap).  Parameters a lane reads at a
+// part-dependent index come from an LDS image.  Used when the LDS fits (it does for every reference config); otherwise the
+// kernel above.
+// geometry of the form with Q lanes per context (Q = 2: 32-context tiles, 8 waves)
+template <int Q>
+struct cnnq {
+  // Q = 4 (16-context tiles, twelve waves: three per SIMD) was written and measured: 10.98 ms per 1e7 contexts against 10.27 ms
+  // for Q = 2 -- the third wave's latency hiding does not pay for the doubled per-tile overheads -- and was not validated.
+  static_assert(Q == 2, "lanes per context: 2");
+  static constexpr int TILE = 64 / Q;            // contexts per wave tile
+  static constexpr int FH = 32 / Q;              // filter slots per lane (30 filters: the last part holds two dummies)
+  static constexpr int JH = CNN_L1 / Q;          // layer-1 units per lane
+  static constexpr int ES = TILE + 4;            // operand staging: row stride in doubles ([feature][context])
+  static constexpr int CS = TILE + 1;            // column-sum staging: row stride in doubles ([column][context])
+  static constexpr int KS = TILE / 4;            // MFMA k-steps over the contexts of a tile
+  static constexpr int NT = TILE / 16;           // MFMA column tiles over the contexts of a tile
+  static constexpr int E_DOUBLES = CNN_NF * ES, T_DOUBLES = CNN_L1 * ES, WAVE_DOUBLES = E_DOUBLES + T_DOUBLES + TILE;
+  static constexpr int WAVES = Q == 2 ? 8 : 12;  // per block = per CU: two / three per SIMD
+  static constexpr int W2Q = CNN_L1 * 5 / Q;     // d weights2 columns a part owns
+  static constexpr int COLQ = 32 / Q;            // staging columns of a part per round of 32
+  static_assert(32 * CS <= E_DOUBLES, "column-sum staging lives in the operand staging area");
+};
+// doubles of LDS next to the per-wave staging: exp table, filter image, half-dependent parameter image, gradient image
+static inline size_t cnnq_fixed_doubles(const cnn_dims &D) {
+  return (size_t)BEAR_EXPTAB_N + (size_t)D.fw * 6 * CNN_NF + 2 * CNN_L1 + CNN_L1 * 5 + 2 * (size_t)D.P * CNN_NF + (size_t)((D.total + 1) & ~1);
 }
-// staged columns [column][context] (stride CNN2_CS): lane (c = lane & 31, hh) returns the sum of column c over contexts [16 hh, 16 hh + 16)
-__device__ __forceinline__ double cnn2_colsum(const double *E, uint32_t lane) {
-  const double *src = E + (lane & 31u) * CNN2_CS + (lane >> 5) * 16u;
+
+// v summed over the Q lanes of a context (lanes ctx, ctx + TILE, ...): every one of them gets the sum
+template <int Q>
+__device__ __forceinline__ double cnnq_psum(double v) {
+#pragma unroll
+  for (int step = 0; step < (Q == 2 ? 1 : 2); ++step) {
+    const long long q = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
+    const bool s32 = Q == 2 || step == 1;
+    const auto a = s32 ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false) : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto c = s32 ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false) : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __longlong_as_double(((long long)c[0] << 32) | a[0]) + __longlong_as_double(((long long)c[1] << 32) | a[1]);
+  }
+  return v;
+}
+// staged columns [column][context] (stride CS): lane (c = lane & 31, hh) returns the sum of column c over its half of the contexts
+template <int Q>
+__device__ __forceinline__ double cnnq_colsum(const double *E, uint32_t lane) {
+  constexpr int HALF = cnnq<Q>::TILE / 2;
+  const double *src = E + (lane & 31u) * cnnq<Q>::CS + (lane >> 5) * HALF;
   double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int r = 0; r < 16; ++r) s4[r & 3] += src[r];
+  for (int r = 0; r < HALF; ++r) s4[r & 3] += src[r];
   return (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
-__global__ __launch_bounds__(CNN2_THREADS) void cnn_backward2_kernel(const unsigned long long *__restrict__ codes, uint64_t n_rows,
-                                                                      cnn_dims D, const double *__restrict__ params,
-                                                                      const double *__restrict__ t1_save,
-                                                                      const double *__restrict__ prior,
-                                                                      const double *__restrict__ grad_prior,
-                                                                      double *__restrict__ partials) {
+template <int Q>
+__global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel(const unsigned long long *__restrict__ codes, uint64_t n_rows,
+                                                                                  cnn_dims D, const double *__restrict__ params,
+                                                                                  const double *__restrict__ t1_save,
+                                                                                  const double *__restrict__ prior,
+                                                                                  const double *__restrict__ grad_prior,
+                                                                                  double *__restrict__ partials) {
+  using C = cnnq<Q>;
+  constexpr int TILE = C::TILE, FH = C::FH, JH = C::JH, ES = C::ES, CS = C::CS, KS = C::KS, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) double cnn_lds[];
   double *exptab = cnn_lds;
   double *Fs = cnn_lds + BEAR_EXPTAB_N;
-  // the parameters a lane reads at a half-dependent index: scale1 [16] | intercept1 [16] | weights2 [16][5] | scale0 [P][30] | intercept0 [P][30]
+  // the parameters a lane reads at a part-dependent index: scale1 [16] | intercept1 [16] | weights2 [16][5] | scale0 [P][30] | intercept0 [P][30]
   double *Ps1 = Fs + D.fw * 6 * CNN_NF, *Pb1 = Ps1 + CNN_L1, *PW2 = Pb1 + CNN_L1, *Ps0 = PW2 + CNN_L1 * 5, *Pb0 = Ps0 + D.P * CNN_NF;
   double *G = Pb0 + D.P * CNN_NF;                 // [total] block gradient image, parameter layout
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-  const uint32_t ctx = lane & 31u;
-  const bool hb = lane >= 32u;                    // the lane's half
-  const uint32_t h = hb ? 1u : 0u;
-  double *E = G + ((D.total + 1) & ~1) + wave * CNN2_WAVE_DOUBLES;   // [30][CNN2_ES] staging
-  double *T = E + CNN2_E_DOUBLES;                                    // [16][CNN2_ES] dT1
-  unsigned long long *Cw = reinterpret_cast<unsigned long long *>(T + CNN2_T_DOUBLES);   // [32] packed contexts
+  const uint32_t ctx = lane & (TILE - 1);
+  const uint32_t h = lane / TILE;                 // the lane's part: filters [FH h, FH h + FH), layer-1 units [JH h, JH h + JH)
+  const bool last = h == Q - 1;                   // ... whose last two filter slots are dummies (30 filters)
+  double *E = G + ((D.total + 1) & ~1) + wave * C::WAVE_DOUBLES;   // [30][ES] staging
+  double *T = E + C::E_DOUBLES;                                     // [16][ES] dT1
+  unsigned long long *Cw = reinterpret_cast<unsigned long long *>(T + C::T_DOUBLES);   // [TILE] packed contexts
   if (threadIdx.x < BEAR_EXPTAB_N) exptab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / BEAR_EXPTAB_N));
   for (int k = threadIdx.x; k < D.fw * 6 * CNN_NF; k += blockDim.x) {
     const int w = k / (6 * CNN_NF), r = k - w * 6 * CNN_NF, a = r / CNN_NF, f = r - a * CNN_NF;
@@ -606,21 +631,24 @@ __global__ __launch_bounds__(CNN2_THREADS) void cnn_backward2_kernel(const unsig
   }
   for (int k = threadIdx.x; k < D.total; k += blockDim.x) G[k] = 0.0;
   __syncthreads();
-  const uint64_t n_tiles = (n_rows + CNN2_TILE - 1) / CNN2_TILE;
+  const uint64_t n_tiles = (n_rows + TILE - 1) / TILE;
+#ifdef CNN_STAMPS
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#endif
   const uint32_t lq = lane >> 4, lr = lane & 15u;     // MFMA lane coordinates: k / row-group index, row / column index
   const int n_mt = (4 * D.fw + 15) / 16;              // M tiles of the one-hot operand: rows (tap w, letter a < 4)
   for (uint64_t tile = (uint64_t)blockIdx.x * n_waves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * n_waves) {
-    const uint64_t i = tile * CNN2_TILE + ctx;
+    const uint64_t i = tile * TILE + ctx;
     const bool live = i < n_rows;
     // dead lanes: every letter "other" and a zero gradient row -> all their contributions are exact zeros
     unsigned long long code = 0;
 #pragma unroll
     for (int l = 0; l < 21; ++l) code |= 5ull << (3 * l);
     if (live) code = codes[i];
-    if (!hb) Cw[ctx] = code;
-    double t1[CNN2_JH], n1[CNN2_JH], e1[CNN2_JH], d1[CNN2_JH], dy1[CNN2_JH];
+    if (h == 0) Cw[ctx] = code;
+    double t1[JH], n1[JH], e1[JH], d1[JH], dy1[JH];
 #pragma unroll
-    for (int j = 0; j < CNN2_JH; ++j) t1[j] = 0.0;
+    for (int j = 0; j < JH; ++j) t1[j] = 0.0;
     double pr[5], gp[5];
 #pragma unroll
     for (int b = 0; b < 5; ++b) {
@@ -628,9 +656,9 @@ __global__ __launch_bounds__(CNN2_THREADS) void cnn_backward2_kernel(const unsig
       gp[b] = 0.0;
     }
     if (live) {
-      const double2 *src = reinterpret_cast<const double2 *>(t1_save + i * CNN_L1 + h * CNN2_JH);
+      const double2 *src = reinterpret_cast<const double2 *>(t1_save + i * CNN_L1 + h * JH);
 #pragma unroll
-      for (int j = 0; j < CNN2_JH / 2; ++j) {
+      for (int j = 0; j < JH / 2; ++j) {
         const double2 v = src[j];
         t1[2 * j] = v.x;
         t1[2 * j + 1] = v.y;
@@ -641,24 +669,24 @@ __global__ __launch_bounds__(CNN2_THREADS) void cnn_backward2_kernel(const unsig
         gp[b] = grad_prior[i * 5 + b];
       }
     }
-    // layer 1 (as cnn_layer1, the 16 units over the two halves)
+    // layer 1 (as cnn_layer1, the 16 units over the Q parts)
     double r1;
     {
       double mu = 0.0;
 #pragma unroll
-      for (int j = 0; j < CNN2_JH; ++j) mu += t1[j];
-      mu = cnn2_hsum(mu) * (1.0 / CNN_L1);
+      for (int j = 0; j < JH; ++j) mu += t1[j];
+      mu = cnnq_psum<Q>(mu) * (1.0 / CNN_L1);
       double var = 0.0;
 #pragma unroll
-      for (int j = 0; j < CNN2_JH; ++j) {
+      for (int j = 0; j < JH; ++j) {
         n1[j] = t1[j] - mu;
         var = __builtin_fma(n1[j], n1[j], var);
       }
-      r1 = cnn_rsqrt(cnn2_hsum(var) * (1.0 / CNN_L1) + CNN_LN_EPS);
+      r1 = cnn_rsqrt(cnnq_psum<Q>(var) * (1.0 / CNN_L1) + CNN_LN_EPS);
 #pragma unroll
-      for (int j = 0; j < CNN2_JH; ++j) {
+      for (int j = 0; j < JH; ++j) {
         n1[j] *= r1;
-        e1[j] = cnn_elu(__builtin_fma(Ps1[h * CNN2_JH + j], n1[j], Pb1[h * CNN2_JH + j]), exptab, d1[j]);
+        e1[j] = cnn_elu(__builtin_fma(Ps1[h * JH + j], n1[j], Pb1[h * JH + j]), exptab, d1[j]);
       }
     }
     // softmax backward
@@ -671,118 +699,123 @@ __global__ __launch_bounds__(CNN2_THREADS) void cnn_backward2_kernel(const unsig
     {
       double ma = 0.0, mb = 0.0;
 #pragma unroll
-      for (int j = 0; j < CNN2_JH; ++j) {
+      for (int j = 0; j < JH; ++j) {
         double de = 0.0;
 #pragma unroll
-        for (int b = 0; b < 5; ++b) de = __builtin_fma(PW2[(h * CNN2_JH + j) * 5 + b], dz[b], de);
+        for (int b = 0; b < 5; ++b) de = __builtin_fma(PW2[(h * JH + j) * 5 + b], dz[b], de);
         dy1[j] = de * d1[j];
-        const double dn = dy1[j] * Ps1[h * CNN2_JH + j];
+        const double dn = dy1[j] * Ps1[h * JH + j];
         t1[j] = dn;
         ma += dn;
         mb = __builtin_fma(dn, n1[j], mb);
       }
-      ma = cnn2_hsum(ma) * (1.0 / CNN_L1);
-      mb = cnn2_hsum(mb) * (1.0 / CNN_L1);
+      ma = cnnq_psum<Q>(ma) * (1.0 / CNN_L1);
+      mb = cnnq_psum<Q>(mb) * (1.0 / CNN_L1);
 #pragma unroll
-      for (int j = 0; j < CNN2_JH; ++j) t1[j] = r1 * (t1[j] - ma - n1[j] * mb);     // dT1
+      for (int j = 0; j < JH; ++j) t1[j] = r1 * (t1[j] - ma - n1[j] * mb);     // dT1
     }
-    // the 117 small gradient columns leave through four rounds of 32 staged columns.  d weights2[j][b] (column j 5 + b) and
-    // d intercept2 are adjacent in the parameter vector; half h owns columns [40 h, 40 h + 40): round rd stages its columns
-    // 16 rd .. 16 rd + 15 at staging column 16 h + (k - 16 rd); round 2 (8 columns per half) also carries d intercept2.
+    // the 117 small gradient columns leave through rounds of 32 staged columns.  d weights2[j][b] is column j 5 + b of the
+    // parameter vector; part h owns columns [W2Q h, W2Q h + W2Q): round rd stages its columns COLQ rd .. COLQ rd + COLQ - 1 at
+    // staging column COLQ h + (k - COLQ rd)
 #pragma unroll
     for (int rd = 0; rd < 3; ++rd) {
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int k = 16 * rd + kk;
-        if (k < 40) E[(h * 16u + kk) * CNN2_CS + ctx] = e1[k / 5] * dz[k % 5];
+      for (int kk = 0; kk < C::COLQ; ++kk) {
+        const int k = C::COLQ * rd + kk;
+        if (k < C::W2Q) E[(h * C::COLQ + kk) * CS + ctx] = e1[k / 5] * dz[k % 5];
       }
-      if (rd == 2 && !hb) {
-#pragma unroll
-        for (int b = 0; b < 5; ++b) E[(8 + b) * CNN2_CS + ctx] = dz[b];
-      }
-      const double cs = cnn2_colsum(E, lane);
-      const uint32_t c = lane & 31u, ch = c >> 4, ck = c & 15u, k = 16u * rd + ck;
-      if (k < 40u) cnn_lds_add(G + D.oW2 + 40 * (int)ch + (int)k, cs);
-      else if (rd == 2 && ch == 0u && ck >= 8u && ck < 13u) cnn_lds_add(G + D.ob2 + (int)ck - 8, cs);
+      const double cs = cnnq_colsum<Q>(E, lane);
+      const uint32_t c = lane & 31u, ch = c / C::COLQ, k = C::COLQ * rd + c % C::COLQ;
+      if (k < (uint32_t)C::W2Q) cnn_lds_add(G + D.oW2 + C::W2Q * (int)ch + (int)k, cs);
       __builtin_amdgcn_sched_barrier(0);   // one round's products at a time (hoisted together they spilled 116 registers)
     }
+    if (h == 0) {                          // d intercept2: five columns
 #pragma unroll
-    for (int j = 0; j < CNN2_JH; ++j) {
-      E[(h * CNN2_JH + j) * CNN2_CS + ctx] = dy1[j] * n1[j];
-      E[(16 + h * CNN2_JH + j) * CNN2_CS + ctx] = dy1[j];
+      for (int b = 0; b < 5; ++b) E[b * CS + ctx] = dz[b];
     }
     {
-      const double cs = cnn2_colsum(E, lane);
+      const double cs = cnnq_colsum<Q>(E, lane);
+      if ((lane & 31u) < 5u) cnn_lds_add(G + D.ob2 + (int)(lane & 31u), cs);
+    }
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+      E[(h * JH + j) * CS + ctx] = dy1[j] * n1[j];
+      E[(16 + h * JH + j) * CS + ctx] = dy1[j];
+    }
+    {
+      const double cs = cnnq_colsum<Q>(E, lane);
       const uint32_t c = lane & 31u;
       cnn_lds_add(G + (c < 16u ? D.os1 + (int)c : D.ob1 + (int)c - 16), cs);
     }
 #pragma unroll
-    for (int j = 0; j < CNN2_JH; ++j) T[(h * CNN2_JH + j) * CNN2_ES + ctx] = t1[j];
-    double tb[8], tb2[4][2];     // dT1 as the B operand of d weights1 (K = contexts) and of d e0 (K = j), the same for every position
+    for (int j = 0; j < JH; ++j) T[(h * JH + j) * ES + ctx] = t1[j];
+    double tb[KS], tb2[4][NT];     // dT1 as the B operand of d weights1 (K = contexts) and of d e0 (K = j), the same for every position
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) tb[ks] = T[lr * CNN2_ES + 4 * ks + lq];
+    for (int ks = 0; ks < KS; ++ks) tb[ks] = T[lr * ES + 4 * ks + lq];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) tb2[ks][nt] = T[(4 * ks + lq) * CNN2_ES + nt * 16 + lr];
+      for (int nt = 0; nt < NT; ++nt) tb2[ks][nt] = T[(4 * ks + lq) * ES + nt * 16 + lr];
+    CNN_STAMP(6)
     // positions
     for (int p = 0; p < D.P; ++p) {
-      double x[CNN2_FH], dy[CNN2_FH], dn[CNN2_FH];
-      // conv row of the lane's filters, layer norm over all 30 (the two dummy filters of the second half stay exact zeros)
+      double x[FH], dy[FH], dn[FH];
+      // conv row of the lane's filters, layer norm over all 30 (the two dummy slots of the last part stay exact zeros)
       double r0;
       {
 #pragma unroll
-        for (int f = 0; f < CNN2_FH; ++f) x[f] = 0.0;
+        for (int f = 0; f < FH; ++f) x[f] = 0.0;
         unsigned long long c = code >> (3 * p);
         for (int w = 0; w < D.fw; ++w) {
           const int a = (int)(c & 7ull);
-          const double2 *row = reinterpret_cast<const double2 *>(Fs + (w * 6 + (a < 5 ? a : 5)) * CNN_NF + h * CNN2_FH);
+          const double2 *row = reinterpret_cast<const double2 *>(Fs + (w * 6 + (a < 5 ? a : 5)) * CNN_NF + h * FH);
           c >>= 3;
 #pragma unroll
-          for (int f2 = 0; f2 < CNN2_FH / 2; ++f2) {
-            const double2 v = row[f2];      // filters 30, 31 of the second half: the next row's first words, discarded below
+          for (int f2 = 0; f2 < FH / 2; ++f2) {
+            const double2 v = row[f2];      // slots 30, 31 of the last part: the next row's first words, discarded below
             x[2 * f2] += v.x;
             x[2 * f2 + 1] += v.y;
           }
         }
-        if (hb) {
-          x[14] = 0.0;
-          x[15] = 0.0;
+        if (last) {
+          x[FH - 2] = 0.0;
+          x[FH - 1] = 0.0;
         }
         double m4[4] = {x[0], x[1], x[2], x[3]};
 #pragma unroll
-        for (int f = 4; f < CNN2_FH; ++f) m4[f & 3] += x[f];
-        const double mu = cnn2_hsum((m4[0] + m4[1]) + (m4[2] + m4[3])) * (1.0 / CNN_NF);
+        for (int f = 4; f < FH; ++f) m4[f & 3] += x[f];
+        const double mu = cnnq_psum<Q>((m4[0] + m4[1]) + (m4[2] + m4[3])) * (1.0 / CNN_NF);
         double v4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int f = 0; f < CNN2_FH; ++f) {
+        for (int f = 0; f < FH; ++f) {
           x[f] -= mu;
-          if (f >= 14 && hb) x[f] = 0.0;
+          if (f >= FH - 2 && last) x[f] = 0.0;
           v4[f & 3] = __builtin_fma(x[f], x[f], v4[f & 3]);
         }
-        r0 = cnn_rsqrt(cnn2_hsum((v4[0] + v4[1]) + (v4[2] + v4[3])) * (1.0 / CNN_NF) + CNN_LN_EPS);
+        r0 = cnn_rsqrt(cnnq_psum<Q>((v4[0] + v4[1]) + (v4[2] + v4[3])) * (1.0 / CNN_NF) + CNN_LN_EPS);
 #pragma unroll
-        for (int f = 0; f < CNN2_FH; ++f) x[f] *= r0;
+        for (int f = 0; f < FH; ++f) x[f] *= r0;
       }
-      // the lane's 16 scales / intercepts of this position (the dummies of the second half read two words past the row: unused)
-      const double *s0 = Ps0 + p * CNN_NF + h * CNN2_FH, *b0 = Pb0 + p * CNN_NF + h * CNN2_FH;
+      // the lane's scales / intercepts of this position (the dummies of the last part read two words past the row: unused)
+      const double *s0 = Ps0 + p * CNN_NF + h * FH, *b0 = Pb0 + p * CNN_NF + h * FH;
       const double *__restrict__ W1 = params + D.oW1 + p * CNN_NF * CNN_L1;
       // pass A: activations e0 (staged as the A operand of d weights1[p]) and elu'; dy holds elu' until pass B
 #pragma unroll
-      for (int f = 0; f < CNN2_FH; ++f) {
+      for (int f = 0; f < FH; ++f) {
         double dv;
         const double e = cnn_elu(__builtin_fma(s0[f], x[f], b0[f]), exptab, dv);
-        if (f < 14 || !hb) E[(h * CNN2_FH + f) * CNN2_ES + ctx] = e;
-        dy[f] = (f >= 14 && hb) ? 0.0 : dv;
+        if (f < FH - 2 || !last) E[(h * FH + f) * ES + ctx] = e;
+        dy[f] = (f >= FH - 2 && last) ? 0.0 : dv;
       }
+      CNN_STAMP(0)
       // d weights1[p][f][j] += sum_ctx e0[ctx][f] dT1[ctx][j]
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         cnn_d4 acc = {0.0, 0.0, 0.0, 0.0};
         const bool row_in = mt * 16 + (int)lr < CNN_NF;
-        const double *arow = E + (row_in ? mt * 16 + (int)lr : 0) * CNN2_ES + lq;
+        const double *arow = E + (row_in ? mt * 16 + (int)lr : 0) * ES + lq;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
           const double a = row_in ? arow[4 * ks] : 0.0;
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tb[ks], acc, 0, 0, 0);
         }
@@ -793,8 +826,9 @@ __global__ __launch_bounds__(CNN2_THREADS) void cnn_backward2_kernel(const unsig
           if (f < CNN_NF) cnn_lds_add(g + f * CNN_L1 + lr, acc[r]);
         }
       }
+      CNN_STAMP(1)
       // pass B: d e0[f][ctx] = sum_j weights1[p][f][j] dT1[ctx][j] as MFMA products (rows f, columns ctx, K = j), the
-      // result handed back to the (context, half) lanes through the staging buffer
+      // result handed back to the (context, part) lanes through the staging buffer
       {
         double wa[2][4];
 #pragma unroll
@@ -804,17 +838,17 @@ __global__ __launch_bounds__(CNN2_THREADS) void cnn_backward2_kernel(const unsig
             const int f = mt * 16 + (int)lr;
             wa[mt][ks] = f < CNN_NF ? W1[f * CNN_L1 + 4 * ks + (int)lq] : 0.0;
           }
-        cnn_d4 c[2][2];
+        cnn_d4 c[2][NT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) c[mt][nt] = cnn_d4{0.0, 0.0, 0.0, 0.0};
+          for (int nt = 0; nt < NT; ++nt) c[mt][nt] = cnn_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) c[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[mt][ks], tb2[ks][nt], c[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) c[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[mt][ks], tb2[ks][nt], c[mt][nt], 0, 0, 0);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -822,54 +856,57 @@ __global__ __launch_bounds__(CNN2_THREADS) void cnn_backward2_kernel(const unsig
             const int f = mt * 16 + (int)lq + 4 * r;
             if (f < CNN_NF) {
 #pragma unroll
-              for (int nt = 0; nt < 2; ++nt) E[f * CNN2_ES + nt * 16 + lr] = c[mt][nt][r];
+              for (int nt = 0; nt < NT; ++nt) E[f * ES + nt * 16 + lr] = c[mt][nt][r];
             }
           }
       }
+      CNN_STAMP(2)
       double a0[2] = {0.0, 0.0}, a1[2] = {0.0, 0.0};
 #pragma unroll
-      for (int f = 0; f < CNN2_FH; ++f) {
-        const double de0 = (f < 14 || !hb) ? E[(h * CNN2_FH + f) * CNN2_ES + ctx] : 0.0;
+      for (int f = 0; f < FH; ++f) {
+        const double de0 = (f < FH - 2 || !last) ? E[(h * FH + f) * ES + ctx] : 0.0;
         dy[f] *= de0;
         dn[f] = dy[f] * s0[f];
         a0[f & 1] += dn[f];
         a1[f & 1] = __builtin_fma(dn[f], x[f], a1[f & 1]);
       }
-      const double ma0 = cnn2_hsum(a0[0] + a0[1]) * (1.0 / CNN_NF), ma1 = cnn2_hsum(a1[0] + a1[1]) * (1.0 / CNN_NF);
-      // d scale0[p], d intercept0[p]: column sums of dy * n0 and dy (staging columns = filters; 30, 31 carry zeros)
+      const double ma0 = cnnq_psum<Q>(a0[0] + a0[1]) * (1.0 / CNN_NF), ma1 = cnnq_psum<Q>(a1[0] + a1[1]) * (1.0 / CNN_NF);
+      // d scale0[p], d intercept0[p]: column sums of dy * n0 and dy (staging columns = filter slots; 30, 31 carry zeros)
 #pragma unroll
-      for (int f = 0; f < CNN2_FH; ++f) E[(h * CNN2_FH + f) * CNN2_CS + ctx] = dy[f] * x[f];
+      for (int f = 0; f < FH; ++f) E[(h * FH + f) * CS + ctx] = dy[f] * x[f];
       {
-        const double cs = cnn2_colsum(E, lane);
+        const double cs = cnnq_colsum<Q>(E, lane);
         if ((lane & 31u) < (uint32_t)CNN_NF) cnn_lds_add(G + D.os0 + p * CNN_NF + (int)(lane & 31u), cs);
       }
 #pragma unroll
-      for (int f = 0; f < CNN2_FH; ++f) E[(h * CNN2_FH + f) * CNN2_CS + ctx] = dy[f];
+      for (int f = 0; f < FH; ++f) E[(h * FH + f) * CS + ctx] = dy[f];
       {
-        const double cs = cnn2_colsum(E, lane);
+        const double cs = cnnq_colsum<Q>(E, lane);
         if ((lane & 31u) < (uint32_t)CNN_NF) cnn_lds_add(G + D.ob0 + p * CNN_NF + (int)(lane & 31u), cs);
       }
+      CNN_STAMP(3)
       // layer-norm backward -> d conv[p][f], staged as the B operand of d filters
       {
         unsigned long long c = code >> (3 * p);
         bool any_start = false;
         for (int w = 0; w < D.fw; ++w) any_start |= ((c >> (3 * w)) & 7ull) == 4ull;
 #pragma unroll
-        for (int f = 0; f < CNN2_FH; ++f) {
-          const double dc = (f >= 14 && hb) ? 0.0 : r0 * (dn[f] - ma0 - x[f] * ma1);
-          if (f < 14 || !hb) E[(h * CNN2_FH + f) * CNN2_ES + ctx] = dc;
+        for (int f = 0; f < FH; ++f) {
+          const double dc = (f >= FH - 2 && last) ? 0.0 : r0 * (dn[f] - ma0 - x[f] * ma1);
+          if (f < FH - 2 || !last) E[(h * FH + f) * ES + ctx] = dc;
           dy[f] = dc;
         }
         if (any_start) {   // the start symbol '[' (rare: only contexts at a sequence start) bypasses the MFMA rows
           for (int w = 0; w < D.fw; ++w)
             if (((c >> (3 * w)) & 7ull) == 4ull) {
-              double *gF = G + D.oF + (w * 5 + 4) * CNN_NF + h * CNN2_FH;
+              double *gF = G + D.oF + (w * 5 + 4) * CNN_NF + h * FH;
 #pragma unroll
-              for (int f = 0; f < CNN2_FH; ++f)
-                if (f < 14 || !hb) cnn_lds_add(gF + f, dy[f]);
+              for (int f = 0; f < FH; ++f)
+                if (f < FH - 2 || !last) cnn_lds_add(gF + f, dy[f]);
             }
         }
       }
+      CNN_STAMP(4)
       // d filters[w][a][f] += sum_ctx [letter_{p+w}(ctx) == a] d conv[ctx][f],  rows (w, a < 4), two column tiles of f
       for (int mt = 0; mt < n_mt; mt += 2) {      // two row tiles per pass share the B operand reads
         cnn_d4 acc[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
@@ -884,11 +921,11 @@ __global__ __launch_bounds__(CNN2_THREADS) void cnn_backward2_kernel(const unsig
           sh[u] = row_ok[u] ? 3 * (p + w) : 0;
         }
         const bool col1_in = 16 + (int)lr < CNN_NF;
-        const double *b1row = E + (col1_in ? 16 + (int)lr : 0) * CNN2_ES + lq;
+        const double *b1row = E + (col1_in ? 16 + (int)lr : 0) * ES + lq;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
           const unsigned long long cc = Cw[4 * ks + lq];
-          const double b0v = E[lr * CNN2_ES + 4 * ks + lq], b1v = col1_in ? b1row[4 * ks] : 0.0;
+          const double b0v = E[lr * ES + 4 * ks + lq], b1v = col1_in ? b1row[4 * ks] : 0.0;
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const double a = (row_ok[u] && ((cc >> sh[u]) & 7ull) == want[u]) ? 1.0 : 0.0;
@@ -908,8 +945,13 @@ __global__ __launch_bounds__(CNN2_THREADS) void cnn_backward2_kernel(const unsig
             }
           }
       }
+      CNN_STAMP(5)
     }
   }
+#ifdef CNN_STAMPS
+  if (lane == 0)
+    for (int k = 0; k < 8; ++k) atomicAdd(&cnn_stamp_sums[k], tph[k]);
+#endif
   __syncthreads();
   for (int k = threadIdx.x; k < D.total; k += blockDim.x) partials[(size_t)blockIdx.x * D.total + k] = G[k];
 }

@@ -1,4 +1,4 @@
-"""Dev helper: cnn backward, both tile forms (BEAR_CNN_BACKWARD=1 forces the one-wave-per-SIMD kernel), results compared."""
+"""Dev helper: cnn backward, both tile forms (BEAR_CNN_BACKWARD=1: 64-context tiles, one wave per SIMD), results compared."""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 if len(sys.argv) > 1:
@@ -27,5 +27,7 @@ else:
     import torch
     for form in ("1", "2"):
         subprocess.run([sys.executable, __file__, "1e7", "/tmp/cnn_ab_%s.pt" % form], env=dict(os.environ, BEAR_CNN_BACKWARD=form), check=True)
-    a, b = torch.load("/tmp/cnn_ab_1.pt"), torch.load("/tmp/cnn_ab_2.pt")
-    print("max |diff| / max |grad| = %.3e" % float((a - b).abs().max() / a.abs().max()))
+    a = torch.load("/tmp/cnn_ab_1.pt")
+    for form in ("2",):
+        b = torch.load("/tmp/cnn_ab_%s.pt" % form)
+        print("form %s vs 1: max |diff| / max |grad| = %.3e" % (form, float((a - b).abs().max() / a.abs().max())))
