@@ -1212,7 +1212,8 @@ int bear_cnn_forward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows
   uint64_t blocks = (n_rows + CNN_THREADS - 1) / CNN_THREADS;
   if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
   hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), lds, static_cast<hipStream_t>(stream),
-                     reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, prior, t1_save);
+                     reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, prior, t1_save,
+                     static_cast<const pln_tile *>(nullptr), static_cast<const uint16_t *>(nullptr), (n_rows + 63) / 64);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
@@ -1256,9 +1257,10 @@ static int cnn_backward_grid(bear_ws *ws, const cnn_dims &D, uint64_t n_rows, in
   return BEAR_OK;
 }
 
+// live_plan [nullable]: a five-column plan of the table -- the part kernel then walks its lists of contexts that hold counts
 static int launch_cnn_backward(bear_ws *ws, const cnn_dims &D, const uint64_t *kmer_code, uint64_t n_rows, int filter_width,
                                const double *params, const double *t1_save, const double *prior, const double *grad_prior,
-                               double *grad_params, hipStream_t s, int may_alloc) {
+                               double *grad_params, hipStream_t s, int may_alloc, const bear_plan *live_plan = nullptr) {
   int waves = 0;
   size_t lds = 0;
   uint64_t blocks = 0;
@@ -1268,9 +1270,12 @@ static int launch_cnn_backward(bear_ws *ws, const cnn_dims &D, const uint64_t *k
   const void *fn = parts2 ? reinterpret_cast<const void *>(cnn_backward_parts_kernel<2>) : reinterpret_cast<const void *>(cnn_backward_kernel);
   if (may_alloc) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned long long *kc = reinterpret_cast<const unsigned long long *>(kmer_code);
-  if (parts2)
+  if (parts2) {
+    const bool lists = live_plan && live_plan->live;
+    const uint64_t groups = lists ? live_plan->n_tiles : (n_rows + cnnq<2>::TILE - 1) / cnnq<2>::TILE;
     hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)blocks), dim3(64 * waves), lds, s, kc, n_rows, D, params, t1_save, prior,
-                       grad_prior, ws->cnn_partials);
+                       grad_prior, ws->cnn_partials, lists ? live_plan->tiles : nullptr, lists ? live_plan->live : nullptr, groups);
+  }
   else
     hipLaunchKernelGGL(cnn_backward_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, s, kc, n_rows, D, params, t1_save, prior,
                        grad_prior, ws->cnn_partials);
@@ -1321,16 +1326,19 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
   hipLaunchKernelGGL(net_params_kernel, dim3(1), dim3(64), 0, s, theta, eps, ws->ref_prm);
   {
     const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF);
-    uint64_t blocks = (n_rows + CNN_THREADS - 1) / CNN_THREADS;
+    // only the contexts that hold training counts: the DM kernel reads nobody else's prior row (their gradient rows are zero)
+    const uint64_t groups = plan->live ? plan->n_tiles : (n_rows + 63) / 64;
+    uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
     if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
     hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), lds, s,
-                       reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, prior_buf, t1_buf);
+                       reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, prior_buf, t1_buf,
+                       plan->live ? plan->tiles : nullptr, plan->live, groups);
   }
   bear_params dummy;
   memset(&dummy, 0, sizeof(dummy));
   st = launch_prior_plan_grad(ws, plan, prior_buf, dummy, ws->ref_prm, train_ar, 1, packed, grad_rows_buf, s);   // softmax rows: normalised
   if (st != BEAR_OK) return st;
-  return launch_cnn_backward(ws, D, kmer_code, n_rows, filter_width, params, t1_buf, prior_buf, grad_rows_buf, packed + 2, s, 0);
+  return launch_cnn_backward(ws, D, kmer_code, n_rows, filter_width, params, t1_buf, prior_buf, grad_rows_buf, packed + 2, s, 0, plan);
 }
 
 int bear_net_cnn_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,

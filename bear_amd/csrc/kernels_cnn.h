@@ -24,6 +24,7 @@
 //   intercept2 [5] | scale0 [P][nf] | scale1 [l1]
 #pragma once
 #include "bear_common.h"
+#include "kernels_plan.h"   // pln_tile, PLN_LIVE_STRIDE: the training step runs over the plan's lists of contexts that hold counts
 
 #define CNN_NF 30
 #define CNN_L1 16
@@ -148,16 +149,25 @@ __device__ __forceinline__ double cnn_layer1(const double (&t1)[CNN_L1], const d
 // ------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(CNN_THREADS) void cnn_forward_kernel(const unsigned long long *__restrict__ codes, uint64_t n_rows,
                                                                    cnn_dims D, const double *__restrict__ params,
-                                                                   double *__restrict__ prior, double *__restrict__ t1_save) {
+                                                                   double *__restrict__ prior, double *__restrict__ t1_save,
+                                                                   const pln_tile *__restrict__ tiles, const uint16_t *__restrict__ live_lists,
+                                                                   uint64_t n_groups) {
   extern __shared__ __attribute__((aligned(16))) double cnn_lds[];
   double *exptab = cnn_lds;                       // [128]
   double *Fs = cnn_lds + BEAR_EXPTAB_N;           // [fw][6][nf]
   if (threadIdx.x < BEAR_EXPTAB_N) exptab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / BEAR_EXPTAB_N));
   cnn_stage_filters(Fs, params, D);
   __syncthreads();
-  for (uint64_t base = (uint64_t)blockIdx.x * CNN_THREADS; base < n_rows; base += (uint64_t)gridDim.x * CNN_THREADS) {
-    const uint64_t i = base + threadIdx.x;
-    const bool live = i < n_rows;
+  // A wave walks groups of contexts, 64 at a time: without lists, group g = rows [64 g, 64 g + 64); with the plan's lists
+  // (the training step) group g = plan tile g and only its contexts that hold counts -- nothing reads the others' rows.
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = CNN_THREADS / 64;
+  for (uint64_t g = (uint64_t)blockIdx.x * n_waves + wave; g < n_groups; g += (uint64_t)gridDim.x * n_waves) {
+    const uint16_t *lst = live_lists ? live_lists + g * PLN_LIVE_STRIDE : nullptr;
+    const uint64_t base = lst ? tiles[g].row0 : g * 64;
+    const uint32_t cnt = lst ? (uint32_t)lst[0] : (uint32_t)(n_rows - base < 64 ? n_rows - base : 64);
+   for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
+    const bool live = c0 + lane < cnt;
+    const uint64_t i = base + (lst ? (uint64_t)lst[1 + (live ? c0 + lane : 0u)] : (uint64_t)lane);
     const unsigned long long code = live ? codes[i] : ~0ull;
     double t1[CNN_L1];
 #pragma unroll
@@ -219,6 +229,7 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_forward_kernel(const unsigned
         for (int j = 0; j < CNN_L1 / 2; ++j) o[j] = make_double2(t1[2 * j], t1[2 * j + 1]);
       }
     }
+   }
   }
 }
 
@@ -599,7 +610,9 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
                                                                                   const double *__restrict__ t1_save,
                                                                                   const double *__restrict__ prior,
                                                                                   const double *__restrict__ grad_prior,
-                                                                                  double *__restrict__ partials) {
+                                                                                  double *__restrict__ partials,
+                                                                                  const pln_tile *__restrict__ tiles,
+                                                                                  const uint16_t *__restrict__ live_lists, uint64_t n_groups) {
   using C = cnnq<Q>;
   constexpr int TILE = C::TILE, FH = C::FH, JH = C::JH, ES = C::ES, CS = C::CS, KS = C::KS, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) double cnn_lds[];
@@ -631,15 +644,20 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
   }
   for (int k = threadIdx.x; k < D.total; k += blockDim.x) G[k] = 0.0;
   __syncthreads();
-  const uint64_t n_tiles = (n_rows + TILE - 1) / TILE;
 #ifdef CNN_STAMPS
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #endif
   const uint32_t lq = lane >> 4, lr = lane & 15u;     // MFMA lane coordinates: k / row-group index, row / column index
   const int n_mt = (4 * D.fw + 15) / 16;              // M tiles of the one-hot operand: rows (tap w, letter a < 4)
-  for (uint64_t tile = (uint64_t)blockIdx.x * n_waves + wave; tile < n_tiles; tile += (uint64_t)gridDim.x * n_waves) {
-    const uint64_t i = tile * TILE + ctx;
-    const bool live = i < n_rows;
+  // A wave walks groups of contexts, TILE at a time: without lists, group g = rows [TILE g, TILE g + TILE); with the plan's
+  // lists (the training step) group g = plan tile g and only its contexts that hold counts (the others' gradient rows are zero)
+  for (uint64_t g = (uint64_t)blockIdx.x * n_waves + wave; g < n_groups; g += (uint64_t)gridDim.x * n_waves) {
+    const uint16_t *lst = live_lists ? live_lists + g * PLN_LIVE_STRIDE : nullptr;
+    const uint64_t base = lst ? tiles[g].row0 : g * TILE;
+    const uint32_t cnt = lst ? (uint32_t)lst[0] : (uint32_t)(n_rows - base < (uint64_t)TILE ? n_rows - base : (uint64_t)TILE);
+   for (uint32_t c0 = 0; c0 < cnt; c0 += TILE) {
+    const bool live = c0 + ctx < cnt;
+    const uint64_t i = base + (lst ? (uint64_t)lst[1 + (live ? c0 + ctx : 0u)] : (uint64_t)ctx);
     // dead lanes: every letter "other" and a zero gradient row -> all their contributions are exact zeros
     unsigned long long code = 0;
 #pragma unroll
@@ -947,6 +965,7 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
       }
       CNN_STAMP(5)
     }
+   }
   }
 #ifdef CNN_STAMPS
   if (lane == 0)

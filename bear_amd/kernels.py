@@ -632,5 +632,6 @@ def cnn_step_buffers(n_rows, lag, filter_width, device, ws=None):
     with torch.cuda.device(device):
         _lib.check(_lib.lib().bear_cnn_reserve(ws.handle, int(n_rows), int(lag), int(filter_width), CNN_NUM_FILTERS, CNN_LAYER1_WIDTH),
                    "bear_cnn_reserve")
-    return (torch.empty((n_rows, 5), dtype=torch.float64, device=device), torch.empty((n_rows, CNN_LAYER1_WIDTH), dtype=torch.float64, device=device),
-            torch.empty((n_rows, 5), dtype=torch.float64, device=device))
+    # zeros: the step only fills the rows of contexts that hold training counts (nothing reads the others: kept finite)
+    return (torch.zeros((n_rows, 5), dtype=torch.float64, device=device), torch.zeros((n_rows, CNN_LAYER1_WIDTH), dtype=torch.float64, device=device),
+            torch.zeros((n_rows, 5), dtype=torch.float64, device=device))

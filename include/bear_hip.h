@@ -159,7 +159,9 @@ int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_
  *   train_ar != 0: theta[0] = h_signed gets no gradient (bear_net.py:194-196)
  *   loss_buf [dev, nullable] double [loss_cap], indexed by the step counter adam_t
  *   the cnn step borrows per-context buffers prior_buf [n,5], t1_buf [n,16], grad_rows_buf [n,5]; call bear_cnn_reserve once
- *   before capturing (it sizes the library's block-partial buffer; nothing allocates inside a step).
+ *   before capturing (it sizes the library's block-partial buffer; nothing allocates inside a step).  The step evaluates the
+ *   AR function only for the contexts that hold training counts (the plan's lists: nothing else enters the ELBO or a gradient);
+ *   the other rows of prior_buf / t1_buf are left as they were -- hand over initialised (e.g. zeroed) buffers.
  */
 int bear_train_apply_f64(double *theta, int n_theta, const double *packed, double *adam_m, double *adam_v, double *adam_t,
                          double learning_rate, double scale, int train_ar, double *loss_buf, uint64_t loss_cap, void *stream);
