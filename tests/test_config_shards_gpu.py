@@ -76,3 +76,23 @@ def test_config4_rank_shard_cnn_step_and_heldout():
     ll_parts = sum(float(r[0]) for r in res)
     assert abs(ll_parts - float(whole[0])) <= 1e-10 * abs(float(whole[0]))
     assert abs(np.exp(-ll_parts / total) - float(whole[3])) <= 1e-9 * float(whole[3])
+
+
+def test_config3_full_size_on_one_gpu_equals_its_eight_shards():
+    """configs[3] at its full size -- 1e9 contexts, 40 GB of count rows -- fits one MI355X: the whole table's packed vector equals
+    the sum over the eight rank shards of the 8-GPU job, each through its own reference-aware plan (what the all-reduce adds)."""
+    import torch
+    from bear_amd import kernels
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(dev).total_memory < 120e9:
+        pytest.skip("needs ~60 GB of HBM")
+    n_all, world = 1_000_000_000, 8
+    args = (0.2, float(np.log(1 / 30)), float(-np.log(100)))
+    t = kernels.synth_counts(20211012, 0, n_all, dev, want=("train", "ref"))
+    whole = kernels.dm_ref_planned(kernels.Plan(t["train"], 4, ref=t["ref"]), t["ref"], *args).cpu().numpy()
+    n = n_all // world
+    parts = np.zeros(4)
+    for r in range(world):
+        tr, rf = t["train"][r * n:(r + 1) * n], t["ref"][r * n:(r + 1) * n]
+        parts += kernels.dm_ref_planned(kernels.Plan(tr, 4, ref=rf), rf, *args).cpu().numpy()
+    assert np.all(np.isfinite(whole)) and np.allclose(parts, whole, rtol=1e-12)
