@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("BEAR_AMD_LIB") or os.path.join(_HERE, "libbear_hip.so
 
 SYMBOLS = [
     "bear_abi_version", "bear_strerror", "bear_last_hip_error", "bear_ws_create", "bear_ws_destroy",
-    "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_dm_items_f64", "bear_eval_f64", "bear_bmm_f64", "bear_pack_kmers_u64", "bear_linear_index_u64", "bear_parse_sparse_counts", "bear_dm_linear_f64",
+    "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_dm_items_f64", "bear_eval_f64", "bear_bmm_f64", "bear_pack_kmers_u64", "bear_linear_index_u64", "bear_parse_sparse_counts", "bear_plan_tile_count", "bear_plan_tile_info", "bear_dm_linear_f64",
     "bear_plan_create", "bear_plan_create_ref", "bear_plan_destroy", "bear_plan_bytes", "bear_dm_prior_plan_f64", "bear_dm_prior_plan_grad_f64", "bear_dm_ref_plan_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
     "bear_count_rows", "bear_parse_counts_tsv", "bear_log_gamma_f64", "bear_logdir_sample_f64",
     "bear_stat_source", "bear_cache_write", "bear_cache_info", "bear_cache_read", "bear_shuffle_rows", "bear_shuffle_source_row",
@@ -68,6 +68,9 @@ def _load():
     L.bear_eval_f64.argtypes = [vp, vp, vp, vp, u64, vp, cint, cint, vp, cint, dbl, u64, u64, vp, vp]
     L.bear_pack_kmers_u64.argtypes = [vp, u64, cint, vp, vp]
     L.bear_linear_index_u64.argtypes = [vp, u64, cint, vp, vp]
+    L.bear_plan_tile_count.argtypes = [vp]
+    L.bear_plan_tile_count.restype = u64
+    L.bear_plan_tile_info.argtypes = [vp, u64, u64, vp, vp, vp, vp]
     L.bear_parse_sparse_counts.argtypes = [ctypes.c_char_p, cint, cint, cint, u64, u64, vp, vp, ctypes.POINTER(u64)]
     L.bear_dm_linear_f64.argtypes = [vp, vp, vp, vp, vp, cint, u64, dbl, dbl, cint, vp, vp, vp]
     L.bear_bmm_f64.argtypes = [vp, vp, u64, vp, cint, vp, vp]

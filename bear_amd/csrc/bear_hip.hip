@@ -355,15 +355,18 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
     e = hipGetLastError();
   }
   unsigned long long h_cnt[3] = {0, 0, 0};
-  if (e == hipSuccess) {
+  if (e == hipSuccess) e = hipMemcpy(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
+  // ---- tiles: greedy cut so that a tile holds <= PLN_NI items and <= PLN_RMAX contexts -- on the device (plan_cut_*_kernel);
+  // BEAR_PLAN_CUT=host keeps the sequential host loop over the per-group counters (the definition; used by the tests to compare)
+  uint64_t off16 = 0, n_tiles = 0;
+  const char *cut_env = getenv("BEAR_PLAN_CUT");
+  const bool host_cut = cut_env && cut_env[0] == 'h';
+  if (e == hipSuccess && host_cut) {
     h_quad = (uint8_t *)malloc(3 * n_quads);
     if (!h_quad) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpy(h_quad, d_quad, 3 * n_quads, hipMemcpyDeviceToHost);
   }
-  if (e == hipSuccess) e = hipMemcpy(h_quad, d_quad, 3 * n_quads, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
-  // ---- tiles: greedy cut so that a tile holds <= PLN_NI items and <= PLN_RMAX contexts
-  uint64_t off16 = 0;
-  if (e == hipSuccess) {
+  if (e == hipSuccess && host_cut) {
     uint64_t q = 0;
     while (q < n_quads) {
       uint32_t items = 0, rows = 0, hcol = 0, hrow = 0;
@@ -394,33 +397,68 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
       }
       tiles.push_back(ti);
     }
+    n_tiles = tiles.size();
   }
   free(h_quad);
+  if (e == hipSuccess && !host_cut) {
+    const uint64_t n_chunks = (n_quads + PLN_CUT_CHUNK - 1) / PLN_CUT_CHUNK;
+    uint32_t *d_walk = nullptr;
+    uint64_t *d_entry = nullptr;           // [n_chunks] entry | [n_chunks] base
+    unsigned long long *d_meta = nullptr, h_meta[3] = {0, 0, 0};
+    e = hipMalloc(&d_walk, sizeof(uint32_t) * n_chunks * PLN_CUT_SPAN);
+    if (e == hipSuccess) e = hipMalloc(&d_entry, sizeof(uint64_t) * 2 * n_chunks);
+    if (e == hipSuccess) e = hipMalloc(&d_meta, sizeof(h_meta));
+    if (e == hipSuccess) e = hipMemset(d_meta, 0, sizeof(h_meta));
+    if (e == hipSuccess) {
+      const uint64_t wb = (n_chunks * PLN_CUT_SPAN + 255) / 256;
+      hipLaunchKernelGGL(plan_cut_walk_kernel, dim3((unsigned)wb), dim3(256), 0, 0, d_quad, n_quads, n_chunks, d_walk);
+      hipLaunchKernelGGL(plan_cut_chain_kernel, dim3(1), dim3(1), 0, 0, d_walk, n_chunks, d_entry, d_entry + n_chunks, d_meta);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h_meta, d_meta, sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    n_tiles = h_meta[0];
+    // + PLN_DESC_PAD zeroed descriptors: the kernels fetch descriptors 32 at a time (1 KiB LDS-DMA pieces)
+    if (e == hipSuccess) e = hipMalloc(&p->tiles, sizeof(pln_tile) * (n_tiles + PLN_DESC_PAD));
+    if (e == hipSuccess) e = hipMemset(p->tiles, 0, sizeof(pln_tile) * (n_tiles + PLN_DESC_PAD));
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(plan_cut_write_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, 0, d_quad, n_quads, n_rows, ncol,
+                         n_chunks, d_entry, d_entry + n_chunks, p->tiles);
+      hipLaunchKernelGGL(plan_cut_offsets_kernel, dim3(1), dim3(1024), 0, 0, p->tiles, n_tiles, d_meta);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(h_meta, d_meta, sizeof(h_meta), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && h_meta[2]) e = hipErrorOutOfMemory;     // plan stream beyond 2^32 16-byte units
+    off16 = h_meta[1];
+    (void)hipFree(d_walk);
+    (void)hipFree(d_entry);
+    (void)hipFree(d_meta);
+  }
   (void)hipFree(d_quad);
-  p->n_tiles = tiles.size();
+  p->n_tiles = n_tiles;
   const uint64_t stream_bytes = off16 * 16 + 1024;  // slack: a DMA piece may be issued for a partial KiB
   for (int k = 0; k < 3; ++k) p->n_heavy[k] = h_cnt[k];
-  // + PLN_DESC_PAD zeroed descriptors: the kernels fetch descriptors 32 at a time (1 KiB LDS-DMA pieces)
-  if (e == hipSuccess) e = hipMalloc(&p->tiles, sizeof(pln_tile) * (tiles.size() + PLN_DESC_PAD));
-  if (e == hipSuccess) e = hipMemset(p->tiles, 0, sizeof(pln_tile) * (tiles.size() + PLN_DESC_PAD));
+  if (host_cut) {   // + PLN_DESC_PAD zeroed descriptors: the kernels fetch descriptors 32 at a time (1 KiB LDS-DMA pieces)
+    if (e == hipSuccess) e = hipMalloc(&p->tiles, sizeof(pln_tile) * (tiles.size() + PLN_DESC_PAD));
+    if (e == hipSuccess) e = hipMemset(p->tiles, 0, sizeof(pln_tile) * (tiles.size() + PLN_DESC_PAD));
+    if (e == hipSuccess) e = hipMemcpy(p->tiles, tiles.data(), sizeof(pln_tile) * tiles.size(), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) e = hipMalloc(&p->stream, stream_bytes);
   if (e == hipSuccess) e = hipMemset(p->stream, 0, stream_bytes);
   if (e == hipSuccess && h_cnt[0]) e = hipMalloc(&p->heavy_col, sizeof(pln_heavy_col) * h_cnt[0]);
   if (e == hipSuccess && h_cnt[1]) e = hipMalloc(&p->heavy_row, sizeof(pln_heavy_row) * h_cnt[1]);
   if (e == hipSuccess && h_cnt[2]) e = hipMalloc(&p->heavy_stop, sizeof(uint64_t) * h_cnt[2]);
-  if (e == hipSuccess) e = hipMemcpy(p->tiles, tiles.data(), sizeof(pln_tile) * tiles.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
-    const uint64_t nt = tiles.size();
+    const uint64_t nt = n_tiles;
     const int grid = (int)(nt < (uint64_t)ws->num_cu * 2 ? nt : (uint64_t)ws->num_cu * 2);
     hipLaunchKernelGGL(plan_fill_kernel, dim3(grid), dim3(1024), 0, 0, counts, n_rows, ncol, p->tiles, nt, p->stream,
                        p->heavy_col, p->heavy_row, p->heavy_stop, d_cnt + 3);
     e = hipGetLastError();
   }
-  const uint64_t live_bytes = ncol == 5 ? sizeof(uint16_t) * PLN_LIVE_STRIDE * (tiles.size() + 1) : 0;   // + 1: DMA pieces are whole KiB
+  const uint64_t live_bytes = ncol == 5 ? sizeof(uint16_t) * PLN_LIVE_STRIDE * (n_tiles + 1) : 0;   // + 1: DMA pieces are whole KiB
   if (e == hipSuccess && live_bytes) e = hipMalloc(&p->live, live_bytes);
   if (e == hipSuccess && live_bytes) e = hipMemset(p->live, 0, live_bytes);
   if (e == hipSuccess && live_bytes) {
-    const uint64_t nt = tiles.size();
+    const uint64_t nt = n_tiles;
     const int grid = (int)(nt < (uint64_t)ws->num_cu * 2 ? nt : (uint64_t)ws->num_cu * 2);
     hipLaunchKernelGGL(plan_live_kernel, dim3(grid), dim3(1024), 0, 0, p->tiles, nt, p->stream, p->live);
     e = hipGetLastError();
@@ -435,7 +473,7 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
     plan_free(p);
     return e == hipErrorOutOfMemory ? BEAR_ERR_NOMEM : BEAR_ERR_HIP;
   }
-  p->bytes = stream_bytes + live_bytes + sizeof(pln_tile) * tiles.size() + sizeof(pln_heavy_col) * h_cnt[0] +
+  p->bytes = stream_bytes + live_bytes + sizeof(pln_tile) * n_tiles + sizeof(pln_heavy_col) * h_cnt[0] +
              sizeof(pln_heavy_row) * h_cnt[1] + sizeof(uint64_t) * h_cnt[2];
   *out = p;
   return BEAR_OK;
@@ -452,6 +490,31 @@ int bear_plan_destroy(bear_plan *plan) {
 }
 
 uint64_t bear_plan_bytes(const bear_plan *plan) { return plan ? plan->bytes : 0; }
+
+uint64_t bear_plan_tile_count(const bear_plan *plan) { return plan ? plan->n_tiles : 0; }
+
+int bear_plan_tile_info(const bear_plan *plan, uint64_t first, uint64_t count, uint64_t *row0, uint32_t *rows, uint32_t *items,
+                        uint64_t *stream_offset) {
+  if (!plan || first + count > plan->n_tiles || (count && (!row0 || !rows || !items || !stream_offset))) return BEAR_ERR_INVALID_ARG;
+  if (!count) return BEAR_OK;
+  std::vector<pln_tile> h(count);
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(plan->device);
+  const hipError_t e = hipMemcpy(h.data(), plan->tiles + first, sizeof(pln_tile) * count, hipMemcpyDeviceToHost);
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    return BEAR_ERR_HIP;
+  }
+  for (uint64_t k = 0; k < count; ++k) {
+    row0[k] = h[k].row0;
+    rows[k] = h[k].rows_items >> 16;
+    items[k] = h[k].rows_items & 0xffffu;
+    stream_offset[k] = (uint64_t)h[k].off16 * 16;
+  }
+  return BEAR_OK;
+}
 
 int bear_plan_create_ref(bear_ws *ws, const uint32_t *train, const uint32_t *ref, uint64_t n_rows, bear_plan **out) {
   if (!out) return BEAR_ERR_INVALID_ARG;

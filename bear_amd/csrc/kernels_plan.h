@@ -136,6 +136,118 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
   if (threadIdx.x < 2 * SRT_NKEY && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
 }
 
+// ---- tile cutting on the device --------------------------------------------------------------------------------------------
+// The greedy cut (a tile takes groups of 4 contexts while it holds <= PLN_RMAX contexts and <= PLN_NI product-path items) is a
+// sequential scan over n_rows / 4 bytes.  A tile spans at most PLN_RMAX / 4 groups, so the cuts inside a CHUNK of groups depend
+// on nothing but the chunk's entry point, one of PLN_CUT_SPAN offsets: (1) every (chunk, entry offset) is walked in parallel
+// (exit offset into the next chunk + number of tiles started), (2) one thread follows the chunks' entry points, (3) one thread
+// per chunk walks again from its real entry point and writes the descriptors, (4) a scan turns block sizes into stream offsets.
+#define PLN_CUT_CHUNK 8192                       // groups of 4 contexts per chunk
+#define PLN_CUT_SPAN (PLN_RMAX / PLN_QUAD)       // possible entry offsets of a chunk
+
+// one greedy tile from group q0: returns the first group of the next tile; sums of the three per-group counters
+__device__ __forceinline__ uint64_t plan_cut_one(const uint8_t *__restrict__ quad, uint64_t n_quads, uint64_t q0, uint32_t *items,
+                                                 uint32_t *hcol, uint32_t *hrow) {
+  uint32_t it = 0, hc = 0, hr = 0, rows = 0;
+  uint64_t q = q0;
+  while (q < n_quads && rows + PLN_QUAD <= PLN_RMAX && it + quad[q] <= PLN_NI) {
+    it += quad[q];
+    if (hcol) {
+      hc += quad[n_quads + q];
+      hr += quad[2 * n_quads + q];
+    }
+    rows += PLN_QUAD;
+    ++q;
+  }
+  *items = it;
+  if (hcol) {
+    *hcol = hc;
+    *hrow = hr;
+  }
+  return q;
+}
+__global__ __launch_bounds__(256) void plan_cut_walk_kernel(const uint8_t *__restrict__ quad, uint64_t n_quads, uint64_t n_chunks,
+                                                            uint32_t *__restrict__ walk) {   // exit offset | tiles started << 16
+  const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= n_chunks * PLN_CUT_SPAN) return;
+  const uint64_t k = id / PLN_CUT_SPAN, j = id - k * PLN_CUT_SPAN, end = (k + 1) * PLN_CUT_CHUNK;
+  uint64_t q = k * PLN_CUT_CHUNK + j;
+  uint32_t cnt = 0, items;
+  while (q < end && q < n_quads) {
+    q = plan_cut_one(quad, n_quads, q, &items, nullptr, nullptr);
+    ++cnt;
+  }
+  walk[id] = (uint32_t)(q >= end ? q - end : 0) | (cnt << 16);
+}
+static_assert(PLN_CUT_CHUNK < 65536 && PLN_CUT_SPAN < 65536, "walk table: 16-bit fields");
+// entry[k] = first group of the first tile that starts in chunk k, base[k] = index of that tile; meta = {n_tiles}
+__global__ void plan_cut_chain_kernel(const uint32_t *__restrict__ walk, uint64_t n_chunks, uint64_t *__restrict__ entry,
+                                      uint64_t *__restrict__ base, unsigned long long *__restrict__ meta) {
+  if (blockIdx.x || threadIdx.x) return;
+  uint64_t j = 0, tiles = 0;
+  for (uint64_t k = 0; k < n_chunks; ++k) {
+    entry[k] = k * PLN_CUT_CHUNK + j;
+    base[k] = tiles;
+    const uint32_t w = walk[k * PLN_CUT_SPAN + j];
+    tiles += w >> 16;
+    j = w & 0xffffu;
+  }
+  meta[0] = tiles;
+}
+__global__ __launch_bounds__(256) void plan_cut_write_kernel(const uint8_t *__restrict__ quad, uint64_t n_quads, uint64_t n_rows, int ncol,
+                                                             uint64_t n_chunks, const uint64_t *__restrict__ entry,
+                                                             const uint64_t *__restrict__ base, pln_tile *__restrict__ tiles) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_chunks) return;
+  const uint64_t end = (k + 1) * PLN_CUT_CHUNK;
+  uint64_t q = entry[k], t = base[k];
+  while (q < end && q < n_quads) {
+    uint32_t items, hcol, hrow;
+    const uint64_t q1 = plan_cut_one(quad, n_quads, q, &items, &hcol, &hrow);
+    pln_tile ti;
+    ti.row0 = q * PLN_QUAD;
+    uint32_t rows = (uint32_t)(q1 - q) * PLN_QUAD;
+    if (ti.row0 + rows > n_rows) rows = (uint32_t)(n_rows - ti.row0);  // ragged end of the table
+    // large-count items evaluated inside the tile (their rows are in LDS anyway); the surplus of very dense tiles goes to the
+    // global lists.  Mode R needs no row data for large totals: they stay global.
+    const uint32_t hc = hcol < PLN_HCAP ? hcol : PLN_HCAP;
+    const uint32_t hr = ncol == 5 ? (hrow < PLN_HCAP ? hrow : PLN_HCAP) : 0u;
+    ti.rows_items = (rows << 16) | items;
+    ti.off16 = 0;
+    ti.hc_hr = (hc << 16) | hr;
+    ti.blk16 = pln_block_layout(rows, items, hc, hr).end / 16;
+    ti.pad = 0;
+    tiles[t++] = ti;
+    q = q1;
+  }
+}
+// off16 = exclusive prefix sum of blk16 (one block; tiles are ~1e-5 of the contexts); meta[1] = total, meta[2] = 1 on overflow
+__global__ __launch_bounds__(1024) void plan_cut_offsets_kernel(pln_tile *__restrict__ tiles, uint64_t n_tiles,
+                                                                unsigned long long *__restrict__ meta) {
+  __shared__ unsigned long long part[1024];
+  const uint64_t per = (n_tiles + 1023) / 1024, lo = per * threadIdx.x, hi = lo + per < n_tiles ? lo + per : n_tiles;
+  unsigned long long s = 0;
+  for (uint64_t t = lo; t < hi; ++t) s += tiles[t].blk16;
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int k = 0; k < 1024; ++k) {
+      const unsigned long long v = part[k];
+      part[k] = run;
+      run += v;
+    }
+    meta[1] = run;
+    meta[2] = run > 0xffffffffull ? 1ull : 0ull;
+  }
+  __syncthreads();
+  unsigned long long off = part[threadIdx.x];
+  for (uint64_t t = lo; t < hi; ++t) {
+    tiles[t].off16 = (uint32_t)off;
+    off += tiles[t].blk16;
+  }
+}
+
 // Pass B: one block per tile: counting sort of the tile's product-path items by count (LDS histogram,
 // replicated 8x) -> thresholds, row totals and sorted uint16 item list written as one block; heavy
 // items appended to the global lists.

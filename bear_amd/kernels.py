@@ -136,6 +136,15 @@ class Plan:
     def nbytes(self):
         return int(_lib.lib().bear_plan_bytes(self._h))
 
+    def tiles(self):
+        """Diagnostics (``bear_plan_tile_info``): (row0 [T] uint64, rows [T] uint32, items [T] uint32, stream_offset [T] uint64)."""
+        import numpy as np
+        n = int(_lib.lib().bear_plan_tile_count(self._h))
+        row0, rows, items, off = np.empty(n, np.uint64), np.empty(n, np.uint32), np.empty(n, np.uint32), np.empty(n, np.uint64)
+        _lib.check(_lib.lib().bear_plan_tile_info(self._h, 0, n, row0.ctypes.data, rows.ctypes.data, items.ctypes.data, off.ctypes.data),
+                   "bear_plan_tile_info")
+        return row0, rows, items, off
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

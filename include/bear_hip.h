@@ -104,6 +104,11 @@ typedef struct bear_plan bear_plan;
 int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int ncol, bear_plan **out);
 int bear_plan_destroy(bear_plan *plan);
 uint64_t bear_plan_bytes(const bear_plan *plan);
+/* Diagnostics: the tiles of a plan -- first context, number of contexts, number of product-path items (1 <= count <= 24) and
+ * byte offset of the tile's block in the plan stream; [host] arrays of `count` entries for tiles [first, first + count). */
+uint64_t bear_plan_tile_count(const bear_plan *plan);
+int bear_plan_tile_info(const bear_plan *plan, uint64_t first, uint64_t count, uint64_t *row0, uint32_t *rows, uint32_t *items,
+                        uint64_t *stream_offset);
 /* A plan for bear_dm_ref_plan_f64 / bear_ref_train_*_f64 that also knows the REFERENCE column `ref` [dev] uint32 [n_rows, 5]
  * -- as constant as the training column while a table is resident.  Contexts without reference counts (most k-mers of a read
  * set that the reference genome does not contain) share one concentration per letter, so all their items collapse into a

@@ -511,6 +511,42 @@ def test_planned_full_size_chunks(dev):
         kernels.dm_prior_planned(pn2, f, 0.0)
 
 
+@pytest.mark.parametrize("n,kind", [(1, "sparse"), (3, "dense"), (1664, "sparse"), (32768 * 2 + 5, "dense"), (32768 * 3, "sparse"),
+                                    (250_007, "mixed"), (1_000_003, "sparse")])
+def test_tile_cut_on_the_device_equals_the_sequential_definition(n, kind, dev, monkeypatch):
+    """bear_plan_create cuts tiles on the device (chunks walked from every possible entry point, then chained): the same tiles
+    -- first row, rows, items, stream offsets -- as the sequential greedy loop over the per-group counters (BEAR_PLAN_CUT=host),
+    for tables that span chunk boundaries, dense / sparse / mixed; the planned sums agree."""
+    import torch
+    from bear_amd import kernels
+    rng = np.random.default_rng(n)
+    if kind == "dense":
+        tr = rng.integers(0, 60, size=(n, 5)).astype(np.uint32)
+    elif kind == "sparse":
+        tr = (rng.random((n, 5)) < 0.25).astype(np.uint32) * rng.integers(1, 6, size=(n, 5)).astype(np.uint32)
+    else:   # stretches of empty, sparse and very dense rows: both limits (contexts, items) bind in turn
+        tr = np.zeros((n, 5), dtype=np.uint32)
+        seg = rng.integers(0, 3, size=n // 997 + 1).repeat(997)[:n]
+        tr[seg == 1] = (rng.random(((seg == 1).sum(), 5)) < 0.3) * rng.integers(1, 30, size=((seg == 1).sum(), 5))
+        tr[seg == 2] = rng.integers(1, 25, size=((seg == 2).sum(), 5))
+    d = _to_dev(tr, dev)
+    f = torch.from_numpy(prior_rows(n, seed=n % 1000)).to(dev)
+    for ncol in (5, 4):
+        plan_dev = kernels.Plan(d, ncol)
+        monkeypatch.setenv("BEAR_PLAN_CUT", "host")
+        plan_host = kernels.Plan(d, ncol)
+        monkeypatch.delenv("BEAR_PLAN_CUT")
+        for a, b in zip(plan_dev.tiles(), plan_host.tiles()):
+            assert np.array_equal(a, b)
+        assert plan_dev.nbytes == plan_host.nbytes
+        r0, rows, _, _ = plan_dev.tiles()
+        assert r0[0] == 0 and np.array_equal(r0[1:], (r0 + rows)[:-1]) and r0[-1] + rows[-1] == n      # a partition of the rows
+        if ncol == 5:
+            a = kernels.dm_prior_planned(plan_dev, f, -0.3).cpu().numpy()
+            b = kernels.dm_prior_planned(plan_host, f, -0.3).cpu().numpy()
+            assert np.allclose(a, b, rtol=1e-13)
+
+
 def test_planned_randomized_shapes(dev):
     """Randomized tables (sizes around the tile / unit boundaries; sparse, dense, mostly-empty, mixed and
     single-column tables; normalised and un-normalised prior rows): planned kernels == oracle."""
