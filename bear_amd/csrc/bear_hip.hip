@@ -1389,13 +1389,20 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
   hipLaunchKernelGGL(net_params_kernel, dim3(1), dim3(64), 0, s, theta, eps, ws->ref_prm);
   {
     const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF);
-    // only the contexts that hold training counts: the DM kernel reads nobody else's prior row (their gradient rows are zero)
-    const uint64_t groups = plan->live ? plan->n_tiles : (n_rows + 63) / 64;
+    // only the contexts that hold training counts: the DM kernel reads nobody else's prior row (their gradient rows are zero).
+    // Only together with the backward kernel that walks the same lists (shapes whose LDS does not fit take all rows in both).
+    int bw_waves = 0;
+    size_t bw_lds = 0;
+    uint64_t bw_blocks = 0;
+    st = cnn_backward_grid(ws, D, n_rows, filter_width, &bw_waves, &bw_lds, &bw_blocks, s, 0);
+    if (st != BEAR_OK) return st;
+    const bool lists = plan->live && bw_waves == cnnq<2>::WAVES;
+    const uint64_t groups = lists ? plan->n_tiles : (n_rows + 63) / 64;
     uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
     if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
     hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), lds, s,
                        reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, prior_buf, t1_buf,
-                       plan->live ? plan->tiles : nullptr, plan->live, groups);
+                       lists ? plan->tiles : nullptr, lists ? plan->live : nullptr, groups);
   }
   bear_params dummy;
   memset(&dummy, 0, sizeof(dummy));

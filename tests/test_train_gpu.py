@@ -361,6 +361,29 @@ def test_bear_net_cnn_graph_replay_matches_eager(train_ar, ysd1):
         assert np.allclose(a, b, rtol=1e-5, atol=1e-7)
 
 
+def test_cnn_step_over_live_contexts_equals_the_step_over_all_rows(ysd1, monkeypatch):
+    """The CNN training step walks the plan's lists of contexts that hold counts (forward and backward skip the others: their
+    gradient rows are zero).  Forcing the all-rows kernels (BEAR_CNN_BACKWARD=1) must give the same losses and parameters; the
+    table gets extra all-zero training rows so that the lists really skip something."""
+    data = dataloader.dataloader(YSD1, "dna", 1500, 3)
+    n = data.num_rows
+    data.counts[0, ::3] = 0                     # a third of the contexts without training counts
+    torch.manual_seed(6)
+    _, init = ar_funcs.make_ar_func_cnn(5, 4, **CNN_CFG)
+    restart = [np.array(0.1)] + [x.detach().numpy().copy() for x in init]
+    steps, runs = 8, []
+    for force in (None, "1"):
+        if force:
+            monkeypatch.setenv("BEAR_CNN_BACKWARD", force)
+        ls = []
+        params, _, _ = bear_net.train(data.repeat(steps), n, steps, 0, "dna", 5, ar_funcs.make_ar_func_cnn, CNN_CFG, 0.01, "Adam", False,
+                                      params_restart=restart, loss_save=ls)
+        runs.append((ls, [p.detach().cpu().numpy() for p in params]))
+    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-10)
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.allclose(a, b, rtol=1e-7, atol=1e-9)
+
+
 def test_graph_path_feeds_the_writer(ysd1):
     class W:
         def __init__(self):
