@@ -215,6 +215,31 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
     return (loss_buf[:n_steps] / acc_steps).cpu().tolist()
 
 
+def live_rows(e, *columns):
+    """Row indices of a resident batch's contexts that hold training counts (cached in the batch entry, together with the gathered
+    ``columns`` as ``<name>_live``), or None when (nearly) all of them do.  An AR function made of torch ops only has to produce
+    the prior rows of those contexts: the DM kernel reads nobody else's row and their gradient rows are zero
+    (``scatter_live`` puts the rows back in place).  BEAR_AMD_ALL_ROWS=1 switches the gather off (tests)."""
+    if "live" not in e:
+        live = None
+        if e["rows"] and not os.environ.get("BEAR_AMD_ALL_ROWS"):
+            idx = (e["train"] != 0).any(dim=1).nonzero().squeeze(1)
+            if idx.numel() < 0.95 * e["rows"]:
+                live = idx
+        e["live"] = live
+    if e["live"] is not None:
+        for c in columns:
+            if c + "_live" not in e:
+                e[c + "_live"] = e[c].index_select(0, e["live"]).contiguous()
+    return e["live"]
+
+
+def scatter_live(rows_live, live, n_rows):
+    """[len(live), W] prior rows -> [n_rows, W] with zero rows for the contexts without counts (differentiable)."""
+    full = torch.zeros((n_rows, rows_live.shape[1]), dtype=rows_live.dtype, device=rows_live.device)
+    return full.index_copy(0, live, rows_live)
+
+
 def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, optimizer, train_ar, acc_steps, normalized, device):
     """The optimizer loop for an AR function made of torch ops (any ``ar_funcs`` plugin; bear_net.py:292-310): per batch the
     prior rows come from ``prior_fn(batch entry)`` with autograd, the planned kernel returns sum LL, d/dh and the gradient rows

@@ -99,7 +99,11 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
         normalized = bool(getattr(ar_func, "normalized_rows", False))   # every reference AR function ends in a softmax
 
         def prior_fn(e):
-            return ar_func(e["codes"]).expand(e["rows"], alphabet_size + 1).contiguous()
+            live = _train.live_rows(e, "codes")          # contexts without training counts need no prior row
+            out = ar_func(e["codes"] if live is None else e["codes_live"])
+            if live is None or out.shape[0] == 1:        # (a parameter-free AR function may return one row for all contexts)
+                return out.expand(e["rows"], alphabet_size + 1).contiguous()
+            return _train.scatter_live(out, live, e["rows"])
         losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, optimizer, train_ar, acc_steps,
                                            normalized, device)
     _train.log_losses(losses, writer, loss_save, acc_steps)

@@ -110,7 +110,10 @@ def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_
     def prior_fn(e):
         if "ref_in" not in e:
             e["ref_in"] = _ref_input(e["ref"])
-        return ar_func(e["codes"], e["ref_in"]).contiguous()
+        live = _train.live_rows(e, "codes", "ref_in")    # contexts without training counts need no prior row
+        if live is None:
+            return ar_func(e["codes"], e["ref_in"]).contiguous()
+        return _train.scatter_live(ar_func(e["codes_live"], e["ref_in_live"]), live, e["rows"])
     losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, optimizer, train_ar, acc_steps,
                                        False, device)
     _train.log_losses(losses, writer, loss_save, acc_steps)

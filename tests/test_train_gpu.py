@@ -384,6 +384,30 @@ def test_cnn_step_over_live_contexts_equals_the_step_over_all_rows(ysd1, monkeyp
         assert np.allclose(a, b, rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("which", ["bear_ref + linear net", "bear_ref + cnn net", "bear_net + SGD (torch loop)"])
+def test_torch_ar_functions_only_see_contexts_with_counts(which, monkeypatch):
+    """The autograd loops hand an AR function only the contexts that hold training counts (gather, scatter back): the same losses
+    and parameters as with all rows (BEAR_AMD_ALL_ROWS=1) on a table where a third of the contexts hold none."""
+    data = dataloader.dataloader(YSD1, "dna", 700, 3)         # two batches
+    data.counts[0, ::3] = 0
+    n, steps, runs = data.num_rows, 6, []
+    for all_rows in (False, True):
+        if all_rows:
+            monkeypatch.setenv("BEAR_AMD_ALL_ROWS", "1")
+        torch.manual_seed(9)
+        ls = []
+        if which.startswith("bear_ref"):
+            make, kw = (ar_funcs.make_ar_func_linear, {}) if "linear" in which else (ar_funcs.make_ar_func_cnn, CNN_CFG)
+            params, _, _ = bear_ref.train(data.repeat(steps), n, steps, 0, 2, "dna", 5, make, kw, 0.01, "Adam", False, loss_save=ls)
+        else:
+            params, _, _ = bear_net.train(data.repeat(steps), n, steps, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "SGD", False,
+                                          loss_save=ls)
+        runs.append((ls, [p.detach().cpu().numpy() for p in params]))
+    assert len(runs[0][0]) == 2 * steps and np.allclose(runs[0][0], runs[1][0], rtol=1e-11)
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.allclose(a, b, rtol=1e-8, atol=1e-10)
+
+
 def test_graph_path_feeds_the_writer(ysd1):
     class W:
         def __init__(self):
