@@ -215,23 +215,25 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
     return (loss_buf[:n_steps] / acc_steps).cpu().tolist()
 
 
-def live_rows(e, *columns):
-    """Row indices of a resident batch's contexts that hold training counts (cached in the batch entry, together with the gathered
-    ``columns`` as ``<name>_live``), or None when (nearly) all of them do.  An AR function made of torch ops only has to produce
-    the prior rows of those contexts: the DM kernel reads nobody else's row and their gradient rows are zero
-    (``scatter_live`` puts the rows back in place).  BEAR_AMD_ALL_ROWS=1 switches the gather off (tests)."""
-    if "live" not in e:
+def live_rows(e, *columns, by="train"):
+    """Row indices of a resident batch's contexts that hold counts in column ``by`` (cached in the batch entry, together with the
+    gathered ``columns`` as ``<name>_live_<by>``), or None when (nearly) all of them do.  An AR function made of torch ops only has
+    to produce the prior rows of those contexts: in training the DM kernel reads nobody else's row and their gradient rows are
+    zero, in evaluation only contexts with held-out counts enter any sum (``scatter_live`` puts the rows back in place).
+    BEAR_AMD_ALL_ROWS=1 switches the gather off (tests)."""
+    key = "live_" + by
+    if key not in e:
         live = None
         if e["rows"] and not os.environ.get("BEAR_AMD_ALL_ROWS"):
-            idx = (e["train"] != 0).any(dim=1).nonzero().squeeze(1)
+            idx = (e[by] != 0).any(dim=1).nonzero().squeeze(1)
             if idx.numel() < 0.95 * e["rows"]:
                 live = idx
-        e["live"] = live
-    if e["live"] is not None:
+        e[key] = live
+    if e[key] is not None:
         for c in columns:
-            if c + "_live" not in e:
-                e[c + "_live"] = e[c].index_select(0, e["live"]).contiguous()
-    return e["live"]
+            if c + "_" + key not in e:
+                e[c + "_" + key] = e[c].index_select(0, e[key]).contiguous()
+    return e[key]
 
 
 def scatter_live(rows_live, live, n_rows):

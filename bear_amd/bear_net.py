@@ -100,7 +100,7 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
 
         def prior_fn(e):
             live = _train.live_rows(e, "codes")          # contexts without training counts need no prior row
-            out = ar_func(e["codes"] if live is None else e["codes_live"])
+            out = ar_func(e["codes"] if live is None else e["codes_live_train"])
             if live is None or out.shape[0] == 1:        # (a parameter-free AR function may return one row for all contexts)
                 return out.expand(e["rows"], alphabet_size + 1).contiguous()
             return _train.scatter_live(out, live, e["rows"])
@@ -120,7 +120,12 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
     total = None
     with torch.no_grad():
         for k, e in enumerate(res.batches):
-            prior = ar_func(e["codes"]).expand(e["rows"], 5).contiguous() if e["rows"] else torch.zeros((0, 5), dtype=dtype, device=device)
+            if not e["rows"]:
+                prior = torch.zeros((0, 5), dtype=dtype, device=device)
+            else:                                        # prior rows of the contexts with held-out counts: nothing else enters a sum
+                live = _train.live_rows(e, "codes", by="test")
+                out = ar_func(e["codes"] if live is None else e["codes_live_test"])
+                prior = out.expand(e["rows"], 5).contiguous() if live is None or out.shape[0] == 1 else _train.scatter_live(out, live, e["rows"])
             part = _train.evaluation_sums(e["test"], prior, h, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"],
                                            plan=res.eval_plan(k) if e["rows"] else None)
             total = part if total is None else tuple(a + b for a, b in zip(total, part))

@@ -113,7 +113,7 @@ def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_
         live = _train.live_rows(e, "codes", "ref_in")    # contexts without training counts need no prior row
         if live is None:
             return ar_func(e["codes"], e["ref_in"]).contiguous()
-        return _train.scatter_live(ar_func(e["codes_live"], e["ref_in_live"]), live, e["rows"])
+        return _train.scatter_live(ar_func(e["codes_live_train"], e["ref_in_live_train"]), live, e["rows"])
     losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, optimizer, train_ar, acc_steps,
                                        False, device)
     _train.log_losses(losses, writer, loss_save, acc_steps)
@@ -136,8 +136,16 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
     total = None
     with torch.no_grad():
         for k, e in enumerate(res.batches):
-            prior = ar_func(e["codes"], _ref_input(e["ref"], dtype)) if e["rows"] else torch.zeros((0, 5), dtype=dtype, device=device)
-            prior = prior.expand(e["rows"], 5).contiguous()
+            if not e["rows"]:
+                prior = torch.zeros((0, 5), dtype=dtype, device=device)
+            else:                                        # prior rows of the contexts with held-out counts: nothing else enters a sum
+                if "ref_in" not in e:
+                    e["ref_in"] = _ref_input(e["ref"], dtype)
+                live = _train.live_rows(e, "codes", "ref_in", by="test")
+                if live is None:
+                    prior = ar_func(e["codes"], e["ref_in"]).expand(e["rows"], 5).contiguous()
+                else:
+                    prior = _train.scatter_live(ar_func(e["codes_live_test"], e["ref_in_live_test"]), live, e["rows"])
             part = _train.evaluation_sums(e["test"], prior, hv, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"],
                                            plan=res.eval_plan(k) if e["rows"] else None)
             total = part if total is None else tuple(a + b for a, b in zip(total, part))
