@@ -45,6 +45,9 @@ def init_from_env():
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", dev_index))
     else:
+        if backend == "gloo" and os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost"):
+            # one node: gloo otherwise resolves the host name to pick its interface (the name may not resolve: a silent hang)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group(backend, rank=rank, world_size=world_size)
     return world()
 

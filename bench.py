@@ -67,6 +67,8 @@ def main():
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
+            if args.backend == "gloo" and os.environ.get("MASTER_ADDR") in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # do not resolve the host name to pick an interface
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from bear_amd import kernels

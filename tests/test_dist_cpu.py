@@ -66,10 +66,13 @@ bdist.shutdown()
 def test_two_rank_gloo_step(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, BEAR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", BEAR_AMD_DIST_BACKEND="gloo")
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    env = dict(os.environ, BEAR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", BEAR_AMD_DIST_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo")
+    with socket.socket() as sk:         # a free port (a fixed one may still be held by an earlier run)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "DIST_OK" in p.stdout

@@ -20,13 +20,20 @@ pytestmark = pytest.mark.gpu
 CNN_CFG = {"num_filters": 30, "filter_width": 3, "kmer_layer1_width": 16}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _launch(script_args, env_extra, tmp_path):
     env = dict(os.environ, BEAR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", BEAR_AMD_DIST_BACKEND="gloo",
-               BEAR_AMD_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
-    port = 29500 + (os.getpid() % 2000)
+               BEAR_AMD_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo", **env_extra)
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + script_args
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
 
 
@@ -123,12 +130,13 @@ def test_bench_under_the_launcher_two_ranks(tmp_path):
     reduced ELBO equals the ELBO of the two row shards computed in this process."""
     from bear_amd import kernels
     n = 2_000_000
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", BEAR_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 31500 + (os.getpid() % 2000)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", BEAR_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               GLOO_SOCKET_IFNAME="lo")
+    port = _free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
            "--contexts", str(n), "--backend", "gloo", "--no-cpu-baseline"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1
