@@ -403,15 +403,18 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   if (e == hipSuccess && !host_cut) {
     const uint64_t n_chunks = (n_quads + PLN_CUT_CHUNK - 1) / PLN_CUT_CHUNK;
     uint32_t *d_walk = nullptr;
+    uint16_t *d_step = nullptr;            // [n_quads] length of the tile that starts at a group
     uint64_t *d_entry = nullptr;           // [n_chunks] entry | [n_chunks] base
     unsigned long long *d_meta = nullptr, h_meta[3] = {0, 0, 0};
     e = hipMalloc(&d_walk, sizeof(uint32_t) * n_chunks * PLN_CUT_SPAN);
+    if (e == hipSuccess) e = hipMalloc(&d_step, sizeof(uint16_t) * n_quads);
     if (e == hipSuccess) e = hipMalloc(&d_entry, sizeof(uint64_t) * 2 * n_chunks);
     if (e == hipSuccess) e = hipMalloc(&d_meta, sizeof(h_meta));
     if (e == hipSuccess) e = hipMemset(d_meta, 0, sizeof(h_meta));
     if (e == hipSuccess) {
       const uint64_t wb = (n_chunks * PLN_CUT_SPAN + 255) / 256;
-      hipLaunchKernelGGL(plan_cut_walk_kernel, dim3((unsigned)wb), dim3(256), 0, 0, d_quad, n_quads, n_chunks, d_walk);
+      hipLaunchKernelGGL(plan_cut_step_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, 0, d_quad, n_quads, n_chunks, d_step);
+      hipLaunchKernelGGL(plan_cut_walk_kernel, dim3((unsigned)wb), dim3(256), 0, 0, d_step, n_quads, n_chunks, d_walk);
       hipLaunchKernelGGL(plan_cut_chain_kernel, dim3(1), dim3(1), 0, 0, d_walk, n_chunks, d_entry, d_entry + n_chunks, d_meta);
       e = hipGetLastError();
     }
@@ -430,6 +433,7 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
     if (e == hipSuccess && h_meta[2]) e = hipErrorOutOfMemory;     // plan stream beyond 2^32 16-byte units
     off16 = h_meta[1];
     (void)hipFree(d_walk);
+    (void)hipFree(d_step);
     (void)hipFree(d_entry);
     (void)hipFree(d_meta);
   }

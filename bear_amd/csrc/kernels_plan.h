@@ -166,15 +166,35 @@ __device__ __forceinline__ uint64_t plan_cut_one(const uint8_t *__restrict__ qua
   }
   return q;
 }
-__global__ __launch_bounds__(256) void plan_cut_walk_kernel(const uint8_t *__restrict__ quad, uint64_t n_quads, uint64_t n_chunks,
+// step[q] = length (in groups) of the greedy tile that starts at group q, for every q of a chunk: one thread per chunk, a
+// two-pointer window (dropping the first group of a tile can only let it reach further), O(chunk) steps
+__global__ __launch_bounds__(256) void plan_cut_step_kernel(const uint8_t *__restrict__ quad, uint64_t n_quads, uint64_t n_chunks,
+                                                            uint16_t *__restrict__ step) {
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_chunks) return;
+  const uint64_t q0 = k * PLN_CUT_CHUNK, q_end = q0 + PLN_CUT_CHUNK < n_quads ? q0 + PLN_CUT_CHUNK : n_quads;
+  uint64_t r = q0;
+  uint32_t items = 0;
+  for (uint64_t q = q0; q < q_end; ++q) {
+    if (r < q) {      // cannot happen (a tile holds at least one group); keeps the window well formed
+      r = q;
+      items = 0;
+    }
+    while (r < n_quads && (uint32_t)(r - q + 1) * PLN_QUAD <= PLN_RMAX && items + quad[r] <= PLN_NI) items += quad[r++];
+    step[q] = (uint16_t)(r - q);
+    items -= quad[q];
+  }
+}
+// every (chunk, entry offset): follow the tiles from the entry point to the chunk's end
+__global__ __launch_bounds__(256) void plan_cut_walk_kernel(const uint16_t *__restrict__ step, uint64_t n_quads, uint64_t n_chunks,
                                                             uint32_t *__restrict__ walk) {   // exit offset | tiles started << 16
   const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (id >= n_chunks * PLN_CUT_SPAN) return;
   const uint64_t k = id / PLN_CUT_SPAN, j = id - k * PLN_CUT_SPAN, end = (k + 1) * PLN_CUT_CHUNK;
   uint64_t q = k * PLN_CUT_CHUNK + j;
-  uint32_t cnt = 0, items;
+  uint32_t cnt = 0;
   while (q < end && q < n_quads) {
-    q = plan_cut_one(quad, n_quads, q, &items, nullptr, nullptr);
+    q += step[q];
     ++cnt;
   }
   walk[id] = (uint32_t)(q >= end ? q - end : 0) | (cnt << 16);
