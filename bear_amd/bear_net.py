@@ -57,10 +57,11 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
         # fused kernels -> finalize [-> all-reduce of the packed vector] -> Adam, no host round trip (_train.run_device_steps)
         theta = torch.cat([h_signed.detach().reshape(1)] + [p.detach().reshape(-1) for p in ar_params]).to(
             device=device, dtype=torch.float64).contiguous()
-        if fused_mat is not None:
+        if True:   # (both fused heads)
             # the sums of a step do not depend on the order of a batch's rows: sorted by k-mer (first letter most significant),
-            # consecutive contexts share all but their last letters and the fused kernel adds whole waves / quads of them to
-            # d/d mat at once instead of one LDS atomic per context, letter and position (kernels_linear.h)
+            # consecutive contexts share all but their last letters -- the fused linear kernel adds whole waves / quads of them to
+            # d/d mat at once instead of one LDS atomic per context, letter and position (kernels_linear.h), the convolutional
+            # kernels evaluate a window that all contexts of a wave share once (kernels_cnn.h)
             for e in res.batches:
                 if e["rows"] > 1:
                     key = torch.zeros(e["rows"], dtype=torch.int64, device=device)

@@ -1275,7 +1275,7 @@ int bear_cnn_forward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows
   if (n_rows == 0) return BEAR_OK;
   if (!kmer_code || !params || !prior || misaligned(t1_save) || (reinterpret_cast<uintptr_t>(prior) & 7u)) return BEAR_ERR_INVALID_ARG;
   const cnn_dims D = cnn_make_dims(lag, filter_width);
-  const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF);
+  const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);
   uint64_t blocks = (n_rows + CNN_THREADS - 1) / CNN_THREADS;
   if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
   hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), lds, static_cast<hipStream_t>(stream),
@@ -1392,7 +1392,7 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
   const double *params = theta + 1;
   hipLaunchKernelGGL(net_params_kernel, dim3(1), dim3(64), 0, s, theta, eps, ws->ref_prm);
   {
-    const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF);
+    const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);
     // only the contexts that hold training counts: the DM kernel reads nobody else's prior row (their gradient rows are zero).
     // Only together with the backward kernel that walks the same lists (shapes whose LDS does not fit take all rows in both).
     int bw_waves = 0;

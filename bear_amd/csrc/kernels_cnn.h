@@ -31,6 +31,7 @@
 #define CNN_THREADS 256
 #define CNN_MAX_LAG 21
 #define CNN_LN_EPS 1e-5
+#define CNN_FWD_SCRATCH 48        // doubles of LDS per wave of the forward kernel (shared-window path)
 
 struct cnn_dims {
   int lag, fw, P;
@@ -146,8 +147,42 @@ __device__ __forceinline__ double cnn_layer1(const double (&t1)[CNN_L1], const d
   return r;
 }
 
+// One window shared by all 64 contexts of a wave: its conv row, layer norm and elu once (lane = filter), then its contribution
+// to the 16 layer-1 sums (lane = unit) into Us[32..48).  Out of line: the forward kernel keeps its 143 registers (three waves per
+// SIMD); inlined, this path pushed it to 197.
+__device__ __noinline__ void cnn_forward_shared_window(const double *Fs, const double *exptab, double *Us, const double *__restrict__ s0,
+                                                       const double *__restrict__ b0, const double *__restrict__ W1, int fw,
+                                                       unsigned long long win0, uint32_t lane) {
+  const uint32_t f = lane < CNN_NF ? lane : CNN_NF - 1;
+  double xf = 0.0;
+  unsigned long long c = win0;
+  for (int w = 0; w < fw; ++w) {
+    const int a = (int)(c & 7ull);
+    xf += Fs[(w * 6 + (a < 5 ? a : 5)) * CNN_NF + f];
+    c >>= 3;
+  }
+  const bool in = lane < CNN_NF;
+  double mu = bear_wave_sum(in ? xf : 0.0);
+  mu = __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(mu) >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__double_as_longlong(mu))) * (1.0 / CNN_NF);
+  const double d = xf - mu;
+  double var = bear_wave_sum(in ? d * d : 0.0);
+  var = __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(var) >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__double_as_longlong(var)));
+  const double r = cnn_rsqrt(var * (1.0 / CNN_NF) + CNN_LN_EPS);
+  double dv;
+  const double e = cnn_elu(__builtin_fma(s0[f], d * r, b0[f]), exptab, dv);
+  if (in) Us[lane] = e;
+  if (lane < CNN_L1) {
+    double u4[2] = {0.0, 0.0};
+#pragma unroll 6
+    for (int ff = 0; ff < CNN_NF; ++ff) u4[ff & 1] = __builtin_fma(Us[ff], W1[ff * CNN_L1 + lane], u4[ff & 1]);
+    Us[32 + lane] = u4[0] + u4[1];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(CNN_THREADS) void cnn_forward_kernel(const unsigned long long *__restrict__ codes, uint64_t n_rows,
+__global__ __launch_bounds__(CNN_THREADS, 3) void cnn_forward_kernel(const unsigned long long *__restrict__ codes, uint64_t n_rows,
                                                                    cnn_dims D, const double *__restrict__ params,
                                                                    double *__restrict__ prior, double *__restrict__ t1_save,
                                                                    const pln_tile *__restrict__ tiles, const uint16_t *__restrict__ live_lists,
@@ -161,6 +196,8 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_forward_kernel(const unsigned
   // A wave walks groups of contexts, 64 at a time: without lists, group g = rows [64 g, 64 g + 64); with the plan's lists
   // (the training step) group g = plan tile g and only its contexts that hold counts -- nothing reads the others' rows.
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = CNN_THREADS / 64;
+  double *Us = Fs + D.fw * 6 * CNN_NF + wave * CNN_FWD_SCRATCH;     // per wave: e0 of a shared window [32] | its layer-1 sums [16]
+  const unsigned long long wmask = 3 * D.fw >= 64 ? ~0ull : (1ull << (3 * D.fw)) - 1ull;
   for (uint64_t g = (uint64_t)blockIdx.x * n_waves + wave; g < n_groups; g += (uint64_t)gridDim.x * n_waves) {
     const uint16_t *lst = live_lists ? live_lists + g * PLN_LIVE_STRIDE : nullptr;
     const uint64_t base = lst ? tiles[g].row0 : g * 64;
@@ -168,11 +205,29 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_forward_kernel(const unsigned
    for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
     const bool live = c0 + lane < cnt;
     const uint64_t i = base + (lst ? (uint64_t)lst[1 + (live ? c0 + lane : 0u)] : (uint64_t)lane);
-    const unsigned long long code = live ? codes[i] : ~0ull;
+    unsigned long long code = codes[i];              // lanes past the end repeat the chunk's first context (nothing is stored for them)
+    {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)code), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(code >> 32));
+      if (!live) code = ((unsigned long long)hi << 32) | lo;
+    }
     double t1[CNN_L1];
 #pragma unroll
     for (int j = 0; j < CNN_L1; ++j) t1[j] = 0.0;
     for (int p = 0; p < D.P; ++p) {
+      // In a k-mer-sorted batch (bear_net.train sorts at upload) the 64 contexts of a wave share their leading letters: a window
+      // [p, p + fw) that lies inside the shared prefix gives every context the SAME conv row, activations and layer-1
+      // contribution.  Then 30 lanes compute the row once (lane = filter), 16 lanes the contribution (lane = unit), and every
+      // context adds it: ~200 instructions instead of ~1500 for the position.
+      const unsigned long long win = (code >> (3 * p)) & wmask;
+      const unsigned long long win0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(win >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)win);
+      if (__builtin_amdgcn_ballot_w64(win != win0) == 0ull) {
+        cnn_forward_shared_window(Fs, exptab, Us, params + D.os0 + p * CNN_NF, params + D.ob0 + p * CNN_NF,
+                                  params + D.oW1 + p * CNN_NF * CNN_L1, D.fw, win0, lane);
+#pragma unroll
+        for (int j = 0; j < CNN_L1; ++j) t1[j] += Us[32 + j];
+        continue;
+      }
       double x[CNN_NF];
       cnn_conv_norm(Fs, code, p, D.fw, x);
       const double *__restrict__ s0 = params + D.os0 + p * CNN_NF, *__restrict__ b0 = params + D.ob0 + p * CNN_NF;

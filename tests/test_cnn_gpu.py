@@ -50,6 +50,36 @@ def test_cnn_forward_matches_oracle(lag, fw, n):
     assert t1.shape == (n, 16)
 
 
+@pytest.mark.parametrize("lag,fw", [(13, 8), (9, 3), (5, 5)])
+def test_cnn_forward_shared_windows_in_sorted_contexts(lag, fw):
+    """k-mer-sorted contexts with long common prefixes (what bear_net.train uploads): whole waves share the windows inside the
+    prefix and the forward kernel evaluates those once per wave; rows against the oracle, also with start symbols and unknown
+    letters inside the shared part, and == the rows of the same contexts in random order."""
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(lag * 31 + fw)
+    n = 3000
+    letters = np.array(list("ACGT[N"))
+    prefix = letters[rng.choice(6, size=lag, p=[0.23, 0.23, 0.23, 0.23, 0.05, 0.03])]
+    tail = max(1, min(3, lag - 1))
+    kmers = []
+    for k in range(n):                     # blocks of ~200 contexts share everything but their last letters; the prefix drifts slowly
+        if k % 200 == 0 and k:
+            prefix = prefix.copy()
+            prefix[rng.integers(0, lag - tail)] = letters[rng.integers(0, 6)]
+        row = prefix.copy()
+        row[lag - tail:] = letters[rng.integers(0, 4, size=tail)]
+        kmers.append("".join(row))
+    ar_func, params = _make(lag, fw, dev, 7)
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+    codes = torch.from_numpy(core.encode_kmers(kmers, "dna")).to(dev)
+    prior, t1 = kernels.cnn_forward(kernels.pack_kmers(codes), flat, lag, fw)
+    want = o.ar_func_cnn(o.one_hot(kmers, "dna"), [p.detach().cpu().numpy() for p in params])
+    assert np.allclose(prior.cpu().numpy(), want, rtol=ROW_RTOL, atol=1e-300)
+    perm = torch.from_numpy(rng.permutation(n)).to(dev)
+    prior_p, t1_p = kernels.cnn_forward(kernels.pack_kmers(codes[perm].contiguous()), flat, lag, fw)
+    assert torch.allclose(prior_p, prior[perm], rtol=1e-12, atol=0) and torch.allclose(t1_p, t1[perm], rtol=1e-11, atol=1e-12)
+
+
 @pytest.mark.parametrize("form", ["32-context tiles, two waves per SIMD", "64-context tiles, one wave per SIMD"])
 @pytest.mark.parametrize("lag,fw,n", [(13, 8, 3000), (5, 3, 1365), (7, 7, 64), (2, 1, 3), (21, 1, 500), (21, 16, 200), (13, 8, 31), (13, 8, 33)])
 def test_cnn_backward_matches_torch_autograd(lag, fw, n, form, monkeypatch):
