@@ -186,7 +186,8 @@ def main():
         key = torch.zeros(n, dtype=torch.int64, device=dev)
         for l in range(lag):
             key = key * 6 + codes[:, l].to(torch.int64)
-        packed = kernels.linear_index(kernels.pack_kmers(codes[torch.argsort(key)].contiguous()), lag)
+        packed_sorted_raw = kernels.pack_kmers(codes[torch.argsort(key)].contiguous())
+        packed = kernels.linear_index(packed_sorted_raw, lag)
         del key, codes
         ms = timed(lambda: kernels.dm_linear(plans["net"], packed, mat, h_s), 5)
         del packed
@@ -210,14 +211,16 @@ def main():
         theta = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), flat]).contiguous()
         bufs = kernels.cnn_step_buffers(n, lag, fw, dev)
         pk = torch.zeros(2 + flat.numel(), dtype=torch.float64, device=dev)
-        s_ms = timed(lambda: kernels.net_cnn_train_reduce(plans["net"], packed, lag, fw, theta, bufs, pk), 3)
+        s_ms = timed(lambda: kernels.net_cnn_train_reduce(plans["net"], packed_sorted_raw, lag, fw, theta, bufs, pk), 3)
+        s_ms_random = timed(lambda: kernels.net_cnn_train_reduce(plans["net"], packed, lag, fw, theta, bufs, pk), 3)
         extra["cnn_head"] = {"lag": lag, "filter_width": fw, "forward_ms": f_ms, "backward_ms": b_ms,
                              "all_rows_step_ms": f_ms + b_ms + extra["net_with_gradient_rows"]["kernel_ms"],
-                             "train_step_ms": s_ms, "step_contexts_per_s": n / (s_ms * 1e-3),
+                             "train_step_ms": s_ms, "train_step_ms_rows_in_random_order": s_ms_random, "step_contexts_per_s": n / (s_ms * 1e-3),
                              "note": "forward_ms / backward_ms: bear_cnn_forward_f64 / bear_cnn_backward_f64 over all rows (any caller); "
                                      "train_step_ms: bear_net_cnn_train_reduce_f64 = forward + planned DM kernel with gradient rows + "
-                                     "backward over the contexts that hold training counts (70 % of this table)"}
-        del packed, packed_raw, bufs, pk, theta
+                                     "backward over the contexts that hold training counts (70 % of this table), rows in k-mer order as "
+                                     "bear_net.train uploads a batch (a wave of the forward kernel evaluates a window its contexts share once)"}
+        del packed, packed_raw, packed_sorted_raw, bufs, pk, theta
         m = min(n, 20_000_000)
         test = kernels.synth_counts(SEED, row0, m, dev, want=("test",))["test"]
         tr_m, pr_m = t["train"][:m], prior[:m]
