@@ -401,7 +401,8 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   }
   free(h_quad);
   if (e == hipSuccess && !host_cut) {
-    const uint64_t n_chunks = (n_quads + PLN_CUT_CHUNK - 1) / PLN_CUT_CHUNK;
+    const uint32_t chunk = plan_cut_chunk(n_quads);
+    const uint64_t n_chunks = (n_quads + chunk - 1) / chunk;
     uint32_t *d_walk = nullptr;
     uint16_t *d_step = nullptr;            // [n_quads] length of the tile that starts at a group
     uint64_t *d_entry = nullptr;           // [n_chunks] entry | [n_chunks] base
@@ -413,9 +414,9 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
     if (e == hipSuccess) e = hipMemset(d_meta, 0, sizeof(h_meta));
     if (e == hipSuccess) {
       const uint64_t wb = (n_chunks * PLN_CUT_SPAN + 255) / 256;
-      hipLaunchKernelGGL(plan_cut_step_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, 0, d_quad, n_quads, n_chunks, d_step);
-      hipLaunchKernelGGL(plan_cut_walk_kernel, dim3((unsigned)wb), dim3(256), 0, 0, d_step, n_quads, n_chunks, d_walk);
-      hipLaunchKernelGGL(plan_cut_chain_kernel, dim3(1), dim3(1), 0, 0, d_walk, n_chunks, d_entry, d_entry + n_chunks, d_meta);
+      hipLaunchKernelGGL(plan_cut_step_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, 0, d_quad, n_quads, n_chunks, chunk, d_step);
+      hipLaunchKernelGGL(plan_cut_walk_kernel, dim3((unsigned)wb), dim3(256), 0, 0, d_step, n_quads, n_chunks, chunk, d_walk);
+      hipLaunchKernelGGL(plan_cut_chain_kernel, dim3(1), dim3(1), 0, 0, d_walk, n_chunks, chunk, d_entry, d_entry + n_chunks, d_meta);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(h_meta, d_meta, sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -425,7 +426,7 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
     if (e == hipSuccess) e = hipMemset(p->tiles, 0, sizeof(pln_tile) * (n_tiles + PLN_DESC_PAD));
     if (e == hipSuccess) {
       hipLaunchKernelGGL(plan_cut_write_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, 0, d_quad, n_quads, n_rows, ncol,
-                         n_chunks, d_entry, d_entry + n_chunks, p->tiles);
+                         n_chunks, chunk, d_entry, d_entry + n_chunks, p->tiles);
       hipLaunchKernelGGL(plan_cut_offsets_kernel, dim3(1), dim3(1024), 0, 0, p->tiles, n_tiles, d_meta);
       e = hipGetLastError();
     }

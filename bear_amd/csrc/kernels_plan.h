@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
 // on nothing but the chunk's entry point, one of PLN_CUT_SPAN offsets: (1) every (chunk, entry offset) is walked in parallel
 // (exit offset into the next chunk + number of tiles started), (2) one thread follows the chunks' entry points, (3) one thread
 // per chunk walks again from its real entry point and writes the descriptors, (4) a scan turns block sizes into stream offsets.
-#define PLN_CUT_CHUNK 8192                       // groups of 4 contexts per chunk
+#define PLN_CUT_CHUNK_MAX 8192                   // groups of 4 contexts per chunk: 2048 up to 2e8 contexts (more threads in the one-thread-per-chunk
+                                                 // kernels), 8192 beyond (fewer steps of the one-thread chain): plan_cut_chunk()
+static inline uint32_t plan_cut_chunk(uint64_t n_quads) { return n_quads <= 50000000ull ? 2048u : (uint32_t)PLN_CUT_CHUNK_MAX; }
 #define PLN_CUT_SPAN (PLN_RMAX / PLN_QUAD)       // possible entry offsets of a chunk
 
 // one greedy tile from group q0: returns the first group of the next tile; sums of the three per-group counters
@@ -169,10 +171,10 @@ __device__ __forceinline__ uint64_t plan_cut_one(const uint8_t *__restrict__ qua
 // step[q] = length (in groups) of the greedy tile that starts at group q, for every q of a chunk: one thread per chunk, a
 // two-pointer window (dropping the first group of a tile can only let it reach further), O(chunk) steps
 __global__ __launch_bounds__(256) void plan_cut_step_kernel(const uint8_t *__restrict__ quad, uint64_t n_quads, uint64_t n_chunks,
-                                                            uint16_t *__restrict__ step) {
+                                                            uint32_t chunk, uint16_t *__restrict__ step) {
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= n_chunks) return;
-  const uint64_t q0 = k * PLN_CUT_CHUNK, q_end = q0 + PLN_CUT_CHUNK < n_quads ? q0 + PLN_CUT_CHUNK : n_quads;
+  const uint64_t q0 = k * chunk, q_end = q0 + chunk < n_quads ? q0 + chunk : n_quads;
   uint64_t r = q0;
   uint32_t items = 0;
   for (uint64_t q = q0; q < q_end; ++q) {
@@ -187,11 +189,11 @@ __global__ __launch_bounds__(256) void plan_cut_step_kernel(const uint8_t *__res
 }
 // every (chunk, entry offset): follow the tiles from the entry point to the chunk's end
 __global__ __launch_bounds__(256) void plan_cut_walk_kernel(const uint16_t *__restrict__ step, uint64_t n_quads, uint64_t n_chunks,
-                                                            uint32_t *__restrict__ walk) {   // exit offset | tiles started << 16
+                                                            uint32_t chunk, uint32_t *__restrict__ walk) {   // exit offset | tiles started << 16
   const uint64_t id = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (id >= n_chunks * PLN_CUT_SPAN) return;
-  const uint64_t k = id / PLN_CUT_SPAN, j = id - k * PLN_CUT_SPAN, end = (k + 1) * PLN_CUT_CHUNK;
-  uint64_t q = k * PLN_CUT_CHUNK + j;
+  const uint64_t k = id / PLN_CUT_SPAN, j = id - k * PLN_CUT_SPAN, end = (k + 1) * chunk;
+  uint64_t q = k * chunk + j;
   uint32_t cnt = 0;
   while (q < end && q < n_quads) {
     q += step[q];
@@ -199,14 +201,14 @@ __global__ __launch_bounds__(256) void plan_cut_walk_kernel(const uint16_t *__re
   }
   walk[id] = (uint32_t)(q >= end ? q - end : 0) | (cnt << 16);
 }
-static_assert(PLN_CUT_CHUNK < 65536 && PLN_CUT_SPAN < 65536, "walk table: 16-bit fields");
+static_assert(PLN_CUT_CHUNK_MAX < 65536 && PLN_CUT_SPAN < 65536 && PLN_CUT_SPAN <= 2048, "walk table: 16-bit fields; a tile is shorter than a chunk");
 // entry[k] = first group of the first tile that starts in chunk k, base[k] = index of that tile; meta = {n_tiles}
-__global__ void plan_cut_chain_kernel(const uint32_t *__restrict__ walk, uint64_t n_chunks, uint64_t *__restrict__ entry,
+__global__ void plan_cut_chain_kernel(const uint32_t *__restrict__ walk, uint64_t n_chunks, uint32_t chunk, uint64_t *__restrict__ entry,
                                       uint64_t *__restrict__ base, unsigned long long *__restrict__ meta) {
   if (blockIdx.x || threadIdx.x) return;
   uint64_t j = 0, tiles = 0;
   for (uint64_t k = 0; k < n_chunks; ++k) {
-    entry[k] = k * PLN_CUT_CHUNK + j;
+    entry[k] = k * chunk + j;
     base[k] = tiles;
     const uint32_t w = walk[k * PLN_CUT_SPAN + j];
     tiles += w >> 16;
@@ -215,11 +217,11 @@ __global__ void plan_cut_chain_kernel(const uint32_t *__restrict__ walk, uint64_
   meta[0] = tiles;
 }
 __global__ __launch_bounds__(256) void plan_cut_write_kernel(const uint8_t *__restrict__ quad, uint64_t n_quads, uint64_t n_rows, int ncol,
-                                                             uint64_t n_chunks, const uint64_t *__restrict__ entry,
+                                                             uint64_t n_chunks, uint32_t chunk, const uint64_t *__restrict__ entry,
                                                              const uint64_t *__restrict__ base, pln_tile *__restrict__ tiles) {
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= n_chunks) return;
-  const uint64_t end = (k + 1) * PLN_CUT_CHUNK;
+  const uint64_t end = (k + 1) * chunk;
   uint64_t q = entry[k], t = base[k];
   while (q < end && q < n_quads) {
     uint32_t items, hcol, hrow;

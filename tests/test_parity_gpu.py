@@ -511,7 +511,7 @@ def test_planned_full_size_chunks(dev):
         kernels.dm_prior_planned(pn2, f, 0.0)
 
 
-@pytest.mark.parametrize("n,kind", [(1, "sparse"), (3, "dense"), (1664, "sparse"), (32768 * 2 + 5, "dense"), (32768 * 3, "sparse"),
+@pytest.mark.parametrize("n,kind", [(1, "sparse"), (3, "dense"), (1664, "sparse"), (8192 * 2 + 5, "dense"), (8192 * 3, "sparse"), (32768 * 2 + 5, "dense"),
                                     (250_007, "mixed"), (1_000_003, "sparse")])
 def test_tile_cut_on_the_device_equals_the_sequential_definition(n, kind, dev, monkeypatch):
     """bear_plan_create cuts tiles on the device (chunks walked from every possible entry point, then chained): the same tiles
