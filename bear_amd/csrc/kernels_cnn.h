@@ -204,7 +204,7 @@ __global__ __launch_bounds__(CNN_THREADS, 3) void cnn_forward_kernel(const unsig
     const uint32_t cnt = lst ? (uint32_t)lst[0] : (uint32_t)(n_rows - base < 64 ? n_rows - base : 64);
    for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
     const bool live = c0 + lane < cnt;
-    const uint64_t i = base + (lst ? (uint64_t)lst[1 + (live ? c0 + lane : 0u)] : (uint64_t)lane);
+    const uint64_t i = base + (lst ? (uint64_t)lst[1 + (live ? c0 + lane : 0u)] : (uint64_t)(live ? lane : 0u));   // lanes past the end: the first context
     unsigned long long code = codes[i];              // lanes past the end repeat the chunk's first context (nothing is stored for them)
     {
       const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)code), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(code >> 32));
