@@ -151,3 +151,18 @@ def test_bench_under_the_launcher_two_ranks(tmp_path):
         want += kernels.dm_prior_planned(kernels.Plan(t, 5), kernels.synth_prior(20211012, r * n, n, dev), 0.0).cpu().numpy()
     # the bench re-reduces its output buffer at every step: after the last step it holds the all-reduced sums of that step
     assert np.allclose(d["result"], want, rtol=1e-12), (d["result"], want)
+
+
+def test_rccl_group_of_one(tmp_path):
+    """RCCL itself on this box: a process group of one rank (two ranks cannot share a card under RCCL) runs the step's
+    collectives behind the planned kernel in stream order -- the library loads, a communicator comes up on the device the
+    rank is bound to, and a sum over one rank leaves the packed vector as the kernel wrote it."""
+    out_file = tmp_path / "rccl.json"
+    env = dict(os.environ, BEAR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               BEAR_OUT=str(out_file))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
+    got = json.load(open(out_file))
+    assert got["backend"] == "nccl" and got["world"] == 1
+    assert got["same"] is True and np.isfinite(got["out"]).all() and got["out"][0] != 0.0
+    assert got["max"] == 1.25 and got["theta"] == [0.0, 1.0, 2.0, 3.0, 4.0]
