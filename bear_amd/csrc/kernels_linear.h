@@ -31,11 +31,15 @@
 // grad_mat); the ELBO and d/dh sums keep the fixed-order reduction of the other kernels.
 #pragma once
 #include "kernels_plan.h"
+#include <type_traits>
 #ifndef LIN_DBG
 #define LIN_DBG 0   // developer cut-offs of phase C (results are then meaningless)
 #endif
 
 #define LIN_MAX_LAG 21
+#ifndef LIN_CH
+#define LIN_CH 4
+#endif
 // Letter groups: pairs over the leading letters, ONE triple over the last three.  In a k-mer-sorted table the last letters
 // vary fastest: with them in a single group, the 64 consecutive contexts of a wave differ in that group only (plus, now and
 // then, the pair before it), so every other group takes one block-level add (see phase C).
@@ -65,6 +69,7 @@ struct pln_lds_lin {
   double exptab[BEAR_EXPTAB_N];
   uint32_t ticket[2];
   uint32_t c_done;               // += 1 by every wave that has read its rows back in phase C (see the tile loop)
+  unsigned long long t_max;      // bits of the largest |logit| in the group tables (table build)
 };
 static_assert(sizeof(pln_lds_lin) <= 160 * 1024, "linear-head kernel: LDS budget");
 
@@ -164,10 +169,47 @@ __device__ __forceinline__ double lin_exp_units(double d, const double *__restri
 }
 
 // softmax row of one context from the group tables (the fifth logit is the zero the tables are relative to)
-template <int NG>
+template <int NG, bool EXP>
 __device__ __forceinline__ void lin_row(const double *T, const double *exptab, unsigned long long cv, double (&f)[5]) {
+  constexpr int CH = LIN_CH;   // table rows in flight (registers: 8 per row)
+  if (EXP) {              // the tables hold exp(logit) (see the table build): a product per letter and no exponential
+    double e[4] = {1.0, 1.0, 1.0, 1.0};
+    unsigned long long cw = cv;
+#pragma unroll
+    for (int g0 = 0; g0 < NG; g0 += CH) {
+      double2 lo[CH], hi[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        if (g0 + j < NG) {
+          const double2 *t = reinterpret_cast<const double2 *>(T + lin_off<NG>(cw, g0 + j));
+          lo[j] = t[0];
+          hi[j] = t[1];
+        }
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+        if (g0 + j < NG) {
+          if (g0 + j == 0) {
+            e[0] = lo[j].x;
+            e[1] = lo[j].y;
+            e[2] = hi[j].x;
+            e[3] = hi[j].y;
+          } else {
+            e[0] *= lo[j].x;
+            e[1] *= lo[j].y;
+            e[2] *= hi[j].x;
+            e[3] *= hi[j].y;
+          }
+        }
+      // the next rows' addresses wait for this product: otherwise all the rows are fetched at once (48 registers at six groups)
+      if (g0 + CH < NG) asm("" : "+v"(cw) : "v"(e[0]));
+    }
+    const double r = bear_rcp(1.0 + ((e[0] + e[1]) + (e[2] + e[3])));
+#pragma unroll
+    for (int b = 0; b < 4; ++b) f[b] = e[b] * r;
+    f[4] = r;
+    return;
+  }
   double z[4] = {0.0, 0.0, 0.0, 0.0};
-  constexpr int CH = 4;   // table rows in flight (registers: 8 per row)
 #pragma unroll
   for (int g0 = 0; g0 < NG; g0 += CH) {
     double2 lo[CH], hi[CH];
@@ -265,9 +307,9 @@ constexpr int LIN_RPT = (PLN_RMAX + PLN_THREADS - 1) / PLN_THREADS;   // context
 // of the same tile) and, by lin_phase_a_store, into LDS for the items.  Contexts without counts are never looked at: nothing
 // reads their rows.  The two halves are separate because a thread's rows differ from tile to tile: the LDS rows may only be
 // overwritten once EVERY wave has read its rows of the previous tile back (phase C) -- the computation does not have to wait.
-template <int NG>
-__device__ __forceinline__ uint32_t lin_phase_a(pln_lds_lin &S, const lin_buf &B, uint32_t n_live, uint32_t tid_in, double (&fA)[LIN_RPT][5],
-                                                unsigned long long (&cA)[LIN_RPT]) {
+template <int NG, bool EXP>
+__device__ __forceinline__ uint32_t lin_phase_a(pln_lds_lin &S, const lin_buf &B, uint32_t n_live, uint32_t tid_in,
+                                                double (&fA)[LIN_RPT][5], unsigned long long (&cA)[LIN_RPT]) {
   static_assert(LIN_RPT == 2 && PLN_RMAX < 0xffff, "two 16-bit row numbers in one register");
   uint32_t rows = 0xffffffffu;     // 0xffff: no row
   uint32_t tid = tid_in;
@@ -279,7 +321,7 @@ __device__ __forceinline__ uint32_t lin_phase_a(pln_lds_lin &S, const lin_buf &B
       const uint32_t row = B.live[1 + j];
       rows = k == 0 ? (rows & 0xffff0000u) | row : (rows & 0xffffu) | (row << 16);
       cA[k] = B.codes[row];
-      lin_row<NG>(S.T, S.exptab, cA[k], fA[k]);
+      lin_row<NG, EXP>(S.T, S.exptab, cA[k], fA[k]);
     }
   }
   return rows;
@@ -463,14 +505,16 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     S.ticket[0] = 0;
     S.ticket[1] = 0;
     S.c_done = 0;
+    S.t_max = 0ull;
   }
   if (tid < BEAR_EXPTAB_N) S.exptab[tid] = exp2((double)tid * (1.0 / BEAR_EXPTAB_N));
   // group tables: a row is the sum of mat[l][a_l][b] - mat[l][a_l][4] over the group's letters, in units of ln2 / 128
   // (lin_exp_units); letter value 5 = unknown and positions beyond the group or the lag contribute nothing
+  double t_abs = 0.0;
   for (int k = tid; k < n_tab; k += PLN_THREADS) {
     double v = 0.0;
     auto letter = [&](int l, int a2, int b) {
-      if (a2 < 5 && l < lag) v += (mat[(l * 5 + a2) * 5 + b] - mat[(l * 5 + a2) * 5 + 4]) * LIN_EXP_UNIT;
+      if (a2 < 5 && l < lag) v += mat[(l * 5 + a2) * 5 + b] - mat[(l * 5 + a2) * 5 + 4];
     };
     if (k < G.npair * LIN_PSTRIDE) {
       const int g = k / LIN_PSTRIDE, r = k - g * LIN_PSTRIDE, combo = r >> 2, b = r & 3;
@@ -484,8 +528,17 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
       letter(G.tri + 2, combo % 6, b);
     }
     S.T[k] = v;
+    t_abs = __builtin_fmax(t_abs, __builtin_fabs(v));
   }
   for (int k = tid; k < LIN_TAB_DOUBLES; k += PLN_THREADS) S.GT[k] = 0.0;
+  // If no context's partial sums of table rows can leave +-600 (ng rows of at most t_max each -- anything a fitted model
+  // produces), the tables hold exp(logit) and a context's softmax numerators are PRODUCTS of table entries: no exponential
+  // per context (about a third of phase A's instructions).  Otherwise logits in units of ln2 / 128 and the per-context form.
+  __syncthreads();                                                        // t_max has been zeroed
+  atomicMax(&S.t_max, (unsigned long long)__double_as_longlong(t_abs));   // non-negative doubles order like their bit patterns
+  __syncthreads();
+  const bool exp_tables = srt_uniform((uint32_t)(__longlong_as_double((long long)S.t_max) * (double)ng < 600.0)) != 0u;
+  for (int k = tid; k < n_tab; k += PLN_THREADS) S.T[k] = exp_tables ? exp(S.T[k]) : S.T[k] * LIN_EXP_UNIT;
   __syncthreads();
 
 #ifndef LIN_DMA_WAVES
@@ -514,6 +567,9 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     }
   };
 
+  // the tile loop, compiled once per table form (one loop with both forms of phase A in it ran out of registers)
+  auto tile_loop = [&](auto exp_tag) {
+  constexpr bool EXP = decltype(exp_tag)::value;
   double fA[LIN_RPT][5];
   unsigned long long cA[LIN_RPT] = {0ull, 0ull};
   uint32_t n_live = 0;   // of the tile whose phase A ran last
@@ -524,7 +580,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
 #ifdef LIN_SKIP_A
     return;
 #endif
-    LIN_FOR_NG(ng, rowA = lin_phase_a<NG>(S, B, n_live, tid, fA, cA))
+    LIN_FOR_NG(ng, rowA = (lin_phase_a<NG, EXP>(S, B, n_live, tid, fA, cA)))
   };
   auto phase_c = [&]() { LIN_FOR_NG(ng, lin_phase_c<NG>(S, n_live, tid, lane, fA, cA, rowA, acc)) };
 
@@ -631,6 +687,14 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   if (lane == 0)
     for (int k = 0; k < 8; ++k) atomicAdd(&lin_stamp_sums[k], tph[k]);
 #endif
+  };
+#ifdef LIN_ONLY_EXP   // developer builds: one form only
+  if (LIN_ONLY_EXP) tile_loop(std::true_type{});
+  else tile_loop(std::false_type{});
+#else
+  if (exp_tables) tile_loop(std::true_type{});
+  else tile_loop(std::false_type{});
+#endif
   srt_wait_dma();
   __syncthreads();
   // ---- items / contexts that overflowed to the plan's global lists (very dense tiles): self-contained
@@ -642,7 +706,11 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     unsigned long long cv = 0ull;
     double f[5];
     cv = kmer_code[row];
-    LIN_FOR_NG(ng, lin_row<NG>(S.T, S.exptab, cv, f))
+    if (exp_tables) {
+      LIN_FOR_NG(ng, (lin_row<NG, true>(S.T, S.exptab, cv, f)))
+    } else {
+      LIN_FOR_NG(ng, (lin_row<NG, false>(S.T, S.exptab, cv, f)))
+    }
     double q;
     if (AR) {
       const double pp = f[b] + eps;

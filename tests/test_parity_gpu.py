@@ -404,8 +404,9 @@ def test_fused_linear_head_parity(case, lag, dev, ysd1):
 
 
 def test_fused_linear_head_saturated_logits(dev):
-    """Logits of several hundred to thousands (a saturated softmax): the kernel leaves its un-shifted fast path (|logit| < 600
-    for the whole wave) for the max-shifted one; parity with the oracle chain either way, also with a mix inside one table."""
+    """Logits of tens (the product-of-exponentials form of the group tables, partial products up to e^+-500), of hundreds
+    (tables of logits, un-shifted softmax while the wave's |logit| < 600) and of thousands (max-shifted: a saturated softmax):
+    parity with the oracle chain in every form, also with a mix inside one table."""
     import torch
     from bear_amd import kernels
     tr = CASES_REF["sparse"]()[0]
@@ -414,7 +415,7 @@ def test_fused_linear_head_saturated_logits(dev):
     codes = rng.integers(0, 4, size=(n, lag)).astype(np.int8)
     plan = kernels.Plan(_to_dev(tr, dev), 5)
     idx = kernels.linear_index(kernels.pack_kmers(torch.from_numpy(codes).to(dev)), lag)
-    for scale in (150.0, 400.0, 3000.0):
+    for scale in (8.0, 25.0, 150.0, 400.0, 3000.0):
         mat = rng.normal(size=(lag, 5, 5)) * scale
         mat[0, 0] *= 0.001                      # contexts starting with letter 0 keep small logits from that position
         for h_s, ar in [(0.0, False), (0.4, True)]:
