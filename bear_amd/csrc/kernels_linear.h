@@ -627,7 +627,25 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
 #else
     const uint32_t n_work = n_hcu + n_hru + n_units;
 #endif
+#ifdef LIN_MIX   // developer build (timing only, results meaningless): half of the waves do their row work (C, A) before the items,
+                 // the other half after half of the items, no synchronisation inside an iteration -- how much would a kernel gain
+                 // whose LDS-bound and VALU-bound parts overlap instead of alternating?
+    const uint32_t nxt_rows = nxt.rows_items >> 16;
+    auto rows_work = [&]() {
+      phase_c();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      phase_a(S.buf[slot ^ 1u], nxt_rows);
+    };
+    bool rows_done = (wave & 1u) != 0u;
+    if (rows_done) rows_work();
+#endif
     for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_work; w = pln_ticket(&S.ticket[slot], lane)) {
+#ifdef LIN_MIX
+      if (!rows_done && w >= n_work / 2u) {
+        rows_done = true;
+        rows_work();
+      }
+#endif
       if (w < n_hcu) {
         const uint32_t i = w * 64u + lane;
         if (i < hc) {
@@ -658,10 +676,15 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
       if (!AR) srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
       if (off != (uint32_t)PLN_SENTINEL) item(off, o[0].D, o[0].P, x[0], (double)ci[0]);
     }
+#ifdef LIN_MIX
+    if (!rows_done) rows_work();
+#endif
     LIN_STAMP(0)     // B: items
     srt_wait_dma();  // the next tile's codes and plan block (issued a whole iteration ago)
     LIN_STAMP(1)     // wait for the DMA
+#if !defined(LIN_NOSYNC) && !defined(LIN_MIX)   // developer build (timing only, results meaningless): the waves run free of each other
     srt_sync();      // ... and every item of this tile has left its mark: nobody reads this tile's buffers any more
+#endif
     LIN_STAMP(2)     // barrier after the items
     cur = nxt;
     nxt = nxt2;
@@ -669,17 +692,23 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     nxt2 = pln_load_tile(pv, t + 3 * GR);
     // ---- C of this tile (rows, index words and softmax rows from phase A's registers), A of the next
     LIN_STAMP(3)     // staging the tile after next
+#ifndef LIN_MIX
     phase_c();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of this tile's LDS rows have returned
     LIN_STAMP(4)     // C
     if (lane == 0) atomicAdd(&S.c_done, 1u);
     c_target += PLN_WAVES;
     phase_a(S.buf[slot ^ 1u], cur.rows_items >> 16);
+#endif
     LIN_STAMP(5)     // A (compute)
+#if !defined(LIN_NOSYNC) && !defined(LIN_MIX)
     while (pln_peek(&S.c_done) < c_target) __builtin_amdgcn_s_sleep(1);   // every wave has: the rows may be overwritten
+#endif
     LIN_STAMP(6)     // wait for the other waves' read-backs
     lin_phase_a_store(S, fA, rowA);
+#ifndef LIN_NOSYNC
     srt_sync();      // the next tile's rows are in place for its items
+#endif
     LIN_STAMP(7)     // row stores + barrier
     slot ^= 1u;
   }
