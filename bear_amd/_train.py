@@ -287,6 +287,18 @@ def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, opti
     return torch.stack(logged).cpu().tolist() if logged else []
 
 
+def compute_dtype(dtype):
+    """``precision`` of the reference configs (``config_files/*.cfg``, `models/train_bear_net.py:58`): the HIP kernels compute
+    in float64 whatever it says -- float32 runs are accepted and carried out (parameters included) in float64."""
+    if dtype in (torch.float64, None):
+        return torch.float64
+    if dtype == torch.float32:
+        import warnings
+        warnings.warn("precision = float32: the HIP path computes and keeps its parameters in float64", stacklevel=3)
+        return torch.float64
+    raise NotImplementedError(f"precision {dtype}: the HIP kernels compute in float64")
+
+
 def log_losses(losses, writer, loss_save, acc_steps=1):
     """The per-step scalars of bear_net.py:303-307 (TensorBoard 'elbo' at batch step acc_steps, 2 acc_steps, ...; loss_save),
     written once the device loop is done."""

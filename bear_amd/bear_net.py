@@ -34,8 +34,7 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
           learning_rate, optimizer_name, train_ar, acc_steps=1,
           params_restart=None, writer=None, loss_save=None, dtype=torch.float64):
     """bear_net.train (bear_net.py:200-321); returns ``(params, h_signed, ar_func)``."""
-    if dtype != torch.float64:
-        raise NotImplementedError("the HIP kernels compute in float64")
+    dtype = _train.compute_dtype(dtype)
     device = _train.require_device()
     alphabet_size = len(core.alphabets_tf[alphabet]) - 1
     if params_restart is None:
@@ -112,6 +111,7 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
 
 
 def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype, seed):
+    dtype = _train.compute_dtype(dtype)
     device = _train.require_device()
     use_train = ds_loc_train >= 0
     cols = {"test": ds_loc_test}

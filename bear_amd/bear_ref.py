@@ -63,8 +63,7 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
     """bear_ref.train (bear_ref.py:262-389).  ``data`` is the (repeated) CountDataset of
     ``bear_amd.dataloader``; rows of every batch are sharded over the ranks of an initialised
     ``torch.distributed`` group (one process per GPU).  Returns ``(params, h_signed, ar_func)``."""
-    if dtype != torch.float64:
-        raise NotImplementedError("the HIP kernels compute in float64 (precision = float64 is the reference's recommendation)")
+    dtype = _train.compute_dtype(dtype)              # float32 configs run in float64 too (the reference recommends float64)
     device = _train.require_device()
     alphabet_size = len(core.alphabets_tf[alphabet]) - 1
     if params_restart is None:
@@ -126,6 +125,7 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
     acc_ear, acc_arm, acc_van).  ``ds_loc_train = -1``: no conditioning on training counts.  The training
     column is used for conditioning (the reference reads the reference column there by mistake,
     bear_ref.py:397 vs bear_net.py:327)."""
+    dtype = _train.compute_dtype(dtype)
     device = _train.require_device()
     use_train = ds_loc_train >= 0
     cols = {"test": ds_loc_test, "ref": ds_loc_ref}

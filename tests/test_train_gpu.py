@@ -549,6 +549,26 @@ def test_unsupported_optimizer_is_a_clear_error():
         bear_ref.train(data.repeat(2), 1365, 2, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Ftrl", False)
 
 
+def test_float32_precision_runs_in_float64():
+    """`precision = float32` of the reference configs (models/train_bear_net.py:58): accepted, with a warning, and carried out
+    in float64 -- the same losses and parameters as the float64 run."""
+    data = dataloader.dataloader(YSD1, "dna", 1500, 3)
+    runs = []
+    for dt in (torch.float64, torch.float32):
+        ls = []
+        if dt == torch.float32:
+            with pytest.warns(UserWarning, match="float64"):
+                p, _, _ = bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False,
+                                         loss_save=ls, dtype=dt)
+        else:
+            p, _, _ = bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False,
+                                     loss_save=ls, dtype=dt)
+        runs.append((ls, [float(x) for x in p[:3]]))
+    assert runs[0] == runs[1]
+    with pytest.raises(NotImplementedError):
+        bear_ref.train(data.repeat(1), 1365, 1, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False, dtype=torch.float16)
+
+
 def test_c_example_compiles_and_runs(tmp_path):
     """examples/ref_step.c: a plain-C caller of the ABI (no Python, no torch) -- compiled with gcc against include/bear_hip.h and
     run; its sums are checked against the C oracle on the same synthetic table."""
