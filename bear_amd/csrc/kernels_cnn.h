@@ -31,6 +31,9 @@
 #define CNN_THREADS 256
 #define CNN_MAX_LAG 21
 #define CNN_LN_EPS 1e-5
+#ifndef CNN_SHARED_PLACE
+#define CNN_SHARED_PLACE 0
+#endif
 #define CNN_FWD_SCRATCH 48        // doubles of LDS per wave of the forward kernel (shared-window path)
 
 struct cnn_dims {
@@ -659,6 +662,91 @@ __device__ __forceinline__ double cnnq_colsum(const double *E, uint32_t lane) {
   return (s4[0] + s4[1]) + (s4[2] + s4[3]);
 }
 
+
+// ---- a window shared by every context of a tile (k-mer-sorted batches: the contexts of a tile differ in their last letters).
+// Its conv row, layer norm and elu are the same for all of them, and everything the backward pass does with such a position is
+// LINEAR in the contexts' dT1 rows: with S = sum over the tile's contexts of dT1,
+//   d weights1[p] = e0 (x) S,   d e0 = W1[p] S,   d scale0 / d intercept0 / d conv from d e0 as for one context,
+//   d filters[w][letter_w] += d conv for the window's letters
+// -- the position costs one context's worth of work (lane = filter) instead of the tile's.  Sx: [0, 16) S, [16, 48) scratch.
+template <int CTRL>
+__device__ __forceinline__ double cnn_dpp(double v) {
+  const long long q = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)q, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(q >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (uint32_t)lo);
+}
+// the same lane of the four rows of 16 summed (every lane gets the sum): v_permlane16_swap / v_permlane32_swap
+__device__ __forceinline__ double cnn_rows_sum(double v) {
+#pragma unroll
+  for (int step = 0; step < 2; ++step) {
+    const long long q = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
+    const auto a = step == 0 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false) : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto c = step == 0 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false) : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __longlong_as_double(((long long)c[0] << 32) | a[0]) + __longlong_as_double(((long long)c[1] << 32) | a[1]);
+  }
+  return v;
+}
+__device__ __forceinline__ double cnn_wave_sum_all(double v) {   // every lane gets the sum over the wave
+  v += cnn_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += cnn_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += cnn_dpp<0x124>(v);   // row_ror:4
+  v += cnn_dpp<0x128>(v);   // row_ror:8
+  return cnn_rows_sum(v);
+}
+__device__ __forceinline__ void cnn_backward_shared_window(const double *Fs, const double *exptab, double *Sx, const double *s0p,
+                                                           const double *b0p, const double *__restrict__ W1, double *G,
+                                                           const cnn_dims &D, int p, unsigned long long win0, uint32_t lane_in) {
+  uint32_t lane = lane_in;
+  asm volatile("" : "+v"(lane));   // nothing derived from the lane number is hoisted out of the tile loop (registers of the position loop)
+  const bool in = lane < CNN_NF;
+  const uint32_t f = in ? lane : CNN_NF - 1;
+  double xf = 0.0;
+  unsigned long long c = win0;
+  for (int w = 0; w < D.fw; ++w) {
+    const int a = (int)(c & 7ull);
+    xf += Fs[(w * 6 + (a < 5 ? a : 5)) * CNN_NF + f];
+    c >>= 3;
+  }
+  const double mu = cnn_wave_sum_all(in ? xf : 0.0) * (1.0 / CNN_NF);
+  const double d = xf - mu;
+  const double r0 = cnn_rsqrt(cnn_wave_sum_all(in ? d * d : 0.0) * (1.0 / CNN_NF) + CNN_LN_EPS);
+  const double xn = d * r0, sc = s0p[f];
+  double dv;
+  const double e = cnn_elu(__builtin_fma(sc, xn, b0p[f]), exptab, dv);
+  double de[2] = {0.0, 0.0};
+  const double2 *wrow = reinterpret_cast<const double2 *>(W1 + f * CNN_L1);
+#pragma unroll
+  for (int j2 = 0; j2 < CNN_L1 / 2; ++j2) {
+    const double2 wv = wrow[j2];
+    de[0] = __builtin_fma(wv.x, Sx[2 * j2], de[0]);
+    de[1] = __builtin_fma(wv.y, Sx[2 * j2 + 1], de[1]);
+  }
+  const double dyv = in ? dv * (de[0] + de[1]) : 0.0, dn = dyv * sc;
+  const double ma0 = cnn_wave_sum_all(dn) * (1.0 / CNN_NF), ma1 = cnn_wave_sum_all(dn * xn) * (1.0 / CNN_NF);
+  const double dc = r0 * (dn - ma0 - xn * ma1);
+  if (in) {
+    Sx[16 + lane] = e;
+    cnn_lds_add(G + D.os0 + p * CNN_NF + (int)lane, dyv * xn);
+    cnn_lds_add(G + D.ob0 + p * CNN_NF + (int)lane, dyv);
+  }
+  c = win0;
+  for (int w = 0; w < D.fw; ++w) {
+    const int a = (int)(c & 7ull);       // wave-uniform; 5..7: a character outside the alphabet has no filter row
+    if (a < 5 && in) cnn_lds_add(G + D.oF + (w * 5 + a) * CNN_NF + (int)lane, dc);
+    c >>= 3;
+  }
+  // d weights1[p][f][j] += e0[f] S[j]: element lane + 64 r is (f = (lane >> 4) + 4 r, j = lane & 15)
+  const double sj = Sx[lane & 15u];
+  double *g1 = G + D.oW1 + p * CNN_NF * CNN_L1 + (int)lane;
+#pragma unroll
+  for (int r = 0; r < (CNN_NF * CNN_L1 + 63) / 64; ++r) {
+    const uint32_t fr = (lane >> 4) + 4u * (uint32_t)r;
+    if (fr < (uint32_t)CNN_NF) cnn_lds_add(g1 + 64 * r, Sx[16 + fr] * sj);
+  }
+}
+
 template <int Q>
 __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel(const unsigned long long *__restrict__ codes, uint64_t n_rows,
                                                                                   cnn_dims D, const double *__restrict__ params,
@@ -676,7 +764,8 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
   // the parameters a lane reads at a part-dependent index: scale1 [16] | intercept1 [16] | weights2 [16][5] | scale0 [P][30] | intercept0 [P][30]
   double *Ps1 = Fs + D.fw * 6 * CNN_NF, *Pb1 = Ps1 + CNN_L1, *PW2 = Pb1 + CNN_L1, *Ps0 = PW2 + CNN_L1 * 5, *Pb0 = Ps0 + D.P * CNN_NF;
   double *G = Pb0 + D.P * CNN_NF;                 // [total] block gradient image, parameter layout
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: group numbers, list pointers and row bases stay out of the vector registers
   const uint32_t ctx = lane & (TILE - 1);
   const uint32_t h = lane / TILE;                 // the lane's part: filters [FH h, FH h + FH), layer-1 units [JH h, JH h + JH)
   const bool last = h == Q - 1;                   // ... whose last two filter slots are dummies (30 filters)
@@ -822,6 +911,43 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
     }
 #pragma unroll
     for (int j = 0; j < JH; ++j) T[(h * JH + j) * ES + ctx] = t1[j];
+    // positions whose window every context of the tile shares (see cnn_backward_shared_window): handled here, once per tile,
+    // from the column sums of dT1; the position loop below skips them
+    uint32_t shared = 0;
+    unsigned long long first = 0ull;
+#ifndef CNN_NO_SHARED_BACKWARD
+    {
+      first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(code >> 32)) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)code);   // lane 0: the tile's first context (always live)
+      const unsigned long long diff = live ? code ^ first : 0ull, wm = (D.fw < 21 ? (1ull << (3 * D.fw)) : 0ull) - 1ull;
+      for (int p = 0; p < D.P; ++p)
+        if (__builtin_amdgcn_ballot_w64(((diff >> (3 * p)) & wm) != 0ull) == 0ull) shared |= 1u << p;
+#ifdef CNN_SHARED_OPAQUE_ZERO   // developer build: the detection runs, nothing is ever shared
+      {
+        uint32_t z;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+        shared &= z;
+      }
+#endif
+#if CNN_SHARED_PLACE == 0
+      if (shared) {
+        static_assert(TILE == 32, "column sums of dT1: four quarters of eight contexts");
+        uint32_t ln = lane;
+        asm volatile("" : "+v"(ln));   // as in cnn_backward_shared_window
+        const double *src = T + (ln & 15u) * ES + (ln >> 4) * (TILE / 4);
+        double sq = 0.0;
+#pragma unroll
+        for (int k = 0; k < TILE / 4; ++k) sq += src[k];
+        sq = cnn_rows_sum(sq);
+        if (ln < CNN_L1) E[ln] = sq;
+        for (int p = 0; p < D.P; ++p)
+          if ((shared >> p) & 1u)
+            cnn_backward_shared_window(Fs, exptab, E, Ps0 + p * CNN_NF, Pb0 + p * CNN_NF, params + D.oW1 + p * CNN_NF * CNN_L1, G, D, p,
+                                       first >> (3 * p), ln);
+      }
+#endif
+    }
+#endif
     double tb[KS], tb2[4][NT];     // dT1 as the B operand of d weights1 (K = contexts) and of d e0 (K = j), the same for every position
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) tb[ks] = T[lr * ES + 4 * ks + lq];
@@ -832,6 +958,9 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
     CNN_STAMP(6)
     // positions
     for (int p = 0; p < D.P; ++p) {
+#ifndef CNN_NO_SKIP
+      if ((shared >> p) & 1u) continue;
+#endif
       double x[FH], dy[FH], dn[FH];
       // conv row of the lane's filters, layer norm over all 30 (the two dummy slots of the last part stay exact zeros)
       double r0;
@@ -843,12 +972,18 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
           const int a = (int)(c & 7ull);
           const double2 *row = reinterpret_cast<const double2 *>(Fs + (w * 6 + (a < 5 ? a : 5)) * CNN_NF + h * FH);
           c >>= 3;
+          double2 v[FH / 2];                // slots 30, 31 of the last part: the next row's first words, discarded below
+#pragma unroll
+          for (int f2 = 0; f2 < FH / 2; ++f2) v[f2] = row[f2];
 #pragma unroll
           for (int f2 = 0; f2 < FH / 2; ++f2) {
-            const double2 v = row[f2];      // slots 30, 31 of the last part: the next row's first words, discarded below
-            x[2 * f2] += v.x;
-            x[2 * f2 + 1] += v.y;
+            x[2 * f2] += v[f2].x;
+            x[2 * f2 + 1] += v[f2].y;
           }
+          // all the reads of a tap in flight, then its adds (left to itself the scheduler sometimes waits for every read in turn:
+          // 5 % of the kernel)
+          __builtin_amdgcn_sched_group_barrier(0x100, FH / 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, FH, 0);
         }
         if (last) {
           x[FH - 2] = 0.0;
@@ -1020,6 +1155,23 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
       }
       CNN_STAMP(5)
     }
+#if CNN_SHARED_PLACE == 1 && !defined(CNN_NO_SHARED_BACKWARD)
+      if (shared) {
+        static_assert(TILE == 32, "column sums of dT1: four quarters of eight contexts");
+        uint32_t ln = lane;
+        asm volatile("" : "+v"(ln));   // as in cnn_backward_shared_window
+        const double *src = T + (ln & 15u) * ES + (ln >> 4) * (TILE / 4);
+        double sq = 0.0;
+#pragma unroll
+        for (int k = 0; k < TILE / 4; ++k) sq += src[k];
+        sq = cnn_rows_sum(sq);
+        if (ln < CNN_L1) E[ln] = sq;
+        for (int p = 0; p < D.P; ++p)
+          if ((shared >> p) & 1u)
+            cnn_backward_shared_window(Fs, exptab, E, Ps0 + p * CNN_NF, Pb0 + p * CNN_NF, params + D.oW1 + p * CNN_NF * CNN_L1, G, D, p,
+                                       first >> (3 * p), ln);
+      }
+#endif
    }
   }
 #ifdef CNN_STAMPS
