@@ -50,6 +50,53 @@ def test_cnn_forward_matches_oracle(lag, fw, n):
     assert t1.shape == (n, 16)
 
 
+def _drifting_prefix_kmers(n, lag, rng, block=200):
+    """Contexts as a k-mer-sorted batch holds them: blocks share everything but their last letters; the prefix drifts slowly and
+    may hold start symbols and letters outside the alphabet."""
+    letters = np.array(list("ACGT[N"))
+    prefix = letters[rng.choice(6, size=lag, p=[0.23, 0.23, 0.23, 0.23, 0.05, 0.03])]
+    tail = max(1, min(3, lag - 1))
+    kmers = []
+    for k in range(n):
+        if k % block == 0 and k:
+            prefix = prefix.copy()
+            prefix[rng.integers(0, lag - tail)] = letters[rng.integers(0, 6)]
+        row = prefix.copy()
+        row[lag - tail:] = letters[rng.integers(0, 4, size=tail)]
+        kmers.append("".join(row))
+    return kmers
+
+
+@pytest.mark.parametrize("lag,fw,n", [(13, 8, 3000), (9, 3, 1000), (5, 5, 777), (13, 8, 40)])
+def test_cnn_backward_shared_windows_in_sorted_contexts(lag, fw, n):
+    """The backward kernel does a position whose window a whole tile of 32 contexts shares ONCE, from the column sums of dT1
+    (everything it adds is linear in dT1): gradients against torch autograd of the one-hot formulation on contexts with long
+    common prefixes (start symbols and unknown letters inside them), and == the gradients of the same contexts in random order."""
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(lag * 17 + fw + n)
+    kmers = _drifting_prefix_kmers(n, lag, rng, block=70)
+    ar_func, params = _make(lag, fw, dev, 11)
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+    codes = torch.from_numpy(core.encode_kmers(kmers, "dna")).to(dev)
+    packed = kernels.pack_kmers(codes)
+    prior, t1 = kernels.cnn_forward(packed, flat, lag, fw)
+    grad_rows = torch.from_numpy(rng.standard_normal((n, 5)) * np.exp(rng.normal(size=(n, 1)))).to(dev)
+    grad_rows[rng.random(n) < 0.3] = 0.0               # contexts without counts
+    got = kernels.cnn_backward(packed, flat, lag, fw, t1, prior, grad_rows)
+    rows = ar_func(core.tf_one_hot(kmers, "dna", device=dev))
+    rows.backward(grad_rows)
+    want = torch.cat([p.grad.reshape(-1) for p in params])
+    k = 0
+    for p in params:
+        m = p.numel()
+        assert (got[k:k + m] - want[k:k + m]).abs().max().item() <= GRAD_RTOL * max(want[k:k + m].abs().max().item(), 1e-30), (p.shape,)
+        k += m
+    perm = torch.from_numpy(rng.permutation(n)).to(dev)
+    got_p = kernels.cnn_backward(packed[perm].contiguous(), flat, lag, fw, t1[perm].contiguous(), prior[perm].contiguous(),
+                                 grad_rows[perm].contiguous())
+    assert (got_p - got).abs().max().item() <= 1e-11 * got.abs().max().item()
+
+
 @pytest.mark.parametrize("lag,fw", [(13, 8), (9, 3), (5, 5)])
 def test_cnn_forward_shared_windows_in_sorted_contexts(lag, fw):
     """k-mer-sorted contexts with long common prefixes (what bear_net.train uploads): whole waves share the windows inside the
