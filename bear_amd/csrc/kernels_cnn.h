@@ -31,8 +31,8 @@
 #define CNN_THREADS 256
 #define CNN_MAX_LAG 21
 #define CNN_LN_EPS 1e-5
-#ifndef CNN_SHARED_PLACE
-#define CNN_SHARED_PLACE 0
+#ifndef CNN_SHARED_RUNS
+#define CNN_SHARED_RUNS 6            // backward: a position is done per distinct window when a tile holds at most this many (cnn_backward_shared_window)
 #endif
 #define CNN_FWD_SCRATCH 48        // doubles of LDS per wave of the forward kernel (shared-window path)
 
@@ -688,62 +688,83 @@ __device__ __forceinline__ double cnn_rows_sum(double v) {
   }
   return v;
 }
-__device__ __forceinline__ double cnn_wave_sum_all(double v) {   // every lane gets the sum over the wave
+__device__ __forceinline__ double cnn_half_sum_all(double v) {   // every lane gets the sum over its half of the wave (32 lanes)
   v += cnn_dpp<0xB1>(v);    // quad_perm [1,0,3,2]
   v += cnn_dpp<0x4E>(v);    // quad_perm [2,3,0,1]
   v += cnn_dpp<0x124>(v);   // row_ror:4
   v += cnn_dpp<0x128>(v);   // row_ror:8
-  return cnn_rows_sum(v);
+  const long long q = __double_as_longlong(v);
+  const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)c[0] << 32) | a[0]) + __longlong_as_double(((long long)c[1] << 32) | a[1]);
 }
-__device__ __forceinline__ void cnn_backward_shared_window(const double *Fs, const double *exptab, double *Sx, const double *s0p,
-                                                           const double *b0p, const double *__restrict__ W1, double *G,
-                                                           const cnn_dims &D, int p, unsigned long long win0, uint32_t lane_in) {
+// TWO (position, window) items per call, one per half of the wave (lane & 31 = filter): the work is a chain of dependent steps
+// (conv, two-pass norm, elu, norm backward), so a second item costs nothing.  Sx: per item 48 doubles, [0, 16) S, [16, 48) scratch.
+__device__ __forceinline__ void cnn_backward_shared_window(const double *Fs, const double *exptab, double *Sx, const double *Ps0,
+                                                           const double *Pb0, const double *__restrict__ W1all, double *G,
+                                                           const cnn_dims &D, int p_a, unsigned long long win_a, int p_b,
+                                                           unsigned long long win_b, bool two, uint32_t lane_in) {
   uint32_t lane = lane_in;
   asm volatile("" : "+v"(lane));   // nothing derived from the lane number is hoisted out of the tile loop (registers of the position loop)
-  const bool in = lane < CNN_NF;
-  const uint32_t f = in ? lane : CNN_NF - 1;
+  const bool second = lane >= 32u;
+  const uint32_t l32 = lane & 31u;
+  const bool in = l32 < CNN_NF && (two || !second);
+  const uint32_t f = l32 < CNN_NF ? l32 : CNN_NF - 1;
+  const int p = second ? p_b : p_a;
+  const unsigned long long win0 = second ? win_b : win_a;
+  double *Sme = Sx + (second ? 48 : 0);
+  // the lane's row of weights1[p] comes from global memory: asked for first, used after the conv / norm / elu chain
+  double2 wv[CNN_L1 / 2];
+  {
+    const double2 *wrow = reinterpret_cast<const double2 *>(W1all + (p * CNN_NF + (int)f) * CNN_L1);
+#pragma unroll
+    for (int j2 = 0; j2 < CNN_L1 / 2; ++j2) wv[j2] = wrow[j2];
+  }
   double xf = 0.0;
   unsigned long long c = win0;
-  for (int w = 0; w < D.fw; ++w) {
-    const int a = (int)(c & 7ull);
-    xf += Fs[(w * 6 + (a < 5 ? a : 5)) * CNN_NF + f];
-    c >>= 3;
+  for (int w = 0; w < D.fw; w += 4) {      // four taps' reads in flight (taps beyond the filter width read a zero row)
+    double t4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int a = (int)((c >> (3 * k)) & 7ull);
+      t4[k] = Fs[(w + k < D.fw ? (w + k) * 6 + (a < 5 ? a : 5) : 5) * CNN_NF + f];
+    }
+    xf += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    c >>= 12;
   }
-  const double mu = cnn_wave_sum_all(in ? xf : 0.0) * (1.0 / CNN_NF);
+  const double mu = cnn_half_sum_all(l32 < CNN_NF ? xf : 0.0) * (1.0 / CNN_NF);
   const double d = xf - mu;
-  const double r0 = cnn_rsqrt(cnn_wave_sum_all(in ? d * d : 0.0) * (1.0 / CNN_NF) + CNN_LN_EPS);
-  const double xn = d * r0, sc = s0p[f];
+  const double r0 = cnn_rsqrt(cnn_half_sum_all(l32 < CNN_NF ? d * d : 0.0) * (1.0 / CNN_NF) + CNN_LN_EPS);
+  const double xn = d * r0, sc = Ps0[p * CNN_NF + (int)f];
   double dv;
-  const double e = cnn_elu(__builtin_fma(sc, xn, b0p[f]), exptab, dv);
+  const double e = cnn_elu(__builtin_fma(sc, xn, Pb0[p * CNN_NF + (int)f]), exptab, dv);
   double de[2] = {0.0, 0.0};
-  const double2 *wrow = reinterpret_cast<const double2 *>(W1 + f * CNN_L1);
 #pragma unroll
   for (int j2 = 0; j2 < CNN_L1 / 2; ++j2) {
-    const double2 wv = wrow[j2];
-    de[0] = __builtin_fma(wv.x, Sx[2 * j2], de[0]);
-    de[1] = __builtin_fma(wv.y, Sx[2 * j2 + 1], de[1]);
+    de[0] = __builtin_fma(wv[j2].x, Sme[2 * j2], de[0]);
+    de[1] = __builtin_fma(wv[j2].y, Sme[2 * j2 + 1], de[1]);
   }
-  const double dyv = in ? dv * (de[0] + de[1]) : 0.0, dn = dyv * sc;
-  const double ma0 = cnn_wave_sum_all(dn) * (1.0 / CNN_NF), ma1 = cnn_wave_sum_all(dn * xn) * (1.0 / CNN_NF);
+  const double dyv = l32 < CNN_NF ? dv * (de[0] + de[1]) : 0.0, dn = dyv * sc;
+  const double ma0 = cnn_half_sum_all(dn) * (1.0 / CNN_NF), ma1 = cnn_half_sum_all(dn * xn) * (1.0 / CNN_NF);
   const double dc = r0 * (dn - ma0 - xn * ma1);
   if (in) {
-    Sx[16 + lane] = e;
-    cnn_lds_add(G + D.os0 + p * CNN_NF + (int)lane, dyv * xn);
-    cnn_lds_add(G + D.ob0 + p * CNN_NF + (int)lane, dyv);
+    Sme[16 + l32] = e;
+    cnn_lds_add(G + D.os0 + p * CNN_NF + (int)l32, dyv * xn);
+    cnn_lds_add(G + D.ob0 + p * CNN_NF + (int)l32, dyv);
   }
   c = win0;
   for (int w = 0; w < D.fw; ++w) {
-    const int a = (int)(c & 7ull);       // wave-uniform; 5..7: a character outside the alphabet has no filter row
-    if (a < 5 && in) cnn_lds_add(G + D.oF + (w * 5 + a) * CNN_NF + (int)lane, dc);
+    const int a = (int)(c & 7ull);       // 5..7: a character outside the alphabet has no filter row
+    if (a < 5 && in) cnn_lds_add(G + D.oF + (w * 5 + a) * CNN_NF + (int)l32, dc);
     c >>= 3;
   }
-  // d weights1[p][f][j] += e0[f] S[j]: element lane + 64 r is (f = (lane >> 4) + 4 r, j = lane & 15)
-  const double sj = Sx[lane & 15u];
-  double *g1 = G + D.oW1 + p * CNN_NF * CNN_L1 + (int)lane;
+  // d weights1[p][f][j] += e0[f] S[j]: element l32 + 32 r of the item is (f = (l32 >> 4) + 2 r, j = l32 & 15)
+  if (two || !second) {
+    const double sj = Sme[l32 & 15u];
+    double *g1 = G + D.oW1 + p * CNN_NF * CNN_L1 + (int)l32;
 #pragma unroll
-  for (int r = 0; r < (CNN_NF * CNN_L1 + 63) / 64; ++r) {
-    const uint32_t fr = (lane >> 4) + 4u * (uint32_t)r;
-    if (fr < (uint32_t)CNN_NF) cnn_lds_add(g1 + 64 * r, Sx[16 + fr] * sj);
+    for (int r = 0; r < CNN_NF * CNN_L1 / 32; ++r) cnn_lds_add(g1 + 32 * r, Sme[16 + (l32 >> 4) + 2u * (uint32_t)r] * sj);
   }
 }
 
@@ -914,40 +935,64 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
     // positions whose window every context of the tile shares (see cnn_backward_shared_window): handled here, once per tile,
     // from the column sums of dT1; the position loop below skips them
     uint32_t shared = 0;
-    unsigned long long first = 0ull;
+    CNN_STAMP(6)
 #ifndef CNN_NO_SHARED_BACKWARD
     {
-      first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(code >> 32)) << 32) |
-                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)code);   // lane 0: the tile's first context (always live)
-      const unsigned long long diff = live ? code ^ first : 0ull, wm = (D.fw < 21 ? (1ull << (3 * D.fw)) : 0ull) - 1ull;
-      for (int p = 0; p < D.P; ++p)
-        if (__builtin_amdgcn_ballot_w64(((diff >> (3 * p)) & wm) != 0ull) == 0ull) shared |= 1u << p;
-#ifdef CNN_SHARED_OPAQUE_ZERO   // developer build: the detection runs, nothing is ever shared
-      {
-        uint32_t z;
-        asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-        shared &= z;
-      }
-#endif
-#if CNN_SHARED_PLACE == 0
-      if (shared) {
-        static_assert(TILE == 32, "column sums of dT1: four quarters of eight contexts");
-        uint32_t ln = lane;
-        asm volatile("" : "+v"(ln));   // as in cnn_backward_shared_window
-        const double *src = T + (ln & 15u) * ES + (ln >> 4) * (TILE / 4);
-        double sq = 0.0;
+      uint32_t ln = lane;
+      asm volatile("" : "+v"(ln));   // as in cnn_backward_shared_window
+      static_assert(TILE == 32, "column sums of dT1: four quarters of eight contexts; lanes 0..31 of a ballot are the contexts");
+      const unsigned long long wm = (D.fw < 21 ? (1ull << (3 * D.fw)) : 0ull) - 1ull;
+      const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
+      auto next_run = [&](unsigned long long wid, unsigned long long rem, unsigned long long *w) {   // the contexts that share the window of rem's first
+        const int leader = __builtin_ctzll(rem);
+        *w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wid >> 32), leader) << 32) |
+             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wid, leader);
+        return __builtin_amdgcn_ballot_w64(wid == *w) & rem;
+      };
+      bool pending = false, have_full = false;
+      double s_full = 0.0;
+      int p_a = 0;
+      unsigned long long w_a = 0ull;
+      for (int p = 0; p < D.P; ++p) {
+        const unsigned long long wid = (code >> (3 * p)) & wm;
+        unsigned long long rem = live_mask, w;
+        for (int runs = 0; rem != 0ull && runs < CNN_SHARED_RUNS; ++runs) rem &= ~next_run(wid, rem, &w);
+        if (rem != 0ull) break;               // more distinct windows than pay: the position loop below takes this position and the
+                                              // later ones (in a sorted batch their windows reach further into the varying letters)
+        shared |= 1u << p;
+        for (rem = live_mask; rem != 0ull;) {
+          const unsigned long long m = next_run(wid, rem, &w);
+          rem &= ~m;
+          // S = the run's column sums of dT1 (lane: unit ln & 15, contexts 8 (ln >> 4) .. + 7); a run of all the tile's contexts
+          // (a fully shared window: most of them) reuses the tile's sums
+          double sq = s_full;
+          if (m != live_mask || !have_full) {
+            const double *src = T + (ln & 15u) * ES + (ln >> 4) * (TILE / 4);
+            const uint32_t mine = (uint32_t)m >> ((ln >> 4) * (TILE / 4));
+            sq = 0.0;
 #pragma unroll
-        for (int k = 0; k < TILE / 4; ++k) sq += src[k];
-        sq = cnn_rows_sum(sq);
-        if (ln < CNN_L1) E[ln] = sq;
-        for (int p = 0; p < D.P; ++p)
-          if ((shared >> p) & 1u)
-            cnn_backward_shared_window(Fs, exptab, E, Ps0 + p * CNN_NF, Pb0 + p * CNN_NF, params + D.oW1 + p * CNN_NF * CNN_L1, G, D, p,
-                                       first >> (3 * p), ln);
+            for (int k = 0; k < TILE / 4; ++k) sq += ((mine >> k) & 1u) ? src[k] : 0.0;
+            sq = cnn_rows_sum(sq);
+            if (m == live_mask) {
+              s_full = sq;
+              have_full = true;
+            }
+          }
+          if (ln < CNN_L1) E[(pending ? 48u : 0u) + ln] = sq;
+          if (!pending) {                     // items go in pairs: one per half of the wave
+            p_a = p;
+            w_a = w;
+            pending = true;
+          } else {
+            cnn_backward_shared_window(Fs, exptab, E, Ps0, Pb0, params + D.oW1, G, D, p_a, w_a, p, w, true, ln);
+            pending = false;
+          }
+        }
       }
-#endif
+      if (pending) cnn_backward_shared_window(Fs, exptab, E, Ps0, Pb0, params + D.oW1, G, D, p_a, w_a, p_a, w_a, false, ln);
     }
 #endif
+    CNN_STAMP(7)
     double tb[KS], tb2[4][NT];     // dT1 as the B operand of d weights1 (K = contexts) and of d e0 (K = j), the same for every position
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) tb[ks] = T[lr * ES + 4 * ks + lq];
@@ -1155,23 +1200,6 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
       }
       CNN_STAMP(5)
     }
-#if CNN_SHARED_PLACE == 1 && !defined(CNN_NO_SHARED_BACKWARD)
-      if (shared) {
-        static_assert(TILE == 32, "column sums of dT1: four quarters of eight contexts");
-        uint32_t ln = lane;
-        asm volatile("" : "+v"(ln));   // as in cnn_backward_shared_window
-        const double *src = T + (ln & 15u) * ES + (ln >> 4) * (TILE / 4);
-        double sq = 0.0;
-#pragma unroll
-        for (int k = 0; k < TILE / 4; ++k) sq += src[k];
-        sq = cnn_rows_sum(sq);
-        if (ln < CNN_L1) E[ln] = sq;
-        for (int p = 0; p < D.P; ++p)
-          if ((shared >> p) & 1u)
-            cnn_backward_shared_window(Fs, exptab, E, Ps0 + p * CNN_NF, Pb0 + p * CNN_NF, params + D.oW1 + p * CNN_NF * CNN_L1, G, D, p,
-                                       first >> (3 * p), ln);
-      }
-#endif
    }
   }
 #ifdef CNN_STAMPS
