@@ -205,21 +205,29 @@ def main():
         pr_c, t1_c = kernels.cnn_forward(packed, flat, lag, fw)
         _, g_c = kernels.dm_prior_planned(plans["net"], pr_c, h_s, want_grad=True)
         b_ms = timed(lambda: kernels.cnn_backward(packed, flat, lag, fw, t1_c, pr_c, g_c), 3)
+        del pr_c, t1_c, g_c
+        # the same two kernels over all rows in k-mer order: a wave's contexts then share their leading letters and both kernels
+        # evaluate a window the whole wave / tile shares once (the backward: per distinct window, from the column sums of dT1)
+        fs_ms = timed(lambda: kernels.cnn_forward(packed_sorted_raw, flat, lag, fw), 3)
+        pr_c, t1_c = kernels.cnn_forward(packed_sorted_raw, flat, lag, fw)
+        _, g_c = kernels.dm_prior_planned(plans["net"], pr_c, h_s, want_grad=True)
+        bs_ms = timed(lambda: kernels.cnn_backward(packed_sorted_raw, flat, lag, fw, t1_c, pr_c, g_c), 3)
+        del pr_c, t1_c, g_c
         # the training step as bear_net.train enqueues it (bear_net_cnn_train_reduce_f64): the same three kernels, forward and
         # backward over the plan's lists of contexts that hold training counts only (the others' gradient rows are zero)
-        del pr_c, t1_c, g_c
         theta = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), flat]).contiguous()
         bufs = kernels.cnn_step_buffers(n, lag, fw, dev)
         pk = torch.zeros(2 + flat.numel(), dtype=torch.float64, device=dev)
         s_ms = timed(lambda: kernels.net_cnn_train_reduce(plans["net"], packed_sorted_raw, lag, fw, theta, bufs, pk), 3)
         s_ms_random = timed(lambda: kernels.net_cnn_train_reduce(plans["net"], packed, lag, fw, theta, bufs, pk), 3)
         extra["cnn_head"] = {"lag": lag, "filter_width": fw, "forward_ms": f_ms, "backward_ms": b_ms,
+                             "forward_ms_rows_in_kmer_order": fs_ms, "backward_ms_rows_in_kmer_order": bs_ms,
                              "all_rows_step_ms": f_ms + b_ms + extra["net_with_gradient_rows"]["kernel_ms"],
                              "train_step_ms": s_ms, "train_step_ms_rows_in_random_order": s_ms_random, "step_contexts_per_s": n / (s_ms * 1e-3),
-                             "note": "forward_ms / backward_ms: bear_cnn_forward_f64 / bear_cnn_backward_f64 over all rows (any caller); "
+                             "note": "forward_ms / backward_ms: bear_cnn_forward_f64 / bear_cnn_backward_f64 over all rows in random order (any caller); "
                                      "train_step_ms: bear_net_cnn_train_reduce_f64 = forward + planned DM kernel with gradient rows + "
                                      "backward over the contexts that hold training counts (70 % of this table), rows in k-mer order as "
-                                     "bear_net.train uploads a batch (a wave of the forward kernel evaluates a window its contexts share once)"}
+                                     "bear_net.train uploads a batch (both kernels evaluate a window that a wave's / tile's contexts share once)"}
         del packed, packed_raw, packed_sorted_raw, bufs, pk, theta
         m = min(n, 20_000_000)
         test = kernels.synth_counts(SEED, row0, m, dev, want=("test",))["test"]
