@@ -34,6 +34,9 @@
 #ifndef CNN_SHARED_RUNS
 #define CNN_SHARED_RUNS 6            // backward: a position is done per distinct window when a tile holds at most this many (cnn_backward_shared_window)
 #endif
+#ifndef CNN_FWD_RUNS
+#define CNN_FWD_RUNS 3               // forward: a position is done per distinct window when a wave holds at most this many
+#endif
 #define CNN_FWD_SCRATCH 48        // doubles of LDS per wave of the forward kernel (shared-window path)
 
 struct cnn_dims {
@@ -198,7 +201,8 @@ __global__ __launch_bounds__(CNN_THREADS, 3) void cnn_forward_kernel(const unsig
   __syncthreads();
   // A wave walks groups of contexts, 64 at a time: without lists, group g = rows [64 g, 64 g + 64); with the plan's lists
   // (the training step) group g = plan tile g and only its contexts that hold counts -- nothing reads the others' rows.
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = CNN_THREADS / 64;
+  const uint32_t lane = threadIdx.x & 63u, n_waves = CNN_THREADS / 64;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: group numbers, list pointers, row bases
   double *Us = Fs + D.fw * 6 * CNN_NF + wave * CNN_FWD_SCRATCH;     // per wave: e0 of a shared window [32] | its layer-1 sums [16]
   const unsigned long long wmask = 3 * D.fw >= 64 ? ~0ull : (1ull << (3 * D.fw)) - 1ull;
   for (uint64_t g = (uint64_t)blockIdx.x * n_waves + wave; g < n_groups; g += (uint64_t)gridDim.x * n_waves) {
@@ -216,19 +220,35 @@ __global__ __launch_bounds__(CNN_THREADS, 3) void cnn_forward_kernel(const unsig
     double t1[CNN_L1];
 #pragma unroll
     for (int j = 0; j < CNN_L1; ++j) t1[j] = 0.0;
+    bool try_shared = true;
     for (int p = 0; p < D.P; ++p) {
       // In a k-mer-sorted batch (bear_net.train sorts at upload) the 64 contexts of a wave share their leading letters: a window
       // [p, p + fw) that lies inside the shared prefix gives every context the SAME conv row, activations and layer-1
       // contribution.  Then 30 lanes compute the row once (lane = filter), 16 lanes the contribution (lane = unit), and every
       // context adds it: ~200 instructions instead of ~1500 for the position.
+      // The same per DISTINCT window when the wave holds a few (CNN_FWD_RUNS; the first position behind the shared prefix).
       const unsigned long long win = (code >> (3 * p)) & wmask;
-      const unsigned long long win0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(win >> 32)) << 32) |
-                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)win);
-      if (__builtin_amdgcn_ballot_w64(win != win0) == 0ull) {
-        cnn_forward_shared_window(Fs, exptab, Us, params + D.os0 + p * CNN_NF, params + D.ob0 + p * CNN_NF,
-                                  params + D.oW1 + p * CNN_NF * CNN_L1, D.fw, win0, lane);
+      auto next_run = [&](unsigned long long rem, unsigned long long *w) {   // the lanes that share the window of rem's first lane
+        const int leader = __builtin_ctzll(rem);
+        *w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(win >> 32), leader) << 32) |
+             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)win, leader);
+        return __builtin_amdgcn_ballot_w64(win == *w) & rem;
+      };
+      unsigned long long rem = ~0ull, wv;
+      if (try_shared)
+        for (int runs = 0; rem != 0ull && runs < CNN_FWD_RUNS; ++runs) rem &= ~next_run(rem, &wv);
+      try_shared = rem == 0ull;               // in a sorted batch the later windows reach further into the varying letters: no further tries
+      if (rem == 0ull) {
+        for (rem = ~0ull; rem != 0ull;) {
+          const unsigned long long m = next_run(rem, &wv);
+          rem &= ~m;
+          cnn_forward_shared_window(Fs, exptab, Us, params + D.os0 + p * CNN_NF, params + D.ob0 + p * CNN_NF,
+                                    params + D.oW1 + p * CNN_NF * CNN_L1, D.fw, wv, lane);
+          if (win == wv) {
 #pragma unroll
-        for (int j = 0; j < CNN_L1; ++j) t1[j] += Us[32 + j];
+            for (int j = 0; j < CNN_L1; ++j) t1[j] += Us[32 + j];
+          }
+        }
         continue;
       }
       double x[CNN_NF];
