@@ -209,9 +209,11 @@ __global__ __launch_bounds__(CNN_THREADS, 3) void cnn_forward_kernel(const unsig
     const uint16_t *lst = live_lists ? live_lists + g * PLN_LIVE_STRIDE : nullptr;
     const uint64_t base = lst ? tiles[g].row0 : g * 64;
     const uint32_t cnt = lst ? (uint32_t)lst[0] : (uint32_t)(n_rows - base < 64 ? n_rows - base : 64);
+   uint32_t row_next = lst ? (uint32_t)lst[1 + (lane < cnt ? lane : 0u)] : (lane < cnt ? lane : 0u);   // a chunk's list entries are read one chunk ahead
    for (uint32_t c0 = 0; c0 < cnt; c0 += 64) {
     const bool live = c0 + lane < cnt;
-    const uint64_t i = base + (lst ? (uint64_t)lst[1 + (live ? c0 + lane : 0u)] : (uint64_t)(live ? lane : 0u));   // lanes past the end: the first context
+    const uint64_t i = base + (uint64_t)row_next;                                                        // lanes past the end: the first context
+    if (lst && c0 + 64 < cnt) row_next = (uint32_t)lst[1 + (c0 + 64 + lane < cnt ? c0 + 64 + lane : 0u)];
     unsigned long long code = codes[i];              // lanes past the end repeat the chunk's first context (nothing is stored for them)
     {
       const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)code), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(code >> 32));
@@ -840,9 +842,11 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
     const uint16_t *lst = live_lists ? live_lists + g * PLN_LIVE_STRIDE : nullptr;
     const uint64_t base = lst ? tiles[g].row0 : g * TILE;
     const uint32_t cnt = lst ? (uint32_t)lst[0] : (uint32_t)(n_rows - base < (uint64_t)TILE ? n_rows - base : (uint64_t)TILE);
-   for (uint32_t c0 = 0; c0 < cnt; c0 += TILE) {
+   uint32_t row_next = lst ? (uint32_t)lst[1 + (ctx < cnt ? ctx : 0u)] : ctx;   // the list entry of a tile is read one tile ahead:
+   for (uint32_t c0 = 0; c0 < cnt; c0 += TILE) {                                // its rows' loads then start at once
     const bool live = c0 + ctx < cnt;
-    const uint64_t i = base + (lst ? (uint64_t)lst[1 + (live ? c0 + ctx : 0u)] : (uint64_t)ctx);
+    const uint64_t i = base + (uint64_t)row_next;
+    if (lst && c0 + TILE < cnt) row_next = (uint32_t)lst[1 + (c0 + TILE + ctx < cnt ? c0 + TILE + ctx : 0u)];
     // dead lanes: every letter "other" and a zero gradient row -> all their contributions are exact zeros
     unsigned long long code = 0;
 #pragma unroll
