@@ -648,7 +648,9 @@ struct cnnq {
   static constexpr int CS = TILE + 1;            // column-sum staging: row stride in doubles ([column][context])
   static constexpr int KS = TILE / 4;            // MFMA k-steps over the contexts of a tile
   static constexpr int NT = TILE / 16;           // MFMA column tiles over the contexts of a tile
-  static constexpr int E_DOUBLES = CNN_NF * ES, T_DOUBLES = CNN_L1 * ES, WAVE_DOUBLES = E_DOUBLES + T_DOUBLES + TILE;
+  static constexpr int CARRY_POS = 2;            // leading positions whose fully shared windows are carried across tiles (below)
+  static constexpr int CARRY_DOUBLES = CARRY_POS * CNN_L1 + 4;   // their column sums, then their windows as raw words
+  static constexpr int E_DOUBLES = CNN_NF * ES, T_DOUBLES = CNN_L1 * ES, WAVE_DOUBLES = E_DOUBLES + T_DOUBLES + TILE + CARRY_DOUBLES;
   static constexpr int WAVES = Q == 2 ? 8 : 12;  // per block = per CU: two / three per SIMD
   static constexpr int W2Q = CNN_L1 * 5 / Q;     // d weights2 columns a part owns
   static constexpr int COLQ = 32 / Q;            // staging columns of a part per round of 32
@@ -809,12 +811,10 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
   double *G = Pb0 + D.P * CNN_NF;                 // [total] block gradient image, parameter layout
   const uint32_t lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: group numbers, list pointers and row bases stay out of the vector registers
-  const uint32_t ctx = lane & (TILE - 1);
-  const uint32_t h = lane / TILE;                 // the lane's part: filters [FH h, FH h + FH), layer-1 units [JH h, JH h + JH)
-  const bool last = h == Q - 1;                   // ... whose last two filter slots are dummies (30 filters)
   double *E = G + ((D.total + 1) & ~1) + wave * C::WAVE_DOUBLES;   // [30][ES] staging
   double *T = E + C::E_DOUBLES;                                     // [16][ES] dT1
   unsigned long long *Cw = reinterpret_cast<unsigned long long *>(T + C::T_DOUBLES);   // [TILE] packed contexts
+  double *Cy = T + C::T_DOUBLES + TILE;                                                // carried column sums and windows
   if (threadIdx.x < BEAR_EXPTAB_N) exptab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / BEAR_EXPTAB_N));
   for (int k = threadIdx.x; k < D.fw * 6 * CNN_NF; k += blockDim.x) {
     const int w = k / (6 * CNN_NF), r = k - w * 6 * CNN_NF, a = r / CNN_NF, f = r - a * CNN_NF;
@@ -834,16 +834,64 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
 #ifdef CNN_STAMPS
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #endif
-  const uint32_t lq = lane >> 4, lr = lane & 15u;     // MFMA lane coordinates: k / row-group index, row / column index
   const int n_mt = (4 * D.fw + 15) / 16;              // M tiles of the one-hot operand: rows (tap w, letter a < 4)
   // A wave walks groups of contexts, TILE at a time: without lists, group g = rows [TILE g, TILE g + TILE); with the plan's
   // lists (the training step) group g = plan tile g and only its contexts that hold counts (the others' gradient rows are zero)
-  for (uint64_t g = (uint64_t)blockIdx.x * n_waves + wave; g < n_groups; g += (uint64_t)gridDim.x * n_waves) {
+  // A wave takes a CONTIGUOUS range of groups: in a k-mer-sorted table consecutive tiles share the windows of their leading
+  // positions, and a fully shared window of position 0 or 1 that the next tile shares too is not worked off per tile -- its
+  // column sums are carried in Cy (the wave's own LDS words: plain read-add-write) until the window changes.
+  const uint64_t wave_id = (uint64_t)blockIdx.x * n_waves + wave, wave_cnt = (uint64_t)gridDim.x * n_waves;
+  uint32_t carry = 0;                         // bit p: position p has a carried window
+  // (position, window) items queue up in the wave's staging area E (free between position loops): slot k = E[48 k ..): S [16],
+  // e0 scratch [30], and the window / the position as raw words at [46], [47]; drain_items works them off in pairs
+  uint32_t n_items = 0;
+  constexpr uint32_t MAX_ITEMS = 20;          // 48 * 20 <= the 1080 doubles of E
+  auto word = [&](const double *q) {          // a word every lane reads from the same LDS address, as a scalar
+    const long long v = __double_as_longlong(*q);
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  };
+  auto push_item = [&](int p, unsigned long long w, double val, uint32_t ln) {   // S[ln] = val from lanes 0..15
+    double *slot = E + 48u * n_items;
+    if (ln < CNN_L1) slot[ln] = val;
+    if (ln == 0u) {
+      slot[46] = __longlong_as_double((long long)w);
+      slot[47] = __longlong_as_double((long long)p);
+    }
+    ++n_items;
+  };
+  auto drain_items = [&](uint32_t ln) {
+    for (uint32_t k = 0; k < n_items; k += 2) {
+      const bool two = k + 1 < n_items;
+      const double *sa = E + 48u * k, *sb = E + 48u * (two ? k + 1 : k);
+      const int pa = (int)word(sa + 47), pb = (int)word(sb + 47);
+      const unsigned long long wa = word(sa + 46), wb = word(sb + 46);
+      cnn_backward_shared_window(Fs, exptab, E + 48u * k, Ps0, Pb0, params + D.oW1, G, D, pa, wa, pb, wb, two, ln);
+    }
+    n_items = 0;
+  };
+  auto flush_carried = [&](int q, uint32_t ln) {
+    push_item(q, word(Cy + C::CARRY_POS * CNN_L1 + q), ln < CNN_L1 ? Cy[q * CNN_L1 + (int)ln] : 0.0, ln);
+    carry &= ~(1u << q);
+  };
+  for (uint64_t g = n_groups * wave_id / wave_cnt; g < n_groups * (wave_id + 1) / wave_cnt; ++g) {
     const uint16_t *lst = live_lists ? live_lists + g * PLN_LIVE_STRIDE : nullptr;
     const uint64_t base = lst ? tiles[g].row0 : g * TILE;
     const uint32_t cnt = lst ? (uint32_t)lst[0] : (uint32_t)(n_rows - base < (uint64_t)TILE ? n_rows - base : (uint64_t)TILE);
-   uint32_t row_next = lst ? (uint32_t)lst[1 + (ctx < cnt ? ctx : 0u)] : ctx;   // the list entry of a tile is read one tile ahead:
-   for (uint32_t c0 = 0; c0 < cnt; c0 += TILE) {                                // its rows' loads then start at once
+   uint32_t row_next;                          // the list entry of a tile is read one tile ahead: its rows' loads then start at once
+   {
+     const uint32_t c = lane & (TILE - 1);
+     row_next = lst ? (uint32_t)lst[1 + (c < cnt ? c : 0u)] : c;
+   }
+   for (uint32_t c0 = 0; c0 < cnt; c0 += TILE) {
+    // the lane's coordinates are derived HERE, from a laundered copy of the lane number: hoisted out of the group loop, the
+    // addresses built on them took (and spilled) two dozen registers
+    uint32_t lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
+    const uint32_t ctx = lane_t & (TILE - 1);
+    const uint32_t h = lane_t / TILE;               // the lane's part: filters [FH h, FH h + FH), layer-1 units [JH h, JH h + JH)
+    const bool last = h == Q - 1;                   // ... whose last two filter slots are dummies (30 filters)
+    const uint32_t lq = lane_t >> 4, lr = lane_t & 15u;   // MFMA lane coordinates: k / row-group index, row / column index
     const bool live = c0 + ctx < cnt;
     const uint64_t i = base + (uint64_t)row_next;
     if (lst && c0 + TILE < cnt) row_next = (uint32_t)lst[1 + (c0 + TILE + ctx < cnt ? c0 + TILE + ctx : 0u)];
@@ -973,10 +1021,8 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)wid, leader);
         return __builtin_amdgcn_ballot_w64(wid == *w) & rem;
       };
-      bool pending = false, have_full = false;
+      bool have_full = false;
       double s_full = 0.0;
-      int p_a = 0;
-      unsigned long long w_a = 0ull;
       for (int p = 0; p < D.P; ++p) {
         const unsigned long long wid = (code >> (3 * p)) & wm;
         unsigned long long rem = live_mask, w;
@@ -1002,18 +1048,25 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
               have_full = true;
             }
           }
-          if (ln < CNN_L1) E[(pending ? 48u : 0u) + ln] = sq;
-          if (!pending) {                     // items go in pairs: one per half of the wave
-            p_a = p;
-            w_a = w;
-            pending = true;
+          if (m == live_mask && p < C::CARRY_POS) {   // fully shared, leading position: carried while the next tiles share it too
+            double *cs = Cy + p * CNN_L1;
+            if (((carry >> p) & 1u) && word(Cy + C::CARRY_POS * CNN_L1 + p) != w) flush_carried(p, ln);
+            if ((carry >> p) & 1u) {
+              if (ln < CNN_L1) cs[ln] += sq;
+            } else {
+              if (ln < CNN_L1) cs[ln] = sq;
+              if (ln == 0u) Cy[C::CARRY_POS * CNN_L1 + p] = __longlong_as_double((long long)w);
+              carry |= 1u << p;
+            }
           } else {
-            cnn_backward_shared_window(Fs, exptab, E, Ps0, Pb0, params + D.oW1, G, D, p_a, w_a, p, w, true, ln);
-            pending = false;
+            push_item(p, w, sq, ln);
           }
+          if (n_items + C::CARRY_POS >= MAX_ITEMS) drain_items(ln);
         }
       }
-      if (pending) cnn_backward_shared_window(Fs, exptab, E, Ps0, Pb0, params + D.oW1, G, D, p_a, w_a, p_a, w_a, false, ln);
+      // a carried window that this tile does not share (any more, or in several runs) stays carried: its sums are complete
+      // whenever it is flushed.  The queue is worked off here: E is the position loop's staging area.
+      if (n_items) drain_items(ln);
     }
 #endif
     CNN_STAMP(7)
@@ -1025,7 +1078,11 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) tb2[ks][nt] = T[(4 * ks + lq) * ES + nt * 16 + lr];
     CNN_STAMP(6)
-    // positions
+    // positions.  Their lane coordinates come from the lane number itself again (not the laundered copy of the head above):
+    // what the loop builds on them is loop-invariant, stays in registers across the tiles, and pairs of stores keep merging
+    {
+    const uint32_t ctx = lane & (TILE - 1), h = lane / TILE, lq = lane >> 4, lr = lane & 15u;
+    const bool last = h == Q - 1;
     for (int p = 0; p < D.P; ++p) {
 #ifndef CNN_NO_SKIP
       if ((shared >> p) & 1u) continue;
@@ -1224,8 +1281,18 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
       }
       CNN_STAMP(5)
     }
+    }
    }
   }
+#ifndef CNN_NO_SHARED_BACKWARD
+  {
+    uint32_t ln = lane;
+    asm volatile("" : "+v"(ln));
+    for (int q = 0; q < C::CARRY_POS; ++q)
+      if ((carry >> q) & 1u) flush_carried(q, ln);
+    if (n_items) drain_items(ln);
+  }
+#endif
 #ifdef CNN_STAMPS
   if (lane == 0)
     for (int k = 0; k < 8; ++k) atomicAdd(&cnn_stamp_sums[k], tph[k]);
