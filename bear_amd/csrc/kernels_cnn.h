@@ -834,7 +834,6 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
 #ifdef CNN_STAMPS
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #endif
-  const int n_mt = (4 * D.fw + 15) / 16;              // M tiles of the one-hot operand: rows (tap w, letter a < 4)
   // A wave walks groups of contexts, TILE at a time: without lists, group g = rows [TILE g, TILE g + TILE); with the plan's
   // lists (the training step) group g = plan tile g and only its contexts that hold counts (the others' gradient rows are zero)
   // A wave takes a CONTIGUOUS range of groups: in a k-mer-sorted table consecutive tiles share the windows of their leading
@@ -890,7 +889,6 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
     asm volatile("" : "+v"(lane_t));
     const uint32_t ctx = lane_t & (TILE - 1);
     const uint32_t h = lane_t / TILE;               // the lane's part: filters [FH h, FH h + FH), layer-1 units [JH h, JH h + JH)
-    const bool last = h == Q - 1;                   // ... whose last two filter slots are dummies (30 filters)
     const uint32_t lq = lane_t >> 4, lr = lane_t & 15u;   // MFMA lane coordinates: k / row-group index, row / column index
     const bool live = c0 + ctx < cnt;
     const uint64_t i = base + (uint64_t)row_next;
@@ -1007,6 +1005,8 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
     // positions whose window every context of the tile shares (see cnn_backward_shared_window): handled here, once per tile,
     // from the column sums of dT1; the position loop below skips them
     uint32_t shared = 0;
+    int n_common = 0;
+    unsigned long long first = 0ull;
     CNN_STAMP(6)
 #ifndef CNN_NO_SHARED_BACKWARD
     {
@@ -1015,6 +1015,12 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
       static_assert(TILE == 32, "column sums of dT1: four quarters of eight contexts; lanes 0..31 of a ballot are the contexts");
       const unsigned long long wm = (D.fw < 21 ? (1ull << (3 * D.fw)) : 0ull) - 1ull;
       const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
+      {   // leading letters that all the tile's contexts share (taps inside them need no one-hot product below)
+        first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(code >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)code);   // lane 0: the tile's first context (always live)
+        const unsigned long long diff = live ? code ^ first : 0ull;
+        while (n_common < D.lag && __builtin_amdgcn_ballot_w64(((diff >> (3 * n_common)) & 7ull) != 0ull) == 0ull) ++n_common;
+      }
       auto next_run = [&](unsigned long long wid, unsigned long long rem, unsigned long long *w) {   // the contexts that share the window of rem's first
         const int leader = __builtin_ctzll(rem);
         *w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(wid >> 32), leader) << 32) |
@@ -1082,11 +1088,12 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
     // what the loop builds on them is loop-invariant, stays in registers across the tiles, and pairs of stores keep merging
     {
     const uint32_t ctx = lane & (TILE - 1), h = lane / TILE, lq = lane >> 4, lr = lane & 15u;
-    const bool last = h == Q - 1;
+    const bool last = h == Q - 1;                   // the part whose last two filter slots are dummies (30 filters)
     for (int p = 0; p < D.P; ++p) {
 #ifndef CNN_NO_SKIP
       if ((shared >> p) & 1u) continue;
 #endif
+      const int w0 = n_common - p < 0 ? 0 : (n_common - p > D.fw ? D.fw : n_common - p);   // leading taps inside the tile's common prefix
       double x[FH], dy[FH], dn[FH];
       // conv row of the lane's filters, layer norm over all 30 (the two dummy slots of the last part stay exact zeros)
       double r0;
@@ -1223,15 +1230,34 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
       {
         unsigned long long c = code >> (3 * p);
         bool any_start = false;
-        for (int w = 0; w < D.fw; ++w) any_start |= ((c >> (3 * w)) & 7ull) == 4ull;
+        for (int w = w0; w < D.fw; ++w) any_start |= ((c >> (3 * w)) & 7ull) == 4ull;
 #pragma unroll
         for (int f = 0; f < FH; ++f) {
           const double dc = (f >= FH - 2 && last) ? 0.0 : r0 * (dn[f] - ma0 - x[f] * ma1);
           if (f < FH - 2 || !last) E[(h * FH + f) * ES + ctx] = dc;
           dy[f] = dc;
         }
+        if (w0 > 0) {      // taps inside the tile's common prefix: every context has the same letter there -- its filter row takes the
+                           // column sums of d conv (lane: feature lane & 31, half of the contexts), no one-hot rows
+          const uint32_t cf = lane & 31u;
+          const double2 *src = reinterpret_cast<const double2 *>(E + (cf < CNN_NF ? cf : 0u) * ES + (lane >> 5) * (TILE / 2));
+          double s2[2] = {0.0, 0.0};
+#pragma unroll
+          for (int k = 0; k < TILE / 4; ++k) {
+            const double2 v = src[k];
+            s2[0] += v.x;
+            s2[1] += v.y;
+          }
+          const double tot = cnnq_psum<Q>(s2[0] + s2[1]);
+          unsigned long long cf1 = first >> (3 * p);
+          for (int w = 0; w < w0; ++w) {
+            const int a = (int)(cf1 & 7ull);
+            if (a < 5 && lane < CNN_NF) cnn_lds_add(G + D.oF + (w * 5 + a) * CNN_NF + (int)lane, tot);
+            cf1 >>= 3;
+          }
+        }
         if (any_start) {   // the start symbol '[' (rare: only contexts at a sequence start) bypasses the MFMA rows
-          for (int w = 0; w < D.fw; ++w)
+          for (int w = w0; w < D.fw; ++w)
             if (((c >> (3 * w)) & 7ull) == 4ull) {
               double *gF = G + D.oF + (w * 5 + 4) * CNN_NF + h * FH;
 #pragma unroll
@@ -1241,15 +1267,19 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
         }
       }
       CNN_STAMP(4)
-      // d filters[w][a][f] += sum_ctx [letter_{p+w}(ctx) == a] d conv[ctx][f],  rows (w, a < 4), two column tiles of f
-      for (int mt = 0; mt < n_mt; mt += 2) {      // two row tiles per pass share the B operand reads
-        cnn_d4 acc[2][2] = {{{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}};
-        int sh[2];
-        unsigned long long want[2];
-        bool row_ok[2];
+      // d filters[w][a][f] += sum_ctx [letter_{p+w}(ctx) == a] d conv[ctx][f],  rows (w - w0, a < 4) over the taps w >= w0 that
+      // vary inside the tile, two column tiles of f; NU row tiles per pass share the B operand reads
+      auto d_filters = [&](auto nu_tag, int mt0) {
+        constexpr int NU = decltype(nu_tag)::value;
+        cnn_d4 acc[NU][2];
+        int sh[NU];
+        unsigned long long want[NU];
+        bool row_ok[NU];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int row = (mt + u) * 16 + (int)lr, w = row >> 2;
+        for (int u = 0; u < NU; ++u) {
+          acc[u][0] = cnn_d4{0.0, 0.0, 0.0, 0.0};
+          acc[u][1] = cnn_d4{0.0, 0.0, 0.0, 0.0};
+          const int row = (mt0 + u) * 16 + (int)lr, w = w0 + (row >> 2);
           want[u] = (unsigned long long)(row & 3);
           row_ok[u] = w < D.fw;
           sh[u] = row_ok[u] ? 3 * (p + w) : 0;
@@ -1261,23 +1291,29 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
           const unsigned long long cc = Cw[4 * ks + lq];
           const double b0v = E[lr * ES + 4 * ks + lq], b1v = col1_in ? b1row[4 * ks] : 0.0;
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
+          for (int u = 0; u < NU; ++u) {
             const double a = (row_ok[u] && ((cc >> sh[u]) & 7ull) == want[u]) ? 1.0 : 0.0;
             acc[u][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0v, acc[u][0], 0, 0, 0);
             acc[u][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1v, acc[u][1], 0, 0, 0);
           }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int orow = (mt + u) * 16 + (int)lq + 4 * r, ow = orow >> 2, oa = orow & 3;
+            const int orow = (mt0 + u) * 16 + (int)lq + 4 * r, ow = w0 + (orow >> 2), oa = orow & 3;
             if (ow < D.fw) {
               double *gF = G + D.oF + (ow * 5 + oa) * CNN_NF;
               cnn_lds_add(gF + lr, acc[u][0][r]);
               if (lr < CNN_NF - 16) cnn_lds_add(gF + 16 + lr, acc[u][1][r]);
             }
           }
+      };
+      {
+        const int n_mt_var = (4 * (D.fw - w0) + 15) / 16;
+        int mt = 0;
+        for (; mt + 1 < n_mt_var; mt += 2) d_filters(std::integral_constant<int, 2>{}, mt);
+        if (mt < n_mt_var) d_filters(std::integral_constant<int, 1>{}, mt);
       }
       CNN_STAMP(5)
     }
