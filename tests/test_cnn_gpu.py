@@ -97,6 +97,43 @@ def test_cnn_backward_shared_windows_in_sorted_contexts(lag, fw, n):
     assert (got_p - got).abs().max().item() <= 1e-11 * got.abs().max().item()
 
 
+def test_cnn_dense_sorted_table_matches_autograd():
+    """A table as dense in k-mer space as the 1e8-context benchmark (2e5 contexts over 4^9 k-mers behind a fixed prefix), rows in
+    k-mer order: whole runs of tiles share the windows of the leading positions (their column sums are carried from tile to
+    tile), the next position has a few windows per tile, the last ones take the per-context path with most taps inside the
+    common prefix.  Prior rows against the torch formulation, gradients against its autograd, and == random order."""
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2024)
+    lag, fw, n = 13, 8, 200_000
+    letters = np.array(list("ACGT"))
+    body = rng.integers(0, 4, size=(n, 9))
+    key = (body * (4 ** np.arange(8, -1, -1))).sum(1)
+    body = body[np.argsort(key, kind="stable")]
+    kmers = ["ACGT" + "".join(letters[r]) for r in body]
+    kmers[:40] = ["[[[[" + k[4:] for k in kmers[:40]]          # a few sequence starts
+    ar_func, params = _make(lag, fw, dev, 3)
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+    codes = torch.from_numpy(core.encode_kmers(kmers, "dna")).to(dev)
+    packed = kernels.pack_kmers(codes)
+    prior, t1 = kernels.cnn_forward(packed, flat, lag, fw)
+    grad_rows = torch.from_numpy(rng.standard_normal((n, 5)) * np.exp(rng.normal(size=(n, 1)))).to(dev)
+    grad_rows[torch.from_numpy(rng.random(n) < 0.3).to(dev)] = 0.0
+    got = kernels.cnn_backward(packed, flat, lag, fw, t1, prior, grad_rows)
+    rows = ar_func(core.tf_one_hot(kmers, "dna", device=dev))
+    assert torch.allclose(rows, prior, rtol=1e-11, atol=0)
+    rows.backward(grad_rows)
+    k = 0
+    for p in params:
+        m = p.numel()
+        want = p.grad.reshape(-1)
+        assert (got[k:k + m] - want).abs().max().item() <= GRAD_RTOL * max(want.abs().max().item(), 1e-30), (p.shape,)
+        k += m
+    perm = torch.from_numpy(rng.permutation(n)).to(dev)
+    got_p = kernels.cnn_backward(packed[perm].contiguous(), flat, lag, fw, t1[perm].contiguous(), prior[perm].contiguous(),
+                                 grad_rows[perm].contiguous())
+    assert (got_p - got).abs().max().item() <= 1e-11 * got.abs().max().item()
+
+
 @pytest.mark.parametrize("lag,fw", [(13, 8), (9, 3), (5, 5)])
 def test_cnn_forward_shared_windows_in_sorted_contexts(lag, fw):
     """k-mer-sorted contexts with long common prefixes (what bear_net.train uploads): whole waves share the windows inside the
