@@ -384,6 +384,42 @@ def test_cnn_step_over_live_contexts_equals_the_step_over_all_rows(ysd1, monkeyp
         assert np.allclose(a, b, rtol=1e-7, atol=1e-9)
 
 
+def test_cnn_step_on_a_dense_sorted_table_equals_its_three_kernels_over_all_rows():
+    """bear_net_cnn_train_reduce_f64 on 3e5 contexts in k-mer order, as dense in k-mer space as the 1e8-context benchmark: the step
+    walks the plan's lists of contexts with counts, tiles of consecutive list entries share their leading windows (per-window
+    path, carried column sums, prefix taps).  Its packed [sum LL, d/dh, d/d params] must equal the three kernels run one
+    after the other over ALL rows in RANDOM order (forward, planned DM step with gradient rows, backward)."""
+    from bear_amd import kernels
+    dev = torch.device("cuda", 0)
+    lag, fw, n = 13, 8, 300_000
+    gen = torch.Generator(dev).manual_seed(5)
+    codes = torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev, generator=gen)
+    codes[:, :4] = torch.tensor([0, 1, 2, 3], dtype=torch.int8, device=dev)          # 4^9 k-mers behind a fixed prefix
+    key = torch.zeros(n, dtype=torch.int64, device=dev)
+    for l in range(lag):
+        key = key * 6 + codes[:, l].to(torch.int64)
+    codes = codes[torch.argsort(key)].contiguous()
+    counts = kernels.synth_counts(7, 0, n, dev, want=("train",))["train"]
+    torch.manual_seed(9)
+    _, params = ar_funcs.make_ar_func_cnn(lag, 4, filter_width=fw, device=dev)
+    flat = torch.cat([q.detach().reshape(-1) for q in params]).contiguous()
+    h_s = -0.3
+    theta = torch.cat([torch.tensor([h_s], dtype=torch.float64, device=dev), flat]).contiguous()
+    packed_codes = kernels.pack_kmers(codes)
+    plan = kernels.Plan(counts, 5)
+    pk = torch.zeros(2 + flat.numel(), dtype=torch.float64, device=dev)
+    kernels.net_cnn_train_reduce(plan, packed_codes, lag, fw, theta, kernels.cnn_step_buffers(n, lag, fw, dev), pk)
+    perm = torch.randperm(n, device=dev, generator=gen)
+    counts_p, codes_p = counts[perm].contiguous(), kernels.pack_kmers(codes[perm].contiguous())
+    prior, t1 = kernels.cnn_forward(codes_p, flat, lag, fw)
+    out, g = kernels.dm_prior_planned(kernels.Plan(counts_p, 5), prior, h_s, want_grad=True)
+    grad = kernels.cnn_backward(codes_p, flat, lag, fw, t1, prior, g)
+    want = torch.cat([out[:2], grad])
+    assert abs(float(pk[0] - want[0])) <= 1e-12 * abs(float(want[0]))
+    assert abs(float(pk[1] - want[1])) <= 1e-10 * max(abs(float(want[1])), 1.0)
+    assert (pk[2:] - want[2:]).abs().max().item() <= 1e-10 * want[2:].abs().max().item()
+
+
 @pytest.mark.parametrize("which", ["bear_ref + linear net", "bear_ref + cnn net", "bear_net + SGD (torch loop)"])
 def test_torch_ar_functions_only_see_contexts_with_counts(which, monkeypatch):
     """The autograd loops hand an AR function only the contexts that hold training counts (gather, scatter back): the same losses
