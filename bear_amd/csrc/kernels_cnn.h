@@ -37,7 +37,8 @@
 #ifndef CNN_FWD_RUNS
 #define CNN_FWD_RUNS 3               // forward: a position is done per distinct window when a wave holds at most this many
 #endif
-#define CNN_FWD_SCRATCH 48        // doubles of LDS per wave of the forward kernel (shared-window path)
+#define CNN_FWD_KEEP 3            // forward: the layer-1 contributions of the last fully shared window of positions < this are kept per wave
+#define CNN_FWD_SCRATCH (48 + 16 * CNN_FWD_KEEP)   // doubles of LDS per wave of the forward kernel: shared-window scratch [48] | kept contributions
 
 struct cnn_dims {
   int lag, fw, P;
@@ -205,7 +206,12 @@ __global__ __launch_bounds__(CNN_THREADS, 3) void cnn_forward_kernel(const unsig
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: group numbers, list pointers, row bases
   double *Us = Fs + D.fw * 6 * CNN_NF + wave * CNN_FWD_SCRATCH;     // per wave: e0 of a shared window [32] | its layer-1 sums [16]
   const unsigned long long wmask = 3 * D.fw >= 64 ? ~0ull : (1ull << (3 * D.fw)) - 1ull;
-  for (uint64_t g = (uint64_t)blockIdx.x * n_waves + wave; g < n_groups; g += (uint64_t)gridDim.x * n_waves) {
+  // A wave takes a CONTIGUOUS range of groups: in a k-mer-sorted table consecutive chunks share the windows of their leading
+  // positions, and the contribution of such a window (16 layer-1 sums) is kept in LDS until the window changes.
+  const uint64_t wave_id = (uint64_t)blockIdx.x * n_waves + wave, wave_cnt = (uint64_t)gridDim.x * n_waves;
+  unsigned long long kept_w[CNN_FWD_KEEP] = {};
+  uint32_t kept = 0;                          // bit p: Us[48 + 16 p ..) holds the contribution of window kept_w[p] at position p
+  for (uint64_t g = n_groups * wave_id / wave_cnt; g < n_groups * (wave_id + 1) / wave_cnt; ++g) {
     const uint16_t *lst = live_lists ? live_lists + g * PLN_LIVE_STRIDE : nullptr;
     const uint64_t base = lst ? tiles[g].row0 : g * 64;
     const uint32_t cnt = lst ? (uint32_t)lst[0] : (uint32_t)(n_rows - base < 64 ? n_rows - base : 64);
@@ -244,11 +250,26 @@ __global__ __launch_bounds__(CNN_THREADS, 3) void cnn_forward_kernel(const unsig
         for (rem = ~0ull; rem != 0ull;) {
           const unsigned long long m = next_run(rem, &wv);
           rem &= ~m;
-          cnn_forward_shared_window(Fs, exptab, Us, params + D.os0 + p * CNN_NF, params + D.ob0 + p * CNN_NF,
-                                    params + D.oW1 + p * CNN_NF * CNN_L1, D.fw, wv, lane);
+          const double *u = Us + 32;
+          bool have = false;
+          if (m == ~0ull && p < CNN_FWD_KEEP) {      // the whole wave shares the window: kept from the previous chunk?
+#pragma unroll
+            for (int q = 0; q < CNN_FWD_KEEP; ++q)
+              if (q == p) {
+                have = ((kept >> q) & 1u) && kept_w[q] == wv;
+                kept_w[q] = wv;
+                kept |= 1u << q;
+              }
+            u = Us + 48 + 16 * p;
+          }
+          if (!have) {
+            cnn_forward_shared_window(Fs, exptab, Us, params + D.os0 + p * CNN_NF, params + D.ob0 + p * CNN_NF,
+                                      params + D.oW1 + p * CNN_NF * CNN_L1, D.fw, wv, lane);
+            if (u != Us + 32 && lane < CNN_L1) Us[48 + 16 * p + lane] = Us[32 + lane];
+          }
           if (win == wv) {
 #pragma unroll
-            for (int j = 0; j < CNN_L1; ++j) t1[j] += Us[32 + j];
+            for (int j = 0; j < CNN_L1; ++j) t1[j] += u[j];
           }
         }
         continue;
