@@ -35,10 +35,10 @@
 #define CNN_SHARED_RUNS 6            // backward: a position is done per distinct window when a tile holds at most this many (cnn_backward_shared_window)
 #endif
 #ifndef CNN_FWD_RUNS
-#define CNN_FWD_RUNS 3               // forward: a position is done per distinct window when a wave holds at most this many
+#define CNN_FWD_RUNS 4               // forward: a position is done per distinct window when a wave holds at most this many
 #endif
 #define CNN_FWD_KEEP 3            // forward: the layer-1 contributions of the last fully shared window of positions < this are kept per wave
-#define CNN_FWD_SCRATCH (48 + 16 * CNN_FWD_KEEP)   // doubles of LDS per wave of the forward kernel: shared-window scratch [48] | kept contributions
+#define CNN_FWD_SCRATCH (96 + 16 * CNN_FWD_KEEP)   // doubles of LDS per wave of the forward kernel: shared-window scratch [96] | kept contributions
 
 struct cnn_dims {
   int lag, fw, P;
@@ -154,42 +154,66 @@ __device__ __forceinline__ double cnn_layer1(const double (&t1)[CNN_L1], const d
   return r;
 }
 
-// One window shared by all 64 contexts of a wave: its conv row, layer norm and elu once (lane = filter), then its contribution
-// to the 16 layer-1 sums (lane = unit) into Us[32..48).  Out of line: the forward kernel keeps its 143 registers (three waves per
-// SIMD); inlined, this path pushed it to 197.
-__device__ __noinline__ void cnn_forward_shared_window(const double *Fs, const double *exptab, double *Us, const double *__restrict__ s0,
-                                                       const double *__restrict__ b0, const double *__restrict__ W1, int fw,
-                                                       unsigned long long win0, uint32_t lane) {
-  const uint32_t f = lane < CNN_NF ? lane : CNN_NF - 1;
+// One window shared by all 64 contexts of a wave (or by a run of them): its conv row, layer norm and elu once (lane = filter),
+// then its contribution to the 16 layer-1 sums (lane = unit).  Out of line: the forward kernel keeps its registers for the
+// per-context path.  TWO (position, window) items go through at once, one per half of the wave (lane & 31 = filter, then = unit): the work is a
+// chain of dependent steps, so the second item costs nothing.  Us: e0 of the items [0, 32) | [32, 64), their contributions
+// [64, 80) | [80, 96).
+__device__ __forceinline__ double cnn_fwd_half_sum(double v) {   // every lane gets the sum over its half of the wave (32 lanes)
+  auto dpp = [](double x, auto ctrl_tag) {
+    constexpr int CTRL = decltype(ctrl_tag)::value;
+    const long long q = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)q, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(q >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (uint32_t)lo);
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x124>{});   // row_ror:4
+  v += dpp(v, std::integral_constant<int, 0x128>{});   // row_ror:8
+  const long long q = __double_as_longlong(v);
+  const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto c = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __longlong_as_double(((long long)c[0] << 32) | a[0]) + __longlong_as_double(((long long)c[1] << 32) | a[1]);
+}
+__device__ __noinline__ void cnn_forward_shared_window2(const double *Fs, const double *exptab, double *Us, const double *__restrict__ s0_all,
+                                                        const double *__restrict__ b0_all, const double *__restrict__ W1_all, int fw,
+                                                        int p_a, unsigned long long win_a, int p_b, unsigned long long win_b, uint32_t lane) {
+  const bool second = lane >= 32u;
+  const uint32_t l32 = lane & 31u, f = l32 < CNN_NF ? l32 : CNN_NF - 1;
+  const int p = second ? p_b : p_a;
   double xf = 0.0;
-  unsigned long long c = win0;
-  for (int w = 0; w < fw; ++w) {
-    const int a = (int)(c & 7ull);
-    xf += Fs[(w * 6 + (a < 5 ? a : 5)) * CNN_NF + f];
-    c >>= 3;
+  unsigned long long c = second ? win_b : win_a;
+  for (int w = 0; w < fw; w += 4) {        // four taps' reads in flight (taps beyond the filter width read a zero row)
+    double t4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int a = (int)((c >> (3 * k)) & 7ull);
+      t4[k] = Fs[(w + k < fw ? (w + k) * 6 + (a < 5 ? a : 5) : 5) * CNN_NF + f];
+    }
+    xf += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+    c >>= 12;
   }
-  const bool in = lane < CNN_NF;
-  double mu = bear_wave_sum(in ? xf : 0.0);
-  mu = __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(mu) >> 32)) << 32) |
-                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__double_as_longlong(mu))) * (1.0 / CNN_NF);
+  const bool in = l32 < CNN_NF;
+  const double mu = cnn_fwd_half_sum(in ? xf : 0.0) * (1.0 / CNN_NF);
   const double d = xf - mu;
-  double var = bear_wave_sum(in ? d * d : 0.0);
-  var = __longlong_as_double(((long long)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(var) >> 32)) << 32) |
-                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__double_as_longlong(var)));
-  const double r = cnn_rsqrt(var * (1.0 / CNN_NF) + CNN_LN_EPS);
+  const double r = cnn_rsqrt(cnn_fwd_half_sum(in ? d * d : 0.0) * (1.0 / CNN_NF) + CNN_LN_EPS);
   double dv;
-  const double e = cnn_elu(__builtin_fma(s0[f], d * r, b0[f]), exptab, dv);
-  if (in) Us[lane] = e;
-  if (lane < CNN_L1) {
+  const double e = cnn_elu(__builtin_fma(s0_all[p * CNN_NF + (int)f], d * r, b0_all[p * CNN_NF + (int)f]), exptab, dv);
+  double *Ue = Us + (second ? 32 : 0);
+  if (in) Ue[l32] = e;
+  if (l32 < CNN_L1) {
+    const double *__restrict__ W1 = W1_all + p * CNN_NF * CNN_L1 + (int)l32;
     double u4[2] = {0.0, 0.0};
 #pragma unroll 6
-    for (int ff = 0; ff < CNN_NF; ++ff) u4[ff & 1] = __builtin_fma(Us[ff], W1[ff * CNN_L1 + lane], u4[ff & 1]);
-    Us[32 + lane] = u4[0] + u4[1];
+    for (int ff = 0; ff < CNN_NF; ++ff) u4[ff & 1] = __builtin_fma(Ue[ff], W1[ff * CNN_L1], u4[ff & 1]);
+    Us[64 + (second ? 16 : 0) + l32] = u4[0] + u4[1];
   }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(CNN_THREADS, 3) void cnn_forward_kernel(const unsigned long long *__restrict__ codes, uint64_t n_rows,
+__global__ __launch_bounds__(CNN_THREADS, 4) void cnn_forward_kernel(const unsigned long long *__restrict__ codes, uint64_t n_rows,
                                                                    cnn_dims D, const double *__restrict__ params,
                                                                    double *__restrict__ prior, double *__restrict__ t1_save,
                                                                    const pln_tile *__restrict__ tiles, const uint16_t *__restrict__ live_lists,
@@ -228,31 +252,52 @@ __global__ __launch_bounds__(CNN_THREADS, 3) void cnn_forward_kernel(const unsig
     double t1[CNN_L1];
 #pragma unroll
     for (int j = 0; j < CNN_L1; ++j) t1[j] = 0.0;
-    bool try_shared = true;
-    for (int p = 0; p < D.P; ++p) {
-      // In a k-mer-sorted batch (bear_net.train sorts at upload) the 64 contexts of a wave share their leading letters: a window
-      // [p, p + fw) that lies inside the shared prefix gives every context the SAME conv row, activations and layer-1
-      // contribution.  Then 30 lanes compute the row once (lane = filter), 16 lanes the contribution (lane = unit), and every
-      // context adds it: ~200 instructions instead of ~1500 for the position.
-      // The same per DISTINCT window when the wave holds a few (CNN_FWD_RUNS; the first position behind the shared prefix).
-      const unsigned long long win = (code >> (3 * p)) & wmask;
-      auto next_run = [&](unsigned long long rem, unsigned long long *w) {   // the lanes that share the window of rem's first lane
-        const int leader = __builtin_ctzll(rem);
-        *w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(win >> 32), leader) << 32) |
-             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)win, leader);
-        return __builtin_amdgcn_ballot_w64(win == *w) & rem;
+    // In a k-mer-sorted batch (bear_net.train sorts at upload) the 64 contexts of a wave share their leading letters: a window
+    // [p, p + fw) that lies inside the shared prefix gives every context the SAME conv row, activations and layer-1
+    // contribution.  Then 30 lanes compute the row once (lane = filter), 16 lanes the contribution (lane = unit), and every
+    // context adds it: ~200 instructions instead of ~1500 for the position.  The same per DISTINCT window while the wave
+    // holds at most CNN_FWD_RUNS of them (the first positions behind the shared prefix); two such items go through
+    // cnn_forward_shared_window2 at once.  The first position with more windows and all later ones (in a sorted batch they
+    // reach further into the varying letters) take the per-context path below.
+    int p_ctx = D.P;
+    {
+      bool pend = false, keep_a = false;
+      int p_a = 0;
+      unsigned long long w_a = 0ull;
+      auto add_u = [&](int p, unsigned long long w, const double *u) {
+        if (((code >> (3 * p)) & wmask) == w) {
+#pragma unroll
+          for (int j = 0; j < CNN_L1; ++j) t1[j] += u[j];
+        }
       };
-      unsigned long long rem = ~0ull, wv;
-      if (try_shared)
+      auto finish = [&](int p_b, unsigned long long w_b, bool two, bool keep_b) {
+        cnn_forward_shared_window2(Fs, exptab, Us, params + D.os0, params + D.ob0, params + D.oW1, D.fw, p_a, w_a, p_b, w_b, lane);
+        if (keep_a && lane < CNN_L1) Us[96 + 16 * p_a + lane] = Us[64 + lane];
+        if (two && keep_b && lane < CNN_L1) Us[96 + 16 * p_b + lane] = Us[80 + lane];
+        add_u(p_a, w_a, Us + 64);
+        if (two) add_u(p_b, w_b, Us + 80);
+        pend = false;
+      };
+      for (int p = 0; p < D.P; ++p) {
+        const unsigned long long win = (code >> (3 * p)) & wmask;
+        auto next_run = [&](unsigned long long rem, unsigned long long *w) {   // the lanes that share the window of rem's first lane
+          const int leader = __builtin_ctzll(rem);
+          *w = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(win >> 32), leader) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)win, leader);
+          return __builtin_amdgcn_ballot_w64(win == *w) & rem;
+        };
+        unsigned long long rem = ~0ull, wv;
         for (int runs = 0; rem != 0ull && runs < CNN_FWD_RUNS; ++runs) rem &= ~next_run(rem, &wv);
-      try_shared = rem == 0ull;               // in a sorted batch the later windows reach further into the varying letters: no further tries
-      if (rem == 0ull) {
+        if (rem != 0ull) {
+          p_ctx = p;
+          break;
+        }
         for (rem = ~0ull; rem != 0ull;) {
           const unsigned long long m = next_run(rem, &wv);
           rem &= ~m;
-          const double *u = Us + 32;
-          bool have = false;
-          if (m == ~0ull && p < CNN_FWD_KEEP) {      // the whole wave shares the window: kept from the previous chunk?
+          const bool full = m == ~0ull && p < CNN_FWD_KEEP;   // the whole wave shares the window: kept from the previous chunk?
+          if (full) {
+            bool have = false;
 #pragma unroll
             for (int q = 0; q < CNN_FWD_KEEP; ++q)
               if (q == p) {
@@ -260,20 +305,24 @@ __global__ __launch_bounds__(CNN_THREADS, 3) void cnn_forward_kernel(const unsig
                 kept_w[q] = wv;
                 kept |= 1u << q;
               }
-            u = Us + 48 + 16 * p;
+            if (have) {
+              add_u(p, wv, Us + 96 + 16 * p);
+              continue;
+            }
           }
-          if (!have) {
-            cnn_forward_shared_window(Fs, exptab, Us, params + D.os0 + p * CNN_NF, params + D.ob0 + p * CNN_NF,
-                                      params + D.oW1 + p * CNN_NF * CNN_L1, D.fw, wv, lane);
-            if (u != Us + 32 && lane < CNN_L1) Us[48 + 16 * p + lane] = Us[32 + lane];
-          }
-          if (win == wv) {
-#pragma unroll
-            for (int j = 0; j < CNN_L1; ++j) t1[j] += u[j];
+          if (!pend) {
+            p_a = p;
+            w_a = wv;
+            keep_a = full;
+            pend = true;
+          } else {
+            finish(p, wv, true, full);
           }
         }
-        continue;
       }
+      if (pend) finish(p_a, w_a, false, false);
+    }
+    for (int p = p_ctx; p < D.P; ++p) {
       double x[CNN_NF];
       cnn_conv_norm(Fs, code, p, D.fw, x);
       const double *__restrict__ s0 = params + D.os0 + p * CNN_NF, *__restrict__ b0 = params + D.ob0 + p * CNN_NF;
