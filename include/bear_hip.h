@@ -236,8 +236,8 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
  *   Row order: any (the sums do not depend on it).  Both kernels are fastest when the rows are sorted by k-mer (first letter
  *   most significant, as bear_net.train uploads a batch): consecutive contexts then share their leading letters, a window that
  *   a whole wave (forward: 64 contexts) / tile (backward: 32) shares is evaluated once per distinct window, and the backward
- *   pass of such a position needs only the column sums of the tile's d t1 rows (it is linear in them) -- 24 / 52 ms instead
- *   of 37 / 103 ms per 1e8 contexts at lag 13, filter width 8.
+ *   pass of such a position needs only the column sums of the tile's d t1 rows (it is linear in them) -- 18 / 52 ms instead
+ *   of 33 / 104 ms per 1e8 contexts at lag 13, filter width 8.
  */
 int bear_cnn_param_count(int lag, int filter_width, int num_filters, int layer1_width);
 int bear_cnn_forward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows, int lag, int filter_width, int num_filters,
