@@ -77,7 +77,11 @@ class ResidentBatches:
     """This rank's row shard of every batch of one epoch, uploaded once: per batch the device slabs of the
     requested dataset columns, the k-mer codes, and (lazily) the kernel plans."""
 
-    def __init__(self, data, columns, device, want_codes=False):
+    def __init__(self, data, columns, device, want_codes=False, drop_empty=None):
+        """``drop_empty``: name of the column a training run fits.  A context without counts in it adds exactly nothing to the
+        ELBO or to any gradient (``D(x, 0) = 0``, core.py:73-74), so its row is left out of the resident batch -- 30 % of the rows
+        of a typical count table (they hold counts in the other columns only); the loss scale keeps the batch's full size
+        (``global_rows``).  BEAR_AMD_ALL_ROWS=1 keeps every row (tests)."""
         if not isinstance(data, CountDataset):
             raise TypeError("train / evaluation expect the CountDataset returned by bear_amd.dataloader")
         self.data, self.device = data, device
@@ -121,6 +125,15 @@ class ResidentBatches:
                     entry[name] = device_column(col, lo, hi)
             if want_codes:
                 entry["codes"] = shuffled["codes"][lo:hi].clone() if shuffled else device_codes(lo, hi)
+            if drop_empty and entry["rows"] and not os.environ.get("BEAR_AMD_ALL_ROWS"):
+                keep = (entry[drop_empty] != 0).any(dim=1)
+                n_keep = int(keep.sum())
+                if n_keep < entry["rows"]:
+                    idx = keep.nonzero().squeeze(1)
+                    for name in list(columns) + (["codes"] if want_codes else []):
+                        entry[name] = entry[name].index_select(0, idx).contiguous()
+                    entry["rows"] = n_keep
+                del keep
             entry["plans"] = {}
             self.batches.append(entry)
         del shuffled

@@ -43,7 +43,7 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
         params, h_signed, ar_func = change_scope_params(lag, alphabet_size, make_ar_func, af_kwargs, params_restart, dtype, device)
     dist.broadcast_params(params)                    # mirrored variables: every rank starts from rank 0's values (bear_net.py:246-256)
     ar_params = params[1:]
-    res = _train.ResidentBatches(data, {"train": ds_loc}, device, want_codes=True)
+    res = _train.ResidentBatches(data, {"train": ds_loc}, device, want_codes=True, drop_empty="train")
     scales = [-(num_kmers / e["global_rows"]) for e in res.batches]       # bear_net.py:190-191 with the global batch
     # linear AR function on a DNA/RNA-sized alphabet: forward, ELBO and all gradients in one launch per batch
     fused_mat = getattr(ar_func, "linear_mat", None)

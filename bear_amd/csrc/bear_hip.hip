@@ -289,6 +289,7 @@ struct bear_plan {
   uint16_t *live;            // five-column plans: per-tile lists of the contexts that hold counts (plan_live_kernel)
   uint64_t n_tiles;
   uint64_t n_heavy[3];
+  uint64_t n_live_rows;      // five-column plans: contexts that hold any count (the kernels that walk `live` skip the lists when all do)
   uint64_t bytes;
   // reference-aware extension (bear_plan_create_ref, kernels_refplan.h)
   const uint32_t *ref;
@@ -472,6 +473,14 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   unsigned long long h_used[3] = {0, 0, 0};  // entries that actually went to the global lists
   if (e == hipSuccess) e = hipMemcpy(h_used, d_cnt + 3, sizeof(h_used), hipMemcpyDeviceToHost);
   for (int k = 0; k < 3; ++k) p->n_heavy[k] = h_used[k];
+  p->n_live_rows = n_rows;
+  if (e == hipSuccess && ncol == 5) {        // rows with a total of 1..SRT_CL (histogram) + rows with a larger one
+    unsigned long long h_hist[SRT_NKEY];
+    e = hipMemcpy(h_hist, p->hist, sizeof(h_hist), hipMemcpyDeviceToHost);
+    unsigned long long live_rows = h_cnt[1];
+    for (int k = 0; k < SRT_NKEY; ++k) live_rows += h_hist[k];
+    p->n_live_rows = live_rows;
+  }
   (void)hipFree(d_cnt);
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
@@ -1339,7 +1348,7 @@ static int launch_cnn_backward(bear_ws *ws, const cnn_dims &D, const uint64_t *k
   if (may_alloc) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned long long *kc = reinterpret_cast<const unsigned long long *>(kmer_code);
   if (parts2) {
-    const bool lists = live_plan && live_plan->live;
+    const bool lists = live_plan && live_plan->live && live_plan->n_live_rows < n_rows;   // all rows live: plain groups of rows
     const uint64_t groups = lists ? live_plan->n_tiles : (n_rows + cnnq<2>::TILE - 1) / cnnq<2>::TILE;
     hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)blocks), dim3(64 * waves), lds, s, kc, n_rows, D, params, t1_save, prior,
                        grad_prior, ws->cnn_partials, lists ? live_plan->tiles : nullptr, lists ? live_plan->live : nullptr, groups);
@@ -1401,7 +1410,7 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
     uint64_t bw_blocks = 0;
     st = cnn_backward_grid(ws, D, n_rows, filter_width, &bw_waves, &bw_lds, &bw_blocks, s, 0);
     if (st != BEAR_OK) return st;
-    const bool lists = plan->live && bw_waves == cnnq<2>::WAVES;
+    const bool lists = plan->live && bw_waves == cnnq<2>::WAVES && plan->n_live_rows < n_rows;   // all rows live: plain groups of rows
     const uint64_t groups = lists ? plan->n_tiles : (n_rows + 63) / 64;
     uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
     if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;

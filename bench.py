@@ -220,14 +220,31 @@ def main():
         pk = torch.zeros(2 + flat.numel(), dtype=torch.float64, device=dev)
         s_ms = timed(lambda: kernels.net_cnn_train_reduce(plans["net"], packed_sorted_raw, lag, fw, theta, bufs, pk), 3)
         s_ms_random = timed(lambda: kernels.net_cnn_train_reduce(plans["net"], packed, lag, fw, theta, bufs, pk), 3)
+        # ... and as bear_net.train holds a batch since the end of round 2: in k-mer order AND without the contexts that hold no
+        # training counts (they add exactly nothing; the loss scale keeps the full batch size) -- a smaller table, all rows live
+        keep = (t["train"] != 0).any(dim=1).nonzero().squeeze(1)
+        tr_kept = t["train"].index_select(0, keep).contiguous()
+        packed_kept = packed_sorted_raw.index_select(0, keep).contiguous()
+        plan_kept = kernels.Plan(tr_kept, 5)
+        bufs_kept = tuple(b[:keep.numel()] for b in bufs)
+        kept_ms = timed(lambda: kernels.net_cnn_train_reduce(plan_kept, packed_kept, lag, fw, theta, bufs_kept, pk), 3)
+        lin_kept = kernels.linear_index(packed_kept, lag)
+        lin_k_ms = timed(lambda: kernels.dm_linear(plan_kept, lin_kept, mat, h_s), 5)
+        extra["linear_head_fused_step"]["kernel_ms_as_bear_net_train_holds_the_batch"] = lin_k_ms
+        kept_frac = keep.numel() / n
+        del keep, tr_kept, packed_kept, plan_kept, bufs_kept, lin_kept
         extra["cnn_head"] = {"lag": lag, "filter_width": fw, "forward_ms": f_ms, "backward_ms": b_ms,
                              "forward_ms_rows_in_kmer_order": fs_ms, "backward_ms_rows_in_kmer_order": bs_ms,
                              "all_rows_step_ms": f_ms + b_ms + extra["net_with_gradient_rows"]["kernel_ms"],
-                             "train_step_ms": s_ms, "train_step_ms_rows_in_random_order": s_ms_random, "step_contexts_per_s": n / (s_ms * 1e-3),
+                             "train_step_ms": s_ms, "train_step_ms_rows_in_random_order": s_ms_random,
+                             "train_step_ms_as_bear_net_train_holds_the_batch": kept_ms, "contexts_with_training_counts": kept_frac,
+                             "step_contexts_per_s": n / (kept_ms * 1e-3),
                              "note": "forward_ms / backward_ms: bear_cnn_forward_f64 / bear_cnn_backward_f64 over all rows in random order (any caller); "
                                      "train_step_ms: bear_net_cnn_train_reduce_f64 = forward + planned DM kernel with gradient rows + "
                                      "backward over the contexts that hold training counts (70 % of this table), rows in k-mer order as "
-                                     "bear_net.train uploads a batch (both kernels evaluate a window that a wave's / tile's contexts share once)"}
+                                     "bear_net.train uploads a batch (both kernels evaluate a window that a wave's / tile's contexts share once); "
+                                     "train_step_ms_as_bear_net_train_holds_the_batch: the same step on the table bear_net.train keeps resident -- "
+                                     "k-mer order and the contexts without training counts left out (step_contexts_per_s counts all 1e8)"}
         del packed, packed_raw, packed_sorted_raw, bufs, pk, theta
         m = min(n, 20_000_000)
         test = kernels.synth_counts(SEED, row0, m, dev, want=("test",))["test"]

@@ -153,6 +153,30 @@ def test_bench_under_the_launcher_two_ranks(tmp_path):
     assert np.allclose(d["result"], want, rtol=1e-12), (d["result"], want)
 
 
+def test_bench_single_rank_line_is_consistent():
+    """bench.py as the driver runs it at N = 1 (small table): one JSON line whose roofline object follows from its own
+    kernel time, with the 'also' entries of the other kernels in it."""
+    n = 3_000_000
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3", "--contexts", str(n), "--no-cpu-baseline"],
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    r = d["roofline"]
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["unit"] == "contexts/s" and d["dtype"] == "f64" and r["bound"] == "hbm"
+    assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert abs(r["achieved"] - n * 60 / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]           # 60 algorithmic bytes per context
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9 and 0.0 < r["frac"] < 1.5 and r["peak"] == 8000.0
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.05
+    also = d["also"]
+    for key in ("ref", "net_with_gradient_rows", "linear_head_fused_step", "cnn_head", "heldout_evaluation"):
+        assert key in also, key
+    c = also["cnn_head"]
+    assert abs(c["step_contexts_per_s"] - n / (c["train_step_ms_as_bear_net_train_holds_the_batch"] * 1e-3)) <= 1e-6 * c["step_contexts_per_s"]
+    assert 0.5 < c["contexts_with_training_counts"] < 0.9
+
+
 def test_rccl_group_of_one(tmp_path):
     """RCCL itself on this box: a process group of one rank (two ranks cannot share a card under RCCL) runs the step's
     collectives behind the planned kernel in stream order -- the library loads, a communicator comes up on the device the

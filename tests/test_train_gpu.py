@@ -384,6 +384,33 @@ def test_cnn_step_over_live_contexts_equals_the_step_over_all_rows(ysd1, monkeyp
         assert np.allclose(a, b, rtol=1e-7, atol=1e-9)
 
 
+@pytest.mark.parametrize("which", ["bear_ref + stop", "bear_net + linear (fused)", "bear_net + cnn (fused)"])
+def test_training_leaves_out_the_contexts_without_training_counts(which, monkeypatch):
+    """A resident training batch holds only the contexts with counts in the fitted column (the others add exactly nothing to the
+    ELBO or to a gradient; the loss scale keeps the full batch size): the same losses and parameters as with every row kept
+    (BEAR_AMD_ALL_ROWS=1) on a table where a third of the contexts hold none, also with two batches per epoch."""
+    data = dataloader.dataloader(YSD1, "dna", 700, 3)
+    data.counts[0, ::3] = 0
+    n = data.num_rows
+    torch.manual_seed(4)
+    runs = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("BEAR_AMD_ALL_ROWS", env)
+        ls = []
+        torch.manual_seed(4)
+        if which.startswith("bear_ref"):
+            params, _, _ = bear_ref.train(data.repeat(3), n, 3, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False, loss_save=ls)
+        elif "linear" in which:
+            params, _, _ = bear_net.train(data.repeat(3), n, 3, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", False, loss_save=ls)
+        else:
+            params, _, _ = bear_net.train(data.repeat(3), n, 3, 0, "dna", 5, ar_funcs.make_ar_func_cnn, CNN_CFG, 0.01, "Adam", False, loss_save=ls)
+        runs.append((ls, np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in params])))
+    assert len(runs[0][0]) == 6
+    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-11)
+    assert np.allclose(runs[0][1], runs[1][1], rtol=1e-8, atol=1e-10)
+
+
 def test_cnn_step_on_a_dense_sorted_table_equals_its_three_kernels_over_all_rows():
     """bear_net_cnn_train_reduce_f64 on 3e5 contexts in k-mer order, as dense in k-mer space as the 1e8-context benchmark: the step
     walks the plan's lists of contexts with counts, tiles of consecutive list entries share their leading windows (per-window
