@@ -13,10 +13,15 @@ key = torch.zeros(n, dtype=torch.int64, device=dev)
 for l in range(lag):
     key = key * 6 + codes[:, l].to(torch.int64)
 packed = kernels.pack_kmers(codes[torch.argsort(key)].contiguous()); del key, codes
+if os.environ.get("CNN_STEP_KEEP"):      # as bear_net.train holds a batch: the contexts without training counts left out
+    keep = (t != 0).any(dim=1).nonzero().squeeze(1)
+    t, packed = t.index_select(0, keep).contiguous(), packed.index_select(0, keep).contiguous()
+    plan = kernels.Plan(t, 5)
+    print("kept %d of %d contexts" % (keep.numel(), n)); del keep
 _, params = ar_funcs.make_ar_func_cnn(lag, 4, filter_width=fw, device=dev, generator=torch.Generator(dev).manual_seed(10))
 flat = torch.cat([q.detach().reshape(-1) for q in params]).contiguous()
 theta = torch.cat([torch.zeros(1, dtype=torch.float64, device=dev), flat]).contiguous()
-bufs = kernels.cnn_step_buffers(n, lag, fw, dev)
+bufs = kernels.cnn_step_buffers(t.shape[0], lag, fw, dev)
 pk = torch.zeros(2 + flat.numel(), dtype=torch.float64, device=dev)
 fn = lambda: kernels.net_cnn_train_reduce(plan, packed, lag, fw, theta, bufs, pk)
 fn(); torch.cuda.synchronize()
