@@ -188,42 +188,53 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
             loss_buf[done[0]:done[0] + 1] = -scale * vec[0:1]
             done[0] += 1
 
-    def epoch():
-        for fn, scale in zip(reduce_fns, scales):
-            fn(packed)
-            kernels.train_apply(theta, packed, m, v, t, learning_rate, scale, loss_buf, train_ar=train_ar)
+    acc = torch.zeros_like(packed) if acc_steps > 1 else None
 
-    graph = None
-    if (adam and world == 1 and acc_steps == 1 and 1 <= n_batches <= GRAPH_MAX_BATCHES and repeats > 1
+    def one_step(k, step):
+        """Batch k as optimizer-loop step number `step` (1-based): reduce -> [one all-reduce] -> update (every acc_steps steps)."""
+        reduce_fns[k](packed)
+        dist.allreduce_sum_(packed)
+        if acc is None:
+            update(packed, scales[k])
+        else:
+            acc.add_(packed, alpha=scales[k])
+            if step % acc_steps == 0:
+                update(acc, 1.0)
+                acc.zero_()
+
+    # HIP graph: the reference traces ONE tf.function for every case (bear_net.py:146, :275-290, several replicas and gradient
+    # accumulation included).  Here the unit that repeats exactly is `period` = lcm(batches per epoch, acc_steps) steps: it is
+    # captured once -- the all-reduce of several ranks too (RCCL collectives are stream-ordered and capturable; gloo stages
+    # through the host and is not) -- and replayed; what is left over runs eagerly.  Every rank takes the same decision (it
+    # depends on the arguments only), so the ranks' collectives stay paired either way.
+    total_steps = repeats * n_batches
+    period = math.lcm(n_batches, acc_steps) if n_batches else 0
+    graph, replays = None, 0
+    if (adam and 1 <= period <= GRAPH_MAX_BATCHES and total_steps >= 2 * period and dist.collective_capturable()
             and not os.environ.get("BEAR_AMD_NO_GRAPH")):
+        if dist.collective_active():
+            dist.allreduce_sum_(torch.zeros_like(packed))     # the communicator comes up outside the capture
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(graph):        # one epoch: the batches in order, one optimizer step each; nothing runs yet
-                epoch()
+            with torch.cuda.graph(graph):        # `period` steps in order; nothing runs yet
+                for i in range(period):
+                    one_step(i % n_batches, i + 1)
         except (_lib.BearError, torch.cuda.OutOfMemoryError):
             raise
         except RuntimeError as err:              # stream capture unavailable: the eager loop below enqueues the same kernels
             warnings.warn(f"HIP-graph capture of the training step failed ({err}); using the eager loop")
             graph = None
+    done_steps = 0
     if graph is not None:
-        for _ in range(repeats):
+        replays = total_steps // period
+        for _ in range(replays):
             graph.replay()
-    else:
-        acc = torch.zeros_like(packed) if acc_steps > 1 else None
-        step = 1
-        for _ in range(repeats):
-            for fn, scale in zip(reduce_fns, scales):
-                fn(packed)
-                dist.allreduce_sum_(packed)
-                if acc is None:
-                    update(packed, scale)
-                else:
-                    acc.add_(packed, alpha=scale)
-                    if step % acc_steps == 0:
-                        update(acc, 1.0)
-                        acc.zero_()
-                step += 1
+        done_steps = replays * period
+    for i in range(done_steps, total_steps):
+        one_step(i % n_batches, i + 1)
+    LAST_RUN.update(graph=graph is not None, replays=replays, period=period, eager_steps=total_steps - done_steps,
+                    world=world, collective=dist.collective_active())
     torch.cuda.synchronize()
     return (loss_buf[:n_steps] / acc_steps).cpu().tolist()
 
@@ -327,7 +338,8 @@ def counts_f64(t):
     return torch.where(t < 0, t.to(torch.float64) + 4294967296.0, t.to(torch.float64))
 
 
-GRAPH_MAX_BATCHES = 64    # an epoch of at most this many resident batches is captured as one HIP graph
+GRAPH_MAX_BATCHES = 64    # a period of at most this many steps is captured as one HIP graph
+LAST_RUN = {}             # how the last run_device_steps call ran (tests, logs): graph?, replays, period, eager_steps
 MAX_EVAL_MODELS = 64   # EVL_MAX_MODELS of kernels_eval.h: h values + van_reg values per launch
 
 

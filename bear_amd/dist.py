@@ -67,6 +67,19 @@ def shard_rows(n_rows, rank=None, world_size=None):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def collective_active():
+    """True when a step's all-reduce actually runs: several ranks -- or a group of ONE with BEAR_AMD_COLLECTIVE_ALWAYS=1, which
+    sends the packed vector through the backend anyway (the only way to exercise RCCL itself on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or bool(os.environ.get("BEAR_AMD_COLLECTIVE_ALWAYS"))
+
+
+def collective_capturable():
+    """Can the step's all-reduce be captured into a HIP graph?  Yes without one, yes on RCCL (stream-ordered), no on gloo (host)."""
+    return (not collective_active()) or dist.get_backend() == "nccl"
+
+
 def _via_host(t):
     """gloo moves host memory: CUDA tensors are staged through the host for it (tests only; RCCL reduces in place)."""
     return t.is_cuda and dist.get_backend() == "gloo"
@@ -75,7 +88,7 @@ def _via_host(t):
 def allreduce_sum_(packed):
     """In-place sum of the packed per-shard partials over all ranks (no-op for a single process).  On RCCL this is
     enqueued on the current stream: no host synchronisation."""
-    if world()[1] > 1:
+    if collective_active():
         if _via_host(packed):
             h = packed.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM)

@@ -34,6 +34,27 @@ def main():
     torch.cuda.synchronize()
     res = {"backend": dist.get_backend(), "world": dist.get_world_size(), "same": bool(torch.equal(before, out)),
            "out": out.cpu().tolist(), "max": float(el.item()), "theta": theta.cpu().tolist()}
+    # the product optimizer loop with the RCCL all-reduce INSIDE the captured HIP graph (BEAR_AMD_COLLECTIVE_ALWAYS=1 sends the
+    # packed vector through the backend although the group has one rank): captured + replayed == enqueued eagerly
+    from bear_amd import _train, ar_funcs, bear_net, bear_ref, dataloader
+    ysd1 = os.path.join(os.environ["BEAR_ROOT"], "tests", "golden", "ysd1_lag_5_file_0_preshuf.tsv")
+    data = dataloader.dataloader(ysd1, "dna", 500, 3)
+    os.environ["BEAR_AMD_COLLECTIVE_ALWAYS"] = "1"
+    runs = {}
+    for name, fn, args, kw in (
+            ("ref", bear_ref.train, (data.repeat(6), 1365, 6, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False), {}),
+            ("net_acc2", bear_net.train, (data.repeat(6), 1365, 6, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", False),
+             {"acc_steps": 2})):
+        for mode in ("graph", "eager"):
+            if mode == "eager":
+                os.environ["BEAR_AMD_NO_GRAPH"] = "1"
+            torch.manual_seed(5)
+            ls = []
+            p, _, _ = fn(*args, loss_save=ls, **kw)
+            os.environ.pop("BEAR_AMD_NO_GRAPH", None)
+            runs[name + "_" + mode] = {"loss": ls, "params": torch.cat([x.detach().reshape(-1) for x in p]).cpu().tolist(),
+                                       "how": dict(_train.LAST_RUN)}
+    res["runs"] = runs
     dist.destroy_process_group()
     json.dump(res, open(os.environ["BEAR_OUT"], "w"))
 

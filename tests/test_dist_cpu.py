@@ -1,4 +1,4 @@
-"""World-size-2 gloo tests of the N > 1 path on CPU: row sharding + the single packed all-reduce of a step.
+"""World-size-2 and -8 gloo tests of the N > 1 path on CPU: row sharding + the single packed all-reduce of a step.
 Per-shard partial sums come from the oracle here (the HIP kernels need a GPU); the reduce, the packing and the
 loss scaling are the product code of bear_amd.dist."""
 import os
@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -17,23 +18,32 @@ import bear_oracle as o
 from bear_amd import dist as bdist
 from util import sparse_table, prior_rows
 rank, world = bdist.init_from_env()          # the product's own set-up (BEAR_AMD_DIST_BACKEND=gloo here, RCCL on the GPU node)
-assert world == 2 and bdist.world() == (rank, 2) and dist.get_backend() == "gloo"
+W = int(os.environ["BEAR_EXPECT_WORLD"])
+assert world == W and bdist.world() == (rank, W) and dist.get_backend() == "gloo"
 # mirrored variables: rank 1 draws other initial values, rank 0's win
 torch.manual_seed(10 + rank)
 ps = [torch.randn(3, 2, dtype=torch.float64), torch.randn((), dtype=torch.float64)]
 bdist.broadcast_params(ps)
-got = [None, None]
+got = [None] * W
 dist.all_gather_object(got, [p.numpy().tolist() for p in ps])
-assert got[0] == got[1]
+assert all(g == got[0] for g in got)
 # input sharding at load time: the two ranks' pieces of every batch tile the table
 from bear_amd import dataloader
 ysd1 = os.path.join(os.environ["BEAR_ROOT"], "tests", "golden", "ysd1_lag_5_file_0_preshuf.tsv")
 part = dataloader.dataloader(ysd1, "dna", 500, 3, shard="auto")
-assert part.shard == (rank, 2) and part.num_rows == 1365
-rows = [None, None]
-dist.all_gather_object(rows, [(g0, g1) for g0, g1, _ in part.rank_pieces(rank, 2)])
-assert rows[0] == [(0, 250), (500, 750), (1000, 1183)] and rows[1] == [(250, 500), (750, 1000), (1183, 1365)]
+assert part.shard == (rank, W) and part.num_rows == 1365
+rows = [None] * W
+dist.all_gather_object(rows, [(g0, g1) for g0, g1, _ in part.rank_pieces(rank, W)])
+if W == 2:
+    assert rows[0] == [(0, 250), (500, 750), (1000, 1183)] and rows[1] == [(250, 500), (750, 1000), (1183, 1365)]
+for k, (a, b) in enumerate([(0, 500), (500, 1000), (1000, 1365)]):      # every batch: the ranks' pieces tile it in rank order
+    assert rows[0][k][0] == a and rows[W - 1][k][1] == b and all(rows[r][k][1] == rows[r + 1][k][0] for r in range(W - 1))
+    sizes = [rows[r][k][1] - rows[r][k][0] for r in range(W)]
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
 assert part.local_rows == sum(b - a for a, b in rows[rank])
+# a table smaller than the world: some ranks hold nothing of a batch (and still take part in the step's all-reduce)
+three = [bdist.shard_rows(3, r, W) for r in range(W)]
+assert sum(hi - lo for lo, hi in three) == 3 and all(hi - lo == (1 if r < 3 else 0) for r, (lo, hi) in enumerate(three)) or W == 2
 train, _, ref = sparse_table(10007, 3)
 f = prior_rows(10007, 4)
 args = (0.2, np.log(1 / 30), -np.log(100))
@@ -63,15 +73,17 @@ bdist.shutdown()
 '''
 
 
-def test_two_rank_gloo_step(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_step(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     import socket
-    env = dict(os.environ, BEAR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", BEAR_AMD_DIST_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo")
+    env = dict(os.environ, BEAR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", BEAR_AMD_DIST_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo",
+               BEAR_EXPECT_WORLD=str(world))
     with socket.socket() as sk:         # a free port (a fixed one may still be held by an earlier run)
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]

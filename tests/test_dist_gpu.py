@@ -27,11 +27,16 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _launch(script_args, env_extra, tmp_path):
+# Ranks that share cuda:0 in the many-rank tests.  The GPU boxes of this pool allow six processes on a card at once and the test
+# process itself holds one, and so does the launcher, so four ranks is the most that can run here; BEAR_TEST_RANKS=8 on a box without that limit.
+MANY = int(os.environ.get("BEAR_TEST_RANKS", "4"))
+
+
+def _launch(script_args, env_extra, tmp_path, nproc=2):
     env = dict(os.environ, BEAR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", BEAR_AMD_DIST_BACKEND="gloo",
                BEAR_AMD_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", GLOO_SOCKET_IFNAME="lo", **env_extra)
     port = _free_port()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + script_args
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
@@ -86,6 +91,85 @@ def test_two_rank_training_matches_single_rank(tmp_path):
         assert np.allclose(a, np.asarray(b), rtol=1e-11)
     # accuracies: integer counts of correct rows, the tie-breaking noise is a function of the global row -> identical
     assert got["eval"][8] == np.asarray(r[8]).tolist()
+
+
+def test_many_ranks_match_single_rank_with_empty_and_uneven_pieces(tmp_path):
+    """MANY processes under torch.distributed.run (all on cuda:0, gloo): bear_ref.train, bear_net.train (linear; BEAR mode, and AR
+    mode with gradient accumulation) and both evaluations on row shards reproduce the single-process run -- on the bundled table
+    (pieces 100 / 73 rows) and on a 23-row table in batches of 7, where a rank's piece of a batch holds 2, 1 or NO rows (the
+    last batch has 2 rows for MANY ranks)."""
+    torch.manual_seed(3)
+    _, lin = ar_funcs.make_ar_func_linear(5, 4)
+    restart = {"linear": np.array([np.array(0.1)] + [x.detach().numpy() for x in lin], dtype=object)}
+    np.savez(tmp_path / "restart.npz", **restart)
+    small = tmp_path / "small.tsv"
+    with open(YSD1) as fh:
+        small.write_text("".join(fh.readlines()[:23]))
+    tables = [["ysd1", YSD1, 500], ["small", str(small), 7]]
+    out_file = tmp_path / "out.json"
+    _launch([os.path.join(ROOT, "tests", "dist_worker_n.py")],
+            {"BEAR_RESTART": str(tmp_path / "restart.npz"), "BEAR_OUT": str(out_file), "BEAR_TABLES": json.dumps(tables),
+             "BEAR_EXPECT_WORLD": str(MANY)}, tmp_path, nproc=MANY)
+    got = json.load(open(out_file))
+    sm = np.asarray(got["small"]["pieces"])                 # [rank][batch]
+    assert sm.shape == (MANY, 4) and sm.sum() == 23 and (sm[:, 3] == 0).sum() == MANY - 2 and sm.min() == 0 and sm.max() >= 2
+    assert np.asarray(got["ysd1"]["pieces"]).sum() == 1365
+    for name, path, batch in tables:
+        data = dataloader.dataloader(path, "dna", batch, 3)
+        g = got[name]
+
+        def check(key, fn, *args, **kw):
+            ls = []
+            p, _, _ = fn(*args, loss_save=ls, **kw)
+            assert len(g[key]["loss"]) == len(ls) and len(ls) > 0, (name, key)
+            assert np.allclose(g[key]["loss"], ls, rtol=1e-10), (name, key)      # the sum over shards in another order: rounding only
+            assert np.allclose(_flat(g[key]["params"]), _flat([x.detach().cpu().numpy() for x in p]), rtol=1e-7, atol=1e-10), (name, key)
+        check("ref_stop", bear_ref.train, data.repeat(4), data.num_rows, 4, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False)
+        check("net_linear", bear_net.train, data.repeat(4), data.num_rows, 4, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", False,
+              params_restart=list(restart["linear"]))
+        check("net_linear_ar_acc2", bear_net.train, data.repeat(4), data.num_rows, 4, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam",
+              True, acc_steps=2, params_restart=list(restart["linear"]))
+        torch.manual_seed(1)
+        f, _ = ar_funcs.make_ar_func_linear(5, 4, device="cuda")
+        r = bear_net.evaluation(data, 0, 1, "dna", torch.tensor(0.37), f, np.array([0.1, 1.0, 10.0]), seed=11)
+        fr, _ = bear_ref._make_ref_ar_func(5, 4, ar_funcs.make_ar_func_stop, {}, device="cuda")
+        rr = bear_ref.evaluation(data, 0, 1, 2, "dna", torch.tensor(0.21), fr, np.array([0.5, 2.0]), seed=3)
+        for key, want in (("eval", r), ("eval_ref", rr)):
+            for a, b in zip(g[key], want):
+                assert np.allclose(a, np.asarray(b), rtol=1e-11), (name, key)
+            # accuracies: integer counts of correct rows over a global-row-keyed noise stream -> identical
+            assert g[key][6] == np.asarray(want[6]).tolist() and g[key][8] == np.asarray(want[8]).tolist(), (name, key)
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_under_the_launcher_many_ranks(scaling, tmp_path):
+    """bench.py --gpus MANY (gloo, all ranks on cuda:0) in both scaling modes: the whole-job value counts every rank's contexts,
+    the per-rank entries carry event-timed kernel and all-reduce times, and the reduced ELBO equals the ELBO of the global table
+    (strong: ONE table of --contexts rows cut into MANY uneven shards)."""
+    from bear_amd import kernels
+    n = 1_000_003
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", BEAR_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               GLOO_SOCKET_IFNAME="lo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={MANY}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(MANY), "--steps", "4", "--warmup", "1",
+           "--contexts", str(n), "--backend", "gloo", "--no-cpu-baseline", "--scaling", scaling]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    total = n if scaling == "strong" else n * MANY
+    assert d["n_gpus"] == MANY and d["scaling"] == scaling and d["config"]["contexts_total"] == total
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    pr = d["per_rank"]
+    assert [e["rank"] for e in pr] == list(range(MANY)) and sum(e["contexts"] for e in pr) == total
+    assert all(e["kernel_ms"] > 0 and e["allreduce_ms"] > 0 for e in pr)
+    if scaling == "strong":
+        assert max(e["contexts"] for e in pr) - min(e["contexts"] for e in pr) == 1      # 1 000 003 rows over MANY ranks
+    dev = torch.device("cuda", 0)
+    t = kernels.synth_counts(20211012, 0, total, dev, want=("train",))["train"]
+    want = kernels.dm_prior_planned(kernels.Plan(t, 5), kernels.synth_prior(20211012, 0, total, dev), 0.0).cpu().numpy()
+    assert np.allclose(d["result"], want, rtol=1e-12), (d["result"], want)
 
 
 @pytest.mark.parametrize("kind", ["ref", "net"])
@@ -190,3 +274,12 @@ def test_rccl_group_of_one(tmp_path):
     assert got["backend"] == "nccl" and got["world"] == 1
     assert got["same"] is True and np.isfinite(got["out"]).all() and got["out"][0] != 0.0
     assert got["max"] == 1.25 and got["theta"] == [0.0, 1.0, 2.0, 3.0, 4.0]
+    # the optimizer loop with the RCCL all-reduce captured into the HIP graph == the eager loop (18 steps, 3 batches per epoch;
+    # with acc_steps = 2 the captured period is lcm(3, 2) = 6 steps)
+    for name, period in (("ref", 3), ("net_acc2", 6)):
+        g, e = got["runs"][name + "_graph"], got["runs"][name + "_eager"]
+        assert g["how"]["graph"] is True and g["how"]["collective"] is True and g["how"]["period"] == period, g["how"]
+        assert g["how"]["replays"] == 18 // period and g["how"]["eager_steps"] == 0
+        assert e["how"]["graph"] is False and e["how"]["eager_steps"] == 18
+        assert len(g["loss"]) == len(e["loss"]) == (18 if name == "ref" else 9)
+        assert np.allclose(g["loss"], e["loss"], rtol=1e-12) and np.allclose(g["params"], e["params"], rtol=1e-10, atol=1e-13), name
