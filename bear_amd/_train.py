@@ -39,11 +39,14 @@ class KerasAdam:
 
 
 # tf.keras optimizers reachable by name (bear_net.py:264-265 `getattr(tf.keras.optimizers, optimizer_name)(learning_rate)`) whose
-# update rule torch.optim reproduces exactly once Keras' defaults are passed explicitly (epsilon 1e-7 everywhere, RMSprop rho 0.9,
+# update rule torch.optim reproduces once Keras' defaults are passed explicitly (epsilon 1e-7 everywhere, RMSprop rho 0.9,
 # Adagrad initial accumulator 0.1, Adadelta rho 0.95).  Adam has its own class (Keras puts epsilon outside the bias correction).
+# RMSprop: with Keras' default momentum = 0 the optimizer_v2 update is `var -= lr g / (sqrt(rms) + epsilon)` (epsilon OUTSIDE the
+# root; only the fused kernel taken for momentum > 0 puts it inside) -- torch.optim.RMSprop's rule.  The reference never passes a
+# momentum (it builds the optimizer from its name and the learning rate alone), so no other case exists here.
 _KERAS_AS_TORCH = {
     "SGD": (torch.optim.SGD, {}),
-    "RMSprop": (torch.optim.RMSprop, {"alpha": 0.9, "eps": 1e-7}),   # TF's kernel has epsilon inside the root: equal to O(1e-7)
+    "RMSprop": (torch.optim.RMSprop, {"alpha": 0.9, "eps": 1e-7, "momentum": 0.0, "centered": False}),
     "Adagrad": (torch.optim.Adagrad, {"initial_accumulator_value": 0.1, "eps": 1e-7}),
     "Adadelta": (torch.optim.Adadelta, {"rho": 0.95, "eps": 1e-7}),
 }
@@ -212,6 +215,9 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
     graph, replays = None, 0
     if (adam and 1 <= period <= GRAPH_MAX_BATCHES and total_steps >= 2 * period and dist.collective_capturable()
             and not os.environ.get("BEAR_AMD_NO_GRAPH")):
+        # a replay costs one graph launch (~15 us, scripts/dev/step_latency.py) whatever it holds: short periods are unrolled
+        # until a graph carries up to GRAPH_MAX_BATCHES steps, as long as at least four replays remain
+        period *= max(1, min(GRAPH_MAX_BATCHES // period, total_steps // (4 * period)))
         if dist.collective_active():
             dist.allreduce_sum_(torch.zeros_like(packed))     # the communicator comes up outside the capture
         torch.cuda.synchronize()

@@ -36,7 +36,7 @@ struct bear_ws {
   double *eval_out;         // [EVL_MAX_OUT] scratch result vector (bear_bmm_f64)
   int eval_blocks;
   double *lin_partials;     // [num_cu][LIN_MAX_GRAD] d/d mat partials (kernels_linear.h)
-  struct bear_params *ref_prm;     // device copy of the mode-R constants (bear_ref_train_step_f64: graph replay)
+  unsigned *arrive;                // arrival counter of the launch that owns `partials` (last block sums them; zero between launches)
   double *cnn_partials;     // [cnn_blocks][cnn total] parameter-gradient partials (kernels_cnn.h), grown on demand
   size_t cnn_partials_cap;  // doubles
 };
@@ -52,10 +52,17 @@ struct bear_params {
   double nw;      // exp(net_weight_signed)
 };
 
+// Partials leave the blocks that store them as AGENT-scope relaxed atomic stores (sc1: visible device-wide once acknowledged)
+// -- not behind __threadfence(): an agent-scope release fence writes back the XCD's whole L2, and one per wave of a 2048-block
+// grid cost 0.25 ms per launch (measured: dm_ref_items_kernel 0.135 -> 0.39 ms).  Only the last block pays one acquire.
+__device__ __forceinline__ void bear_store_agent(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ------------------------------------------------------------------ block reduction
 // Sums NOUT per-thread accumulators over the block (any block size that is a multiple of 64, up to
 // 1024) and stores one partial per block.
-template <int NOUT>
+template <int NOUT, bool AGENT = false>
 __device__ __forceinline__ void block_store_partials(double (&acc)[NOUT], double *partials) {
   __shared__ double red[16][BEAR_MAX_OUT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -69,8 +76,99 @@ __device__ __forceinline__ void block_store_partials(double (&acc)[NOUT], double
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w][threadIdx.x];
-    partials[(size_t)blockIdx.x * BEAR_MAX_OUT + threadIdx.x] = s;
+    if (AGENT) bear_store_agent(&partials[(size_t)blockIdx.x * BEAR_MAX_OUT + threadIdx.x], s);
+    else partials[(size_t)blockIdx.x * BEAR_MAX_OUT + threadIdx.x] = s;
   }
+}
+
+// ------------------------------------------------------------------ one launch per reduce
+// How a launch of a planned kernel gets its constants and leaves its sums.  A training step on a small shard is bound by its
+// launches, not by its kernels (scripts/dev/step_latency.py), so neither the constants nor the final sum take a launch of
+// their own: every block derives the constants from the device-resident parameters in its prologue (a few exponentials), and
+// the LAST block to finish sums the per-block partials -- in the fixed order of finalize_kernel, whichever block that is.
+#define BEAR_THETA_NET 1   // theta = {h_signed, ...}                      (bear_net.py:43)
+#define BEAR_THETA_REF 2   // theta = {h_signed, tau_signed, net_weight_signed}  (bear_ref.py:45-47, 106)
+struct bear_step_io {
+  const double *theta;   // non-NULL: constants from these parameters (kind), else the by-value bear_params of the launch
+  int kind;
+  double *out;           // non-NULL: the last block writes the fixed-order sums here; NULL: a finalize_kernel launch follows
+  unsigned *arrive;      // arrival counter (bear_ws::arrive), zero between launches
+};
+
+__device__ __forceinline__ double bear_uniform_f64(double v) {   // a wave-uniform value back into scalar registers
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// What bear_dm_ref_plan_f64 / bear_dm_prior_plan_f64 derive on the host, from parameters the optimizer moves on the device.
+__device__ __forceinline__ bear_params bear_params_of(const bear_params &arg, const bear_step_io &io) {
+  if (!io.theta) return arg;
+  bear_params p;
+  p.eps = arg.eps;
+  p.inv_h = bear_uniform_f64(1.0 / exp(io.theta[0]));
+  p.E = p.tauE = p.tau = p.V = p.nw = 0.0;
+  if (io.kind == BEAR_THETA_REF) {
+    const double tau = exp(io.theta[1]), nw = exp(io.theta[2]);
+    const double E = exp(-tau);
+    p.E = bear_uniform_f64(E);
+    p.tauE = bear_uniform_f64(tau * E);
+    p.tau = bear_uniform_f64(tau);
+    p.V = bear_uniform_f64(1.0 / (nw + 1.0));
+    p.nw = bear_uniform_f64(nw);
+  }
+  return p;
+}
+
+// After its partials are stored (bear_store_agent) a block announces itself; true for the block that arrived last.  Every
+// thread waits for the acknowledgement of its own stores (s_waitcnt vmcnt(0): gfx9 counts stores there; a workgroup-scope
+// release fence compiles to nothing on gfx950) before the barrier, so the arrival counter is bumped only after all of this
+// block's partials are visible to the device.
+__device__ __forceinline__ bool bear_arrive_last(unsigned *arrive) {
+  __shared__ unsigned s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_last = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return false;
+  // the one block that goes on to read: a single agent-scope acquire (invalidates this CU's L1 and the XCD's L2 lines that may
+  // still hold the previous launch's partials), then plain, pipelined loads
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+
+// The arithmetic of finalize_kernel (256 threads, same order) inside the last block of the producing launch.
+__device__ __forceinline__ void bear_finalize_in_block(const double *partials, int n_out, double *out, unsigned *arrive) {
+  __shared__ double fred[4][BEAR_MAX_OUT];
+  const int n_blocks = (int)gridDim.x;
+  if (threadIdx.x < 256) {
+    double acc[BEAR_MAX_OUT] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < n_blocks; b += 256)
+#pragma unroll
+      for (int k = 0; k < BEAR_MAX_OUT; ++k)
+        if (k < n_out) acc[k] += partials[(size_t)b * BEAR_MAX_OUT + k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < BEAR_MAX_OUT; ++k) {
+      double v = bear_wave_sum(acc[k]);
+      if (lane == 0) fred[wave][k] = v;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n_out) out[threadIdx.x] = (fred[0][threadIdx.x] + fred[1][threadIdx.x]) + (fred[2][threadIdx.x] + fred[3][threadIdx.x]);
+  if (threadIdx.x == 0) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch (stream order) starts from zero
+}
+
+template <int NOUT>
+__device__ __forceinline__ void block_finish(double (&acc)[NOUT], double *partials, const bear_step_io &io) {
+  if (!io.out) {
+    block_store_partials<NOUT>(acc, partials);
+    return;
+  }
+  block_store_partials<NOUT, true>(acc, partials);
+  if (bear_arrive_last(io.arrive)) bear_finalize_in_block(partials, NOUT, io.out, io.arrive);
 }
 
 // ------------------------------------------------------------------ finalize: fixed-order sum of block partials

@@ -7,7 +7,7 @@
 // stated by the reference's own test (bear_model/tests/test_summarize.py:88-115): for every sequence and lag L,
 //     full = '[' * L + seq + ']' ;  for j in [L, len(full)):  counts[full[j-L:j]][group][full[j]] += 1 .
 // On an MI355X that is one pass per lag over the resident text: every transition becomes a (context code, group * 5 +
-// next letter) pair, the pairs are radix-sorted by context (rocPRIM via hipCUB: a library sort is the right tool for
+// next letter) pair, the pairs are radix-sorted by context (rocPRIM radix_sort_pairs: a library sort is the right tool for
 // the sort itself), and a run-length pass turns runs of equal contexts into rows and scatters the pair values into the
 // planar uint32 [group][row][5] slabs the training kernels consume -- no KMC, no intermediate files, and the table can
 // go to training without ever being text.
@@ -17,7 +17,8 @@
 // filled with the start symbol.  Transitions whose context or next letter contains a 6 are dropped (KMC drops k-mers
 // with non-ACGT letters likewise).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <stdint.h>
 
 #include "../../include/bear_hip.h"
@@ -147,9 +148,9 @@ int bear_kmer_sort_create(const uint8_t *text, const uint8_t *group, uint64_t n_
   CNT_TRY(hipMalloc(&h->vals, n_pos * 4));
   hipLaunchKernelGGL(cnt_emit_kernel, dim3(grid_for(n_pos)), dim3(256), 0, s, text, group, n_pos, lag, keys_in, vals_in);
   CNT_TRY(hipGetLastError());
-  CNT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb_sort, keys_in, h->keys, vals_in, h->vals, n_pos, 0, 3 * lag + 1, s));
+  CNT_TRY(rocprim::radix_sort_pairs(nullptr, tb_sort, keys_in, h->keys, vals_in, h->vals, n_pos, 0u, (unsigned)(3 * lag + 1), s));
   CNT_TRY(hipMalloc(&temp, tb_sort ? tb_sort : 8));
-  CNT_TRY(hipcub::DeviceRadixSort::SortPairs(temp, tb_sort, keys_in, h->keys, vals_in, h->vals, n_pos, 0, 3 * lag + 1, s));
+  CNT_TRY(rocprim::radix_sort_pairs(temp, tb_sort, keys_in, h->keys, vals_in, h->vals, n_pos, 0u, (unsigned)(3 * lag + 1), s));
   CNT_TRY(hipStreamSynchronize(s));
   (void)hipFree(temp);
   temp = nullptr;
@@ -160,9 +161,9 @@ int bear_kmer_sort_create(const uint8_t *text, const uint8_t *group, uint64_t n_
   CNT_TRY(hipMalloc(&h->rows, n_pos * 4));
   hipLaunchKernelGGL(cnt_flag_kernel, dim3(grid_for(n_pos)), dim3(256), 0, s, h->keys, n_pos, lag, flags);
   CNT_TRY(hipGetLastError());
-  CNT_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tb_scan, flags, h->rows, n_pos, s));
+  CNT_TRY(rocprim::inclusive_scan(nullptr, tb_scan, flags, h->rows, n_pos, rocprim::plus<uint32_t>(), s));
   CNT_TRY(hipMalloc(&temp, tb_scan ? tb_scan : 8));
-  CNT_TRY(hipcub::DeviceScan::InclusiveSum(temp, tb_scan, flags, h->rows, n_pos, s));
+  CNT_TRY(rocprim::inclusive_scan(temp, tb_scan, flags, h->rows, n_pos, rocprim::plus<uint32_t>(), s));
   CNT_TRY(hipMemcpyAsync(&last, h->rows + (n_pos - 1), 4, hipMemcpyDeviceToHost, s));
   CNT_TRY(hipStreamSynchronize(s));
   h->n_rows = last;

@@ -81,7 +81,8 @@ int bear_ws_create(int device, bear_ws **out) {
       if (e == hipSuccess) e = hipMalloc(&ws->eval_partials, sizeof(double) * EVL_MAX_OUT * (size_t)ws->eval_blocks);
       if (e == hipSuccess) e = hipMalloc(&ws->eval_out, sizeof(double) * EVL_MAX_OUT);
       if (e == hipSuccess) e = hipMalloc(&ws->lin_partials, sizeof(double) * LIN_MAX_GRAD * (size_t)ws->num_cu);
-      if (e == hipSuccess) e = hipMalloc(&ws->ref_prm, sizeof(bear_params));
+      if (e == hipSuccess) e = hipMalloc(&ws->arrive, sizeof(unsigned));
+      if (e == hipSuccess) e = hipMemset(ws->arrive, 0, sizeof(unsigned));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_linear_plan_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_lin));
@@ -167,7 +168,7 @@ int bear_ws_destroy(bear_ws *ws) {
   (void)hipFree(ws->eval_out);
   (void)hipFree(ws->lin_partials);
   if (ws->cnn_partials) (void)hipFree(ws->cnn_partials);
-  if (ws->ref_prm) (void)hipFree(ws->ref_prm);
+  if (ws->arrive) (void)hipFree(ws->arrive);
   (void)hipSetDevice(prev);
   delete ws;
   return BEAR_OK;
@@ -607,21 +608,22 @@ static int grid_plan(const bear_ws *ws, uint64_t n_tiles) {
   return g < 1 ? 1 : (int)g;
 }
 
+// theta != NULL: the kernels derive their constants from the device-resident parameters (kind: BEAR_THETA_NET / _REF; prm.eps is
+// still read from `prm`).  Either way ONE launch: the last block to finish writes the fixed-order sums to `out`.
 static int launch_prior_plan(bear_ws *ws, const bear_plan *plan, const double *prior, uint64_t n_rows, const bear_params &prm,
-                             const bear_params *prm_dev, int train_ar, int prior_normalized, double *out, hipStream_t s) {
+                             const double *theta, int train_ar, int prior_normalized, double *out, hipStream_t s) {
   const int grid = grid_plan(ws, plan->n_tiles);
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  const bear_step_io io{theta, BEAR_THETA_NET, out, ws->arrive};
   if (train_ar)
     hipLaunchKernelGGL((dm_prior_plan_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
-                       plan_view(plan), lt, ws->partials, prm_dev PLN_DBG_ARG);
+                       plan_view(plan), lt, ws->partials, io PLN_DBG_ARG);
   else if (prior_normalized)
     hipLaunchKernelGGL((dm_prior_plan_kernel<true, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
-                       plan_view(plan), lt, ws->partials, prm_dev PLN_DBG_ARG);
+                       plan_view(plan), lt, ws->partials, io PLN_DBG_ARG);
   else
     hipLaunchKernelGGL((dm_prior_plan_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
-                       plan_view(plan), lt, ws->partials, prm_dev PLN_DBG_ARG);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
+                       plan_view(plan), lt, ws->partials, io PLN_DBG_ARG);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
@@ -643,32 +645,31 @@ int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *c
 }
 
 static int launch_prior_plan_grad(bear_ws *ws, const bear_plan *plan, const double *prior, const bear_params &prm,
-                                  const bear_params *prm_dev, int train_ar, int prior_normalized, double *out, double *grad_prior,
+                                  const double *theta, int train_ar, int prior_normalized, double *out, double *grad_prior,
                                   hipStream_t s) {
   const int grid = grid_plan(ws, plan->n_tiles);
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const pln_view pv = plan_view(plan);
+  const bear_step_io io{theta, BEAR_THETA_NET, out, ws->arrive};
   if (train_ar)
     hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
-                       grad_prior, ws->partials, prm_dev);
+                       grad_prior, ws->partials, io);
   else if (prior_normalized)
     hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
-                       grad_prior, ws->partials, prm_dev);
+                       grad_prior, ws->partials, io);
   else
     hipLaunchKernelGGL((dm_prior_plan_grad_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
-                       grad_prior, ws->partials, prm_dev);
-  HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
+                       grad_prior, ws->partials, io);
   HIP_TRY(hipGetLastError());
   if (pv.n_heavy_col + pv.n_heavy_row) {
     const uint64_t nh = pv.n_heavy_col + pv.n_heavy_row;
     const int g2 = (int)((nh + 255) / 256 < (uint64_t)ws->num_cu * 4 ? (nh + 255) / 256 : (uint64_t)ws->num_cu * 4);
     if (train_ar)
-      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, true>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, prm_dev);
+      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, true>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, io);
     else if (prior_normalized)
-      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, prm_dev);
+      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, io);
     else
-      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<false, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, prm_dev);
+      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<false, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, io);
     HIP_TRY(hipGetLastError());
   }
   return BEAR_OK;
@@ -703,18 +704,19 @@ int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_
     return BEAR_ERR_INVALID_ARG;
   if (misaligned(prior) || misaligned(grad_prior) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  bear_params dummy;
-  memset(&dummy, 0, sizeof(dummy));
-  hipLaunchKernelGGL(net_params_kernel, dim3(1), dim3(64), 0, s, h_signed_dev, eps, ws->ref_prm);
-  if (grad_prior) return launch_prior_plan_grad(ws, plan, prior, dummy, ws->ref_prm, train_ar, prior_normalized, out, grad_prior, s);
-  return launch_prior_plan(ws, plan, prior, n_rows, dummy, ws->ref_prm, train_ar, prior_normalized, out, s);
+  bear_params only_eps;
+  memset(&only_eps, 0, sizeof(only_eps));
+  only_eps.eps = eps;
+  if (grad_prior) return launch_prior_plan_grad(ws, plan, prior, only_eps, h_signed_dev, train_ar, prior_normalized, out, grad_prior, s);
+  return launch_prior_plan(ws, plan, prior, n_rows, only_eps, h_signed_dev, train_ar, prior_normalized, out, s);
 }
 
 // The mode-R step on a plan: the reference-aware item stream when the plan was built with this reference column
-// (bear_plan_create_ref), the streaming kernel otherwise.  prm_dev != NULL: parameters from device memory.
+// (bear_plan_create_ref), the streaming kernel otherwise.  theta != NULL: constants from the device-resident parameters.
 static int launch_ref_plan(bear_ws *ws, const bear_plan *plan, const uint32_t *ref, uint64_t n_rows, const bear_params &prm,
-                           const bear_params *prm_dev, int train_ar, double *out, hipStream_t s) {
+                           const double *theta, int train_ar, double *out, hipStream_t s) {
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  const bear_step_io io{theta, BEAR_THETA_REF, out, ws->arrive};
   int grid;
   if (plan->ref) {
     if (plan->ref != ref) return BEAR_ERR_INVALID_ARG;   // the plan is valid for the reference buffer it was built from
@@ -728,21 +730,20 @@ static int launch_ref_plan(bear_ws *ws, const bear_plan *plan, const uint32_t *r
     const uint64_t units = (plan->n_ref_items + 63) / 64, want = (units + 3) / 4 + 2;   // 4 waves per block
     grid = (int)(want < (uint64_t)ws->num_cu * 8 ? want : (uint64_t)ws->num_cu * 8);
     if (train_ar)
-      hipLaunchKernelGGL(dm_ref_items_kernel<true>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, prm_dev);
+      hipLaunchKernelGGL(dm_ref_items_kernel<true>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, io);
     else
-      hipLaunchKernelGGL(dm_ref_items_kernel<false>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, prm_dev);
+      hipLaunchKernelGGL(dm_ref_items_kernel<false>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, io);
   } else {
     grid = grid_plan(ws, plan->n_tiles);
     if (train_ar)
       hipLaunchKernelGGL(dm_ref_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan), lt,
-                         ws->partials, prm_dev);
+                         ws->partials, io);
     else
       hipLaunchKernelGGL(dm_ref_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan), lt,
-                         ws->partials, prm_dev);
+                         ws->partials, io);
   }
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 4, out);
-  HIP_TRY(hipGetLastError());
+  (void)grid;
   return BEAR_OK;
 }
 
@@ -773,9 +774,8 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
 // several ranks put ONE all-reduce of `packed` between them (bear_net.py:278-290) -- no host round trip either way.
 static int launch_train_apply(double *theta, int n_theta, const double *packed, double *adam_m, double *adam_v, double *adam_t,
                               double learning_rate, double scale, int train_ar, double *loss_buf, uint64_t loss_cap, hipStream_t s) {
-  hipLaunchKernelGGL(adam_vec_kernel, dim3((n_theta + 255) / 256), dim3(256), 0, s, theta, packed, packed + 2, n_theta - 1, adam_m, adam_v,
+  hipLaunchKernelGGL(adam_vec_kernel, dim3(1), dim3(1024), 0, s, theta, packed, packed + 2, n_theta - 1, adam_m, adam_v,
                      adam_t, learning_rate, scale, train_ar, loss_buf, (unsigned long long)loss_cap);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, adam_t);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
@@ -796,10 +796,10 @@ int bear_ref_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t
     return BEAR_ERR_INVALID_ARG;
   if (misaligned(ref) || (reinterpret_cast<uintptr_t>(packed) & 7u)) return BEAR_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  bear_params dummy;
-  memset(&dummy, 0, sizeof(dummy));
-  hipLaunchKernelGGL(ref_params_kernel, dim3(1), dim3(64), 0, s, theta, eps, ws->ref_prm);
-  return launch_ref_plan(ws, plan, ref, n_rows, dummy, ws->ref_prm, train_ar, packed, s);
+  bear_params only_eps;
+  memset(&only_eps, 0, sizeof(only_eps));
+  only_eps.eps = eps;
+  return launch_ref_plan(ws, plan, ref, n_rows, only_eps, theta, train_ar, packed, s);
 }
 
 int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
@@ -902,17 +902,15 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
   prm.eps = eps;
   const int grid = grid_plan(ws, plan->n_tiles);
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  const bear_step_io io{nullptr, BEAR_THETA_NET, out, ws->arrive};   // one launch: the last block sums the partials
   if (train_ar)
     hipLaunchKernelGGL(dm_linear_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
                        reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, prm, plan_view(plan), lt, ws->partials,
-                       ws->lin_partials, static_cast<const bear_params *>(nullptr));
+                       ws->lin_partials, io, grad_mat);
   else
     hipLaunchKernelGGL(dm_linear_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
                        reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, prm, plan_view(plan), lt, ws->partials,
-                       ws->lin_partials, static_cast<const bear_params *>(nullptr));
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, out);
-  hipLaunchKernelGGL(linear_finalize_kernel, dim3((lag * 25 + 3) / 4), dim3(256), 0, s, ws->lin_partials, grid, lag * 25,
-                     grad_mat);
+                       ws->lin_partials, io, grad_mat);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
@@ -928,20 +926,19 @@ int bear_net_linear_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const u
   hipStream_t s = static_cast<hipStream_t>(stream);
   bear_params dummy;
   memset(&dummy, 0, sizeof(dummy));
+  dummy.eps = eps;
   const int grid = grid_plan(ws, plan->n_tiles);
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const double *mat = theta + 1;
-  hipLaunchKernelGGL(net_params_kernel, dim3(1), dim3(64), 0, s, theta, eps, ws->ref_prm);
+  const bear_step_io io{theta, BEAR_THETA_NET, packed, ws->arrive};   // constants from theta, sums by the last block: one launch
   if (train_ar)
     hipLaunchKernelGGL(dm_linear_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
                        reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, dummy, plan_view(plan), lt, ws->partials,
-                       ws->lin_partials, static_cast<const bear_params *>(ws->ref_prm));
+                       ws->lin_partials, io, packed + 2);
   else
     hipLaunchKernelGGL(dm_linear_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
                        reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, dummy, plan_view(plan), lt, ws->partials,
-                       ws->lin_partials, static_cast<const bear_params *>(ws->ref_prm));
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->partials, grid, 2, packed);
-  hipLaunchKernelGGL(linear_finalize_kernel, dim3((lag * 25 + 3) / 4), dim3(256), 0, s, ws->lin_partials, grid, lag * 25, packed + 2);
+                       ws->lin_partials, io, packed + 2);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
@@ -1400,7 +1397,6 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
   hipStream_t s = static_cast<hipStream_t>(stream);
   const cnn_dims D = cnn_make_dims(lag, filter_width);
   const double *params = theta + 1;
-  hipLaunchKernelGGL(net_params_kernel, dim3(1), dim3(64), 0, s, theta, eps, ws->ref_prm);
   {
     const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);
     // only the contexts that hold training counts: the DM kernel reads nobody else's prior row (their gradient rows are zero).
@@ -1418,9 +1414,10 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
                        reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, prior_buf, t1_buf,
                        lists ? plan->tiles : nullptr, lists ? plan->live : nullptr, groups);
   }
-  bear_params dummy;
-  memset(&dummy, 0, sizeof(dummy));
-  st = launch_prior_plan_grad(ws, plan, prior_buf, dummy, ws->ref_prm, train_ar, 1, packed, grad_rows_buf, s);   // softmax rows: normalised
+  bear_params only_eps;
+  memset(&only_eps, 0, sizeof(only_eps));
+  only_eps.eps = eps;
+  st = launch_prior_plan_grad(ws, plan, prior_buf, only_eps, theta, train_ar, 1, packed, grad_rows_buf, s);   // softmax rows: normalised
   if (st != BEAR_OK) return st;
   return launch_cnn_backward(ws, D, kmer_code, n_rows, filter_width, params, t1_buf, prior_buf, grad_rows_buf, packed + 2, s, 0, plan);
 }

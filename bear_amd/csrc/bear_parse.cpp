@@ -227,6 +227,7 @@ extern "C" int bear_parse_sparse_counts(const char *path, int num_ds, int width,
       if ((*c >= '0' && *c <= '9') || *c == '-') {
         char *stop = nullptr;
         pos.push_back(strtoll(c, &stop, 10));
+        if (stop == c) return BEAR_ERR_PARSE;   // a '-' with no digit behind it: strtoll converts nothing and would never advance
         c = stop;
       } else {
         ++c;

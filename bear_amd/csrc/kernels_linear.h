@@ -484,10 +484,10 @@ template <bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_kernel(
     const unsigned long long *__restrict__ kmer_code, const double *__restrict__ mat, int lag, bear_params prm_arg, pln_view pv,
     const double2 *__restrict__ logtab_g, double *__restrict__ partials, double *__restrict__ grad_partials,
-    const bear_params *__restrict__ prm_dev) {
+    const bear_step_io io, double *__restrict__ grad_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_lin &S = *reinterpret_cast<pln_lds_lin *>(srt_smem);
-  const bear_params prm = prm_dev ? *prm_dev : prm_arg;   // device-resident parameters for HIP-graph replay (bear_net_linear_train_step_f64)
+  const bear_params prm = bear_params_of(prm_arg, io);   // device-resident parameters: constants derived in the prologue
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
   const lin_geom G = lin_make_geom(lag);
@@ -789,9 +789,42 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
       const int g = l >> 1;
       for (int p = 0; p < 6; ++p) add(g * LIN_PAIR_COMBOS + ((l & 1) ? p * 6 + a : a * 6 + p));
     }
-    grad_partials[(size_t)blockIdx.x * LIN_MAX_GRAD + k] = s;
+    if (io.out) bear_store_agent(&grad_partials[(size_t)blockIdx.x * LIN_MAX_GRAD + k], s);
+    else grad_partials[(size_t)blockIdx.x * LIN_MAX_GRAD + k] = s;
   }
-  block_store_partials<2>(acc, partials);
+  if (!io.out) {                             // a finalize_kernel + linear_finalize_kernel pair follows
+    block_store_partials<2>(acc, partials);
+    return;
+  }
+  block_store_partials<2, true>(acc, partials);
+  if (!bear_arrive_last(io.arrive)) return;
+  // the last block to finish: d/d mat[k] = sum over the blocks in a fixed order -- three threads per entry take a third of the
+  // blocks each (independent loads, consecutive threads on consecutive entries), their sums meet in LDS
+  {
+    double *part = reinterpret_cast<double *>(srt_smem);          // the tile loop is over: the dynamic LDS is free
+    const int n_grad = lag * 25, nb = (int)gridDim.x, third = (nb + 2) / 3;
+    __syncthreads();
+    for (int t = tid; t < 3 * n_grad; t += PLN_THREADS) {
+      const int k = t % n_grad, c = t / n_grad;
+      const int b0 = c * third, b1 = b0 + third < nb ? b0 + third : nb;
+      // sixteen independent loads in flight per thread (the lines come from memory: the L2 was just invalidated); fixed order
+      const double *src = grad_partials + k;
+      double s = 0.0;
+      int b = b0;
+      for (; b + 16 <= b1; b += 16) {
+        double v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(b + j) * LIN_MAX_GRAD];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += v[j];
+      }
+      for (; b < b1; ++b) s += src[(size_t)b * LIN_MAX_GRAD];
+      part[c * LIN_MAX_GRAD + k] = s;
+    }
+    __syncthreads();
+    for (int k = tid; k < n_grad; k += PLN_THREADS) grad_out[k] = (part[k] + part[LIN_MAX_GRAD + k]) + part[2 * LIN_MAX_GRAD + k];
+  }
+  bear_finalize_in_block(partials, 2, io.out, io.arrive);
 }
 
 // fixed-order sum of the per-block d/d mat partials: one wave per entry
@@ -807,39 +840,31 @@ __global__ __launch_bounds__(256) void linear_finalize_kernel(const double *__re
 
 
 // ---- the bear_net / linear optimizer step on the device (HIP-graph replay) ---------------------------------------
-// theta = {h_signed, mat[lag,5,5]} contiguous.  net_params_kernel derives 1/h; adam_vec_kernel is tf.keras Adam on the whole
+// theta = {h_signed, AR parameters...} contiguous (the kernels derive 1/h from it in their prologue); adam_vec_kernel is tf.keras Adam on the whole
 // vector with gradients grad[k] * scale (k = 0: d/dh from out[1], skipped in AR mode; k >= 1: d/d mat).
-__global__ void net_params_kernel(const double *__restrict__ theta, double eps, bear_params *__restrict__ prm) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  bear_params p;
-  p.inv_h = 1.0 / exp(theta[0]);
-  p.eps = eps;
-  p.E = p.tauE = p.tau = p.V = p.nw = 0.0;
-  *prm = p;
-}
-
-__global__ __launch_bounds__(256) void adam_vec_kernel(double *__restrict__ theta, const double *__restrict__ out2,
-                                                       const double *__restrict__ grad_rest, int n_rest, double *__restrict__ m,
-                                                       double *__restrict__ v, const double *__restrict__ t_state, double lr,
-                                                       double scale, int train_ar, double *__restrict__ loss_buf,
-                                                       unsigned long long loss_cap) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k > n_rest) return;
-  const double t = t_state[0] + 1.0;
+// ONE block: every thread reads the step counter before the barrier and thread 0 advances it after it, so the update and the
+// tick are a single launch (a step is launch-bound on small shards: scripts/dev/step_latency.py).
+__global__ __launch_bounds__(1024) void adam_vec_kernel(double *__restrict__ theta, const double *__restrict__ out2,
+                                                        const double *__restrict__ grad_rest, int n_rest, double *__restrict__ m,
+                                                        double *__restrict__ v, double *__restrict__ t_state, double lr,
+                                                        double scale, int train_ar, double *__restrict__ loss_buf,
+                                                        unsigned long long loss_cap) {
+  const double t0 = t_state[0], t = t0 + 1.0;
   const double b1 = 0.9, b2 = 0.999, aeps = 1e-7;
   const double lr_t = lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
-  if (!(train_ar && k == 0)) {
+  for (int k = threadIdx.x; k <= n_rest; k += 1024) {
+    if (train_ar && k == 0) continue;
     const double g = scale * (k == 0 ? out2[1] : grad_rest[k - 1]);
     const double mk = b1 * m[k] + (1.0 - b1) * g, vk = b2 * v[k] + (1.0 - b2) * g * g;
     m[k] = mk;
     v[k] = vk;
     theta[k] -= lr_t * mk / (sqrt(vk) + aeps);
   }
-  if (k == 0) {
-    const unsigned long long step = (unsigned long long)t_state[0];
+  if (threadIdx.x == 0) {
+    const unsigned long long step = (unsigned long long)t0;
     if (loss_buf && step < loss_cap) loss_buf[step] = -scale * out2[0];
   }
+  __syncthreads();
+  if (threadIdx.x == 0) t_state[0] = t;
 }
-__global__ void adam_tick_kernel(double *__restrict__ t_state) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) t_state[0] += 1.0;
-}
+

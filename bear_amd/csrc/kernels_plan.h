@@ -588,14 +588,14 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
                                                                                     pln_view pv,
                                                                                     const double2 *__restrict__ logtab_g,
                                                                                     double *__restrict__ partials,
-                                                                                    const bear_params *__restrict__ prm_dev
+                                                                                    const bear_step_io io
 #ifdef PLN_STAMPS
                                                                                     , unsigned long long *__restrict__ dbg
 #endif
                                                                                     ) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_n &S = *reinterpret_cast<pln_lds_n *>(srt_smem);
-  const bear_params prm = prm_dev ? *prm_dev : prm_arg;   // device-resident parameters: steps enqueued without a host round trip
+  const bear_params prm = bear_params_of(prm_arg, io);   // device-resident parameters: steps enqueued without a host round trip
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
   double acc[2] = {0.0, 0.0};
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
     acc[1] = __builtin_fma(u * m, S.tabP[tid], acc[1]);
   }
   __syncthreads();
-  block_store_partials<2>(acc, partials);
+  block_finish<2>(acc, partials, io);
 }
 
 // ---- mode R ---------------------------------------------------------------------------------
@@ -867,11 +867,11 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
                                                                                   pln_view pv,
                                                                                   const double2 *__restrict__ logtab_g,
                                                                                   double *__restrict__ partials,
-                                                                                  const bear_params *__restrict__ prm_dev) {
+                                                                                  const bear_step_io io) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_r &S = *reinterpret_cast<pln_lds_r *>(srt_smem);
   // parameters by value, or -- for a step that is replayed from a HIP graph while the optimizer moves them -- from device memory
-  const bear_params prm = prm_dev ? *prm_dev : prm_arg;
+  const bear_params prm = bear_params_of(prm_arg, io);
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps;
   const double A = u + 5.0 * eps;              // sum_b alpha_b
@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
     acc[0] = __builtin_fma(c4sum, bear_log_tab(p4, S.logtab), acc[0]);
     acc[3] = __builtin_fma(c4sum * bear_rcp(p4), nwV * (1.0 - f4), acc[3]);  // d f_4 / d nu_s = nw V (1 - f_4)
     __syncthreads();
-    block_store_partials<4>(acc, partials);
+    block_finish<4>(acc, partials, io);
     return;
   }
   for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
     acc[3] = __builtin_fma(VU * nwV, P4, acc[3]);                 // d alpha_4/d nu_s = u nw V^2
   }
   __syncthreads();
-  block_store_partials<4>(acc, partials);
+  block_finish<4>(acc, partials, io);
 }
 
 // ---- mode N with gradient rows --------------------------------------------------------------
@@ -1092,10 +1092,10 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
                                                                                          const double2 *__restrict__ logtab_g,
                                                                                          double *__restrict__ grad_out,
                                                                                          double *__restrict__ partials,
-                                                                                         const bear_params *__restrict__ prm_dev) {
+                                                                                         const bear_step_io io) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_g &S = *reinterpret_cast<pln_lds_g *>(srt_smem);
-  const bear_params prm = prm_dev ? *prm_dev : prm_arg;   // device-resident parameters for HIP-graph replay
+  const bear_params prm = bear_params_of(prm_arg, io);   // device-resident parameters for HIP-graph replay
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
   double acc[2] = {0.0, 0.0};
@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
     acc[1] = __builtin_fma(A - eps5, o.P, acc[1]);
   }
   __syncthreads();
-  block_store_partials<2>(acc, partials);
+  block_finish<2>(acc, partials, io);
 }
 
 // Gradient cells of the items in the plan's global overflow lists (very dense tiles only).  A cell can be hit by
@@ -1256,8 +1256,8 @@ template <bool NORM, bool AR>
 __global__ __launch_bounds__(256) void dm_prior_grad_fixup_kernel(const double *__restrict__ prior, bear_params prm_arg, pln_view pv,
                                                                    const double2 *__restrict__ logtab_g,
                                                                    double *__restrict__ grad_out,
-                                                                   const bear_params *__restrict__ prm_dev) {
-  const bear_params prm = prm_dev ? *prm_dev : prm_arg;
+                                                                   const bear_step_io io) {
+  const bear_params prm = bear_params_of(prm_arg, io);
   __shared__ double2 logtab[BEAR_LOGTAB_N];
   if (threadIdx.x < BEAR_LOGTAB_N) logtab[threadIdx.x] = logtab_g[threadIdx.x];
   __syncthreads();
@@ -1280,46 +1280,4 @@ __global__ __launch_bounds__(256) void dm_prior_grad_fixup_kernel(const double *
     const bear_dp o = srt_general_fast(A, h.n, logtab);
     for (int b = 0; b < 5; ++b) atomicAdd(&grad_out[h.row * 5 + b], -u * o.P);
   }
-}
-
-
-// ---- the bear_ref optimizer step on the device (HIP-graph replay) ---------------------------------------------
-// theta = (h_signed, tau_signed, net_weight_signed).  ref_params_kernel derives the kernel constants from theta (what
-// bear_dm_ref_plan_f64 does on the host); adam_ref_kernel applies tf.keras.optimizers.Adam's update (defaults beta 0.9 /
-// 0.999, epsilon 1e-7; bear_model/bear_ref.py:312-313, 346-350) to the gradients the DM kernel left in out[1..3].
-__global__ void ref_params_kernel(const double *__restrict__ theta, double eps, bear_params *__restrict__ prm) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const double tau = exp(theta[1]), nw = exp(theta[2]);
-  bear_params p;
-  p.inv_h = 1.0 / exp(theta[0]);
-  p.eps = eps;
-  p.E = exp(-tau);
-  p.tauE = tau * p.E;
-  p.tau = tau;
-  p.V = 1.0 / (nw + 1.0);
-  p.nw = nw;
-  *prm = p;
-}
-
-__global__ void adam_ref_kernel(double *__restrict__ theta, const double *__restrict__ out4, double *__restrict__ m,
-                                double *__restrict__ v, double *__restrict__ t_state, double lr, double scale, int train_ar,
-                                double *__restrict__ loss_buf, unsigned long long loss_cap) {
-  if (blockIdx.x != 0 || threadIdx.x >= 3) return;
-  const int k = threadIdx.x;
-  const double t = t_state[0] + 1.0;
-  const double b1 = 0.9, b2 = 0.999, aeps = 1e-7;
-  const double lr_t = lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
-  if (!(train_ar && k == 0)) {      // AR mode: h_signed gets no gradient (bear_ref.py:256-258)
-    const double g = scale * out4[1 + k];
-    const double mk = b1 * m[k] + (1.0 - b1) * g, vk = b2 * v[k] + (1.0 - b2) * g * g;
-    m[k] = mk;
-    v[k] = vk;
-    theta[k] -= lr_t * mk / (sqrt(vk) + aeps);
-  }
-  if (k == 0) {
-    const unsigned long long step = (unsigned long long)t_state[0];
-    if (loss_buf && step < loss_cap) loss_buf[step] = -scale * out4[0];
-  }
-  __syncthreads();
-  if (k == 0) t_state[0] = t;
 }

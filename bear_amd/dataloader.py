@@ -35,6 +35,10 @@ class CountDataset:
         self.dtype = dtype
         self.repeats = int(repeats)
         self.shard = None if shard is None else (int(shard[0]), int(shard[1]))
+        if shard is not None and total_rows is None:
+            raise ValueError("a sharded CountDataset needs total_rows (the row count of the whole table)")
+        if shard is not None and not (0 <= self.shard[0] < self.shard[1]):
+            raise ValueError(f"shard = (rank, world) with 0 <= rank < world, got {self.shard}")
         self.total_rows = int(total_rows) if shard is not None else None
         if self.shard is not None and self.local_rows != sum(hi - lo for lo, hi in self._pieces()):
             raise ValueError("sharded CountDataset: the arrays do not hold exactly this rank's rows")
@@ -193,6 +197,17 @@ def concatenate(datasets):
     d0 = datasets[0]
     if any(d.shard != d0.shard or d.total_rows != d0.total_rows for d in datasets):
         raise ValueError("cannot concatenate count tables with different sharding")
+    parts = [d for d in datasets if isinstance(d, _ShardPart)]
+    if parts:
+        if len(parts) != len(datasets):
+            raise ValueError("cannot mix whole sharded tables and per-file parts")
+        at = 0
+        for d in parts:          # the parts must tile the table: each file starts where the previous one ended
+            if d.row_base != at:
+                raise ValueError(f"sharded parts are not consecutive: a part starts at global row {d.row_base}, expected {at}")
+            at += d.file_rows
+        if at != d0.total_rows:
+            raise ValueError(f"sharded parts cover {at} rows of a table of {d0.total_rows}")
     return CountDataset(np.concatenate([d.kmers for d in datasets]), np.concatenate([d.counts for d in datasets], axis=1),
                         d0.alphabet, d0.batch_size, d0.dtype, shard=d0.shard, total_rows=d0.total_rows)
 
@@ -262,7 +277,9 @@ def dataloader(file, alphabet, batch_size, num_ds, cache=True, header=False, n_p
     ``BEAR_AMD_CACHE_DIR`` environment variable) keeps the parsed table on disk so later runs skip the text.
 
     ``shard=(rank, world)``: load only this rank's rows (see ``CountDataset``); ``shard="auto"`` takes them from the initialised
-    ``torch.distributed`` group.  ``row_base`` / ``total_rows`` place the file inside a table made of several files (the batches
+    ``torch.distributed`` group.  A sharded load READS a fresh binary cache (ranged reads) but never writes one -- the cache holds a
+    whole table and no rank of a sharded run has it; build it once with an unsharded ``dataloader(..., binary_cache=...)`` call
+    (``models/_driver.py`` does that on rank 0 when ``[data] binary_cache`` is set and the table fits its host memory).  ``row_base`` / ``total_rows`` place the file inside a table made of several files (the batches
     -- and so the pieces -- are cut on the whole table); by default the file is the table."""
     L = _lib.lib()
     A1 = len(core.alphabets_tf[alphabet])
@@ -290,7 +307,8 @@ def dataloader(file, alphabet, batch_size, num_ds, cache=True, header=False, n_p
     else:
         _lib.check(L.bear_parse_counts_tsv(str(file).encode(), int(num_ds), int(lag), n_rows, kmers.ctypes.data,
                                            counts.ctypes.data, ctypes.byref(got)), "bear_parse_counts_tsv")
-    assert got.value == n_rows
+    if got.value != n_rows:
+        raise RuntimeError(f"{file}: {got.value} rows parsed, {n_rows} counted (did the file change while it was read?)")
     if binary_cache:
         fsz, fmt = ctypes.c_uint64(), ctypes.c_int64()
         _lib.check(L.bear_stat_source(str(file).encode(), ctypes.byref(fsz), ctypes.byref(fmt)), "bear_stat_source")
@@ -331,24 +349,28 @@ def _load_shard(file, alphabet, batch_size, num_ds, header, dtype, binary_cache,
             _lib.check(L.bear_cache_read(path, g0 - row_base, n, kmers[off:off + n].ctypes.data, tmp.ctypes.data), "bear_cache_read")
             counts[:, off:off + n] = tmp
             off += n
-        assert off == n_local.value
+        if off != n_local.value:
+            raise RuntimeError(f"{file}: the binary cache returned {off} rows for this rank, expected {n_local.value}")
     else:
         got, seen = ctypes.c_uint64(), ctypes.c_uint64()
         _lib.check(L.bear_parse_counts_tsv_shard(str(file).encode(), num_ds, int(lag), 1 if header else 0, row_base, int(total_rows),
                                                  batch_size, rank, world, n_local.value, kmers.ctypes.data, counts.ctypes.data,
                                                  ctypes.byref(got), ctypes.byref(seen)), "bear_parse_counts_tsv_shard")
-        assert got.value == n_local.value and seen.value == file_rows
+        if got.value != n_local.value or seen.value != file_rows:
+            raise RuntimeError(f"{file}: the sharded reader kept {got.value} of {seen.value} rows, expected {n_local.value} of {file_rows} "
+                               "(did the file change while it was read?)")
     if row_base == 0 and file_rows == total_rows:
         return CountDataset(kmers, counts, alphabet, batch_size, dtype, shard=(rank, world), total_rows=total_rows)
-    return _ShardPart(kmers, counts, alphabet, batch_size, dtype, (rank, world), int(total_rows))
+    return _ShardPart(kmers, counts, alphabet, batch_size, dtype, (rank, world), int(total_rows), row_base, file_rows)
 
 
 class _ShardPart:
     """One file's share of a sharded multi-file table: only ``concatenate`` makes a dataset of the parts."""
 
-    def __init__(self, kmers, counts, alphabet, batch_size, dtype, shard, total_rows):
+    def __init__(self, kmers, counts, alphabet, batch_size, dtype, shard, total_rows, row_base, file_rows):
         self.kmers, self.counts, self.alphabet, self.batch_size, self.dtype = kmers, counts, alphabet, batch_size, dtype
         self.shard, self.total_rows = shard, total_rows
+        self.row_base, self.file_rows = int(row_base), int(file_rows)     # where the file sits in the table (checked by concatenate)
 
 
 def sparse_dataloader(file, alphabet, batch_size, num_ds, cache=False, header=True, n_par=1, dtype=torch.float64):

@@ -52,9 +52,11 @@ def init_from_env():
     return world()
 
 
-def shutdown():
+def shutdown(barrier=True):
+    """Leaves the process group (no-op without one).  ``barrier=False`` on error paths: the other ranks may never arrive."""
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if barrier:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -36,7 +36,17 @@ def main(config, kind):
     Multi-GPU (replaces the MirroredStrategy of bear_net.py:246 / bear_ref.py:310): launched as one process per GPU --
     ``python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train_bear_ref.py cfg`` -- every
     process binds to its GPU and joins the RCCL group here, before any GPU work; each rank loads only its rows of every batch,
-    rank 0 alone writes the output files."""
+    rank 0 alone writes the output files.  A process group this call created is destroyed again when it returns or raises (the
+    exception propagates: the process exits non-zero and the launcher tears the job down)."""
+    owned = not (torch.distributed.is_available() and torch.distributed.is_initialized())
+    try:
+        return _run(config, kind)
+    finally:
+        if owned:
+            dist.shutdown(barrier=False)
+
+
+def _run(config, kind):
     rank, world = dist.init_from_env()
     mod = bear_net if kind == "net" else bear_ref
     time_stamp = datetime.datetime.now().strftime("%Y%m%d-%H%M%S")
@@ -81,6 +91,14 @@ def main(config, kind):
     if world > 1 and load is dataloader.dataloader and not shuffle_seed:
         # every rank decodes and holds only its pieces of the batches (the device shuffle needs whole columns: then, as for the
         # small sparse format, each rank loads the table and slices its rows at upload)
+        if extra_kw.get("binary_cache"):
+            # a sharded load reads a binary cache but cannot write one (no rank holds the whole table): rank 0 builds the missing
+            # ones with a plain load first, the others wait, then every rank reads its row ranges
+            if rank == 0:
+                for f in files:
+                    if dataloader._cache_meta(dataloader.cache_path_for(f, extra_kw["binary_cache"]), f, num_ds) is None:
+                        load(f, config["data"]["alphabet"], kmer_batch_size, num_ds, dtype=dtype, **extra_kw)
+            dist.barrier()
         file_rows = [dataloader.count_rows(f) for f in files]
         total, base, parts = sum(file_rows), 0, []
         for f, n in zip(files, file_rows):

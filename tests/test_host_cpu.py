@@ -86,7 +86,8 @@ def test_sparse_dataloader_against_oracle_and_malformed_rows(tmp_path):
     assert d.num_rows == 500 and d.lag == 4 and [bytes(r) for r in d.kmers] == want_k
     assert np.array_equal(d.counts, want_c.transpose(1, 0, 2))
     for bad in ("ACGT; [[0,1]]\n", "ACGT; [[0,1],[1]]; [1,2]\n", "ACGT; [[3,1]]; [1]\n", "ACGT; [[0,5]]; [1]\n", "ACGT; [[0,1]]; [1.5]\n",
-                "ACGT; [[0,1]]; [-1]\n", "ACGT; [[0,1]]; [1,2]\n", "ACG; [[0,1]]; [1]\n"):
+                "ACGT; [[0,1]]; [-1]\n", "ACGT; [[0,1]]; [1,2]\n", "ACG; [[0,1]]; [1]\n",
+                "ACGT; [[-, 1]]; [3]\n", "ACGT; [[0, 1-]]; [3]\n", "ACGT; [[0,1]]; [-]\n"):     # a sign without digits (once: an endless loop)
         with open(path, "w") as fh:
             fh.write("h\nACGT; [[0,1]]; [1]\n" + bad)
         with pytest.raises(Exception):
