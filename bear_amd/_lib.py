@@ -117,7 +117,7 @@ def _load():
     L.bear_eval_plan_destroy.argtypes = [vp]
     L.bear_eval_plan_bytes.argtypes = [vp]
     L.bear_eval_plan_bytes.restype = u64
-    L.bear_eval_plan_f64.argtypes = [vp, vp, vp, vp, vp, u64, vp, cint, cint, vp, cint, dbl, u64, u64, vp, vp]
+    L.bear_eval_plan_f64.argtypes = [vp, vp, vp, vp, vp, u64, vp, cint, cint, vp, cint, dbl, u64, u64, vp, vp, vp]
     L.bear_count_rows.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]
     L.bear_parse_counts_tsv.argtypes = [ctypes.c_char_p, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
     for name in SYMBOLS:

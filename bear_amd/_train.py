@@ -81,10 +81,12 @@ class ResidentBatches:
     requested dataset columns, the k-mer codes, and (lazily) the kernel plans."""
 
     def __init__(self, data, columns, device, want_codes=False, drop_empty=None):
-        """``drop_empty``: name of the column a training run fits.  A context without counts in it adds exactly nothing to the
-        ELBO or to any gradient (``D(x, 0) = 0``, core.py:73-74), so its row is left out of the resident batch -- 30 % of the rows
-        of a typical count table (they hold counts in the other columns only); the loss scale keeps the batch's full size
-        (``global_rows``).  BEAR_AMD_ALL_ROWS=1 keeps every row (tests)."""
+        """``drop_empty``: name of the column a training run fits, or an evaluation scores.  A context without counts in it adds
+        exactly nothing to the ELBO or to any gradient (``D(x, 0) = 0``, core.py:73-74) -- nor to any of the seven sums of
+        ``_evaluation_step`` (bear_net.py:323-371: every term carries a held-out count as a factor) -- so its row is left out of the
+        resident batch: 30 % of the rows of a typical count table for training, half of them for a held-out column; the loss
+        scale keeps the batch's full size (``global_rows``) and ``row_ids`` remembers where each kept row sits in the table
+        (the evaluation's tie-breaking noise is keyed by it).  BEAR_AMD_ALL_ROWS=1 keeps every row (tests)."""
         if not isinstance(data, CountDataset):
             raise TypeError("train / evaluation expect the CountDataset returned by bear_amd.dataloader")
         self.data, self.device = data, device
@@ -136,6 +138,8 @@ class ResidentBatches:
                     for name in list(columns) + (["codes"] if want_codes else []):
                         entry[name] = entry[name].index_select(0, idx).contiguous()
                     entry["rows"] = n_keep
+                    # row i of the compacted batch is row row0 + row_ids[i] of the table: the key of the evaluation's tie noise
+                    entry["row_ids"] = idx.to(torch.int32).contiguous()
                 del keep
             entry["plans"] = {}
             self.batches.append(entry)
@@ -349,12 +353,14 @@ LAST_RUN = {}             # how the last run_device_steps call ran (tests, logs)
 MAX_EVAL_MODELS = 64   # EVL_MAX_MODELS of kernels_eval.h: h values + van_reg values per launch
 
 
-def evaluation_sums(test, prior, h, van_reg, train=None, eps=epsilon, noise_seed=0, row_base=0, plan=None):
+def evaluation_sums(test, prior, h, van_reg, train=None, eps=epsilon, noise_seed=0, row_base=0, plan=None, row_ids=None):
     """The 7 partial sums of ``_evaluation_step`` (bear_net.py:323-371) for this rank's rows: one launch of
     ``bear_eval_f64`` (all h values, the AR model and all van_reg values in a single pass over the rows).
     test / train: uint32 [n,5] device slabs; prior: float64 [n,5] = ar_func rows; h: float or 1-D sequence
-    (h_scan, bear_net.py:523).  ``row_base`` is the global index of row 0, so the arg-max noise stream
-    does not depend on how the rows are sharded."""
+    (h_scan, bear_net.py:523).  ``row_base`` is the global index of row 0 (``row_ids``: of a compacted batch, row i is table row
+    ``row_base + row_ids[i]``), so the arg-max noise stream does not depend on how the rows are sharded or compacted."""
+    if row_ids is not None and plan is None:
+        raise ValueError("row_ids go with a planned evaluation (resident batches)")
     hs = np.atleast_1d(np.asarray(h, dtype=np.float64)).reshape(-1)
     van = np.atleast_1d(np.asarray(van_reg, dtype=np.float64)).reshape(-1)
     if van.size >= MAX_EVAL_MODELS:
@@ -367,7 +373,7 @@ def evaluation_sums(test, prior, h, van_reg, train=None, eps=epsilon, noise_seed
         first = k == 0
         if plan is not None:      # resident table: the sorted plan of the test column (kernels_evalplan.h)
             out = kernels.evaluate_planned(plan, prior, hk, van if first else None, eps=eps, with_ar=first,
-                                           noise_seed=noise_seed + k, row_base=row_base).cpu().numpy()
+                                           noise_seed=noise_seed + k, row_base=row_base, row_ids=row_ids).cpu().numpy()
         else:
             out = kernels.evaluate(test, prior, hk, van if first else None, train, eps=eps, with_ar=first,
                                    noise_seed=noise_seed + k, row_base=row_base).cpu().numpy()

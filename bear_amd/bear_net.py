@@ -117,7 +117,8 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
     cols = {"test": ds_loc_test}
     if use_train:
         cols["train"] = ds_loc_train
-    res = _train.ResidentBatches(data, cols, device, want_codes=True)
+    # only the contexts with held-out counts are kept resident: nothing else enters any sum (their table rows travel as row_ids)
+    res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test")
     total = None
     with torch.no_grad():
         for k, e in enumerate(res.batches):
@@ -128,7 +129,7 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
                 out = ar_func(e["codes"] if live is None else e["codes_live_test"])
                 prior = out.expand(e["rows"], 5).contiguous() if live is None or out.shape[0] == 1 else _train.scatter_live(out, live, e["rows"])
             part = _train.evaluation_sums(e["test"], prior, h, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"],
-                                           plan=res.eval_plan(k) if e["rows"] else None)
+                                           plan=res.eval_plan(k) if e["rows"] else None, row_ids=e.get("row_ids") if e["rows"] else None)
             total = part if total is None else tuple(a + b for a, b in zip(total, part))
     return total, device
 

@@ -131,7 +131,8 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
     cols = {"test": ds_loc_test, "ref": ds_loc_ref}
     if use_train:
         cols["train"] = ds_loc_train
-    res = _train.ResidentBatches(data, cols, device, want_codes=True)
+    # only the contexts with held-out counts are kept resident: nothing else enters any sum (their table rows travel as row_ids)
+    res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test")
     hv = float(torch.as_tensor(h).item()) if np.ndim(torch.as_tensor(h).detach().cpu().numpy()) == 0 else torch.as_tensor(h).detach().cpu().numpy()
     total = None
     with torch.no_grad():
@@ -147,6 +148,6 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
                 else:
                     prior = _train.scatter_live(ar_func(e["codes_live_test"], e["ref_in_live_test"]), live, e["rows"])
             part = _train.evaluation_sums(e["test"], prior, hv, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"],
-                                           plan=res.eval_plan(k) if e["rows"] else None)
+                                           plan=res.eval_plan(k) if e["rows"] else None, row_ids=e.get("row_ids") if e["rows"] else None)
             total = part if total is None else tuple(a + b for a, b in zip(total, part))
     return _train.reduce_evaluation(total, device, np.ndim(hv) == 0)

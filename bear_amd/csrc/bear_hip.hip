@@ -1094,14 +1094,16 @@ uint64_t bear_eval_plan_bytes(const bear_eval_plan *plan) { return plan ? plan->
 
 int bear_eval_plan_f64(bear_ws *ws, const bear_eval_plan *plan, const uint32_t *test, const uint32_t *train, const double *prior,
                        uint64_t n_rows, const double *h, int n_h, int with_ar, const double *van_reg, int n_van, double eps,
-                       uint64_t noise_seed, uint64_t row_base, double *out, void *stream) {
+                       uint64_t noise_seed, uint64_t row_base, const uint32_t *row_ids, double *out, void *stream) {
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
   if (!plan || plan->test != test || plan->train != train || plan->n_rows != n_rows || plan->device != ws->device)
     return BEAR_ERR_INVALID_ARG;
+  if (misaligned(row_ids)) return BEAR_ERR_INVALID_ARG;
   evl_args A;
   st = eval_make_args(test, train, prior, n_rows, h, n_h, with_ar, van_reg, n_van, eps, noise_seed, row_base, out, &A);
   if (st != BEAR_OK) return st;
+  A.has_rid = row_ids ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int n_models = A.n_h + A.n_van;
   const uint64_t nt = plan->n_tiles;
@@ -1135,7 +1137,7 @@ int bear_eval_plan_f64(bear_ws *ws, const bear_eval_plan *plan, const uint32_t *
     if (const char *dbgs = getenv("BEAR_EVP_DEBUG")) common |= atoi(dbgs) << 4;
 #endif
 #define EVP_LAUNCH(NH_, NV_)                                                                                                        \
-  hipLaunchKernelGGL((eval_plan_kernel<NH_, NV_>), dim3(grid), dim3(EVP_THREADS), sizeof(evp_lds), s, test, train, prior, n_rows, A, \
+  hipLaunchKernelGGL((eval_plan_kernel<NH_, NV_>), dim3(grid), dim3(EVP_THREADS), sizeof(evp_lds), s, test, train, prior, row_ids, n_rows, A, \
                      h0, nh, v0, nv, common, plan->items, plan->tile_info, nt, lt, ws->eval_partials EVP_DBG_ARG)
     if (nh == 0) EVP_LAUNCH(0, 4);
     else if (nh == 1 && nv == 0) EVP_LAUNCH(1, 0);

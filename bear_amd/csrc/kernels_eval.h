@@ -27,6 +27,7 @@
 
 struct evl_args {
   int n_h, n_van, arm, has_train, has_prior;
+  int has_rid;                                // planned kernel only: row i is row row_base + row_ids[i] of the table (compacted batch)
   double eps;
   uint64_t seed, row_base;                    // noise stream; global index of row 0 (rank shards / batches)
   double inv_h[EVL_MAX_MODELS];               // [0, n_h): 1 / h_j; [n_h, n_h + n_van): v_k

@@ -148,6 +148,7 @@ struct evp_buf {
   __attribute__((aligned(16))) uint32_t trn[EVP_ROWS * 5 + 8];
   __attribute__((aligned(16))) double pri[EVP_ROWS * 5 + 6];     // sentinel row = 1
   __attribute__((aligned(16))) uint16_t items[EVP_ITEMS_CAP];
+  __attribute__((aligned(16))) uint32_t rid[EVP_ROWS + 4];       // table row of each row (compacted batches; ties only)
 };
 struct evp_lds {
   evp_buf buf[EVP_NSLOT];
@@ -223,7 +224,8 @@ __device__ __forceinline__ uint32_t evp_peek(const uint32_t *p) {
 // v0 .. v0 + nv of A; A.inv_h[j] = 1 / h_j for j < n_h, A.inv_h[n_h + k] = van_reg[k]).
 template <int NH, int NV>
 __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *__restrict__ test, const uint32_t *__restrict__ train,
-                                                                 const double *__restrict__ prior, uint64_t n_rows, evl_args A, int h0,
+                                                                 const double *__restrict__ prior, const uint32_t *__restrict__ row_ids,
+                                                                 uint64_t n_rows, evl_args A, int h0,
                                                                  int nh, int v0, int nv, int do_common,
                                                                  const uint16_t *__restrict__ plan_items,
                                                                  const uint32_t *__restrict__ tile_info, uint64_t n_tiles,
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
       slab(B.tst, test + row0 * 5, cbytes);
       if (A.has_train) slab(B.trn, train + row0 * 5, cbytes);
       if (A.has_prior) slab(B.pri, prior + row0 * 5, pbytes & ~15u);
+      if (A.has_rid) slab(B.rid, row_ids + row0, (rows * 4u) & ~15u);
       {
         // the up-to-3 trailing dwords of the table's last tile through the scalar path (a vector load would be followed by
         // s_waitcnt vmcnt(0) at its use)
@@ -336,6 +339,13 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
           if (lane == 0) {
             B.tst[q] = v;
             if (A.has_train) B.trn[q] = w;
+          }
+        }
+        if (A.has_rid) {
+          for (uint32_t q = rows & ~3u; q < rows; ++q) {
+            const __attribute__((address_space(4))) uint32_t *ic = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)(row_ids + row0 + q);
+            const uint32_t v = *ic;
+            if (lane == 0) B.rid[q] = v;
           }
         }
         if (A.has_prior && (pbytes & 15u)) {
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
 #pragma unroll
                 for (int q = 0; q < 5; ++q) a[q] = is_arm ? f[q] + eps : __builtin_fma(f[q], wsl, (double)r[q]) + eps;
                 const int im = evl_argmax_noisy(a, is_arm ? eps : sig_dm, A.seed, is_arm ? EVL_ID_ARM : (uint32_t)(h0 + sl),
-                                                A.row_base + row0 + row, S.logtab);
+                                                A.row_base + (A.has_rid ? (uint64_t)B.rid[row] : row0 + row), S.logtab);
                 const double hit = (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
                 if (is_arm) acc_carm += hit;
 #pragma unroll
@@ -481,7 +491,8 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
             double a[5];
 #pragma unroll
             for (int q = 0; q < 5; ++q) a[q] = ((double)r[q] + vk) + eps;
-            const int im = evl_argmax_noisy(a, sig_dm, A.seed, EVL_ID_VAN + (uint32_t)(v0 + (int)k), A.row_base + row0 + row, S.logtab);
+            const int im = evl_argmax_noisy(a, sig_dm, A.seed, EVL_ID_VAN + (uint32_t)(v0 + (int)k),
+                                            A.row_base + (A.has_rid ? (uint64_t)B.rid[row] : row0 + row), S.logtab);
             const double hit = (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
 #pragma unroll
             for (int q = 0; q < NV; ++q)

@@ -317,11 +317,15 @@ class EvalPlan:
                 pass
 
 
-def evaluate_planned(plan, prior, h, van_reg, eps=EPSILON, with_ar=True, noise_seed=0, row_base=0):
+def evaluate_planned(plan, prior, h, van_reg, eps=EPSILON, with_ar=True, noise_seed=0, row_base=0, row_ids=None):
     """One ``bear_eval_plan_f64`` call: ``evaluate`` on a sorted plan of the test column (same output vector); the conditioning
-    column is the one the plan was built with."""
+    column is the one the plan was built with.  ``row_ids`` (int32 storage, uint32 values, [n]): the plan's buffers are a
+    compacted batch whose row i is table row ``row_base + row_ids[i]`` (the key of the tie-breaking noise)."""
     test, train = plan.test, plan.train
     n = test.shape[0]
+    if row_ids is not None and not (row_ids.is_cuda and row_ids.dtype == torch.int32 and row_ids.is_contiguous()
+                                    and row_ids.shape == (n,) and row_ids.data_ptr() % 16 == 0):
+        raise ValueError("row_ids must be a contiguous, 16-byte aligned CUDA int32 tensor [n_rows]")
     if prior is not None:
         _check_rows(prior, torch.float64, "prior")
         if prior.shape[0] != n or prior.data_ptr() % 16:
@@ -331,7 +335,7 @@ def evaluate_planned(plan, prior, h, van_reg, eps=EPSILON, with_ar=True, noise_s
     out = torch.empty(2 * (hs.size + vs.size) + 3, dtype=torch.float64, device=test.device)
     with torch.cuda.device(test.device):
         st = _lib.lib().bear_eval_plan_f64(plan.ws.handle, plan._h, _ptr(test), _ptr(train), _ptr(prior), n, hp, hs.size, int(bool(with_ar)),
-                                           vp, vs.size, float(eps), int(noise_seed), int(row_base), _ptr(out), _stream())
+                                           vp, vs.size, float(eps), int(noise_seed), int(row_base), _ptr(row_ids), _ptr(out), _stream())
     _lib.check(st, "bear_eval_plan_f64")
     return out
 

@@ -273,6 +273,10 @@ int bear_eval_f64(bear_ws *ws, const uint32_t *test, const uint32_t *train, cons
  * rows without test transitions cost nothing.  Arguments, output vector and noise stream are those of bear_eval_f64
  * (identical results up to the order of the fp64 sums; accuracies exactly).  The plan is valid for exactly the buffer contents
  * it was built from.
+ *   row_ids [dev, nullable] uint32 [n_rows], 16-byte aligned: the buffers hold a COMPACTED batch -- only the contexts with
+ *           held-out counts (nothing else enters any of the sums) -- and row i is row `row_base + row_ids[i]` of the table: the
+ *           key of its tie-breaking noise, so the accuracies of a compacted batch equal those of the whole batch exactly.
+ *           NULL: row i is row `row_base + i`.
  */
 typedef struct bear_eval_plan bear_eval_plan;
 int bear_eval_plan_create(bear_ws *ws, const uint32_t *test, const uint32_t *train, uint64_t n_rows, bear_eval_plan **out, void *stream);
@@ -280,7 +284,7 @@ int bear_eval_plan_destroy(bear_eval_plan *plan);
 uint64_t bear_eval_plan_bytes(const bear_eval_plan *plan);
 int bear_eval_plan_f64(bear_ws *ws, const bear_eval_plan *plan, const uint32_t *test, const uint32_t *train, const double *prior,
                        uint64_t n_rows, const double *h, int n_h, int with_ar, const double *van_reg, int n_van, double eps,
-                       uint64_t noise_seed, uint64_t row_base, double *out, void *stream);
+                       uint64_t noise_seed, uint64_t row_base, const uint32_t *row_ids, double *out, void *stream);
 
 /*
  * BMM marginal likelihood of one dataset column: replaces _marginal_step of bear_model/dataloader.py:111-118,

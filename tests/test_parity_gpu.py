@@ -665,6 +665,17 @@ def test_eval_plan_kernel_parity(case, dev, ysd1):
             both = (a + b).cpu().numpy()
             assert np.array_equal(both[H + V + 1:], got[H + V + 1:])
             assert np.allclose(both[:H + V + 1], got[:H + V + 1], rtol=1e-12)
+        # a COMPACTED batch -- only the rows with held-out counts, their table rows as row_ids (what evaluation() keeps
+        # resident): the same seven sums, accuracies exactly (the noise is keyed by the table row, not by the position)
+        keep = np.flatnonzero(te.any(axis=1))
+        if 0 < len(keep) < n:
+            ids = torch.from_numpy(keep.astype(np.int32)).to(dev)
+            pc = kernels.EvalPlan(_to_dev(te[keep], dev), _to_dev(tr[keep], dev) if use_train else None)
+            comp = kernels.evaluate_planned(pc, _to_dev(f[keep], dev), hs, van, noise_seed=77, row_base=1000, row_ids=ids).cpu().numpy()
+            assert np.array_equal(comp[H + V + 1:], got[H + V + 1:]), (case, use_train)
+            assert np.allclose(comp[:H + V + 1], got[:H + V + 1], rtol=1e-12), (case, use_train)
+            with pytest.raises(ValueError):
+                kernels.evaluate_planned(pc, _to_dev(f[keep], dev), hs, van, row_ids=ids[:-1])
     # no AR model, vanilla models only, no prior at all (what bmm-style callers pass)
     plan = kernels.EvalPlan(d_te, d_tr)
     got = kernels.evaluate_planned(plan, None, None, van, with_ar=False, noise_seed=3).cpu().numpy()

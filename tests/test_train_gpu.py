@@ -11,7 +11,7 @@ import torch
 from scipy.special import loggamma
 
 import bear_oracle as o
-from bear_amd import ar_funcs, bear_net, bear_ref, core, dataloader
+from bear_amd import ar_funcs, bear_net, bear_ref, core, dataloader, kernels
 from conftest import ROOT, YSD1
 
 pytestmark = pytest.mark.gpu
@@ -185,6 +185,53 @@ def test_evaluation_matches_oracle(ysd1):
     pri = o.ref_ar_func(o.ar_func_stop(None), o.ref_input(counts[:, 2]), np.log(1 / 30), -np.log(100))
     w = o.evaluation_step(counts[:, 1], pri, 0.5, van, counts[:, 0])
     assert np.isclose(got[0], w[0], rtol=1e-11) and np.isclose(got[1], w[1], rtol=1e-11) and np.allclose(got[2], w[2], rtol=1e-11)
+
+
+def test_evaluation_keeps_only_the_contexts_with_heldout_counts(tmp_path, monkeypatch):
+    """evaluation / h_scan keep resident only the contexts that hold counts in the scored column (half of a sparse table; their
+    table rows travel as row_ids for the tie noise): every one of the nine results equals the evaluation over all rows
+    (BEAR_AMD_ALL_ROWS=1) -- accuracies exactly, sums to rounding -- and the oracle on the whole table."""
+    from util import sparse_table
+    n = 6000
+    tr, te, rf = sparse_table(n, 21)
+    assert 0.2 < (te.any(axis=1)).mean() < 0.8            # a column worth compacting
+    rng = np.random.default_rng(4)
+    km = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 5))]
+    path = tmp_path / "sparse.tsv"
+    dataloader.write_counts_tsv(str(path), km, np.stack([tr, te, rf]))
+    data = dataloader.dataloader(str(path), "dna", 2500, 3)              # three batches, the last one short
+    torch.manual_seed(2)
+    f, p = ar_funcs.make_ar_func_linear(5, 4, device="cuda")
+    _, _, arf = bear_ref._create_params(5, 4, ar_funcs.make_ar_func_stop, {}, device=torch.device("cuda"))
+    van = np.array([0.1, 1.0, 10.0])
+
+    def run():
+        a = bear_net.evaluation(data, 0, 1, "dna", torch.tensor(0.37), f, van, seed=11)
+        b = bear_net.evaluation(data, -1, 1, "dna", torch.tensor(0.37), f, van, seed=11)
+        c = bear_net.h_scan(data, 0, 1, "dna", torch.tensor([0.05, 0.37, 2.0]), f, seed=5)
+        d = bear_ref.evaluation(data, 0, 1, 2, "dna", torch.tensor(0.5), arf, van, seed=7)
+        return [np.asarray(v, dtype=np.float64) for r in (a, b, c, d) for v in r]
+    seen = []
+    orig = kernels.evaluate_planned
+    monkeypatch.setattr(kernels, "evaluate_planned", lambda plan, *a, **kw: (seen.append((plan.test.shape[0], kw.get("row_ids") is not None)),
+                                                                            orig(plan, *a, **kw))[1])
+    compact = run()
+    assert seen and all(ids for _, ids in seen) and sum(r for r, _ in seen[:3]) == int(te.any(axis=1).sum())
+    seen.clear()
+    monkeypatch.setenv("BEAR_AMD_ALL_ROWS", "1")
+    whole = run()
+    assert seen and not any(ids for _, ids in seen) and sum(r for r, _ in seen[:3]) == n
+    names = ["ll", "ll", "ll", "perp", "perp", "perp", "acc", "acc", "acc"]
+    for k, (a, b) in enumerate(zip(compact, whole)):
+        kind = (names * 2 + ["ll", "perp", "acc"] + names)[k]
+        if kind == "acc":
+            assert np.array_equal(a, b), k
+        else:
+            assert np.allclose(a, b, rtol=1e-12), k
+    prior = o.ar_func_linear(o.one_hot([bytes(r).decode() for r in km]), p[0].detach().cpu().numpy())
+    w = o.evaluation_step(te, prior, float(torch.tensor(0.37)), van, tr, rng=o.HashNoise(11, 0, n))     # (the float32 the call passes)
+    assert np.isclose(compact[0], w[0], rtol=1e-11) and np.allclose(compact[2], w[2], rtol=1e-11)
+    assert np.all(np.abs(compact[8] - w[5] / w[6]) < 1e-12)
 
 
 @pytest.mark.parametrize("kind", ["net", "ref"])
