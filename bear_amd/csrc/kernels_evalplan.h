@@ -23,9 +23,9 @@
 //     rare ties of the BEAR / AR models (continuous concentrations) are resolved in place.
 //   * short units.  A row's work is split into an "H" unit (AR + BEAR models: needs the prior row) and a "V" unit (vanilla
 //     models: integer arg-max, lgamma tables); ties are (row, model) units.
-// Per launch: one 768-thread block per CU (168 registers per lane: no spills -- at 1024 threads the spilled loop state went
-// through scratch memory every tile); two of its 12 waves only stream, by LDS-DMA, the tiles' test / training / prior rows and
-// lists into the ring (see dm_prior_plan_kernel for why dedicated DMA waves), the other 10 draw tickets.
+// Per launch: one 1024-thread block per CU (128 registers per lane, no vector spills in the <1,4> instantiation); two of its 16
+// waves only stream, by LDS-DMA, the tiles' test / training / prior rows and lists into the ring (see dm_prior_plan_kernel for
+// why dedicated DMA waves), the other 14 draw tickets.  (Round 2 ran 768 threads: the kernel then needed 168 registers.)
 //
 // The two model families cost very different amounts (measured: 854 VALU instructions per total unit when all four models of
 // the bench configuration went through the general product path):
@@ -41,10 +41,12 @@
 #include "kernels_plan.h"
 
 #ifndef EVP_THREADS
-#define EVP_THREADS 768
+#define EVP_THREADS 1024   // round 3: the <1,4> instantiation fits 128 registers, so 16 waves (14 compute) fit a CU: -10 % on a compacted batch
 #endif
 #define EVP_WAVES (EVP_THREADS / 64)
+#ifndef EVP_DMA_WAVES
 #define EVP_DMA_WAVES 2
+#endif
 #define EVP_CWAVES (EVP_WAVES - EVP_DMA_WAVES)    // compute waves
 #define EVP_NSLOT 3                               // LDS ring: a tile being finished, the tile being worked on, a tile landing
 #ifndef EVP_ROWS
@@ -378,9 +380,9 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
       const uint32_t n_cells = inf & 0xfffu, n_tots = (inf >> 12) & 0x3ffu, n_ties = inf >> 22;
       const uint32_t n_cu = (n_cells + 63u) >> 6, n_tu = (n_tots + 63u) >> 6, n_ku = (n_ties + 63u) >> 6;
       const uint32_t tot_base = n_cu * 64u, tie_base = tot_base + n_tu * 64u;
-      // work list, dearest first: H units (AR + BEAR models of the rows with transitions), tie units (one per vanilla model and
-      // 64 tied rows), V units (vanilla models of the rows), cell units
-      const uint32_t n_hu = (NH > 0 || (do_common && A.arm)) ? n_tu : 0u, n_ktu = NV > 0 ? n_ku * (uint32_t)nv : 0u;
+      // work list, dearest first: H units (AR + BEAR models of the rows with transitions), tie units (64 tied rows, all vanilla
+      // models), V units (vanilla models of the rows), cell units
+      const uint32_t n_hu = (NH > 0 || (do_common && A.arm)) ? n_tu : 0u, n_ktu = NV > 0 ? n_ku : 0u;
       const uint32_t n_vu = (NV > 0 || (do_common && n_hu == 0u)) ? n_tu : 0u;
       const uint32_t w_k = n_hu, w_v = w_k + n_ktu, w_c = w_v + n_vu, n_work = w_c + n_cu;
       const bool tot_in_h = n_hu != 0u;   // which unit kind carries the total length
@@ -474,11 +476,11 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
           continue;
         }
         if (w < w_v) {
-          // ---- tie unit: 64 rows whose largest training counts tie, one vanilla model: the noise decides among the tied letters
+          // ---- tie unit: 64 rows whose largest training counts tie: per vanilla model the noise decides among the tied letters
 #ifdef EVP_DEBUG_SWITCHES
           if (dbg_flags & 2) continue;
 #endif
-          const uint32_t q0 = w - w_k, k = q0 / n_ku, un = q0 % n_ku;   // k: wave-uniform model index
+          const uint32_t un = w - w_k;
           const uint32_t row = B.items[tie_base + un * 64u + lane];
           uint32_t t[5], r[5];
 #pragma unroll
@@ -487,16 +489,18 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
             r[q] = B.trn[row * 5 + q];
           }
           if (row != (uint32_t)EVP_SENT_ROW) {
-            const double vk = A.inv_h[A.n_h + v0 + (int)k];
-            double a[5];
+            const uint64_t grow = A.row_base + (A.has_rid ? (uint64_t)B.rid[row] : row0 + row);
 #pragma unroll
-            for (int q = 0; q < 5; ++q) a[q] = ((double)r[q] + vk) + eps;
-            const int im = evl_argmax_noisy(a, sig_dm, A.seed, EVL_ID_VAN + (uint32_t)(v0 + (int)k),
-                                            A.row_base + (A.has_rid ? (uint64_t)B.rid[row] : row0 + row), S.logtab);
-            const double hit = (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
+            for (int k = 0; k < NV; ++k) {     // every vanilla model of the launch on the same gathered row (its own noise stream each)
+              if (k < nv) {
+                const double vk = A.inv_h[A.n_h + v0 + k];
+                double a[5];
 #pragma unroll
-            for (int q = 0; q < NV; ++q)
-              if ((uint32_t)q == k) accV_cor[q] += hit;
+                for (int q = 0; q < 5; ++q) a[q] = ((double)r[q] + vk) + eps;
+                const int im = evl_argmax_noisy(a, sig_dm, A.seed, EVL_ID_VAN + (uint32_t)(v0 + k), grow, S.logtab);
+                accV_cor[k] += (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
+              }
+            }
           }
           EVP_STAMP(4)
           continue;

@@ -7,14 +7,19 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
 dev = torch.device("cuda", 0)
 t = kernels.synth_counts(20211012, 0, n, dev, want=("train", "test"))
 f = kernels.synth_prior(20211012, 0, n, dev)
-plan = kernels.EvalPlan(t["test"], t["train"])
+if os.environ.get("EVP_ALL_ROWS"):
+    plan, ids = kernels.EvalPlan(t["test"], t["train"]), None
+else:       # as evaluation() holds a batch: the contexts with held-out counts only
+    keep = (t["test"] != 0).any(dim=1).nonzero().squeeze(1)
+    f = f.index_select(0, keep).contiguous()
+    plan, ids = kernels.EvalPlan(t["test"].index_select(0, keep).contiguous(), t["train"].index_select(0, keep).contiguous()), keep.to(torch.int32)
 L = _lib.lib()
 L.bear_debug_read_timing.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 names = ["wait for tile", "H units", "cell units", "V units", "tie units", "tickets/rest", "DMA issue", "DMA wait"]
 for label, hs, van in (("1h+AR+3van", [1.0], [0.1, 1.0, 10.0]),):
-    kernels.evaluate_planned(plan, f, hs, van); torch.cuda.synchronize()
+    kernels.evaluate_planned(plan, f, hs, van, row_ids=ids); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); kernels.evaluate_planned(plan, f, hs, van); e1.record(); torch.cuda.synchronize()
+    e0.record(); kernels.evaluate_planned(plan, f, hs, van, row_ids=ids); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     nb, nw = 256, 12
     buf = np.zeros(nb * nw * 8, dtype=np.uint64)
