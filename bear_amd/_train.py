@@ -76,17 +76,107 @@ def require_device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+class Uploader:
+    """Host arrays -> HBM through a ring of reusable PINNED staging buffers on a side stream (the reference's input pipeline
+    keeps `prefetch(10)` batches in flight while a step runs, bear_net.py:268-273).  ``put`` copies a contiguous NumPy block
+    into a pinned buffer piece by piece (host memcpy) and enqueues the asynchronous H2D copy of each piece; the host only
+    waits when it needs a staging buffer back, so the DMA of piece k overlaps the memcpy of piece k + 1 -- and whatever the
+    compute stream is doing (the previous batch's compaction, sort and plan).  ``wait`` orders the compute stream behind
+    everything enqueued so far.  Pageable `.to(device)` copies (round 2) ran at a fraction of the PCIe rate and blocked."""
+
+    PIECE = 64 << 20      # bytes per staging buffer
+
+    def __init__(self, device, n_buffers=3):
+        self.device = device
+        self.consumer = torch.cuda.current_stream(device)     # the stream the uploaded tensors will be used on
+        self.stream = torch.cuda.Stream(device)
+        self.bufs = [torch.empty(self.PIECE, dtype=torch.uint8, pin_memory=True) for _ in range(n_buffers)]
+        self.views = [b.numpy() for b in self.bufs]
+        self.free_at = [None] * n_buffers          # event after which a staging buffer may be overwritten
+        self.k = 0
+        self.bytes = 0
+
+    def put(self, array, dtype):
+        """Device tensor of ``dtype`` with the shape (and bytes) of the C-contiguous NumPy ``array``; valid after ``wait``."""
+        array = np.ascontiguousarray(array)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+            dst = torch.empty(array.shape, dtype=dtype, device=self.device)   # the side stream's own block: no wait for the consumer
+        dst.record_stream(self.consumer)
+        if dst.element_size() != array.dtype.itemsize:
+            raise ValueError("Uploader.put: dtype sizes differ")
+        nbytes = array.nbytes
+        if nbytes == 0:
+            return dst
+        src = array.reshape(-1).view(np.uint8)
+        dst_bytes = dst.view(-1).view(torch.uint8)
+        for off in range(0, nbytes, self.PIECE):
+            n = min(self.PIECE, nbytes - off)
+            b = self.k % len(self.bufs)
+            if self.free_at[b] is not None:
+                self.free_at[b].synchronize()
+            np.copyto(self.views[b][:n], src[off:off + n])
+            with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
+                dst_bytes[off:off + n].copy_(self.bufs[b][:n], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            self.free_at[b] = ev
+            self.k += 1
+        self.bytes += nbytes
+        return dst
+
+    def wait(self):
+        self.consumer.wait_stream(self.stream)
+
+
+class _Ready:
+    def __init__(self, value):
+        self._value = value
+
+    def result(self):
+        return self._value
+
+
+def hbm_budget_check(data, n_columns, want_codes, device, rows=None, per_row_extra=0):
+    """Raises before the first byte goes up when this rank's share of the epoch cannot stay resident: every batch is kept in HBM
+    for all epochs (counts 20 B per column and context, k-mer letters, packed codes, ~7 B of plan, per-context scratch of a
+    fused AR function), and a table that does not fit is a matter of more ranks (rows shard: `python -m torch.distributed.run
+    --nproc-per-node N ...`), not of a slower path."""
+    rows = data.local_rows if rows is None else rows
+    lag = data.lag
+    need = rows * (20 * n_columns + (lag + 8 if want_codes else 0) + 8 + per_row_extra)
+    need = int(need * 1.15) + (256 << 20)           # the upload holds a column next to its compacted copy for a moment
+    free, total = torch.cuda.mem_get_info(device)
+    if need > free:
+        raise MemoryError(f"this rank's {rows} contexts need about {need / 2**30:.1f} GiB of HBM resident ({n_columns} count column(s)"
+                          f"{', k-mer codes' if want_codes else ''}, plans), {free / 2**30:.1f} of {total / 2**30:.1f} GiB are free: "
+                          "shard the rows over more GPUs (python -m torch.distributed.run --nproc-per-node N ...)")
+    return need
+
+
+def sort_by_kmer(codes, lag):
+    """Permutation that orders int8 letter codes [n, lag] lexicographically (first letter most significant; unknown letters last)."""
+    key = torch.zeros(codes.shape[0], dtype=torch.int64, device=codes.device)
+    for l in range(lag):
+        c = codes[:, l].to(torch.int64)
+        key = key * 6 + torch.where((c >= 0) & (c <= 4), c, torch.full_like(c, 5))
+    return torch.argsort(key)
+
+
 class ResidentBatches:
     """This rank's row shard of every batch of one epoch, uploaded once: per batch the device slabs of the
     requested dataset columns, the k-mer codes, and (lazily) the kernel plans."""
 
-    def __init__(self, data, columns, device, want_codes=False, drop_empty=None):
+    def __init__(self, data, columns, device, want_codes=False, drop_empty=None, kmer_order=False, prebuild=(), per_row_extra=0):
         """``drop_empty``: name of the column a training run fits, or an evaluation scores.  A context without counts in it adds
         exactly nothing to the ELBO or to any gradient (``D(x, 0) = 0``, core.py:73-74) -- nor to any of the seven sums of
         ``_evaluation_step`` (bear_net.py:323-371: every term carries a held-out count as a factor) -- so its row is left out of the
         resident batch: 30 % of the rows of a typical count table for training, half of them for a held-out column; the loss
         scale keeps the batch's full size (``global_rows``) and ``row_ids`` remembers where each kept row sits in the table
-        (the evaluation's tie-breaking noise is keyed by it).  BEAR_AMD_ALL_ROWS=1 keeps every row (tests)."""
+        (the evaluation's tie-breaking noise is keyed by it).  BEAR_AMD_ALL_ROWS=1 keeps every row (tests).
+
+        ``kmer_order``: the rows of every batch are sorted by k-mer (the sums of a step do not depend on the order; the fused
+        AR-function kernels share work between neighbouring contexts).  ``prebuild``: plan keys ``(column, ncol, ref_column)``
+        cut for every batch as soon as it has landed -- while the next batch is still crossing PCIe (``Uploader``)."""
         if not isinstance(data, CountDataset):
             raise TypeError("train / evaluation expect the CountDataset returned by bear_amd.dataloader")
         self.data, self.device = data, device
@@ -95,55 +185,105 @@ class ResidentBatches:
         fast_codes = want_codes and data.alphabet in ("dna", "rna") and data.lag > 0
         on_dev = getattr(data, "counts_dev", None) is not None       # DeviceCountDataset: the table is in HBM already
         codes = data.codes() if (want_codes and not fast_codes) else None
+        rank, world = dist.world()
+        pieces = list(zip(data.batch_bounds(), data.rank_pieces(rank, world)))
+        if not on_dev:
+            hbm_budget_check(data, len(columns), want_codes, device, rows=sum(g1 - g0 for _, (g0, g1, _) in pieces),
+                             per_row_extra=per_row_extra)
+        up = None if on_dev else Uploader(device)
+        self.upload_bytes = 0
 
         def device_column(col, lo, hi):
             if on_dev:
                 return data.counts_dev[col, lo:hi].to(device).contiguous().clone()
-            return torch.from_numpy(np.ascontiguousarray(data.counts[col, lo:hi]).view(np.int32)).to(device)
+            return up.put(data.counts[col, lo:hi].view(np.int32), torch.int32)
 
         def device_codes(lo, hi):
+            """-> (tensor, needs_encoding)"""
             if fast_codes:
-                km = data.kmers_dev[lo:hi].to(device).contiguous() if on_dev else \
-                    torch.from_numpy(np.ascontiguousarray(data.kmers[lo:hi])).to(device)
-                return kernels.encode_kmers(km, data.alphabet)
-            return torch.from_numpy(np.ascontiguousarray(codes[lo:hi])).to(device)
+                if on_dev:
+                    return data.kmers_dev[lo:hi].to(device).contiguous(), True
+                return up.put(data.kmers[lo:hi], torch.uint8), True
+            return up.put(codes[lo:hi], torch.int8), False
         shuffled = {}
         if data.shuffle_seed is not None and data.num_rows:
             # whole columns go up once, are permuted by one gather pass each (same seed: columns stay aligned), and the
             # batches below are slices of the permuted slabs
             for name, col in columns.items():
-                up = device_column(col, 0, data.local_rows)
-                shuffled[name] = kernels.shuffle_rows(up, data.shuffle_seed)
-                del up
+                t = device_column(col, 0, data.local_rows)
+                if up:
+                    up.wait()
+                shuffled[name] = kernels.shuffle_rows(t, data.shuffle_seed)
+                del t
             if want_codes:
-                shuffled["codes"] = kernels.shuffle_rows(device_codes(0, data.local_rows), data.shuffle_seed)
-        rank, world = dist.world()
+                t, raw = device_codes(0, data.local_rows)
+                if up:
+                    up.wait()
+                shuffled["codes"] = kernels.shuffle_rows(kernels.encode_kmers(t, data.alphabet) if raw else t, data.shuffle_seed)
+                del t
         if shuffled and data.shard is not None:
             raise ValueError("a sharded table cannot be shuffled on the device")
-        for (a, b), (g0, g1, off) in zip(data.batch_bounds(), data.rank_pieces(rank, world)):
+        names = list(columns) + (["codes"] if want_codes else [])
+
+        def enqueue(k):
+            """Batch k's slabs: asynchronous uploads on the side stream (or slices of the shuffled columns)."""
+            (a, b), (g0, g1, off) = pieces[k]
             lo, hi = off, off + (g1 - g0)           # this rank's piece of the batch inside the dataset's arrays
-            entry = {"global_rows": b - a, "rows": hi - lo, "row0": g0}
+            entry = {"global_rows": b - a, "rows": hi - lo, "row0": g0, "plans": {}}
             for name, col in columns.items():
-                if shuffled:
-                    entry[name] = shuffled[name][lo:hi].clone()
-                else:
-                    entry[name] = device_column(col, lo, hi)
+                entry[name] = shuffled[name][lo:hi].clone() if shuffled else device_column(col, lo, hi)
             if want_codes:
-                entry["codes"] = shuffled["codes"][lo:hi].clone() if shuffled else device_codes(lo, hi)
+                if shuffled:
+                    entry["codes"] = shuffled["codes"][lo:hi].clone()
+                else:
+                    entry["codes"], entry["_raw_codes"] = device_codes(lo, hi)
+            return entry
+
+        def finish(entry):
+            """Everything of a landed batch that runs on the compute stream: encode, drop the empty rows, k-mer order, plans."""
+            if entry.pop("_raw_codes", False):
+                entry["codes"] = kernels.encode_kmers(entry["codes"], data.alphabet)
             if drop_empty and entry["rows"] and not os.environ.get("BEAR_AMD_ALL_ROWS"):
                 keep = (entry[drop_empty] != 0).any(dim=1)
                 n_keep = int(keep.sum())
                 if n_keep < entry["rows"]:
                     idx = keep.nonzero().squeeze(1)
-                    for name in list(columns) + (["codes"] if want_codes else []):
+                    for name in names:
                         entry[name] = entry[name].index_select(0, idx).contiguous()
                     entry["rows"] = n_keep
                     # row i of the compacted batch is row row0 + row_ids[i] of the table: the key of the evaluation's tie noise
                     entry["row_ids"] = idx.to(torch.int32).contiguous()
                 del keep
-            entry["plans"] = {}
+            if kmer_order and want_codes and entry["rows"] > 1:
+                order = sort_by_kmer(entry["codes"], data.lag)
+                for name in names + (["row_ids"] if "row_ids" in entry else []):
+                    entry[name] = entry[name][order].contiguous()
+                del order
             self.batches.append(entry)
+            if entry["rows"]:
+                for column, ncol, ref_column in prebuild:
+                    self.plan(len(self.batches) - 1, column, ncol, ref_column)
+
+        # one batch in flight: a worker thread feeds batch k + 1 through the staging ring (memcpy and waits release the GIL)
+        # while this thread compacts, sorts and plans batch k on the compute stream
+        import concurrent.futures
+        pool = concurrent.futures.ThreadPoolExecutor(1) if (up and len(pieces) > 1 and not shuffled) else None
+        try:
+            submit = (lambda k: pool.submit(enqueue, k)) if pool else (lambda k: _Ready(enqueue(k)))
+            pending = submit(0) if pieces else None
+            for k in range(len(pieces)):
+                landed = pending.result()
+                if up:
+                    up.wait()                              # the compute stream waits for batch k's copies (not the host)
+                pending = submit(k + 1) if k + 1 < len(pieces) else None
+                finish(landed)
+        finally:
+            if pool:
+                pool.shutdown(wait=True)
         del shuffled
+        if up:
+            self.upload_bytes = up.bytes
+            torch.cuda.current_stream(device).synchronize()    # the staging buffers go away with `up`
 
     def eval_plan(self, k, column="test", train_column="train"):
         """Sorted plan of batch k's test column given its conditioning column, if any (built on first use, kept for later

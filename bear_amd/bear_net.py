@@ -43,34 +43,26 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
         params, h_signed, ar_func = change_scope_params(lag, alphabet_size, make_ar_func, af_kwargs, params_restart, dtype, device)
     dist.broadcast_params(params)                    # mirrored variables: every rank starts from rank 0's values (bear_net.py:246-256)
     ar_params = params[1:]
-    res = _train.ResidentBatches(data, {"train": ds_loc}, device, want_codes=True, drop_empty="train")
-    scales = [-(num_kmers / e["global_rows"]) for e in res.batches]       # bear_net.py:190-191 with the global batch
     # linear AR function on a DNA/RNA-sized alphabet: forward, ELBO and all gradients in one launch per batch
     fused_mat = getattr(ar_func, "linear_mat", None)
     if fused_mat is not None and not (alphabet_size == 4 and lag <= kernels.LINEAR_MAX_LAG and fused_mat is ar_params[0]):
         fused_mat = None
     cnn_ok = (getattr(ar_func, "fused", False) and alphabet_size == 4 and len(ar_params) == 8
               and all(a is b for a, b in zip(getattr(ar_func, "cnn_params", []), ar_params)))
-    if fused_mat is not None or cnn_ok:
+    fused = fused_mat is not None or cnn_ok
+    # Fused heads: the sums of a step do not depend on the order of a batch's rows, so every batch is kept sorted by k-mer (first
+    # letter most significant) -- consecutive contexts share all but their last letters: the fused linear kernel adds whole waves /
+    # quads of them to d/d mat at once instead of one LDS atomic per context, letter and position (kernels_linear.h), the
+    # convolutional kernels evaluate a window that all contexts of a wave share once (kernels_cnn.h).  The plans are cut as the
+    # batches land, while the next batch is still being uploaded.
+    res = _train.ResidentBatches(data, {"train": ds_loc}, device, want_codes=True, drop_empty="train", kmer_order=fused,
+                                 prebuild=[("train", 5, None)], per_row_extra=(8 + (208 if cnn_ok else 0)) if fused else 80)
+    scales = [-(num_kmers / e["global_rows"]) for e in res.batches]       # bear_net.py:190-191 with the global batch
+    if fused:
         # theta = {h_signed, flattened AR parameters} lives on the device for the whole run: one step is constants-from-theta ->
-        # fused kernels -> finalize [-> all-reduce of the packed vector] -> Adam, no host round trip (_train.run_device_steps)
+        # fused kernels [-> all-reduce of the packed vector] -> Adam, no host round trip (_train.run_device_steps)
         theta = torch.cat([h_signed.detach().reshape(1)] + [p.detach().reshape(-1) for p in ar_params]).to(
             device=device, dtype=torch.float64).contiguous()
-        if True:   # (both fused heads)
-            # the sums of a step do not depend on the order of a batch's rows: sorted by k-mer (first letter most significant),
-            # consecutive contexts share all but their last letters -- the fused linear kernel adds whole waves / quads of them to
-            # d/d mat at once instead of one LDS atomic per context, letter and position (kernels_linear.h), the convolutional
-            # kernels evaluate a window that all contexts of a wave share once (kernels_cnn.h)
-            for e in res.batches:
-                if e["rows"] > 1:
-                    key = torch.zeros(e["rows"], dtype=torch.int64, device=device)
-                    for l in range(lag):
-                        c = e["codes"][:, l].to(torch.int64)
-                        key = key * 6 + torch.where((c >= 0) & (c <= 4), c, torch.full_like(c, 5))
-                    order = torch.argsort(key)
-                    e["train"] = e["train"][order].contiguous()
-                    e["codes"] = e["codes"][order].contiguous()
-                    del key, order
         packs = [kernels.pack_kmers(e["codes"].contiguous()) if e["rows"] else None for e in res.batches]
         if fused_mat is not None:       # the linear head reads table-row words, not packed letters
             packs = [kernels.linear_index(q, lag) if q is not None else None for q in packs]

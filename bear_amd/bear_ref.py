@@ -77,7 +77,8 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
                               ds_loc, ds_loc_ref, device)
     # stop net function: theta = (h_signed, tau_signed, net_weight_signed) lives on the device for the whole run; one step is
     # constants-from-theta -> planned mode-R kernel -> finalize [-> all-reduce of 4 doubles] -> Adam, no host round trip
-    res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device, drop_empty="train")
+    res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device, drop_empty="train",
+                                 prebuild=[("train", 4, "ref")])       # plans cut while the next batch is still crossing PCIe
     theta = torch.stack([p.detach().reshape(()) for p in params[:3]]).to(device=device, dtype=torch.float64).contiguous()
 
     def reducer(k):
@@ -104,7 +105,8 @@ def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_
     ``(nw net(kmers) + jukes_cantor(ref, tau)) / (nw + 1)`` are formed by torch ops, the planned kernel returns
     the ELBO, d/dh and the gradient rows, and autograd carries the rows back to tau, the net weight and the
     net parameters -- the same loop as bear_net.train with two more parameters."""
-    res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device, want_codes=True, drop_empty="train")
+    res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device, want_codes=True, drop_empty="train",
+                                 prebuild=[("train", 5, None)], per_row_extra=120)
 
     def prior_fn(e):
         if "ref_in" not in e:

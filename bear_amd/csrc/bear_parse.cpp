@@ -494,52 +494,127 @@ extern "C" int bear_cache_read(const char *path, uint64_t row0, uint64_t n_rows,
 
 // ------------------------------------------------------------------ count-table writer (summarize.py:429-449 row format)
 // Rows row_begin, row_begin + row_step, ... of a planar table:  kmer \t [[g0 A,C,G,T,$],[g1 ...],...] \n
+namespace {
+inline int dec_digits(uint32_t v) {
+  return v < 10u ? 1 : v < 100u ? 2 : v < 1000u ? 3 : v < 10000u ? 4 : v < 100000u ? 5 : v < 1000000u ? 6 : v < 10000000u ? 7
+         : v < 100000000u ? 8 : v < 1000000000u ? 9 : 10;
+}
+// bytes of one row: kmer \t [ [a,b,c,d,e] , [..] ... ] \n
+inline size_t row_bytes(const uint32_t *counts, uint64_t n_rows, uint64_t r, int lag, int num_ds) {
+  size_t n = (size_t)lag + 1 + 1 + 1 + 1;                       // kmer, tab, outer [ ... ], newline
+  for (int d = 0; d < num_ds; ++d) {
+    const uint32_t *c = counts + ((uint64_t)d * n_rows + r) * BEAR_ROW_WIDTH;
+    n += 2 + (BEAR_ROW_WIDTH - 1) + (d ? 1 : 0);                // [ ] , the commas inside, the comma in front of a later group
+    for (int b = 0; b < BEAR_ROW_WIDTH; ++b) n += (size_t)dec_digits(c[b]);
+  }
+  return n;
+}
+inline char *format_row(char *o, const char *kmers, const uint32_t *counts, uint64_t n_rows, uint64_t r, int lag, int num_ds) {
+  memcpy(o, kmers + r * (uint64_t)lag, (size_t)lag);
+  o += lag;
+  *o++ = '\t';
+  *o++ = '[';
+  for (int d = 0; d < num_ds; ++d) {
+    if (d) *o++ = ',';
+    *o++ = '[';
+    const uint32_t *c = counts + ((uint64_t)d * n_rows + r) * BEAR_ROW_WIDTH;
+    for (int b = 0; b < BEAR_ROW_WIDTH; ++b) {
+      if (b) *o++ = ',';
+      uint32_t v = c[b];
+      const int k = dec_digits(v);
+      for (int j = k - 1; j >= 0; --j) {
+        o[j] = (char)('0' + v % 10);
+        v /= 10;
+      }
+      o += k;
+    }
+    *o++ = ']';
+  }
+  *o++ = ']';
+  *o++ = '\n';
+  return o;
+}
+}  // namespace
+
+// Two passes over the selected rows, both cut into one contiguous range per hardware thread: the byte length of every range
+// (digit counting), a prefix sum, then each thread formats its range into 4 MiB pieces and writes them at its own file offset
+// (pwrite) -- the text of a 1e8-row, three-column table (5 GB) in seconds instead of the half minute of one thread.
 extern "C" int bear_write_counts_tsv(const char *path, const char *kmers, const uint32_t *counts, uint64_t n_rows, int lag,
                                      int num_ds, uint64_t row_begin, uint64_t row_step, int append) {
   if (!path || !counts || (!kmers && lag > 0 && n_rows) || lag < 0 || num_ds < 1 || row_step == 0) return BEAR_ERR_INVALID_ARG;
-  FILE *fh = fopen(path, append ? "ab" : "wb");
-  if (!fh) return BEAR_ERR_IO;
-  static const size_t BUF = 1u << 20;
-  char *buf = static_cast<char *>(malloc(BUF + 64 + (size_t)lag + (size_t)num_ds * 64));
-  if (!buf) {
-    fclose(fh);
-    return BEAR_ERR_NOMEM;
+  const int fd = open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0644);
+  if (fd < 0) return BEAR_ERR_IO;
+  off_t base = 0;
+  if (append) {
+    base = lseek(fd, 0, SEEK_END);
+    if (base < 0) {
+      close(fd);
+      return BEAR_ERR_IO;
+    }
   }
-  size_t fill = 0;
-  bool ok = true;
-  for (uint64_t r = row_begin; r < n_rows && ok; r += row_step) {
-    memcpy(buf + fill, kmers + r * (uint64_t)lag, (size_t)lag);
-    fill += (size_t)lag;
-    buf[fill++] = '\t';
-    buf[fill++] = '[';
-    for (int d = 0; d < num_ds; ++d) {
-      buf[fill++] = d ? ',' : '[';
-      if (d) buf[fill++] = '[';
-      const uint32_t *c = counts + ((uint64_t)d * n_rows + r) * BEAR_ROW_WIDTH;
-      for (int b = 0; b < BEAR_ROW_WIDTH; ++b) {
-        if (b) buf[fill++] = ',';
-        char tmp[12];
-        int k = 0;
-        uint32_t v = c[b];
-        do {
-          tmp[k++] = (char)('0' + v % 10);
-          v /= 10;
-        } while (v);
-        while (k) buf[fill++] = tmp[--k];
+  const uint64_t n_sel = row_begin < n_rows ? (n_rows - row_begin + row_step - 1) / row_step : 0;   // rows row_begin + i row_step
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > 64) nt = 64;
+  if ((uint64_t)nt > (n_sel + 65535) / 65536) nt = (unsigned)((n_sel + 65535) / 65536);   // at least 64 Ki rows per thread
+  if (nt == 0) nt = 1;
+  std::vector<uint64_t> first(nt + 1), bytes(nt + 1, 0);
+  for (unsigned t = 0; t <= nt; ++t) first[t] = n_sel * t / nt;
+  auto measure = [&](unsigned t) {
+    size_t n = 0;
+    for (uint64_t i = first[t]; i < first[t + 1]; ++i) n += row_bytes(counts, n_rows, row_begin + i * row_step, lag, num_ds);
+    bytes[t + 1] = n;
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(measure, t);
+    measure(0);
+    for (auto &x : th) x.join();
+  }
+  for (unsigned t = 0; t < nt; ++t) bytes[t + 1] += bytes[t];
+  std::vector<int> status(nt, BEAR_OK);
+  auto emit = [&](unsigned t) {
+    static const size_t PIECE = 4u << 20;
+    const size_t slack = 64 + (size_t)lag + (size_t)num_ds * 64;
+    char *buf = static_cast<char *>(malloc(PIECE + slack));
+    if (!buf) {
+      status[t] = BEAR_ERR_NOMEM;
+      return;
+    }
+    off_t at = base + (off_t)bytes[t];
+    char *o = buf;
+    auto flush = [&]() {
+      size_t done = 0, n = (size_t)(o - buf);
+      while (done < n) {
+        const ssize_t w = pwrite(fd, buf + done, n - done, at + (off_t)done);
+        if (w <= 0) {
+          status[t] = BEAR_ERR_IO;
+          return;
+        }
+        done += (size_t)w;
       }
-      buf[fill++] = ']';
+      at += (off_t)n;
+      o = buf;
+    };
+    for (uint64_t i = first[t]; i < first[t + 1] && status[t] == BEAR_OK; ++i) {
+      o = format_row(o, kmers, counts, n_rows, row_begin + i * row_step, lag, num_ds);
+      if ((size_t)(o - buf) >= PIECE) flush();
     }
-    buf[fill++] = ']';
-    buf[fill++] = '\n';
-    if (fill >= BUF) {
-      ok = fwrite(buf, 1, fill, fh) == fill;
-      fill = 0;
-    }
+    if (status[t] == BEAR_OK && o != buf) flush();
+    if (status[t] == BEAR_OK && at != base + (off_t)bytes[t + 1]) status[t] = BEAR_ERR_IO;   // the two passes disagree: never silently
+    free(buf);
+  };
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(emit, t);
+    emit(0);
+    for (auto &x : th) x.join();
   }
-  if (ok && fill) ok = fwrite(buf, 1, fill, fh) == fill;
-  free(buf);
-  ok = (fclose(fh) == 0) && ok;
-  return ok ? BEAR_OK : BEAR_ERR_IO;
+  int st = BEAR_OK;
+  for (unsigned t = 0; t < nt; ++t)
+    if (status[t] != BEAR_OK) st = status[t];
+  if (close(fd) != 0 && st == BEAR_OK) st = BEAR_ERR_IO;
+  return st;
 }
 
 // ------------------------------------------------------------------ FASTA / FASTQ -> device code text (summarize path)

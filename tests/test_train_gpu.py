@@ -234,6 +234,39 @@ def test_evaluation_keeps_only_the_contexts_with_heldout_counts(tmp_path, monkey
     assert np.all(np.abs(compact[8] - w[5] / w[6]) < 1e-12)
 
 
+def test_uploader_and_hbm_budget(monkeypatch, ysd1):
+    """The upload path: pinned staging ring on a side stream -- bytes arrive intact across piece boundaries, for several tensors
+    in flight; a table that cannot stay resident is refused with a clear error before anything is uploaded."""
+    from bear_amd import _train
+    dev = torch.device("cuda", 0)
+    monkeypatch.setattr(_train.Uploader, "PIECE", 4096)          # many pieces, ring wrap-around
+    up = _train.Uploader(dev, n_buffers=2)
+    rng = np.random.default_rng(0)
+    arrays = [rng.integers(0, 2 ** 31, size=(n, 5)).astype(np.int32) for n in (1, 203, 5000, 0, 12345)]
+    arrays.append(rng.integers(0, 255, size=(7001, 13)).astype(np.uint8))
+    outs = [up.put(a, torch.int32 if a.dtype == np.int32 else torch.uint8) for a in arrays]
+    up.wait()
+    for a, t in zip(arrays, outs):
+        assert t.shape == a.shape and np.array_equal(t.cpu().numpy(), a)
+    assert up.bytes == sum(a.nbytes for a in arrays)
+    with pytest.raises(ValueError):
+        up.put(arrays[0], torch.float64)
+    # training through the pipelined upload (3 batches: worker thread + staging ring of tiny pieces) == the oracle-checked result
+    data = dataloader.dataloader(YSD1, "dna", 500, 3)
+    ls_small = []
+    bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False, loss_save=ls_small)
+    monkeypatch.undo()
+    ls = []
+    bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False, loss_save=ls)
+    assert len(ls) == 9 and np.allclose(ls, ls_small, rtol=1e-13, atol=0)     # (a plan's item order -- the order of the sums -- is not fixed)
+    # the budget: 1365 contexts do not fit a card with 1 MiB free
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (1 << 20, 288 << 30))
+    with pytest.raises(MemoryError, match="shard the rows over more GPUs"):
+        bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False)
+    with pytest.raises(MemoryError):
+        bear_net.evaluation(data, 0, 1, "dna", torch.tensor(0.4), ar_funcs.make_ar_func_linear(5, 4, device="cuda")[0], np.array([1.0]))
+
+
 @pytest.mark.parametrize("kind", ["net", "ref"])
 def test_run_config_driver(kind, ysd1):
     """bear_model/tests/test_run.py:12-51 re-stated: the bear_test.cfg workflow returns 1 and the train-set BMM
