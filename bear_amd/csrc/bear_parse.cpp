@@ -46,20 +46,14 @@ inline bool blank_line(const char *b, const char *e) {
 }
 }  // namespace
 
+static uint64_t count_lines_mt(const char *base, size_t size);
+
 extern "C" int bear_count_rows(const char *path, uint64_t *n_rows_out) {
   if (!path || !n_rows_out) return BEAR_ERR_INVALID_ARG;
   mapped_file f;
   int st = f.open_ro(path);
   if (st != BEAR_OK) return st;
-  uint64_t n = 0;
-  const char *p = f.data, *end = f.data + f.size;
-  while (p < end) {
-    const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
-    const char *le = nl ? nl : end;
-    if (!blank_line(p, le)) ++n;
-    p = le + 1;
-  }
-  *n_rows_out = n;
+  *n_rows_out = count_lines_mt(f.data, f.size);
   return BEAR_OK;
 }
 
@@ -134,6 +128,34 @@ uint64_t count_lines(const char *p, const char *end) {
   return n;
 }
 }  // namespace
+
+// Non-blank lines of a mapped text, one chunk (cut at a line start) per hardware thread: the row count of a 5 GB table is a
+// pass at memory speed instead of half a second of one thread's memchr.
+static uint64_t count_lines_mt(const char *base, size_t size) {
+  const char *end = base + size;
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *env = getenv("BEAR_PARSE_THREADS")) nt = (unsigned)atoi(env);
+  if (nt < 1) nt = 1;
+  if (nt > 64) nt = 64;
+  if (size < (size_t)(1u << 20)) nt = 1;
+  if (nt == 1) return count_lines(base, end);
+  std::vector<const char *> cut(nt + 1);
+  cut[0] = base;
+  cut[nt] = end;
+  for (unsigned k = 1; k < nt; ++k) {
+    const char *p = base + (size / nt) * k;
+    const char *nl = p < end ? static_cast<const char *>(memchr(p, '\n', (size_t)(end - p))) : nullptr;
+    cut[k] = nl ? nl + 1 : end;
+    if (cut[k] < cut[k - 1]) cut[k] = cut[k - 1];
+  }
+  std::vector<uint64_t> part(nt, 0);
+  std::vector<std::thread> th;
+  for (unsigned k = 0; k < nt; ++k) th.emplace_back([&, k] { part[k] = count_lines(cut[k], cut[k + 1]); });
+  for (auto &t : th) t.join();
+  uint64_t n = 0;
+  for (unsigned k = 0; k < nt; ++k) n += part[k];
+  return n;
+}
 
 // Text decoding is the first-epoch cost of a large table (~60-80 GB of text at 1e9 rows), so the file is
 // cut at line boundaries into one chunk per hardware thread: pass 1 counts the rows of each chunk, a prefix sum gives

@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--no-settle", action="store_true", help="skip the clock-settle launches in front of the measurement")
     ap.add_argument("--workload", choices=["net", "ref"], default="net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ingest-rows", type=float, default=None,
+                    help="rows of the text table of the also.ingest entry (text -> first step wall time); default: min(--contexts, 1e8); 0 = skip")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N > 1 path)")
     return ap.parse_args()
 
@@ -335,6 +337,16 @@ def main():
                                                "(row_ids carry their table rows); contexts_per_s counts all contexts of the batch; "
                                                "kernel_ms_all_rows_resident: the same kernel over every row (round 2's figure)"}
         del keep_t, te_k, tr_k, pr_k, ids_k, eplan_k
+        # text -> first optimizer step (parse, pinned upload, compaction, plans): wall clock, bounded, 1 GPU only
+        ingest_rows = int(min(n, 1e8) if args.ingest_rows is None else args.ingest_rows)
+        if ingest_rows > 0:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            try:
+                import ingest_time
+                torch.cuda.empty_cache()
+                extra["ingest"] = ingest_time.measure(ingest_rows, dev)
+            except Exception as err:    # e.g. no room for the text file on this box: reported, never fatal for the bench line
+                extra["ingest"] = {"rows": ingest_rows, "error": f"{type(err).__name__}: {err}"}
         del test, eplan
 
     value = total * args.steps / elapsed
