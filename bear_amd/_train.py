@@ -154,12 +154,9 @@ def hbm_budget_check(data, n_columns, want_codes, device, rows=None, per_row_ext
 
 
 def sort_by_kmer(codes, lag):
-    """Permutation that orders int8 letter codes [n, lag] lexicographically (first letter most significant; unknown letters last)."""
-    key = torch.zeros(codes.shape[0], dtype=torch.int64, device=codes.device)
-    for l in range(lag):
-        c = codes[:, l].to(torch.int64)
-        key = key * 6 + torch.where((c >= 0) & (c <= 4), c, torch.full_like(c, 5))
-    return torch.argsort(key)
+    """Permutation (int32 storage) that orders int8 letter codes [n, lag] lexicographically -- first letter most significant,
+    unknown letters last, equal k-mers in their given order: a device radix sort of the packed contexts (``bear_kmer_order_u64``)."""
+    return kernels.kmer_order(kernels.pack_kmers(codes.contiguous()), lag)
 
 
 class ResidentBatches:
@@ -257,7 +254,7 @@ class ResidentBatches:
             if kmer_order and want_codes and entry["rows"] > 1:
                 order = sort_by_kmer(entry["codes"], data.lag)
                 for name in names + (["row_ids"] if "row_ids" in entry else []):
-                    entry[name] = entry[name][order].contiguous()
+                    entry[name] = kernels.gather_rows(entry[name], order)
                 del order
             self.batches.append(entry)
             if entry["rows"]:

@@ -207,3 +207,76 @@ int bear_kmer_sort_destroy(bear_kmer_sort *h) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ k-mer order of a batch (fused AR-function kernels)
+// The sums of a training step do not depend on the order of a batch's rows, and the fused linear / convolutional kernels run
+// about twice as fast when consecutive contexts share their leading letters (kernels_linear.h phase C, kernels_cnn.h shared
+// windows).  bear_kmer_order_u64 returns the permutation that sorts packed contexts lexicographically, FIRST letter most
+// significant (a radix sort over 3 lag bits of the letter-reversed code); bear_gather_rows applies a permutation to any
+// row-major slab (count rows, packed contexts, k-mer bytes) -- once per batch, before its plan is built.
+namespace {
+__global__ __launch_bounds__(256) void order_keys_kernel(const unsigned long long *__restrict__ code, uint64_t n, int lag,
+                                                         unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const unsigned long long w = code[i];
+    unsigned long long k = 0ull;
+    for (int l = 0; l < lag; ++l) k = (k << 3) | ((w >> (3 * l)) & 7ull);      // letter 0 ends up in the top field
+    keys[i] = k;
+    vals[i] = (uint32_t)i;
+  }
+}
+__global__ __launch_bounds__(256) void gather_rows_kernel(const unsigned char *__restrict__ src, const uint32_t *__restrict__ perm,
+                                                          unsigned char *__restrict__ dst, uint64_t n_rows, uint32_t row_bytes) {
+  if ((row_bytes & 3u) == 0u) {      // word rows: one thread per 4-byte word, consecutive threads on consecutive words of a row
+    const uint32_t wpr = row_bytes >> 2;
+    const uint64_t total = n_rows * wpr;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
+      const uint64_t r = t / wpr;
+      const uint32_t k = (uint32_t)(t - r * wpr);
+      reinterpret_cast<uint32_t *>(dst)[t] = reinterpret_cast<const uint32_t *>(src)[(uint64_t)perm[r] * wpr + k];
+    }
+  } else {
+    const uint64_t total = n_rows * row_bytes;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
+      const uint64_t r = t / row_bytes;
+      dst[t] = src[(uint64_t)perm[r] * row_bytes + (t - r * row_bytes)];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int bear_kmer_order_u64(const uint64_t *kmer_code, uint64_t n_rows, int lag, uint32_t *perm, void *stream) {
+  if ((n_rows && (!kmer_code || !perm)) || lag < 1 || lag > 21 || n_rows > 0xffffffffull) return BEAR_ERR_INVALID_ARG;
+  if (n_rows == 0) return BEAR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int st = BEAR_OK;
+  unsigned long long *keys_in = nullptr, *keys_out = nullptr;
+  uint32_t *vals_in = nullptr;
+  void *temp = nullptr;
+  size_t tb = 0;
+  CNT_TRY(hipMalloc(&keys_in, n_rows * 8));
+  CNT_TRY(hipMalloc(&keys_out, n_rows * 8));
+  CNT_TRY(hipMalloc(&vals_in, n_rows * 4));
+  hipLaunchKernelGGL(order_keys_kernel, dim3(grid_for(n_rows)), dim3(256), 0, s, reinterpret_cast<const unsigned long long *>(kmer_code),
+                     n_rows, lag, keys_in, vals_in);
+  CNT_TRY(hipGetLastError());
+  CNT_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out, vals_in, perm, n_rows, 0u, (unsigned)(3 * lag), s));
+  CNT_TRY(hipMalloc(&temp, tb ? tb : 8));
+  CNT_TRY(rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, vals_in, perm, n_rows, 0u, (unsigned)(3 * lag), s));
+  CNT_TRY(hipStreamSynchronize(s));        // the scratch goes away with this call (set-up path: once per batch)
+done:
+  if (temp) (void)hipFree(temp);
+  if (keys_in) (void)hipFree(keys_in);
+  if (keys_out) (void)hipFree(keys_out);
+  if (vals_in) (void)hipFree(vals_in);
+  return st;
+}
+
+extern "C" int bear_gather_rows(const void *src, const uint32_t *perm, void *dst, uint64_t n_rows, uint32_t row_bytes, void *stream) {
+  if ((n_rows && (!src || !perm || !dst)) || row_bytes == 0 || src == dst) return BEAR_ERR_INVALID_ARG;
+  if (n_rows == 0) return BEAR_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n_rows * ((row_bytes & 3u) ? row_bytes : row_bytes >> 2))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const unsigned char *>(src), perm, static_cast<unsigned char *>(dst),
+                     n_rows, row_bytes);
+  return hipGetLastError() == hipSuccess ? BEAR_OK : BEAR_ERR_HIP;
+}

@@ -419,6 +419,31 @@ def shuffle_rows(src, seed):
     return dst
 
 
+def kmer_order(kmer_code, lag):
+    """``bear_kmer_order_u64``: int32-storage permutation [n] that sorts packed contexts (``pack_kmers``) lexicographically, first
+    letter most significant, stable.  Synchronises the current stream (set-up path)."""
+    _check_codes(kmer_code)
+    perm = torch.empty(kmer_code.shape[0], dtype=torch.int32, device=kmer_code.device)
+    with torch.cuda.device(kmer_code.device):
+        st = _lib.lib().bear_kmer_order_u64(_ptr(kmer_code), kmer_code.shape[0], int(lag), _ptr(perm), _stream())
+    _lib.check(st, "bear_kmer_order_u64")
+    return perm
+
+
+def gather_rows(src, perm):
+    """One launch of ``bear_gather_rows``: a new tensor with ``dst[i] = src[perm[i]]`` along dim 0 (perm: int32 storage)."""
+    if not (src.is_cuda and src.is_contiguous() and src.dim() >= 1 and perm.is_cuda and perm.dtype == torch.int32
+            and perm.is_contiguous() and perm.shape == (src.shape[0],)):
+        raise ValueError("src: contiguous CUDA tensor; perm: contiguous CUDA int32 [n_rows]")
+    dst = torch.empty_like(src)
+    n = src.shape[0]
+    row_bytes = src.element_size() * (src.numel() // n) if n else 1
+    with torch.cuda.device(src.device):
+        st = _lib.lib().bear_gather_rows(_ptr(src), _ptr(perm), _ptr(dst), n, row_bytes, _stream())
+    _lib.check(st, "bear_gather_rows")
+    return dst
+
+
 def shuffle_source_row(i, n_rows, seed):
     """Host evaluation of the permutation: the source row of shuffled row i."""
     return int(_lib.lib().bear_shuffle_source_row(int(i), int(n_rows), int(seed) & (2 ** 64 - 1)))

@@ -403,6 +403,22 @@ int bear_shuffle_rows(const void *src, void *dst, uint64_t n_rows, uint32_t row_
 uint64_t bear_shuffle_source_row(uint64_t i, uint64_t n_rows, uint64_t seed);
 
 /*
+ * k-mer order of a batch.  The sums of a training step (bear_net.py:146-197) do not depend on the order of a batch's rows, and
+ * the fused AR-function entries below (bear_dm_linear_f64, bear_cnn_forward / backward_f64, bear_net_*_train_*_f64) run about
+ * twice as fast when consecutive contexts share their leading letters -- 1.8 vs 2.9 ms (linear) and 54 vs 104 ms (cnn) per
+ * 1e8 contexts: they are CORRECT for any order, the order is a performance precondition.  A caller establishes it once per
+ * batch, before bear_plan_create (a plan is tied to the row order of the count slab it was built from):
+ *   bear_kmer_order_u64: perm [dev] uint32 [n_rows] such that kmer_code[perm[0]] <= kmer_code[perm[1]] <= ... lexicographically
+ *                        with the FIRST letter most significant (stable: equal contexts keep their order); kmer_code [dev] is
+ *                        the bear_pack_kmers_u64 form; n_rows < 2^32.  Synchronises `stream` (scratch is freed on return).
+ *   bear_gather_rows:    dst[i] = src[perm[i]] for rows of row_bytes bytes (20: a count slab; 8: packed contexts; lag: k-mer
+ *                        bytes); dst != src; asynchronous on `stream`.
+ * bear_amd.bear_net.train does exactly this at upload (bear_amd/_train.py: ResidentBatches(kmer_order=True)).
+ */
+int bear_kmer_order_u64(const uint64_t *kmer_code, uint64_t n_rows, int lag, uint32_t *perm, void *stream);
+int bear_gather_rows(const void *src, const uint32_t *perm, void *dst, uint64_t n_rows, uint32_t row_bytes, void *stream);
+
+/*
  * k-mer transition counting on the device: the rows summarize.py produces through KMC and its stage-3
  * heap merge (bear_model/summarize.py:380-622), computed from the sequences as bear_model/tests/test_summarize.py:88-115
  * defines them.  Per lag: emit (context, group*5 + next letter) per transition, radix sort by context, run-length reduce.

@@ -53,3 +53,32 @@ def test_device_kmer_encoding_matches_host():
     for alphabet in ("dna", "rna"):
         got = kernels.encode_kmers(torch.from_numpy(ascii_).to(dev), alphabet).cpu().numpy()
         assert np.array_equal(got, core.encode_kmers(ascii_, alphabet))
+
+
+def test_kmer_order_and_gather_rows():
+    """bear_kmer_order_u64 / bear_gather_rows (the k-mer order the fused AR-function kernels want, include/bear_hip.h): the
+    permutation sorts the contexts lexicographically with the first letter most significant, is stable, and the gather applies it
+    to slabs of any row width."""
+    import torch
+    from bear_amd import kernels
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(7)
+    for n, lag in ((1, 1), (5000, 3), (100_003, 13), (4097, 21)):
+        codes = rng.integers(-1, 6, size=(n, lag)).astype(np.int8)          # -1 / 5: unknown letters (sorted last), 4: the start symbol
+        d_codes = torch.from_numpy(codes).to(dev)
+        packed = kernels.pack_kmers(d_codes)
+        perm = kernels.kmer_order(packed, lag)
+        clean = np.where((codes >= 0) & (codes <= 4), codes, 5).astype(np.int64)
+        key = np.zeros(n, dtype=object)
+        for l in range(lag):
+            key = key * 6 + clean[:, l]
+        want = np.array(sorted(range(n), key=lambda i: (key[i], i)), dtype=np.int64)      # stable
+        assert np.array_equal(perm.cpu().numpy().astype(np.int64), want), (n, lag)
+        for width, dtype in ((5, torch.int32), (1, torch.int64), (lag, torch.int8), (7, torch.uint8)):
+            src = torch.from_numpy(rng.integers(0, 100, size=(n, width))).to(dev).to(dtype).contiguous()
+            if width == 1:
+                src = src.reshape(n)
+            got = kernels.gather_rows(src, perm)
+            assert torch.equal(got, src[perm.long()]), (n, lag, width)
+    with pytest.raises(Exception):
+        kernels.kmer_order(packed, 22)
