@@ -35,6 +35,65 @@ import torch.distributed as dist
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 BYTES_PER_CONTEXT = {"net": 60, "ref": 40}
 SEED = 20211012
+FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector (= matrix) peak, MI355X_MICROARCH.md
+
+# ---- useful fp64 flops of the instruction-bound kernels: counted from the ALGORITHM as it is implemented
+# (gfx950 has no fp64 transcendental hardware, so a log / exp / reciprocal is the polynomial it takes), fma = 2:
+#   product path of an item with count c <= 24:  p, p' by the product rule = (add, mul, fma) per factor          4 c
+#   table log 20, reciprocal (v_rcp_f64 + two Newton steps) 9, table exp 20
+FLOPS_LOG, FLOPS_RCP, FLOPS_EXP = 20, 9, 20
+
+
+def _item_stats(counts, ncol):
+    """(number of non-zero cells, sum of min(c, 24) over them) of the first ncol columns: the work items of the DM kernels."""
+    c = counts[:, :ncol]
+    nz = c != 0
+    return int(nz.sum()), int(torch.clamp(c, max=24).to(torch.int64).sum())
+
+
+def flops_ref_items(train, ref):
+    """dm_ref_items_kernel: only the items of contexts WITH reference counts are records (the others are a histogram):
+    per record  alpha from (r_b, R): rcp + 2 fma = 13;  D, P: 4 c + log + rcp + mul = 4 c + 30;  four accumulators: 10."""
+    has_ref = (ref[:, :4] != 0).any(dim=1)
+    items, csum = _item_stats(train[has_ref], 4)
+    return items * (13 + 30 + 10) + 4 * csum
+
+
+def flops_linear(train, lag):
+    """dm_linear_plan_kernel per LIVE context: softmax numerators as products of ng group rows 4 (ng - 1), normalisation 4 + rcp + 4,
+    backward w / s / g = 5 + 5 + 8, its share of the wave reductions ~10;  per item: x = f u + eps 2, D / P 4 c + 30, q, -f q, sums 7."""
+    ng = (max(lag - 3, 0) + 1) // 2 + 1
+    live = int((train != 0).any(dim=1).sum())
+    items, csum = _item_stats(train, 5)
+    return live * (4 * (ng - 1) + 8 + FLOPS_RCP + 18 + 10) + items * (2 + 30 + 7) + 4 * csum
+
+
+def flops_eval(test, n_h=1, n_van=3):
+    """eval_plan_kernel<1,4> (1 h + AR + 3 van_reg) per row with held-out counts: AR arg-max 13, BEAR concentrations + arg-max
+    10 + 5 + 13, -D(A, n) 4 n + log, vanilla table differences 2 each;  per held-out cell: AR c log(f + eps) log + 2, BEAR
+    x + D 3 + 4 c + log, vanilla 2 each.  (The tie noise is integer hashing + fp32 transcendentals: not counted.)"""
+    rows = int((test != 0).any(dim=1).sum())
+    cells, csum = _item_stats(test, 5)
+    nsum = int(torch.clamp(test.to(torch.int64).sum(dim=1), max=24).sum())
+    return (rows * (13 + n_h * (28 + FLOPS_LOG) + 2 * n_van) + n_h * 4 * nsum
+            + cells * (FLOPS_LOG + 2 + n_h * (3 + FLOPS_LOG) + 2 * n_van) + n_h * 4 * csum)
+
+
+def flops_cnn(lag, fw, nf=30, l1=16):
+    """(forward, backward) per context of make_ar_func_cnn (ar_funcs.py:49-99) at P = lag - fw + 1 positions: conv over a one-hot
+    input = fw nf adds, layer norm over nf ~5 nf + rsqrt, elu nf exps, tensordot nf l1 fma;  head: layer norm l1, elu, l1 x 5 fma,
+    softmax.  Backward = the gradient of every one of those products (2x) + the recomputed forward of a position (1x)."""
+    pos = lag - fw + 1
+    per_pos = fw * nf + 5 * nf + FLOPS_RCP + nf * FLOPS_EXP + 2 * nf * l1
+    head = 5 * l1 + FLOPS_RCP + l1 * FLOPS_EXP + 2 * l1 * 5 + 5 * FLOPS_EXP + FLOPS_RCP + 5
+    fwd = pos * per_pos + head
+    return fwd, 3 * fwd
+
+
+def fp64_roofline(flops, ms, per="launch"):
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"bound": "fp64 VALU (instruction-bound)", "useful_fp64_flops_per_%s" % per: flops, "achieved_TFLOPs": tf,
+            "peak_TFLOPs": FP64_PEAK_TFLOPS, "frac_of_fp64_peak": tf / FP64_PEAK_TFLOPS}
 
 
 def parse_args():
@@ -256,6 +315,7 @@ def main():
         del packed
         extra["linear_head_fused_step"] = {"lag": lag, "kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3),
                                            "kernel_ms_rows_in_random_order": ms_shuffled,
+                                           "roofline": fp64_roofline(flops_linear(t["train"], lag), ms),
                                            "note": "forward + ELBO + d/dh + d/dmat from 8-byte context words, rows in k-mer order "
                                                    "(as bear_net.train uploads a batch)"}
         # BASELINE configs[4]: the convolutional AR function, forward + DM step with gradient rows + backward
@@ -296,7 +356,12 @@ def main():
         extra["linear_head_fused_step"]["kernel_ms_as_bear_net_train_holds_the_batch"] = lin_k_ms
         kept_frac = keep.numel() / n
         del keep, tr_kept, packed_kept, plan_kept, bufs_kept, lin_kept
+        cnn_f, cnn_b = flops_cnn(lag, fw)
         extra["cnn_head"] = {"lag": lag, "filter_width": fw, "forward_ms": f_ms, "backward_ms": b_ms,
+                             "roofline_forward_rows_in_kmer_order": fp64_roofline(cnn_f * n, fs_ms),
+                             "roofline_backward_rows_in_kmer_order": fp64_roofline(cnn_b * n, bs_ms),
+                             "roofline_forward_rows_in_random_order": fp64_roofline(cnn_f * n, f_ms),
+                             "roofline_backward_rows_in_random_order": fp64_roofline(cnn_b * n, b_ms),
                              "forward_ms_rows_in_kmer_order": fs_ms, "backward_ms_rows_in_kmer_order": bs_ms,
                              "all_rows_step_ms": f_ms + b_ms + extra["net_with_gradient_rows"]["kernel_ms"],
                              "train_step_ms": s_ms, "train_step_ms_rows_in_random_order": s_ms_random,
@@ -329,6 +394,7 @@ def main():
                                        "contexts_per_s": m / (ms * 1e-3), "achieved_GBps": m * 80 / (ms * 1e-3) / 1e9,
                                        "frac_of_hbm_peak": m * 80 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                        "contexts_with_heldout_counts": keep_t.numel() / m,
+                                       "roofline": fp64_roofline(flops_eval(test), ms),
                                        "compacted_equals_all_rows": same,
                                        "kernel_ms_all_rows_resident": ms_all,
                                        "plan_bytes_per_context": eplan_k.nbytes / m,
@@ -355,6 +421,19 @@ def main():
     achieved = n * bpc / (k_ms * 1e-3) / 1e9  # per-GPU algorithmic GB/s of the dominant kernel
 
     line = None
+    if rank == 0 and extra:
+        # vector-ALU utilisation of the instruction-bound kernels as the SQ counters of the committed profile saw it (not this run)
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+            src = "profiles/traffic_latest.json (%s): SQ_ACTIVE_INST_VALU / (8 SQ_BUSY_CYCLES), rocprofv3 --pmc pass of this command, not this run" % prof.get("tag", "?")
+            for entry, key in (("linear_head_fused_step", "linear_head"), ("heldout_evaluation", "heldout_eval")):
+                if "valu_busy_frac" in prof.get(key, {}) and "roofline" in extra.get(entry, {}):
+                    extra[entry]["roofline"].update(valu_busy_frac_profiled=prof[key]["valu_busy_frac"], valu_source=src)
+            for which, key in (("forward", "cnn_forward"), ("backward", "cnn_backward")):
+                if "valu_busy_frac" in prof.get(key, {}):
+                    extra["cnn_head"]["roofline_%s_rows_in_kmer_order" % which].update(valu_busy_frac_profiled_all_launches=prof[key]["valu_busy_frac"], valu_source=src)
+        except Exception:
+            pass
     if rank == 0:
         # HBM bytes per launch as the PMC counters saw them (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, separate rocprofv3 --pmc
         # passes of this command, scripts/profile_round.sh): NOT measured in this run -- read from the committed profile
@@ -429,14 +508,20 @@ def main():
                 other: {
                     "contexts_per_s": total / (o_elapsed / max(5, args.steps // 5)),
                     "kernel_ms": o_k_ms,
-                    "algorithmic_GBps": n * BYTES_PER_CONTEXT[other] / (o_k_ms * 1e-3) / 1e9,
-                    "algorithmic_frac": n * BYTES_PER_CONTEXT[other] / (o_k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    **({"algorithmic_GBps": n * BYTES_PER_CONTEXT[other] / (o_k_ms * 1e-3) / 1e9,
+                        "algorithmic_frac": n * BYTES_PER_CONTEXT[other] / (o_k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS} if other == "net" else
+                       # the reference-aware plan reads no count rows at all: SURVEY 8d's 40 B per context is not what bounds it
+                       {"roofline": {**fp64_roofline(flops_ref_items(t["train"], t["ref"]), o_k_ms),
+                                     **({"valu_busy_frac_profiled": json.load(open(tpath)).get("ref", {}).get("valu_busy_frac")}
+                                        if os.path.exists(tpath) else {})},
+                        "not_a_roofline_credited_GBps_at_40_B_per_context": n * 40 / (o_k_ms * 1e-3) / 1e9}),
                     "moved_bytes_per_context": other_moved / n,
                     "moved_GBps": other_moved / (o_k_ms * 1e-3) / 1e9,
                     "moved_bytes_source": other_moved_source,
-                    "note": "credited with SURVEY 8d's algorithmic bytes; a plan holds the constant count columns in sorted sparse "
-                            "form, so fewer bytes move (mode R with the reference-aware plan: no row data at all, only the "
-                            "plan's item records) and the algorithmic figure can exceed the HBM peak -- moved_GBps is the bus rate",
+                    "note": "mode R on the reference-aware plan (bear_plan_create_ref) streams only the item records of contexts WITH "
+                            "reference counts (3.3 B per context; the others are a histogram): instruction-bound, so its roofline is the "
+                            "fp64 rate on the useful flops of those records, and moved_GBps is the bus rate; SURVEY 8d's 40 B per "
+                            "context applies to the streaming form (also.ref_streaming_reference_rows)",
                 },
                 "net_prior_normalized_asserted": None if norm_ms is None else {
                     "kernel_ms": norm_ms, "contexts_per_s_per_gpu": n / (norm_ms * 1e-3)},

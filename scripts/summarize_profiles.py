@@ -68,9 +68,20 @@ for kind in ("fetch", "write", "sq"):
                 traffic.setdefault(name, {})["fetch_bytes_per_launch"] = sum(x) / len(x) * 1024 * 2
             if c == "WRITE_SIZE":
                 traffic.setdefault(name, {})["write_bytes_per_launch"] = sum(x) / len(x) * 1024
+    if kind == "sq":
+        # SQ_BUSY_CYCLES sums the 32 shader engines, SQ_ACTIVE_INST_VALU counts quad-cycles over all 1024 SIMDs:
+        # fraction of the kernel's cycles a SIMD spends issuing vector-ALU instructions = ACTIVE_VALU * 4 / (BUSY / 32 * 1024)
+        for k, v in agg.items():
+            if not any(x in k for x in ("plan_kernel", "plan_grad_kernel", "eval_", "cnn_", "items_kernel")): continue
+            mean = {c: sum(x) / len(x) for c, x in v.items()}
+            if mean.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in mean:
+                d = traffic.setdefault(kernel_key(k), {})
+                d["valu_busy_frac"] = mean["SQ_ACTIVE_INST_VALU"] / (8.0 * mean["SQ_BUSY_CYCLES"])
+                d["valu_wave_instructions_per_launch"] = mean.get("SQ_INSTS_VALU")
     out_md.append("")
 for name, d in list(traffic.items()):
-    d["bytes_per_launch"] = d.get("fetch_bytes_per_launch", 0) + d.get("write_bytes_per_launch", 0)
+    if "fetch_bytes_per_launch" in d or "write_bytes_per_launch" in d:
+        d["bytes_per_launch"] = d.get("fetch_bytes_per_launch", 0) + d.get("write_bytes_per_launch", 0)
     # bench.py defaults (--contexts 1e8; the evaluation extra runs on the first 2e7); bench.py scales linearly for other sizes
     d["contexts_per_launch"] = 20000000 if name.startswith("heldout_eval") else 100000000
 if traffic:
