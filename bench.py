@@ -579,9 +579,14 @@ def cpu_baseline(t, prior, workload, params, result):
         _, want = run(n)
         k = want.size
         rel = float(abs(result[0] - want[0]) / abs(want[0]))
-        scale = float(np.abs(want[1:]).max() + abs(want[0]) * 1e-3)
-        check = {"contexts": n, "elbo_rel_err": rel, "grad_abs_err_over_scale": float(np.abs(result[1:k] - want[1:]).max() / scale),
-                 "note": "output of the timed launch vs oracle/bear_oracle.c on the whole table"}
+        # every gradient against ITS OWN L1 mass (the sum of the absolute values of its terms, oracle/bear_oracle.c) and its own value
+        mass = np.array([co.dm_prior_mass(tr, other, h_s, nthreads=cores)]) if workload == "net" else \
+            co.dm_ref_mass(tr, other, h_s, tau_s, nu_s, nthreads=cores)
+        err = np.abs(result[1:k] - want[1:])
+        check = {"contexts": n, "elbo_rel_err": rel, "grad_abs_err_over_l1_mass": float((err / mass).max()),
+                 "grad_rel_err": float((err / np.abs(want[1:])).max()),
+                 "note": "output of the timed launch vs oracle/bear_oracle.c on the whole table; a gradient's L1 mass = the sum of the "
+                         "absolute values of the per-row terms it is the sum of"}
     return base, rel, check
 
 

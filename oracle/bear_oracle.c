@@ -197,3 +197,82 @@ void oracle_dm_ref_f64(const uint32_t *train, const uint32_t *ref, uint64_t n_ro
   }
   free(part);
 }
+
+/*
+ * L1 MASS of the gradients above: the sum of the absolute values of the terms each gradient is the sum of, at the finest
+ * granularity this file has (per row and letter, the item part psi(a+c) - psi(a) and the context part psi(A+n) - psi(A)
+ * counted separately: they cancel).  The parity tests bound a gradient's error by a multiple of ITS OWN mass -- the scale
+ * rounding errors of a sum live on -- instead of borrowing the ELBO's magnitude.  mass[0] = d/dh_signed; the reference form
+ * also mass[1] = d/dtau_signed, mass[2] = d/dnet_weight_signed.  BEAR mode only for d/dh (AR mode has no h gradient).
+ */
+void oracle_dm_prior_mass_f64(const uint32_t *counts, const double *prior, uint64_t n_rows, double h_signed, double eps,
+                              double *mass, int nthreads) {
+  const int W = 5;
+  const double h = exp(h_signed);
+  if (nthreads < 1) nthreads = 1;
+  double m = 0.0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static) reduction(+ : m)
+#endif
+  for (int64_t i = 0; i < (int64_t)n_rows; ++i) {
+    const double *f = prior + (size_t)i * W;
+    double A = 0.0, n = 0.0;
+    for (int b = 0; b < W; ++b) {
+      A += f[b] / h + eps;
+      n += (double)counts[(size_t)i * W + b];
+    }
+    const double gn = digamma(A + n) - digamma(A);
+    for (int b = 0; b < W; ++b) {
+      const double a = f[b] / h + eps, c = (double)counts[(size_t)i * W + b];
+      m += (fabs(digamma(a + c) - digamma(a)) + fabs(gn)) * fabs(f[b] / h);
+    }
+  }
+  mass[0] = m;
+}
+
+void oracle_dm_ref_mass_f64(const uint32_t *train, const uint32_t *ref, uint64_t n_rows, double h_signed, double tau_signed,
+                            double nu_signed, double eps, int train_ar, double *mass, int nthreads) {
+  const int W = 5;
+  const double h = exp(h_signed), tau = exp(tau_signed), nw = exp(nu_signed), E = exp(-tau);
+  if (nthreads < 1) nthreads = 1;
+  double m0 = 0.0, m1 = 0.0, m2 = 0.0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static) reduction(+ : m0, m1, m2)
+#endif
+  for (int64_t i = 0; i < (int64_t)n_rows; ++i) {
+    double c[5], r[5], f[5], dft[5], dfn[5];
+    double R = 0.0, A = 0.0, n = 0.0;
+    for (int b = 0; b < W; ++b) {
+      c[b] = (double)train[(size_t)i * W + b];
+      r[b] = (b < W - 1) ? ((double)ref[(size_t)i * W + b] + eps) : 0.0;
+      R += r[b];
+    }
+    for (int b = 0; b < W; ++b) {
+      const double sh = (b < W - 1) ? 1.0 : 0.0, gnet = (b < W - 1) ? 0.0 : 1.0, norm = r[b] / R;
+      const double base = 0.25 * sh + E * (norm - 0.25 * sh);
+      f[b] = (nw * gnet + base) / (nw + 1.0);
+      /* magnitudes of the terms INSIDE df/dtau and df/dnu as well: norm - 1/4 and gnet - f cancel (exactly, for a context
+         without reference counts), and what is left of them in floating point scales with the parts, not with the difference */
+      dft[b] = (tau * E) * (fabs(norm) + 0.25 * sh) / (nw + 1.0);
+      dfn[b] = nw * (fabs(gnet) + fabs(f[b])) / (nw + 1.0);
+      A += f[b] / h + eps;
+      n += c[b];
+    }
+    const double gn = train_ar ? 0.0 : digamma(A + n) - digamma(A);
+    for (int b = 0; b < W; ++b) {
+      double q;      /* |dLL/df_b|, item and context part apart */
+      if (train_ar) {
+        q = c[b] / (f[b] + eps);
+      } else {
+        const double a = f[b] / h + eps;
+        q = (fabs(digamma(a + c[b]) - digamma(a)) + fabs(gn)) / h;
+        m0 += q * fabs(f[b]);
+      }
+      m1 += q * fabs(dft[b]);
+      m2 += q * fabs(dfn[b]);
+    }
+  }
+  mass[0] = m0;
+  mass[1] = m1;
+  mass[2] = m2;
+}

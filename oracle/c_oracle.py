@@ -29,6 +29,11 @@ def lib():
         L.oracle_dm_ref_f64.argtypes = [u32p, u32p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double,
                                         ctypes.c_double, ctypes.c_double, ctypes.c_int, f64p, ctypes.c_int]
         L.oracle_dm_ref_f64.restype = None
+        L.oracle_dm_prior_mass_f64.argtypes = [u32p, f64p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, f64p, ctypes.c_int]
+        L.oracle_dm_prior_mass_f64.restype = None
+        L.oracle_dm_ref_mass_f64.argtypes = [u32p, u32p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                             ctypes.c_double, ctypes.c_int, f64p, ctypes.c_int]
+        L.oracle_dm_ref_mass_f64.restype = None
         _lib = L
     return _lib
 
@@ -66,4 +71,23 @@ def dm_ref(train, ref, h_signed, tau_signed, nu_signed, eps=1e-7, train_ar=False
     assert c.shape == r.shape and c.shape[-1] == 5
     out, op = _f64(np.zeros(4))
     lib().oracle_dm_ref_f64(cp, rp, c.shape[0], h_signed, tau_signed, nu_signed, eps, int(train_ar), op, nthreads)
+    return out
+
+
+def dm_prior_mass(counts, prior, h_signed, eps=1e-7, nthreads=1):
+    """L1 mass of d sum LL / d h_signed (BEAR mode): the sum of the absolute values of its per-row-and-letter terms -- the scale
+    the parity tests bound that gradient's error by."""
+    c, cp = _u32(counts)
+    f, fp = _f64(prior)
+    out, op = _f64(np.zeros(1))
+    lib().oracle_dm_prior_mass_f64(cp, fp, c.shape[0], h_signed, eps, op, nthreads)
+    return float(out[0])
+
+
+def dm_ref_mass(train, ref, h_signed, tau_signed, nu_signed, eps=1e-7, train_ar=False, nthreads=1):
+    """L1 masses [d/dh_signed, d/dtau_signed, d/dnet_weight_signed] of the bear_ref gradients."""
+    c, cp = _u32(train)
+    r, rp = _u32(ref)
+    out, op = _f64(np.zeros(3))
+    lib().oracle_dm_ref_mass_f64(cp, rp, c.shape[0], h_signed, tau_signed, nu_signed, eps, int(train_ar), op, nthreads)
     return out

@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path (through the C ABI) against the oracle on the same seeded
 inputs.  Tolerance: north_star asks 1e-9 relative on the fp64 ELBO; we hold 1e-11 on the
-ELBO and 1e-9 (relative to the L1 mass of the gradient terms) on gradients."""
+ELBO, 2e-13 of a scalar gradient's own L1 mass (MASS_RTOL below) and 1e-9 of the largest entry on gradient rows."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -12,7 +13,11 @@ from util import dense_table, edge_table, prior_rows, sparse_table
 pytestmark = pytest.mark.gpu
 
 ELBO_RTOL = 1e-11
-GRAD_RTOL = 1e-9
+GRAD_RTOL = 1e-9       # gradient ROWS (per context), relative to the largest entry
+# The scalar gradients (d/dh, d/dtau, d/dnet_weight) are sums of terms of both signs: their error is bounded by a multiple of
+# THEIR OWN L1 mass -- the sum of the absolute values of those terms, from the C oracle (c_oracle.dm_*_mass) -- and of nothing
+# else (round 2 borrowed 1e-3 |ELBO| as a stand-in for that mass).  Observed: every case passes at 1e-13, some fail at 3e-14.
+MASS_RTOL = float(os.environ.get("BEAR_TEST_MASS_RTOL", "2e-13"))
 
 
 @pytest.fixture(scope="module")
@@ -32,6 +37,18 @@ def _to_dev(a, dev):
 def _close(got, want, rtol, scale=None):
     scale = abs(want) if scale is None else scale
     assert abs(got - want) <= rtol * max(scale, 1e-300), (got, want, abs(got - want) / max(scale, 1e-300))
+
+
+def _mass_close(got, want, mass, what=None):
+    # + 1e-14 absolute: a table whose terms all vanish exactly (no counts) leaves ~1e-17 per context (the table log of exactly 1.0
+    # is ~1e-16, not 0)
+    assert abs(got - want) <= MASS_RTOL * mass + 1e-14, (what, got, want, abs(got - want) / max(mass, 1e-300))
+
+
+def _ref_grads_close(got, want, tr, rf, args, train_ar=False, what=None):
+    mass = co.dm_ref_mass(tr, rf, *args, train_ar=train_ar, nthreads=4)
+    for k in range(1, 4):
+        _mass_close(got[k], want[k], mass[k - 1], (what, k))
 
 
 def _grad_scale_ref(tr, rf, args):
@@ -64,9 +81,7 @@ def test_dm_ref_parity(case, train_ar, dev, ysd1):
         want = co.dm_ref(tr, rf, *args, train_ar=train_ar, nthreads=4)
         got = kernels.dm_ref(d_tr, d_rf, *args, train_ar=train_ar).cpu().numpy()
         _close(got[0], want[0], ELBO_RTOL)
-        scale = np.abs(want[1:]).max() + abs(want[0]) * 1e-3
-        for k in range(1, 4):
-            _close(got[k], want[k], GRAD_RTOL, scale)
+        _ref_grads_close(got, want, tr, rf, args, train_ar, (case, args))
 
 
 def test_dm_ref_known_answers(dev, ysd1):
@@ -96,7 +111,10 @@ def test_dm_prior_parity(case, train_ar, dev, ysd1):
         out, g = kernels.dm_prior(_to_dev(tr, dev), _to_dev(f, dev), h_s, train_ar=train_ar, want_grad=True)
         out, g = out.cpu().numpy(), g.cpu().numpy()
         _close(out[0], want[0], ELBO_RTOL)
-        _close(out[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
+        if train_ar:
+            assert out[1] == 0.0 and want[1] == 0.0       # no h in the multinomial
+        else:
+            _mass_close(out[1], want[1], co.dm_prior_mass(tr, f, h_s, nthreads=4), (case, seed))
         assert np.allclose(g, wg, rtol=1e-9, atol=1e-9 * np.abs(wg).max())
         out2, g2 = kernels.dm_prior(_to_dev(tr, dev), _to_dev(f, dev), h_s, train_ar=train_ar, want_grad=False)
         assert g2 is None
@@ -244,30 +262,29 @@ def test_planned_kernels_parity(case, dev, ysd1):
         want = co.dm_ref(tr, rf, *args, nthreads=4)
         got = kernels.dm_ref_planned(plan_r, d_rf, *args).cpu().numpy()
         _close(got[0], want[0], ELBO_RTOL)
-        scale = np.abs(want[1:]).max() + abs(want[0]) * 1e-3
-        for k in range(1, 4):
-            _close(got[k], want[k], GRAD_RTOL, scale)
-        assert np.allclose(got, kernels.dm_ref(d_tr, d_rf, *args).cpu().numpy(), rtol=1e-11, atol=1e-9 * scale)
+        _ref_grads_close(got, want, tr, rf, args, False, (case, args))
+        _ref_grads_close(kernels.dm_ref(d_tr, d_rf, *args).cpu().numpy(), got, tr, rf, args, False, (case, args, "unplanned"))
     n = len(tr)
     for seed, h_s, conc in [(1, 0.0, 1.0), (2, -3.0, 0.2), (3, 1.7, 5.0)]:
         f = prior_rows(n, seed, conc)
         if seed == 3:
             f = f * np.linspace(0.5, 3.0, n)[:, None]  # rows that do not sum to one: every context owns its A
         want, _ = co.dm_prior(tr, f, h_s, nthreads=4)
+        mass_h = co.dm_prior_mass(tr, f, h_s, nthreads=4)
         got = kernels.dm_prior_planned(plan_n, _to_dev(f, dev), h_s).cpu().numpy()
         _close(got[0], want[0], ELBO_RTOL)
-        _close(got[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
+        _mass_close(got[1], want[1], mass_h, (case, seed))
         wantg = co.dm_prior(tr, f, h_s, want_grad=True, nthreads=4)[1]
         for norm in ([False, True] if seed != 3 else [False]):   # planned kernel that also writes the gradient rows
             got, g = kernels.dm_prior_planned(plan_n, _to_dev(f, dev), h_s, normalized=norm, want_grad=True)
             got, g = got.cpu().numpy(), g.cpu().numpy()
             _close(got[0], want[0], ELBO_RTOL)
-            _close(got[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
+            _mass_close(got[1], want[1], mass_h, (case, seed, norm))
             assert np.allclose(g, wantg, rtol=1e-9, atol=1e-9 * np.abs(wantg).max()), (case, seed, np.abs(g - wantg).max())
         if seed != 3:  # rows sum to one: the caller may assert it (context terms from the plan's histogram)
             got = kernels.dm_prior_planned(plan_n, _to_dev(f, dev), h_s, normalized=True).cpu().numpy()
             _close(got[0], want[0], ELBO_RTOL)
-            _close(got[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
+            _mass_close(got[1], want[1], mass_h, (case, seed, "normalized"))
 
 
 @pytest.mark.parametrize("case", ["ysd1", "sparse", "sparse_hot", "dense", "edge", "one_row"])
@@ -286,9 +303,7 @@ def test_planned_ar_mode_parity(case, dev, ysd1):
         got = kernels.dm_ref_planned(plan_r, d_rf, *args, train_ar=True).cpu().numpy()
         _close(got[0], want[0], ELBO_RTOL)
         assert got[1] == 0.0 and want[1] == 0.0          # no h in the multinomial
-        scale = np.abs(want[2:]).max() + abs(want[0]) * 1e-3
-        for k in (2, 3):
-            _close(got[k], want[k], GRAD_RTOL, scale)
+        _ref_grads_close(got, want, tr, rf, args, True, (case, args))
     n = len(tr)
     for seed, conc in [(1, 1.0), (2, 0.2), (3, 5.0)]:
         f = prior_rows(n, seed, conc)
@@ -369,7 +384,8 @@ def _linear_oracle(tr, codes, mat, h_s, train_ar):
     f = o.ar_func_linear(onehot, mat)
     out, G = co.dm_prior(tr, f, h_s, train_ar=train_ar, want_grad=True, nthreads=4)
     gz = f * (G - (f * G).sum(-1, keepdims=True))
-    return out, np.einsum("njk,nl->jkl", onehot, gz)
+    mass_h = 0.0 if train_ar else co.dm_prior_mass(tr, f, h_s, nthreads=4)
+    return np.append(out, mass_h), np.einsum("njk,nl->jkl", onehot, gz)
 
 
 @pytest.mark.parametrize("case", ["sparse", "sparse_hot", "dense", "edge", "ysd1"])
@@ -399,7 +415,7 @@ def test_fused_linear_head_parity(case, lag, dev, ysd1):
         got, g = kernels.dm_linear(plan, packed, d_mat, h_s, train_ar=ar)
         got, g = got.cpu().numpy(), g.cpu().numpy()
         _close(got[0], want[0], ELBO_RTOL)
-        _close(got[1], want[1], GRAD_RTOL, abs(want[1]) + abs(want[0]) * 1e-3)
+        _mass_close(got[1], want[1], want[2], (case, lag, h_s, ar))        # want[2]: the L1 mass of d/dh (0 in AR mode: both are 0)
         assert np.allclose(g, wantg, rtol=1e-9, atol=1e-9 * np.abs(wantg).max()), (case, lag, h_s, ar, np.abs(g - wantg).max())
 
 
@@ -584,10 +600,11 @@ def test_planned_randomized_shapes(dev):
         gn = kernels.dm_prior_planned(pn, d_f, h).cpu().numpy()
         gg, g = kernels.dm_prior_planned(pn, d_f, h, want_grad=True)
         assert abs(gr[0] - wr[0]) <= ELBO_RTOL * abs(wr[0]) + 1e-300, (it, n, kind)
-        assert np.all(np.abs(gr[1:] - wr[1:]) <= GRAD_RTOL * (np.abs(wr[1:]).max() + abs(wr[0]) * 1e-3 + 1e-300)), (it, n, kind)
+        _ref_grads_close(gr, wr, tr, rf, args, False, (it, n, kind))
+        mass_h = co.dm_prior_mass(tr, f, h, nthreads=4)
         for got in (gn, gg.cpu().numpy()):
             assert abs(got[0] - wn[0]) <= ELBO_RTOL * abs(wn[0]) + 1e-300, (it, n, kind)
-            assert abs(got[1] - wn[1]) <= GRAD_RTOL * (abs(wn[1]) + abs(wn[0]) * 1e-3 + 1e-300), (it, n, kind)
+            _mass_close(got[1], wn[1], mass_h, (it, n, kind))
         assert np.allclose(g.cpu().numpy(), wg, rtol=1e-9, atol=1e-9 * (np.abs(wg).max() + 1e-300)), (it, n, kind)
 
 
@@ -757,11 +774,10 @@ def test_reference_aware_plan_parity(case, train_ar, dev, ysd1):
         want = co.dm_ref(tr, rf, *args, train_ar=train_ar, nthreads=4)
         got = kernels.dm_ref_planned(plan, d_rf, *args, train_ar=train_ar).cpu().numpy()
         _close(got[0], want[0], ELBO_RTOL)
-        scale = np.abs(want[1:]).max() + abs(want[0]) * 1e-3
-        for k in range(1, 4):
-            _close(got[k], want[k], GRAD_RTOL, scale)
+        _ref_grads_close(got, want, tr, rf, args, train_ar, (case, args))
         old = kernels.dm_ref_planned(stream, d_rf, *args, train_ar=train_ar).cpu().numpy()
-        assert np.allclose(got, old, rtol=1e-11, atol=1e-9 * scale)
+        _close(old[0], got[0], ELBO_RTOL)
+        _ref_grads_close(old, got, tr, rf, args, train_ar, (case, args, "streaming plan"))
     other = d_rf.clone()
     with pytest.raises(Exception):      # the plan is bound to the reference buffer it was built from
         kernels.dm_ref_planned(plan, other, *PARAMS[0])
