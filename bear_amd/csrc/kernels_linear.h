@@ -6,7 +6,7 @@
 //
 // Contexts arrive as one 64-bit word each (bear_linear_index_u64: the k-mer as row numbers of the letter-group tables below),
 // 8 bytes per context instead of the 40-byte prior row, and nothing is written per context.  Per tile of the plan, two barriers:
-//   A  one thread per LIVE context (entries tid, tid + 1024 of the plan's per-tile list of contexts that hold counts; ~30% of
+//   A  one thread per LIVE context (entries tid, tid + 896 of the plan's per-tile list of contexts that hold counts; ~30% of
 //      the rows of a count table hold none in the training column and are never looked at): logits from GROUP tables -- pairs
 //      of letters T[g][a, a'] = mat[2g][a] + mat[2g+1][a'] over the leading letters and one triple over the last three, rows of
 //      four doubles relative to the fifth letter's logit and in units of ln2/128 (6 table rows of 32 bytes for lag 13, read
@@ -301,7 +301,16 @@ __device__ __forceinline__ unsigned long long lin_first_lane(unsigned long long 
   return ((unsigned long long)hi << 32) | lo;
 }
 
-constexpr int LIN_RPT = (PLN_RMAX + PLN_THREADS - 1) / PLN_THREADS;   // contexts of a tile per thread
+// The waves that issue a tile's DMA (the last LIN_DMA_WAVES of the block) take no rows in phases A / C: with HBM busy every DMA
+// instruction parks its wave for ~700 clocks, a tile is ~25 of them, and a wave that also had its share of rows reached the
+// phase barrier ~4000 clocks (a fifth of a tile's time) after the others.  Rows go to the first LIN_ROW_THREADS threads.
+#ifndef LIN_DMA_WAVES
+#define LIN_DMA_WAVES 2
+#endif
+#ifndef LIN_ROW_THREADS
+#define LIN_ROW_THREADS (PLN_THREADS - 64 * LIN_DMA_WAVES)
+#endif
+constexpr int LIN_RPT = (PLN_RMAX + LIN_ROW_THREADS - 1) / LIN_ROW_THREADS;   // contexts of a tile per row thread
 
 // ---- phase A over the tile's live contexts (entry tid + 1024 k of the plan's list): softmax rows into fA (kept until phase C
 // of the same tile) and, by lin_phase_a_store, into LDS for the items.  Contexts without counts are never looked at: nothing
@@ -316,8 +325,8 @@ __device__ __forceinline__ uint32_t lin_phase_a(pln_lds_lin &S, const lin_buf &B
   asm volatile("" : "+v"(tid));    // as in phase C: nothing derived from the thread number is worth a register across the tile loop
 #pragma unroll
   for (int k = 0; k < LIN_RPT; ++k) {
-    const uint32_t j = tid + PLN_THREADS * k;
-    if (j < n_live) {
+    const uint32_t j = tid + LIN_ROW_THREADS * k;
+    if (tid < LIN_ROW_THREADS && j < n_live) {
       const uint32_t row = B.live[1 + j];
       rows = k == 0 ? (rows & 0xffff0000u) | row : (rows & 0xffffu) | (row << 16);
       cA[k] = B.codes[row];
@@ -352,8 +361,8 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uin
 #endif
 #pragma unroll
   for (int k = 0; k < LIN_RPT; ++k) {
-    const uint32_t j0 = (tid & ~63u) + PLN_THREADS * k;      // first of this wave's 64 consecutive list entries
-    if (j0 >= n_live) continue;                              // wave-uniform
+    const uint32_t j0 = (tid & ~63u) + LIN_ROW_THREADS * k;  // first of this wave's 64 consecutive list entries
+    if (tid >= LIN_ROW_THREADS || j0 >= n_live) continue;    // wave-uniform
     // keep LLVM from hoisting every lane-derived value of the ten NG variants out of the tile loop (that spilled 30 registers)
     asm volatile("" : "+v"(lane));
     const bool live = j0 + lane < n_live;
@@ -541,9 +550,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   for (int k = tid; k < n_tab; k += PLN_THREADS) S.T[k] = exp_tables ? exp(S.T[k]) : S.T[k] * LIN_EXP_UNIT;
   __syncthreads();
 
-#ifndef LIN_DMA_WAVES
-#define LIN_DMA_WAVES 2              // waves that issue the tile DMA (the last ones of the block: they never hold a second batch of rows); measured 16 / 8 / 4 / 2 waves: 1.92 / 1.89 / 1.87 / 1.86 ms
-#endif
+  // LIN_DMA_WAVES waves issue the tile DMA (the last ones of the block); measured in round 2, when they also had rows: 16 / 8 / 4 / 2 waves: 1.92 / 1.89 / 1.87 / 1.86 ms
   auto stage = [&](const pln_tile &ti, uint64_t tile, uint32_t b) {
     const uint32_t rows = ti.rows_items >> 16;
     if (rows == 0) return;
