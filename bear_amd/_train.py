@@ -85,12 +85,21 @@ class Uploader:
     everything enqueued so far.  Pageable `.to(device)` copies (round 2) ran at a fraction of the PCIe rate and blocked."""
 
     PIECE = 64 << 20      # bytes per staging buffer
+    _ring = {}            # device index -> (piece bytes, pinned buffers): page-locking 192 MiB takes longer than a small table's
+                          # whole run, so the ring is kept for the process and sized by what has been asked for so far
 
-    def __init__(self, device, n_buffers=3):
+    def __init__(self, device, n_buffers=3, expect_bytes=None):
         self.device = device
         self.consumer = torch.cuda.current_stream(device)     # the stream the uploaded tensors will be used on
         self.stream = torch.cuda.Stream(device)
-        self.bufs = [torch.empty(self.PIECE, dtype=torch.uint8, pin_memory=True) for _ in range(n_buffers)]
+        piece = self.PIECE if expect_bytes is None else max(1 << 16, min(self.PIECE, -(-int(expect_bytes) // 4096) * 4096))
+        key = (device.index, n_buffers)
+        have = Uploader._ring.get(key)
+        if have is None or have[0] < piece:
+            have = (piece, [torch.empty(piece, dtype=torch.uint8, pin_memory=True) for _ in range(n_buffers)])
+            Uploader._ring[key] = have
+        self.piece = min(have[0], self.PIECE)
+        self.bufs = have[1]
         self.views = [b.numpy() for b in self.bufs]
         self.free_at = [None] * n_buffers          # event after which a staging buffer may be overwritten
         self.k = 0
@@ -109,8 +118,8 @@ class Uploader:
             return dst
         src = array.reshape(-1).view(np.uint8)
         dst_bytes = dst.view(-1).view(torch.uint8)
-        for off in range(0, nbytes, self.PIECE):
-            n = min(self.PIECE, nbytes - off)
+        for off in range(0, nbytes, self.piece):
+            n = min(self.piece, nbytes - off)
             b = self.k % len(self.bufs)
             if self.free_at[b] is not None:
                 self.free_at[b].synchronize()
@@ -187,7 +196,8 @@ class ResidentBatches:
         if not on_dev:
             hbm_budget_check(data, len(columns), want_codes, device, rows=sum(g1 - g0 for _, (g0, g1, _) in pieces),
                              per_row_extra=per_row_extra)
-        up = None if on_dev else Uploader(device)
+        up = None if on_dev else Uploader(device, expect_bytes=max(
+            [(g1 - g0) * 20 for _, (g0, g1, _) in pieces] + [data.local_rows * 20 if data.shuffle_seed is not None else 0, 1]))
         self.upload_bytes = 0
 
         def device_column(col, lo, hi):
