@@ -143,10 +143,13 @@ int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_
 /*
  * One optimizer step with every moving quantity in device memory, in two halves:
  *
- *   bear_*_train_reduce_f64  this rank's shard: kernel constants from theta -> planned kernel(s) -> finalize into
+ *   bear_*_train_reduce_f64  this rank's shard, ONE launch for bear_ref and the linear head (every block derives the kernel
+ *                            constants from theta in its prologue, the last block to finish sums the per-block partials in a
+ *                            fixed order; the cnn step adds its forward / backward launches) into
  *                            packed [dev] double [1 + n_theta] = { sum LL, d sum LL / d theta[0..n_theta) }  (unscaled)
  *   bear_train_apply_f64     tf.keras Adam (beta 0.9 / 0.999, epsilon 1e-7; bear_ref.py:312-313, 346-350) on theta with the
- *                            gradients scale * packed[1..]; loss_buf[step] = -scale * packed[0] (the "elbo" the reference logs)
+ *                            gradients scale * packed[1..]; loss_buf[step] = -scale * packed[0] (the "elbo" the reference logs);
+ *                            one single-block launch (update, step counter, loss record)
  *
  * Nothing synchronises with the host.  One rank enqueues them back to back (bear_*_train_step_f64 below: capturable in a
  * HIP graph and replayed -- the reference traces its step once with tf.function, bear_model/bear_ref.py:207; the bundled
