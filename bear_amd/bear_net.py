@@ -110,7 +110,7 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
     if use_train:
         cols["train"] = ds_loc_train
     # only the contexts with held-out counts are kept resident: nothing else enters any sum (their table rows travel as row_ids)
-    res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test")
+    res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test", per_row_extra=60)   # prior rows + plan
     total = None
     with torch.no_grad():
         for k, e in enumerate(res.batches):

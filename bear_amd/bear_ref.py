@@ -134,7 +134,7 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
     if use_train:
         cols["train"] = ds_loc_train
     # only the contexts with held-out counts are kept resident: nothing else enters any sum (their table rows travel as row_ids)
-    res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test")
+    res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test", per_row_extra=60)   # prior rows + plan
     hv = float(torch.as_tensor(h).item()) if np.ndim(torch.as_tensor(h).detach().cpu().numpy()) == 0 else torch.as_tensor(h).detach().cpu().numpy()
     total = None
     with torch.no_grad():

@@ -278,8 +278,17 @@ def main():
     extra = {}
     if rank == 0 and world == 1:  # the rows of SURVEY 8f built on the same kernels: kernel-only times, 1 GPU
         def timed(fn, reps):
-            fn()
+            """Mean HIP-event time of `fn` over at least `reps` back-to-back calls and at least 5 ms, behind ~20 ms of untimed
+            calls: every entry below follows host-side set-up during which the card clocks down (see settle() above)."""
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            first = max(e0.elapsed_time(e1), 1e-3)
+            for _ in range(min(64, int(20.0 / first))):
+                fn()
+            reps = max(reps, min(256, int(5.0 / first) + 1))
             e0.record()
             for _ in range(reps):
                 fn()
