@@ -747,6 +747,21 @@ def test_eval_plan_full_size_properties(dev):
                              t["train"][lo:lo + m].cpu().numpy().view(np.uint32), rng=o.HashNoise(9, lo, m))
     assert np.isclose(gs[0], want[0], rtol=ELBO_RTOL) and np.isclose(gs[1], want[1], rtol=ELBO_RTOL) and np.allclose(gs[2:5], want[2], rtol=ELBO_RTOL)
     assert gs[5] == want[3] and gs[6] == want[4] and np.array_equal(gs[7:10], want[5]) and gs[10] == want[6]
+    # the batch as evaluation() keeps it since round 3: the contexts with held-out counts only, their table rows as row_ids --
+    # the same sums at full size, accuracies exactly, also when the compacted batch is itself cut into two shards
+    keep = (t["test"] != 0).any(dim=1).nonzero().squeeze(1)
+    assert 0.3 * n < keep.numel() < 0.7 * n
+    te_k, tr_k, f_k, ids = (t["test"][keep].contiguous(), t["train"][keep].contiguous(), f[keep].contiguous(), keep.to(torch.int32))
+    comp = kernels.evaluate_planned(kernels.EvalPlan(te_k, tr_k), f_k, hs, van, noise_seed=9, row_ids=ids).cpu().numpy()
+    assert np.array_equal(comp[5:], got[5:]) and np.allclose(comp[:5], got[:5], rtol=1e-12)
+    half = keep.numel() // 2 // 4 * 4
+    parts = None
+    for a0, a1 in ((0, half), (half, keep.numel())):
+        r = kernels.evaluate_planned(kernels.EvalPlan(te_k[a0:a1].clone(), tr_k[a0:a1].clone()), f_k[a0:a1].clone(), hs, van, noise_seed=9,
+                                     row_ids=ids[a0:a1].clone())
+        parts = r if parts is None else parts + r
+    parts = parts.cpu().numpy()
+    assert np.array_equal(parts[5:], got[5:]) and np.allclose(parts[:5], got[:5], rtol=1e-12)
 
 
 @pytest.mark.parametrize("case", ["ysd1", "sparse", "sparse_hot", "dense", "edge", "one_row", "no_ref", "all_ref"])
