@@ -20,6 +20,7 @@ The other workload is measured too and reported under "also".
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -220,16 +221,19 @@ def main():
                         "untimed, before --warmup" % (group, tol * 100, cap_s)}
 
     def measure(wl, steps, warmup, do_settle=False):
+        gc.collect()         # now, not between the warm-up and the timed steps: the card must not idle there
         settle_info = settle(wl) if do_settle else None
         for _ in range(warmup):
             step(wl)
         evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3 if world > 1 else 2)) for _ in range(steps)]
+        gc.disable()         # no collector pause between two launches of the timed region (the GPU queue is only K steps deep)
         barrier()
         t_start = time.perf_counter()
         for k in range(steps):
             step(wl, evs[k])
         barrier()
         elapsed = time.perf_counter() - t_start
+        gc.enable()
         # kernel-only duration (main kernel + finalize) of every step, HIP events on the launch stream
         per_step = np.array([e[0].elapsed_time(e[1]) for e in evs])
         k_ms = float(per_step.mean())
@@ -278,8 +282,10 @@ def main():
     extra = {}
     if rank == 0 and world == 1:  # the rows of SURVEY 8f built on the same kernels: kernel-only times, 1 GPU
         def timed(fn, reps):
-            """Mean HIP-event time of `fn` over at least `reps` back-to-back calls and at least 5 ms, behind ~20 ms of untimed
-            calls: every entry below follows host-side set-up during which the card clocks down (see settle() above)."""
+            """Median over five or more event-timed groups of back-to-back calls of `fn` (each group at least `reps` / 5 calls and
+            ~1 ms), behind ~20 ms of untimed calls: every entry below follows host-side set-up during which the card clocks down
+            (see settle() above), and a one-off host stall inside a group (a GC pause, an allocator call) must not become the
+            figure -- one default run of round 3 read 1.65 ms for a 0.375 ms kernel that way."""
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn()
@@ -288,13 +294,16 @@ def main():
             first = max(e0.elapsed_time(e1), 1e-3)
             for _ in range(min(64, int(20.0 / first))):
                 fn()
-            reps = max(reps, min(256, int(5.0 / first) + 1))
-            e0.record()
-            for _ in range(reps):
-                fn()
-            e1.record()
+            per_group = max(1, -(-reps // 5), min(64, int(1.0 / first) + 1))
+            n_groups = 5 if first > 5.0 else 7
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_groups)]
+            for a, b in evs:
+                a.record()
+                for _ in range(per_group):
+                    fn()
+                b.record()
             torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps
+            return float(np.median([a.elapsed_time(b) / per_group for a, b in evs]))
         plan_stream = kernels.Plan(t["train"], 4)     # mode R with the reference rows streamed every step (plan from the training counts only)
         ms = timed(lambda: kernels.dm_ref_planned(plan_stream, t["ref"], h_s, tau_s, nu_s), 10)
         extra["ref_streaming_reference_rows"] = {"kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3), "achieved_GBps": n * 40 / (ms * 1e-3) / 1e9,
