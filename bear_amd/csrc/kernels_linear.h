@@ -389,7 +389,7 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uin
       const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)code, (int)last), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(code >> 32), (int)last);
       if (!live) cv = ((unsigned long long)hi << 32) | lo;
     }
-    const double th = lin_row16_sum(lin_quad_letter_sum(g, lane)), tw = lin_wave_sum(th);   // of letter lin_letter(lane)
+    const double tq = lin_quad_letter_sum(g, lane), th = lin_row16_sum(tq), tw = lin_wave_sum(th);   // of letter lin_letter(lane)
     const uint32_t bl = lin_letter(lane);
     // How many LEADING groups does my row of 16 share (l_row), how many the whole wave (l_wave)?  In a sorted table the shared
     // groups are the leading ones; anything else is merely handled one level lower than it could be.  e = my index word xor my
@@ -423,9 +423,18 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uin
     const unsigned long long wave_or = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)whi) << 32) |
                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)wlo);
     const unsigned long long row_or = ((unsigned long long)rhi << 32) | rlo;
+    // ... and my quad: the OR of e over its lanes 1..3
+    const bool quad_first = (lane & 3u) == 0u;
+    uint32_t qlo = quad_first ? 0u : elo, qhi = quad_first ? 0u : ehi;
+    qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2], [2,3,0,1]
+    qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0xB1, 0xf, 0xf, false);
+    qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0x4E, 0xf, 0xf, false);
+    qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0x4E, 0xf, 0xf, false);
+    const unsigned long long quad_or = ((unsigned long long)qhi << 32) | qlo;
     // group of bit position p: p / 6 (the last group is wider: clamp); 43 / 256 ~ 1 / 6 is exact for p < 64
     const uint32_t l_wave = wave_or ? min((uint32_t)(__builtin_ctzll(wave_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG;
     const uint32_t l_row = row_or ? min((uint32_t)(__builtin_ctzll(row_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG;   // >= l_wave
+    const uint32_t l_quad = quad_or ? min((uint32_t)(__builtin_ctzll(quad_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG; // >= l_row
 #if LIN_DBG == 1
     acc[1] += tw * 1e-300 + th * 1e-300 + (double)l_row * 1e-300;
     continue;
@@ -447,11 +456,19 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uin
 #if LIN_DBG == 4
     continue;
 #endif
+    // 2b. the first group a row does NOT share, where my quad still does: in a sorted table a row of 16 that straddles two prefix
+    //     blocks has one such group (the last pair), and per context its adds hit ONE address with eight lanes at a time (LDS
+    //     atomics on one address serialise).  Lane (quad, letter) adds the quad's sum instead; only the quad on the boundary is
+    //     left to step 3.
+    const bool quad_covers = l_row < l_quad && l_row < l_wave + 4u;    // (groups at or beyond l_wave + 4 are step 3's anyway)
+    if (__builtin_amdgcn_ballot_w64(quad_covers)) {
+      if (quad_covers && tq != 0.0) atomicAdd(&S.GT[bl * LIN_GT_PLANE + (lin_off_any(cv, l_row, NG) >> 2)], tq);
+    }
     // 3. one add per context and letter for every group not covered above
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) {
       if ((uint32_t)gq < l_wave) continue;                   // wave-uniform test
-      const bool mine = nz && ((uint32_t)gq >= l_row || (uint32_t)gq >= l_wave + 4u);
+      const bool mine = nz && ((uint32_t)gq >= l_row || (uint32_t)gq >= l_wave + 4u) && !(quad_covers && (uint32_t)gq == l_row);
       if (!__builtin_amdgcn_ballot_w64(mine)) continue;
       if (mine) {
         double *gt = &S.GT[lin_off<NG>(cv, gq) >> 2];
