@@ -468,6 +468,12 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uin
 #pragma unroll
     for (int gq = 0; gq < NG; ++gq) {
       if ((uint32_t)gq < l_wave) continue;                   // wave-uniform test
+#ifdef LIN_SKIP_TRIPLE   // developer build (timing only): what do the triple's per-context adds cost?
+      if (gq == NG - 1) continue;
+#endif
+#ifdef LIN_SKIP_PAIRS3   // developer build (timing only): ... and those of every other group?
+      if (gq != NG - 1) continue;
+#endif
       const bool mine = nz && ((uint32_t)gq >= l_row || (uint32_t)gq >= l_wave + 4u) && !(quad_covers && (uint32_t)gq == l_row);
       if (!__builtin_amdgcn_ballot_w64(mine)) continue;
       if (mine) {
