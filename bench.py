@@ -110,6 +110,9 @@ def parse_args():
                     help="weak: every rank holds --contexts rows; strong: ONE table of --contexts rows split over the ranks "
                          "(north_star's 10^8 table at 1/2/4/8 GPUs)")
     ap.add_argument("--no-settle", action="store_true", help="skip the clock-settle launches in front of the measurement")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="run the N > 1 code path (process group, per-step all-reduce, gathers) although WORLD_SIZE is 1: the only "
+                         "way to exercise the RCCL path of this file on a one-GPU box (tests/test_dist_gpu.py)")
     ap.add_argument("--workload", choices=["net", "ref"], default="net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ingest-rows", type=float, default=None,
@@ -129,8 +132,10 @@ def main():
     dev_index = int(os.environ.get("BEAR_BENCH_DEVICE", local_rank))  # override only for single-GPU smoke tests
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    multi = world > 1 or args.force_collective      # the N > 1 code path
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -175,13 +180,13 @@ def main():
         launch(wl)
         if ev is not None:
             ev[1].record()
-        if world > 1:
+        if multi:
             dist.all_reduce(outs[wl])  # one packed RCCL all-reduce of (ELBO, gradients) per step
             if ev is not None:
                 ev[2].record()         # the collective is ordered into the launch stream: ev[1] -> ev[2] is its latency there
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -225,7 +230,7 @@ def main():
         settle_info = settle(wl) if do_settle else None
         for _ in range(warmup):
             step(wl)
-        evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3 if world > 1 else 2)) for _ in range(steps)]
+        evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3 if multi else 2)) for _ in range(steps)]
         gc.disable()         # no collector pause between two launches of the timed region (the GPU queue is only K steps deep)
         barrier()
         t_start = time.perf_counter()
@@ -239,9 +244,9 @@ def main():
         k_ms = float(per_step.mean())
         stats = {"kernel_ms_min": float(per_step.min()), "kernel_ms_median": float(np.median(per_step)),
                  "kernel_ms_p90": float(np.percentile(per_step, 90)), "kernel_ms_max": float(per_step.max())}
-        ar_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs])) if world > 1 else None
+        ar_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs])) if multi else None
         per_rank = None
-        if world > 1:
+        if multi:
             el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
             elapsed = float(el.item())
@@ -552,7 +557,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -261,6 +261,29 @@ def test_bench_single_rank_line_is_consistent():
     assert 0.5 < c["contexts_with_training_counts"] < 0.9
 
 
+def test_bench_rccl_path_on_a_group_of_one():
+    """bench.py's N > 1 code path on RCCL itself (--force-collective: process group "nccl", one all-reduce per timed step behind
+    the kernel, the MAX / gather collectives of the timing, barrier, teardown) with the one rank a one-GPU box has: the line is
+    complete, the all-reduce is event-timed, and the reduced sums are the kernel's."""
+    from bear_amd import kernels
+    n = 2_000_000
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--steps", "6", "--warmup", "2",
+                        "--contexts", str(n), "--no-cpu-baseline", "--ingest-rows", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["per_rank"] is not None and len(d["per_rank"]) == 1
+    assert d["per_rank"][0]["contexts"] == n and d["per_rank"][0]["kernel_ms"] > 0 and d["per_rank"][0]["allreduce_ms"] > 0
+    dev = torch.device("cuda", 0)
+    t = kernels.synth_counts(20211012, 0, n, dev, want=("train",))["train"]
+    want = kernels.dm_prior_planned(kernels.Plan(t, 5), kernels.synth_prior(20211012, 0, n, dev), 0.0).cpu().numpy()
+    assert np.allclose(d["result"], want, rtol=1e-12)
+
+
 def test_rccl_group_of_one(tmp_path):
     """RCCL itself on this box: a process group of one rank (two ranks cannot share a card under RCCL) runs the step's
     collectives behind the planned kernel in stream order -- the library loads, a communicator comes up on the device the
