@@ -261,54 +261,40 @@ def main():
     other = "ref" if primary == "net" else "net"
     elapsed, k_ms, result, k_stats, settle_info, per_rank = measure(primary, args.steps, args.warmup, do_settle=not args.no_settle)
     o_elapsed, o_k_ms, o_result, _, _, _ = measure(other, max(5, args.steps // 5), 2)
-    norm_ms = None
-    if rank == 0:  # the same net kernel with the caller asserting normalised prior rows
-        for _ in range(2):
-            kernels.dm_prior_planned(plans["net"], prior, h_s, normalized=True)
+    def timed(fn, reps):
+        """Median over five or more event-timed groups of back-to-back calls of `fn` (each group at least `reps` / 5 calls and
+        ~1 ms), behind ~20 ms of untimed calls: every entry below follows host-side set-up during which the card clocks down
+        (see settle() above), and a one-off host stall inside a group (a GC pause, an allocator call) must not become the
+        figure -- one default run of round 3 read 1.65 ms for a 0.375 ms kernel that way."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10):
-            kernels.dm_prior_planned(plans["net"], prior, h_s, normalized=True)
+        fn()
         e1.record()
         torch.cuda.synchronize()
-        norm_ms = e0.elapsed_time(e1) / 10
+        first = max(e0.elapsed_time(e1), 1e-3)
+        for _ in range(min(64, int(20.0 / first))):
+            fn()
+        per_group = max(1, -(-reps // 5), min(64, int(1.0 / first) + 1))
+        n_groups = 5 if first > 5.0 else 7
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_groups)]
+        for a, b in evs:
+            a.record()
+            for _ in range(per_group):
+                fn()
+            b.record()
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) / per_group for a, b in evs]))
+
+    norm_ms = None
+    if rank == 0:  # the same net kernel with the caller asserting normalised prior rows
+        norm_ms = timed(lambda: kernels.dm_prior_planned(plans["net"], prior, h_s, normalized=True), 10)
 
     stream_gbps = None
     if rank == 0:   # measured read-only stream over the same prior rows (4 GB): the practical ceiling under the spec peak
-        kernels.stream_read(prior)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            kernels.stream_read(prior)
-        e1.record()
-        torch.cuda.synchronize()
-        stream_gbps = prior.numel() * 8 / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9
+        stream_gbps = prior.numel() * 8 / (timed(lambda: kernels.stream_read(prior), 10) * 1e-3) / 1e9
 
     extra = {}
     if rank == 0 and world == 1:  # the rows of SURVEY 8f built on the same kernels: kernel-only times, 1 GPU
-        def timed(fn, reps):
-            """Median over five or more event-timed groups of back-to-back calls of `fn` (each group at least `reps` / 5 calls and
-            ~1 ms), behind ~20 ms of untimed calls: every entry below follows host-side set-up during which the card clocks down
-            (see settle() above), and a one-off host stall inside a group (a GC pause, an allocator call) must not become the
-            figure -- one default run of round 3 read 1.65 ms for a 0.375 ms kernel that way."""
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn()
-            e1.record()
-            torch.cuda.synchronize()
-            first = max(e0.elapsed_time(e1), 1e-3)
-            for _ in range(min(64, int(20.0 / first))):
-                fn()
-            per_group = max(1, -(-reps // 5), min(64, int(1.0 / first) + 1))
-            n_groups = 5 if first > 5.0 else 7
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_groups)]
-            for a, b in evs:
-                a.record()
-                for _ in range(per_group):
-                    fn()
-                b.record()
-            torch.cuda.synchronize()
-            return float(np.median([a.elapsed_time(b) / per_group for a, b in evs]))
         plan_stream = kernels.Plan(t["train"], 4)     # mode R with the reference rows streamed every step (plan from the training counts only)
         ms = timed(lambda: kernels.dm_ref_planned(plan_stream, t["ref"], h_s, tau_s, nu_s), 10)
         extra["ref_streaming_reference_rows"] = {"kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3), "achieved_GBps": n * 40 / (ms * 1e-3) / 1e9,
