@@ -184,6 +184,9 @@ def test_config_driver_under_the_launcher(kind, tmp_path):
         config["train"]["epochs"] = "6"
         config["train"]["batch_size"] = "400"
         config["train"]["train_ar"] = "False"
+        if kind == "ref" and out.name == "two":
+            # [data] binary_cache under the launcher: rank 0 builds the missing cache with a plain load, the ranks then read row ranges
+            config["data"]["binary_cache"] = str(tmp_path / "cache")
         path = str(out) + ".cfg"
         with open(path, "w") as fh:
             config.write(fh)
@@ -204,6 +207,8 @@ def test_config_driver_under_the_launcher(kind, tmp_path):
             params = pickle.load(fh)["params"]
         res.append((c["results"], _flat(params)))
     assert np.allclose(res[0][1], res[1][1], rtol=1e-7, atol=1e-10)
+    if kind == "ref":
+        assert any(f.endswith(".bearcache") for f in os.listdir(tmp_path / "cache"))
     for key in ("h", "heldout_perplex_BEAR", "heldout_perplex_AR", "perplex_BEAR", "heldout_accuracy_BEAR"):
         assert np.allclose(json.loads(res[0][0][key]), json.loads(res[1][0][key]), rtol=1e-9), key
 
