@@ -173,3 +173,27 @@ def test_count_table_writer_round_trip(tmp_path):
     c = rng.integers(0, 4_000_000_000, size=(2, 7, 5), dtype=np.uint64).astype(np.uint32)
     dataloader.write_counts_tsv(tmp_path / "r.tsv", ["[[ACG"] * 7, c)
     assert np.array_equal(dataloader.dataloader(str(tmp_path / "r.tsv"), "dna", 3, 2).counts, c)
+
+
+def test_bench_flop_models():
+    """The useful-flop counts behind the fp64 rooflines of the bench line (bench.py:flops_*) on tables small
+    enough to count by hand."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fwd, bwd = bench.flops_cnn(13, 8)
+    per_pos = 8 * 30 + 5 * 30 + 9 + 30 * 20 + 2 * 30 * 16
+    head = 5 * 16 + 9 + 16 * 20 + 2 * 16 * 5 + 5 * 20 + 9 + 5
+    assert fwd == 6 * per_pos + head == 12437 and bwd == 3 * fwd
+    train = torch.tensor([[2, 0, 0, 1, 0], [0, 0, 0, 0, 0], [30, 0, 1, 0, 3]], dtype=torch.int32)
+    ref = torch.tensor([[1, 0, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0]], dtype=torch.int32)
+    # mode R: records exist only for the items of contexts WITH reference counts: row 0 -> items c = 2, 1
+    assert bench.flops_ref_items(train, ref) == 2 * 53 + 4 * (2 + 1)
+    # linear head at lag 13 (six groups): 2 live contexts, 5 items with min(c, 24) = 2, 1, 24, 1, 3
+    assert bench.flops_linear(train, 13) == 2 * 65 + 5 * 39 + 4 * (2 + 1 + 24 + 1 + 3)
+    # evaluation: 2 rows with held-out counts (totals 3 and min(34, 24)), 5 cells
+    assert bench.flops_eval(train) == 2 * 67 + 4 * (3 + 24) + 5 * 51 + 4 * (2 + 1 + 24 + 1 + 3)
+    r = bench.fp64_roofline(78.6e12 * 1e-3, 1.0)          # 78.6 GFLOP in 1 ms = the peak
+    assert abs(r["frac_of_fp64_peak"] - 1.0) < 1e-12 and r["peak_TFLOPs"] == 78.6
