@@ -85,6 +85,8 @@ class Uploader:
     everything enqueued so far.  Pageable `.to(device)` copies (round 2) ran at a fraction of the PCIe rate and blocked."""
 
     PIECE = 64 << 20      # bytes per staging buffer
+    COPY_THREADS = 4      # host threads that fill a staging buffer (one thread's memcpy, ~20 GB/s, is less than half of what PCIe takes)
+    _copiers = None
     _ring = {}            # device index -> (piece bytes, pinned buffers): page-locking 192 MiB takes longer than a small table's
                           # whole run, so the ring is kept for the process and sized by what has been asked for so far
 
@@ -123,7 +125,7 @@ class Uploader:
             b = self.k % len(self.bufs)
             if self.free_at[b] is not None:
                 self.free_at[b].synchronize()
-            np.copyto(self.views[b][:n], src[off:off + n])
+            self._fill(self.views[b], src, off, n)
             with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
                 dst_bytes[off:off + n].copy_(self.bufs[b][:n], non_blocking=True)
                 ev = torch.cuda.Event()
@@ -132,6 +134,21 @@ class Uploader:
             self.k += 1
         self.bytes += nbytes
         return dst
+
+    @classmethod
+    def _fill(cls, view, src, off, n):
+        """view[:n] = src[off:off + n], large pieces cut over COPY_THREADS host threads (NumPy's copy releases the GIL)."""
+        if n < (8 << 20) or cls.COPY_THREADS <= 1:
+            np.copyto(view[:n], src[off:off + n])
+            return
+        if cls._copiers is None:
+            import concurrent.futures
+            cls._copiers = concurrent.futures.ThreadPoolExecutor(cls.COPY_THREADS)
+        step = -(-n // cls.COPY_THREADS)
+        step += (-step) % 4096
+        jobs = [cls._copiers.submit(np.copyto, view[a:min(a + step, n)], src[off + a:off + min(a + step, n)]) for a in range(0, n, step)]
+        for j in jobs:
+            j.result()
 
     def wait(self):
         self.consumer.wait_stream(self.stream)

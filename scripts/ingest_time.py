@@ -51,11 +51,24 @@ def measure(n_rows, dev, batches=4, tmpdir=None, seed=20211012):
         kernels.ref_train_reduce(res.plan(0, "train", 4, ref_column="ref"), e["ref"], theta, packed)
         first = packed.cpu().numpy()
         t3 = time.perf_counter()
+        out["resident_rows"] = int(sum(b["rows"] for b in res.batches))
+        out["upload_bytes"] = res.upload_bytes
         assert np.array_equal(data.counts, counts), "the parsed table differs from the one written"
+        # the bare host -> HBM rate of the staging ring (one 2 GB column, nothing else running): what a caller that hands over
+        # HOST buffers every step would pay per byte
+        del res
+        up = _train.Uploader(dev)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        col = up.put(data.counts[0].view(np.int32), torch.int32)
+        up.wait()
+        torch.cuda.synchronize()
+        out["h2d_pinned_ring_GBps"] = col.numel() * 4 / (time.perf_counter() - t4) / 1e9
+        del col, up
         out.update(parse_s=t1 - t0, resident_s=t2 - t1, first_step_s=t3 - t2, text_to_first_step_s=t3 - t0,
-                   parse_GBps=out["text_bytes"] / (t1 - t0) / 1e9, upload_bytes=res.upload_bytes,
-                   upload_and_plan_GBps=res.upload_bytes / (t2 - t1) / 1e9,
-                   resident_rows=int(sum(b["rows"] for b in res.batches)), first_step_sum_ll=float(first[0]),
+                   parse_GBps=out["text_bytes"] / (t1 - t0) / 1e9,
+                   upload_and_plan_GBps=out["upload_bytes"] / (t2 - t1) / 1e9,
+                   first_step_sum_ll=float(first[0]),
                    host_threads=os.cpu_count(),
                    note="parse: threaded mmap reader; resident: pinned staging ring + async H2D on a side stream, compaction to the "
                         "contexts with training counts, reference-aware plans cut per batch as it lands; the file was just written "
