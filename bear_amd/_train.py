@@ -84,7 +84,7 @@ class Uploader:
     compute stream is doing (the previous batch's compaction, sort and plan).  ``wait`` orders the compute stream behind
     everything enqueued so far.  Pageable `.to(device)` copies (round 2) ran at a fraction of the PCIe rate and blocked."""
 
-    PIECE = 64 << 20      # bytes per staging buffer
+    PIECE = 64 << 20      # bytes per staging buffer (16 MiB pieces: 39 instead of 45 GB/s)
     COPY_THREADS = 4      # host threads that fill a staging buffer (one thread's memcpy, ~20 GB/s, is less than half of what PCIe takes)
     _copiers = None
     _ring = {}            # device index -> (piece bytes, pinned buffers): page-locking 192 MiB takes longer than a small table's

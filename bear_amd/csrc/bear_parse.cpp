@@ -44,6 +44,15 @@ struct mapped_file {
   }
 };
 
+// The page tables of a thread's chunk of the mapped file in one call (MADV_POPULATE_READ, Linux 5.14+) instead of one minor
+// fault per 4 KiB page: a 5 GB table is 1.3 M page-cache pages, and faulting them in one by one from 64 threads was most of the
+// parser's 0.39 s.  A kernel that does not know the advice returns EINVAL: the pages then come in by faults as before.
+inline void populate_read(const char *b, const char *e) {
+  if (e <= b) return;
+  const uintptr_t a0 = reinterpret_cast<uintptr_t>(b) & ~(uintptr_t)4095;
+  (void)madvise(reinterpret_cast<void *>(a0), (size_t)(reinterpret_cast<uintptr_t>(e) - a0), 22 /* MADV_POPULATE_READ */);
+}
+
 inline bool blank_line(const char *b, const char *e) {
   for (; b < e; ++b)
     if (*b != ' ' && *b != '\r' && *b != '\t') return false;
@@ -198,7 +207,11 @@ extern "C" int bear_parse_counts_tsv(const char *path, int num_ds, int lag, uint
   }
   {
     std::vector<std::thread> th;
-    for (unsigned k = 0; k < nt; ++k) th.emplace_back([&, k] { first[k + 1] = count_lines(cut[k], cut[k + 1]); });
+    for (unsigned k = 0; k < nt; ++k)
+      th.emplace_back([&, k] {
+        populate_read(cut[k], cut[k + 1]);
+        first[k + 1] = count_lines(cut[k], cut[k + 1]);
+      });
     for (auto &t : th) t.join();
   }
   for (unsigned k = 0; k < nt; ++k) first[k + 1] += first[k];
