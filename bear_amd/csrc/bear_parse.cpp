@@ -380,7 +380,11 @@ extern "C" int bear_parse_counts_tsv_shard(const char *path, int num_ds, int lag
   std::vector<int> status(nt, BEAR_OK);
   {
     std::vector<std::thread> th;
-    for (unsigned k = 0; k < nt; ++k) th.emplace_back([&, k] { first[k + 1] = count_lines(cut[k], cut[k + 1]); });
+    for (unsigned k = 0; k < nt; ++k)
+      th.emplace_back([&, k] {
+        populate_read(cut[k], cut[k + 1]);
+        first[k + 1] = count_lines(cut[k], cut[k + 1]);
+      });
     for (auto &t : th) t.join();
   }
   for (unsigned k = 0; k < nt; ++k) first[k + 1] += first[k];
