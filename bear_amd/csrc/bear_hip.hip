@@ -115,8 +115,8 @@ int bear_ws_create(int device, bear_ws **out) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_kernel<false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_g));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_kernel<true, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_g));
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_inplace_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_gi));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
@@ -654,8 +654,8 @@ static int launch_prior_plan_grad(bear_ws *ws, const bear_plan *plan, const doub
   if (train_ar)
     hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
                        grad_prior, ws->partials, io);
-  else if (prior_normalized)
-    hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
+  else if (prior_normalized)   // rows asserted normalised: the in-place, double-buffered form
+    hipLaunchKernelGGL(dm_prior_plan_grad_inplace_kernel, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_gi), s, prior, prm, pv, lt,
                        grad_prior, ws->partials, io);
   else
     hipLaunchKernelGGL((dm_prior_plan_grad_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,

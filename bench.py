@@ -304,6 +304,13 @@ def main():
         del plan_stream
         ms = timed(lambda: kernels.dm_prior_planned(plans["net"], prior, h_s, want_grad=True), 5)
         extra["net_with_gradient_rows"] = {"kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3)}
+        ms_n = timed(lambda: kernels.dm_prior_planned(plans["net"], prior, h_s, want_grad=True, normalized=True), 5)
+        moved = 40 + plans["net"].nbytes / n + 40      # prior rows in, plan in, gradient rows out
+        extra["net_with_gradient_rows"].update({
+            "kernel_ms_rows_asserted_normalized": ms_n, "contexts_per_s_rows_asserted_normalized": n / (ms_n * 1e-3),
+            "moved_bytes_per_context": moved, "moved_GBps_rows_asserted_normalized": n * moved / (ms_n * 1e-3) / 1e9,
+            "note": "what any torch ar_func trains through (bear_net.train passes the assertion for AR functions that end in a "
+                    "softmax: dm_prior_plan_grad_inplace_kernel, double-buffered; without it dm_prior_plan_grad_kernel)"})
         ms = timed(lambda: kernels.dm_prior_planned(plans["net"], prior, h_s, train_ar=True), 5)
         extra["net_multinomial_mode"] = {"kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3)}
         lag = 13

@@ -125,7 +125,9 @@ int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *c
                            uint64_t n_rows, double h_signed, double eps, int train_ar, int prior_normalized,
                            double *out, void *stream);
 /* The same with the gradient rows: grad_prior [dev] double [n_rows, 5] = d sum LL / d prior (BEAR mode), what
- * grad_tape.gradient hands back to ar_func (bear_model/bear_net.py:193). */
+ * grad_tape.gradient hands back to ar_func (bear_model/bear_net.py:193).  With prior_normalized != 0 the rows are turned into
+ * their gradient in place in LDS (double-buffered tiles: 84 B per context at the streaming rate); as everywhere, prior rows
+ * are non-negative (a concentration f / h + eps must be positive). */
 int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior,
                                 uint64_t n_rows, double h_signed, double eps, int train_ar, int prior_normalized,
                                 double *out, double *grad_prior, void *stream);
