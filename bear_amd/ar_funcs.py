@@ -6,9 +6,10 @@ reference (selected with ``getattr(ar_funcs, 'make_ar_func_' + name)``, models/t
 of the DM kernels).  Contexts are accepted in the reference's one-hot form ``[..., lag, A+1]`` or, to
 avoid materialising 5.2 GB of one-hot at 1e7 contexts, as integer codes ``[..., lag]``
 (-1 = unknown letter = all-zero one-hot row).  Parameters are torch tensors with ``requires_grad``.  On
-integer codes the linear function is fused into the DM step (``bear_dm_linear_f64``) and the convolutional one
-runs as ``bear_cnn_forward_f64`` / ``bear_cnn_backward_f64`` behind torch autograd; one-hot input (and shapes the
-kernels do not cover) takes the PyTorch-ROCm formulation, the DM kernels consume the rows either way.
+integer codes bear_net.train fuses the linear function into the DM step (``bear_dm_linear_f64``); called on its own
+(evaluation, bear_ref.train, get_var_probs) it runs as ``bear_linear_forward_f64`` / ``bear_linear_backward_f64`` and the
+convolutional one as ``bear_cnn_forward_f64`` / ``bear_cnn_backward_f64``, both behind torch autograd; one-hot input (and
+shapes the kernels do not cover) takes the PyTorch-ROCm formulation, the DM kernels consume the rows either way.
 """
 import numpy as np
 import torch
@@ -49,6 +50,27 @@ class _FusedCnn(torch.autograd.Function):
         return (None, None, None) + tuple(out)
 
 
+class _FusedLinear(torch.autograd.Function):
+    """The linear AR function on integer context codes as one HIP launch per direction (``bear_linear_forward_f64`` /
+    ``bear_linear_backward_f64``, kernels_linrows.h) behind torch autograd: evaluation and bear_ref.train get the rows without
+    the [n, lag] int64 index matrix and the scatter-add of an embedding-bag (121 ms per 1e7 contexts forward + backward)."""
+
+    @staticmethod
+    def forward(ctx, codes, lag, mat):
+        from . import kernels
+        packed = kernels.pack_kmers(codes.reshape(-1, lag).to(torch.int8).contiguous())
+        prior = kernels.linear_forward(packed, mat.detach().contiguous(), lag)
+        ctx.lag = lag
+        ctx.save_for_backward(packed, prior)
+        return prior.reshape(codes.shape[:-1] + (5,))
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        from . import kernels
+        packed, prior = ctx.saved_tensors
+        return None, None, kernels.linear_backward(packed, ctx.lag, prior, grad_rows.reshape(-1, 5).to(torch.float64).contiguous())
+
+
 def _l2_normalize(x, dims):
     return x / torch.sqrt(torch.clamp((x * x).sum(dim=dims, keepdim=True), min=1e-12))
 
@@ -65,7 +87,12 @@ def make_ar_func_linear(lag, alphabet_size, dtype=torch.float64, device=None, ge
     mat = torch.randn(lag, alphabet_size + 1, alphabet_size + 1, dtype=dtype, device=device, generator=generator)
     mat = (0.05 * _l2_normalize(mat, (1,))).requires_grad_(True)
 
+    from . import kernels
+    fused_ok = dtype == torch.float64 and kernels.linear_supported(lag, alphabet_size)
+
     def ar_func(kmers):
+        if fused_ok and _is_codes(kmers) and kmers.is_cuda and mat.is_cuda and kmers.shape[-1] == lag and kmers.numel():
+            return _FusedLinear.apply(kmers, lag, mat)
         if _is_codes(kmers):
             # sum_l mat[l, a_l]: an embedding-bag over the flattened [lag * (A+1), A+1] table (unknown letters
             # carry weight 0) -- no [.., lag, A+1] intermediate, and a dense scatter-add backward
@@ -78,6 +105,7 @@ def make_ar_func_linear(lag, alphabet_size, dtype=torch.float64, device=None, ge
             z = torch.einsum("...jk,jkl->...l", kmers, mat)
         return torch.softmax(z, dim=-1)
     ar_func.linear_mat = mat      # bear_net.train: whole step fused in one kernel (bear_dm_linear_f64)
+    ar_func.fused = fused_ok      # integer codes on the device take bear_linear_forward / backward_f64; one-hot input the torch ops
     ar_func.normalized_rows = True   # softmax output: the DM kernels may take the shared concentration total (prior_normalized)
     return ar_func, [mat]
 

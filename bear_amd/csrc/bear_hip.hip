@@ -18,6 +18,7 @@
 #include "kernels_plan.h"
 #include "kernels_synth.h"
 #include "kernels_linear.h"
+#include "kernels_linrows.h"
 #include "kernels_sample.h"
 #include "kernels_shuffle.h"
 #include "kernels_cnn.h"
@@ -911,6 +912,47 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
     hipLaunchKernelGGL(dm_linear_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
                        reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, prm, plan_view(plan), lt, ws->partials,
                        ws->lin_partials, io, grad_mat);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+// ---- the linear AR function as rows (kernels_linrows.h): evaluation, bear_ref with the linear net function ------------
+static int linrows_grid(const bear_ws *ws, uint64_t n_rows) {
+  uint64_t blocks = (n_rows + LNR_THREADS - 1) / LNR_THREADS;
+  if (blocks > (uint64_t)ws->num_cu) blocks = (uint64_t)ws->num_cu;   // lin_partials holds num_cu blocks
+  return blocks ? (int)blocks : 1;
+}
+
+int bear_linear_forward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows, int lag, const double *mat, double *prior,
+                            void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (lag < 1 || lag > LIN_MAX_LAG || !mat) return BEAR_ERR_INVALID_ARG;
+  if (n_rows == 0) return BEAR_OK;
+  if (!kmer_code || !prior || misaligned(prior) || (reinterpret_cast<uintptr_t>(kmer_code) & 7u) || (reinterpret_cast<uintptr_t>(mat) & 7u))
+    return BEAR_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(linear_rows_forward_kernel, dim3(linrows_grid(ws, n_rows)), dim3(LNR_THREADS), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, mat, lag, prior);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_linear_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows, int lag, const double *prior,
+                             const double *grad_prior, double *grad_mat, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (lag < 1 || lag > LIN_MAX_LAG || !grad_mat || (reinterpret_cast<uintptr_t>(grad_mat) & 7u)) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_rows == 0) {
+    HIP_TRY(hipMemsetAsync(grad_mat, 0, sizeof(double) * (size_t)lag * 25, s));
+    return BEAR_OK;
+  }
+  if (!kmer_code || !prior || !grad_prior) return BEAR_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(kmer_code) | reinterpret_cast<uintptr_t>(prior) | reinterpret_cast<uintptr_t>(grad_prior)) & 7u)
+    return BEAR_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(linear_rows_backward_kernel, dim3(linrows_grid(ws, n_rows)), dim3(LNR_THREADS), 0, s,
+                     reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, lag, prior, grad_prior, ws->lin_partials,
+                     ws->arrive, grad_mat);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }

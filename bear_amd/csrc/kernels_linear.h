@@ -346,12 +346,112 @@ __device__ __forceinline__ void lin_phase_a_store(pln_lds_lin &S, const double (
   }
 }
 
-// ---- phase C for the thread's rows: g_b = w_b - f_b s into the gradient tables, whole waves at a time.
-// One LDS fp64 atomic wave-instruction costs ~20 clocks of CU time whatever the number of active lanes (measured,
+// ---- the gradient of 64 consecutive contexts (one per lane: index word cv, g_b = d L / d logit_b for b < 4, nz = the lane has
+// anything to add; lanes beyond the end of a list repeat its last context's word with g = 0) into the letter-major gradient tables
+// GT.  One LDS fp64 atomic wave-instruction costs ~20 clocks of CU time whatever the number of active lanes (measured,
 // scripts/dev/lds_atomic_lanes.hip), so what counts is the number of INSTRUCTIONS: lanes are mapped to (group, letter) pairs
 //   1. all groups whose row the whole wave shares: lane 4 g + b adds the wave's sum of g_b              (one instruction)
 //   2. up to four groups that a lane's row of 16 shares: lane (slot, b) of each row adds the row's sum   (one instruction)
 //   3. what is left (in a sorted table: the triple of the last letters): one add per context and letter (four per group)
+template <int NG>
+__device__ __forceinline__ void lin_scatter_grad(double *GT, unsigned long long cv, const double (&g)[4], bool nz, uint32_t lane,
+                                                 double (&acc)[2]) {
+  const double tq = lin_quad_letter_sum(g, lane), th = lin_row16_sum(tq), tw = lin_wave_sum(th);   // of letter lin_letter(lane)
+  const uint32_t bl = lin_letter(lane);
+  // How many LEADING groups does my row of 16 share (l_row), how many the whole wave (l_wave)?  In a sorted table the shared
+  // groups are the leading ones; anything else is merely handled one level lower than it could be.  e = my index word xor my
+  // predecessor's (wave_ror:1); a row shares the groups below the lowest set bit of the OR of e over its lanes 1..15, the
+  // wave those below the lowest set bit of the OR over all lanes (lane 0's e = word 0 xor word 63 is the xor of all the
+  // others: it cannot lower that bit).
+  const uint32_t clo = (uint32_t)cv, chi = (uint32_t)(cv >> 32);
+  const uint32_t elo = clo ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clo, 0x13C, 0xf, 0xf, false);
+  const uint32_t ehi = chi ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)chi, 0x13C, 0xf, 0xf, false);
+  const bool row_first = (lane & 15u) == 0u;
+  uint32_t rlo = row_first ? 0u : elo, rhi = row_first ? 0u : ehi;
+  rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x121, 0xf, 0xf, false);   // row_ror:1, 2, 4, 8: OR over the row in every lane
+  rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x121, 0xf, 0xf, false);
+  rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x122, 0xf, 0xf, false);
+  rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x122, 0xf, 0xf, false);
+  rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x124, 0xf, 0xf, false);
+  rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x124, 0xf, 0xf, false);
+  rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x128, 0xf, 0xf, false);
+  rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x128, 0xf, 0xf, false);
+  uint32_t wlo = rlo | elo, whi = rhi | ehi;                     // lanes 0, 16, 32, 48 carry the steps between rows
+  {
+    auto a = __builtin_amdgcn_permlane16_swap(wlo, wlo, false, false);
+    auto c = __builtin_amdgcn_permlane16_swap(whi, whi, false, false);
+    wlo = a[0] | a[1];
+    whi = c[0] | c[1];
+    a = __builtin_amdgcn_permlane32_swap(wlo, wlo, false, false);
+    c = __builtin_amdgcn_permlane32_swap(whi, whi, false, false);
+    wlo = a[0] | a[1];
+    whi = c[0] | c[1];
+  }
+  const unsigned long long wave_or = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)whi) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)wlo);
+  const unsigned long long row_or = ((unsigned long long)rhi << 32) | rlo;
+  // ... and my quad: the OR of e over its lanes 1..3
+  const bool quad_first = (lane & 3u) == 0u;
+  uint32_t qlo = quad_first ? 0u : elo, qhi = quad_first ? 0u : ehi;
+  qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2], [2,3,0,1]
+  qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0xB1, 0xf, 0xf, false);
+  qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0x4E, 0xf, 0xf, false);
+  qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0x4E, 0xf, 0xf, false);
+  const unsigned long long quad_or = ((unsigned long long)qhi << 32) | qlo;
+  // group of bit position p: p / 6 (the last group is wider: clamp); 43 / 256 ~ 1 / 6 is exact for p < 64
+  const uint32_t l_wave = wave_or ? min((uint32_t)(__builtin_ctzll(wave_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG;
+  const uint32_t l_row = row_or ? min((uint32_t)(__builtin_ctzll(row_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG;   // >= l_wave
+  const uint32_t l_quad = quad_or ? min((uint32_t)(__builtin_ctzll(quad_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG; // >= l_row
+#if LIN_DBG == 1
+  acc[1] += tw * 1e-300 + th * 1e-300 + (double)l_row * 1e-300;
+  return;
+#endif
+  // 1. the groups the whole wave shares
+  {
+    const uint32_t gq = lane >> 2;
+    if (gq < l_wave && tw != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, gq, NG) >> 2)], tw);
+  }
+#if LIN_DBG == 2
+  return;
+#endif
+  if (l_wave == (uint32_t)NG) return;
+  // 2. the next (up to four) groups, shared by a row of 16: slot s of the row takes group l_wave + s
+  {
+    const uint32_t pick = l_wave + ((lane & 15u) >> 2);
+    if (pick < l_row && th != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
+  }
+#if LIN_DBG == 4
+  return;
+#endif
+  // 2b. the first group a row does NOT share, where my quad still does: in a sorted table a row of 16 that straddles two prefix
+  //     blocks has one such group (the last pair), and per context its adds hit ONE address with eight lanes at a time (LDS
+  //     atomics on one address serialise).  Lane (quad, letter) adds the quad's sum instead; only the quad on the boundary is
+  //     left to step 3.
+  const bool quad_covers = l_row < l_quad && l_row < l_wave + 4u;    // (groups at or beyond l_wave + 4 are step 3's anyway)
+  if (__builtin_amdgcn_ballot_w64(quad_covers)) {
+    if (quad_covers && tq != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, l_row, NG) >> 2)], tq);
+  }
+  // 3. one add per context and letter for every group not covered above
+#pragma unroll
+  for (int gq = 0; gq < NG; ++gq) {
+    if ((uint32_t)gq < l_wave) continue;                   // wave-uniform test
+#ifdef LIN_SKIP_TRIPLE   // developer build (timing only): what do the triple's per-context adds cost?
+    if (gq == NG - 1) continue;
+#endif
+#ifdef LIN_SKIP_PAIRS3   // developer build (timing only): ... and those of every other group?
+    if (gq != NG - 1) continue;
+#endif
+    const bool mine = nz && ((uint32_t)gq >= l_row || (uint32_t)gq >= l_wave + 4u) && !(quad_covers && (uint32_t)gq == l_row);
+    if (!__builtin_amdgcn_ballot_w64(mine)) continue;
+    if (mine) {
+      double *gt = &GT[lin_off<NG>(cv, gq) >> 2];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) atomicAdd(&gt[b * LIN_GT_PLANE], g[b]);
+    }
+  }
+}
+
+// ---- phase C for the thread's rows: g_b = w_b - f_b s into the gradient tables (lin_scatter_grad), whole waves at a time.
 template <int NG>
 __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uint32_t tid, uint32_t lane_in, const double (&fA)[LIN_RPT][5],
                                             const unsigned long long (&cA)[LIN_RPT], uint32_t rowA, double (&acc)[2]) {
@@ -389,100 +489,98 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uin
       const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)code, (int)last), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(code >> 32), (int)last);
       if (!live) cv = ((unsigned long long)hi << 32) | lo;
     }
-    const double tq = lin_quad_letter_sum(g, lane), th = lin_row16_sum(tq), tw = lin_wave_sum(th);   // of letter lin_letter(lane)
-    const uint32_t bl = lin_letter(lane);
-    // How many LEADING groups does my row of 16 share (l_row), how many the whole wave (l_wave)?  In a sorted table the shared
-    // groups are the leading ones; anything else is merely handled one level lower than it could be.  e = my index word xor my
-    // predecessor's (wave_ror:1); a row shares the groups below the lowest set bit of the OR of e over its lanes 1..15, the
-    // wave those below the lowest set bit of the OR over all lanes (lane 0's e = word 0 xor word 63 is the xor of all the
-    // others: it cannot lower that bit).
-    const uint32_t clo = (uint32_t)cv, chi = (uint32_t)(cv >> 32);
-    const uint32_t elo = clo ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clo, 0x13C, 0xf, 0xf, false);
-    const uint32_t ehi = chi ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)chi, 0x13C, 0xf, 0xf, false);
-    const bool row_first = (lane & 15u) == 0u;
-    uint32_t rlo = row_first ? 0u : elo, rhi = row_first ? 0u : ehi;
-    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x121, 0xf, 0xf, false);   // row_ror:1, 2, 4, 8: OR over the row in every lane
-    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x121, 0xf, 0xf, false);
-    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x122, 0xf, 0xf, false);
-    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x122, 0xf, 0xf, false);
-    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x124, 0xf, 0xf, false);
-    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x124, 0xf, 0xf, false);
-    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x128, 0xf, 0xf, false);
-    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x128, 0xf, 0xf, false);
-    uint32_t wlo = rlo | elo, whi = rhi | ehi;                     // lanes 0, 16, 32, 48 carry the steps between rows
-    {
-      auto a = __builtin_amdgcn_permlane16_swap(wlo, wlo, false, false);
-      auto c = __builtin_amdgcn_permlane16_swap(whi, whi, false, false);
-      wlo = a[0] | a[1];
-      whi = c[0] | c[1];
-      a = __builtin_amdgcn_permlane32_swap(wlo, wlo, false, false);
-      c = __builtin_amdgcn_permlane32_swap(whi, whi, false, false);
-      wlo = a[0] | a[1];
-      whi = c[0] | c[1];
-    }
-    const unsigned long long wave_or = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)whi) << 32) |
-                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)wlo);
-    const unsigned long long row_or = ((unsigned long long)rhi << 32) | rlo;
-    // ... and my quad: the OR of e over its lanes 1..3
-    const bool quad_first = (lane & 3u) == 0u;
-    uint32_t qlo = quad_first ? 0u : elo, qhi = quad_first ? 0u : ehi;
-    qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2], [2,3,0,1]
-    qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0xB1, 0xf, 0xf, false);
-    qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0x4E, 0xf, 0xf, false);
-    qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0x4E, 0xf, 0xf, false);
-    const unsigned long long quad_or = ((unsigned long long)qhi << 32) | qlo;
-    // group of bit position p: p / 6 (the last group is wider: clamp); 43 / 256 ~ 1 / 6 is exact for p < 64
-    const uint32_t l_wave = wave_or ? min((uint32_t)(__builtin_ctzll(wave_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG;
-    const uint32_t l_row = row_or ? min((uint32_t)(__builtin_ctzll(row_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG;   // >= l_wave
-    const uint32_t l_quad = quad_or ? min((uint32_t)(__builtin_ctzll(quad_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG; // >= l_row
-#if LIN_DBG == 1
-    acc[1] += tw * 1e-300 + th * 1e-300 + (double)l_row * 1e-300;
-    continue;
-#endif
-    // 1. the groups the whole wave shares
-    {
-      const uint32_t gq = lane >> 2;
-      if (gq < l_wave && tw != 0.0) atomicAdd(&S.GT[bl * LIN_GT_PLANE + (lin_off_any(cv, gq, NG) >> 2)], tw);
-    }
-#if LIN_DBG == 2
-    continue;
-#endif
-    if (l_wave == (uint32_t)NG) continue;
-    // 2. the next (up to four) groups, shared by a row of 16: slot s of the row takes group l_wave + s
-    {
-      const uint32_t pick = l_wave + ((lane & 15u) >> 2);
-      if (pick < l_row && th != 0.0) atomicAdd(&S.GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
-    }
-#if LIN_DBG == 4
-    continue;
-#endif
-    // 2b. the first group a row does NOT share, where my quad still does: in a sorted table a row of 16 that straddles two prefix
-    //     blocks has one such group (the last pair), and per context its adds hit ONE address with eight lanes at a time (LDS
-    //     atomics on one address serialise).  Lane (quad, letter) adds the quad's sum instead; only the quad on the boundary is
-    //     left to step 3.
-    const bool quad_covers = l_row < l_quad && l_row < l_wave + 4u;    // (groups at or beyond l_wave + 4 are step 3's anyway)
-    if (__builtin_amdgcn_ballot_w64(quad_covers)) {
-      if (quad_covers && tq != 0.0) atomicAdd(&S.GT[bl * LIN_GT_PLANE + (lin_off_any(cv, l_row, NG) >> 2)], tq);
-    }
-    // 3. one add per context and letter for every group not covered above
-#pragma unroll
-    for (int gq = 0; gq < NG; ++gq) {
-      if ((uint32_t)gq < l_wave) continue;                   // wave-uniform test
-#ifdef LIN_SKIP_TRIPLE   // developer build (timing only): what do the triple's per-context adds cost?
-      if (gq == NG - 1) continue;
-#endif
-#ifdef LIN_SKIP_PAIRS3   // developer build (timing only): ... and those of every other group?
-      if (gq != NG - 1) continue;
-#endif
-      const bool mine = nz && ((uint32_t)gq >= l_row || (uint32_t)gq >= l_wave + 4u) && !(quad_covers && (uint32_t)gq == l_row);
-      if (!__builtin_amdgcn_ballot_w64(mine)) continue;
-      if (mine) {
-        double *gt = &S.GT[lin_off<NG>(cv, gq) >> 2];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) atomicAdd(&gt[b * LIN_GT_PLANE], g[b]);
-      }
-    }
+    lin_scatter_grad<NG>(S.GT, cv, g, nz, lane, acc);
   }
+}
+
+// ---- the group tables of a launch, built by the whole block (n_threads threads; *t_max: a word of LDS).  A row is the sum of mat[l][a_l][b] - mat[l][a_l][4] over the group's letters;
+// letter value 5 = unknown and positions beyond the group or the lag contribute nothing.
+// If no context's partial sums of table rows can leave +-600 (ng rows of at most t_max each -- anything a fitted model
+// produces), the tables hold exp(logit) and a context's softmax numerators are PRODUCTS of table entries: no exponential
+// per context (about a third of phase A's instructions) -- returns true.  Otherwise logits in units of ln2 / 128
+// (lin_exp_units) and the per-context form.  Ends with a barrier.
+__device__ __forceinline__ bool lin_build_tables(double *T, unsigned long long *t_max, const double *__restrict__ mat, const lin_geom &G,
+                                                 int tid, int n_threads) {
+  const int lag = G.lag, n_tab = G.npair * LIN_PSTRIDE + LIN_TRI_COMBOS * 4;
+  if (tid == 0) *t_max = 0ull;
+  double t_abs = 0.0;
+  for (int k = tid; k < n_tab; k += n_threads) {
+    double v = 0.0;
+    auto letter = [&](int l, int a2, int b) {
+      if (a2 < 5 && l < lag) v += mat[(l * 5 + a2) * 5 + b] - mat[(l * 5 + a2) * 5 + 4];
+    };
+    if (k < G.npair * LIN_PSTRIDE) {
+      const int g = k / LIN_PSTRIDE, r = k - g * LIN_PSTRIDE, combo = r >> 2, b = r & 3;
+      const int a0 = combo / 6, a1 = combo - a0 * 6;
+      letter(2 * g, a0, b);
+      if (2 * g + 1 < G.tri) letter(2 * g + 1, a1, b);
+    } else {
+      const int r = k - G.npair * LIN_PSTRIDE, combo = r >> 2, b = r & 3;
+      letter(G.tri, combo / 36, b);
+      letter(G.tri + 1, (combo / 6) % 6, b);
+      letter(G.tri + 2, combo % 6, b);
+    }
+    T[k] = v;
+    t_abs = __builtin_fmax(t_abs, __builtin_fabs(v));
+  }
+  __syncthreads();                                                        // t_max has been zeroed
+  atomicMax(t_max, (unsigned long long)__double_as_longlong(t_abs));      // non-negative doubles order like their bit patterns
+  __syncthreads();
+  const bool exp_tables = srt_uniform((uint32_t)(__longlong_as_double((long long)*t_max) * (double)G.ng < 600.0)) != 0u;
+  for (int k = tid; k < n_tab; k += n_threads) T[k] = exp_tables ? exp(T[k]) : T[k] * LIN_EXP_UNIT;
+  __syncthreads();
+  return exp_tables;
+}
+
+// ---- fold the group tables into this block's d/d mat[l][a][b] partials: sum over the group's other letters; only b < 4 was
+// accumulated (the softmax gradient of a context sums to zero over b: the last column is minus the sum of the others)
+__device__ __forceinline__ void lin_fold_tables(const double *GT, const lin_geom &G, int tid, int n_threads, double *__restrict__ dst) {
+  for (int k = tid; k < G.lag * 25; k += n_threads) {
+    const int l = k / 25, r = k - l * 25, a = r / 5, b = r - a * 5;
+    double s = 0.0;
+    auto add = [&](int row) {
+      const double *gt = &GT[row];
+      s += b < 4 ? gt[b * LIN_GT_PLANE] : -((gt[0] + gt[LIN_GT_PLANE]) + (gt[2 * LIN_GT_PLANE] + gt[3 * LIN_GT_PLANE]));
+    };
+    if (l >= G.tri) {
+      const int pos = l - G.tri, base = G.npair * LIN_PAIR_COMBOS;
+      for (int p = 0; p < 36; ++p) {
+        const int p0 = p / 6, p1 = p % 6;
+        add(base + (pos == 0 ? (a * 6 + p0) * 6 + p1 : pos == 1 ? (p0 * 6 + a) * 6 + p1 : (p0 * 6 + p1) * 6 + a));
+      }
+    } else {
+      const int g = l >> 1;
+      for (int p = 0; p < 6; ++p) add(g * LIN_PAIR_COMBOS + ((l & 1) ? p * 6 + a : a * 6 + p));
+    }
+    bear_store_agent(&dst[k], s);
+  }
+}
+
+// ---- the last block to finish (bear_arrive_last): d/d mat[k] = sum over the blocks' partials [gridDim.x][LIN_MAX_GRAD] in a fixed
+// order -- three threads per entry take a third of the blocks each (independent loads, consecutive threads on consecutive
+// entries), their sums meet in `part` (3 * LIN_MAX_GRAD doubles of LDS).
+__device__ __forceinline__ void lin_sum_block_partials(const double *__restrict__ grad_partials, int n_grad, double *part, int tid,
+                                                       int n_threads, double *__restrict__ grad_out) {
+  const int nb = (int)gridDim.x, third = (nb + 2) / 3;
+  for (int t = tid; t < 3 * n_grad; t += n_threads) {
+    const int k = t % n_grad, c = t / n_grad;
+    const int b0 = c * third, b1 = b0 + third < nb ? b0 + third : nb;
+    // sixteen independent loads in flight per thread (the lines come from memory: the L2 was just invalidated); fixed order
+    const double *src = grad_partials + k;
+    double s = 0.0;
+    int b = b0;
+    for (; b + 16 <= b1; b += 16) {
+      double v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(b + j) * LIN_MAX_GRAD];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s += v[j];
+    }
+    for (; b < b1; ++b) s += src[(size_t)b * LIN_MAX_GRAD];
+    part[c * LIN_MAX_GRAD + k] = s;
+  }
+  __syncthreads();
+  for (int k = tid; k < n_grad; k += n_threads) grad_out[k] = (part[k] + part[LIN_MAX_GRAD + k]) + part[2 * LIN_MAX_GRAD + k];
 }
 
 // compile-time group count from the run-time one
@@ -523,7 +621,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
   const lin_geom G = lin_make_geom(lag);
-  const int ng = G.ng, n_tab = G.npair * LIN_PSTRIDE + LIN_TRI_COMBOS * 4;
+  const int ng = G.ng;
   double acc[2] = {0.0, 0.0};
 
   if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
@@ -537,41 +635,10 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     S.ticket[0] = 0;
     S.ticket[1] = 0;
     S.c_done = 0;
-    S.t_max = 0ull;
   }
   if (tid < BEAR_EXPTAB_N) S.exptab[tid] = exp2((double)tid * (1.0 / BEAR_EXPTAB_N));
-  // group tables: a row is the sum of mat[l][a_l][b] - mat[l][a_l][4] over the group's letters, in units of ln2 / 128
-  // (lin_exp_units); letter value 5 = unknown and positions beyond the group or the lag contribute nothing
-  double t_abs = 0.0;
-  for (int k = tid; k < n_tab; k += PLN_THREADS) {
-    double v = 0.0;
-    auto letter = [&](int l, int a2, int b) {
-      if (a2 < 5 && l < lag) v += mat[(l * 5 + a2) * 5 + b] - mat[(l * 5 + a2) * 5 + 4];
-    };
-    if (k < G.npair * LIN_PSTRIDE) {
-      const int g = k / LIN_PSTRIDE, r = k - g * LIN_PSTRIDE, combo = r >> 2, b = r & 3;
-      const int a0 = combo / 6, a1 = combo - a0 * 6;
-      letter(2 * g, a0, b);
-      if (2 * g + 1 < G.tri) letter(2 * g + 1, a1, b);
-    } else {
-      const int r = k - G.npair * LIN_PSTRIDE, combo = r >> 2, b = r & 3;
-      letter(G.tri, combo / 36, b);
-      letter(G.tri + 1, (combo / 6) % 6, b);
-      letter(G.tri + 2, combo % 6, b);
-    }
-    S.T[k] = v;
-    t_abs = __builtin_fmax(t_abs, __builtin_fabs(v));
-  }
   for (int k = tid; k < LIN_TAB_DOUBLES; k += PLN_THREADS) S.GT[k] = 0.0;
-  // If no context's partial sums of table rows can leave +-600 (ng rows of at most t_max each -- anything a fitted model
-  // produces), the tables hold exp(logit) and a context's softmax numerators are PRODUCTS of table entries: no exponential
-  // per context (about a third of phase A's instructions).  Otherwise logits in units of ln2 / 128 and the per-context form.
-  __syncthreads();                                                        // t_max has been zeroed
-  atomicMax(&S.t_max, (unsigned long long)__double_as_longlong(t_abs));   // non-negative doubles order like their bit patterns
-  __syncthreads();
-  const bool exp_tables = srt_uniform((uint32_t)(__longlong_as_double((long long)S.t_max) * (double)ng < 600.0)) != 0u;
-  for (int k = tid; k < n_tab; k += PLN_THREADS) S.T[k] = exp_tables ? exp(S.T[k]) : S.T[k] * LIN_EXP_UNIT;
-  __syncthreads();
+  const bool exp_tables = lin_build_tables(S.T, &S.t_max, mat, G, tid, PLN_THREADS);
 
   // LIN_DMA_WAVES waves issue the tile DMA (the last ones of the block); measured in round 2, when they also had rows: 16 / 8 / 4 / 2 waves: 1.92 / 1.89 / 1.87 / 1.86 ms
   auto stage = [&](const pln_tile &ti, uint64_t tile, uint32_t b) {
@@ -800,55 +867,11 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     acc[1] = __builtin_fma(u * m, S.tabP[tid], acc[1]);
   }
   __syncthreads();
-  // ---- fold the group tables into d/d mat[l][a][b]: sum over the group's other letters; only b < 4 was accumulated (the softmax
-  // gradient of a context sums to zero over b: the last column is minus the sum of the others)
-  for (int k = tid; k < lag * 25; k += PLN_THREADS) {
-    const int l = k / 25, r = k - l * 25, a = r / 5, b = r - a * 5;
-    double s = 0.0;
-    auto add = [&](int row) {
-      const double *gt = &S.GT[row];
-      s += b < 4 ? gt[b * LIN_GT_PLANE] : -((gt[0] + gt[LIN_GT_PLANE]) + (gt[2 * LIN_GT_PLANE] + gt[3 * LIN_GT_PLANE]));
-    };
-    if (l >= G.tri) {
-      const int pos = l - G.tri, base = G.npair * LIN_PAIR_COMBOS;
-      for (int p = 0; p < 36; ++p) {
-        const int p0 = p / 6, p1 = p % 6;
-        add(base + (pos == 0 ? (a * 6 + p0) * 6 + p1 : pos == 1 ? (p0 * 6 + a) * 6 + p1 : (p0 * 6 + p1) * 6 + a));
-      }
-    } else {
-      const int g = l >> 1;
-      for (int p = 0; p < 6; ++p) add(g * LIN_PAIR_COMBOS + ((l & 1) ? p * 6 + a : a * 6 + p));
-    }
-    bear_store_agent(&grad_partials[(size_t)blockIdx.x * LIN_MAX_GRAD + k], s);
-  }
+  lin_fold_tables(S.GT, G, (int)tid, PLN_THREADS, grad_partials + (size_t)blockIdx.x * LIN_MAX_GRAD);
   block_store_partials<2, true>(acc, partials);      // (io.out is never NULL here: both entry points sum in this launch)
   if (!bear_arrive_last(io.arrive)) return;
-  // the last block to finish: d/d mat[k] = sum over the blocks in a fixed order -- three threads per entry take a third of the
-  // blocks each (independent loads, consecutive threads on consecutive entries), their sums meet in LDS
-  {
-    double *part = reinterpret_cast<double *>(srt_smem);          // the tile loop is over: the dynamic LDS is free
-    const int n_grad = lag * 25, nb = (int)gridDim.x, third = (nb + 2) / 3;
-    __syncthreads();
-    for (int t = tid; t < 3 * n_grad; t += PLN_THREADS) {
-      const int k = t % n_grad, c = t / n_grad;
-      const int b0 = c * third, b1 = b0 + third < nb ? b0 + third : nb;
-      // sixteen independent loads in flight per thread (the lines come from memory: the L2 was just invalidated); fixed order
-      const double *src = grad_partials + k;
-      double s = 0.0;
-      int b = b0;
-      for (; b + 16 <= b1; b += 16) {
-        double v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(b + j) * LIN_MAX_GRAD];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) s += v[j];
-      }
-      for (; b < b1; ++b) s += src[(size_t)b * LIN_MAX_GRAD];
-      part[c * LIN_MAX_GRAD + k] = s;
-    }
-    __syncthreads();
-    for (int k = tid; k < n_grad; k += PLN_THREADS) grad_out[k] = (part[k] + part[LIN_MAX_GRAD + k]) + part[2 * LIN_MAX_GRAD + k];
-  }
+  __syncthreads();
+  lin_sum_block_partials(grad_partials, lag * 25, reinterpret_cast<double *>(srt_smem), (int)tid, PLN_THREADS, grad_out);   // the tile loop is over: the dynamic LDS is free
   bear_finalize_in_block(partials, 2, io.out, io.arrive);
 }
 

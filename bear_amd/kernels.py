@@ -502,6 +502,47 @@ def cnn_backward(kmer_code, flat_params, lag, filter_width, t1, prior, grad_prio
     return grad
 
 
+LINEAR_MAX_LAG = 21
+
+
+def linear_supported(lag, alphabet_size):
+    return alphabet_size == 4 and 1 <= lag <= LINEAR_MAX_LAG
+
+
+def _check_mat(mat, lag):
+    if not (mat.is_cuda and mat.dtype == torch.float64 and mat.is_contiguous() and tuple(mat.shape) == (lag, 5, 5)):
+        raise ValueError("mat must be a contiguous CUDA float64 tensor [lag, 5, 5]")
+
+
+def linear_forward(kmer_code, mat, lag, ws=None):
+    """One launch of ``bear_linear_forward_f64``: the rows softmax(sum_l mat[l, kmer[l], :]) [n, 5] of packed contexts."""
+    _check_codes(kmer_code)
+    _check_mat(mat, lag)
+    n = kmer_code.shape[0]
+    ws = ws or default_workspace(kmer_code.device)
+    prior = torch.empty((n, 5), dtype=torch.float64, device=kmer_code.device)
+    with torch.cuda.device(kmer_code.device):
+        st = _lib.lib().bear_linear_forward_f64(ws.handle, _ptr(kmer_code), n, int(lag), _ptr(mat), _ptr(prior), _stream())
+    _lib.check(st, "bear_linear_forward_f64")
+    return prior
+
+
+def linear_backward(kmer_code, lag, prior, grad_prior, ws=None):
+    """One launch of ``bear_linear_backward_f64``: d L / d mat [lag, 5, 5] from the forward rows and d L / d prior."""
+    _check_codes(kmer_code)
+    n = kmer_code.shape[0]
+    for t in (prior, grad_prior):
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and tuple(t.shape) == (n, 5)):
+            raise ValueError("prior and grad_prior must be contiguous CUDA float64 tensors [n, 5]")
+    ws = ws or default_workspace(kmer_code.device)
+    grad = torch.empty((lag, 5, 5), dtype=torch.float64, device=kmer_code.device)
+    with torch.cuda.device(kmer_code.device):
+        st = _lib.lib().bear_linear_backward_f64(ws.handle, _ptr(kmer_code), n, int(lag), _ptr(prior), _ptr(grad_prior), _ptr(grad),
+                                                 _stream())
+    _lib.check(st, "bear_linear_backward_f64")
+    return grad
+
+
 def stream_read(t, ws=None):
     """One launch of ``bear_stream_read`` over tensor ``t`` (measurement helper: a pure HBM read)."""
     ws = ws or default_workspace(t.device)

@@ -227,6 +227,24 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
                        double *out, double *grad_mat, void *stream);
 
 /*
+ * The linear AR function as prior ROWS, forward and backward: replaces make_ar_func_linear's ar_func (bear_model/ar_funcs.py:41-45)
+ * and grad_tape.gradient through it wherever the rows themselves are needed -- evaluation / h_scan (bear_model/bear_net.py:
+ * 387-531), bear_ref with the linear net function (the rows are mixed with the reference prior, bear_model/bear_ref.py:63-68),
+ * get_var_probs.  (bear_net's training step never forms them: bear_dm_linear_f64 above.)
+ *   kmer_code  [dev] uint64 [n_rows]    packed contexts (bear_pack_kmers_u64); lag <= 21
+ *   mat        [dev] double [lag,5,5]   the AR parameter
+ *   forward:   prior [dev] double [n_rows,5] = softmax(sum_l mat[l, kmer[l], :]), 16-byte aligned; unknown letters add nothing
+ *   backward:  grad_prior [dev] double [n_rows,5] = d L / d prior; prior = the forward rows;
+ *              grad_mat [dev] double [lag,5,5] = d L / d mat (overwritten; LDS fp64 atomics: reproducible to rounding)
+ * Row order: any; fastest in k-mer order (consecutive contexts share their leading letters and the backward pass adds once
+ * per wave for them).  Asynchronous on `stream`; one launch each.
+ */
+int bear_linear_forward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows, int lag, const double *mat, double *prior,
+                            void *stream);
+int bear_linear_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows, int lag, const double *prior,
+                             const double *grad_prior, double *grad_mat, void *stream);
+
+/*
  * The convolutional AR function of bear_net, forward and backward (replaces make_ar_func_cnn's ar_func,
  * bear_model/ar_funcs.py:49-99, and grad_tape.gradient through it, bear_model/bear_net.py:193) for 4-letter alphabets,
  * num_filters = 30 and kmer_layer1_width = 16 (every reference config), lag <= 21, filter_width <= lag.
