@@ -20,6 +20,23 @@ def _counts_to_probs(ref_counts, tau, alphabet_size, dtype=torch.float64):
     return (1 / alphabet_size) * shape + torch.exp(-tau) * (norm - (1 / alphabet_size) * shape)
 
 
+class _FusedRefMix(torch.autograd.Function):
+    """``(nw net + jukes_cantor(ref, tau)) / (nw + 1)`` (bear_ref.py:63-68) as ``bear_ref_mix_forward_f64`` /
+    ``bear_ref_mix_backward_f64`` behind torch autograd: a dozen passes over [n, 5] temporaries become one launch each way."""
+
+    @staticmethod
+    def forward(ctx, net_rows, ref_rows, tau_signed, net_weight_signed):
+        net_rows, ref_rows = net_rows.detach().contiguous(), ref_rows.detach().contiguous()
+        ctx.save_for_backward(net_rows, ref_rows, tau_signed.detach(), net_weight_signed.detach())
+        return kernels.ref_mix_forward(net_rows, ref_rows, tau_signed.detach(), net_weight_signed.detach())
+
+    @staticmethod
+    def backward(ctx, grad_prior):
+        net_rows, ref_rows, tau_signed, net_weight_signed = ctx.saved_tensors
+        grad_rows, scalars = kernels.ref_mix_backward(net_rows, ref_rows, grad_prior.contiguous(), tau_signed, net_weight_signed)
+        return grad_rows, None, scalars[0].reshape(tau_signed.shape), scalars[1].reshape(net_weight_signed.shape)
+
+
 def _make_ref_ar_func(lag, alphabet_size, make_net_func, af_kwargs, dtype=torch.float64, device=None):
     """bear_ref.py:36-69: params = [tau_signed, net_weight_signed] + net params."""
     net_weight_signed = torch.tensor(-np.log(100), dtype=dtype, device=device, requires_grad=True)
@@ -27,10 +44,16 @@ def _make_ref_ar_func(lag, alphabet_size, make_net_func, af_kwargs, dtype=torch.
     net_func, ar_func_params = make_net_func(lag, alphabet_size, **af_kwargs, dtype=dtype, device=device)
 
     def ar_func(kmer_seqs, ref_counts):
+        net = net_func(kmer_seqs)
+        if (alphabet_size == 4 and dtype == torch.float64 and ref_counts.is_cuda and net.is_cuda and tau_signed.is_cuda
+                and net.dim() == 2 and net.shape == ref_counts.shape and ref_counts.dtype == torch.float64 and net.shape[0]):
+            return _FusedRefMix.apply(net, ref_counts, tau_signed, net_weight_signed)   # one launch per direction (kernels_refmix.h)
         nw = torch.exp(net_weight_signed)
         tau = torch.exp(tau_signed)
-        return (nw * net_func(kmer_seqs) + _counts_to_probs(ref_counts, tau, alphabet_size, dtype=dtype)) / (nw + 1)
+        return (nw * net + _counts_to_probs(ref_counts, tau, alphabet_size, dtype=dtype)) / (nw + 1)
     ar_func.net_is_stop = bool(getattr(net_func, "is_stop", False))
+    # the Jukes-Cantor row sums to one, so the mixture does whenever the net function's rows do (every reference AR function)
+    ar_func.normalized_rows = bool(getattr(net_func, "normalized_rows", False))
     return ar_func, ([tau_signed, net_weight_signed] + ar_func_params)
 
 
@@ -102,9 +125,10 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
 def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_ar, acc_steps, writer, loss_save,
                    ds_loc, ds_loc_ref, device):
     """bear_ref.train with a parametrised net function (linear, cnn; bear_ref.py:63-68): the mixed prior rows
-    ``(nw net(kmers) + jukes_cantor(ref, tau)) / (nw + 1)`` are formed by torch ops, the planned kernel returns
-    the ELBO, d/dh and the gradient rows, and autograd carries the rows back to tau, the net weight and the
-    net parameters -- the same loop as bear_net.train with two more parameters."""
+    ``(nw net(kmers) + jukes_cantor(ref, tau)) / (nw + 1)`` are formed by ``bear_ref_mix_forward_f64`` from the net function's
+    rows (``bear_linear_forward_f64`` / ``bear_cnn_forward_f64``), the planned kernel returns the ELBO, d/dh and the gradient
+    rows, and autograd carries the rows back through the matching backward launches to tau, the net weight and the net
+    parameters -- the same loop as bear_net.train with two more parameters."""
     res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device, want_codes=True, drop_empty="train",
                                  prebuild=[("train", 5, None)], per_row_extra=120)
 
@@ -116,7 +140,7 @@ def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_
             return ar_func(e["codes"], e["ref_in"]).contiguous()
         return _train.scatter_live(ar_func(e["codes_live_train"], e["ref_in_live_train"]), live, e["rows"])
     losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, optimizer, train_ar, acc_steps,
-                                       False, device)
+                                       ar_func.normalized_rows, device)
     _train.log_losses(losses, writer, loss_save, acc_steps)
     return params, h_signed, ar_func
 

@@ -59,6 +59,25 @@ __device__ __forceinline__ void bear_store_agent(double *p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ------------------------------------------------------------------ 5-wide fp64 rows out of a wave
+// One row per lane (rows i0 .. i0 + valid of a [n, 5] table, i0 a multiple of 64): a lane's own 40 bytes are five partial-line
+// stores; through R (64 * 5 doubles of this wave's LDS) the wave's valid * 40 bytes leave as consecutive 16-byte pieces
+// (i0 * 40 is a multiple of 16 when dst is 16-byte aligned); an odd count leaves one double.
+__device__ __forceinline__ void bear_wave_store_rows5(double *R, const double (&f)[5], double *__restrict__ dst, uint64_t i0,
+                                                      uint32_t valid, uint32_t lane) {
+#pragma unroll
+  for (int b = 0; b < 5; ++b) R[lane * 5u + b] = f[b];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t n16 = (valid * 5u) >> 1;
+  double2 *out = reinterpret_cast<double2 *>(dst + i0 * 5u);
+  const double2 *src = reinterpret_cast<const double2 *>(R);
+  for (uint32_t k = lane; k < n16; k += 64u) out[k] = src[k];
+  if ((valid & 1u) && lane == 0) dst[(i0 + valid) * 5u - 1u] = R[valid * 5u - 1u];
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_wave_barrier();   // the reads are done before the wave's next rows land in R
+}
+
 // ------------------------------------------------------------------ block reduction
 // Sums NOUT per-thread accumulators over the block (any block size that is a multiple of 64, up to
 // 1024) and stores one partial per block.

@@ -19,6 +19,7 @@
 #include "kernels_synth.h"
 #include "kernels_linear.h"
 #include "kernels_linrows.h"
+#include "kernels_refmix.h"
 #include "kernels_sample.h"
 #include "kernels_shuffle.h"
 #include "kernels_cnn.h"
@@ -953,6 +954,51 @@ int bear_linear_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_
   hipLaunchKernelGGL(linear_rows_backward_kernel, dim3(linrows_grid(ws, n_rows)), dim3(LNR_THREADS), 0, s,
                      reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, lag, prior, grad_prior, ws->lin_partials,
                      ws->arrive, grad_mat);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+// ---- bear_ref's prior rows for a parametrised net function (kernels_refmix.h) ---------------------------------------------
+static int refmix_grid(const bear_ws *ws, uint64_t n_rows) {
+  uint64_t blocks = (n_rows + RMX_THREADS - 1) / RMX_THREADS;
+  uint64_t cap = (uint64_t)ws->num_cu * 2;
+  if (cap > (uint64_t)ws->max_blocks) cap = (uint64_t)ws->max_blocks;
+  if (blocks > cap) blocks = cap;
+  return blocks ? (int)blocks : 1;
+}
+static inline bool misaligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) != 0; }
+
+int bear_ref_mix_forward_f64(bear_ws *ws, const double *net_rows, const double *ref_rows, uint64_t n_rows, const double *tau_signed,
+                             const double *net_weight_signed, double *prior, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!tau_signed || !net_weight_signed || misaligned8(tau_signed) || misaligned8(net_weight_signed)) return BEAR_ERR_INVALID_ARG;
+  if (n_rows == 0) return BEAR_OK;
+  if (!net_rows || !ref_rows || !prior || misaligned8(net_rows) || misaligned8(ref_rows) || misaligned(prior)) return BEAR_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(ref_mix_forward_kernel, dim3(refmix_grid(ws, n_rows)), dim3(RMX_THREADS), 0, static_cast<hipStream_t>(stream),
+                     net_rows, ref_rows, tau_signed, net_weight_signed, n_rows, prior);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_ref_mix_backward_f64(bear_ws *ws, const double *net_rows, const double *ref_rows, const double *grad_prior, uint64_t n_rows,
+                              const double *tau_signed, const double *net_weight_signed, double *grad_net_rows, double *grad_scalars,
+                              void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!tau_signed || !net_weight_signed || !grad_scalars || misaligned8(tau_signed) || misaligned8(net_weight_signed) ||
+      misaligned8(grad_scalars))
+    return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_rows == 0) {
+    HIP_TRY(hipMemsetAsync(grad_scalars, 0, 2 * sizeof(double), s));
+    return BEAR_OK;
+  }
+  if (!net_rows || !ref_rows || !grad_prior || !grad_net_rows || misaligned8(net_rows) || misaligned8(ref_rows) ||
+      misaligned8(grad_prior) || misaligned(grad_net_rows))
+    return BEAR_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(ref_mix_backward_kernel, dim3(refmix_grid(ws, n_rows)), dim3(RMX_THREADS), 0, s, net_rows, ref_rows, grad_prior,
+                     tau_signed, net_weight_signed, n_rows, grad_net_rows, ws->partials, ws->arrive, grad_scalars);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }

@@ -45,18 +45,7 @@ __global__ __launch_bounds__(LNR_THREADS) void linear_rows_forward_kernel(const 
       const unsigned long long cv = lin_index_word(kmer_code[i0 + (lane < valid ? lane : valid - 1u)], G);
       double f[5];
       LIN_FOR_NG(ng, (lin_row<NG, EXP>(S.T, S.exptab, cv, f)))
-#pragma unroll
-      for (int b = 0; b < 5; ++b) R[lane * 5u + b] = f[b];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      // valid * 40 bytes from LDS to prior + i0 * 5 (i0 * 40 is a multiple of 16) as 16-byte pieces; an odd count leaves one double
-      const uint32_t n16 = (valid * 5u) >> 1;
-      double2 *dst = reinterpret_cast<double2 *>(prior + i0 * 5u);
-      const double2 *src = reinterpret_cast<const double2 *>(R);
-      for (uint32_t k = lane; k < n16; k += 64u) dst[k] = src[k];
-      if ((valid & 1u) && lane == 0) prior[(i0 + valid) * 5u - 1u] = R[valid * 5u - 1u];
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      __builtin_amdgcn_wave_barrier();   // the reads are done before the next chunk's rows land
+      bear_wave_store_rows5(R, f, prior, i0, valid, lane);
     }
   };
   if (exp_tables) run(std::true_type{});

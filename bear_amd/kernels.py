@@ -543,6 +543,47 @@ def linear_backward(kmer_code, lag, prior, grad_prior, ws=None):
     return grad
 
 
+def _check_rows5(n, **tensors):
+    for name, t in tensors.items():
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and tuple(t.shape) == (n, 5)):
+            raise ValueError(f"{name} must be a contiguous CUDA float64 tensor [{n}, 5]")
+
+
+def _check_scalar_param(**tensors):
+    for name, t in tensors.items():
+        if not (t.is_cuda and t.dtype == torch.float64 and t.numel() == 1):
+            raise ValueError(f"{name} must be a CUDA float64 tensor of one element")
+
+
+def ref_mix_forward(net_rows, ref_rows, tau_signed, net_weight_signed, ws=None):
+    """One launch of ``bear_ref_mix_forward_f64``: (nw net_rows + jukes_cantor(ref_rows, tau)) / (nw + 1) (bear_ref.py:63-68)."""
+    n = net_rows.shape[0]
+    _check_rows5(n, net_rows=net_rows, ref_rows=ref_rows)
+    _check_scalar_param(tau_signed=tau_signed, net_weight_signed=net_weight_signed)
+    ws = ws or default_workspace(net_rows.device)
+    prior = torch.empty_like(net_rows)
+    with torch.cuda.device(net_rows.device):
+        st = _lib.lib().bear_ref_mix_forward_f64(ws.handle, _ptr(net_rows), _ptr(ref_rows), n, _ptr(tau_signed), _ptr(net_weight_signed),
+                                                 _ptr(prior), _stream())
+    _lib.check(st, "bear_ref_mix_forward_f64")
+    return prior
+
+
+def ref_mix_backward(net_rows, ref_rows, grad_prior, tau_signed, net_weight_signed, ws=None):
+    """One launch of ``bear_ref_mix_backward_f64``: (d L / d net_rows [n, 5], [d L / d tau_signed, d L / d net_weight_signed])."""
+    n = net_rows.shape[0]
+    _check_rows5(n, net_rows=net_rows, ref_rows=ref_rows, grad_prior=grad_prior)
+    _check_scalar_param(tau_signed=tau_signed, net_weight_signed=net_weight_signed)
+    ws = ws or default_workspace(net_rows.device)
+    grad_rows = torch.empty_like(net_rows)
+    scalars = torch.empty(2, dtype=torch.float64, device=net_rows.device)
+    with torch.cuda.device(net_rows.device):
+        st = _lib.lib().bear_ref_mix_backward_f64(ws.handle, _ptr(net_rows), _ptr(ref_rows), _ptr(grad_prior), n, _ptr(tau_signed),
+                                                  _ptr(net_weight_signed), _ptr(grad_rows), _ptr(scalars), _stream())
+    _lib.check(st, "bear_ref_mix_backward_f64")
+    return grad_rows, scalars
+
+
 def stream_read(t, ws=None):
     """One launch of ``bear_stream_read`` over tensor ``t`` (measurement helper: a pure HBM read)."""
     ws = ws or default_workspace(t.device)

@@ -245,6 +245,25 @@ int bear_linear_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_
                              const double *grad_prior, double *grad_mat, void *stream);
 
 /*
+ * bear_ref's prior rows for a net function with parameters (linear, cnn): replaces the arithmetic of _make_ref_ar_func's ar_func
+ * (bear_model/bear_ref.py:63-68 with _counts_to_probs, :9-33) and grad_tape.gradient through it.  (With the stop net function
+ * the mixing lives inside bear_dm_ref_*_f64 and no rows exist.)
+ *   net_rows  [dev] double [n_rows,5]  the net function's rows g (bear_linear_forward_f64, bear_cnn_forward_f64, ...)
+ *   ref_rows  [dev] double [n_rows,5]  the reference column as the driver passes it: (counts + eps) with the stop column
+ *                                      zeroed (bear_model/bear_ref.py:332-337)
+ *   tau_signed, net_weight_signed [dev] double [1]  the two parameters, read on the device (the optimizer's tensors)
+ *   forward:  prior [dev] double [n_rows,5] = (nw g + jukes_cantor(ref, tau)) / (nw + 1), 16-byte aligned
+ *   backward: grad_prior [dev] double [n_rows,5] = d L / d prior;  grad_net_rows [dev] double [n_rows,5] = d L / d g (16-byte
+ *             aligned);  grad_scalars [dev] double [2] = { d L / d tau_signed, d L / d net_weight_signed }
+ * Asynchronous on `stream`; one launch each.  4-letter alphabets.
+ */
+int bear_ref_mix_forward_f64(bear_ws *ws, const double *net_rows, const double *ref_rows, uint64_t n_rows, const double *tau_signed,
+                             const double *net_weight_signed, double *prior, void *stream);
+int bear_ref_mix_backward_f64(bear_ws *ws, const double *net_rows, const double *ref_rows, const double *grad_prior, uint64_t n_rows,
+                              const double *tau_signed, const double *net_weight_signed, double *grad_net_rows, double *grad_scalars,
+                              void *stream);
+
+/*
  * The convolutional AR function of bear_net, forward and backward (replaces make_ar_func_cnn's ar_func,
  * bear_model/ar_funcs.py:49-99, and grad_tape.gradient through it, bear_model/bear_net.py:193) for 4-letter alphabets,
  * num_filters = 30 and kmer_layer1_width = 16 (every reference config), lag <= 21, filter_width <= lag.
