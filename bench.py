@@ -334,6 +334,30 @@ def main():
                                            "roofline": fp64_roofline(flops_linear(t["train"], lag), ms),
                                            "note": "forward + ELBO + d/dh + d/dmat from 8-byte context words, rows in k-mer order "
                                                    "(as bear_net.train uploads a batch)"}
+        # the linear AR function as rows (evaluation, bear_ref with the linear net function) and bear_ref's mixing of net rows with
+        # the reference prior: one bandwidth-bound launch per direction each
+        pr_l = kernels.linear_forward(packed_sorted_raw, mat, lag)
+        lf_ms = timed(lambda: kernels.linear_forward(packed_sorted_raw, mat, lag), 5)
+        _, g_l = kernels.dm_prior_planned(plans["net"], pr_l, h_s, want_grad=True, normalized=True)
+        lb_ms = timed(lambda: kernels.linear_backward(packed_sorted_raw, lag, pr_l, g_l), 5)
+        lb_ms_random = timed(lambda: kernels.linear_backward(packed_raw, lag, pr_l, g_l), 5)
+        ref_in = t["ref"].to(torch.float64) + 1e-7       # bear_ref.py:332-337 (synthetic counts are far below 2^31)
+        ref_in[:, -1] = 0
+        tau_s_dev = torch.tensor(tau_s, dtype=torch.float64, device=dev)
+        nu_s_dev = torch.tensor(nu_s, dtype=torch.float64, device=dev)
+        mf_ms = timed(lambda: kernels.ref_mix_forward(pr_l, ref_in, tau_s_dev, nu_s_dev), 5)
+        mb_ms = timed(lambda: kernels.ref_mix_backward(pr_l, ref_in, g_l, tau_s_dev, nu_s_dev), 5)
+        del pr_l, g_l, ref_in
+        extra["ar_function_rows"] = {
+            "lag": lag,
+            "linear_forward_ms": lf_ms, "linear_forward_GBps": n * 48 / (lf_ms * 1e-3) / 1e9,
+            "linear_backward_ms": lb_ms, "linear_backward_GBps": n * 88 / (lb_ms * 1e-3) / 1e9,
+            "linear_backward_ms_rows_in_random_order": lb_ms_random,
+            "ref_mix_forward_ms": mf_ms, "ref_mix_forward_GBps": n * 120 / (mf_ms * 1e-3) / 1e9,
+            "ref_mix_backward_ms": mb_ms, "ref_mix_backward_GBps": n * 160 / (mb_ms * 1e-3) / 1e9,
+            "note": "bear_linear_forward / backward_f64 (8 + 40 B; 8 + 40 + 40 B per context, rows in k-mer order) and "
+                    "bear_ref_mix_forward / backward_f64 (40 + 40 + 40 B; 3 x 40 + 40 B): what evaluation and bear_ref.train with a "
+                    "parametrised net function call; HBM-bound, GB/s on those bytes"}
         # BASELINE configs[4]: the convolutional AR function, forward + DM step with gradient rows + backward
         from bear_amd import ar_funcs
         fw = 8
