@@ -19,7 +19,7 @@ SYMBOLS = [
     "bear_abi_version", "bear_strerror", "bear_last_hip_error", "bear_ws_create", "bear_ws_destroy",
     "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_dm_items_f64", "bear_eval_f64", "bear_bmm_f64", "bear_pack_kmers_u64", "bear_linear_index_u64", "bear_parse_sparse_counts", "bear_plan_tile_count", "bear_plan_tile_info", "bear_dm_linear_f64",
     "bear_plan_create", "bear_plan_create_ref", "bear_plan_destroy", "bear_plan_bytes", "bear_dm_prior_plan_f64", "bear_dm_prior_plan_grad_f64", "bear_dm_ref_plan_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
-    "bear_count_rows", "bear_parse_counts_tsv", "bear_log_gamma_f64", "bear_logdir_sample_f64",
+    "bear_count_rows", "bear_count_newlines", "bear_parse_counts_tsv", "bear_log_gamma_f64", "bear_logdir_sample_f64",
     "bear_stat_source", "bear_cache_write", "bear_cache_info", "bear_cache_read", "bear_shuffle_rows", "bear_shuffle_source_row",
     "bear_stream_read", "bear_encode_kmers_i8", "bear_ref_train_step_f64", "bear_net_linear_train_step_f64", "bear_cnn_reserve", "bear_net_cnn_train_step_f64", "bear_cnn_param_count", "bear_cnn_forward_f64", "bear_cnn_backward_f64", "bear_linear_forward_f64", "bear_linear_backward_f64", "bear_ref_mix_forward_f64", "bear_ref_mix_backward_f64",
     "bear_dm_prior_plan_dev_f64", "bear_train_apply_f64", "bear_ref_train_reduce_f64", "bear_net_linear_train_reduce_f64", "bear_net_cnn_train_reduce_f64",
@@ -126,6 +126,7 @@ def _load():
     L.bear_gather_rows.argtypes = [vp, vp, vp, u64, ctypes.c_uint32, vp]
     L.bear_eval_plan_f64.argtypes = [vp, vp, vp, vp, vp, u64, vp, cint, cint, vp, cint, dbl, u64, u64, vp, vp, vp]
     L.bear_count_rows.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]
+    L.bear_count_newlines.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]
     L.bear_parse_counts_tsv.argtypes = [ctypes.c_char_p, cint, cint, u64, vp, vp, ctypes.POINTER(u64)]
     for name in SYMBOLS:
         fn = getattr(L, name)

@@ -270,6 +270,13 @@ def count_rows(file, header=False):
     return n.value - (1 if header and n.value else 0)
 
 
+def count_newlines(file):
+    """``wc -l`` of a file on all host threads (the reference's ``num_kmers``, models/train_bear_net.py:52-55)."""
+    n = ctypes.c_uint64()
+    _lib.check(_lib.lib().bear_count_newlines(str(file).encode(), ctypes.byref(n)), "bear_count_newlines")
+    return n.value
+
+
 def dataloader(file, alphabet, batch_size, num_ds, cache=True, header=False, n_par=1, dtype=torch.float64,
                binary_cache=None, shard=None, row_base=0, total_rows=None):
     """dataloader.py:6-50.  ``cache`` / ``n_par`` are accepted for signature compatibility: the table

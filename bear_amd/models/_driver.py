@@ -14,11 +14,7 @@ PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _count_lines(path):
-    n = 0
-    with open(path, "rb") as fh:
-        for block in iter(lambda: fh.read(1 << 22), b""):
-            n += block.count(b"\n")
-    return n
+    return dataloader.count_newlines(path)      # `wc -l` on all host threads (a Python block loop took 5x the parse)
 
 
 def _writer(out_folder):

@@ -391,12 +391,14 @@ int bear_synth_prior_f64(uint64_t seed, uint64_t row0, uint64_t n_rows, double *
  * replaces the CsvDataset + tfio decode_json path of bear_model/dataloader.py:35-46).
  * Row: kmer '\t' '[[' c,c,c,c,c '],[' ... ']]' '\n' with num_ds groups of 5.
  *   bear_count_rows: number of non-empty lines.
+ *   bear_count_newlines: `wc -l` of the file (newline bytes) -- the reference's num_kmers (models/train_bear_net.py:52-55).
  *   bear_parse_counts_tsv: fills, for rows [0, max_rows):
  *     kmers  [host] char  [max_rows, lag]      (no terminator; '[' padded as in the file)
  *     counts [host] uint32 [num_ds, max_rows, 5] (planar by dataset column)
  *   *n_rows_out receives the number of rows parsed.
  */
 int bear_count_rows(const char *path, uint64_t *n_rows_out);
+int bear_count_newlines(const char *path, uint64_t *n_out);
 /* The sparse row format of dataloader.sparse_dataloader (bear_model/dataloader.py:52-109): `kmer; [[ds, col], ...]; [value, ...]`,
  * one line per k-mer behind `skip_lines` header lines.  counts [host] uint32 [num_ds, max_rows, width] (zeroed here, then filled). */
 int bear_parse_sparse_counts(const char *path, int num_ds, int width, int lag, uint64_t skip_lines, uint64_t max_rows,

@@ -197,3 +197,19 @@ def test_bench_flop_models():
     assert bench.flops_eval(train) == 2 * 67 + 4 * (3 + 24) + 5 * 51 + 4 * (2 + 1 + 24 + 1 + 3)
     r = bench.fp64_roofline(78.6e12 * 1e-3, 1.0)          # 78.6 GFLOP in 1 ms = the peak
     assert abs(r["frac_of_fp64_peak"] - 1.0) < 1e-12 and r["peak_TFLOPs"] == 78.6
+
+
+def test_count_newlines_is_wc_l(tmp_path):
+    """The driver's num_kmers is `wc -l` (models/train_bear_net.py:52-55): newline bytes -- blank lines and a header count, a last
+    line without a newline does not; small files on one thread, large ones cut by byte offset over the host threads."""
+    rng = np.random.default_rng(1)
+    cases = {"empty": b"", "one": b"ACGTA\t[[1,2,3,4,5]]\n", "no_final_newline": b"a\nb\nc", "blank_lines": b"a\n\n \nb\n\n",
+             "large": b"".join(rng.choice([b"ACGT\t[[1,0,0,0,0]]\n", b"\n", b"x" * 37 + b"\n"], size=120_000).tolist()) + b"tail"}
+    assert len(cases["large"]) > (1 << 20)
+    for name, blob in cases.items():
+        p = tmp_path / (name + ".tsv")
+        p.write_bytes(blob)
+        assert dataloader.count_newlines(p) == blob.count(b"\n"), name
+    assert dataloader.count_newlines(YSD1) == 1365
+    with pytest.raises(Exception):
+        dataloader.count_newlines(tmp_path / "missing.tsv")
