@@ -26,7 +26,7 @@ if ks:
         out_md += ["## the same trace, first launches apart (clock ramp after idle)", "",
                    "| kernel | calls | avg ns, first quarter of the launches | avg ns, last half |", "|---|---|---|---|"]
         for name, d in sorted(per.items(), key=lambda kv: -sum(kv[1])):
-            if len(d) >= 8 and any(t in name for t in ("dm_", "eval_", "cnn_", "stream_read")):
+            if len(d) >= 8 and any(t in name for t in ("dm_", "eval_", "cnn_", "stream_read", "linear_rows", "ref_mix")):
                 q, h = d[:len(d) // 4], d[len(d) // 2:]
                 out_md.append(f"| `{name[:70]}` | {len(d)} | {sum(q) / len(q):.0f} | {sum(h) / len(h):.0f} |")
         out_md.append("")
@@ -40,7 +40,12 @@ def kernel_key(k):
     if "cnn_forward" in k: return "cnn_forward"
     if "cnn_backward" in k: return "cnn_backward"
     if "dm_linear" in k: return "linear_head"
+    if "plan_grad_inplace" in k: return "net_grad_inplace"
     if "plan_grad_kernel" in k: return "net_grad"
+    if "linear_rows_forward" in k: return "linear_rows_forward"
+    if "linear_rows_backward" in k: return "linear_rows_backward"
+    if "ref_mix_forward" in k: return "ref_mix_forward"
+    if "ref_mix_backward" in k: return "ref_mix_backward"
     if "dm_ref" in k: return "ref_ar" if "<true>" in k else "ref"
     if "<true, true>" in k: return "net_ar"
     if "<true, false>" in k: return "net_norm"
@@ -58,7 +63,7 @@ for kind in ("fetch", "write", "sq"):
     if not agg: continue
     out_md += [f"## PMC pass: {kind}", "", "| kernel | counter | mean per launch |", "|---|---|---|"]
     for k, v in agg.items():
-        if not any(x in k for x in ("plan_kernel", "plan_grad_kernel", "sorted", "eval_", "cnn_", "items_kernel")): continue
+        if not any(x in k for x in ("plan_kernel", "plan_grad_kernel", "plan_grad_inplace", "sorted", "eval_", "cnn_", "items_kernel", "linear_rows", "ref_mix")): continue
         for c, x in v.items():
             out_md.append(f"| `{k[:40]}` | {c} | {sum(x)/len(x):.0f} |")
             name = kernel_key(k)
@@ -72,7 +77,7 @@ for kind in ("fetch", "write", "sq"):
         # SQ_BUSY_CYCLES sums the 32 shader engines, SQ_ACTIVE_INST_VALU counts quad-cycles over all 1024 SIMDs:
         # fraction of the kernel's cycles a SIMD spends issuing vector-ALU instructions = ACTIVE_VALU * 4 / (BUSY / 32 * 1024)
         for k, v in agg.items():
-            if not any(x in k for x in ("plan_kernel", "plan_grad_kernel", "eval_", "cnn_", "items_kernel")): continue
+            if not any(x in k for x in ("plan_kernel", "plan_grad_kernel", "plan_grad_inplace", "eval_", "cnn_", "items_kernel", "linear_rows", "ref_mix")): continue
             mean = {c: sum(x) / len(x) for c, x in v.items()}
             if mean.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in mean:
                 d = traffic.setdefault(kernel_key(k), {})
