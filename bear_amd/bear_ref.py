@@ -25,15 +25,20 @@ class _FusedRefMix(torch.autograd.Function):
     ``bear_ref_mix_backward_f64`` behind torch autograd: a dozen passes over [n, 5] temporaries become one launch each way."""
 
     @staticmethod
+    def _rows(t):            # contiguous and 16-byte aligned (a slice of a larger tensor may start at an odd row)
+        t = t.detach().contiguous()
+        return t if t.data_ptr() % 16 == 0 else t.clone()
+
+    @staticmethod
     def forward(ctx, net_rows, ref_rows, tau_signed, net_weight_signed):
-        net_rows, ref_rows = net_rows.detach().contiguous(), ref_rows.detach().contiguous()
+        net_rows, ref_rows = _FusedRefMix._rows(net_rows), _FusedRefMix._rows(ref_rows)
         ctx.save_for_backward(net_rows, ref_rows, tau_signed.detach(), net_weight_signed.detach())
         return kernels.ref_mix_forward(net_rows, ref_rows, tau_signed.detach(), net_weight_signed.detach())
 
     @staticmethod
     def backward(ctx, grad_prior):
         net_rows, ref_rows, tau_signed, net_weight_signed = ctx.saved_tensors
-        grad_rows, scalars = kernels.ref_mix_backward(net_rows, ref_rows, grad_prior.contiguous(), tau_signed, net_weight_signed)
+        grad_rows, scalars = kernels.ref_mix_backward(net_rows, ref_rows, _FusedRefMix._rows(grad_prior), tau_signed, net_weight_signed)
         return grad_rows, None, scalars[0].reshape(tau_signed.shape), scalars[1].reshape(net_weight_signed.shape)
 
 

@@ -80,6 +80,26 @@ __device__ __forceinline__ void bear_wave_store_rows5(double *R, const double (&
   __builtin_amdgcn_wave_barrier();   // the reads are done before the wave's next rows land in R
 }
 
+// The reverse: rows i0 .. i0 + valid of a [n, 5] table into one row per lane, as consecutive 16-byte loads through R (a lane's own
+// 40 bytes would be five 8-byte loads at a 40-byte stride: every line is touched by several instructions and part of it is
+// fetched again).  Lanes beyond `valid` get the last row.  src 16-byte aligned.
+__device__ __forceinline__ void bear_wave_load_rows5(double *R, const double *__restrict__ src, uint64_t i0, uint32_t valid,
+                                                     uint32_t lane, double (&f)[5]) {
+  typedef double bear_v2d __attribute__((ext_vector_type(2)));
+  const uint32_t n16 = (valid * 5u) >> 1;
+  const bear_v2d *in = reinterpret_cast<const bear_v2d *>(src + i0 * 5u);
+  bear_v2d *dst = reinterpret_cast<bear_v2d *>(R);
+  for (uint32_t k = lane; k < n16; k += 64u) dst[k] = __builtin_nontemporal_load(in + k);
+  if ((valid & 1u) && lane == 0) R[valid * 5u - 1u] = src[(i0 + valid) * 5u - 1u];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t row = lane < valid ? lane : valid - 1u;
+#pragma unroll
+  for (int b = 0; b < 5; ++b) f[b] = R[row * 5u + b];
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_wave_barrier();   // the reads are done before R is reused
+}
+
 // ------------------------------------------------------------------ block reduction
 // Sums NOUT per-thread accumulators over the block (any block size that is a multiple of 64, up to
 // 1024) and stores one partial per block.

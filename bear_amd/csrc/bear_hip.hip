@@ -974,7 +974,7 @@ int bear_ref_mix_forward_f64(bear_ws *ws, const double *net_rows, const double *
   if (st != BEAR_OK) return st;
   if (!tau_signed || !net_weight_signed || misaligned8(tau_signed) || misaligned8(net_weight_signed)) return BEAR_ERR_INVALID_ARG;
   if (n_rows == 0) return BEAR_OK;
-  if (!net_rows || !ref_rows || !prior || misaligned8(net_rows) || misaligned8(ref_rows) || misaligned(prior)) return BEAR_ERR_INVALID_ARG;
+  if (!net_rows || !ref_rows || !prior || misaligned(net_rows) || misaligned(ref_rows) || misaligned(prior)) return BEAR_ERR_INVALID_ARG;
   hipLaunchKernelGGL(ref_mix_forward_kernel, dim3(refmix_grid(ws, n_rows)), dim3(RMX_THREADS), 0, static_cast<hipStream_t>(stream),
                      net_rows, ref_rows, tau_signed, net_weight_signed, n_rows, prior);
   HIP_TRY(hipGetLastError());
@@ -994,8 +994,8 @@ int bear_ref_mix_backward_f64(bear_ws *ws, const double *net_rows, const double 
     HIP_TRY(hipMemsetAsync(grad_scalars, 0, 2 * sizeof(double), s));
     return BEAR_OK;
   }
-  if (!net_rows || !ref_rows || !grad_prior || !grad_net_rows || misaligned8(net_rows) || misaligned8(ref_rows) ||
-      misaligned8(grad_prior) || misaligned(grad_net_rows))
+  if (!net_rows || !ref_rows || !grad_prior || !grad_net_rows || misaligned(net_rows) || misaligned(ref_rows) ||
+      misaligned(grad_prior) || misaligned(grad_net_rows))
     return BEAR_ERR_INVALID_ARG;
   hipLaunchKernelGGL(ref_mix_backward_kernel, dim3(refmix_grid(ws, n_rows)), dim3(RMX_THREADS), 0, s, net_rows, ref_rows, grad_prior,
                      tau_signed, net_weight_signed, n_rows, grad_net_rows, ws->partials, ws->arrive, grad_scalars);

@@ -545,8 +545,8 @@ def linear_backward(kmer_code, lag, prior, grad_prior, ws=None):
 
 def _check_rows5(n, **tensors):
     for name, t in tensors.items():
-        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and tuple(t.shape) == (n, 5)):
-            raise ValueError(f"{name} must be a contiguous CUDA float64 tensor [{n}, 5]")
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and tuple(t.shape) == (n, 5) and t.data_ptr() % 16 == 0):
+            raise ValueError(f"{name} must be a contiguous, 16-byte aligned CUDA float64 tensor [{n}, 5]")
 
 
 def _check_scalar_param(**tensors):

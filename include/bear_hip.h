@@ -248,6 +248,7 @@ int bear_linear_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_
  * bear_ref's prior rows for a net function with parameters (linear, cnn): replaces the arithmetic of _make_ref_ar_func's ar_func
  * (bear_model/bear_ref.py:63-68 with _counts_to_probs, :9-33) and grad_tape.gradient through it.  (With the stop net function
  * the mixing lives inside bear_dm_ref_*_f64 and no rows exist.)
+ *   Every [n_rows,5] array is 16-byte aligned.
  *   net_rows  [dev] double [n_rows,5]  the net function's rows g (bear_linear_forward_f64, bear_cnn_forward_f64, ...)
  *   ref_rows  [dev] double [n_rows,5]  the reference column as the driver passes it: (counts + eps) with the stop column
  *                                      zeroed (bear_model/bear_ref.py:332-337)

@@ -80,6 +80,10 @@ def test_ref_ar_func_takes_the_fused_path_and_matches_the_torch_one():
         assert float((a.grad.cpu() - b.grad).abs().max()) <= 1e-11 * float(b.grad.abs().max())
     with torch.no_grad():
         assert torch.equal(af_d(codes.to(dev), ref.to(dev)), y_d.detach())
+        # rows that start at an odd row of a larger tensor (8-byte aligned only) are copied, not refused
+        c1, r1 = codes.to(dev)[1:], ref.to(dev)[1:]
+        assert r1.data_ptr() % 16 == 8
+        assert torch.equal(af_d(c1, r1), y_d.detach()[1:])
 
 
 def test_ref_mix_argument_errors_and_empty_batch():
