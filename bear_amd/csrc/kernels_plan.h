@@ -61,6 +61,9 @@ static_assert(sizeof(pln_tile) == 32, "tile descriptors are fetched with one s_l
 #ifndef PLN_DMA_WAVES
 #define PLN_DMA_WAVES 2                     // waves of each block that only stream tiles into LDS (see dm_prior_plan_kernel)
 #endif
+#ifndef PLN_PREFETCH_KIB
+#define PLN_PREFETCH_KIB 24                 // L2 prefetch of the tile after next by the DMA waves of the light mode-N forms (0: off)
+#endif
 #define PLN_DESC_CHUNK 32                   // descriptors per 1 KiB LDS-DMA piece
 #define PLN_DESC_PAD (2 * PLN_DESC_CHUNK)   // zeroed descriptors behind the last tile (plan allocation)
 
@@ -493,6 +496,8 @@ __device__ __forceinline__ void pln_wait_all_but(uint32_t younger) {
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -554,6 +559,7 @@ struct pln_lds_n {
   double tabP[SRT_NKEY];
   uint32_t ticket[PLN_NBUF];  // per ring slot; zeroed one tile ahead
   __attribute__((aligned(16))) pln_tile desc[2][PLN_DESC_CHUNK];  // descriptors of this block's tile range, 2 x 32
+  __attribute__((aligned(16))) uint32_t pf_scratch[64];           // where the L2 prefetch's dwords land (never read)
 };
 
 // Tile descriptor j of the block's range from the LDS ring (wave-uniform: every lane reads the same address).
@@ -634,6 +640,36 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
     }
   };
 
+  // The ring holds ONE tile in flight per CU (LDS): the bytes in flight over the chip fall short of what the HBM latency asks for
+  // (5.7 TB/s on the 44 B moved, against 6.0 for a plain read stream).  Where the tile's compute is light -- rows asserted
+  // normalised (no context pass) and the multinomial mode -- the DMA waves therefore also touch the first 24 KiB of the tile
+  // AFTER next: one lane per 128-byte line, a dword each, landing in a scratch word of LDS; that tile's DMA, one iteration
+  // later, finds those lines in the L2 / infinity cache: 0.778 -> 0.715 ms (NORM), 0.768 -> 0.705 ms (multinomial) per 1e8
+  // contexts, 6.2 TB/s on the bytes moved.  NOT in the general form: its tiles are bound by their compute (the context pass),
+  // and the card trades shader clock for memory power -- with the prefetch its item units ran 10 % slower (s_memtime: 2045 ->
+  // 2010 ticks per us) and the kernel 0.775 -> 0.81 ms.  Returns the number of instructions this wave issued (they are younger
+  // than the tile's DMA pieces: the wait for the tile leaves exactly that many outstanding).
+  constexpr uint32_t PF_INSTR = (NORM || AR) ? PLN_PREFETCH_KIB / 8u : 0u;
+  auto prefetch_behind = [&](const pln_tile &ti) -> uint32_t {
+    const uint32_t rows = ti.rows_items >> 16;
+    if (PF_INSTR == 0 || rows == 0) return 0u;
+    const uint64_t end_bytes = n_rows * 40ull, base = (ti.row0 + rows) * 40ull;
+    const uint32_t m = srt_uniform((uint32_t)(uintptr_t)S.pf_scratch);
+    uint32_t issued = 0;
+    for (uint32_t k = dw; k < PF_INSTR; k += PLN_DMA_WAVES) {
+      uint64_t off = base + ((uint64_t)(k * 64u + lane) << 7);
+      if (off + 4u > end_bytes) off = end_bytes - 4u;
+      const unsigned char *g = reinterpret_cast<const unsigned char *>(prior) + off;
+      uint32_t keep_m0;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0)
+                   : "v"(g), "s"(m)
+                   : "memory");
+      ++issued;
+    }
+    return issued;
+  };
+  uint32_t pf_young = 0;   // prefetch instructions issued behind the DMA of the tile that lands next
 #ifdef PLN_STAMPS
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
   int prev_kind = 0;
@@ -670,7 +706,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
     PLN_STAMP(prev_kind)  // last work item of the previous tile + the failed ticket draw
     prev_kind = 4;        // slot 4: first ticket draw of a tile
 #endif
-    if (dma_wave) srt_wait_dma();  // tile j has landed
+    if (dma_wave) pln_wait_all_but(pf_young);  // tile j has landed (the prefetch issued behind it may still be in flight)
     PLN_STAMP(1)
     srt_sync();  // ... and every compute wave is done with tile j - 1: its slot is free
     PLN_STAMP(2)  // barrier
@@ -678,6 +714,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
     if (dma_wave) {
       if ((j & (PLN_DESC_CHUNK - 1)) == 0 && j != 0) fetch_desc(j + PLN_DESC_CHUNK);  // the ring half just left behind
       stage(nxt, slot ^ 1u);
+      pf_young = prefetch_behind(nxt);
       cur = nxt;
       nxt = nn;
       slot ^= 1u;

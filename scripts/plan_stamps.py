@@ -24,5 +24,7 @@ for label, kw in [("net", {}), ("net_norm", {"normalized": True})]:
     a = buf.reshape(nb, nw, 8).astype(np.float64)
     tot = a.sum(-1).mean()
     print(f"{label}: kernel {ms:.3f} ms (stamped build); ticks per wave {tot:.0f} -> {tot / ms / 1e3:.1f} ticks/us")
+    n_dma = int(os.environ.get("DMA_WAVES", "2"))      # the block's last waves only stream tiles into LDS
     for k, nme in enumerate(names):
-        print(f"  {nme:14s} {a[:, :, k].mean() / tot * 100:5.1f} %   ({a[:, :, k].mean() / tot * ms * 1e3:7.1f} us)")
+        c, d = a[:, :nw - n_dma, k].mean(), a[:, nw - n_dma:, k].mean()
+        print(f"  {nme:14s} all waves {a[:, :, k].mean() / tot * 100:5.1f} %   compute waves {c / tot * ms * 1e3:7.1f} us   DMA waves {d / tot * ms * 1e3:7.1f} us")
