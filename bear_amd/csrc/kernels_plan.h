@@ -1184,15 +1184,6 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
     if (tid == 0) S.ticket = 0;
     srt_wait_dma();
     srt_sync();
-    // the tile this block takes next: its prior rows and its plan block into the L2 while this one is computed and stored (the
-    // kernel is single-buffered: load, compute and store take turns, and the load then starts from the L2): 1.764 -> 1.645 ms per
-    // 1e8 contexts.  Not in the multinomial mode, whose tiles have next to no compute to hide anything under (1.51 -> 1.62).
-    if (!AR && wave < 10u) {
-      const pln_tile nx = pln_load_tile(pv, t + gridDim.x);
-      const uint32_t nrows = nx.rows_items >> 16;
-      if (wave < 9u) pln_touch_lines(S.pf_scratch, prior + nx.row0 * 5, nrows * 40u, wave, lane);
-      else pln_touch_lines(S.pf_scratch, pv.stream + (size_t)nx.off16 * 16, nx.blk16 * 16u, 0u, lane);
-    }
     const uint16_t *E = reinterpret_cast<const uint16_t *>(S.blk);
     const uint8_t *nrow = S.blk + L.nrow;
     const uint16_t *items = reinterpret_cast<const uint16_t *>(S.blk + L.items);
@@ -1239,6 +1230,18 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
       for (int b = 0; b < 5; ++b) S.grad[row * 5 + b] = -u * o.P;
     }
     srt_sync();
+    // The tile this block takes next: its prior rows and its plan block into the L2 while this one's items are computed and its
+    // rows stored (the kernel is single-buffered: load, compute and store take turns, and the next load then starts from the L2):
+    // 1.764 -> 1.62 ms per 1e8 contexts.  Issued here, behind the context pass: from the top of the tile the lines had to outlive
+    // the whole tile in an L2 that the stores of 32 CUs stream through, and 60 % of them were fetched twice (FETCH_SIZE 70 B per
+    // context; here 51 against 44 without any prefetch); before the store phase it is too late (1.90 ms).  Not in the multinomial
+    // mode, whose tiles have next to no compute to hide anything under (1.51 -> 1.62).
+    if (!AR && wave < 10u) {
+      const pln_tile nx = pln_load_tile(pv, t + gridDim.x);
+      const uint32_t nrows = nx.rows_items >> 16;
+      if (wave < 9u) pln_touch_lines(S.pf_scratch, prior + nx.row0 * 5, nrows * 40u, wave, lane);
+      else pln_touch_lines(S.pf_scratch, pv.stream + (size_t)nx.off16 * 16, nx.blk16 * 16u, 0u, lane);
+    }
     // ---- 3: item units (tickets, dearest first): ELBO, d/dh, and u P_b into the item's own cell
     const uint32_t n_hcu = (hc + 63u) >> 6, n_units = (n_light + 63u) >> 6;
     for (uint32_t w = pln_ticket(&S.ticket, lane); w < n_hcu + n_units; w = pln_ticket(&S.ticket, lane)) {
