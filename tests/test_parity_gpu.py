@@ -515,6 +515,14 @@ def test_planned_full_size_chunks(dev):
     a = kernels.dm_prior_planned(pn, f, -0.4).cpu().numpy()
     b = kernels.dm_prior(t["train"], f, -0.4)[0].cpu().numpy()
     assert np.allclose(a, b, rtol=1e-12)
+    # the light forms (rows asserted normalised, multinomial): their DMA waves wait for a tile with prefetch instructions still
+    # in flight behind it (s_waitcnt vmcnt(k)) -- a tile read before it has landed would show as a launch that disagrees
+    norm = [kernels.dm_prior_planned(pn, f, -0.4, normalized=True).cpu().numpy() for _ in range(20)]
+    assert np.allclose(norm[0], a, rtol=1e-11)             # the synthetic prior rows are normalised
+    assert all(np.allclose(x, norm[0], rtol=1e-13, atol=0) for x in norm[1:])
+    ar = [kernels.dm_prior_planned(pn, f, -0.4, train_ar=True).cpu().numpy() for _ in range(20)]
+    assert np.allclose(ar[0][0], kernels.dm_prior(t["train"], f, -0.4, train_ar=True)[0].cpu().numpy()[0], rtol=1e-12)
+    assert all(np.allclose(x, ar[0], rtol=1e-13, atol=0) for x in ar[1:])
     lo, hi = 4_000_003, 4_100_003
     tr, rf = t["train"][lo:hi].clone(), t["ref"][lo:hi].clone()
     fc = f[lo:hi].clone()
