@@ -21,7 +21,7 @@ SYMBOLS = [
     "bear_plan_create", "bear_plan_create_ref", "bear_plan_destroy", "bear_plan_bytes", "bear_dm_prior_plan_f64", "bear_dm_prior_plan_grad_f64", "bear_dm_ref_plan_f64", "bear_synth_counts_u32", "bear_synth_prior_f64",
     "bear_count_rows", "bear_count_newlines", "bear_parse_counts_tsv", "bear_log_gamma_f64", "bear_logdir_sample_f64",
     "bear_stat_source", "bear_cache_write", "bear_cache_info", "bear_cache_read", "bear_shuffle_rows", "bear_shuffle_source_row",
-    "bear_stream_read", "bear_encode_kmers_i8", "bear_ref_train_step_f64", "bear_net_linear_train_step_f64", "bear_cnn_reserve", "bear_net_cnn_train_step_f64", "bear_cnn_param_count", "bear_cnn_forward_f64", "bear_cnn_backward_f64", "bear_linear_forward_f64", "bear_linear_backward_f64", "bear_ref_mix_forward_f64", "bear_ref_mix_backward_f64",
+    "bear_stream_read", "bear_encode_kmers_i8", "bear_ref_train_step_f64", "bear_net_linear_train_step_f64", "bear_cnn_reserve", "bear_net_cnn_train_step_f64", "bear_cnn_param_count", "bear_cnn_forward_f64", "bear_cnn_backward_f64", "bear_linear_forward_f64", "bear_linear_backward_f64", "bear_ref_mix_forward_f64", "bear_ref_mix_backward_f64", "bear_dm_refmix_plan_grad_f64",
     "bear_dm_prior_plan_dev_f64", "bear_train_apply_f64", "bear_ref_train_reduce_f64", "bear_net_linear_train_reduce_f64", "bear_net_cnn_train_reduce_f64",
     "bear_eval_plan_create", "bear_eval_plan_destroy", "bear_eval_plan_bytes", "bear_eval_plan_f64",
     "bear_shard_rows_count", "bear_parse_counts_tsv_shard",
@@ -97,6 +97,7 @@ def _load():
     L.bear_linear_backward_f64.argtypes = [vp, vp, u64, cint, vp, vp, vp, vp]
     L.bear_ref_mix_forward_f64.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
     L.bear_ref_mix_backward_f64.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp, vp, vp]
+    L.bear_dm_refmix_plan_grad_f64.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp, vp, dbl, vp, vp, vp]
     L.bear_kmer_sort_create.argtypes = [vp, vp, u64, cint, ctypes.POINTER(vp), ctypes.POINTER(u64), vp]
     L.bear_kmer_sort_reduce.argtypes = [vp, cint, vp, vp, vp, vp]
     L.bear_kmer_sort_destroy.argtypes = [vp]

@@ -440,15 +440,22 @@ def scatter_live(rows_live, live, n_rows):
     return full.index_copy(0, live, rows_live)
 
 
-def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, optimizer, train_ar, acc_steps, normalized, device):
+def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, optimizer, train_ar, acc_steps, normalized, device,
+                       ref_mix=None):
     """The optimizer loop for an AR function made of torch ops (any ``ar_funcs`` plugin; bear_net.py:292-310): per batch the
     prior rows come from ``prior_fn(batch entry)`` with autograd, the planned kernel returns sum LL, d/dh and the gradient rows
     (h_signed is read from the parameter tensor on the device), ``Tensor.backward`` carries the rows to the parameters, one
     all-reduce sums the packed ``[sum LL, d/dh, parameter gradients]`` over the ranks, and the optimizer updates the (mirrored)
-    parameters.  No host round trip per step: the logged losses stay on the device until the loop is done."""
+    parameters.  No host round trip per step: the logged losses stay on the device until the loop is done.
+
+    ``ref_mix = (net_fn, ref_fn, tau_signed, net_weight_signed)`` (bear_ref with a net function that has parameters, BEAR mode,
+    normalised net rows): ``net_fn(batch entry)`` are the NET rows (autograd), ``ref_fn(batch entry)`` the reference rows, and the
+    mixing of bear_ref.py:63-68 happens inside the DM kernel (``bear_dm_refmix_plan_grad_f64``), which also returns the gradients
+    of the two mixing parameters; ``prior_fn`` is then not called."""
     rest = params[1:]
     acc = [torch.zeros_like(p) for p in params]
     out = torch.zeros(2, dtype=torch.float64, device=device)
+    out4 = torch.zeros(4, dtype=torch.float64, device=device)
     h_dev = h_signed.detach().reshape(1)                      # same storage as the parameter the optimizer updates
     loss = torch.zeros((), dtype=torch.float64, device=device)
     logged, step = [], 1
@@ -457,7 +464,17 @@ def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, opti
             scale = -(num_kmers / e["global_rows"])                    # bear_net.py:190-191 with the global batch
             for p in rest:
                 p.grad = None
-            if e["rows"]:
+            if e["rows"] and ref_mix is not None:
+                net_fn, ref_fn, tau_p, nw_p = ref_mix
+                net = net_fn(e)
+                out4, grad_net = kernels.dm_refmix_planned_dev(res.plan(k, "train", 5), net.detach().contiguous(), ref_fn(e), h_dev,
+                                                               tau_p.detach().reshape(1), nw_p.detach().reshape(1), out=out4)
+                if net.requires_grad:
+                    net.backward(scale * grad_net)                     # d loss / d net parameters
+                tau_p.grad = (scale * out4[2]).reshape(tau_p.shape)
+                nw_p.grad = (scale * out4[3]).reshape(nw_p.shape)
+                out.copy_(out4[:2])
+            elif e["rows"]:
                 prior = prior_fn(e)
                 need_rows = prior.requires_grad                        # parameter-free AR function (stop): nothing to feed back
                 r = kernels.dm_prior_planned_dev(res.plan(k, "train", 5), prior.detach(), h_dev, out=out, want_grad=need_rows,

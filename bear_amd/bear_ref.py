@@ -5,6 +5,8 @@ Same entry points and argument meaning as the reference: ``train`` (bear_ref.py:
 (``ar_funcs.make_ar_func_stop``, the reference's bear_stop_*.cfg configurations) a training step is one
 launch of ``bear_dm_ref[_plan]_f64`` per batch shard plus one all-reduce of 4 doubles.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -57,6 +59,7 @@ def _make_ref_ar_func(lag, alphabet_size, make_net_func, af_kwargs, dtype=torch.
         tau = torch.exp(tau_signed)
         return (nw * net + _counts_to_probs(ref_counts, tau, alphabet_size, dtype=dtype)) / (nw + 1)
     ar_func.net_is_stop = bool(getattr(net_func, "is_stop", False))
+    ar_func.net_func, ar_func.tau_signed, ar_func.net_weight_signed = net_func, tau_signed, net_weight_signed
     # the Jukes-Cantor row sums to one, so the mixture does whenever the net function's rows do (every reference AR function)
     ar_func.normalized_rows = bool(getattr(net_func, "normalized_rows", False))
     return ar_func, ([tau_signed, net_weight_signed] + ar_func_params)
@@ -137,15 +140,31 @@ def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_
     res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device, want_codes=True, drop_empty="train",
                                  prebuild=[("train", 5, None)], per_row_extra=120)
 
-    def prior_fn(e):
+    def prior_fn_inputs(e):
         if "ref_in" not in e:
             e["ref_in"] = _ref_input(e["ref"])
+
+    def prior_fn(e):
+        prior_fn_inputs(e)
         live = _train.live_rows(e, "codes", "ref_in")    # contexts without training counts need no prior row
         if live is None:
             return ar_func(e["codes"], e["ref_in"]).contiguous()
         return _train.scatter_live(ar_func(e["codes_live_train"], e["ref_in_live_train"]), live, e["rows"])
+    # BEAR mode, normalised net rows, the reference's own mixing parameters: the mixing runs inside the DM kernel
+    # (bear_dm_refmix_plan_grad_f64: one launch instead of mix-forward, gradient rows, mix-backward); BEAR_AMD_UNFUSED_MIX=1 keeps
+    # the three launches (tests compare the two)
+    ref_mix = None
+    if (not train_ar and ar_func.normalized_rows and getattr(ar_func, "net_func", None) is not None and params[1] is ar_func.tau_signed
+            and params[2] is ar_func.net_weight_signed and not os.environ.get("BEAR_AMD_UNFUSED_MIX")):
+        def net_fn(e):
+            prior_fn_inputs(e)
+            live = _train.live_rows(e, "codes", "ref_in")
+            if live is None:
+                return ar_func.net_func(e["codes"])
+            return _train.scatter_live(ar_func.net_func(e["codes_live_train"]), live, e["rows"])
+        ref_mix = (net_fn, lambda e: e["ref_in"], params[1], params[2])
     losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, optimizer, train_ar, acc_steps,
-                                       ar_func.normalized_rows, device)
+                                       ar_func.normalized_rows, device, ref_mix=ref_mix)
     _train.log_losses(losses, writer, loss_save, acc_steps)
     return params, h_signed, ar_func
 

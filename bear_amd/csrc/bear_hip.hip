@@ -20,6 +20,7 @@
 #include "kernels_linear.h"
 #include "kernels_linrows.h"
 #include "kernels_refmix.h"
+#include "kernels_mixplan.h"
 #include "kernels_sample.h"
 #include "kernels_shuffle.h"
 #include "kernels_cnn.h"
@@ -120,6 +121,9 @@ int bear_ws_create(int device, bear_ws **out) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_inplace_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_gi));
       if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_refmix_plan_grad_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_g));
+      if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<true, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_n));
       if (e == hipSuccess)
@@ -185,6 +189,7 @@ static int check_ws(const bear_ws *ws) {
 }
 
 static inline bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+static inline bool misaligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) != 0; }
 
 static int grid_sorted(const bear_ws *ws, uint64_t n_rows) {
   uint64_t tiles = (n_rows + SRT_TILE - 1) / SRT_TILE;
@@ -713,6 +718,36 @@ int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_
   return launch_prior_plan(ws, plan, prior, n_rows, only_eps, h_signed_dev, train_ar, prior_normalized, out, s);
 }
 
+// bear_ref's step for a net function with parameters: the reference mixing inside the DM step (kernels_mixplan.h)
+int bear_dm_refmix_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *net_rows,
+                                 const double *ref_rows, uint64_t n_rows, const double *h_signed_dev, const double *tau_signed_dev,
+                                 const double *net_weight_signed_dev, double eps, double *out, double *grad_net_rows, void *stream) {
+  int st = check_ws(ws);
+  if (st != BEAR_OK) return st;
+  if (!plan || !out || !h_signed_dev || !tau_signed_dev || !net_weight_signed_dev) return BEAR_ERR_INVALID_ARG;
+  if (n_rows && (!counts || !net_rows || !ref_rows || !grad_net_rows)) return BEAR_ERR_INVALID_ARG;
+  if (plan->ncol != 5 || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
+  if (misaligned(net_rows) || misaligned(ref_rows) || misaligned(grad_net_rows) || misaligned8(out) || misaligned8(h_signed_dev) ||
+      misaligned8(tau_signed_dev) || misaligned8(net_weight_signed_dev) || !(eps >= 0.0))
+    return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int grid = grid_plan(ws, plan->n_tiles);
+  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  const pln_view pv = plan_view(plan);
+  const bear_step_io io{nullptr, BEAR_THETA_REF, out, ws->arrive};
+  hipLaunchKernelGGL(dm_refmix_plan_grad_kernel, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, net_rows, ref_rows, h_signed_dev,
+                     tau_signed_dev, net_weight_signed_dev, eps, pv, lt, grad_net_rows, ws->partials, io);
+  HIP_TRY(hipGetLastError());
+  if (pv.n_heavy_col + pv.n_heavy_row) {
+    const uint64_t nh = pv.n_heavy_col + pv.n_heavy_row;
+    const int g2 = (int)((nh + 255) / 256 < (uint64_t)ws->num_cu * 4 ? (nh + 255) / 256 : (uint64_t)ws->num_cu * 4);
+    hipLaunchKernelGGL(dm_refmix_fixup_kernel, dim3(g2), dim3(256), 0, s, net_rows, ref_rows, h_signed_dev, tau_signed_dev,
+                       net_weight_signed_dev, eps, pv, lt, grad_net_rows);
+    HIP_TRY(hipGetLastError());
+  }
+  return BEAR_OK;
+}
+
 // The mode-R step on a plan: the reference-aware item stream when the plan was built with this reference column
 // (bear_plan_create_ref), the streaming kernel otherwise.  theta != NULL: constants from the device-resident parameters.
 static int launch_ref_plan(bear_ws *ws, const bear_plan *plan, const uint32_t *ref, uint64_t n_rows, const bear_params &prm,
@@ -966,7 +1001,6 @@ static int refmix_grid(const bear_ws *ws, uint64_t n_rows) {
   if (blocks > cap) blocks = cap;
   return blocks ? (int)blocks : 1;
 }
-static inline bool misaligned8(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7u) != 0; }
 
 int bear_ref_mix_forward_f64(bear_ws *ws, const double *net_rows, const double *ref_rows, uint64_t n_rows, const double *tau_signed,
                              const double *net_weight_signed, double *prior, void *stream) {

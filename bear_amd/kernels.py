@@ -630,6 +630,27 @@ def dm_prior_planned_dev(plan, prior, h_signed_dev, eps=EPSILON, out=None, norma
     return (out, grad) if want_grad else out
 
 
+def dm_refmix_planned_dev(plan, net_rows, ref_rows, h_signed_dev, tau_signed_dev, net_weight_signed_dev, eps=EPSILON, out=None):
+    """``bear_dm_refmix_plan_grad_f64``: bear_ref's step for a net function with parameters, the reference mixing inside the DM step.
+    Returns (out [4] = sum LL, d/dh_signed, d/dtau_signed, d/dnet_weight_signed; d sum LL / d net_rows [n, 5])."""
+    counts = plan.counts
+    n = counts.shape[0]
+    _check_rows5(n, net_rows=net_rows, ref_rows=ref_rows)
+    if plan.ncol != 5:
+        raise ValueError("a five-column plan of the training counts is needed")
+    _check_scalar_param(h_signed_dev=h_signed_dev, tau_signed_dev=tau_signed_dev, net_weight_signed_dev=net_weight_signed_dev)
+    if out is None:
+        out = torch.empty(4, dtype=torch.float64, device=counts.device)
+    _f64_vec(out, 4, "out")
+    grad = torch.empty_like(net_rows)
+    with torch.cuda.device(counts.device):
+        st = _lib.lib().bear_dm_refmix_plan_grad_f64(plan.ws.handle, plan._h, _ptr(counts), _ptr(net_rows), _ptr(ref_rows), n,
+                                                     _ptr(h_signed_dev), _ptr(tau_signed_dev), _ptr(net_weight_signed_dev), float(eps),
+                                                     _ptr(out), _ptr(grad), _stream())
+    _lib.check(st, "bear_dm_refmix_plan_grad_f64")
+    return out, grad
+
+
 def train_apply(theta, packed, adam_m, adam_v, adam_t, learning_rate, scale, loss_buf=None, train_ar=False):
     """Enqueues ``bear_train_apply_f64``: tf.keras Adam on ``theta`` with the gradients ``scale * packed[1:]``;
     ``loss_buf[step] = -scale * packed[0]``.  packed = [sum LL, d/d theta...] (after the all-reduce when rows are sharded)."""

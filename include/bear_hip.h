@@ -265,6 +265,23 @@ int bear_ref_mix_backward_f64(bear_ws *ws, const double *net_rows, const double 
                               void *stream);
 
 /*
+ * bear_ref's training step for a net function with parameters, the reference mixing INSIDE the DM step: replaces _train_step of
+ * bear_model/bear_ref.py:207-259 from the net function's rows onwards -- the mixing of bear_ref.py:63-68 (as
+ * bear_ref_mix_forward_f64), sum LL and its gradients (as bear_dm_prior_plan_grad_f64 with prior_normalized), and the way back
+ * through the mixing (as bear_ref_mix_backward_f64) -- in one launch: 127 B per context instead of three launches and 367 B.
+ *   plan       five-column plan of the training counts (bear_plan_create(ws, counts, n_rows, 5, ...))
+ *   net_rows   [dev] double [n_rows,5]  the net function's rows g: non-negative, every row sums to one (softmax output)
+ *   ref_rows   [dev] double [n_rows,5]  (reference counts + eps) with the stop column zeroed (bear_model/bear_ref.py:332-337)
+ *   h_signed_dev, tau_signed_dev, net_weight_signed_dev  [dev] double [1] each (the optimizer's tensors)
+ *   out        [dev] double [4] = { sum LL, d/d h_signed, d/d tau_signed, d/d net_weight_signed }  (unscaled, BEAR mode)
+ *   grad_net_rows [dev] double [n_rows,5] = d sum LL / d g: what the net function's backward pass takes
+ * Row arrays 16-byte aligned.  BEAR mode only (train_ar: mix, then bear_dm_prior_plan_grad_f64 with train_ar).
+ */
+int bear_dm_refmix_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *net_rows,
+                                 const double *ref_rows, uint64_t n_rows, const double *h_signed_dev, const double *tau_signed_dev,
+                                 const double *net_weight_signed_dev, double eps, double *out, double *grad_net_rows, void *stream);
+
+/*
  * The convolutional AR function of bear_net, forward and backward (replaces make_ar_func_cnn's ar_func,
  * bear_model/ar_funcs.py:49-99, and grad_tape.gradient through it, bear_model/bear_net.py:193) for 4-letter alphabets,
  * num_filters = 30 and kmer_layer1_width = 16 (every reference config), lag <= 21, filter_width <= lag.
