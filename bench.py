@@ -347,6 +347,9 @@ def main():
         nu_s_dev = torch.tensor(nu_s, dtype=torch.float64, device=dev)
         mf_ms = timed(lambda: kernels.ref_mix_forward(pr_l, ref_in, tau_s_dev, nu_s_dev), 5)
         mb_ms = timed(lambda: kernels.ref_mix_backward(pr_l, ref_in, g_l, tau_s_dev, nu_s_dev), 5)
+        # ... and bear_ref's whole step on given net rows with the mixing inside the DM kernel (what bear_ref.train runs in BEAR mode)
+        h_s_dev = torch.tensor([h_s], dtype=torch.float64, device=dev)
+        fused_ms = timed(lambda: kernels.dm_refmix_planned_dev(plans["net"], pr_l, ref_in, h_s_dev, tau_s_dev, nu_s_dev), 5)
         del pr_l, g_l, ref_in
         extra["ar_function_rows"] = {
             "lag": lag,
@@ -355,9 +358,12 @@ def main():
             "linear_backward_ms_rows_in_random_order": lb_ms_random,
             "ref_mix_forward_ms": mf_ms, "ref_mix_forward_GBps": n * 120 / (mf_ms * 1e-3) / 1e9,
             "ref_mix_backward_ms": mb_ms, "ref_mix_backward_GBps": n * 160 / (mb_ms * 1e-3) / 1e9,
+            "ref_mix_dm_step_fused_ms": fused_ms, "ref_mix_dm_step_fused_GBps": n * (120 + plans["net"].nbytes / n) / (fused_ms * 1e-3) / 1e9,
             "note": "bear_linear_forward / backward_f64 (8 + 40 B; 8 + 40 + 40 B per context, rows in k-mer order) and "
                     "bear_ref_mix_forward / backward_f64 (40 + 40 + 40 B; 3 x 40 + 40 B): what evaluation and bear_ref.train with a "
-                    "parametrised net function call; HBM-bound, GB/s on those bytes"}
+                    "parametrised net function call; HBM-bound, GB/s on those bytes.  ref_mix_dm_step_fused: bear_dm_refmix_plan_grad_f64 = "
+                    "mixing + sum LL + all gradients in one launch (40 + 40 B + plan in, 40 B out), which bear_ref.train uses in BEAR mode "
+                    "instead of mix-forward + gradient rows + mix-backward"}
         # BASELINE configs[4]: the convolutional AR function, forward + DM step with gradient rows + backward
         from bear_amd import ar_funcs
         fw = 8
