@@ -97,7 +97,7 @@ def _load():
     L.bear_linear_backward_f64.argtypes = [vp, vp, u64, cint, vp, vp, vp, vp]
     L.bear_ref_mix_forward_f64.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp]
     L.bear_ref_mix_backward_f64.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp, vp, vp]
-    L.bear_dm_refmix_plan_grad_f64.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp, vp, dbl, vp, vp, vp]
+    L.bear_dm_refmix_plan_grad_f64.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp, vp, dbl, cint, vp, vp, vp]
     L.bear_kmer_sort_create.argtypes = [vp, vp, u64, cint, ctypes.POINTER(vp), ctypes.POINTER(u64), vp]
     L.bear_kmer_sort_reduce.argtypes = [vp, cint, vp, vp, vp, vp]
     L.bear_kmer_sort_destroy.argtypes = [vp]

@@ -448,8 +448,8 @@ def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, opti
     all-reduce sums the packed ``[sum LL, d/dh, parameter gradients]`` over the ranks, and the optimizer updates the (mirrored)
     parameters.  No host round trip per step: the logged losses stay on the device until the loop is done.
 
-    ``ref_mix = (net_fn, ref_fn, tau_signed, net_weight_signed)`` (bear_ref with a net function that has parameters, BEAR mode,
-    normalised net rows): ``net_fn(batch entry)`` are the NET rows (autograd), ``ref_fn(batch entry)`` the reference rows, and the
+    ``ref_mix = (net_fn, ref_fn, tau_signed, net_weight_signed)`` (bear_ref with a net function that has parameters and
+    normalised rows): ``net_fn(batch entry)`` are the NET rows (autograd), ``ref_fn(batch entry)`` the reference rows, and the
     mixing of bear_ref.py:63-68 happens inside the DM kernel (``bear_dm_refmix_plan_grad_f64``), which also returns the gradients
     of the two mixing parameters; ``prior_fn`` is then not called."""
     rest = params[1:]
@@ -468,7 +468,8 @@ def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, opti
                 net_fn, ref_fn, tau_p, nw_p = ref_mix
                 net = net_fn(e)
                 out4, grad_net = kernels.dm_refmix_planned_dev(res.plan(k, "train", 5), net.detach().contiguous(), ref_fn(e), h_dev,
-                                                               tau_p.detach().reshape(1), nw_p.detach().reshape(1), out=out4)
+                                                               tau_p.detach().reshape(1), nw_p.detach().reshape(1), out=out4,
+                                                               train_ar=train_ar)
                 if net.requires_grad:
                     net.backward(scale * grad_net)                     # d loss / d net parameters
                 tau_p.grad = (scale * out4[2]).reshape(tau_p.shape)

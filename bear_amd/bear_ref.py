@@ -150,11 +150,11 @@ def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_
         if live is None:
             return ar_func(e["codes"], e["ref_in"]).contiguous()
         return _train.scatter_live(ar_func(e["codes_live_train"], e["ref_in_live_train"]), live, e["rows"])
-    # BEAR mode, normalised net rows, the reference's own mixing parameters: the mixing runs inside the DM kernel
+    # normalised net rows, the reference's own mixing parameters: the mixing runs inside the DM kernel
     # (bear_dm_refmix_plan_grad_f64: one launch instead of mix-forward, gradient rows, mix-backward); BEAR_AMD_UNFUSED_MIX=1 keeps
     # the three launches (tests compare the two)
     ref_mix = None
-    if (not train_ar and ar_func.normalized_rows and getattr(ar_func, "net_func", None) is not None and params[1] is ar_func.tau_signed
+    if (ar_func.normalized_rows and getattr(ar_func, "net_func", None) is not None and params[1] is ar_func.tau_signed
             and params[2] is ar_func.net_weight_signed and not os.environ.get("BEAR_AMD_UNFUSED_MIX")):
         def net_fn(e):
             prior_fn_inputs(e)

@@ -121,7 +121,10 @@ int bear_ws_create(int device, bear_ws **out) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_inplace_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_gi));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_refmix_plan_grad_kernel),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_refmix_plan_grad_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_g));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_refmix_plan_grad_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_g));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_kernel<true, false>),
@@ -721,7 +724,8 @@ int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_
 // bear_ref's step for a net function with parameters: the reference mixing inside the DM step (kernels_mixplan.h)
 int bear_dm_refmix_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *net_rows,
                                  const double *ref_rows, uint64_t n_rows, const double *h_signed_dev, const double *tau_signed_dev,
-                                 const double *net_weight_signed_dev, double eps, double *out, double *grad_net_rows, void *stream) {
+                                 const double *net_weight_signed_dev, double eps, int train_ar, double *out, double *grad_net_rows,
+                                 void *stream) {
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
   if (!plan || !out || !h_signed_dev || !tau_signed_dev || !net_weight_signed_dev) return BEAR_ERR_INVALID_ARG;
@@ -735,14 +739,22 @@ int bear_dm_refmix_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint3
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const pln_view pv = plan_view(plan);
   const bear_step_io io{nullptr, BEAR_THETA_REF, out, ws->arrive};
-  hipLaunchKernelGGL(dm_refmix_plan_grad_kernel, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, net_rows, ref_rows, h_signed_dev,
-                     tau_signed_dev, net_weight_signed_dev, eps, pv, lt, grad_net_rows, ws->partials, io);
+  if (train_ar)
+    hipLaunchKernelGGL(dm_refmix_plan_grad_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, net_rows, ref_rows,
+                       h_signed_dev, tau_signed_dev, net_weight_signed_dev, eps, pv, lt, grad_net_rows, ws->partials, io);
+  else
+    hipLaunchKernelGGL(dm_refmix_plan_grad_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, net_rows, ref_rows,
+                       h_signed_dev, tau_signed_dev, net_weight_signed_dev, eps, pv, lt, grad_net_rows, ws->partials, io);
   HIP_TRY(hipGetLastError());
   if (pv.n_heavy_col + pv.n_heavy_row) {
     const uint64_t nh = pv.n_heavy_col + pv.n_heavy_row;
     const int g2 = (int)((nh + 255) / 256 < (uint64_t)ws->num_cu * 4 ? (nh + 255) / 256 : (uint64_t)ws->num_cu * 4);
-    hipLaunchKernelGGL(dm_refmix_fixup_kernel, dim3(g2), dim3(256), 0, s, net_rows, ref_rows, h_signed_dev, tau_signed_dev,
-                       net_weight_signed_dev, eps, pv, lt, grad_net_rows);
+    if (train_ar)
+      hipLaunchKernelGGL(dm_refmix_fixup_kernel<true>, dim3(g2), dim3(256), 0, s, net_rows, ref_rows, h_signed_dev, tau_signed_dev,
+                         net_weight_signed_dev, eps, pv, lt, grad_net_rows);
+    else
+      hipLaunchKernelGGL(dm_refmix_fixup_kernel<false>, dim3(g2), dim3(256), 0, s, net_rows, ref_rows, h_signed_dev, tau_signed_dev,
+                         net_weight_signed_dev, eps, pv, lt, grad_net_rows);
     HIP_TRY(hipGetLastError());
   }
   return BEAR_OK;

@@ -20,6 +20,8 @@
 // Single-buffered like dm_prior_plan_grad_kernel (two row buffers fill the LDS), with its L2 prefetch of the next tile.
 // Rows g must be normalised (every reference net function ends in a softmax) and the alphabet has four letters.  Items and
 // contexts in the plan's global overflow lists (very dense tiles only) are handled by the epilogue and dm_refmix_fixup_kernel.
+// AR (train_ar, the multinomial of core.py:138-139): sum LL = sum c log(f + eps), q = c / (f + eps) on item cells only, no context
+// terms and no h gradient -- the same passes with less in them.
 #pragma once
 #include "kernels_plan.h"
 #include "kernels_refmix.h"
@@ -55,6 +57,7 @@ __device__ __forceinline__ void mxp_cell(const double *__restrict__ g_row, const
   *f = (C.nw * g_row[b] + *jc) * C.V;
 }
 
+template <bool AR>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_grad_kernel(
     const double *__restrict__ net_rows, const double *__restrict__ ref_rows, const double *__restrict__ h_s,
     const double *__restrict__ tau_s, const double *__restrict__ nw_s, double eps_arg, pln_view pv, const double2 *__restrict__ logtab_g,
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
         S.grad[row * 5 + b] = d[b];
       }
       const uint32_t n = nrow[row];
-      if (n != 0 && n != 255u) {
+      if (!AR && n != 0 && n != 255u) {
         acc[0] -= S.tabD[n - 1];
         acc[1] = __builtin_fma(u, S.tabP[n - 1], acc[1]);
       }
@@ -143,18 +146,23 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
       }
     }
     // ---- 2: item units (tickets, dearest first): sum LL, d/dh, the two parameter sums; u P into the d cell, the f cell marked
+    // (o.D = the item's log-likelihood term, o.P = q / u: BEAR mode D, P of the DM item; multinomial mode c log(f + eps), c / (f + eps) / u)
     auto item = [&](uint32_t off, double x, double fb, const bear_dp &o, bool on) {
       const double uP = u * o.P, db = S.grad[off];
       const uint32_t b = off - 5u * (uint32_t)(((unsigned long long)off * 52429ull) >> 18);   // off % 5 for off < 2^16
       const double jc = (b < 4u ? 0.25 : 0.0) + C.E * db;
       if (on) {
         acc[0] += o.D;
-        acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
+        if (!AR) acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
         acc[2] = __builtin_fma(uP, db, acc[2]);
         acc[3] = __builtin_fma(uP, fb - jc, acc[3]);
         S.grad[off] = uP;
         S.pri[off] = -fb;
       }
+    };
+    auto multinomial = [&](double fb, double cnt) {   // c log(f + eps) and c / (f + eps), the latter over u (item() multiplies it back)
+      const double pp = fb + eps;
+      return bear_dp{cnt * bear_log_tab(pp, S.logtab), cnt * bear_rcp(pp) * bear_rcp(u)};
     };
     const uint32_t n_hcu = (hc + 63u) >> 6, n_units = (n_light + 63u) >> 6;
     for (uint32_t w = pln_ticket(&S.ticket, lane); w < n_hcu + n_units; w = pln_ticket(&S.ticket, lane)) {
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
           const uint32_t off = reinterpret_cast<const uint16_t *>(S.blk + L.hoff)[i];
           const double cnt = (double)reinterpret_cast<const uint32_t *>(S.blk + L.hcnt)[i];
           const double fb = S.pri[off], x = __builtin_fma(fb, u, eps);
-          const bear_dp o = srt_general_fast(x, cnt, S.logtab);
+          const bear_dp o = AR ? multinomial(fb, cnt) : srt_general_fast(x, cnt, S.logtab);
           item(off, x, fb, o, true);
         }
         continue;
@@ -176,14 +184,15 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
       const double fb = S.pri[off];
       const double x[1] = {__builtin_fma(fb, u, eps)};
       bear_dp o[1];
-      srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
+      if (AR) o[0] = multinomial(fb, (double)ci[0]);
+      else srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
       item(off, x[0], fb, o[0], ci[0] != 0);
     }
     srt_sync();
     // ---- 3: one thread per row: d/dg = ((marked ? u P : 0) - u P(A, n)) nw / (nw + 1); rows without counts get exact zeros
     for (uint32_t row = tid; row < rows; row += PLN_THREADS) {
       const uint32_t n = nrow[row];
-      const double base = (n != 0 && n != 255u) ? -u * S.tabP[n - 1] : 0.0;   // large totals: step 4 / fix-up kernel
+      const double base = (!AR && n != 0 && n != 255u) ? -u * S.tabP[n - 1] : 0.0;   // large totals: step 4 / fix-up kernel
 #pragma unroll
       for (int b = 0; b < 5; ++b) {
         const bool marked = n != 0 && __builtin_signbit(S.pri[row * 5 + b]);
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
     }
     srt_sync();
     // ---- 4: contexts of this tile with a large total: their context term, and its base on their five cells
-    for (uint32_t i = tid; i < hr; i += PLN_THREADS) {
+    for (uint32_t i = tid; !AR && i < hr; i += PLN_THREADS) {
       const uint32_t row = reinterpret_cast<const uint16_t *>(S.blk + L.hrow)[i];
       const bear_dp o = srt_general_fast(u + eps5, reinterpret_cast<const double *>(S.blk + L.hn)[i], S.logtab);
       acc[0] -= o.D;
@@ -219,13 +228,14 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
     double fb, db, jc;
     mxp_cell(net_rows + row * 5, ref_rows + row * 5, (uint32_t)(h.off - row * 5u), C, &fb, &db, &jc);
     const double x = __builtin_fma(fb, u, eps);
-    const bear_dp o = srt_general_fast(x, (double)h.c, S.logtab);
+    const bear_dp o = AR ? bear_dp{(double)h.c * bear_log_tab(fb + eps, S.logtab), (double)h.c * bear_rcp(fb + eps) * bear_rcp(u)}
+                         : srt_general_fast(x, (double)h.c, S.logtab);
     acc[0] += o.D;
-    acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
+    if (!AR) acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
     acc[2] = __builtin_fma(u * o.P, db, acc[2]);
     acc[3] = __builtin_fma(u * o.P, fb - jc, acc[3]);
   }
-  for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
+  for (uint64_t i = gtid; !AR && i < pv.n_heavy_row; i += gsz) {
     const bear_dp o = srt_general_fast(u + eps5, pv.heavy_row[i].n, S.logtab);
     acc[0] -= o.D;
     acc[1] = __builtin_fma(u, o.P, acc[1]);
@@ -237,6 +247,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
 }
 
 // Gradient cells of the items / contexts in the plan's global overflow lists, scaled like the rest (rare path: fp64 atomics).
+template <bool AR>
 __global__ __launch_bounds__(256) void dm_refmix_fixup_kernel(const double *__restrict__ net_rows, const double *__restrict__ ref_rows,
                                                               const double *__restrict__ h_s, const double *__restrict__ tau_s,
                                                               const double *__restrict__ nw_s, double eps_arg, pln_view pv,
@@ -253,10 +264,10 @@ __global__ __launch_bounds__(256) void dm_refmix_fixup_kernel(const double *__re
     const uint64_t row = h.off / 5u;
     double fb, db, jc;
     mxp_cell(net_rows + row * 5, ref_rows + row * 5, (uint32_t)(h.off - row * 5u), C, &fb, &db, &jc);
-    const bear_dp o = srt_general_fast(__builtin_fma(fb, u, eps), (double)h.c, logtab);
-    atomicAdd(&grad_out[h.off], u * o.P * C.nwV);
+    const double q = AR ? (double)h.c * bear_rcp(fb + eps) : u * srt_general_fast(__builtin_fma(fb, u, eps), (double)h.c, logtab).P;
+    atomicAdd(&grad_out[h.off], q * C.nwV);
   }
-  for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
+  for (uint64_t i = gtid; !AR && i < pv.n_heavy_row; i += gsz) {
     const pln_heavy_row h = pv.heavy_row[i];
     const bear_dp o = srt_general_fast(u + eps5, h.n, logtab);
     for (int b = 0; b < 5; ++b) atomicAdd(&grad_out[h.row * 5 + b], -u * o.P * C.nwV);

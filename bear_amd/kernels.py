@@ -630,7 +630,8 @@ def dm_prior_planned_dev(plan, prior, h_signed_dev, eps=EPSILON, out=None, norma
     return (out, grad) if want_grad else out
 
 
-def dm_refmix_planned_dev(plan, net_rows, ref_rows, h_signed_dev, tau_signed_dev, net_weight_signed_dev, eps=EPSILON, out=None):
+def dm_refmix_planned_dev(plan, net_rows, ref_rows, h_signed_dev, tau_signed_dev, net_weight_signed_dev, eps=EPSILON, out=None,
+                          train_ar=False):
     """``bear_dm_refmix_plan_grad_f64``: bear_ref's step for a net function with parameters, the reference mixing inside the DM step.
     Returns (out [4] = sum LL, d/dh_signed, d/dtau_signed, d/dnet_weight_signed; d sum LL / d net_rows [n, 5])."""
     counts = plan.counts
@@ -646,7 +647,7 @@ def dm_refmix_planned_dev(plan, net_rows, ref_rows, h_signed_dev, tau_signed_dev
     with torch.cuda.device(counts.device):
         st = _lib.lib().bear_dm_refmix_plan_grad_f64(plan.ws.handle, plan._h, _ptr(counts), _ptr(net_rows), _ptr(ref_rows), n,
                                                      _ptr(h_signed_dev), _ptr(tau_signed_dev), _ptr(net_weight_signed_dev), float(eps),
-                                                     _ptr(out), _ptr(grad), _stream())
+                                                     int(bool(train_ar)), _ptr(out), _ptr(grad), _stream())
     _lib.check(st, "bear_dm_refmix_plan_grad_f64")
     return out, grad
 

@@ -273,13 +273,15 @@ int bear_ref_mix_backward_f64(bear_ws *ws, const double *net_rows, const double 
  *   net_rows   [dev] double [n_rows,5]  the net function's rows g: non-negative, every row sums to one (softmax output)
  *   ref_rows   [dev] double [n_rows,5]  (reference counts + eps) with the stop column zeroed (bear_model/bear_ref.py:332-337)
  *   h_signed_dev, tau_signed_dev, net_weight_signed_dev  [dev] double [1] each (the optimizer's tensors)
- *   out        [dev] double [4] = { sum LL, d/d h_signed, d/d tau_signed, d/d net_weight_signed }  (unscaled, BEAR mode)
+ *   train_ar   != 0: the multinomial of bear_model/core.py:138-139 on the mixed rows (no h: out[1] = 0)
+ *   out        [dev] double [4] = { sum LL, d/d h_signed, d/d tau_signed, d/d net_weight_signed }  (unscaled)
  *   grad_net_rows [dev] double [n_rows,5] = d sum LL / d g: what the net function's backward pass takes
- * Row arrays 16-byte aligned.  BEAR mode only (train_ar: mix, then bear_dm_prior_plan_grad_f64 with train_ar).
+ * Row arrays 16-byte aligned.
  */
 int bear_dm_refmix_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *net_rows,
                                  const double *ref_rows, uint64_t n_rows, const double *h_signed_dev, const double *tau_signed_dev,
-                                 const double *net_weight_signed_dev, double eps, double *out, double *grad_net_rows, void *stream);
+                                 const double *net_weight_signed_dev, double eps, int train_ar, double *out, double *grad_net_rows,
+                                 void *stream);
 
 /*
  * The convolutional AR function of bear_net, forward and backward (replaces make_ar_func_cnn's ar_func,

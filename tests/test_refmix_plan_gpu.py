@@ -28,7 +28,8 @@ def _scalars(dev, *vals):
 
 
 @pytest.mark.parametrize("case", list(CASES_REF))
-def test_refmix_plan_with_the_stop_row_is_mode_r(case, ysd1):
+@pytest.mark.parametrize("train_ar", [False, True])
+def test_refmix_plan_with_the_stop_row_is_mode_r(case, train_ar, ysd1):
     from bear_amd import kernels
     dev = torch.device("cuda", 0)
     tr, rf = _case(case, ysd1)
@@ -38,18 +39,21 @@ def test_refmix_plan_with_the_stop_row_is_mode_r(case, ysd1):
     g[:, 4] = 1.0
     ref_in = torch.from_numpy(o.ref_input(rf)).to(dev)
     for args in PARAMS:
-        want = co.dm_ref(tr, rf, *args, nthreads=4)
-        out, rows = kernels.dm_refmix_planned_dev(plan, g, ref_in, *_scalars(dev, *args))
+        want = co.dm_ref(tr, rf, *args, train_ar=train_ar, nthreads=4)
+        out, rows = kernels.dm_refmix_planned_dev(plan, g, ref_in, *_scalars(dev, *args), train_ar=train_ar)
         got = out.cpu().numpy()
         _close(got[0], want[0], ELBO_RTOL)
-        mass = co.dm_ref_mass(tr, rf, *args, nthreads=4)
+        mass = co.dm_ref_mass(tr, rf, *args, train_ar=train_ar, nthreads=4)
         for k in range(1, 4):
             _mass_close(got[k], want[k], mass[k - 1], (case, args, k))
         assert np.all(np.isfinite(rows.cpu().numpy()))
+        if train_ar:
+            assert got[1] == 0.0 and want[1] == 0.0      # no h in the multinomial
 
 
 @pytest.mark.parametrize("case", list(CASES_REF))
-def test_refmix_plan_matches_the_oracle_chain_and_the_unfused_launches(case, ysd1):
+@pytest.mark.parametrize("train_ar", [False, True])
+def test_refmix_plan_matches_the_oracle_chain_and_the_unfused_launches(case, train_ar, ysd1):
     from bear_amd import kernels
     dev = torch.device("cuda", 0)
     tr, rf = _case(case, ysd1)
@@ -64,17 +68,18 @@ def test_refmix_plan_matches_the_oracle_chain_and_the_unfused_launches(case, ysd
         nw, tau = np.exp(nu_s), np.exp(tau_s)
         V, E = 1.0 / (nw + 1.0), np.exp(-tau)
         f = o.ref_ar_func(g, ref_in, tau_s, nu_s)
-        want, G = co.dm_prior(tr, f, h_s, want_grad=True, nthreads=4)
+        want, G = co.dm_prior(tr, f, h_s, train_ar=train_ar, want_grad=True, nthreads=4)
+        mass_h = 0.0 if train_ar else co.dm_prior_mass(tr, f, h_s, nthreads=4)
         d = ref_in / np.abs(ref_in).sum(-1, keepdims=True) - np.r_[np.full(4, 0.25), 0.0]
         jc = o.counts_to_probs(ref_in, tau)
         t_terms, w_terms = (G * d).sum(-1), (G * (g - jc)).sum(-1)
         want_tau, mass_tau = -tau * E * V * t_terms.sum(), tau * E * V * np.abs(G * d).sum()
         want_nw, mass_nw = nw * V * V * w_terms.sum(), nw * V * V * np.abs(G * (g - jc)).sum()
         hp, tp, wp = _scalars(dev, h_s, tau_s, nu_s)
-        out, rows = kernels.dm_refmix_planned_dev(plan, d_g, d_ref, hp, tp, wp)
+        out, rows = kernels.dm_refmix_planned_dev(plan, d_g, d_ref, hp, tp, wp, train_ar=train_ar)
         got, rows = out.cpu().numpy(), rows.cpu().numpy()
         _close(got[0], want[0], ELBO_RTOL)
-        _mass_close(got[1], want[1], co.dm_prior_mass(tr, f, h_s, nthreads=4), (case, "h"))
+        _mass_close(got[1], want[1], mass_h, (case, "h"))
         # the context term cancels in both parameter gradients analytically; in the oracle chain it cancels to rounding of terms
         # of its own size, which is what the mass (sum of |G d|, |G (g - jc)| over ALL cells) measures
         _mass_close(got[2], want_tau, mass_tau, (case, "tau"))
@@ -83,11 +88,11 @@ def test_refmix_plan_matches_the_oracle_chain_and_the_unfused_launches(case, ysd
         assert np.allclose(rows, want_rows, rtol=GRAD_RTOL, atol=GRAD_RTOL * np.abs(want_rows).max()), (case, np.abs(rows - want_rows).max())
         # the three launches it replaces
         f_d = kernels.ref_mix_forward(d_g, d_ref, tp, wp)
-        out2, q = kernels.dm_prior_planned_dev(plan, f_d, hp.reshape(1), want_grad=True, normalized=True)
+        out2, q = kernels.dm_prior_planned_dev(plan, f_d, hp.reshape(1), want_grad=True, normalized=True, train_ar=train_ar)
         rows2, sc = kernels.ref_mix_backward(d_g, d_ref, q, tp, wp)
         out2, sc = out2.cpu().numpy(), sc.cpu().numpy()
         _close(got[0], out2[0], ELBO_RTOL)
-        _mass_close(got[1], out2[1], co.dm_prior_mass(tr, f, h_s, nthreads=4), (case, "h, unfused"))
+        _mass_close(got[1], out2[1], mass_h, (case, "h, unfused"))
         _mass_close(got[2], sc[0], mass_tau, (case, "tau, unfused"))
         _mass_close(got[3], sc[1], mass_nw, (case, "nw, unfused"))
         assert np.allclose(rows, rows2.cpu().numpy(), rtol=GRAD_RTOL, atol=GRAD_RTOL * np.abs(want_rows).max())
@@ -119,8 +124,8 @@ def test_refmix_plan_rows_without_counts_and_ragged_tiles():
     assert np.allclose(rows[keep], G * nw / (nw + 1), rtol=GRAD_RTOL, atol=GRAD_RTOL * np.abs(G).max())
 
 
-@pytest.mark.parametrize("net", ["linear", "cnn"])
-def test_bear_ref_train_fused_mixing_equals_the_three_launches(net, monkeypatch):
+@pytest.mark.parametrize("net,train_ar", [("linear", False), ("cnn", False), ("linear", True)])
+def test_bear_ref_train_fused_mixing_equals_the_three_launches(net, train_ar, monkeypatch):
     """bear_ref.train with a net function that has parameters: the loop with the mixing inside the DM kernel against the loop
     that mixes, takes gradient rows and goes back through the mixing in three launches (BEAR_AMD_UNFUSED_MIX=1)."""
     from bear_amd import _train, ar_funcs, bear_ref, dataloader
@@ -133,7 +138,7 @@ def test_bear_ref_train_fused_mixing_equals_the_three_launches(net, monkeypatch)
             monkeypatch.setenv("BEAR_AMD_UNFUSED_MIX", "1")
         torch.manual_seed(5)
         losses = []
-        params, _, _ = bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, make, kw, 0.01, "Adam", False, loss_save=losses)
+        params, _, _ = bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, make, kw, 0.01, "Adam", train_ar, loss_save=losses)
         runs.append((losses, [p.detach().cpu().numpy().copy() for p in params]))
     monkeypatch.delenv("BEAR_AMD_UNFUSED_MIX")
     assert np.allclose(runs[0][0], runs[1][0], rtol=1e-10)
