@@ -144,3 +144,42 @@ def test_bear_ref_train_fused_mixing_equals_the_three_launches(net, train_ar, mo
     assert np.allclose(runs[0][0], runs[1][0], rtol=1e-10)
     for a, b in zip(runs[0][1], runs[1][1]):
         assert np.allclose(a, b, rtol=1e-7, atol=1e-9)
+
+
+def test_refmix_plan_full_size_properties():
+    """1e7 contexts: the fused step == the three launches; its sums are the sums of two halves (each with its own plan); repeated
+    launches agree; a sampled chunk equals the oracle chain."""
+    from bear_amd import kernels
+    dev = torch.device("cuda", 0)
+    N = 10_000_019
+    t = kernels.synth_counts(20211012, 0, N, dev, want=("train", "ref"))
+    g = kernels.synth_prior(3, 0, N, dev)
+    ref_in = t["ref"].to(torch.float64) + 1e-7
+    ref_in[:, -1] = 0
+    args = (-0.3, float(np.log(1 / 30)) + 0.2, -1.5)
+    hp, tp, wp = _scalars(dev, *args)
+    plan = kernels.Plan(t["train"], 5)
+    runs = [kernels.dm_refmix_planned_dev(plan, g, ref_in, hp, tp, wp) for _ in range(4)]
+    out, rows = runs[0][0].cpu().numpy(), runs[0][1]
+    for o2, r2 in runs[1:]:
+        assert np.allclose(o2.cpu().numpy(), out, rtol=1e-13, atol=0) and torch.equal(r2, rows)
+    f = kernels.ref_mix_forward(g, ref_in, tp, wp)
+    out2, q = kernels.dm_prior_planned_dev(plan, f, hp.reshape(1), want_grad=True, normalized=True)
+    rows2, sc = kernels.ref_mix_backward(g, ref_in, q, tp, wp)
+    want = np.r_[out2.cpu().numpy(), sc.cpu().numpy()]
+    assert np.allclose(out, want, rtol=1e-11), (out, want)
+    assert float((rows - rows2).abs().max()) <= 1e-12 * float(rows2.abs().max())
+    cut = 5_000_004
+    parts = np.zeros(4)
+    for lo, hi in ((0, cut), (cut, N)):
+        tr = t["train"][lo:hi].clone()
+        o_p, r_p = kernels.dm_refmix_planned_dev(kernels.Plan(tr, 5), g[lo:hi].clone(), ref_in[lo:hi].clone(), hp, tp, wp)
+        parts += o_p.cpu().numpy()
+        assert float((r_p - rows[lo:hi]).abs().max()) <= 1e-13 * float(rows.abs().max())
+    assert np.allclose(parts, out, rtol=1e-11)
+    lo, hi = 7_000_001, 7_050_001
+    tr = t["train"][lo:hi].cpu().numpy().view(np.uint32)
+    fc = o.ref_ar_func(g[lo:hi].cpu().numpy(), ref_in[lo:hi].cpu().numpy(), args[1], args[2])
+    _, G = co.dm_prior(tr, fc, args[0], want_grad=True, nthreads=4)
+    nw = np.exp(args[2])
+    assert np.allclose(rows[lo:hi].cpu().numpy(), G * nw / (nw + 1), rtol=GRAD_RTOL, atol=GRAD_RTOL * np.abs(G).max())
