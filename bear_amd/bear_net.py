@@ -9,7 +9,7 @@ log-likelihood, its gradient w.r.t. ``h_signed`` and w.r.t. the AR rows come fro
 import numpy as np
 import torch
 
-from . import _train, core, dist, kernels
+from . import _train, ar_funcs, core, dist, kernels
 
 epsilon = core.epsilon
 
@@ -110,7 +110,8 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
     if use_train:
         cols["train"] = ds_loc_train
     # only the contexts with held-out counts are kept resident: nothing else enters any sum (their table rows travel as row_ids)
-    res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test", per_row_extra=60)   # prior rows + plan
+    res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test", per_row_extra=60,   # prior rows + plan
+                                 kmer_order=ar_funcs.wants_kmer_order(ar_func))
     total = None
     with torch.no_grad():
         for k, e in enumerate(res.batches):

@@ -137,7 +137,10 @@ def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_
     rows (``bear_linear_forward_f64`` / ``bear_cnn_forward_f64``), the planned kernel returns the ELBO, d/dh and the gradient
     rows, and autograd carries the rows back through the matching backward launches to tau, the net weight and the net
     parameters -- the same loop as bear_net.train with two more parameters."""
+    # a fused net function (linear rows / cnn kernels) shares work between neighbouring contexts: batches are kept in k-mer order
+    # (the sums do not depend on the order; cnn forward + backward 70 instead of 137 ms per 1e8 contexts, linear backward 1.45 / 2.0)
     res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device, want_codes=True, drop_empty="train",
+                                 kmer_order=bool(getattr(getattr(ar_func, "net_func", None), "fused", False)),
                                  prebuild=[("train", 5, None)], per_row_extra=120)
 
     def prior_fn_inputs(e):
@@ -182,7 +185,8 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
     if use_train:
         cols["train"] = ds_loc_train
     # only the contexts with held-out counts are kept resident: nothing else enters any sum (their table rows travel as row_ids)
-    res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test", per_row_extra=60)   # prior rows + plan
+    res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test", per_row_extra=60,   # prior rows + plan
+                                 kmer_order=_ar_funcs.wants_kmer_order(getattr(ar_func, "net_func", ar_func)))
     hv = float(torch.as_tensor(h).item()) if np.ndim(torch.as_tensor(h).detach().cpu().numpy()) == 0 else torch.as_tensor(h).detach().cpu().numpy()
     total = None
     with torch.no_grad():

@@ -11,7 +11,7 @@ import torch
 from scipy.special import loggamma
 
 import bear_oracle as o
-from bear_amd import ar_funcs, bear_net, bear_ref, core, dataloader, kernels
+from bear_amd import _train, ar_funcs, bear_net, bear_ref, core, dataloader, kernels
 from conftest import ROOT, YSD1
 
 pytestmark = pytest.mark.gpu
@@ -232,6 +232,42 @@ def test_evaluation_keeps_only_the_contexts_with_heldout_counts(tmp_path, monkey
     w = o.evaluation_step(te, prior, float(torch.tensor(0.37)), van, tr, rng=o.HashNoise(11, 0, n))     # (the float32 the call passes)
     assert np.isclose(compact[0], w[0], rtol=1e-11) and np.allclose(compact[2], w[2], rtol=1e-11)
     assert np.all(np.abs(compact[8] - w[5] / w[6]) < 1e-12)
+
+
+def test_evaluation_with_the_fused_cnn_keeps_batches_in_kmer_order(tmp_path, monkeypatch):
+    """An evaluation with the fused convolutional AR function sorts every resident batch by k-mer (its forward kernel evaluates a
+    window that neighbouring contexts share once); the tie noise is keyed by table row, so every result equals the oracle's on the
+    table in file order -- accuracies exactly -- and bear_ref's evaluation with the cnn net function does the same."""
+    from util import sparse_table
+    n = 5000
+    tr, te, rf = sparse_table(n, 33)
+    rng = np.random.default_rng(9)
+    km = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 5))]
+    path = tmp_path / "cnn_eval.tsv"
+    dataloader.write_counts_tsv(str(path), km, np.stack([tr, te, rf]))
+    data = dataloader.dataloader(str(path), "dna", 2000, 3)
+    torch.manual_seed(3)
+    f, p = ar_funcs.make_ar_func_cnn(5, 4, device="cuda", **CNN_CFG)
+    assert f.fused and ar_funcs.wants_kmer_order(f) and not ar_funcs.wants_kmer_order(ar_funcs.make_ar_func_linear(5, 4, device="cuda")[0])
+    orders = []
+    orig = _train.sort_by_kmer
+    monkeypatch.setattr(_train, "sort_by_kmer", lambda codes, lag: (orders.append(codes.shape[0]), orig(codes, lag))[1])
+    van = np.array([0.1, 1.0, 10.0])
+    got = bear_net.evaluation(data, 0, 1, "dna", torch.tensor(0.37), f, van, seed=11)
+    assert len(orders) == 3                                   # three batches, each sorted once
+    prior = o.ar_func_cnn(o.one_hot([bytes(r).decode() for r in km]), [q.detach().cpu().numpy() for q in p])
+    w = o.evaluation_step(te, prior, float(torch.tensor(0.37)), van, tr, rng=o.HashNoise(11, 0, n))
+    assert np.isclose(got[0], w[0], rtol=1e-11) and np.isclose(got[1], w[1], rtol=1e-11) and np.allclose(got[2], w[2], rtol=1e-11)
+    # (BEAR / AR accuracies: the prior rows come from the HIP kernel here and from NumPy in the oracle: a near-tie row may flip)
+    assert abs(float(got[6]) - w[3] / w[6]) < 1e-3 and abs(float(got[7]) - w[4] / w[6]) < 1e-3
+    assert np.all(np.abs(np.asarray(got[8]) - w[5] / w[6]) < 1e-12)     # vanilla models: integer concentrations + the same noise: exact
+    # the order is not the result: the same evaluation over batches left in file order
+    monkeypatch.setattr(ar_funcs, "wants_kmer_order", lambda f: False)
+    plain = bear_net.evaluation(data, 0, 1, "dna", torch.tensor(0.37), f, van, seed=11)
+    assert len(orders) == 3
+    for a, b in zip(got, plain):
+        assert np.allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=1e-12, atol=0)
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got[6:], plain[6:]))       # accuracies exactly
 
 
 def test_uploader_and_hbm_budget(monkeypatch, ysd1):
