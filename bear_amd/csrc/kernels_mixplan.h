@@ -17,7 +17,7 @@
 //   * a row pass turns (g, r) into (f, d) in place; an item reads f and d of its own cell, adds its terms, leaves u P in the
 //     d cell and marks the f cell with the sign bit (f >= 0; a cell belongs to at most one item); a second row pass forms
 //     d/dg = (marked ? u P : 0) - u P(A, n) per cell, scaled by nw / (nw + 1), and the rows leave as one coalesced stream.
-// Single-buffered like dm_prior_plan_grad_kernel (two row buffers fill the LDS), with its L2 prefetch of the next tile.
+// Single-buffered like dm_prior_plan_grad_kernel (two row buffers fill the LDS).
 // Rows g must be normalised (every reference net function ends in a softmax) and the alphabet has four letters.  Items and
 // contexts in the plan's global overflow lists (very dense tiles only) are handled by the epilogue and dm_refmix_fixup_kernel.
 // AR (train_ar, the multinomial of core.py:138-139): sum LL = sum c log(f + eps), q = c / (f + eps) on item cells only, no context
@@ -134,17 +134,9 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
       }
     }
     srt_sync();
-    // the tile this block takes next into the L2 while this one's items are computed and its rows stored (dm_prior_plan_grad_kernel)
-    if (wave < 10u) {
-      const pln_tile nx = pln_load_tile(pv, t + gridDim.x);
-      const uint32_t nbytes = (nx.rows_items >> 16) * 40u;
-      if (wave < 9u) {
-        pln_touch_lines(S.pf_scratch, net_rows + nx.row0 * 5, nbytes, wave, lane);
-        pln_touch_lines(S.pf_scratch, ref_rows + nx.row0 * 5, nbytes, wave, lane);
-      } else {
-        pln_touch_lines(S.pf_scratch, pv.stream + (size_t)nx.off16 * 16, nx.blk16 * 16u, 0u, lane);
-      }
-    }
+    // (No L2 prefetch of the next tile here, unlike dm_prior_plan_grad_kernel: two row arrays per tile are more than the L2 holds next
+    // to the tiles in flight -- touching both bought nothing, 2.62 ms either way, and 60 of 146 B per context fetched twice; the net
+    // rows alone 2.52 ms at 111 B.  Without it FETCH_SIZE is the algorithmic 87 B.)
     // ---- 2: item units (tickets, dearest first): sum LL, d/dh, the two parameter sums; u P into the d cell, the f cell marked
     // (o.D = the item's log-likelihood term, o.P = q / u: BEAR mode D, P of the DM item; multinomial mode c log(f + eps), c / (f + eps) / u)
     auto item = [&](uint32_t off, double x, double fb, const bear_dp &o, bool on) {

@@ -40,6 +40,7 @@ def kernel_key(k):
     if "cnn_forward" in k: return "cnn_forward"
     if "cnn_backward" in k: return "cnn_backward"
     if "dm_linear" in k: return "linear_head"
+    if "dm_refmix_plan" in k: return "ref_mix_dm_step"
     if "plan_grad_inplace" in k: return "net_grad_inplace"
     if "plan_grad_kernel" in k: return "net_grad"
     if "linear_rows_forward" in k: return "linear_rows_forward"
@@ -63,7 +64,7 @@ for kind in ("fetch", "write", "sq"):
     if not agg: continue
     out_md += [f"## PMC pass: {kind}", "", "| kernel | counter | mean per launch |", "|---|---|---|"]
     for k, v in agg.items():
-        if not any(x in k for x in ("plan_kernel", "plan_grad_kernel", "plan_grad_inplace", "sorted", "eval_", "cnn_", "items_kernel", "linear_rows", "ref_mix")): continue
+        if not any(x in k for x in ("plan_kernel", "plan_grad_kernel", "plan_grad_inplace", "sorted", "eval_", "cnn_", "items_kernel", "linear_rows", "ref_mix", "refmix")): continue
         for c, x in v.items():
             out_md.append(f"| `{k[:40]}` | {c} | {sum(x)/len(x):.0f} |")
             name = kernel_key(k)
@@ -77,7 +78,7 @@ for kind in ("fetch", "write", "sq"):
         # SQ_BUSY_CYCLES sums the 32 shader engines, SQ_ACTIVE_INST_VALU counts quad-cycles over all 1024 SIMDs:
         # fraction of the kernel's cycles a SIMD spends issuing vector-ALU instructions = ACTIVE_VALU * 4 / (BUSY / 32 * 1024)
         for k, v in agg.items():
-            if not any(x in k for x in ("plan_kernel", "plan_grad_kernel", "plan_grad_inplace", "eval_", "cnn_", "items_kernel", "linear_rows", "ref_mix")): continue
+            if not any(x in k for x in ("plan_kernel", "plan_grad_kernel", "plan_grad_inplace", "eval_", "cnn_", "items_kernel", "linear_rows", "ref_mix", "refmix")): continue
             mean = {c: sum(x) / len(x) for c, x in v.items()}
             if mean.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in mean:
                 d = traffic.setdefault(kernel_key(k), {})
