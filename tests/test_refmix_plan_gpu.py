@@ -124,8 +124,8 @@ def test_refmix_plan_rows_without_counts_and_ragged_tiles():
     assert np.allclose(rows[keep], G * nw / (nw + 1), rtol=GRAD_RTOL, atol=GRAD_RTOL * np.abs(G).max())
 
 
-@pytest.mark.parametrize("net,train_ar", [("linear", False), ("cnn", False), ("linear", True)])
-def test_bear_ref_train_fused_mixing_equals_the_three_launches(net, train_ar, monkeypatch):
+@pytest.mark.parametrize("net,train_ar,acc_steps", [("linear", False, 1), ("cnn", False, 1), ("linear", True, 1), ("linear", False, 2)])
+def test_bear_ref_train_fused_mixing_equals_the_three_launches(net, train_ar, acc_steps, monkeypatch):
     """bear_ref.train with a net function that has parameters: the loop with the mixing inside the DM kernel against the loop
     that mixes, takes gradient rows and goes back through the mixing in three launches (BEAR_AMD_UNFUSED_MIX=1)."""
     from bear_amd import _train, ar_funcs, bear_ref, dataloader
@@ -138,7 +138,8 @@ def test_bear_ref_train_fused_mixing_equals_the_three_launches(net, train_ar, mo
             monkeypatch.setenv("BEAR_AMD_UNFUSED_MIX", "1")
         torch.manual_seed(5)
         losses = []
-        params, _, _ = bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, make, kw, 0.01, "Adam", train_ar, loss_save=losses)
+        params, _, _ = bear_ref.train(data.repeat(3), 1365, 3, 0, 2, "dna", 5, make, kw, 0.01, "Adam", train_ar, acc_steps=acc_steps,
+                                      loss_save=losses)
         runs.append((losses, [p.detach().cpu().numpy().copy() for p in params]))
     monkeypatch.delenv("BEAR_AMD_UNFUSED_MIX")
     assert np.allclose(runs[0][0], runs[1][0], rtol=1e-10)
