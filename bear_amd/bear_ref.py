@@ -132,11 +132,12 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
 
 def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_ar, acc_steps, writer, loss_save,
                    ds_loc, ds_loc_ref, device):
-    """bear_ref.train with a parametrised net function (linear, cnn; bear_ref.py:63-68): the mixed prior rows
-    ``(nw net(kmers) + jukes_cantor(ref, tau)) / (nw + 1)`` are formed by ``bear_ref_mix_forward_f64`` from the net function's
-    rows (``bear_linear_forward_f64`` / ``bear_cnn_forward_f64``), the planned kernel returns the ELBO, d/dh and the gradient
-    rows, and autograd carries the rows back through the matching backward launches to tau, the net weight and the net
-    parameters -- the same loop as bear_net.train with two more parameters."""
+    """bear_ref.train with a parametrised net function (linear, cnn; bear_ref.py:63-68).  Per batch: the net function's rows
+    (``bear_linear_forward_f64`` / ``bear_cnn_forward_f64`` behind autograd), then ONE launch of ``bear_dm_refmix_plan_grad_f64``
+    -- the mixing ``(nw net + jukes_cantor(ref, tau)) / (nw + 1)``, sum LL, d/dh, d/dtau, d/dnet_weight and d/d(net rows) -- and
+    the net function's backward launch.  Net rows that are not asserted normalised (a plugin without ``normalized_rows``) take
+    three launches instead: ``bear_ref_mix_forward_f64``, the planned kernel with gradient rows, ``bear_ref_mix_backward_f64``
+    through autograd -- the same loop as bear_net.train with two more parameters."""
     # a fused net function (linear rows / cnn kernels) shares work between neighbouring contexts: batches are kept in k-mer order
     # (the sums do not depend on the order; cnn forward + backward 70 instead of 137 ms per 1e8 contexts, linear backward 1.45 / 2.0)
     res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device, want_codes=True, drop_empty="train",
