@@ -144,7 +144,8 @@ def load_text(seq_list_file, reverse=False):
         got = ctypes.c_uint64()
         _lib.check(L.bear_fastx_encode(path.encode(), int(ftype == "fq"), int(bool(reverse)), int(group), n.value, text.ctypes.data,
                                        grp.ctypes.data, ctypes.byref(got)), "bear_fastx_encode")
-        assert got.value == n.value
+        if got.value != n.value:      # the file changed between the sizing pass and the encoding pass
+            raise RuntimeError(f"{path}: {got.value} positions encoded, {n.value} counted")
         parts.append(text)
         gparts.append(grp)
         groups.append(group)
