@@ -15,6 +15,8 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEAR_AMD_LIB") or os.path.join(_HERE, "libbear_hip.so")  # env: developer A/B builds
 
+ABI_VERSION = 4   # BEAR_ABI_VERSION of include/bear_hip.h the argtypes below were written against
+
 SYMBOLS = [
     "bear_abi_version", "bear_strerror", "bear_last_hip_error", "bear_ws_create", "bear_ws_destroy",
     "bear_dm_prior_f64", "bear_dm_ref_f64", "bear_dm_items_f64", "bear_eval_f64", "bear_bmm_f64", "bear_pack_kmers_u64", "bear_linear_index_u64", "bear_parse_sparse_counts", "bear_plan_tile_count", "bear_plan_tile_info", "bear_dm_linear_f64",
@@ -52,6 +54,10 @@ def _load():
     L = ctypes.CDLL(LIB_PATH)
     vp, u64, dbl, cint = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_double, ctypes.c_int
     L.bear_abi_version.restype = cint
+    if L.bear_abi_version() != ABI_VERSION:
+        # a library from another tree may export every symbol and still take its arguments in another order
+        raise ImportError(f"{LIB_PATH} speaks ABI version {L.bear_abi_version()}, this binding was written for {ABI_VERSION}: "
+                          f"rebuild it with `make -C {os.path.join(_HERE, 'csrc')}`")
     L.bear_strerror.restype = ctypes.c_char_p
     L.bear_strerror.argtypes = [cint]
     L.bear_last_hip_error.restype = cint
@@ -123,7 +129,7 @@ def _load():
     L.bear_eval_plan_destroy.argtypes = [vp]
     L.bear_eval_plan_bytes.argtypes = [vp]
     L.bear_eval_plan_bytes.restype = u64
-    L.bear_kmer_order_u64.argtypes = [vp, u64, cint, vp, vp]
+    L.bear_kmer_order_u64.argtypes = [vp, u64, cint, vp, vp, ctypes.POINTER(u64), vp]
     L.bear_gather_rows.argtypes = [vp, vp, vp, u64, ctypes.c_uint32, vp]
     L.bear_eval_plan_f64.argtypes = [vp, vp, vp, vp, vp, u64, vp, cint, cint, vp, cint, dbl, u64, u64, vp, vp, vp]
     L.bear_count_rows.argtypes = [ctypes.c_char_p, ctypes.POINTER(u64)]

@@ -170,7 +170,13 @@ def hbm_budget_check(data, n_columns, want_codes, device, rows=None, per_row_ext
     rows = data.local_rows if rows is None else rows
     lag = data.lag
     need = rows * (20 * n_columns + (lag + 8 if want_codes else 0) + 8 + per_row_extra)
+    # (the k-mer sort's scratch, ~20 B per row of ONE batch at a time, is a torch tensor and fits the 15 % margin below)
     need = int(need * 1.15) + (256 << 20)           # the upload holds a column next to its compacted copy for a moment
+    # blocks the caching allocator holds but nobody uses (an earlier train() call's slabs, allocated on another Uploader's side
+    # stream and so not reusable from this one's pool) are given back first: mem_get_info does not count them as free
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     free, total = torch.cuda.mem_get_info(device)
     if need > free:
         raise MemoryError(f"this rank's {rows} contexts need about {need / 2**30:.1f} GiB of HBM resident ({n_columns} count column(s)"
@@ -282,6 +288,10 @@ class ResidentBatches:
                 order = sort_by_kmer(entry["codes"], data.lag)
                 for name in names + (["row_ids"] if "row_ids" in entry else []):
                     entry[name] = kernels.gather_rows(entry[name], order)
+                if "row_ids" not in entry:
+                    # no row was dropped, but row i is no longer table row row0 + i: the permutation itself says where each row sits
+                    # (the evaluation's tie-breaking noise is keyed by the table row, whatever the order or the sharding)
+                    entry["row_ids"] = order.to(torch.int32).contiguous()
                 del order
             self.batches.append(entry)
             if entry["rows"]:

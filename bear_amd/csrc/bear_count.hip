@@ -245,30 +245,37 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const unsigned char *_
 }
 }  // namespace
 
-extern "C" int bear_kmer_order_u64(const uint64_t *kmer_code, uint64_t n_rows, int lag, uint32_t *perm, void *stream) {
-  if ((n_rows && (!kmer_code || !perm)) || lag < 1 || lag > 21 || n_rows > 0xffffffffull) return BEAR_ERR_INVALID_ARG;
-  if (n_rows == 0) return BEAR_OK;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  int st = BEAR_OK;
-  unsigned long long *keys_in = nullptr, *keys_out = nullptr;
-  uint32_t *vals_in = nullptr;
-  void *temp = nullptr;
+extern "C" int bear_kmer_order_u64(const uint64_t *kmer_code, uint64_t n_rows, int lag, uint32_t *perm, void *scratch,
+                                   uint64_t *scratch_bytes, void *stream) {
+  if (!scratch_bytes || lag < 1 || lag > 21 || n_rows > 0xffffffffull) return BEAR_ERR_INVALID_ARG;
+  // caller-owned scratch: two key arrays, the identity values, rocPRIM's temporary storage (each piece 256-byte aligned)
+  const uint64_t keys_b = (n_rows * 8 + 255) & ~255ull, vals_b = (n_rows * 4 + 255) & ~255ull;
   size_t tb = 0;
-  CNT_TRY(hipMalloc(&keys_in, n_rows * 8));
-  CNT_TRY(hipMalloc(&keys_out, n_rows * 8));
-  CNT_TRY(hipMalloc(&vals_in, n_rows * 4));
-  hipLaunchKernelGGL(order_keys_kernel, dim3(grid_for(n_rows)), dim3(256), 0, s, reinterpret_cast<const unsigned long long *>(kmer_code),
-                     n_rows, lag, keys_in, vals_in);
-  CNT_TRY(hipGetLastError());
-  CNT_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys_out, vals_in, perm, n_rows, 0u, (unsigned)(3 * lag), s));
-  CNT_TRY(hipMalloc(&temp, tb ? tb : 8));
-  CNT_TRY(rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, vals_in, perm, n_rows, 0u, (unsigned)(3 * lag), s));
-  CNT_TRY(hipStreamSynchronize(s));        // the scratch goes away with this call (set-up path: once per batch)
+  int st = BEAR_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_rows)
+    CNT_TRY(rocprim::radix_sort_pairs(nullptr, tb, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr,
+                                      (uint32_t *)nullptr, n_rows, 0u, (unsigned)(3 * lag), s));
+  {
+    const uint64_t need = n_rows ? 2 * keys_b + vals_b + (tb ? tb : 8) : 0;
+    if (!scratch) {            // size query
+      *scratch_bytes = need;
+      return BEAR_OK;
+    }
+    if (n_rows == 0) return BEAR_OK;
+    if (!kmer_code || !perm || *scratch_bytes < need || (reinterpret_cast<uintptr_t>(scratch) & 255)) return BEAR_ERR_INVALID_ARG;
+    unsigned char *base = static_cast<unsigned char *>(scratch);
+    unsigned long long *keys_in = reinterpret_cast<unsigned long long *>(base);
+    unsigned long long *keys_out = reinterpret_cast<unsigned long long *>(base + keys_b);
+    uint32_t *vals_in = reinterpret_cast<uint32_t *>(base + 2 * keys_b);
+    void *temp = base + 2 * keys_b + vals_b;
+    hipLaunchKernelGGL(order_keys_kernel, dim3(grid_for(n_rows)), dim3(256), 0, s, reinterpret_cast<const unsigned long long *>(kmer_code),
+                       n_rows, lag, keys_in, vals_in);
+    CNT_TRY(hipGetLastError());
+    // stream-ordered from here on: the scratch is the caller's, nothing is freed and nothing waits on the host
+    CNT_TRY(rocprim::radix_sort_pairs(temp, tb, keys_in, keys_out, vals_in, perm, n_rows, 0u, (unsigned)(3 * lag), s));
+  }
 done:
-  if (temp) (void)hipFree(temp);
-  if (keys_in) (void)hipFree(keys_in);
-  if (keys_out) (void)hipFree(keys_out);
-  if (vals_in) (void)hipFree(vals_in);
   return st;
 }
 

@@ -38,12 +38,18 @@ _default_ws = {}
 
 
 def default_workspace(device):
+    """The workspace of (device, current stream).  A workspace serves ONE stream at a time (include/bear_hip.h: its block
+    partials and the arrival counter of the "last block finalizes" kernels are per-launch state), so a side stream gets its own;
+    a stream that is capturing a graph shares the device's first workspace (nothing may be allocated during capture, and a
+    capture orders every launch of the step on that one stream anyway)."""
     idx = torch.device(device).index
     if idx is None:
         idx = torch.cuda.current_device()
-    ws = _default_ws.get(idx)
+    stream = torch.cuda.current_stream(idx)
+    key = (idx, 0 if (stream == torch.cuda.default_stream(idx) or torch.cuda.is_current_stream_capturing()) else stream.cuda_stream)
+    ws = _default_ws.get(key)
     if ws is None:
-        ws = _default_ws[idx] = Workspace(torch.device("cuda", idx))
+        ws = _default_ws[key] = Workspace(torch.device("cuda", idx))
     return ws
 
 
@@ -421,13 +427,24 @@ def shuffle_rows(src, seed):
 
 def kmer_order(kmer_code, lag):
     """``bear_kmer_order_u64``: int32-storage permutation [n] that sorts packed contexts (``pack_kmers``) lexicographically, first
-    letter most significant, stable.  Synchronises the current stream (set-up path)."""
+    letter most significant, stable.  Stream-ordered: the sort's scratch (``kmer_order_scratch_bytes``: ~20 B per row) is a torch
+    tensor, so it comes out of -- and goes back to -- the caching allocator like every other slab."""
     _check_codes(kmer_code)
-    perm = torch.empty(kmer_code.shape[0], dtype=torch.int32, device=kmer_code.device)
+    n = kmer_code.shape[0]
+    perm = torch.empty(n, dtype=torch.int32, device=kmer_code.device)
+    nbytes = ctypes.c_uint64(kmer_order_scratch_bytes(n, lag))
+    scratch = torch.empty(max(int(nbytes.value), 1), dtype=torch.uint8, device=kmer_code.device)
     with torch.cuda.device(kmer_code.device):
-        st = _lib.lib().bear_kmer_order_u64(_ptr(kmer_code), kmer_code.shape[0], int(lag), _ptr(perm), _stream())
+        st = _lib.lib().bear_kmer_order_u64(_ptr(kmer_code), n, int(lag), _ptr(perm), _ptr(scratch), ctypes.byref(nbytes), _stream())
     _lib.check(st, "bear_kmer_order_u64")
     return perm
+
+
+def kmer_order_scratch_bytes(n_rows, lag):
+    """Device scratch ``bear_kmer_order_u64`` asks of its caller for a batch of n_rows contexts."""
+    nbytes = ctypes.c_uint64(0)
+    _lib.check(_lib.lib().bear_kmer_order_u64(None, int(n_rows), int(lag), None, None, ctypes.byref(nbytes), None), "bear_kmer_order_u64")
+    return int(nbytes.value)
 
 
 def gather_rows(src, perm):

@@ -121,13 +121,48 @@ def parse_args():
     return ap.parse_args()
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher (the reference needs none for its replicas either: MirroredStrategy() inside
+    the process, bear_net.py:246).  One process per GPU is this framework's model, so the bare command starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same args>`
+    as a CHILD process (never an exec: this process stays alive, has not initialised the GPU and does not), relays rank 0's JSON
+    line on stdout (anything else the ranks print goes to stderr) and returns the child's exit code -- non-zero when any rank
+    dies; no retry, no fallback to fewer ranks."""
+    import socket
+    import subprocess
+    if "BEAR_BENCH_DEVICE" not in os.environ:        # (that override puts every rank on one card: single-GPU tests of this path)
+        have = torch.cuda.device_count()             # counting devices does not initialise the GPU
+        if have < n_ranks:
+            print(f"bench.py: --gpus {n_ranks} but this node shows {have} GPU(s)", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BEAR_BENCH_LAUNCHER="self")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_ranks) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in child.stdout:                                  # stderr is inherited: the ranks' diagnostics stream through live
+        if ln.startswith('{"metric"'):
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+        else:
+            sys.stderr.write(ln)
+    return child.wait()
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: this process becomes the launcher (it never touches the GPU) and the ranks are its children
+        raise SystemExit(self_launch(args.gpus))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the two must agree")
     assert torch.cuda.is_available(), "bench.py needs MI355X devices"
     dev_index = int(os.environ.get("BEAR_BENCH_DEVICE", local_rank))  # override only for single-GPU smoke tests
     torch.cuda.set_device(dev_index)
@@ -250,11 +285,11 @@ def main():
             el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
             elapsed = float(el.item())
-            mine = torch.tensor([k_ms, ar_ms, float(n)], dtype=torch.float64, device=dev)
+            mine = torch.tensor([k_ms, ar_ms, float(n), float(dev_index)], dtype=torch.float64, device=dev)
             allr = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allr, mine)
-            per_rank = [{"rank": r, "contexts": int(v[2].item()), "kernel_ms": float(v[0].item()), "allreduce_ms": float(v[1].item())}
-                        for r, v in enumerate(allr)]
+            per_rank = [{"rank": r, "device": int(v[3].item()), "contexts": int(v[2].item()), "kernel_ms": float(v[0].item()),
+                         "allreduce_ms": float(v[1].item())} for r, v in enumerate(allr)]
         return elapsed, k_ms, outs[wl].cpu().numpy().copy(), stats, settle_info, per_rank
 
     primary = args.workload
@@ -546,6 +581,10 @@ def main():
                 "measured_stream_read_GBps": stream_gbps,
             },
             "settle": settle_info,
+            # what the collective actually ran on: the process group's own world size and backend (nccl = RCCL), how the ranks were started
+            "ranks": {"world_size": dist.get_world_size() if multi else 1, "backend": dist.get_backend() if multi else None,
+                      "launcher": os.environ.get("BEAR_BENCH_LAUNCHER", "external") if "WORLD_SIZE" in os.environ else "none (one process)",
+                      "devices": [e["device"] for e in per_rank] if per_rank else [dev_index]},
             "per_rank": per_rank,
             "plan_build_s": plan_build_s,
             "plan_bytes_per_context": plans[primary].nbytes / n,

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BEAR_ABI_VERSION 2
+#define BEAR_ABI_VERSION 4
 #define BEAR_ROW_WIDTH 5 /* alphabet_size + 1 for dna/rna */
 
 typedef enum bear_status {
@@ -56,7 +56,10 @@ const char *bear_strerror(int status);
 /* hipError_t of the most recent failing HIP call on this thread (0 if none). */
 int bear_last_hip_error(void);
 
-/* Allocates the workspace on `device` (makes no change to the caller's current device). */
+/* Allocates the workspace on `device` (makes no change to the caller's current device).
+ * A workspace serves ONE stream at a time: the block partials and the arrival counter of the kernels whose last block
+ * forms the final sums are per-launch state, so launches that may overlap (two streams, two host threads) each take
+ * their own workspace; launches ordered on one stream share one freely. */
 int bear_ws_create(int device, bear_ws **out);
 int bear_ws_destroy(bear_ws *ws);
 
@@ -474,12 +477,16 @@ uint64_t bear_shuffle_source_row(uint64_t i, uint64_t n_rows, uint64_t seed);
  * batch, before bear_plan_create (a plan is tied to the row order of the count slab it was built from):
  *   bear_kmer_order_u64: perm [dev] uint32 [n_rows] such that kmer_code[perm[0]] <= kmer_code[perm[1]] <= ... lexicographically
  *                        with the FIRST letter most significant (stable: equal contexts keep their order); kmer_code [dev] is
- *                        the bear_pack_kmers_u64 form; n_rows < 2^32.  Synchronises `stream` (scratch is freed on return).
+ *                        the bear_pack_kmers_u64 form; n_rows < 2^32.  The scratch is the CALLER's: call once with
+ *                        scratch = NULL to get the size in *scratch_bytes (about 20 B per row + rocPRIM's temporary storage),
+ *                        then with a 256-byte aligned device buffer of at least that size (*scratch_bytes = its size).
+ *                        Asynchronous on `stream`: nothing is allocated, freed or waited for on the host.
  *   bear_gather_rows:    dst[i] = src[perm[i]] for rows of row_bytes bytes (20: a count slab; 8: packed contexts; lag: k-mer
  *                        bytes); dst != src; asynchronous on `stream`.
  * bear_amd.bear_net.train does exactly this at upload (bear_amd/_train.py: ResidentBatches(kmer_order=True)).
  */
-int bear_kmer_order_u64(const uint64_t *kmer_code, uint64_t n_rows, int lag, uint32_t *perm, void *stream);
+int bear_kmer_order_u64(const uint64_t *kmer_code, uint64_t n_rows, int lag, uint32_t *perm, void *scratch, uint64_t *scratch_bytes,
+                        void *stream);
 int bear_gather_rows(const void *src, const uint32_t *perm, void *dst, uint64_t n_rows, uint32_t row_bytes, void *stream);
 
 /*

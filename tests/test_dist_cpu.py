@@ -88,3 +88,23 @@ def test_gloo_step(tmp_path, world):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "DIST_OK" in p.stdout
+
+
+def test_bench_bare_multi_gpu_command_fails_loudly_without_the_devices():
+    """`python3 bench.py --gpus N` without a launcher: the parent counts the devices BEFORE it starts any rank (no GPU in this
+    container -> exit code 2 and a message, nothing spawned), and with the ranks started (BEAR_BENCH_DEVICE puts them all on one
+    card, which does not exist here) a rank that dies makes the whole command fail -- no JSON line, non-zero exit code."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BEAR_BENCH_DEVICE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "--gpus 2 but this node shows 0 GPU" in p.stderr and p.stdout == ""
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo"], env=dict(env, BEAR_BENCH_DEVICE="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and p.stdout == "" and "bench.py needs MI355X devices" in p.stderr

@@ -242,6 +242,33 @@ def test_bench_under_the_launcher_two_ranks(tmp_path):
     assert np.allclose(d["result"], want, rtol=1e-12), (d["result"], want)
 
 
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_bare_command_starts_its_own_ranks(scaling):
+    """`python3 bench.py --gpus N` with NO launcher and no WORLD_SIZE in the environment -- the shape of the driver's N = 1 command
+    with another N: the process starts torch.distributed.run itself as a child, relays rank 0's one line and exits with the
+    child's code (here: MANY ranks on cuda:0 over gloo)."""
+    from bear_amd import kernels
+    n = 2_000_000
+    env = dict(os.environ, BEAR_BENCH_DEVICE="0", GLOO_SOCKET_IFNAME="lo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(MANY), "--backend", "gloo", "--contexts", "2e6",
+                        "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--scaling", scaling],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith('{"metric"'), p.stdout[-2000:]      # stdout is the one line, nothing else
+    d = json.loads(lines[0])
+    total = n if scaling == "strong" else n * MANY
+    assert d["n_gpus"] == MANY and d["scaling"] == scaling and d["steps"] == 6 and d["config"]["contexts_total"] == total
+    assert d["ranks"] == {"world_size": MANY, "backend": "gloo", "launcher": "self", "devices": [0] * MANY}
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    dev = torch.device("cuda", 0)
+    t = kernels.synth_counts(20211012, 0, total, dev, want=("train",))["train"]
+    want = kernels.dm_prior_planned(kernels.Plan(t, 5), kernels.synth_prior(20211012, 0, total, dev), 0.0).cpu().numpy()
+    assert np.allclose(d["result"], want, rtol=1e-12), (d["result"], want)
+
+
 def test_bench_single_rank_line_is_consistent():
     """bench.py as the driver runs it at N = 1 (small table): one JSON line whose roofline object follows from its own
     kernel time, with the 'also' entries of the other kernels in it."""

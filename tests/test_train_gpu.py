@@ -268,6 +268,19 @@ def test_evaluation_with_the_fused_cnn_keeps_batches_in_kmer_order(tmp_path, mon
     for a, b in zip(got, plain):
         assert np.allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=1e-12, atol=0)
     assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got[6:], plain[6:]))       # accuracies exactly
+    # a batch that drops NO row (every row kept) is permuted all the same: the permutation is then its row_ids, or the noise would
+    # be keyed by the sorted position (round-3 advisor finding)
+    monkeypatch.undo()
+    monkeypatch.setenv("BEAR_AMD_ALL_ROWS", "1")
+    seen = []
+    orig_eval = kernels.evaluate_planned
+    monkeypatch.setattr(kernels, "evaluate_planned", lambda plan, *a, **kw: (seen.append((plan.test.shape[0], kw.get("row_ids") is not None)),
+                                                                            orig_eval(plan, *a, **kw))[1])
+    whole = bear_net.evaluation(data, 0, 1, "dna", torch.tensor(0.37), f, van, seed=11)
+    assert [r for r, _ in seen] == [2000, 2000, 1000] and all(ids for _, ids in seen)
+    for a, b in zip(got, whole):
+        assert np.allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=1e-12, atol=0)
+    assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got[6:], whole[6:]))
 
 
 def test_uploader_and_hbm_budget(monkeypatch, ysd1):
