@@ -75,6 +75,10 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
             if e["rows"] == 0:
                 return lambda packed: packed.zero_()
             plan = res.plan(k, "train", 5)           # built here, before any capture (plan creation allocates and synchronises)
+            if fused_mat is not None and packs[k].data_ptr() % 16 == 0:
+                # neighbours of the sorted batch that share all letters but the last three go through the step two at a time
+                # (kernels_linear.h, paired lists); declined by the library for tables too sparse to gain from it
+                plan.pair_contexts(packs[k], lag)
             if cnn_ok:
                 views = tuple(b[:e["rows"]] for b in bufs)
                 return lambda packed: kernels.net_cnn_train_reduce(plan, packs[k], lag, fw, theta, views, packed, train_ar=train_ar)

@@ -181,7 +181,7 @@ __device__ __forceinline__ bool bear_arrive_last(unsigned *arrive) {
 }
 
 // The arithmetic of finalize_kernel (256 threads, same order) inside the last block of the producing launch.
-__device__ __forceinline__ void bear_finalize_in_block(const double *partials, int n_out, double *out, unsigned *arrive) {
+__device__ __forceinline__ void bear_finalize_in_block(const double *partials, int n_out, double *out, unsigned *arrive, bool accumulate = false) {
   __shared__ double fred[4][BEAR_MAX_OUT];
   const int n_blocks = (int)gridDim.x;
   if (threadIdx.x < 256) {
@@ -198,7 +198,10 @@ __device__ __forceinline__ void bear_finalize_in_block(const double *partials, i
     }
   }
   __syncthreads();
-  if ((int)threadIdx.x < n_out) out[threadIdx.x] = (fred[0][threadIdx.x] + fred[1][threadIdx.x]) + (fred[2][threadIdx.x] + fred[3][threadIdx.x]);
+  if ((int)threadIdx.x < n_out) {
+    const double v = (fred[0][threadIdx.x] + fred[1][threadIdx.x]) + (fred[2][threadIdx.x] + fred[3][threadIdx.x]);
+    out[threadIdx.x] = accumulate ? out[threadIdx.x] + v : v;    // (accumulate: the second launch of a step that takes two)
+  }
   if (threadIdx.x == 0) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch (stream order) starts from zero
 }
 

@@ -86,12 +86,11 @@ int bear_ws_create(int device, bear_ws **out) {
       if (e == hipSuccess) e = hipMalloc(&ws->lin_partials, sizeof(double) * LIN_MAX_GRAD * (size_t)ws->num_cu);
       if (e == hipSuccess) e = hipMalloc(&ws->arrive, sizeof(unsigned));
       if (e == hipSuccess) e = hipMemset(ws->arrive, 0, sizeof(unsigned));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_linear_plan_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_lin));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_linear_plan_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_lin));
+      for (const void *fn : {reinterpret_cast<const void *>(dm_linear_plan_kernel<false, false>),
+                             reinterpret_cast<const void *>(dm_linear_plan_kernel<true, false>),
+                             reinterpret_cast<const void *>(dm_linear_plan_kernel<false, true>),
+                             reinterpret_cast<const void *>(dm_linear_plan_kernel<true, true>)})
+        if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_lin));
       if (e == hipSuccess) {
         // {r_i, -log r_i}: r_i = 1 / midpoint of the i-th mantissa cell of [0.5, 1) (bear_log_tab)
         double tab[2 * BEAR_LOGTAB_N];
@@ -302,6 +301,14 @@ struct bear_plan {
   uint64_t n_heavy[3];
   uint64_t n_live_rows;      // five-column plans: contexts that hold any count (the kernels that walk `live` skip the lists when all do)
   uint64_t bytes;
+  // bear_plan_pair_contexts: the paired form of `live` for the index words at pair_codes (kernels_linear.h), and the plan's
+  // tiles sorted into those that took it (tiles_p) and those that keep their plain list (tiles_u), each followed by PLN_DESC_PAD
+  // zeroed descriptors; spare word of a descriptor = tile number << 32 | entries of the paired list
+  uint16_t *live2;
+  pln_tile *tiles_p, *tiles_u;
+  uint64_t n_tiles_p, n_tiles_u;
+  const uint64_t *pair_codes;
+  int pair_lag;
   // reference-aware extension (bear_plan_create_ref, kernels_refplan.h)
   const uint32_t *ref;
   rpl_item *ref_items;
@@ -321,6 +328,9 @@ static void plan_free(bear_plan *p) {
   (void)hipFree(p->heavy_stop);
   (void)hipFree(p->hist);
   (void)hipFree(p->live);
+  (void)hipFree(p->live2);
+  (void)hipFree(p->tiles_p);
+  (void)hipFree(p->tiles_u);
   (void)hipFree(p->ref_items);
   (void)hipFree(p->hist0_base);
   (void)hipFree(p->heavy0);
@@ -604,6 +614,8 @@ static pln_view plan_view(const bear_plan *p) {
   v.heavy_stop = p->heavy_stop;
   v.hist = p->hist;
   v.live = p->live;
+  v.live2 = p->live2;
+  v.subset = 0;
   v.n_tiles = p->n_tiles;
   v.n_heavy_col = p->n_heavy[0];
   v.n_heavy_row = p->n_heavy[1];
@@ -935,6 +947,138 @@ int bear_encode_kmers_i8(const uint8_t *ascii, uint64_t n_rows, int lag, int rna
   return BEAR_OK;
 }
 
+// The fused step's launch.  A plan paired for exactly these index words (bear_plan_pair_contexts): the PAIRED form of the kernel
+// over the paired tiles and, when some tiles kept their plain list, a second launch of the plain form over those, which adds
+// its sums to the first one's (same stream: the workspace is free again when it starts).
+static void launch_linear(bear_ws *ws, const bear_plan *plan, const uint64_t *kmer_code, const double *mat, int lag, const bear_params &prm,
+                          int train_ar, const bear_step_io &io, double *grad_mat, hipStream_t s) {
+  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  const unsigned long long *kc = reinterpret_cast<const unsigned long long *>(kmer_code);
+  const bool paired = plan->live2 && plan->pair_codes == kmer_code && plan->pair_lag == lag && !getenv("BEAR_AMD_LINEAR_UNPAIRED");
+#define LIN_LAUNCH(AR, PAIRED, PV, NT, ACC)                                                                                             \
+  hipLaunchKernelGGL((dm_linear_plan_kernel<AR, PAIRED>), dim3(grid_plan(ws, NT)), dim3(PLN_THREADS), sizeof(pln_lds_lin), s, kc, mat,  \
+                     lag, prm, PV, lt, ws->partials, ws->lin_partials, io, grad_mat, ACC)
+  pln_view pv = plan_view(plan);
+  if (!paired) {
+    if (train_ar) LIN_LAUNCH(true, false, pv, plan->n_tiles, 0);
+    else LIN_LAUNCH(false, false, pv, plan->n_tiles, 0);
+    return;
+  }
+  pln_view pp = pv;           // the paired tiles; the plan's global lists and histogram go with this launch
+  pp.tiles = plan->tiles_p;
+  pp.n_tiles = plan->n_tiles_p;
+  pp.subset = 1;
+  if (train_ar) LIN_LAUNCH(true, true, pp, plan->n_tiles_p, 0);
+  else LIN_LAUNCH(false, true, pp, plan->n_tiles_p, 0);
+  if (plan->n_tiles_u == 0) return;
+  pln_view pu = pv;           // the rest: tiles only
+  pu.tiles = plan->tiles_u;
+  pu.n_tiles = plan->n_tiles_u;
+  pu.subset = 1;
+  pu.n_heavy_col = pu.n_heavy_row = pu.n_heavy_stop = 0;
+  pu.hist = nullptr;
+  if (train_ar) LIN_LAUNCH(true, false, pu, plan->n_tiles_u, 1);
+  else LIN_LAUNCH(false, false, pu, plan->n_tiles_u, 1);
+#undef LIN_LAUNCH
+}
+
+static void plan_unpair(bear_plan *plan) {
+  if (!plan->live2) return;
+  plan->bytes -= plan->n_tiles * LIN_LIVE2_STRIDE * sizeof(uint16_t) + (plan->n_tiles + 2 * PLN_DESC_PAD) * sizeof(pln_tile);
+  (void)hipFree(plan->live2);
+  (void)hipFree(plan->tiles_p);
+  (void)hipFree(plan->tiles_u);
+  plan->live2 = nullptr;
+  plan->tiles_p = plan->tiles_u = nullptr;
+  plan->n_tiles_p = plan->n_tiles_u = 0;
+  plan->pair_codes = nullptr;
+}
+
+// Pairs the contexts of every tile's list for the fused linear step (kernels_linear.h, LIN_PAIR_CAP): kmer_index are the index
+// words the step will be called with (bear_linear_index_u64 for `lag`), in the row order of the plan's count slab.
+int bear_plan_pair_contexts(bear_plan *plan, const uint64_t *kmer_index, int lag, int *paired, void *stream) {
+  if (paired) *paired = 0;
+  if (!plan || plan->ncol != 5 || lag < 1 || lag > LIN_MAX_LAG) return BEAR_ERR_INVALID_ARG;
+  if (plan->n_rows && (!kmer_index || misaligned(kmer_index))) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (plan->live2) {           // a plan holds one pairing: the new one replaces it
+    HIP_TRY(hipStreamSynchronize(s));
+    plan_unpair(plan);
+  }
+  const uint64_t nt = plan->n_tiles;
+  if (nt == 0 || !plan->live) return BEAR_OK;
+  uint16_t *live2 = nullptr, *n_ent_dev = nullptr;
+  pln_tile *tp = nullptr, *tu = nullptr;
+  std::vector<uint16_t> n_ent;
+  std::vector<pln_tile> host, hp, hu;
+  try {
+    n_ent.resize(nt);
+    host.resize(nt);
+  } catch (const std::bad_alloc &) {
+    return BEAR_ERR_NOMEM;
+  }
+  hipError_t e = hipMalloc(&live2, nt * LIN_LIVE2_STRIDE * sizeof(uint16_t));
+  if (e == hipSuccess) e = hipMalloc(&n_ent_dev, nt * sizeof(uint16_t));
+  if (e == hipSuccess) {
+    uint64_t blocks = (nt + 63) / 64;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(plan_pair_kernel, dim3((unsigned)blocks), dim3(64), 0, s, plan->tiles, nt, plan->live,
+                       reinterpret_cast<const unsigned long long *>(kmer_index), lag, live2, n_ent_dev);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(n_ent.data(), n_ent_dev, nt * sizeof(uint16_t), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(host.data(), plan->tiles, nt * sizeof(pln_tile), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(n_ent_dev);
+  uint64_t n_p = 0;
+  bool keep = false;
+  if (e == hipSuccess) {
+    try {
+      for (uint64_t t = 0; t < nt; ++t) {
+        pln_tile d = host[t];
+        const bool fits = n_ent[t] != 0xffffu;         // (a tile without live contexts fits with 0 entries)
+        d.pad = (t << 32) | (fits ? n_ent[t] : 0u);
+        (fits ? hp : hu).push_back(d);
+      }
+      n_p = hp.size();
+      // fewer than half of the tiles paired (a sparse table: runs of one context): nothing to gain, the plan stays as it was
+      keep = 2 * n_p >= nt;
+      if (keep) {
+        const pln_tile zero = {};
+        hp.insert(hp.end(), PLN_DESC_PAD, zero);
+        hu.insert(hu.end(), PLN_DESC_PAD, zero);
+      }
+    } catch (const std::bad_alloc &) {
+      (void)hipFree(live2);
+      return BEAR_ERR_NOMEM;
+    }
+  }
+  if (e == hipSuccess && keep) e = hipMalloc(&tp, hp.size() * sizeof(pln_tile));
+  if (e == hipSuccess && keep) e = hipMalloc(&tu, hu.size() * sizeof(pln_tile));
+  if (e == hipSuccess && keep) e = hipMemcpy(tp, hp.data(), hp.size() * sizeof(pln_tile), hipMemcpyHostToDevice);
+  if (e == hipSuccess && keep) e = hipMemcpy(tu, hu.data(), hu.size() * sizeof(pln_tile), hipMemcpyHostToDevice);
+  if (e != hipSuccess || !keep) {
+    (void)hipFree(live2);
+    (void)hipFree(tp);
+    (void)hipFree(tu);
+    if (e != hipSuccess) {
+      g_last_hip_error = (int)e;
+      return e == hipErrorOutOfMemory ? BEAR_ERR_NOMEM : BEAR_ERR_HIP;
+    }
+    return BEAR_OK;
+  }
+  plan->live2 = live2;
+  plan->tiles_p = tp;
+  plan->tiles_u = tu;
+  plan->n_tiles_p = n_p;
+  plan->n_tiles_u = nt - n_p;
+  plan->pair_codes = kmer_index;
+  plan->pair_lag = lag;
+  plan->bytes += nt * LIN_LIVE2_STRIDE * sizeof(uint16_t) + (nt + 2 * PLN_DESC_PAD) * sizeof(pln_tile);
+  if (paired) *paired = 1;
+  return BEAR_OK;
+}
+
 int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code,
                        const double *mat, int lag, uint64_t n_rows, double h_signed, double eps, int train_ar,
                        double *out, double *grad_mat, void *stream) {
@@ -949,17 +1093,8 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
   memset(&prm, 0, sizeof(prm));
   prm.inv_h = 1.0 / exp(h_signed);
   prm.eps = eps;
-  const int grid = grid_plan(ws, plan->n_tiles);
-  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const bear_step_io io{nullptr, BEAR_THETA_NET, out, ws->arrive};   // one launch: the last block sums the partials
-  if (train_ar)
-    hipLaunchKernelGGL(dm_linear_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
-                       reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, prm, plan_view(plan), lt, ws->partials,
-                       ws->lin_partials, io, grad_mat);
-  else
-    hipLaunchKernelGGL(dm_linear_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
-                       reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, prm, plan_view(plan), lt, ws->partials,
-                       ws->lin_partials, io, grad_mat);
+  launch_linear(ws, plan, kmer_code, mat, lag, prm, train_ar, io, grad_mat, s);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
@@ -1061,18 +1196,9 @@ int bear_net_linear_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const u
   bear_params dummy;
   memset(&dummy, 0, sizeof(dummy));
   dummy.eps = eps;
-  const int grid = grid_plan(ws, plan->n_tiles);
-  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const double *mat = theta + 1;
   const bear_step_io io{theta, BEAR_THETA_NET, packed, ws->arrive};   // constants from theta, sums by the last block: one launch
-  if (train_ar)
-    hipLaunchKernelGGL(dm_linear_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
-                       reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, dummy, plan_view(plan), lt, ws->partials,
-                       ws->lin_partials, io, packed + 2);
-  else
-    hipLaunchKernelGGL(dm_linear_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_lin), s,
-                       reinterpret_cast<const unsigned long long *>(kmer_code), mat, lag, dummy, plan_view(plan), lt, ws->partials,
-                       ws->lin_partials, io, packed + 2);
+  launch_linear(ws, plan, kmer_code, mat, lag, dummy, train_ar, io, packed + 2, s);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }

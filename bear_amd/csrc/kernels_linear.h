@@ -53,10 +53,22 @@
 #define LIN_GT_PLANE (LIN_TAB_DOUBLES / 4)   // rows of all group tables
 #define LIN_MAX_GRAD (LIN_MAX_LAG * 25)
 
+// The PAIRED form of a tile's list (plan_pair_kernel, built once per batch from the plan's list and the index words): the same
+// rows in the same order, with an empty entry (0xffff) in front of every run of equal leading letters (all pair groups) that
+// would otherwise start at an odd position -- so entries 2 j and 2 j + 1 always share every pair group, and thread j takes both:
+// the pair rows are read and multiplied once for two contexts (phase A), and one reduction / run detection / wave- and row-level
+// add serves 128 contexts instead of 64 (phase C).  A tile whose list would grow beyond what the row threads take (2 per thread: a
+// stretch of the table where a run is one context) keeps its plain list: the step is then two launches, the paired form of the
+// kernel over the paired tiles and the plain form over the rest (both forms in one kernel ran out of registers).
+#define LIN_PAIR_CAP (2 * (PLN_THREADS - 64 * 2))           // entries the row threads of a block take (LIN_RPT * LIN_ROW_THREADS, asserted below)
+#define LIN_LIVE2_STRIDE (LIN_PAIR_CAP + 8)                 // uint16 per tile of the paired lists (a multiple of 8: 16-byte rows)
+#define LIN_EMPTY 0xffffu
+
 struct lin_buf {
   __attribute__((aligned(16))) unsigned long long codes[PLN_RMAX + 2];
   __attribute__((aligned(16))) unsigned char blk[PLN_BLOCK_MAX];
-  __attribute__((aligned(16))) uint16_t live[PLN_LIVE_STRIDE];   // the plan's list of contexts with counts: [0] = how many, then rows
+  __attribute__((aligned(16))) uint16_t live[LIN_LIVE2_STRIDE];  // the plan's list of contexts with counts: [0] = how many, then rows
+                                                                 // (paired form, bear_plan_pair_contexts: [0] = entries, [1] unused, then entries)
 };
 struct pln_lds_lin {
   double pri[PLN_RMAX * 5 + 2];  // [PLN_SENTINEL] = 1.0
@@ -67,6 +79,7 @@ struct pln_lds_lin {
   double tabD[SRT_NKEY];
   double tabP[SRT_NKEY];
   double exptab[BEAR_EXPTAB_N];
+  __attribute__((aligned(16))) pln_tile desc[4];   // tile descriptors, landed by LDS-DMA two iterations ahead of their use (see the tile loop)
   uint32_t ticket[2];
   uint32_t c_done;               // += 1 by every wave that has read its rows back in phase C (see the tile loop)
   unsigned long long t_max;      // bits of the largest |logit| in the group tables (table build)
@@ -139,6 +152,39 @@ __global__ void linear_index_kernel(const unsigned long long *__restrict__ raw, 
   const lin_geom G = lin_make_geom(lag);
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
     out[i] = lin_index_word(raw[i], G);
+}
+// ---- bear_plan_pair_contexts: the paired lists of every tile (see LIN_PAIR_CAP).  One thread per tile walks the tile's list (set-up
+// path: once per batch); the number of entries goes to the list's first word and to n_ent[tile] (0xffff: the list does not fit, the
+// tile keeps its plain list -- the host sorts the tiles into two descriptor arrays, one per form of the kernel).
+__global__ __launch_bounds__(64) void plan_pair_kernel(const pln_tile *__restrict__ tiles, uint64_t n_tiles, const uint16_t *__restrict__ live,
+                                                       const unsigned long long *__restrict__ kmer_index, int lag, uint16_t *__restrict__ live2,
+                                                       uint16_t *__restrict__ n_ent) {
+  const lin_geom G = lin_make_geom(lag);
+  const unsigned long long pair_mask = (1ull << (6 * G.npair)) - 1ull;      // every pair group of the index word (bear_linear_index_u64)
+  for (uint64_t t = (uint64_t)blockIdx.x * 64 + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * 64) {
+    const uint16_t *in = live + t * PLN_LIVE_STRIDE;
+    uint16_t *out = live2 + t * LIN_LIVE2_STRIDE;
+    const uint64_t row0 = tiles[t].row0;
+    const uint32_t n = in[0];
+    uint32_t m = 0;
+    unsigned long long prev = 0ull;
+    for (uint32_t j = 0; j < n; ++j) {
+      const uint32_t row = in[1 + j];
+      const unsigned long long p = kmer_index[row0 + row] & pair_mask;
+      if (j && p != prev && (m & 1u)) {
+        if (m < LIN_PAIR_CAP) out[2 + m] = (uint16_t)LIN_EMPTY;
+        ++m;
+      }
+      if (m < LIN_PAIR_CAP) out[2 + m] = (uint16_t)row;
+      ++m;
+      prev = p;
+    }
+    const bool fits = m <= LIN_PAIR_CAP;
+    if (fits && (m & 1u)) out[2 + m] = (uint16_t)LIN_EMPTY, ++m;     // (LIN_PAIR_CAP is even: this stays inside)
+    out[0] = fits ? (uint16_t)m : (uint16_t)0;
+    out[1] = 0;
+    n_ent[t] = fits ? (uint16_t)m : (uint16_t)0xffffu;
+  }
 }
 // offset (in doubles) of group g's table row; g a constant after unrolling
 template <int NG>
@@ -255,6 +301,104 @@ __device__ __forceinline__ void lin_row(const double *T, const double *exptab, u
   for (int b = 0; b < 5; ++b) f[b] *= r;
 }
 
+// Two contexts that share every pair group (a thread's two entries of the PAIRED list): the pair rows are read and combined once,
+// each context adds its own triple row.  has1 = false: there is no second context (f1 is then not meaningful).
+template <int NG, bool EXP>
+__device__ __forceinline__ void lin_row2(const double *T, const double *exptab, unsigned long long c0, unsigned long long c1,
+                                         double (&f0)[5], double (&f1)[5]) {
+  constexpr int CH = LIN_CH;
+  constexpr int NP = NG - 1;                 // pair groups
+  double e[4] = {EXP ? 1.0 : 0.0, EXP ? 1.0 : 0.0, EXP ? 1.0 : 0.0, EXP ? 1.0 : 0.0};
+  unsigned long long cw = c0;
+#pragma unroll
+  for (int g0 = 0; g0 < NP; g0 += CH) {
+    double2 lo[CH], hi[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      if (g0 + j < NP) {
+        const double2 *t = reinterpret_cast<const double2 *>(T + lin_off<NG>(cw, g0 + j));
+        lo[j] = t[0];
+        hi[j] = t[1];
+      }
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      if (g0 + j < NP) {
+        if (EXP && g0 + j == 0) {
+          e[0] = lo[j].x;
+          e[1] = lo[j].y;
+          e[2] = hi[j].x;
+          e[3] = hi[j].y;
+        } else if (EXP) {
+          e[0] *= lo[j].x;
+          e[1] *= lo[j].y;
+          e[2] *= hi[j].x;
+          e[3] *= hi[j].y;
+        } else {
+          e[0] += lo[j].x;
+          e[1] += lo[j].y;
+          e[2] += hi[j].x;
+          e[3] += hi[j].y;
+        }
+      }
+    if (g0 + CH < NP) asm("" : "+v"(cw) : "v"(e[0]));     // as in lin_row: the next rows' addresses wait for this product
+  }
+  const double2 *t0 = reinterpret_cast<const double2 *>(T + lin_off<NG>(c0, NG - 1));
+  const double2 *t1 = reinterpret_cast<const double2 *>(T + lin_off<NG>(c1, NG - 1));
+  const double2 a0 = t0[0], b0 = t0[1], a1 = t1[0], b1 = t1[1];
+  if (EXP) {
+    const double x0[4] = {e[0] * a0.x, e[1] * a0.y, e[2] * b0.x, e[3] * b0.y};
+    const double x1[4] = {e[0] * a1.x, e[1] * a1.y, e[2] * b1.x, e[3] * b1.y};
+    const double r0 = bear_rcp(1.0 + ((x0[0] + x0[1]) + (x0[2] + x0[3])));
+    const double r1 = bear_rcp(1.0 + ((x1[0] + x1[1]) + (x1[2] + x1[3])));
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      f0[b] = x0[b] * r0;
+      f1[b] = x1[b] * r1;
+    }
+    f0[4] = r0;
+    f1[4] = r1;
+    return;
+  }
+  double z[2][4] = {{e[0] + a0.x, e[1] + a0.y, e[2] + b0.x, e[3] + b0.y}, {e[0] + a1.x, e[1] + a1.y, e[2] + b1.x, e[3] + b1.y}};
+  double za = 0.0;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) za = __builtin_fmax(za, __builtin_fabs(z[k][b]));
+  const bool plain = __builtin_amdgcn_ballot_w64(!(za < 600.0 * LIN_EXP_UNIT)) == 0ull;      // as in lin_row, for both contexts
+  double fo[2][5];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    double (&f)[5] = fo[k];
+    double sum;
+    if (plain) {
+      sum = 1.0;
+      f[4] = 1.0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        f[b] = lin_exp_units(z[k][b], exptab);
+        sum += f[b];
+      }
+    } else {
+      const double m = __builtin_fmax(__builtin_fmax(__builtin_fmax(z[k][0], z[k][1]), __builtin_fmax(z[k][2], z[k][3])), 0.0);
+      sum = 0.0;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        f[b] = lin_exp_units(__builtin_fmax((b < 4 ? z[k][b] : 0.0) - m, -700.0 * LIN_EXP_UNIT), exptab);
+        sum += f[b];
+      }
+    }
+    const double r = bear_rcp(sum);
+#pragma unroll
+    for (int b = 0; b < 5; ++b) f[b] *= r;
+  }
+#pragma unroll
+  for (int b = 0; b < 5; ++b) {
+    f0[b] = fo[0][b];
+    f1[b] = fo[1][b];
+  }
+}
+
 // ---- cross-lane sums on DPP (a double = two 32-bit moves + one add per step; the generic __shfl_xor of a double costs
 // two ds_bpermute round trips: measured 0.76 ms per 1e8 contexts for the 24 of them a wave needs here)
 template <int CTRL, int ROW_MASK>
@@ -344,6 +488,25 @@ __device__ __forceinline__ void lin_phase_a_store(pln_lds_lin &S, const double (
       for (int b = 0; b < 5; ++b) S.pri[row * 5 + b] = fA[k][b];
     }
   }
+}
+
+// ---- phase A over the PAIRED list: thread j takes entries 2 j and 2 j + 1 (they share every pair group, or the second is empty).
+// Returns the two rows as lin_phase_a does (0xffff: none).
+template <int NG, bool EXP>
+__device__ __forceinline__ uint32_t lin_phase_a_paired(pln_lds_lin &S, const lin_buf &B, uint32_t n_ent, uint32_t tid_in,
+                                                       double (&fA)[LIN_RPT][5], unsigned long long (&cA)[LIN_RPT]) {
+  static_assert(LIN_RPT == 2 && LIN_RPT * LIN_ROW_THREADS == LIN_PAIR_CAP, "a thread takes one pair of entries");
+  uint32_t rows = 0xffffffffu;
+  uint32_t tid = tid_in;
+  asm volatile("" : "+v"(tid));
+  if (tid < LIN_ROW_THREADS && 2u * tid < n_ent) {
+    rows = reinterpret_cast<const uint32_t *>(B.live)[1 + tid];       // entries 2 tid, 2 tid + 1 behind the two header words
+    const uint32_t r0 = rows & 0xffffu, r1 = rows >> 16;              // (plan_pair_kernel: an empty entry only ever sits in the odd slot)
+    cA[0] = B.codes[r0];
+    cA[1] = r1 != LIN_EMPTY ? B.codes[r1] : cA[0];
+    lin_row2<NG, EXP>(S.T, S.exptab, cA[0], cA[1], fA[0], fA[1]);
+  }
+  return rows;
 }
 
 // ---- the gradient of 64 consecutive contexts (one per lane: index word cv, g_b = d L / d logit_b for b < 4, nz = the lane has
@@ -493,6 +656,136 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uin
   }
 }
 
+// ---- lin_scatter_grad for 64 PAIRS of contexts (c0, c1 share every pair group; g0 / g1 their gradients, zero where there is no
+// context or no item): the pair groups take the pair's SUM gs through the same wave / row-of-16 / quad levels -- one reduction, one
+// run detection and one add per level for 128 contexts -- and each context adds its own g to its triple row.
+template <int NG>
+__device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned long long c0, unsigned long long c1, const double (&g0)[4],
+                                                        const double (&g1)[4], bool nz0, bool nz1, uint32_t lane) {
+  constexpr uint32_t NP = NG - 1;          // pair groups: the only ones the levels may share
+  if (NP > 0) {
+    const double gs[4] = {g0[0] + g1[0], g0[1] + g1[1], g0[2] + g1[2], g0[3] + g1[3]};
+    const double tq = lin_quad_letter_sum(gs, lane), th = lin_row16_sum(tq), tw = lin_wave_sum(th);
+    const uint32_t bl = lin_letter(lane);
+    const unsigned long long pm = (1ull << (6 * NP)) - 1ull;
+    const unsigned long long cv = c0 & pm;
+    const uint32_t clo = (uint32_t)cv, chi = (uint32_t)(cv >> 32);
+    const uint32_t elo = clo ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clo, 0x13C, 0xf, 0xf, false);
+    const uint32_t ehi = chi ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)chi, 0x13C, 0xf, 0xf, false);
+    const bool row_first = (lane & 15u) == 0u;
+    uint32_t rlo = row_first ? 0u : elo, rhi = row_first ? 0u : ehi;
+    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x121, 0xf, 0xf, false);
+    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x121, 0xf, 0xf, false);
+    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x122, 0xf, 0xf, false);
+    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x122, 0xf, 0xf, false);
+    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x124, 0xf, 0xf, false);
+    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x124, 0xf, 0xf, false);
+    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x128, 0xf, 0xf, false);
+    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x128, 0xf, 0xf, false);
+    uint32_t wlo = rlo | elo, whi = rhi | ehi;
+    {
+      auto a = __builtin_amdgcn_permlane16_swap(wlo, wlo, false, false);
+      auto c = __builtin_amdgcn_permlane16_swap(whi, whi, false, false);
+      wlo = a[0] | a[1];
+      whi = c[0] | c[1];
+      a = __builtin_amdgcn_permlane32_swap(wlo, wlo, false, false);
+      c = __builtin_amdgcn_permlane32_swap(whi, whi, false, false);
+      wlo = a[0] | a[1];
+      whi = c[0] | c[1];
+    }
+    const unsigned long long wave_or = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)whi) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)wlo);
+    const unsigned long long row_or = ((unsigned long long)rhi << 32) | rlo;
+    const bool quad_first = (lane & 3u) == 0u;
+    uint32_t qlo = quad_first ? 0u : elo, qhi = quad_first ? 0u : ehi;
+    qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0xB1, 0xf, 0xf, false);
+    qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0xB1, 0xf, 0xf, false);
+    qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0x4E, 0xf, 0xf, false);
+    qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0x4E, 0xf, 0xf, false);
+    const unsigned long long quad_or = ((unsigned long long)qhi << 32) | qlo;
+    // leading PAIR groups shared by the wave / my row of 16 / my quad (only pair bits are in the words: no clamp beyond NP)
+    const uint32_t l_wave = wave_or ? ((uint32_t)(__builtin_ctzll(wave_or) * 43) >> 8) : NP;
+    const uint32_t l_row = row_or ? ((uint32_t)(__builtin_ctzll(row_or) * 43) >> 8) : NP;
+    const uint32_t l_quad = quad_or ? ((uint32_t)(__builtin_ctzll(quad_or) * 43) >> 8) : NP;
+    {
+      const uint32_t gq = lane >> 2;
+      if (gq < l_wave && tw != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, gq, NG) >> 2)], tw);
+    }
+    if (l_wave < NP) {
+      {
+        const uint32_t pick = l_wave + ((lane & 15u) >> 2);
+        if (pick < l_row && th != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
+      }
+      const bool quad_covers = l_row < l_quad && l_row < l_wave + 4u;
+      if (__builtin_amdgcn_ballot_w64(quad_covers)) {
+        if (quad_covers && tq != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, l_row, NG) >> 2)], tq);
+      }
+#pragma unroll
+      for (int gq = 0; gq < (int)NP; ++gq) {
+        if ((uint32_t)gq < l_wave) continue;
+        const bool mine = (nz0 || nz1) && ((uint32_t)gq >= l_row || (uint32_t)gq >= l_wave + 4u) && !(quad_covers && (uint32_t)gq == l_row);
+        if (!__builtin_amdgcn_ballot_w64(mine)) continue;
+        if (mine) {
+          double *gt = &GT[lin_off<NG>(cv, gq) >> 2];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) atomicAdd(&gt[b * LIN_GT_PLANE], gs[b]);
+        }
+      }
+    }
+  }
+  // the triple rows: one add per context and letter
+  if (nz0) {
+    double *gt = &GT[lin_off<NG>(c0, NG - 1) >> 2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) atomicAdd(&gt[b * LIN_GT_PLANE], g0[b]);
+  }
+  if (__builtin_amdgcn_ballot_w64(nz1)) {
+    if (nz1) {
+      double *gt = &GT[lin_off<NG>(c1, NG - 1) >> 2];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) atomicAdd(&gt[b * LIN_GT_PLANE], g1[b]);
+    }
+  }
+}
+
+// ---- phase C over the PAIRED list: a thread reads both of its rows back; a wave scatters 64 pairs at once.
+template <int NG>
+__device__ __forceinline__ void lin_phase_c_paired(pln_lds_lin &S, uint32_t n_ent, uint32_t tid, uint32_t lane_in,
+                                                   const double (&fA)[LIN_RPT][5], const unsigned long long (&cA)[LIN_RPT], uint32_t rowA) {
+  uint32_t lane = lane_in;
+  const uint32_t j0 = 2u * (tid & ~63u);                      // first entry of this wave's 64 pairs
+  if (tid >= LIN_ROW_THREADS || j0 >= n_ent) return;          // wave-uniform
+  asm volatile("" : "+v"(lane));
+  double g[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  bool nz[2] = {false, false};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t row = (rowA >> (16 * k)) & 0xffffu;
+    if (row != LIN_EMPTY) {
+      double w[5], sw = 0.0;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const double v = S.pri[row * 5 + b];
+        w[b] = __builtin_fmax(-v, 0.0);
+        sw += w[b];
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) g[k][b] = __builtin_fma(-fA[k][b], sw, w[b]);
+      nz[k] = sw > 0.0;
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(nz[0] || nz[1]) == 0ull) return;
+  // lanes beyond the end of the list repeat the last pair's leading letters: they add nothing and never break a run
+  const uint32_t n_pairs = (n_ent - j0) >> 1;                 // wave-uniform (both even)
+  const uint32_t last = n_pairs < 64u ? n_pairs - 1u : 63u;
+  unsigned long long c0 = cA[0], c1 = cA[1];
+  if (last != 63u) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cA[0], (int)last), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cA[0] >> 32), (int)last);
+    if (lane > last) c0 = c1 = ((unsigned long long)hi << 32) | lo;
+  }
+  lin_scatter_grad_paired<NG>(S.GT, c0, c1, g[0], g[1], nz[0], nz[1], lane);
+}
+
 // ---- the group tables of a launch, built by the whole block (n_threads threads; *t_max: a word of LDS).  A row is the sum of mat[l][a_l][b] - mat[l][a_l][4] over the group's letters;
 // letter value 5 = unknown and positions beyond the group or the lag contribute nothing.
 // If no context's partial sums of table rows can leave +-600 (ng rows of at most t_max each -- anything a fitted model
@@ -560,7 +853,7 @@ __device__ __forceinline__ void lin_fold_tables(const double *GT, const lin_geom
 // order -- three threads per entry take a third of the blocks each (independent loads, consecutive threads on consecutive
 // entries), their sums meet in `part` (3 * LIN_MAX_GRAD doubles of LDS).
 __device__ __forceinline__ void lin_sum_block_partials(const double *__restrict__ grad_partials, int n_grad, double *part, int tid,
-                                                       int n_threads, double *__restrict__ grad_out) {
+                                                       int n_threads, double *__restrict__ grad_out, bool accumulate = false) {
   const int nb = (int)gridDim.x, third = (nb + 2) / 3;
   for (int t = tid; t < 3 * n_grad; t += n_threads) {
     const int k = t % n_grad, c = t / n_grad;
@@ -580,7 +873,10 @@ __device__ __forceinline__ void lin_sum_block_partials(const double *__restrict_
     part[c * LIN_MAX_GRAD + k] = s;
   }
   __syncthreads();
-  for (int k = tid; k < n_grad; k += n_threads) grad_out[k] = (part[k] + part[LIN_MAX_GRAD + k]) + part[2 * LIN_MAX_GRAD + k];
+  for (int k = tid; k < n_grad; k += n_threads) {
+    const double v = (part[k] + part[LIN_MAX_GRAD + k]) + part[2 * LIN_MAX_GRAD + k];
+    grad_out[k] = accumulate ? grad_out[k] + v : v;
+  }
 }
 
 // compile-time group count from the run-time one
@@ -610,11 +906,11 @@ __device__ unsigned long long lin_stamp_sums[8];
 #else
 #define LIN_STAMP(k)
 #endif
-template <bool AR>
+template <bool AR, bool PAIRED>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_kernel(
     const unsigned long long *__restrict__ kmer_code, const double *__restrict__ mat, int lag, bear_params prm_arg, pln_view pv,
     const double2 *__restrict__ logtab_g, double *__restrict__ partials, double *__restrict__ grad_partials,
-    const bear_step_io io, double *__restrict__ grad_out) {
+    const bear_step_io io, double *__restrict__ grad_out, int accumulate) {   // accumulate: add to io.out / grad_out (second launch of a step)
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_lin &S = *reinterpret_cast<pln_lds_lin *>(srt_smem);
   const bear_params prm = bear_params_of(prm_arg, io);   // device-resident parameters: constants derived in the prologue
@@ -641,6 +937,28 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   const bool exp_tables = lin_build_tables(S.T, &S.t_max, mat, G, tid, PLN_THREADS);
 
   // LIN_DMA_WAVES waves issue the tile DMA (the last ones of the block); measured in round 2, when they also had rows: 16 / 8 / 4 / 2 waves: 1.92 / 1.89 / 1.87 / 1.86 ms
+  // Tile descriptors reach the waves through LDS: a scalar load inside the tile loop costs every wave a full memory latency per
+  // tile (~1800 clocks with HBM busy: s_load shares lgkmcnt with the LDS, so the wave's next LDS result waits for it -- the
+  // `staging` stamp of round 3, 9 % of the kernel).  The first DMA wave lands descriptor `tile` (a zeroed one behind the last
+  // tile) in ring slot `slot`; it is read two barriers later.
+  auto stage_desc = [&](uint64_t tile, uint32_t slot_d) {
+    if (wave != PLN_WAVES - LIN_DMA_WAVES) return;
+    uint32_t lane = tid & 63u;
+    asm volatile("" : "+v"(lane));
+    pln_dma_piece(&S.desc[slot_d], pv.tiles + (tile < pv.n_tiles ? tile : pv.n_tiles), (uint32_t)sizeof(pln_tile), 0u, lane);
+  };
+  auto read_desc = [&](uint32_t slot_d) {
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(&S.desc[slot_d]);
+    pln_tile ti;
+    const uint32_t lo = srt_uniform(d[0]), hi = srt_uniform(d[1]);
+    ti.row0 = ((uint64_t)hi << 32) | lo;
+    ti.rows_items = srt_uniform(d[2]);
+    ti.off16 = srt_uniform(d[3]);
+    ti.hc_hr = srt_uniform(d[4]);
+    ti.blk16 = srt_uniform(d[5]);
+    ti.pad = ((uint64_t)srt_uniform(d[7]) << 32) | srt_uniform(d[6]);
+    return ti;
+  };
   auto stage = [&](const pln_tile &ti, uint64_t tile, uint32_t b) {
     const uint32_t rows = ti.rows_items >> 16;
     if (rows == 0) return;
@@ -649,12 +967,18 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     asm volatile("" : "+v"(lane));   // no lane-derived addresses kept (and spilled) across the tile loop
     // the three slabs of a tile as one sequence of 1 KiB pieces dealt round-robin to the issuing waves
     const uint32_t dw = wave - (PLN_WAVES - LIN_DMA_WAVES);
-    const uint32_t cb = (rows * 8u) & ~15u, bb = ti.blk16 * 16u, lb = ((rows + 1u) * 2u + 15u) & ~15u;
+    // (the paired list: its length sits in the descriptor's spare word, plan_pair_kernel)
+    // a launch over a SUBSET of the tiles (pv.subset): the descriptor's spare word holds the tile's number in the plan (its lists
+    // are indexed by it) and, for the paired form, the length of its paired list
+    const uint64_t ltile = pv.subset ? ti.pad >> 32 : tile;
+    const uint32_t cb = (rows * 8u) & ~15u, bb = ti.blk16 * 16u,
+                   lb = PAIRED ? ((((uint32_t)ti.pad & 0xffffu) + 2u) * 2u + 15u) & ~15u : ((rows + 1u) * 2u + 15u) & ~15u;
     const uint32_t pc = (cb + 1023u) >> 10, pb = (bb + 1023u) >> 10, pl = (lb + 1023u) >> 10;
     for (uint32_t q = dw; q < pc + pb + pl; q += LIN_DMA_WAVES) {
       if (q < pc) pln_dma_piece(S.buf[b].codes, kmer_code + ti.row0, cb, q, lane);
       else if (q < pc + pb) pln_dma_piece(S.buf[b].blk, pv.stream + (size_t)ti.off16 * 16, bb, q - pc, lane);
-      else pln_dma_piece(S.buf[b].live, pv.live + tile * PLN_LIVE_STRIDE, lb, q - pc - pb, lane);
+      else if (PAIRED) pln_dma_piece(S.buf[b].live, pv.live2 + ltile * LIN_LIVE2_STRIDE, lb, q - pc - pb, lane);
+      else pln_dma_piece(S.buf[b].live, pv.live + ltile * PLN_LIVE_STRIDE, lb, q - pc - pb, lane);
     }
     if ((rows * 8u) & 15u) {  // odd row count: trailing word through the scalar path (see dm_prior_plan_kernel)
       const __attribute__((address_space(4))) unsigned long long *tail =
@@ -671,27 +995,38 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   unsigned long long cA[LIN_RPT] = {0ull, 0ull};
   uint32_t n_live = 0;   // of the tile whose phase A ran last
   uint32_t rowA = 0xffffffffu;
-  auto phase_a = [&](const lin_buf &B, uint32_t rows) {
+  auto phase_a = [&](const lin_buf &B, const pln_tile &ti) {
+    const uint32_t rows = ti.rows_items >> 16;
     n_live = rows ? srt_uniform((uint32_t)B.live[0]) : 0u;
     rowA = 0xffffffffu;
 #ifdef LIN_SKIP_A
     return;
 #endif
-    LIN_FOR_NG(ng, rowA = (lin_phase_a<NG, EXP>(S, B, n_live, tid, fA, cA)))
+    if (PAIRED) {
+      LIN_FOR_NG(ng, rowA = (lin_phase_a_paired<NG, EXP>(S, B, n_live, tid, fA, cA)))
+    } else {
+      LIN_FOR_NG(ng, rowA = (lin_phase_a<NG, EXP>(S, B, n_live, tid, fA, cA)))
+    }
   };
-  auto phase_c = [&]() { LIN_FOR_NG(ng, lin_phase_c<NG>(S, n_live, tid, lane, fA, cA, rowA, acc)) };
+  auto phase_c = [&]() {
+    if (PAIRED) {
+      LIN_FOR_NG(ng, lin_phase_c_paired<NG>(S, n_live, tid, lane, fA, cA, rowA))
+    } else {
+      LIN_FOR_NG(ng, lin_phase_c<NG>(S, n_live, tid, lane, fA, cA, rowA, acc))
+    }
+  };
 
   const uint64_t GR = gridDim.x;
-  pln_tile cur = pln_load_tile(pv, blockIdx.x), nxt = pln_load_tile(pv, blockIdx.x + GR);
+  pln_tile cur = pln_load_tile(pv, blockIdx.x), nxt = pln_load_tile(pv, blockIdx.x + GR);    // (prologue: scalar loads)
   stage(cur, blockIdx.x, 0);
   srt_wait_dma();
   srt_sync();
-  phase_a(S.buf[0], cur.rows_items >> 16);
+  phase_a(S.buf[0], cur);
   lin_phase_a_store(S, fA, rowA);
   srt_sync();
   stage(nxt, blockIdx.x + GR, 1);
-  pln_tile nxt2 = pln_load_tile(pv, blockIdx.x + 2 * GR);   // descriptors by scalar loads, one iteration ahead of their use
-  uint32_t slot = 0, c_target = 0;
+  stage_desc(blockIdx.x + 2 * GR, 2);     // descriptor j of this block's tiles lives in ring slot j & 3
+  uint32_t slot = 0, c_target = 0, iter = 0;
 #ifdef LIN_STAMPS
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #endif
@@ -727,11 +1062,10 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
 #ifdef LIN_MIX   // developer build (timing only, results meaningless): half of the waves do their row work (C, A) before the items,
                  // the other half after half of the items, no synchronisation inside an iteration -- how much would a kernel gain
                  // whose LDS-bound and VALU-bound parts overlap instead of alternating?
-    const uint32_t nxt_rows = nxt.rows_items >> 16;
     auto rows_work = [&]() {
       phase_c();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      phase_a(S.buf[slot ^ 1u], nxt_rows);
+      phase_a(S.buf[slot ^ 1u], nxt);
     };
     bool rows_done = (wave & 1u) != 0u;
     if (rows_done) rows_work();
@@ -784,9 +1118,10 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
 #endif
     LIN_STAMP(2)     // barrier after the items
     cur = nxt;
-    nxt = nxt2;
+    nxt = read_desc((iter + 2u) & 3u);    // landed an iteration ago; this block's DMA wave has waited for it, the barrier published it
     stage(nxt, t + 2 * GR, slot);   // the tile after next lands while phases C, A and the next tile's B run
-    nxt2 = pln_load_tile(pv, t + 3 * GR);
+    stage_desc(t + 3 * GR, (iter + 3u) & 3u);
+    ++iter;
     // ---- C of this tile (rows, index words and softmax rows from phase A's registers), A of the next
     LIN_STAMP(3)     // staging the tile after next
 #ifndef LIN_MIX
@@ -795,7 +1130,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     LIN_STAMP(4)     // C
     if (lane == 0) atomicAdd(&S.c_done, 1u);
     c_target += PLN_WAVES;
-    phase_a(S.buf[slot ^ 1u], cur.rows_items >> 16);
+    phase_a(S.buf[slot ^ 1u], cur);
 #endif
     LIN_STAMP(5)     // A (compute)
 #if !defined(LIN_NOSYNC) && !defined(LIN_MIX)
@@ -861,7 +1196,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     acc[0] -= o.D;
     acc[1] = __builtin_fma(u, o.P, acc[1]);
   }
-  if (!AR && blockIdx.x == 0 && tid < SRT_CL) {  // context terms of the small totals: the plan's histogram
+  if (!AR && pv.hist && blockIdx.x == 0 && tid < SRT_CL) {  // context terms of the small totals: the plan's histogram
     const double m = (double)pv.hist[tid];
     acc[0] -= m * S.tabD[tid];
     acc[1] = __builtin_fma(u * m, S.tabP[tid], acc[1]);
@@ -871,8 +1206,8 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   block_store_partials<2, true>(acc, partials);      // (io.out is never NULL here: both entry points sum in this launch)
   if (!bear_arrive_last(io.arrive)) return;
   __syncthreads();
-  lin_sum_block_partials(grad_partials, lag * 25, reinterpret_cast<double *>(srt_smem), (int)tid, PLN_THREADS, grad_out);   // the tile loop is over: the dynamic LDS is free
-  bear_finalize_in_block(partials, 2, io.out, io.arrive);
+  lin_sum_block_partials(grad_partials, lag * 25, reinterpret_cast<double *>(srt_smem), (int)tid, PLN_THREADS, grad_out, accumulate != 0);   // the tile loop is over: the dynamic LDS is free
+  bear_finalize_in_block(partials, 2, io.out, io.arrive, accumulate != 0);
 }
 
 // ---- the bear_net / linear optimizer step on the device (HIP-graph replay) ---------------------------------------

@@ -442,6 +442,8 @@ struct pln_view {  // device-side view of a plan
   const unsigned long long *hist;  // [0..31] contexts with total n = j+1, [32..63] with stop count j+1 (<= SRT_CL)
   uint64_t n_tiles, n_heavy_col, n_heavy_row, n_heavy_stop;
   const uint16_t *live;            // [n_tiles][PLN_LIVE_STRIDE] (five-column plans): [0] = contexts with counts, then their rows, ascending
+  const uint16_t *live2;           // [n_tiles][LIN_LIVE2_STRIDE] or NULL: the paired form of `live` for one set of k-mers (kernels_linear.h)
+  int subset;                      // `tiles` is a subset of the plan's tiles: a descriptor's spare word holds (tile number << 32 | list length)
 };
 
 // DMA of `bytes` (multiple of 16) to LDS: 1 KiB pieces round-robin over the waves starting at wave
@@ -519,6 +521,7 @@ __device__ __forceinline__ pln_tile pln_load_tile(const pln_view &pv, uint64_t t
     ti.off16 = tc[t].off16;
     ti.hc_hr = tc[t].hc_hr;
     ti.blk16 = tc[t].blk16;
+    ti.pad = tc[t].pad;       // (subset launches of the linear step, kernels_linear.h; zero in the plan's own array)
   }
   return ti;
 }

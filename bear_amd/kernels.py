@@ -142,6 +142,20 @@ class Plan:
     def nbytes(self):
         return int(_lib.lib().bear_plan_bytes(self._h))
 
+    def pair_contexts(self, kmer_index, lag):
+        """``bear_plan_pair_contexts``: ties this (five-column) plan to the index words ``kmer_index`` (``linear_index``) of its rows
+        so that the fused linear step takes neighbouring contexts with equal leading letters two at a time.  Returns False when the
+        table is too sparse for it (the plan is then unchanged).  The tensor is kept alive; it must not be modified afterwards."""
+        _check_codes(kmer_index)
+        if kmer_index.shape[0] != self.counts.shape[0] or kmer_index.data_ptr() % 16:
+            raise ValueError("kmer_index: one 16-byte aligned index word per row of the plan's count slab")
+        ok = ctypes.c_int(0)
+        with torch.cuda.device(self.counts.device):
+            st = _lib.lib().bear_plan_pair_contexts(self._h, _ptr(kmer_index), int(lag), ctypes.byref(ok), _stream())
+        _lib.check(st, "bear_plan_pair_contexts")
+        self.paired_codes = kmer_index if ok.value else None
+        return bool(ok.value)
+
     def tiles(self):
         """Diagnostics (``bear_plan_tile_info``): (row0 [T] uint64, rows [T] uint32, items [T] uint32, stream_offset [T] uint64)."""
         import numpy as np

@@ -362,9 +362,19 @@ def main():
         packed_sorted_raw = kernels.pack_kmers(codes[torch.argsort(key)].contiguous())
         packed = kernels.linear_index(packed_sorted_raw, lag)
         del key, codes
+        ms_plain = timed(lambda: kernels.dm_linear(plans["net"], packed, mat, h_s), 5)
+        plain_out = [x.clone() for x in kernels.dm_linear(plans["net"], packed, mat, h_s)]
+        # ... and as bear_net.train runs it on a sorted batch: neighbouring contexts that share all letters but the last three
+        # taken two at a time (bear_plan_pair_contexts, once per batch; same sums)
+        lin_paired = plans["net"].pair_contexts(packed, lag)
         ms = timed(lambda: kernels.dm_linear(plans["net"], packed, mat, h_s), 5)
-        del packed
+        paired_out = kernels.dm_linear(plans["net"], packed, mat, h_s)
+        lin_same = bool(torch.allclose(paired_out[0], plain_out[0], rtol=1e-12, atol=0)
+                        and float((paired_out[1] - plain_out[1]).abs().max()) <= 1e-10 * float(plain_out[1].abs().max()))
+        del packed, plain_out, paired_out
         extra["linear_head_fused_step"] = {"lag": lag, "kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3),
+                                           "paired_contexts": lin_paired, "paired_equals_plain": lin_same,
+                                           "kernel_ms_plain_lists": ms_plain,
                                            "kernel_ms_rows_in_random_order": ms_shuffled,
                                            "roofline": fp64_roofline(flops_linear(t["train"], lag), ms),
                                            "note": "forward + ELBO + d/dh + d/dmat from 8-byte context words, rows in k-mer order "
@@ -433,6 +443,7 @@ def main():
         bufs_kept = tuple(b[:keep.numel()] for b in bufs)
         kept_ms = timed(lambda: kernels.net_cnn_train_reduce(plan_kept, packed_kept, lag, fw, theta, bufs_kept, pk), 3)
         lin_kept = kernels.linear_index(packed_kept, lag)
+        plan_kept.pair_contexts(lin_kept, lag)
         lin_k_ms = timed(lambda: kernels.dm_linear(plan_kept, lin_kept, mat, h_s), 5)
         extra["linear_head_fused_step"]["kernel_ms_as_bear_net_train_holds_the_batch"] = lin_k_ms
         kept_frac = keep.numel() / n

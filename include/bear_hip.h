@@ -228,6 +228,17 @@ int bear_encode_kmers_i8(const uint8_t *ascii, uint64_t n_rows, int lag, int rna
 int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_index,
                        const double *mat, int lag, uint64_t n_rows, double h_signed, double eps, int train_ar,
                        double *out, double *grad_mat, void *stream);
+/*
+ * Optional, once per batch, after bear_plan_create and bear_linear_index_u64 (and after the k-mer order below, if any): pairs
+ * neighbouring contexts of the plan's lists that share all letters but the last three, so that the fused step reads their
+ * shared table rows once and reduces their gradients together -- about 10 % off a step on a k-mer-sorted table; the sums are
+ * the same.  The pairing is tied to the buffer kmer_index (identity and contents: it must not change afterwards, like the
+ * plan's count slab) and to lag: bear_dm_linear_f64 / bear_net_linear_train_*_f64 called with that pointer and lag take the
+ * paired form, any other call the plain one.  A tile whose paired list would not fit the kernel's row threads (a stretch of
+ * the table where neighbours share nothing) keeps its plain list; *paired (nullable) = 0 when that is true of more than half
+ * of the tiles (a sparse table): the plan is then left as it was.  Synchronises `stream` (set-up path).
+ */
+int bear_plan_pair_contexts(bear_plan *plan, const uint64_t *kmer_index, int lag, int *paired, void *stream);
 
 /*
  * The linear AR function as prior ROWS, forward and backward: replaces make_ar_func_linear's ar_func (bear_model/ar_funcs.py:41-45)

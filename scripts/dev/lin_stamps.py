@@ -15,6 +15,8 @@ for l in range(LAG):
 order = torch.argsort(key); del key
 tr_s = t["train"][order].contiguous(); idx = kernels.linear_index(kernels.pack_kmers(codes[order].contiguous()), LAG); del order
 plan = kernels.Plan(tr_s, 5)
+if os.environ.get("PAIRED"):
+    print("paired:", plan.pair_contexts(idx, LAG))
 for _ in range(3): kernels.dm_linear(plan, idx, mat.detach(), 0.0)
 torch.cuda.synchronize()
 L = _lib.lib()

@@ -47,3 +47,20 @@ print("sorted vs random order: ELBO rel diff %.2e, d/dh rel diff %.2e, max |d ma
 for ar in (False, True):
     ms = timed(lambda: kernels.dm_linear(plan_s, packed_s, mat.detach(), 0.0, train_ar=ar))
     print(f"k-mer sorted  ar={ar}: {ms:.3f} ms ({N / ms / 1e6:.2f} Gctx/s)")
+# ... and the paired form (bear_plan_pair_contexts): neighbours with equal leading letters two at a time
+ok = plan_s.pair_contexts(packed_s, LAG)
+out_p, g_p = kernels.dm_linear(plan_s, packed_s, mat.detach(), 0.0)
+print("paired:", ok, "vs plain: ELBO rel diff %.2e, max |d mat| diff %.2e of %.2e" % (
+    abs((out_p[0] - out_s[0]) / out_s[0]).item(), (g_p - g_s).abs().max().item(), g_s.abs().max().item()))
+for ar in (False, True):
+    ms = timed(lambda: kernels.dm_linear(plan_s, packed_s, mat.detach(), 0.0, train_ar=ar))
+    print(f"k-mer sorted, paired  ar={ar}: {ms:.3f} ms ({N / ms / 1e6:.2f} Gctx/s)")
+# as bear_net.train keeps the batch: the contexts without training counts left out
+keep = (tr_s != 0).any(dim=1).nonzero().squeeze(1)
+tr_k, pk_k = tr_s.index_select(0, keep).contiguous(), packed_s.index_select(0, keep).contiguous()
+plan_k = kernels.Plan(tr_k, 5)
+ms = timed(lambda: kernels.dm_linear(plan_k, pk_k, mat.detach(), 0.0))
+print(f"kept rows only, plain: {ms:.3f} ms")
+print("paired:", plan_k.pair_contexts(pk_k, LAG))
+ms = timed(lambda: kernels.dm_linear(plan_k, pk_k, mat.detach(), 0.0))
+print(f"kept rows only, paired: {ms:.3f} ms")

@@ -419,6 +419,91 @@ def test_fused_linear_head_parity(case, lag, dev, ysd1):
         assert np.allclose(g, wantg, rtol=1e-9, atol=1e-9 * np.abs(wantg).max()), (case, lag, h_s, ar, np.abs(g - wantg).max())
 
 
+def _sorted_by_kmer(codes):
+    clean = np.where((codes >= 0) & (codes <= 4), codes, 5).astype(np.int64)
+    key = np.zeros(len(codes), dtype=object)
+    for l in range(codes.shape[1]):
+        key = key * 6 + clean[:, l]
+    return np.array(sorted(range(len(codes)), key=lambda i: (key[i], i)), dtype=np.int64)
+
+
+@pytest.mark.parametrize("lag", [1, 2, 3, 4, 5, 8, 13, 21])
+@pytest.mark.parametrize("case", ["sparse", "dense", "ysd1"])
+def test_fused_linear_head_paired_contexts(case, lag, dev, ysd1, monkeypatch):
+    """bear_plan_pair_contexts: the fused step over PAIRED lists (two neighbouring contexts with equal leading letters per
+    thread) against the oracle chain and against the plain form of the same launch -- k-mer-sorted tables whose runs of equal
+    leading letters have every length from one context up (start symbols and unknown letters among them), BEAR and multinomial
+    mode, tables of exponentials and tables of logits; a pointer or lag the pairing was not made for takes the plain form."""
+    import torch
+    from bear_amd import kernels
+    tr = ysd1[1][:, 0].astype(np.uint32) if case == "ysd1" else CASES_REF[case]()[0]
+    n = len(tr)
+    rng = np.random.default_rng(lag * 11 + n)
+    # few distinct prefixes (runs of many contexts) for most rows, random contexts (runs of one or two) for the rest
+    n_pre = max(1, n // 40)
+    pre = rng.integers(0, 4, size=(n_pre, max(lag - 3, 0))).astype(np.int8)
+    codes = rng.integers(0, 4, size=(n, lag)).astype(np.int8)
+    half = n - n // 33
+    codes[:half, :max(lag - 3, 0)] = pre[rng.integers(0, n_pre, size=half)]
+    odd = rng.choice(n, size=max(2, n // 50), replace=False)       # one row in fifty holds start symbols / unknown letters somewhere
+    for r in odd:
+        codes[r, rng.integers(0, lag)] = 4 if rng.random() < 0.6 else -1
+    order = _sorted_by_kmer(codes)
+    codes, tr = codes[order], np.ascontiguousarray(tr[order])
+    d_tr = _to_dev(tr, dev)
+    plan = kernels.Plan(d_tr, 5)
+    idx = kernels.linear_index(kernels.pack_kmers(torch.from_numpy(codes).to(dev)), lag)
+    assert plan.pair_contexts(idx, lag) is True
+    other = idx.clone()
+    for scale, cases in ((0.4, [(0.0, False), (-2.5, False), (0.3, True)]), (150.0, [(0.2, False)]), (3000.0, [(0.0, True)])):
+        mat = rng.normal(size=(lag, 5, 5)) * scale
+        if scale > 1:
+            mat[0, 0] *= 0.001                  # contexts starting with letter 0 keep small logits from that position (as above)
+        d_mat = torch.from_numpy(mat).to(dev)
+        for h_s, ar in cases:
+            want, wantg = _linear_oracle(tr, codes, mat, h_s, ar)
+            got, g = kernels.dm_linear(plan, idx, d_mat, h_s, train_ar=ar)
+            plain, gp = kernels.dm_linear(plan, other, d_mat, h_s, train_ar=ar)        # another buffer: the plain form
+            monkeypatch.setenv("BEAR_AMD_LINEAR_UNPAIRED", "1")
+            plain2, gp2 = kernels.dm_linear(plan, idx, d_mat, h_s, train_ar=ar)
+            monkeypatch.delenv("BEAR_AMD_LINEAR_UNPAIRED")
+            got, g, plain, gp = got.cpu().numpy(), g.cpu().numpy(), plain.cpu().numpy(), gp.cpu().numpy()
+            _close(got[0], want[0], ELBO_RTOL)
+            _mass_close(got[1], want[1], want[2], (case, lag, h_s, ar))
+            tol = 1e-9 if scale < 1000 else 1e-8
+            # (a fully saturated softmax leaves gradients of 1e-12 and less: held to the scale of ONE count then, not to their own)
+            assert np.allclose(g, wantg, rtol=tol, atol=1e-9 * max(np.abs(wantg).max(), 1.0 if scale > 1000 else 1e-300)), (
+                case, lag, scale, h_s, ar, np.abs(g - wantg).max())
+            # (the order of a sum varies between the forms and, with ticketed item units, from launch to launch: d/dh is held to its L1 mass)
+            same = lambda a, b: np.isclose(a[0], b[0], rtol=1e-13, atol=0) and abs(a[1] - b[1]) <= 1e-13 * max(want[2], abs(b[1]))
+            assert same(got, plain) and np.allclose(g, gp, rtol=0, atol=1e-11 * max(np.abs(gp).max(), 1.0 if scale > 1000 else 1e-300))
+            assert same(plain2.cpu().numpy(), plain)
+    # a plan holds one pairing: pairing it again (for the other buffer) replaces the first
+    assert plan.pair_contexts(other, lag) is True
+    a, ga = kernels.dm_linear(plan, other, d_mat, 0.1)
+    b, gb = kernels.dm_linear(plan, idx, d_mat, 0.1)
+    assert torch.allclose(a, b, rtol=1e-13, atol=0) and float((ga - gb).abs().max()) <= 1e-11 * float(gb.abs().max())
+
+
+def test_pairing_declines_a_sparse_table(dev):
+    """A table of random 13-mers has runs of one context: a paired list would be twice the plain one and no longer fit the
+    kernel's row threads -- bear_plan_pair_contexts says so, leaves the plan as it was, and the step runs in its plain form."""
+    import torch
+    from bear_amd import kernels
+    n, lag = 200_000, 13
+    t = kernels.synth_counts(20211012, 0, n, dev, want=("train",))["train"]
+    gen = torch.Generator(dev).manual_seed(5)
+    codes = torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev, generator=gen)
+    idx = kernels.linear_index(kernels.pack_kmers(codes), lag)
+    mat = (0.3 * torch.randn(lag, 5, 5, dtype=torch.float64, device=dev, generator=gen)).contiguous()
+    plan = kernels.Plan(t, 5)
+    before = plan.nbytes
+    want, gw = kernels.dm_linear(plan, idx, mat, 0.2)
+    assert plan.pair_contexts(idx, lag) is False and plan.nbytes == before
+    got, g = kernels.dm_linear(plan, idx, mat, 0.2)
+    assert torch.allclose(got, want, rtol=1e-12, atol=0) and float((g - gw).abs().max()) <= 1e-11 * float(gw.abs().max())
+
+
 def test_fused_linear_head_saturated_logits(dev):
     """Logits of tens (the product-of-exponentials form of the group tables, partial products up to e^+-500), of hundreds
     (tables of logits, un-shifted softmax while the wave's |logit| < 600) and of thousands (max-shifted: a saturated softmax):
@@ -482,6 +567,12 @@ def test_fused_linear_head_full_size(dev):
     plan_s, idx_s = kernels.Plan(ts, 5), kernels.linear_index(kernels.pack_kmers(cs), lag)
     runs = [kernels.dm_linear(plan_s, idx_s, mat, -0.4) for _ in range(6)]
     for out_k, g_k in runs[1:]:
+        assert torch.allclose(out_k, runs[0][0], rtol=1e-13, atol=0)
+        assert float((g_k - runs[0][1]).abs().max()) <= 1e-11 * scale
+    # ... and the paired form of the same step (what bear_net.train runs on a sorted batch), repeated as well
+    assert plan_s.pair_contexts(idx_s, lag) is True
+    for _ in range(4):
+        out_k, g_k = kernels.dm_linear(plan_s, idx_s, mat, -0.4)
         assert torch.allclose(out_k, runs[0][0], rtol=1e-13, atol=0)
         assert float((g_k - runs[0][1]).abs().max()) <= 1e-11 * scale
     del plan_s, idx_s, runs
