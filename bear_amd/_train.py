@@ -338,14 +338,19 @@ class ResidentBatches:
         return e["plans"][key]
 
 
-def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimizer_name, train_ar, acc_steps, device):
+def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimizer_name, train_ar, acc_steps, device,
+                     eager_first_period=False, graph_ok=True):
     """The optimizer loop with every moving quantity in device memory (bear_net.py:292-310 / bear_ref.py:360-381 without a host
     round trip per step).  Per batch k: ``reduce_fns[k](packed)`` enqueues this rank's shard reduce into
     ``packed = [sum LL, d/d theta]``; with several ranks ONE all-reduce of ``packed`` follows on the same stream (bear_net.py:278-290);
     then the update: gradients ``scale_k * packed[1:]`` summed over ``acc_steps`` batches (bear_net.py:193-196: summed, not averaged),
     applied by tf.keras Adam on the device (``bear_train_apply_f64``) or a Keras-equivalent torch optimizer.  With one rank, Adam
     and no accumulation the epoch is captured in a HIP graph and replayed.  ``theta`` is updated in place; returns the logged
-    "elbo" of every optimizer step, ``-(sum of the scaled losses) / acc_steps`` (bear_net.py:303-305), read back once at the end."""
+    "elbo" of every optimizer step, ``-(sum of the scaled losses) / acc_steps`` (bear_net.py:303-305), read back once at the end.
+
+    ``eager_first_period`` (reduce functions made of torch ops and autograd, ``run_autograd_steps``): the first period of steps is
+    enqueued eagerly before anything is captured -- the libraries behind the ops pick their algorithms, the allocator its blocks and
+    the plans are cut outside the capture.  ``graph_ok = False``: never capture."""
     n_theta, n_batches = theta.numel(), len(reduce_fns)
     world = dist.world()[1]
     packed = torch.zeros(n_theta + 1, dtype=torch.float64, device=device)
@@ -390,12 +395,16 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
     # depends on the arguments only), so the ranks' collectives stay paired either way.
     total_steps = repeats * n_batches
     period = math.lcm(n_batches, acc_steps) if n_batches else 0
-    graph, replays = None, 0
-    if (adam and 1 <= period <= GRAPH_MAX_BATCHES and total_steps >= 2 * period and dist.collective_capturable()
-            and not os.environ.get("BEAR_AMD_NO_GRAPH")):
+    graph, replays, done_steps = None, 0, 0
+    if (graph_ok and adam and 1 <= period <= GRAPH_MAX_BATCHES and total_steps >= (3 if eager_first_period else 2) * period
+            and dist.collective_capturable() and not os.environ.get("BEAR_AMD_NO_GRAPH")):
+        if eager_first_period:
+            for i in range(period):
+                one_step(i % n_batches, i + 1)
+            done_steps = period                  # (a multiple of the batches per epoch and of acc_steps: the pattern repeats from here)
         # a replay costs one graph launch (~15 us, scripts/dev/step_latency.py) whatever it holds: short periods are unrolled
         # until a graph carries up to GRAPH_MAX_BATCHES steps, as long as at least four replays remain
-        period *= max(1, min(GRAPH_MAX_BATCHES // period, total_steps // (4 * period)))
+        period *= max(1, min(GRAPH_MAX_BATCHES // period, (total_steps - done_steps) // (4 * period)))
         if dist.collective_active():
             dist.allreduce_sum_(torch.zeros_like(packed))     # the communicator comes up outside the capture
         torch.cuda.synchronize()
@@ -409,15 +418,15 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
         except RuntimeError as err:              # stream capture unavailable: the eager loop below enqueues the same kernels
             warnings.warn(f"HIP-graph capture of the training step failed ({err}); using the eager loop")
             graph = None
-    done_steps = 0
+    eager_steps = done_steps
     if graph is not None:
-        replays = total_steps // period
+        replays = (total_steps - done_steps) // period
         for _ in range(replays):
             graph.replay()
-        done_steps = replays * period
+        done_steps += replays * period
     for i in range(done_steps, total_steps):
         one_step(i % n_batches, i + 1)
-    LAST_RUN.update(graph=graph is not None, replays=replays, period=period, eager_steps=total_steps - done_steps,
+    LAST_RUN.update(graph=graph is not None, replays=replays, period=period, eager_steps=eager_steps + total_steps - done_steps,
                     world=world, collective=dist.collective_active())
     torch.cuda.synchronize()
     return (loss_buf[:n_steps] / acc_steps).cpu().tolist()
@@ -450,67 +459,93 @@ def scatter_live(rows_live, live, n_rows):
     return full.index_copy(0, live, rows_live)
 
 
-def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, optimizer, train_ar, acc_steps, normalized, device,
-                       ref_mix=None):
+def check_normalized_rows(rows, what):
+    """The plugin's ``normalized_rows`` promise, checked ONCE per train() call on the first batch's rows: the kernels that take it
+    never form a row's sum (the concentration total is then shared by all contexts), so a wrong flag would give silently wrong
+    sums.  Rows of zeros are contexts without counts that ``scatter_live`` filled in: nobody reads them."""
+    s = rows.detach().sum(dim=1)
+    off = torch.where(s != 0, (s - 1.0).abs(), torch.zeros_like(s)).max() if s.numel() else torch.zeros(())
+    if float(off) > 1e-12:
+        raise ValueError(f"{what} sets normalized_rows, but its rows do not sum to one (off by up to {float(off):.3g}): "
+                         "drop the attribute (the general kernel forms every row's sum) or normalise the rows")
+
+
+def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, learning_rate, optimizer_name, train_ar, acc_steps,
+                       normalized, device, ref_mix=None):
     """The optimizer loop for an AR function made of torch ops (any ``ar_funcs`` plugin; bear_net.py:292-310): per batch the
     prior rows come from ``prior_fn(batch entry)`` with autograd, the planned kernel returns sum LL, d/dh and the gradient rows
-    (h_signed is read from the parameter tensor on the device), ``Tensor.backward`` carries the rows to the parameters, one
-    all-reduce sums the packed ``[sum LL, d/dh, parameter gradients]`` over the ranks, and the optimizer updates the (mirrored)
-    parameters.  No host round trip per step: the logged losses stay on the device until the loop is done.
+    (h_signed is read from the parameter vector on the device), ``Tensor.backward`` carries the rows to the parameters, and the
+    sums and gradients leave as ONE packed vector ``[sum LL, d/dh, d/d parameters...]`` -- from there on the loop IS
+    ``run_device_steps``: one all-reduce of the packed vector over the ranks, tf.keras Adam on the whole parameter vector in one
+    launch (``bear_train_apply_f64``; another Keras optimizer through torch), the logged losses on the device, and one period of
+    steps captured into a HIP graph and replayed.  For that the parameters become views of one device vector ``theta`` (their
+    ``.data`` is re-pointed: they stay the leaves the AR function closes over).
+
+    A small table (configs[0]: 1365 rows) is launch-bound: an eager step was ~220 launches from Python (half of them the
+    per-parameter optimizer arithmetic), a replayed one is the AR function's own kernels back to back.  Large batches gain nothing
+    from a graph and would pin the AR function's intermediates in its memory pool: eager above BEAR_AMD_GRAPH_MAX_ROWS rows.
 
     ``ref_mix = (net_fn, ref_fn, tau_signed, net_weight_signed)`` (bear_ref with a net function that has parameters and
     normalised rows): ``net_fn(batch entry)`` are the NET rows (autograd), ``ref_fn(batch entry)`` the reference rows, and the
     mixing of bear_ref.py:63-68 happens inside the DM kernel (``bear_dm_refmix_plan_grad_f64``), which also returns the gradients
     of the two mixing parameters; ``prior_fn`` is then not called."""
+    with torch.no_grad():
+        theta = torch.cat([p.detach().reshape(-1).to(device=device, dtype=torch.float64) for p in params]).contiguous()
+        k = 0
+        for p in params:                     # the parameters live in theta from here on (and still do when the caller gets them back)
+            p.data = theta[k:k + p.numel()].view(p.shape)
+            k += p.numel()
     rest = params[1:]
-    acc = [torch.zeros_like(p) for p in params]
     out = torch.zeros(2, dtype=torch.float64, device=device)
     out4 = torch.zeros(4, dtype=torch.float64, device=device)
-    h_dev = h_signed.detach().reshape(1)                      # same storage as the parameter the optimizer updates
-    loss = torch.zeros((), dtype=torch.float64, device=device)
-    logged, step = [], 1
-    for _ in range(repeats):
-        for k, e in enumerate(res.batches):
-            scale = -(num_kmers / e["global_rows"])                    # bear_net.py:190-191 with the global batch
+    h_dev = theta[0:1]
+    promise_checked = [not (normalized or ref_mix is not None)]
+
+    def reducer(k):
+        e = res.batches[k]
+
+        def reduce(packed):
+            """packed = [sum LL, d/dh, d/d parameters] of this rank's piece of batch k (unscaled sums).  Tensor ops, autograd and
+            kernel launches on the current stream only: capturable."""
             for p in rest:
                 p.grad = None
+            sums = out
             if e["rows"] and ref_mix is not None:
                 net_fn, ref_fn, tau_p, nw_p = ref_mix
                 net = net_fn(e)
-                out4, grad_net = kernels.dm_refmix_planned_dev(res.plan(k, "train", 5), net.detach().contiguous(), ref_fn(e), h_dev,
-                                                               tau_p.detach().reshape(1), nw_p.detach().reshape(1), out=out4,
-                                                               train_ar=train_ar)
+                if not promise_checked[0]:
+                    check_normalized_rows(net, "the net function")
+                    promise_checked[0] = True
+                _, grad_net = kernels.dm_refmix_planned_dev(res.plan(k, "train", 5), net.detach().contiguous(), ref_fn(e), h_dev,
+                                                            tau_p.detach().reshape(1), nw_p.detach().reshape(1), out=out4,
+                                                            train_ar=train_ar)
                 if net.requires_grad:
-                    net.backward(scale * grad_net)                     # d loss / d net parameters
-                tau_p.grad = (scale * out4[2]).reshape(tau_p.shape)
-                nw_p.grad = (scale * out4[3]).reshape(nw_p.shape)
-                out.copy_(out4[:2])
+                    net.backward(grad_net)                         # d sum LL / d net parameters
+                tau_p.grad = out4[2].reshape(tau_p.shape)
+                nw_p.grad = out4[3].reshape(nw_p.shape)
+                sums = out4[:2]
             elif e["rows"]:
                 prior = prior_fn(e)
-                need_rows = prior.requires_grad                        # parameter-free AR function (stop): nothing to feed back
+                if not promise_checked[0]:
+                    check_normalized_rows(prior, "the AR function")
+                    promise_checked[0] = True
+                need_rows = prior.requires_grad                    # parameter-free AR function (stop): nothing to feed back
                 r = kernels.dm_prior_planned_dev(res.plan(k, "train", 5), prior.detach(), h_dev, out=out, want_grad=need_rows,
                                                  train_ar=train_ar, normalized=normalized)
                 if need_rows:
-                    prior.backward(scale * r[1])                       # d loss / d AR parameters
+                    prior.backward(r[1])                           # d sum LL / d AR parameters
             else:
                 out.zero_()
-            flat, unpack = dist.pack([out] + [p.grad if p.grad is not None else torch.zeros_like(p) for p in rest])
-            dist.allreduce_sum_(flat)                                  # one packed all-reduce: loss, d/dh, AR grads
-            parts = unpack(flat)
-            loss = loss + scale * parts[0][0]
-            if not train_ar:
-                acc[0] += scale * parts[0][1]                          # AR mode: h_signed gets no gradient (bear_net.py:194-196)
-            for a, g in zip(acc[1:], parts[1:]):
-                a += g.to(a.dtype)
-            if step % acc_steps == 0:
-                logged.append(-loss / acc_steps)
-                optimizer.apply_gradients([None if train_ar else acc[0]] + acc[1:])
-                for a in acc:
-                    a.zero_()
-                loss = torch.zeros((), dtype=torch.float64, device=device)
-            step += 1
-    torch.cuda.synchronize()
-    return torch.stack(logged).cpu().tolist() if logged else []
+            torch.cat([sums] + [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in rest], out=packed)
+            for p in rest:
+                p.grad = None                  # (inside a capture these are blocks of the graph's pool: nobody holds them between replays)
+        return reduce
+
+    scales = [-(num_kmers / e["global_rows"]) for e in res.batches]       # bear_net.py:190-191 with the global batch
+    max_rows = max([e["global_rows"] for e in res.batches] + [0])
+    return run_device_steps([reducer(k) for k in range(len(res.batches))], scales, theta, repeats, learning_rate, optimizer_name,
+                            train_ar, acc_steps, device, eager_first_period=True,
+                            graph_ok=max_rows <= int(os.environ.get("BEAR_AMD_GRAPH_MAX_ROWS", 1 << 22)))
 
 
 def compute_dtype(dtype):
@@ -545,37 +580,60 @@ LAST_RUN = {}             # how the last run_device_steps call ran (tests, logs)
 MAX_EVAL_MODELS = 64   # EVL_MAX_MODELS of kernels_eval.h: h values + van_reg values per launch
 
 
+class EvaluationSums:
+    """The seven partial sums of ``_evaluation_step`` (bear_net.py:323-371) of any number of batches, kept ON THE DEVICE: ``add``
+    enqueues one launch per batch (and per chunk of h values) and returns at once; ``result`` sums the batches' output vectors
+    on the device and reads them back -- one host synchronisation per evaluation, not one per batch."""
+
+    def __init__(self, h, van_reg, eps=epsilon, noise_seed=0):
+        self.hs = np.atleast_1d(np.asarray(h, dtype=np.float64)).reshape(-1)
+        self.van = np.atleast_1d(np.asarray(van_reg, dtype=np.float64)).reshape(-1)
+        if self.van.size >= MAX_EVAL_MODELS:
+            raise ValueError(f"at most {MAX_EVAL_MODELS - 1} van_reg values")
+        self.eps, self.noise_seed = eps, noise_seed
+        self.step = MAX_EVAL_MODELS - self.van.size           # h values per launch; more: chunks, noise stream seed + k
+        self.outs = [[] for _ in range(0, max(self.hs.size, 1), self.step)]
+
+    def add(self, test, prior, train=None, row_base=0, plan=None, row_ids=None):
+        """test / train: uint32 [n,5] device slabs; prior: float64 [n,5] = ar_func rows.  ``row_base`` is the global index of row 0
+        (``row_ids``: of a compacted batch, row i is table row ``row_base + row_ids[i]``), so the arg-max noise stream does not
+        depend on how the rows are sharded or compacted."""
+        if row_ids is not None and plan is None:
+            raise ValueError("row_ids go with a planned evaluation (resident batches)")
+        for c, k in enumerate(range(0, max(self.hs.size, 1), self.step)):
+            hk = self.hs[k:k + self.step]
+            first = k == 0
+            if plan is not None:      # resident table: the sorted plan of the test column (kernels_evalplan.h)
+                out = kernels.evaluate_planned(plan, prior, hk, self.van if first else None, eps=self.eps, with_ar=first,
+                                               noise_seed=self.noise_seed + k, row_base=row_base, row_ids=row_ids)
+            else:
+                out = kernels.evaluate(test, prior, hk, self.van if first else None, train, eps=self.eps, with_ar=first,
+                                       noise_seed=self.noise_seed + k, row_base=row_base)
+            self.outs[c].append(out)
+
+    def result(self):
+        """(ll_ear [H], ll_arm, ll_van [V], cor_ear [H], cor_arm, cor_van [V], total_len) summed over the batches added so far."""
+        ll_ear, cor_ear, rest = [], [], None
+        for c, k in enumerate(range(0, max(self.hs.size, 1), self.step)):
+            H, V = self.hs[k:k + self.step].size, self.van.size if k == 0 else 0
+            if self.outs[c]:
+                out = (self.outs[c][0] if len(self.outs[c]) == 1 else torch.stack(self.outs[c]).sum(dim=0)).cpu().numpy()
+            else:
+                out = np.zeros(2 * (H + V) + 3)
+            ll_ear.append(out[:H])
+            cor_ear.append(out[H + V + 1:2 * H + V + 1])
+            if k == 0:
+                rest = (out[H], out[H + 1:H + 1 + V], out[2 * H + V + 1], out[2 * H + V + 2:2 * H + 2 * V + 2], out[-1])
+        ll_arm, ll_van, cor_arm, cor_van, total_len = rest
+        return (np.concatenate(ll_ear), ll_arm, ll_van, np.concatenate(cor_ear), cor_arm, cor_van, total_len)
+
+
 def evaluation_sums(test, prior, h, van_reg, train=None, eps=epsilon, noise_seed=0, row_base=0, plan=None, row_ids=None):
-    """The 7 partial sums of ``_evaluation_step`` (bear_net.py:323-371) for this rank's rows: one launch of
-    ``bear_eval_f64`` (all h values, the AR model and all van_reg values in a single pass over the rows).
-    test / train: uint32 [n,5] device slabs; prior: float64 [n,5] = ar_func rows; h: float or 1-D sequence
-    (h_scan, bear_net.py:523).  ``row_base`` is the global index of row 0 (``row_ids``: of a compacted batch, row i is table row
-    ``row_base + row_ids[i]``), so the arg-max noise stream does not depend on how the rows are sharded or compacted."""
-    if row_ids is not None and plan is None:
-        raise ValueError("row_ids go with a planned evaluation (resident batches)")
-    hs = np.atleast_1d(np.asarray(h, dtype=np.float64)).reshape(-1)
-    van = np.atleast_1d(np.asarray(van_reg, dtype=np.float64)).reshape(-1)
-    if van.size >= MAX_EVAL_MODELS:
-        raise ValueError(f"at most {MAX_EVAL_MODELS - 1} van_reg values")
-    ll_ear, cor_ear = [], []
-    rest = None
-    step = MAX_EVAL_MODELS - van.size
-    for k in range(0, max(hs.size, 1), step):        # more h values than fit one launch: chunks, noise stream seed + k
-        hk = hs[k:k + step]
-        first = k == 0
-        if plan is not None:      # resident table: the sorted plan of the test column (kernels_evalplan.h)
-            out = kernels.evaluate_planned(plan, prior, hk, van if first else None, eps=eps, with_ar=first,
-                                           noise_seed=noise_seed + k, row_base=row_base, row_ids=row_ids).cpu().numpy()
-        else:
-            out = kernels.evaluate(test, prior, hk, van if first else None, train, eps=eps, with_ar=first,
-                                   noise_seed=noise_seed + k, row_base=row_base).cpu().numpy()
-        H, V = hk.size, van.size if first else 0
-        ll_ear.append(out[:H])
-        cor_ear.append(out[H + V + 1:2 * H + V + 1])
-        if first:
-            rest = (out[H], out[H + 1:H + 1 + V], out[2 * H + V + 1], out[2 * H + V + 2:2 * H + 2 * V + 2], out[-1])
-    ll_arm, ll_van, cor_arm, cor_van, total_len = rest
-    return (np.concatenate(ll_ear), ll_arm, ll_van, np.concatenate(cor_ear), cor_arm, cor_van, total_len)
+    """The 7 partial sums of ``_evaluation_step`` (bear_net.py:323-371) for ONE batch of this rank's rows (``EvaluationSums``
+    with a single ``add``): h float or 1-D sequence (h_scan, bear_net.py:523)."""
+    sums = EvaluationSums(h, van_reg, eps=eps, noise_seed=noise_seed)
+    sums.add(test, prior, train, row_base=row_base, plan=plan, row_ids=row_ids)
+    return sums.result()
 
 
 def reduce_evaluation(parts, device, scalar_h):

@@ -135,16 +135,21 @@ def make_ar_func_cnn(lag, alphabet_size, filter_width=8, num_filters=30, kmer_la
     kmer_weights2 = (small_start * _l2_normalize(torch.randn(kmer_layer1_width, A1, generator=generator, **kw), (0,))).requires_grad_(True)
     kmer_intercept2 = torch.zeros(A1, **kw).requires_grad_(True)
 
+    windows = {}        # the index form of the last code tensor seen: a training loop hands over the same resident batch every step
+
     def conv(data):
         if _is_codes(data):
             # conv1d VALID over a one-hot input = for every output position the sum of filter_width rows of the
             # flattened [filter_width * (A+1), nf] filter table: one embedding-bag (dense scatter-add backward)
-            idx = data.long()
-            win = idx.unfold(-1, filter_width, 1)                                  # [..., P, fw] windows
-            flat = win.clamp(min=0) + A1 * torch.arange(filter_width, device=idx.device)
-            out = F.embedding_bag(flat.reshape(-1, filter_width), filters.reshape(filter_width * A1, num_filters), mode="sum",
-                                  per_sample_weights=(win >= 0).to(filters.dtype).reshape(-1, filter_width))
-            return out.reshape(idx.shape[:-1] + (P, num_filters))                 # [..., P, nf]
+            key = (data.data_ptr(), tuple(data.shape), data.dtype, data._version, str(data.device))
+            if windows.get("key") != key:
+                idx = data.long()
+                win = idx.unfold(-1, filter_width, 1)                                  # [..., P, fw] windows
+                flat = (win.clamp(min=0) + A1 * torch.arange(filter_width, device=idx.device)).reshape(-1, filter_width)
+                windows.update(key=key, keep=data, flat=flat, weights=(win >= 0).to(filters.dtype).reshape(-1, filter_width))
+            out = F.embedding_bag(windows["flat"], filters.reshape(filter_width * A1, num_filters), mode="sum",
+                                  per_sample_weights=windows["weights"])
+            return out.reshape(data.shape[:-1] + (P, num_filters))                # [..., P, nf]
         x = data.reshape((-1,) + data.shape[-2:]).transpose(1, 2)          # [B, A1, lag]
         y = F.conv1d(x, filters.permute(2, 1, 0))                          # [B, nf, P]
         return y.transpose(1, 2).reshape(data.shape[:-2] + (P, num_filters))

@@ -91,7 +91,6 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
                 p.copy_(theta[k:k + p.numel()].reshape(p.shape))
                 k += p.numel()
     else:
-        optimizer = _train.make_optimizer(optimizer_name, params, learning_rate)
         normalized = bool(getattr(ar_func, "normalized_rows", False))   # every reference AR function ends in a softmax
 
         def prior_fn(e):
@@ -100,8 +99,8 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
             if live is None or out.shape[0] == 1:        # (a parameter-free AR function may return one row for all contexts)
                 return out.expand(e["rows"], alphabet_size + 1).contiguous()
             return _train.scatter_live(out, live, e["rows"])
-        losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, optimizer, train_ar, acc_steps,
-                                           normalized, device)
+        losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, learning_rate, optimizer_name, train_ar,
+                                           acc_steps, normalized, device)
     _train.log_losses(losses, writer, loss_save, acc_steps)
     return params, h_signed, ar_func
 
@@ -116,7 +115,7 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
     # only the contexts with held-out counts are kept resident: nothing else enters any sum (their table rows travel as row_ids)
     res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test", per_row_extra=60,   # prior rows + plan
                                  kmer_order=ar_funcs.wants_kmer_order(ar_func))
-    total = None
+    sums = _train.EvaluationSums(h, van_reg, noise_seed=seed)     # the batches' sums stay on the device until all are enqueued
     with torch.no_grad():
         for k, e in enumerate(res.batches):
             if not e["rows"]:
@@ -125,10 +124,9 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
                 live = _train.live_rows(e, "codes", by="test")
                 out = ar_func(e["codes"] if live is None else e["codes_live_test"])
                 prior = out.expand(e["rows"], 5).contiguous() if live is None or out.shape[0] == 1 else _train.scatter_live(out, live, e["rows"])
-            part = _train.evaluation_sums(e["test"], prior, h, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"],
-                                           plan=res.eval_plan(k) if e["rows"] else None, row_ids=e.get("row_ids") if e["rows"] else None)
-            total = part if total is None else tuple(a + b for a, b in zip(total, part))
-    return total, device
+            sums.add(e["test"], prior, e.get("train"), row_base=e["row0"], plan=res.eval_plan(k) if e["rows"] else None,
+                     row_ids=e.get("row_ids") if e["rows"] else None)
+    return sums.result(), device
 
 
 def evaluation(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype=torch.float64, seed=0):

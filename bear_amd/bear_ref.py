@@ -103,9 +103,8 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
         params, h_signed, ar_func = change_scope_params(lag, alphabet_size, make_ar_func, af_kwargs, params_restart, dtype, device)
     dist.broadcast_params(params)                    # mirrored variables: every rank starts from rank 0's values (bear_ref.py:310-321)
     if not ar_func.net_is_stop:
-        optimizer = _train.make_optimizer(optimizer_name, params, learning_rate)
-        return _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_ar, acc_steps, writer, loss_save,
-                              ds_loc, ds_loc_ref, device)
+        return _train_general(data, num_kmers, params, h_signed, ar_func, learning_rate, optimizer_name, train_ar, acc_steps, writer,
+                              loss_save, ds_loc, ds_loc_ref, device)
     # stop net function: theta = (h_signed, tau_signed, net_weight_signed) lives on the device for the whole run; one step is
     # constants-from-theta -> planned mode-R kernel -> finalize [-> all-reduce of 4 doubles] -> Adam, no host round trip
     res = _train.ResidentBatches(data, {"train": ds_loc, "ref": ds_loc_ref}, device, drop_empty="train",
@@ -130,7 +129,7 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
     return params, h_signed, ar_func
 
 
-def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_ar, acc_steps, writer, loss_save,
+def _train_general(data, num_kmers, params, h_signed, ar_func, learning_rate, optimizer_name, train_ar, acc_steps, writer, loss_save,
                    ds_loc, ds_loc_ref, device):
     """bear_ref.train with a parametrised net function (linear, cnn; bear_ref.py:63-68).  Per batch: the net function's rows
     (``bear_linear_forward_f64`` / ``bear_cnn_forward_f64`` behind autograd), then ONE launch of ``bear_dm_refmix_plan_grad_f64``
@@ -167,8 +166,8 @@ def _train_general(data, num_kmers, params, h_signed, ar_func, optimizer, train_
                 return ar_func.net_func(e["codes"])
             return _train.scatter_live(ar_func.net_func(e["codes_live_train"]), live, e["rows"])
         ref_mix = (net_fn, lambda e: e["ref_in"], params[1], params[2])
-    losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, optimizer, train_ar, acc_steps,
-                                       ar_func.normalized_rows, device, ref_mix=ref_mix)
+    losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, learning_rate, optimizer_name, train_ar,
+                                       acc_steps, ar_func.normalized_rows, device, ref_mix=ref_mix)
     _train.log_losses(losses, writer, loss_save, acc_steps)
     return params, h_signed, ar_func
 
@@ -189,7 +188,7 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
     res = _train.ResidentBatches(data, cols, device, want_codes=True, drop_empty="test", per_row_extra=60,   # prior rows + plan
                                  kmer_order=_ar_funcs.wants_kmer_order(getattr(ar_func, "net_func", ar_func)))
     hv = float(torch.as_tensor(h).item()) if np.ndim(torch.as_tensor(h).detach().cpu().numpy()) == 0 else torch.as_tensor(h).detach().cpu().numpy()
-    total = None
+    sums = _train.EvaluationSums(hv, van_reg, noise_seed=seed)     # the batches' sums stay on the device until all are enqueued
     with torch.no_grad():
         for k, e in enumerate(res.batches):
             if not e["rows"]:
@@ -202,7 +201,6 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
                     prior = ar_func(e["codes"], e["ref_in"]).expand(e["rows"], 5).contiguous()
                 else:
                     prior = _train.scatter_live(ar_func(e["codes_live_test"], e["ref_in_live_test"]), live, e["rows"])
-            part = _train.evaluation_sums(e["test"], prior, hv, van_reg, e.get("train"), noise_seed=seed, row_base=e["row0"],
-                                           plan=res.eval_plan(k) if e["rows"] else None, row_ids=e.get("row_ids") if e["rows"] else None)
-            total = part if total is None else tuple(a + b for a, b in zip(total, part))
-    return _train.reduce_evaluation(total, device, np.ndim(hv) == 0)
+            sums.add(e["test"], prior, e.get("train"), row_base=e["row0"], plan=res.eval_plan(k) if e["rows"] else None,
+                     row_ids=e.get("row_ids") if e["rows"] else None)
+    return _train.reduce_evaluation(sums.result(), device, np.ndim(hv) == 0)

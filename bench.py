@@ -348,6 +348,20 @@ def main():
                     "softmax: dm_prior_plan_grad_inplace_kernel, double-buffered; without it dm_prior_plan_grad_kernel)"})
         ms = timed(lambda: kernels.dm_prior_planned(plans["net"], prior, h_s, train_ar=True), 5)
         extra["net_multinomial_mode"] = {"kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3)}
+        # prior rows that are NOT normalised (a plugin whose rows do not end in a softmax): every context then forms its own
+        # A = u sum f + 5 eps, one log and one reciprocal (kernels_plan.h, the branch behind SRT_SUM1_TOL), instead of the table
+        # look-up the softmax rows of the headline take.  Rows scaled by 1 + 1e-3 x a hash of the row number.
+        scale_rows = 1.0 + 1e-3 * ((torch.arange(n, device=dev, dtype=torch.int64) * 2654435761 % 1000003).to(torch.float64) / 1000003.0)
+        prior_un = (prior * scale_rows[:, None]).contiguous()
+        del scale_rows
+        ms_un = timed(lambda: kernels.dm_prior_planned(plans["net"], prior_un, h_s), 5)
+        ms_un_g = timed(lambda: kernels.dm_prior_planned(plans["net"], prior_un, h_s, want_grad=True), 5)
+        del prior_un
+        extra["net_rows_not_normalised"] = {
+            "kernel_ms": ms_un, "contexts_per_s": n / (ms_un * 1e-3), "credited_GBps_at_60_B": n * 60 / (ms_un * 1e-3) / 1e9,
+            "frac_credited": n * 60 / (ms_un * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms_with_gradient_rows": ms_un_g,
+            "note": "dm_prior_plan_kernel<false,false> on rows whose sums differ from 1 by up to 1e-3: the per-context own-A path; "
+                    "the headline's rows are softmax outputs (every reference AR function) and take the shared-A table"}
         lag = 13
         mat = 0.05 * torch.randn(lag, 5, 5, dtype=torch.float64, device=dev, generator=torch.Generator(dev).manual_seed(10))
         codes = torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev, generator=torch.Generator(dev).manual_seed(SEED))
@@ -591,6 +605,16 @@ def main():
                 **k_stats,
                 "measured_stream_read_GBps": stream_gbps,
             },
+            # north_star names the gradient w.r.t. the AR-prior logits too: the kernel every parametrised prior trains through,
+            # next to the d/dh-only one above (SURVEY 8d credits the 60 B read; the 40 B gradient row written per context is not credited)
+            "roofline_gradient_rows": None if "net_with_gradient_rows" not in extra else (lambda g: {
+                "kernel": "dm_prior_plan_grad_inplace_kernel", "bound": "hbm", "kernel_ms": g["kernel_ms_rows_asserted_normalized"],
+                "credited_read_B": 60, "frac_credited": n * 60 / (g["kernel_ms_rows_asserted_normalized"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "moved_B": g["moved_bytes_per_context"],
+                "frac_moved": n * g["moved_bytes_per_context"] / (g["kernel_ms_rows_asserted_normalized"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "general_kernel": "dm_prior_plan_grad_kernel", "general_kernel_ms": g["kernel_ms"],
+                "general_frac_credited": n * 60 / (g["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s"})(extra["net_with_gradient_rows"]),
             "settle": settle_info,
             # what the collective actually ran on: the process group's own world size and backend (nccl = RCCL), how the ranks were started
             "ranks": {"world_size": dist.get_world_size() if multi else 1, "backend": dist.get_backend() if multi else None,

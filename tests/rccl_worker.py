@@ -44,7 +44,10 @@ def main():
     for name, fn, args, kw in (
             ("ref", bear_ref.train, (data.repeat(6), 1365, 6, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False), {}),
             ("net_acc2", bear_net.train, (data.repeat(6), 1365, 6, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", False),
-             {"acc_steps": 2})):
+             {"acc_steps": 2}),
+            # an AR function of torch ops (a cnn shape the fused kernels do not take): the generic loop, its all-reduce in the graph too
+            ("net_generic", bear_net.train, (data.repeat(6), 1365, 6, 0, "dna", 5, ar_funcs.make_ar_func_cnn,
+                                             {"num_filters": 20, "filter_width": 3, "kmer_layer1_width": 16}, 0.01, "Adam", False), {})):
         for mode in ("graph", "eager"):
             if mode == "eager":
                 os.environ["BEAR_AMD_NO_GRAPH"] = "1"

@@ -338,3 +338,9 @@ def test_rccl_group_of_one(tmp_path):
         assert e["how"]["graph"] is False and e["how"]["eager_steps"] == 18
         assert len(g["loss"]) == len(e["loss"]) == (18 if name == "ref" else 9)
         assert np.allclose(g["loss"], e["loss"], rtol=1e-12) and np.allclose(g["params"], e["params"], rtol=1e-10, atol=1e-13), name
+    # ... and the generic loop (an AR function of torch ops): first period eager, the rest replayed with the all-reduce captured
+    g, e = got["runs"]["net_generic_graph"], got["runs"]["net_generic_eager"]
+    assert g["how"]["graph"] is True and g["how"]["collective"] is True and g["how"]["replays"] >= 1, g["how"]
+    assert e["how"]["graph"] is False and e["how"]["eager_steps"] == 18
+    assert len(g["loss"]) == len(e["loss"]) == 18
+    assert np.allclose(g["loss"], e["loss"], rtol=1e-12) and np.allclose(g["params"], e["params"], rtol=1e-12, atol=1e-14)

@@ -490,6 +490,42 @@ def test_bear_net_cnn_graph_replay_matches_eager(train_ar, ysd1):
         assert np.allclose(a, b, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("which,acc_steps,train_ar", [("net cnn 20 filters", 1, False), ("net cnn 20 filters", 3, False),
+                                                      ("net cnn 20 filters", 2, True), ("ref linear", 1, False), ("ref cnn", 2, False)])
+def test_generic_plugin_step_graph_replay_matches_eager(which, acc_steps, train_ar, monkeypatch):
+    """An AR function made of torch ops (make_ar_func_cnn with a shape the fused kernels do not take; bear_ref with a parametrised
+    net function): the optimizer loop captures one period of steps -- the function's ops, the planned DM kernel, autograd's
+    backward, the packed reduce, Keras' Adam with its counter on the device -- and replays it; losses and parameters equal the
+    eager loop's to 1e-12 (the same operations in the same order), with and without gradient accumulation, two batches per epoch."""
+    data = dataloader.dataloader(YSD1, "dna", 700, 3)
+    steps, runs = 12, []
+    for no_graph in (False, True):
+        if no_graph:
+            monkeypatch.setenv("BEAR_AMD_NO_GRAPH", "1")
+        torch.manual_seed(4)
+        ls = []
+        if which.startswith("net"):
+            params, _, _ = bear_net.train(data.repeat(steps), 1365, steps, 0, "dna", 5, ar_funcs.make_ar_func_cnn,
+                                          {"num_filters": 20, "filter_width": 3, "kmer_layer1_width": 16}, 0.01, "Adam", train_ar,
+                                          acc_steps=acc_steps, loss_save=ls)
+        else:
+            make, kw = (ar_funcs.make_ar_func_linear, {}) if "linear" in which else (ar_funcs.make_ar_func_cnn, CNN_CFG)
+            params, _, _ = bear_ref.train(data.repeat(steps), 1365, steps, 0, 2, "dna", 5, make, kw, 0.01, "Adam", train_ar,
+                                          acc_steps=acc_steps, loss_save=ls)
+        how = dict(_train.LAST_RUN)
+        base = math.lcm(2, acc_steps)
+        if no_graph:
+            assert how["graph"] is False and how["eager_steps"] == 2 * steps
+        else:   # the first period runs eagerly (the libraries settle, the normalized_rows promise is checked), the rest is replayed
+            assert how["graph"] is True and how["replays"] >= 1 and how["period"] % base == 0
+            assert how["eager_steps"] == 2 * steps - how["replays"] * how["period"] and how["eager_steps"] >= base
+        runs.append((ls, [p.detach().cpu().numpy() for p in params]))
+    assert len(runs[0][0]) == 2 * steps // acc_steps
+    assert np.allclose(runs[0][0], runs[1][0], rtol=1e-12, atol=0)
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-14)
+
+
 def test_cnn_step_over_live_contexts_equals_the_step_over_all_rows(ysd1, monkeypatch):
     """The CNN training step walks the plan's lists of contexts that hold counts (forward and backward skip the others: their
     gradient rows are zero).  Forcing the all-rows kernels (BEAR_CNN_BACKWARD=1) must give the same losses and parameters; the
@@ -598,6 +634,29 @@ def test_torch_ar_functions_only_see_contexts_with_counts(which, monkeypatch):
     assert len(runs[0][0]) == 2 * steps and np.allclose(runs[0][0], runs[1][0], rtol=1e-11)
     for a, b in zip(runs[0][1], runs[1][1]):
         assert np.allclose(a, b, rtol=1e-8, atol=1e-10)
+
+
+def test_wrong_normalized_rows_promise_is_refused():
+    """A plugin that sets ``normalized_rows`` on rows that do not sum to one (bear_net.py takes any ar_funcs.make_ar_func_<name>):
+    train() checks the promise once, on the first batch, and raises -- the normalised kernel would have returned wrong sums
+    silently.  Without the attribute the same function trains through the general kernel."""
+    data = dataloader.dataloader(YSD1, "dna", 700, 3)
+
+    def make_unnormalised(promise):
+        def make(lag, alphabet_size, dtype=torch.float64, device=None):
+            w = torch.zeros(alphabet_size + 1, dtype=dtype, device=device, requires_grad=True)
+
+            def ar_func(codes):
+                return (torch.softmax(w, 0) * 1.001).expand(codes.shape[0], alphabet_size + 1)
+            if promise:
+                ar_func.normalized_rows = True
+            return ar_func, [w]
+        return make
+    with pytest.raises(ValueError, match="normalized_rows"):
+        bear_net.train(data.repeat(2), data.num_rows, 2, 0, "dna", 5, make_unnormalised(True), {}, 0.01, "Adam", False)
+    ls = []
+    bear_net.train(data.repeat(2), data.num_rows, 2, 0, "dna", 5, make_unnormalised(False), {}, 0.01, "Adam", False, loss_save=ls)
+    assert len(ls) == 4 and np.all(np.isfinite(ls))
 
 
 def test_graph_path_feeds_the_writer(ysd1):
