@@ -80,6 +80,10 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
                 # (kernels_linear.h, paired lists); declined by the library for tables too sparse to gain from it
                 plan.pair_contexts(packs[k], lag)
             if cnn_ok:
+                if packs[k].data_ptr() % 16 == 0:
+                    # a position of the sorted batch once per distinct prefix (kernels_cnn.h, prefix levels); none attached when the
+                    # prefixes of the table do not repeat
+                    plan.attach_cnn_levels(packs[k], lag, fw)
                 views = tuple(b[:e["rows"]] for b in bufs)
                 return lambda packed: kernels.net_cnn_train_reduce(plan, packs[k], lag, fw, theta, views, packed, train_ar=train_ar)
             return lambda packed: kernels.net_linear_train_reduce(plan, packs[k], lag, theta, packed, train_ar=train_ar)

@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/bear_hip.h"
+#include "bear_levels.h"
 
 namespace {
 thread_local int g_count_hip_error = 0;
@@ -286,4 +287,83 @@ extern "C" int bear_gather_rows(const void *src, const uint32_t *perm, void *dst
                      static_cast<hipStream_t>(stream), static_cast<const unsigned char *>(src), perm, static_cast<unsigned char *>(dst),
                      n_rows, row_bytes);
   return hipGetLastError() == hipSuccess ? BEAR_OK : BEAR_ERR_HIP;
+}
+
+// ------------------------------------------------------------------ prefix levels of a sorted batch (bear_levels.h, kernels_cnn.h)
+namespace {
+__global__ __launch_bounds__(256) void level_flag_kernel(const unsigned long long *__restrict__ codes, uint64_t n, unsigned long long mask,
+                                                         uint32_t *__restrict__ flag) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256)
+    flag[i] = (i == 0 || ((codes[i] ^ codes[i - 1]) & mask) != 0ull) ? 1u : 0u;
+}
+// scan[i] = number of runs that start at or before row i: row i belongs to run scan[i] - 1; a run's first row writes the run's record
+__global__ __launch_bounds__(256) void level_compact_kernel(const unsigned long long *__restrict__ codes, uint64_t n, unsigned long long mask,
+                                                            unsigned long long fill, const uint32_t *__restrict__ flag,
+                                                            uint32_t *__restrict__ scan_to_parent, unsigned long long *__restrict__ out_codes,
+                                                            uint32_t *__restrict__ child_start, uint64_t n_runs) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const uint32_t run = scan_to_parent[i] - 1u;
+    if (flag[i]) {
+      out_codes[run] = (codes[i] & mask) | fill;
+      child_start[run] = (uint32_t)i;
+    }
+    scan_to_parent[i] = run;
+    if (i == 0) child_start[n_runs] = (uint32_t)n;
+  }
+}
+}  // namespace
+
+void bear_level_free(bear_level_dev *lv) {
+  if (!lv) return;
+  (void)hipFree(lv->codes);
+  (void)hipFree(lv->parent_of_below);
+  (void)hipFree(lv->child_start);
+  (void)hipFree(lv->rows);
+  lv->codes = nullptr;
+  lv->parent_of_below = nullptr;
+  lv->child_start = nullptr;
+  lv->rows = nullptr;
+  lv->n = 0;
+}
+
+int bear_level_build(const unsigned long long *codes_below, uint64_t n_below, int letters, bear_level_dev *out, hipStream_t s) {
+  if (!codes_below || !out || n_below == 0 || n_below > 0xfffffffeull || letters < 1 || letters > 21) return BEAR_ERR_INVALID_ARG;
+  int st = BEAR_OK;
+  const unsigned long long mask = (1ull << (3 * letters)) - 1ull;
+  unsigned long long fill = 0ull;
+  for (int l = letters; l < 22 && 3 * l < 64; ++l) fill |= 5ull << (3 * l);     // (bear_pack_kmers_u64 fills positions >= lag the same way)
+  uint32_t *flag = nullptr, *scan = nullptr, n_runs = 0;
+  void *temp = nullptr;
+  size_t tb = 0;
+  out->n = 0;
+  out->letters = letters;
+  out->codes = nullptr;
+  out->parent_of_below = nullptr;
+  out->child_start = nullptr;
+  out->rows = nullptr;
+  CNT_TRY(hipMalloc(&flag, n_below * sizeof(uint32_t)));
+  CNT_TRY(hipMalloc(&scan, n_below * sizeof(uint32_t)));
+  hipLaunchKernelGGL(level_flag_kernel, dim3(grid_for(n_below)), dim3(256), 0, s, codes_below, n_below, mask, flag);
+  CNT_TRY(hipGetLastError());
+  CNT_TRY(rocprim::inclusive_scan(nullptr, tb, flag, scan, n_below, rocprim::plus<uint32_t>(), s));
+  CNT_TRY(hipMalloc(&temp, tb ? tb : 8));
+  CNT_TRY(rocprim::inclusive_scan(temp, tb, flag, scan, n_below, rocprim::plus<uint32_t>(), s));
+  CNT_TRY(hipMemcpyAsync(&n_runs, scan + (n_below - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  CNT_TRY(hipStreamSynchronize(s));
+  CNT_TRY(hipMalloc(&out->codes, (size_t)n_runs * sizeof(unsigned long long)));
+  CNT_TRY(hipMalloc(&out->child_start, ((size_t)n_runs + 1) * sizeof(uint32_t)));
+  CNT_TRY(hipMalloc(&out->rows, (size_t)n_runs * 16 * sizeof(double)));
+  hipLaunchKernelGGL(level_compact_kernel, dim3(grid_for(n_below)), dim3(256), 0, s, codes_below, n_below, mask, fill, flag, scan, out->codes,
+                     out->child_start, (uint64_t)n_runs);
+  CNT_TRY(hipGetLastError());
+  CNT_TRY(hipStreamSynchronize(s));
+  out->n = n_runs;
+  out->parent_of_below = scan;
+  scan = nullptr;
+done:
+  if (temp) (void)hipFree(temp);
+  if (flag) (void)hipFree(flag);
+  if (scan) (void)hipFree(scan);
+  if (st != BEAR_OK) bear_level_free(out);
+  return st;
 }

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "bear_common.h"
+#include "bear_levels.h"
 #include "kernels_rows.h"
 #include "kernels_eval.h"
 #include "kernels_sorted.h"
@@ -304,6 +305,11 @@ struct bear_plan {
   // bear_plan_pair_contexts: the paired form of `live` for the index words at pair_codes (kernels_linear.h), and the plan's
   // tiles sorted into those that took it (tiles_p) and those that keep their plain list (tiles_u), each followed by PLN_DESC_PAD
   // zeroed descriptors; spare word of a descriptor = tile number << 32 | entries of the paired list
+  // bear_plan_attach_cnn_levels: prefix levels of the (k-mer-sorted) contexts at cnn_codes for the convolutional step
+  // (kernels_cnn.h, cnn_level_io); levels[k - 1] = level k, k = 1 .. n_cnn_levels
+  bear_level_dev cnn_levels[CNN_MAX_LAG];
+  int n_cnn_levels, cnn_lag, cnn_fw;
+  const uint64_t *cnn_codes;
   uint16_t *live2;
   pln_tile *tiles_p, *tiles_u;
   uint64_t n_tiles_p, n_tiles_u;
@@ -328,6 +334,7 @@ static void plan_free(bear_plan *p) {
   (void)hipFree(p->heavy_stop);
   (void)hipFree(p->hist);
   (void)hipFree(p->live);
+  for (int k = 0; k < p->n_cnn_levels; ++k) bear_level_free(&p->cnn_levels[k]);
   (void)hipFree(p->live2);
   (void)hipFree(p->tiles_p);
   (void)hipFree(p->tiles_u);
@@ -1549,7 +1556,7 @@ int bear_cnn_forward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows
   if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
   hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), lds, static_cast<hipStream_t>(stream),
                      reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, prior, t1_save,
-                     static_cast<const pln_tile *>(nullptr), static_cast<const uint16_t *>(nullptr), (n_rows + 63) / 64);
+                     static_cast<const pln_tile *>(nullptr), static_cast<const uint16_t *>(nullptr), (n_rows + 63) / 64, cnn_all_positions(D));
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
@@ -1610,7 +1617,8 @@ static int launch_cnn_backward(bear_ws *ws, const cnn_dims &D, const uint64_t *k
     const bool lists = live_plan && live_plan->live && live_plan->n_live_rows < n_rows;   // all rows live: plain groups of rows
     const uint64_t groups = lists ? live_plan->n_tiles : (n_rows + cnnq<2>::TILE - 1) / cnnq<2>::TILE;
     hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)blocks), dim3(64 * waves), lds, s, kc, n_rows, D, params, t1_save, prior,
-                       grad_prior, ws->cnn_partials, lists ? live_plan->tiles : nullptr, lists ? live_plan->live : nullptr, groups);
+                       grad_prior, ws->cnn_partials, lists ? live_plan->tiles : nullptr, lists ? live_plan->live : nullptr, groups,
+                       cnn_all_positions(D));
   }
   else
     hipLaunchKernelGGL(cnn_backward_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, s, kc, n_rows, D, params, t1_save, prior,
@@ -1647,6 +1655,121 @@ int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, in
   return BEAR_OK;
 }
 
+// ---- the convolutional step over prefix levels (kernels_cnn.h, cnn_level_io): the forward kernel once per level from the shortest
+// prefixes down to the contexts, the planned DM kernel with gradient rows, the backward kernel once per level the other way with a
+// row-sum launch in between; block partials accumulate in the workspace's buffer (stream order), one finalize at the end.
+// Level k < K evaluates position P - 1 - k, the last level K the positions [0, P - K).
+static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn_dims &D, const uint64_t *kmer_code, uint64_t n_rows,
+                                   const double *theta, double *prior_buf, double *t1_buf, double *grad_rows_buf, double eps, int train_ar,
+                                   double *packed, hipStream_t s) {
+  const int K = plan->n_cnn_levels;
+  const double *params = theta + 1;
+  int bw_waves = 0;
+  size_t bw_lds = 0;
+  uint64_t bw_blocks = 0;
+  int st = cnn_backward_grid(ws, D, n_rows, D.fw, &bw_waves, &bw_lds, &bw_blocks, s, 0);
+  if (st != BEAR_OK) return st;
+  if (bw_waves != cnnq<2>::WAVES) return BEAR_ERR_INVALID_ARG;      // (attach refuses shapes whose staging does not fit: not reached)
+  auto level_codes = [&](int k) { return k == 0 ? reinterpret_cast<const unsigned long long *>(kmer_code) : plan->cnn_levels[k - 1].codes; };
+  auto level_rows = [&](int k) { return k == 0 ? n_rows : plan->cnn_levels[k - 1].n; };
+  auto level_table = [&](int k) { return k == 0 ? t1_buf : plan->cnn_levels[k - 1].rows; };
+  auto level_io = [&](int k) {
+    cnn_level_io io = cnn_all_positions(D);
+    io.p_lo = k == K ? 0 : D.P - 1 - k;
+    io.p_hi = D.P - k;
+    io.head = k == 0;
+    return io;
+  };
+  const size_t fwd_lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)D.fw * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);
+  for (int k = K; k >= 0; --k) {
+    cnn_level_io io = level_io(k);
+    if (k < K) {
+      io.t1_parent = plan->cnn_levels[k].rows;                 // level k + 1
+      io.parent = plan->cnn_levels[k].parent_of_below;
+    }
+    const uint64_t n = level_rows(k), groups = (n + 63) / 64;
+    uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
+    if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
+    hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), fwd_lds, s, level_codes(k), n, D, params,
+                       k == 0 ? prior_buf : static_cast<double *>(nullptr), level_table(k), static_cast<const pln_tile *>(nullptr),
+                       static_cast<const uint16_t *>(nullptr), groups, io);
+  }
+  HIP_TRY(hipGetLastError());
+  bear_params only_eps;
+  memset(&only_eps, 0, sizeof(only_eps));
+  only_eps.eps = eps;
+  st = launch_prior_plan_grad(ws, plan, prior_buf, only_eps, theta, train_ar, 1, packed, grad_rows_buf, s);   // softmax rows: normalised
+  if (st != BEAR_OK) return st;
+  for (int k = 0; k <= K; ++k) {
+    cnn_level_io io = level_io(k);
+    io.accumulate = k > 0;
+    const uint64_t n = level_rows(k);
+    if (k > 0) {        // this level's dT1 rows = the sums of its children's
+      uint64_t sb = (n * CNN_L1 + 255) / 256;
+      if (sb > (uint64_t)ws->num_cu * 32) sb = (uint64_t)ws->num_cu * 32;
+      hipLaunchKernelGGL(cnn_level_sum_kernel, dim3((unsigned)sb), dim3(256), 0, s, level_table(k - 1), plan->cnn_levels[k - 1].child_start,
+                         n, level_table(k));
+    }
+    io.dT1 = (k == 0 && K > 0) ? t1_buf : (k > 0 ? level_table(k) : nullptr);   // level 0 leaves its dT1 rows where its t1 rows were
+    const uint64_t per_block = (uint64_t)cnnq<2>::TILE * cnnq<2>::WAVES;
+    uint64_t blocks = (n + per_block - 1) / per_block;
+    if (blocks > bw_blocks) blocks = bw_blocks;
+    if (blocks == 0) blocks = 1;
+    if (k == 0) blocks = bw_blocks;      // the first launch writes every row of the partial buffer the finalize reads
+    hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)blocks), dim3(64 * cnnq<2>::WAVES), bw_lds, s, level_codes(k), n, D, params,
+                       t1_buf, prior_buf, grad_rows_buf, ws->cnn_partials, static_cast<const pln_tile *>(nullptr),
+                       static_cast<const uint16_t *>(nullptr), (n + cnnq<2>::TILE - 1) / cnnq<2>::TILE, io);
+  }
+  hipLaunchKernelGGL(cnn_finalize_kernel, dim3((D.total + 3) / 4), dim3(256), 0, s, ws->cnn_partials, (int)bw_blocks, D.total, packed + 2);
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+// Prefix levels of the plan's (k-mer-sorted) contexts for the convolutional step: see include/bear_hip.h.
+int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int lag, int filter_width, int *n_levels, void *stream) {
+  if (n_levels) *n_levels = 0;
+  if (!plan || plan->ncol != 5 || lag < 1 || lag > CNN_MAX_LAG || filter_width < 1 || filter_width > lag) return BEAR_ERR_INVALID_ARG;
+  if (plan->n_rows && (!kmer_code || misaligned(kmer_code))) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int k = 0; k < plan->n_cnn_levels; ++k) {      // a plan holds one set of levels: the new one replaces it
+    plan->bytes -= plan->cnn_levels[k].n * (8 + 4 + 16 * 8) + 4 * (k == 0 ? plan->n_rows : plan->cnn_levels[k - 1].n);
+    bear_level_free(&plan->cnn_levels[k]);
+  }
+  plan->n_cnn_levels = 0;
+  plan->cnn_codes = nullptr;
+  const cnn_dims D = cnn_make_dims(lag, filter_width);
+  // (the part form of the backward kernel is the one with a position range: shapes whose staging does not fit keep the plain step)
+  if (sizeof(double) * (cnnq_fixed_doubles(D) + (size_t)cnnq<2>::WAVES * cnnq<2>::WAVE_DOUBLES) > 160u * 1024u) return BEAR_OK;
+  if (plan->n_rows < 2 || plan->n_live_rows != plan->n_rows) return BEAR_OK;   // (the step walks the plan's lists instead: no levels)
+  const unsigned long long *below = reinterpret_cast<const unsigned long long *>(kmer_code);
+  uint64_t n_below = plan->n_rows;
+  for (int k = 1; k <= D.P - 1; ++k) {
+    bear_level_dev lv;
+    const int st = bear_level_build(below, n_below, lag - k, &lv, s);
+    if (st != BEAR_OK) {
+      if (st == BEAR_ERR_HIP) g_last_hip_error = bear_count_last_hip_error();
+      return st;
+    }
+    // a level pays when it is clearly smaller than the one below (a position per row either way, plus the row traffic)
+    if (10 * lv.n > 6 * n_below) {
+      bear_level_free(&lv);
+      break;
+    }
+    plan->cnn_levels[plan->n_cnn_levels++] = lv;
+    plan->bytes += lv.n * (8 + 4 + 16 * 8) + 4 * n_below;
+    below = lv.codes;
+    n_below = lv.n;
+  }
+  if (plan->n_cnn_levels) {
+    plan->cnn_codes = kmer_code;
+    plan->cnn_lag = lag;
+    plan->cnn_fw = filter_width;
+  }
+  if (n_levels) *n_levels = plan->n_cnn_levels;
+  return BEAR_OK;
+}
+
 int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,
                                   int lag, int filter_width, int num_filters, int layer1_width, const double *theta, double *prior_buf,
                                   double *t1_buf, double *grad_rows_buf, double eps, int train_ar, double *packed, void *stream) {
@@ -1659,6 +1782,9 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
   hipStream_t s = static_cast<hipStream_t>(stream);
   const cnn_dims D = cnn_make_dims(lag, filter_width);
   const double *params = theta + 1;
+  if (plan->n_cnn_levels > 0 && plan->cnn_codes == kmer_code && plan->cnn_lag == lag && plan->cnn_fw == filter_width &&
+      plan->n_live_rows == n_rows && !getenv("BEAR_AMD_CNN_NO_LEVELS"))
+    return cnn_train_reduce_levels(ws, plan, D, kmer_code, n_rows, theta, prior_buf, t1_buf, grad_rows_buf, eps, train_ar, packed, s);
   {
     const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);
     // only the contexts that hold training counts: the DM kernel reads nobody else's prior row (their gradient rows are zero).
@@ -1674,7 +1800,7 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
     if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
     hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), lds, s,
                        reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, D, params, prior_buf, t1_buf,
-                       lists ? plan->tiles : nullptr, lists ? plan->live : nullptr, groups);
+                       lists ? plan->tiles : nullptr, lists ? plan->live : nullptr, groups, cnn_all_positions(D));
   }
   bear_params only_eps;
   memset(&only_eps, 0, sizeof(only_eps));

@@ -62,6 +62,35 @@ static inline cnn_dims cnn_make_dims(int lag, int fw) {
   return d;
 }
 
+// ---- prefix levels (bear_plan_attach_cnn_levels).  In a k-mer-sorted batch the window of position p = letters [p, p + fw) is
+// shared by every context with the same first p + fw letters, and such contexts are neighbours: position p is evaluated once per
+// DISTINCT prefix of p + fw letters instead of once per context.  Level 0 are the contexts themselves and take the last position;
+// level k >= 1 are the distinct prefixes of lag - k letters (as packed contexts whose trailing letters are "unknown"), each with a
+// row of 16 layer-1 sums: its own position P - 1 - k plus the row of its parent at level k + 1 (the last level takes all the
+// positions that are left).  Forward runs the levels from the shortest prefixes down to the contexts; backward runs them the
+// other way, a level's dT1 rows being the sums of its children's (everything a position does with dT1 is linear in it).  Both
+// are the kernels below with a position range and a row source: a dense sorted table does ~1.3 positions per context, not 6.
+struct cnn_level_io {
+  int p_lo, p_hi;                 // the positions this launch evaluates
+  int head;                       // 1: the rows are contexts -- layer 1 onwards (forward: prior rows; backward: dT1 from the head)
+  int accumulate;                 // backward: add this launch's block partials to what the buffer holds (a later level of a step)
+  const double *t1_parent;        // forward: [n_parent][16] sums of the earlier positions, or NULL (the last level)
+  const uint32_t *parent;         // forward: [n_rows] row of t1_parent
+  double *dT1;                    // backward: head -> the contexts' dT1 rows are also written here [n_rows][16] (NULL: not wanted; may be the
+                                  // t1 buffer itself); no head -> the rows' dT1 are READ from here
+};
+static inline cnn_level_io cnn_all_positions(const cnn_dims &D) {
+  cnn_level_io io;
+  io.p_lo = 0;
+  io.p_hi = D.P;
+  io.head = 1;
+  io.accumulate = 0;
+  io.t1_parent = nullptr;
+  io.parent = nullptr;
+  io.dT1 = nullptr;
+  return io;
+}
+
 // LDS image of the filter bank: 6 letter rows per tap (row 5 = zeros: characters outside the alphabet, core.py:173)
 __device__ __forceinline__ void cnn_stage_filters(double *Fs, const double *__restrict__ params, const cnn_dims &D) {
   for (int k = threadIdx.x; k < D.fw * 6 * CNN_NF; k += CNN_THREADS) {
@@ -217,7 +246,7 @@ __global__ __launch_bounds__(CNN_THREADS, 4) void cnn_forward_kernel(const unsig
                                                                    cnn_dims D, const double *__restrict__ params,
                                                                    double *__restrict__ prior, double *__restrict__ t1_save,
                                                                    const pln_tile *__restrict__ tiles, const uint16_t *__restrict__ live_lists,
-                                                                   uint64_t n_groups) {
+                                                                   uint64_t n_groups, const cnn_level_io io) {
   extern __shared__ __attribute__((aligned(16))) double cnn_lds[];
   double *exptab = cnn_lds;                       // [128]
   double *Fs = cnn_lds + BEAR_EXPTAB_N;           // [fw][6][nf]
@@ -252,6 +281,15 @@ __global__ __launch_bounds__(CNN_THREADS, 4) void cnn_forward_kernel(const unsig
     double t1[CNN_L1];
 #pragma unroll
     for (int j = 0; j < CNN_L1; ++j) t1[j] = 0.0;
+    if (io.t1_parent) {      // a level's rows start from their parent's sums (the earlier positions); neighbours share the parent
+      const double2 *src = reinterpret_cast<const double2 *>(io.t1_parent + (size_t)io.parent[i] * CNN_L1);
+#pragma unroll
+      for (int j = 0; j < CNN_L1 / 2; ++j) {
+        const double2 v = src[j];
+        t1[2 * j] = v.x;
+        t1[2 * j + 1] = v.y;
+      }
+    }
     // In a k-mer-sorted batch (bear_net.train sorts at upload) the 64 contexts of a wave share their leading letters: a window
     // [p, p + fw) that lies inside the shared prefix gives every context the SAME conv row, activations and layer-1
     // contribution.  Then 30 lanes compute the row once (lane = filter), 16 lanes the contribution (lane = unit), and every
@@ -259,7 +297,7 @@ __global__ __launch_bounds__(CNN_THREADS, 4) void cnn_forward_kernel(const unsig
     // holds at most CNN_FWD_RUNS of them (the first positions behind the shared prefix); two such items go through
     // cnn_forward_shared_window2 at once.  The first position with more windows and all later ones (in a sorted batch they
     // reach further into the varying letters) take the per-context path below.
-    int p_ctx = D.P;
+    int p_ctx = io.p_hi;
     {
       bool pend = false, keep_a = false;
       int p_a = 0;
@@ -278,7 +316,7 @@ __global__ __launch_bounds__(CNN_THREADS, 4) void cnn_forward_kernel(const unsig
         if (two) add_u(p_b, w_b, Us + 80);
         pend = false;
       };
-      for (int p = 0; p < D.P; ++p) {
+      for (int p = io.p_lo; p < io.p_hi; ++p) {
         const unsigned long long win = (code >> (3 * p)) & wmask;
         auto next_run = [&](unsigned long long rem, unsigned long long *w) {   // the lanes that share the window of rem's first lane
           const int leader = __builtin_ctzll(rem);
@@ -322,7 +360,7 @@ __global__ __launch_bounds__(CNN_THREADS, 4) void cnn_forward_kernel(const unsig
       }
       if (pend) finish(p_a, w_a, false, false);
     }
-    for (int p = p_ctx; p < D.P; ++p) {
+    for (int p = p_ctx; p < io.p_hi; ++p) {
       double x[CNN_NF];
       cnn_conv_norm(Fs, code, p, D.fw, x);
       const double *__restrict__ s0 = params + D.os0 + p * CNN_NF, *__restrict__ b0 = params + D.ob0 + p * CNN_NF;
@@ -351,6 +389,14 @@ __global__ __launch_bounds__(CNN_THREADS, 4) void cnn_forward_kernel(const unsig
         sc = sn;
         bc = bn;
       }
+    }
+    if (!io.head) {          // a level of prefixes: its rows of layer-1 sums are all there is
+      if (live) {
+        double2 *o = reinterpret_cast<double2 *>(t1_save + i * CNN_L1);
+#pragma unroll
+        for (int j = 0; j < CNN_L1 / 2; ++j) o[j] = make_double2(t1[2 * j], t1[2 * j + 1]);
+      }
+      continue;
     }
     double n1[CNN_L1], e1[CNN_L1], d1[CNN_L1];
     cnn_layer1(t1, params, D, exptab, n1, e1, d1);
@@ -870,7 +916,8 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
                                                                                   const double *__restrict__ grad_prior,
                                                                                   double *__restrict__ partials,
                                                                                   const pln_tile *__restrict__ tiles,
-                                                                                  const uint16_t *__restrict__ live_lists, uint64_t n_groups) {
+                                                                                  const uint16_t *__restrict__ live_lists, uint64_t n_groups,
+                                                                                  const cnn_level_io io) {
   using C = cnnq<Q>;
   constexpr int TILE = C::TILE, FH = C::FH, JH = C::JH, ES = C::ES, CS = C::CS, KS = C::KS, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) double cnn_lds[];
@@ -979,19 +1026,22 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
       gp[b] = 0.0;
     }
     if (live) {
-      const double2 *src = reinterpret_cast<const double2 *>(t1_save + i * CNN_L1 + h * JH);
+      const double2 *src = reinterpret_cast<const double2 *>((io.head ? t1_save : io.dT1) + i * CNN_L1 + h * JH);
 #pragma unroll
       for (int j = 0; j < JH / 2; ++j) {
         const double2 v = src[j];
         t1[2 * j] = v.x;
         t1[2 * j + 1] = v.y;
       }
+      if (io.head) {
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        pr[b] = prior[i * 5 + b];
-        gp[b] = grad_prior[i * 5 + b];
+        for (int b = 0; b < 5; ++b) {
+          pr[b] = prior[i * 5 + b];
+          gp[b] = grad_prior[i * 5 + b];
+        }
       }
     }
+    if (io.head) {      // (a level of prefixes: t1 holds the rows' dT1 already -- the sums of their children's)
     // layer 1 (as cnn_layer1, the 16 units over the Q parts)
     double r1;
     {
@@ -1070,6 +1120,12 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
       const uint32_t c = lane & 31u;
       cnn_lds_add(G + (c < 16u ? D.os1 + (int)c : D.ob1 + (int)c - 16), cs);
     }
+    if (io.dT1 && live) {     // the contexts' dT1 rows: what the next level's rows are the sums of
+      double2 *o = reinterpret_cast<double2 *>(io.dT1 + i * CNN_L1 + h * JH);
+#pragma unroll
+      for (int j = 0; j < JH / 2; ++j) o[j] = make_double2(t1[2 * j], t1[2 * j + 1]);
+    }
+    }
 #pragma unroll
     for (int j = 0; j < JH; ++j) T[(h * JH + j) * ES + ctx] = t1[j];
     // positions whose window every context of the tile shares (see cnn_backward_shared_window): handled here, once per tile,
@@ -1099,7 +1155,7 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
       };
       bool have_full = false;
       double s_full = 0.0;
-      for (int p = 0; p < D.P; ++p) {
+      for (int p = io.p_lo; p < io.p_hi; ++p) {
         const unsigned long long wid = (code >> (3 * p)) & wm;
         unsigned long long rem = live_mask, w;
         for (int runs = 0; rem != 0ull && runs < CNN_SHARED_RUNS; ++runs) rem &= ~next_run(wid, rem, &w);
@@ -1159,7 +1215,7 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
     {
     const uint32_t ctx = lane & (TILE - 1), h = lane / TILE, lq = lane >> 4, lr = lane & 15u;
     const bool last = h == Q - 1;                   // the part whose last two filter slots are dummies (30 filters)
-    for (int p = 0; p < D.P; ++p) {
+    for (int p = io.p_lo; p < io.p_hi; ++p) {
 #ifndef CNN_NO_SKIP
       if ((shared >> p) & 1u) continue;
 #endif
@@ -1404,7 +1460,28 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
     for (int k = 0; k < 8; ++k) atomicAdd(&cnn_stamp_sums[k], tph[k]);
 #endif
   __syncthreads();
-  for (int k = threadIdx.x; k < D.total; k += blockDim.x) partials[(size_t)blockIdx.x * D.total + k] = G[k];
+  for (int k = threadIdx.x; k < D.total; k += blockDim.x) {
+    double *dst = partials + (size_t)blockIdx.x * D.total + k;
+    *dst = io.accumulate ? *dst + G[k] : G[k];       // (launches of one step are stream-ordered: block b owns row b of the buffer)
+  }
+}
+
+// a level's dT1 rows from its children's (the children of a row are neighbours): one thread per (row, unit)
+__global__ __launch_bounds__(256) void cnn_level_sum_kernel(const double *__restrict__ child_rows, const uint32_t *__restrict__ child_start,
+                                                            uint64_t n_rows, double *__restrict__ rows) {
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n_rows * CNN_L1; t += (uint64_t)gridDim.x * 256) {
+    const uint64_t u = t / CNN_L1;
+    const uint32_t j = (uint32_t)(t - u * CNN_L1);
+    const uint32_t c0 = child_start[u], c1 = child_start[u + 1];
+    double s2[2] = {0.0, 0.0};
+    uint32_t c = c0;
+    for (; c + 1 < c1; c += 2) {
+      s2[0] += child_rows[(size_t)c * CNN_L1 + j];
+      s2[1] += child_rows[(size_t)(c + 1) * CNN_L1 + j];
+    }
+    if (c < c1) s2[0] += child_rows[(size_t)c * CNN_L1 + j];
+    rows[t] = s2[0] + s2[1];
+  }
 }
 
 // fixed-order sum of the block partial vectors: one wave per parameter (lane-strided partial sums, then the shuffle tree)

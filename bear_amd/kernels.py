@@ -156,6 +156,20 @@ class Plan:
         self.paired_codes = kmer_index if ok.value else None
         return bool(ok.value)
 
+    def attach_cnn_levels(self, kmer_code, lag, filter_width):
+        """``bear_plan_attach_cnn_levels``: prefix levels of the (k-mer-sorted) packed contexts ``kmer_code`` (``pack_kmers``) of this
+        plan's rows for the convolutional training step -- a position is then evaluated once per distinct prefix.  Returns the
+        number of levels attached (0: the step runs as before).  The tensor is kept alive; it must not be modified afterwards."""
+        _check_codes(kmer_code)
+        if kmer_code.shape[0] != self.counts.shape[0] or kmer_code.data_ptr() % 16:
+            raise ValueError("kmer_code: one 16-byte aligned packed context per row of the plan's count slab")
+        n = ctypes.c_int(0)
+        with torch.cuda.device(self.counts.device):
+            st = _lib.lib().bear_plan_attach_cnn_levels(self._h, _ptr(kmer_code), int(lag), int(filter_width), ctypes.byref(n), _stream())
+        _lib.check(st, "bear_plan_attach_cnn_levels")
+        self.cnn_codes = kmer_code if n.value else None
+        return int(n.value)
+
     def tiles(self):
         """Diagnostics (``bear_plan_tile_info``): (row0 [T] uint64, rows [T] uint32, items [T] uint32, stream_offset [T] uint64)."""
         import numpy as np

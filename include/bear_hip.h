@@ -176,6 +176,18 @@ int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_
  *   AR function only for the contexts that hold training counts (the plan's lists: nothing else enters the ELBO or a gradient);
  *   the other rows of prior_buf / t1_buf are left as they were -- hand over initialised (e.g. zeroed) buffers.
  */
+/*
+ * Optional, once per batch, after bear_plan_create (and after the k-mer order, if any): prefix levels for the convolutional step.
+ * In a k-mer-sorted batch the window of position p (letters [p, p + filter_width)) is the same for all contexts that share their
+ * first p + filter_width letters, and those are neighbours; with levels attached, bear_net_cnn_train_reduce_f64 / _step_f64
+ * called with this plan, this kmer_code pointer, lag and filter_width evaluate a position once per DISTINCT prefix, forward and
+ * backward (one launch per level; the sums are the same up to rounding) -- about 1.3 instead of 6 positions per context on a
+ * dense sorted table of 13-mers.  The levels are tied to the buffer kmer_code (bear_pack_kmers_u64 form; identity and contents,
+ * like the plan's count slab).  *n_levels (nullable) = 0: nothing was attached (rows in another order, a table too sparse for its
+ * prefixes to repeat, a plan whose lists skip rows, a shape outside the fused kernels): the step runs as before.
+ * Holds about 45 bytes per context on a dense table.  Synchronises `stream` (set-up path).
+ */
+int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int lag, int filter_width, int *n_levels, void *stream);
 int bear_train_apply_f64(double *theta, int n_theta, const double *packed, double *adam_m, double *adam_v, double *adam_t,
                          double learning_rate, double scale, int train_ar, double *loss_buf, uint64_t loss_cap, void *stream);
 int bear_ref_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,

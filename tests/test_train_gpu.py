@@ -612,6 +612,67 @@ def test_cnn_step_on_a_dense_sorted_table_equals_its_three_kernels_over_all_rows
     assert (pk[2:] - want[2:]).abs().max().item() <= 1e-10 * want[2:].abs().max().item()
 
 
+@pytest.mark.parametrize("lag,fw,n,fixed,want_levels", [(13, 8, 300_000, 4, 5), (13, 8, 40_000, 6, 5), (7, 3, 50_000, 0, 4), (9, 9, 20_000, 0, 0),
+                                                       (13, 8, 5_000, 0, 0), (5, 3, 3_000, 0, 2), (21, 8, 60_000, 15, 0), (16, 12, 60_000, 9, None)])
+def test_cnn_step_over_prefix_levels_equals_the_plain_kernels(lag, fw, n, fixed, want_levels, monkeypatch):
+    """bear_plan_attach_cnn_levels: with prefix levels the convolutional step evaluates a position once per distinct prefix of the
+    sorted batch (forward: the levels' rows of layer-1 sums down to the contexts; backward: dT1 rows summed up the levels).  Its
+    packed [sum LL, d/dh, d/d params] must equal the three plain kernels over all rows in RANDOM order, and the step without levels
+    (BEAR_AMD_CNN_NO_LEVELS=1) -- on tables as dense in k-mer space as the benchmark, with duplicates, start symbols and unknown
+    letters, on shapes with one position (no level possible), on a table too sparse for any prefix to repeat (none attached) and
+    on a shape whose backward pass does not fit the part form of the kernel (lag 21: none attached either)."""
+    from bear_amd import kernels
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(dev).manual_seed(lag * 100 + fw)
+    codes = torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev, generator=gen)
+    if fixed:
+        codes[:, :fixed] = torch.randint(0, 4, (fixed,), dtype=torch.int8, device=dev, generator=gen)     # 4^(lag - fixed) k-mers behind one prefix
+    odd = torch.randperm(n, device=dev, generator=gen)[:max(2, n // 200)]
+    codes[odd[::2], 0] = 4                                             # start symbols at the front, an unknown letter somewhere
+    codes[odd[1::2], torch.randint(0, lag, (odd[1::2].numel(),), device=dev, generator=gen)] = -1
+    key = torch.zeros(n, dtype=torch.int64, device=dev)
+    for l in range(lag):
+        c = codes[:, l].to(torch.int64)
+        key = key * 6 + torch.where(c >= 0, c, torch.full_like(c, 5))
+    codes = codes[torch.argsort(key)].contiguous()
+    counts = kernels.synth_counts(7, 0, n, dev, want=("train",))["train"]
+    counts[:, 4] += (counts == 0).all(dim=1).to(counts.dtype)          # every context holds a count: the step takes plain groups of rows
+    torch.manual_seed(9)
+    _, params = ar_funcs.make_ar_func_cnn(lag, 4, filter_width=fw, device=dev)
+    flat = torch.cat([q.detach().reshape(-1) for q in params]).contiguous()
+    h_s = -0.3
+    theta = torch.cat([torch.tensor([h_s], dtype=torch.float64, device=dev), flat]).contiguous()
+    packed_codes = kernels.pack_kmers(codes)
+    plan = kernels.Plan(counts, 5)
+    bufs = kernels.cnn_step_buffers(n, lag, fw, dev)
+    got_levels = plan.attach_cnn_levels(packed_codes, lag, fw)
+    if want_levels is not None:
+        assert got_levels == want_levels
+    else:
+        assert 1 <= got_levels <= lag - fw
+    pk = torch.zeros(2 + flat.numel(), dtype=torch.float64, device=dev)
+    for ar in (False, True):
+        kernels.net_cnn_train_reduce(plan, packed_codes, lag, fw, theta, bufs, pk, train_ar=ar)
+        with_levels = pk.clone()
+        monkeypatch.setenv("BEAR_AMD_CNN_NO_LEVELS", "1")
+        kernels.net_cnn_train_reduce(plan, packed_codes, lag, fw, theta, bufs, pk, train_ar=ar)
+        monkeypatch.delenv("BEAR_AMD_CNN_NO_LEVELS")
+        perm = torch.randperm(n, device=dev, generator=gen)
+        counts_p, codes_p = counts[perm].contiguous(), kernels.pack_kmers(codes[perm].contiguous())
+        prior, t1 = kernels.cnn_forward(codes_p, flat, lag, fw)
+        out, g = kernels.dm_prior_planned(kernels.Plan(counts_p, 5), prior, h_s, want_grad=True, train_ar=ar)
+        grad = kernels.cnn_backward(codes_p, flat, lag, fw, t1, prior, g)
+        want = torch.cat([out[:2], grad])
+        for name, got in (("levels", with_levels), ("plain step", pk)):
+            assert abs(float(got[0] - want[0])) <= 1e-12 * abs(float(want[0])), (name, ar)
+            assert abs(float(got[1] - want[1])) <= 1e-10 * max(abs(float(want[1])), 1.0), (name, ar)
+            assert (got[2:] - want[2:]).abs().max().item() <= 1e-10 * want[2:].abs().max().item(), (name, ar)
+    # another buffer with the same contents, another filter width: the plain step
+    other = packed_codes.clone()
+    kernels.net_cnn_train_reduce(plan, other, lag, fw, theta, bufs, pk, train_ar=True)
+    assert (pk[2:] - want[2:]).abs().max().item() <= 1e-10 * want[2:].abs().max().item()
+
+
 @pytest.mark.parametrize("which", ["bear_ref + linear net", "bear_ref + cnn net", "bear_net + SGD (torch loop)"])
 def test_torch_ar_functions_only_see_contexts_with_counts(which, monkeypatch):
     """The autograd loops hand an AR function only the contexts that hold training counts (gather, scatter back): the same losses
