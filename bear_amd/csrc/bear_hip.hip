@@ -1655,6 +1655,12 @@ int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, in
   return BEAR_OK;
 }
 
+static int cnn_forward_levels(bear_ws *ws, const bear_plan *plan, const cnn_dims &D, const uint64_t *kmer_code, uint64_t n_rows,
+                              const double *params, double *prior, double *t1_buf, hipStream_t s);
+static bool cnn_parts_form_forced_off() {      // BEAR_CNN_BACKWARD=1 (cnn_backward_grid): the 64-context form of the backward kernel, which has no position range
+  const char *force = getenv("BEAR_CNN_BACKWARD");
+  return force && force[0] == '1';
+}
 // ---- the convolutional step over prefix levels (kernels_cnn.h, cnn_level_io): the forward kernel once per level from the shortest
 // prefixes down to the contexts, the planned DM kernel with gradient rows, the backward kernel once per level the other way with a
 // row-sum launch in between; block partials accumulate in the workspace's buffer (stream order), one finalize at the end.
@@ -1680,21 +1686,8 @@ static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn
     io.head = k == 0;
     return io;
   };
-  const size_t fwd_lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)D.fw * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);
-  for (int k = K; k >= 0; --k) {
-    cnn_level_io io = level_io(k);
-    if (k < K) {
-      io.t1_parent = plan->cnn_levels[k].rows;                 // level k + 1
-      io.parent = plan->cnn_levels[k].parent_of_below;
-    }
-    const uint64_t n = level_rows(k), groups = (n + 63) / 64;
-    uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
-    if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
-    hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), fwd_lds, s, level_codes(k), n, D, params,
-                       k == 0 ? prior_buf : static_cast<double *>(nullptr), level_table(k), static_cast<const pln_tile *>(nullptr),
-                       static_cast<const uint16_t *>(nullptr), groups, io);
-  }
-  HIP_TRY(hipGetLastError());
+  st = cnn_forward_levels(ws, plan, D, kmer_code, n_rows, params, prior_buf, t1_buf, s);
+  if (st != BEAR_OK) return st;
   bear_params only_eps;
   memset(&only_eps, 0, sizeof(only_eps));
   only_eps.eps = eps;
@@ -1770,6 +1763,51 @@ int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int 
   return BEAR_OK;
 }
 
+int bear_plan_cnn_level_rows(const bear_plan *plan, uint64_t *rows_out, int capacity) {
+  if (!plan || (capacity > 0 && !rows_out)) return BEAR_ERR_INVALID_ARG;
+  for (int k = 0; k < plan->n_cnn_levels && k < capacity; ++k) rows_out[k] = plan->cnn_levels[k].n;
+  return plan->n_cnn_levels;
+}
+
+// The forward pass alone over a plan's prefix levels (evaluation-style callers, bench.py): prior rows and the contexts' layer-1 sums.
+static int cnn_forward_levels(bear_ws *ws, const bear_plan *plan, const cnn_dims &D, const uint64_t *kmer_code, uint64_t n_rows,
+                              const double *params, double *prior, double *t1_buf, hipStream_t s) {
+  const int K = plan->n_cnn_levels;
+  const size_t fwd_lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)D.fw * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);
+  for (int k = K; k >= 0; --k) {
+    cnn_level_io io = cnn_all_positions(D);
+    io.p_lo = k == K ? 0 : D.P - 1 - k;
+    io.p_hi = D.P - k;
+    io.head = k == 0;
+    if (k < K) {
+      io.t1_parent = plan->cnn_levels[k].rows;                 // level k + 1
+      io.parent = plan->cnn_levels[k].parent_of_below;
+    }
+    const uint64_t n = k == 0 ? n_rows : plan->cnn_levels[k - 1].n, groups = (n + 63) / 64;
+    uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
+    if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
+    hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), fwd_lds, s,
+                       k == 0 ? reinterpret_cast<const unsigned long long *>(kmer_code) : plan->cnn_levels[k - 1].codes, n, D, params,
+                       k == 0 ? prior : static_cast<double *>(nullptr), k == 0 ? t1_buf : plan->cnn_levels[k - 1].rows,
+                       static_cast<const pln_tile *>(nullptr), static_cast<const uint16_t *>(nullptr), groups, io);
+  }
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
+int bear_cnn_forward_plan_f64(bear_ws *ws, const bear_plan *plan, const uint64_t *kmer_code, uint64_t n_rows, int lag, int filter_width,
+                              int num_filters, int layer1_width, const double *params, double *prior, double *t1_save, void *stream) {
+  int st = cnn_check(ws, lag, filter_width, num_filters, layer1_width);
+  if (st != BEAR_OK) return st;
+  if (!plan || plan->n_rows != n_rows || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
+  if (n_rows == 0) return BEAR_OK;
+  if (!kmer_code || !params || !prior || !t1_save || misaligned(t1_save) || (reinterpret_cast<uintptr_t>(prior) & 7u)) return BEAR_ERR_INVALID_ARG;
+  if (!(plan->n_cnn_levels > 0 && plan->cnn_codes == kmer_code && plan->cnn_lag == lag && plan->cnn_fw == filter_width) ||
+      getenv("BEAR_AMD_CNN_NO_LEVELS"))
+    return bear_cnn_forward_f64(ws, kmer_code, n_rows, lag, filter_width, num_filters, layer1_width, params, prior, t1_save, stream);
+  return cnn_forward_levels(ws, plan, cnn_make_dims(lag, filter_width), kmer_code, n_rows, params, prior, t1_save, static_cast<hipStream_t>(stream));
+}
+
 int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,
                                   int lag, int filter_width, int num_filters, int layer1_width, const double *theta, double *prior_buf,
                                   double *t1_buf, double *grad_rows_buf, double eps, int train_ar, double *packed, void *stream) {
@@ -1783,7 +1821,7 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
   const cnn_dims D = cnn_make_dims(lag, filter_width);
   const double *params = theta + 1;
   if (plan->n_cnn_levels > 0 && plan->cnn_codes == kmer_code && plan->cnn_lag == lag && plan->cnn_fw == filter_width &&
-      plan->n_live_rows == n_rows && !getenv("BEAR_AMD_CNN_NO_LEVELS"))
+      plan->n_live_rows == n_rows && !getenv("BEAR_AMD_CNN_NO_LEVELS") && !cnn_parts_form_forced_off())
     return cnn_train_reduce_levels(ws, plan, D, kmer_code, n_rows, theta, prior_buf, t1_buf, grad_rows_buf, eps, train_ar, packed, s);
   {
     const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);

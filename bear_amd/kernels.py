@@ -170,6 +170,15 @@ class Plan:
         self.cnn_codes = kmer_code if n.value else None
         return int(n.value)
 
+    def cnn_level_rows(self):
+        """Rows of the attached prefix levels 1 .. n (``bear_plan_cnn_level_rows``); [] without levels."""
+        n = int(_lib.lib().bear_plan_cnn_level_rows(self._h, None, 0))
+        if n <= 0:
+            return []
+        rows = (ctypes.c_uint64 * n)()
+        _lib.lib().bear_plan_cnn_level_rows(self._h, rows, n)
+        return [int(r) for r in rows]
+
     def tiles(self):
         """Diagnostics (``bear_plan_tile_info``): (row0 [T] uint64, rows [T] uint32, items [T] uint32, stream_offset [T] uint64)."""
         import numpy as np
@@ -513,10 +522,19 @@ def _check_codes(kmer_code):
         raise ValueError("kmer_code must be a contiguous CUDA int64 tensor [n_rows] (pack_kmers)")
 
 
-def cnn_forward(kmer_code, flat_params, lag, filter_width, save=True, ws=None):
-    """One launch of ``bear_cnn_forward_f64``: (prior [n,5], t1 [n,16] or None)."""
+def cnn_forward(kmer_code, flat_params, lag, filter_width, save=True, ws=None, plan=None):
+    """One launch of ``bear_cnn_forward_f64``: (prior [n,5], t1 [n,16] or None).  ``plan``: a plan of the same rows -- the forward
+    pass then runs over its prefix levels when they were attached for this tensor (``bear_cnn_forward_plan_f64``; t1 is kept)."""
     _check_codes(kmer_code)
     n = kmer_code.shape[0]
+    if plan is not None:
+        prior = torch.empty((n, 5), dtype=torch.float64, device=kmer_code.device)
+        t1 = torch.empty((n, CNN_LAYER1_WIDTH), dtype=torch.float64, device=kmer_code.device)
+        with torch.cuda.device(kmer_code.device):
+            st = _lib.lib().bear_cnn_forward_plan_f64(plan.ws.handle, plan._h, _ptr(kmer_code), n, int(lag), int(filter_width), CNN_NUM_FILTERS,
+                                                      CNN_LAYER1_WIDTH, _ptr(flat_params), _ptr(prior), _ptr(t1), _stream())
+        _lib.check(st, "bear_cnn_forward_plan_f64")
+        return prior, t1
     if not (flat_params.is_cuda and flat_params.dtype == torch.float64 and flat_params.is_contiguous()
             and flat_params.numel() == cnn_param_count(lag, filter_width)):
         raise ValueError("flat_params must be the contiguous CUDA float64 parameter vector of bear_cnn_param_count elements")

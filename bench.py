@@ -97,6 +97,18 @@ def fp64_roofline(flops, ms, per="launch"):
             "peak_TFLOPs": FP64_PEAK_TFLOPS, "frac_of_fp64_peak": tf / FP64_PEAK_TFLOPS}
 
 
+def cnn_rates(credited, executed, ms):
+    """The convolutional kernels in k-mer order SKIP work that neighbouring contexts share, so two rates: `credited` = what a
+    context-by-context evaluation would execute (flops_cnn per context) over the time -- an algorithmic speed, NOT a utilisation
+    and not bounded by the peak -- and `executed` = the flops of the evaluations actually carried out (None where the kernel
+    decides per wave what to share and no count exists) over the same time, which is the fraction of the fp64 peak."""
+    out = {"credited_fp64_flops": credited, "credited_TFLOPs": credited / (ms * 1e-3) / 1e12, "peak_TFLOPs": FP64_PEAK_TFLOPS,
+           "executed_fp64_flops": executed}
+    if executed is not None:
+        out.update(executed_TFLOPs=executed / (ms * 1e-3) / 1e12, frac_of_fp64_peak=executed / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS)
+    return out
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -455,7 +467,17 @@ def main():
         packed_kept = packed_sorted_raw.index_select(0, keep).contiguous()
         plan_kept = kernels.Plan(tr_kept, 5)
         bufs_kept = tuple(b[:keep.numel()] for b in bufs)
+        kept_plain_ms = timed(lambda: kernels.net_cnn_train_reduce(plan_kept, packed_kept, lag, fw, theta, bufs_kept, pk), 3)
+        pk_plain = pk.clone()
+        # ... with prefix levels (bear_plan_attach_cnn_levels, as bear_net.train attaches them to every sorted batch): a position is
+        # evaluated once per distinct prefix of the batch, forward and backward
+        n_levels = plan_kept.attach_cnn_levels(packed_kept, lag, fw)
+        level_rows = plan_kept.cnn_level_rows()
         kept_ms = timed(lambda: kernels.net_cnn_train_reduce(plan_kept, packed_kept, lag, fw, theta, bufs_kept, pk), 3)
+        levels_same = bool(abs(float(pk[0] - pk_plain[0])) <= 1e-12 * abs(float(pk_plain[0]))
+                           and float((pk[2:] - pk_plain[2:]).abs().max()) <= 1e-10 * float(pk_plain[2:].abs().max()))
+        kept_fwd_ms = timed(lambda: kernels.cnn_forward(packed_kept, flat, lag, fw, plan=plan_kept), 3)
+        del pk_plain
         lin_kept = kernels.linear_index(packed_kept, lag)
         plan_kept.pair_contexts(lin_kept, lag)
         lin_k_ms = timed(lambda: kernels.dm_linear(plan_kept, lin_kept, mat, h_s), 5)
@@ -463,22 +485,42 @@ def main():
         kept_frac = keep.numel() / n
         del keep, tr_kept, packed_kept, plan_kept, bufs_kept, lin_kept
         cnn_f, cnn_b = flops_cnn(lag, fw)
+        # flops the level launches execute: level k < K one position per row, the last level the positions that are left; the head
+        # (layer 1 onwards) per context
+        n_kept = int(kept_frac * n + 0.5)
+        pos_f = (cnn_f - flops_cnn(fw, fw)[0]) / (lag - fw)            # one position's share of a context's forward flops
+        head_f = cnn_f - (lag - fw + 1) * pos_f
+        lv = [n_kept] + level_rows
+        pos_evals = sum(r * ((lag - fw + 1 - k) if k == len(lv) - 1 else 1) for k, r in enumerate(lv))
+        exec_f = pos_evals * pos_f + n_kept * head_f
         extra["cnn_head"] = {"lag": lag, "filter_width": fw, "forward_ms": f_ms, "backward_ms": b_ms,
-                             "roofline_forward_rows_in_kmer_order": fp64_roofline(cnn_f * n, fs_ms),
-                             "roofline_backward_rows_in_kmer_order": fp64_roofline(cnn_b * n, bs_ms),
+                             "rates_forward_rows_in_kmer_order": cnn_rates(cnn_f * n, None, fs_ms),
+                             "rates_backward_rows_in_kmer_order": cnn_rates(cnn_b * n, None, bs_ms),
                              "roofline_forward_rows_in_random_order": fp64_roofline(cnn_f * n, f_ms),
                              "roofline_backward_rows_in_random_order": fp64_roofline(cnn_b * n, b_ms),
                              "forward_ms_rows_in_kmer_order": fs_ms, "backward_ms_rows_in_kmer_order": bs_ms,
                              "all_rows_step_ms": f_ms + b_ms + extra["net_with_gradient_rows"]["kernel_ms"],
                              "train_step_ms": s_ms, "train_step_ms_rows_in_random_order": s_ms_random,
                              "train_step_ms_as_bear_net_train_holds_the_batch": kept_ms, "contexts_with_training_counts": kept_frac,
+                             "train_step_ms_without_prefix_levels": kept_plain_ms,
+                             "prefix_levels": {"attached": n_levels, "rows": lv, "position_evaluations_per_context": pos_evals / max(n_kept, 1),
+                                               "equals_step_without_levels": levels_same,
+                                               "forward_ms": kept_fwd_ms,
+                                               "forward_ms_scaled_to_all_contexts": kept_fwd_ms / max(kept_frac, 1e-9),
+                                               "rates_forward": cnn_rates(cnn_f * n_kept, exec_f, kept_fwd_ms),
+                                               "rates_step_forward_plus_backward": cnn_rates((cnn_f + cnn_b) * n_kept, exec_f * (1 + cnn_b / cnn_f),
+                                                                                           kept_ms - extra["net_with_gradient_rows"]["kernel_ms_rows_asserted_normalized"] * kept_frac),
+                                               "note": "bear_plan_attach_cnn_levels: rows[k] = distinct prefixes of lag - k letters of the sorted batch; level k "
+                                                       "evaluates position P - 1 - k once per row (the last level the positions left), forward and backward"},
                              "step_contexts_per_s": n / (kept_ms * 1e-3),
                              "note": "forward_ms / backward_ms: bear_cnn_forward_f64 / bear_cnn_backward_f64 over all rows in random order (any caller); "
                                      "train_step_ms: bear_net_cnn_train_reduce_f64 = forward + planned DM kernel with gradient rows + "
                                      "backward over the contexts that hold training counts (70 % of this table), rows in k-mer order as "
                                      "bear_net.train uploads a batch (both kernels evaluate a window that a wave's / tile's contexts share once); "
                                      "train_step_ms_as_bear_net_train_holds_the_batch: the same step on the table bear_net.train keeps resident -- "
-                                     "k-mer order and the contexts without training counts left out (step_contexts_per_s counts all 1e8)"}
+                                     "k-mer order, the contexts without training counts left out, prefix levels attached (step_contexts_per_s counts all "
+                                     "1e8).  rates_*: credited flops / time is an algorithmic speed, not a utilisation (sorted-order kernels skip shared "
+                                     "work); frac_of_fp64_peak only where the executed flops are counted"}
         del packed, packed_raw, packed_sorted_raw, bufs, pk, theta
         m = min(n, 20_000_000)
         test = kernels.synth_counts(SEED, row0, m, dev, want=("test",))["test"]
@@ -537,7 +579,7 @@ def main():
                     extra[entry]["roofline"].update(valu_busy_frac_profiled=prof[key]["valu_busy_frac"], valu_source=src)
             for which, key in (("forward", "cnn_forward"), ("backward", "cnn_backward")):
                 if "valu_busy_frac" in prof.get(key, {}):
-                    extra["cnn_head"]["roofline_%s_rows_in_kmer_order" % which].update(valu_busy_frac_profiled_all_launches=prof[key]["valu_busy_frac"], valu_source=src)
+                    extra["cnn_head"]["rates_%s_rows_in_kmer_order" % which].update(valu_busy_frac_profiled_all_launches=prof[key]["valu_busy_frac"], valu_source=src)
         except Exception:
             pass
     if rank == 0:

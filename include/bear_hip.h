@@ -188,6 +188,12 @@ int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_
  * Holds about 45 bytes per context on a dense table.  Synchronises `stream` (set-up path).
  */
 int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int lag, int filter_width, int *n_levels, void *stream);
+/* Rows of the attached levels 1 .. n (rows_out [host, nullable when capacity = 0]); returns their number. */
+int bear_plan_cnn_level_rows(const bear_plan *plan, uint64_t *rows_out, int capacity);
+/* bear_cnn_forward_f64 over the plan's prefix levels when they were attached for this kmer_code pointer, lag and filter width
+ * (the plain forward otherwise); t1_save is required. */
+int bear_cnn_forward_plan_f64(bear_ws *ws, const bear_plan *plan, const uint64_t *kmer_code, uint64_t n_rows, int lag, int filter_width,
+                              int num_filters, int layer1_width, const double *params, double *prior, double *t1_save, void *stream);
 int bear_train_apply_f64(double *theta, int n_theta, const double *packed, double *adam_m, double *adam_v, double *adam_t,
                          double learning_rate, double scale, int train_ar, double *loss_buf, uint64_t loss_cap, void *stream);
 int bear_ref_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,

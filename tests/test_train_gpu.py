@@ -613,7 +613,7 @@ def test_cnn_step_on_a_dense_sorted_table_equals_its_three_kernels_over_all_rows
 
 
 @pytest.mark.parametrize("lag,fw,n,fixed,want_levels", [(13, 8, 300_000, 4, 5), (13, 8, 40_000, 6, 5), (7, 3, 50_000, 0, 4), (9, 9, 20_000, 0, 0),
-                                                       (13, 8, 5_000, 0, 0), (5, 3, 3_000, 0, 2), (21, 8, 60_000, 15, 0), (16, 12, 60_000, 9, None)])
+                                                       (13, 8, 5_000, 0, 0), (5, 3, 3_000, 0, 2), (21, 8, 60_000, 15, 0), (11, 6, 60_000, 4, None)])
 def test_cnn_step_over_prefix_levels_equals_the_plain_kernels(lag, fw, n, fixed, want_levels, monkeypatch):
     """bear_plan_attach_cnn_levels: with prefix levels the convolutional step evaluates a position once per distinct prefix of the
     sorted batch (forward: the levels' rows of layer-1 sums down to the contexts; backward: dT1 rows summed up the levels).  Its
