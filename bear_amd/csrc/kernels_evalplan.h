@@ -48,7 +48,15 @@
 #define EVP_DMA_WAVES 2
 #endif
 #define EVP_CWAVES (EVP_WAVES - EVP_DMA_WAVES)    // compute waves
-#define EVP_NSLOT 3                               // LDS ring: a tile being finished, the tile being worked on, a tile landing
+#ifndef EVP_MERGE_HV
+#define EVP_MERGE_HV 0   // 1: a row's vanilla part rides on its H unit (measured in round 4: 0.455 against 0.408 ms -- the <1,4> form then spills)
+#endif
+#ifndef EVP_TICKET_PREFETCH
+#define EVP_TICKET_PREFETCH 0   // 1: the next ticket is drawn while the current unit runs (measured in round 4, same box, three runs each:
+#endif                          // 0.432 against 0.404 ms -- a wave then holds a unit it is not working on while others wait at the tile's end)
+#ifndef EVP_NSLOT
+#define EVP_NSLOT 3
+#endif                                            // LDS ring: a tile being finished, the tile being worked on, a tile landing
 #ifndef EVP_ROWS
 #define EVP_ROWS 448                              // contexts per tile (multiple of 64; row0 * 20 B stays 16-byte aligned)
 #endif
@@ -383,10 +391,57 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
       // work list, dearest first: H units (AR + BEAR models of the rows with transitions), tie units (64 tied rows, all vanilla
       // models), V units (vanilla models of the rows), cell units
       const uint32_t n_hu = (NH > 0 || (do_common && A.arm)) ? n_tu : 0u, n_ktu = NV > 0 ? n_ku : 0u;
+#if EVP_MERGE_HV
+      const uint32_t n_vu = n_hu == 0u && (NV > 0 || do_common) ? n_tu : 0u;
+#else
       const uint32_t n_vu = (NV > 0 || (do_common && n_hu == 0u)) ? n_tu : 0u;
+#endif
       const uint32_t w_k = n_hu, w_v = w_k + n_ktu, w_c = w_v + n_vu, n_work = w_c + n_cu;
       const bool tot_in_h = n_hu != 0u;   // which unit kind carries the total length
+      // the vanilla models of a row with test transitions: arg-max (the largest training count, if it is alone at the top: tied
+      // rows are the tie units', the plan lists them by the same rule) and -D(N_r + 5 (v + eps), n) from the table
+      auto vanilla_row = [&](const uint32_t (&t)[5], const uint32_t (&r)[5], double n, bool live) {
+        uint32_t rmax = r[0], im = 0, ntop = 1;
+#pragma unroll
+        for (int q = 1; q < 5; ++q) {
+          ntop = r[q] > rmax ? 1u : ntop + (r[q] == rmax ? 1u : 0u);
+          im = r[q] > rmax ? (uint32_t)q : im;
+          rmax = r[q] > rmax ? r[q] : rmax;
+        }
+        if (live && ntop == 1u) {
+          const double hit = (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
+#pragma unroll
+          for (int k = 0; k < NV; ++k)
+            if (k < nv) accV_cor[k] += hit;
+        }
+        const double Nr = (((double)r[0] + (double)r[1]) + ((double)r[2] + (double)r[3])) + (double)r[4];
+        const bool in_tab = Nr + n < (double)EVP_TABK;
+        const uint32_t k0 = in_tab ? (uint32_t)Nr : 0u, k1 = in_tab ? (uint32_t)(Nr + n) : 0u;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+          if (k < nv) accV_ll[k] -= S.tabT[k][k1] - S.tabT[k][k0];
+        if (__builtin_amdgcn_ballot_w64(live && !in_tab)) {
+#pragma unroll 1
+          for (int k = 0; k < nv; ++k) {
+            if (live && !in_tab) {
+              const double d = srt_general_fast(Nr + 5.0 * (A.inv_h[A.n_h + v0 + k] + eps), n, S.logtab).D;
+#pragma unroll
+              for (int q = 0; q < NV; ++q)
+                if (q == k) accV_ll[q] -= d;
+            }
+          }
+        }
+      };
+      // the next ticket is drawn while the current unit runs (the LDS atomic's answer is back long before it is looked at)
+#if EVP_TICKET_PREFETCH
+      uint32_t w_next = pln_ticket_issue(&S.ticket[b], lane);
+      for (;;) {
+        const uint32_t w = srt_uniform(w_next);
+        if (w >= n_work) break;
+        w_next = pln_ticket_issue(&S.ticket[b], lane);
+#else
       for (uint32_t w = pln_ticket(&S.ticket[b], lane); w < n_work; w = pln_ticket(&S.ticket[b], lane)) {
+#endif
         if (w < w_k) {
           // ---- H unit: 64 rows with test transitions, largest totals first: the AR model's and the BEAR models' arg-max,
           //      the BEAR models' -D(A, n)
@@ -472,6 +527,9 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
               }
             }
           }
+#if EVP_MERGE_HV
+          if (NV > 0) vanilla_row(t, r, n, live);
+#endif
           EVP_STAMP(1)
           continue;
         }
@@ -522,38 +580,7 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
           const double n = (((double)t[0] + (double)t[1]) + ((double)t[2] + (double)t[3])) + (double)t[4];
           const bool live = n != 0.0;
           if (do_common && !tot_in_h) acc_tot += n;
-          if (NV > 0) {
-            uint32_t rmax = r[0], im = 0, ntop = 1;
-#pragma unroll
-            for (int q = 1; q < 5; ++q) {
-              ntop = r[q] > rmax ? 1u : ntop + (r[q] == rmax ? 1u : 0u);
-              im = r[q] > rmax ? (uint32_t)q : im;
-              rmax = r[q] > rmax ? r[q] : rmax;
-            }
-            if (live && ntop == 1u) {   // tied rows are the tie units' (the plan lists them by the same rule)
-              const double hit = (double)(im == 0 ? t[0] : im == 1 ? t[1] : im == 2 ? t[2] : im == 3 ? t[3] : t[4]);
-#pragma unroll
-              for (int k = 0; k < NV; ++k)
-                if (k < nv) accV_cor[k] += hit;
-            }
-            const double Nr = (((double)r[0] + (double)r[1]) + ((double)r[2] + (double)r[3])) + (double)r[4];
-            const bool in_tab = Nr + n < (double)EVP_TABK;
-            const uint32_t k0 = in_tab ? (uint32_t)Nr : 0u, k1 = in_tab ? (uint32_t)(Nr + n) : 0u;
-#pragma unroll
-            for (int k = 0; k < NV; ++k)
-              if (k < nv) accV_ll[k] -= S.tabT[k][k1] - S.tabT[k][k0];
-            if (__builtin_amdgcn_ballot_w64(live && !in_tab)) {
-#pragma unroll 1
-              for (int k = 0; k < nv; ++k) {
-                if (live && !in_tab) {
-                  const double d = srt_general_fast(Nr + 5.0 * (A.inv_h[A.n_h + v0 + k] + eps), n, S.logtab).D;
-#pragma unroll
-                  for (int q = 0; q < NV; ++q)
-                    if (q == k) accV_ll[q] -= d;
-                }
-              }
-            }
-          }
+          if (NV > 0) vanilla_row(t, r, n, live);
           EVP_STAMP(3)
           continue;
         }

@@ -533,6 +533,13 @@ __device__ __forceinline__ uint32_t pln_ticket(uint32_t *counter, uint32_t lane)
   return srt_uniform(t);
 }
 
+// The same draw without waiting for its answer: lane 0's return value, to be made uniform (srt_uniform) when it is looked at.
+__device__ __forceinline__ uint32_t pln_ticket_issue(uint32_t *counter, uint32_t lane) {
+  uint32_t t = 0;
+  if (lane == 0) t = atomicAdd(counter, 1u);
+  return t;
+}
+
 // Counts of the 64 items of unit `un` from the tile's thresholds: an item's count is the number of
 // thresholds E[c] that do not exceed its index.  Returns the lane's count (0 beyond n_light) and the
 // wave-uniform range of the unit.
