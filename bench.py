@@ -578,8 +578,10 @@ def main():
                 if "valu_busy_frac" in prof.get(key, {}) and "roofline" in extra.get(entry, {}):
                     extra[entry]["roofline"].update(valu_busy_frac_profiled=prof[key]["valu_busy_frac"], valu_source=src)
             for which, key in (("forward", "cnn_forward"), ("backward", "cnn_backward")):
-                if "valu_busy_frac" in prof.get(key, {}):
-                    extra["cnn_head"]["rates_%s_rows_in_kmer_order" % which].update(valu_busy_frac_profiled_all_launches=prof[key]["valu_busy_frac"], valu_source=src)
+                # per row order (scripts/dev/cnn_order_pmc.py, one order per profiled process, 2e7 contexts)
+                for order, entry in (("sorted", "rates_%s_rows_in_kmer_order" % which), ("random", "roofline_%s_rows_in_random_order" % which)):
+                    if "valu_busy_frac" in prof.get(key + "_" + order, {}):
+                        extra["cnn_head"][entry].update(valu_busy_frac_profiled=prof[key + "_" + order]["valu_busy_frac"], valu_source=src)
         except Exception:
             pass
     if rank == 0:

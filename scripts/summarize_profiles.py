@@ -85,11 +85,27 @@ for kind in ("fetch", "write", "sq"):
                 d["valu_busy_frac"] = mean["SQ_ACTIVE_INST_VALU"] / (8.0 * mean["SQ_BUSY_CYCLES"])
                 d["valu_wave_instructions_per_launch"] = mean.get("SQ_INSTS_VALU")
     out_md.append("")
+# the convolutional kernels by row order (scripts/dev/cnn_order_pmc.py: one order per process, 2e7 contexts)
+for order in ("random", "sorted", "levels"):
+    agg = pmc(f"sqcnn_{order}")
+    if not agg: continue
+    out_md += [f"## PMC pass: convolutional kernels, rows in {order} order (2e7 contexts, scripts/dev/cnn_order_pmc.py)", "",
+               "| kernel | launches | VALU busy | VALU wave-instructions per launch |", "|---|---|---|---|"]
+    for k, v in agg.items():
+        if "cnn_" not in k or "finalize" in k: continue
+        mean = {c: sum(x) / len(x) for c, x in v.items()}
+        if not mean.get("SQ_BUSY_CYCLES"): continue
+        busy = mean["SQ_ACTIVE_INST_VALU"] / (8.0 * mean["SQ_BUSY_CYCLES"])
+        which = "cnn_forward" if "cnn_forward" in k else ("cnn_level_sum" if "level_sum" in k else "cnn_backward")
+        out_md.append(f"| `{k[:40]}` | {len(v['SQ_BUSY_CYCLES'])} | {busy:.3f} | {mean.get('SQ_INSTS_VALU', 0):.0f} |")
+        traffic.setdefault(f"{which}_{order}", {}).update(valu_busy_frac=busy, valu_wave_instructions_per_launch=mean.get("SQ_INSTS_VALU"),
+                                                        contexts_per_launch=20000000, launches_averaged=len(v["SQ_BUSY_CYCLES"]))
+    out_md.append("")
 for name, d in list(traffic.items()):
     if "fetch_bytes_per_launch" in d or "write_bytes_per_launch" in d:
         d["bytes_per_launch"] = d.get("fetch_bytes_per_launch", 0) + d.get("write_bytes_per_launch", 0)
     # bench.py defaults (--contexts 1e8; the evaluation extra runs on the first 2e7); bench.py scales linearly for other sizes
-    d["contexts_per_launch"] = 20000000 if name.startswith("heldout_eval") else 100000000
+    d.setdefault("contexts_per_launch", 20000000 if name.startswith("heldout_eval") else 100000000)
 if traffic:
     traffic["tag"] = tag
     json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
