@@ -212,6 +212,7 @@ def main():
     plans = {"net": kernels.Plan(t["train"], 5), "ref": kernels.Plan(t["train"], 4, ref=t["ref"])}
     torch.cuda.synchronize()
     plan_build_s = time.time() - t0
+    plan_nbytes = {k: v.nbytes for k, v in plans.items()}     # (before the linear head's paired lists are attached to the net plan below)
 
     outs = {"net": torch.zeros(2, dtype=torch.float64, device=dev), "ref": torch.zeros(4, dtype=torch.float64, device=dev)}
 
@@ -352,7 +353,7 @@ def main():
         ms = timed(lambda: kernels.dm_prior_planned(plans["net"], prior, h_s, want_grad=True), 5)
         extra["net_with_gradient_rows"] = {"kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3)}
         ms_n = timed(lambda: kernels.dm_prior_planned(plans["net"], prior, h_s, want_grad=True, normalized=True), 5)
-        moved = 40 + plans["net"].nbytes / n + 40      # prior rows in, plan in, gradient rows out
+        moved = 40 + plan_nbytes["net"] / n + 40      # prior rows in, plan in, gradient rows out
         extra["net_with_gradient_rows"].update({
             "kernel_ms_rows_asserted_normalized": ms_n, "contexts_per_s_rows_asserted_normalized": n / (ms_n * 1e-3),
             "moved_bytes_per_context": moved, "moved_GBps_rows_asserted_normalized": n * moved / (ms_n * 1e-3) / 1e9,
@@ -429,7 +430,7 @@ def main():
             "linear_backward_ms_rows_in_random_order": lb_ms_random,
             "ref_mix_forward_ms": mf_ms, "ref_mix_forward_GBps": n * 120 / (mf_ms * 1e-3) / 1e9,
             "ref_mix_backward_ms": mb_ms, "ref_mix_backward_GBps": n * 160 / (mb_ms * 1e-3) / 1e9,
-            "ref_mix_dm_step_fused_ms": fused_ms, "ref_mix_dm_step_fused_GBps": n * (120 + plans["net"].nbytes / n) / (fused_ms * 1e-3) / 1e9,
+            "ref_mix_dm_step_fused_ms": fused_ms, "ref_mix_dm_step_fused_GBps": n * (120 + plan_nbytes["net"] / n) / (fused_ms * 1e-3) / 1e9,
             "note": "bear_linear_forward / backward_f64 (8 + 40 B; 8 + 40 + 40 B per context, rows in k-mer order) and "
                     "bear_ref_mix_forward / backward_f64 (40 + 40 + 40 B; 3 x 40 + 40 B): what evaluation and bear_ref.train with a "
                     "parametrised net function call; HBM-bound, GB/s on those bytes.  ref_mix_dm_step_fused: bear_dm_refmix_plan_grad_f64 = "
@@ -599,9 +600,9 @@ def main():
                     traffic_source = "profiles/traffic_latest.json (%s): rocprofv3 --pmc passes of this command, not this run" % tj.get("tag", "?")
             except Exception:
                 traffic = None
-        moved = traffic if traffic is not None else n * (40 if primary == "net" else 0) + plans[primary].nbytes
+        moved = traffic if traffic is not None else n * (40 if primary == "net" else 0) + plan_nbytes[primary]
         # the other workload: PMC bytes of the committed profile when there are any, else an upper estimate (rows + whole plan)
-        other_moved, other_moved_source = n * (40 if other == "net" else 0) + plans[other].nbytes, "estimate: row bytes + plan bytes"
+        other_moved, other_moved_source = n * (40 if other == "net" else 0) + plan_nbytes[other], "estimate: row bytes + plan bytes"
         try:
             ent = json.load(open(tpath)).get(other, {})
             if ent.get("bytes_per_launch") is not None:
@@ -666,7 +667,7 @@ def main():
                       "devices": [e["device"] for e in per_rank] if per_rank else [dev_index]},
             "per_rank": per_rank,
             "plan_build_s": plan_build_s,
-            "plan_bytes_per_context": plans[primary].nbytes / n,
+            "plan_bytes_per_context": plan_nbytes[primary] / n,
             "result": result.tolist(),
             "also": {
                 other: {
