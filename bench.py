@@ -127,6 +127,9 @@ def parse_args():
                          "way to exercise the RCCL path of this file on a one-GPU box (tests/test_dist_gpu.py)")
     ap.add_argument("--workload", choices=["net", "ref"], default="net")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-unnormalised-rows", action="store_true",
+                    help="skip also.net_rows_not_normalised: it launches the HEADLINE's kernel instantiation on other data (2.5x slower per "
+                         "launch), which a per-kernel-name profile of this command cannot tell apart (scripts/profile_round.sh passes it)")
     ap.add_argument("--ingest-rows", type=float, default=None,
                     help="rows of the text table of the also.ingest entry (text -> first step wall time); default: min(--contexts, 1e8); 0 = skip")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N > 1 path)")
@@ -367,10 +370,12 @@ def main():
         scale_rows = 1.0 + 1e-3 * ((torch.arange(n, device=dev, dtype=torch.int64) * 2654435761 % 1000003).to(torch.float64) / 1000003.0)
         prior_un = (prior * scale_rows[:, None]).contiguous()
         del scale_rows
-        ms_un = timed(lambda: kernels.dm_prior_planned(plans["net"], prior_un, h_s), 5)
-        ms_un_g = timed(lambda: kernels.dm_prior_planned(plans["net"], prior_un, h_s, want_grad=True), 5)
+        ms_un = ms_un_g = float("nan")
+        if not args.no_unnormalised_rows:
+            ms_un = timed(lambda: kernels.dm_prior_planned(plans["net"], prior_un, h_s), 5)
+            ms_un_g = timed(lambda: kernels.dm_prior_planned(plans["net"], prior_un, h_s, want_grad=True), 5)
         del prior_un
-        extra["net_rows_not_normalised"] = {
+        extra["net_rows_not_normalised"] = None if args.no_unnormalised_rows else {
             "kernel_ms": ms_un, "contexts_per_s": n / (ms_un * 1e-3), "credited_GBps_at_60_B": n * 60 / (ms_un * 1e-3) / 1e9,
             "frac_credited": n * 60 / (ms_un * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms_with_gradient_rows": ms_un_g,
             "note": "dm_prior_plan_kernel<false,false> on rows whose sums differ from 1 by up to 1e-3: the per-context own-A path; "

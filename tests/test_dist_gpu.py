@@ -291,6 +291,20 @@ def test_bench_single_rank_line_is_consistent():
     c = also["cnn_head"]
     assert abs(c["step_contexts_per_s"] - n / (c["train_step_ms_as_bear_net_train_holds_the_batch"] * 1e-3)) <= 1e-6 * c["step_contexts_per_s"]
     assert 0.5 < c["contexts_with_training_counts"] < 0.9
+    # round 4: the gradient-row kernel next to the headline, the convolutional step over prefix levels (same sums as without them;
+    # executed flops <= credited flops), the linear head on paired lists (same sums), the own-A path of rows that are not normalised
+    g = d["roofline_gradient_rows"]
+    assert g["kernel"] == "dm_prior_plan_grad_inplace_kernel" and g["credited_read_B"] == 60 and 0.0 < g["frac_credited"] < g["frac_moved"] < 1.2
+    lv = c["prefix_levels"]
+    assert lv["equals_step_without_levels"] is True and lv["rows"][0] == round(c["contexts_with_training_counts"] * n)
+    if lv["attached"]:
+        assert lv["rows"] == sorted(lv["rows"], reverse=True) and 1.0 <= lv["position_evaluations_per_context"] < 6.0
+        assert lv["rates_forward"]["executed_fp64_flops"] < lv["rates_forward"]["credited_fp64_flops"]
+    assert "frac_of_fp64_peak" not in c["rates_forward_rows_in_kmer_order"]           # (no executed-flop count there: no utilisation claimed)
+    lin = also["linear_head_fused_step"]
+    assert lin["paired_equals_plain"] is True and isinstance(lin["paired_contexts"], bool)
+    assert also["net_rows_not_normalised"]["kernel_ms"] >= r["kernel_ms"] * 0.9
+    assert d["ranks"] == {"world_size": 1, "backend": None, "launcher": "none (one process)", "devices": [0]}
 
 
 def test_bench_rccl_path_on_a_group_of_one():
