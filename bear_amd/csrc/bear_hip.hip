@@ -1657,6 +1657,17 @@ int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, in
 
 static int cnn_forward_levels(bear_ws *ws, const bear_plan *plan, const cnn_dims &D, const uint64_t *kmer_code, uint64_t n_rows,
                               const double *params, double *prior, double *t1_buf, hipStream_t s);
+// Level k's rows are prefixes of L_k letters (L_0 = lag: the contexts): it evaluates the positions whose window [p, p + fw) lies
+// inside its prefix but not inside the next level's shorter one -- p + fw in (L_{k+1}, L_k]; the last level takes what is left.
+static cnn_level_io cnn_level_positions(const bear_plan *plan, const cnn_dims &D, int k) {
+  const int K = plan->n_cnn_levels;
+  const int L = k == 0 ? D.lag : plan->cnn_levels[k - 1].letters;
+  cnn_level_io io = cnn_all_positions(D);
+  io.p_hi = L - D.fw + 1;
+  io.p_lo = k == K ? 0 : plan->cnn_levels[k].letters - D.fw + 1;
+  io.head = k == 0;
+  return io;
+}
 static bool cnn_parts_form_forced_off() {      // BEAR_CNN_BACKWARD=1 (cnn_backward_grid): the 64-context form of the backward kernel, which has no position range
   const char *force = getenv("BEAR_CNN_BACKWARD");
   return force && force[0] == '1';
@@ -1679,13 +1690,7 @@ static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn
   auto level_codes = [&](int k) { return k == 0 ? reinterpret_cast<const unsigned long long *>(kmer_code) : plan->cnn_levels[k - 1].codes; };
   auto level_rows = [&](int k) { return k == 0 ? n_rows : plan->cnn_levels[k - 1].n; };
   auto level_table = [&](int k) { return k == 0 ? t1_buf : plan->cnn_levels[k - 1].rows; };
-  auto level_io = [&](int k) {
-    cnn_level_io io = cnn_all_positions(D);
-    io.p_lo = k == K ? 0 : D.P - 1 - k;
-    io.p_hi = D.P - k;
-    io.head = k == 0;
-    return io;
-  };
+  auto level_io = [&](int k) { return cnn_level_positions(plan, D, k); };
   st = cnn_forward_levels(ws, plan, D, kmer_code, n_rows, params, prior_buf, t1_buf, s);
   if (st != BEAR_OK) return st;
   bear_params only_eps;
@@ -1737,18 +1742,23 @@ int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int 
   if (plan->n_rows < 2 || plan->n_live_rows != plan->n_rows) return BEAR_OK;   // (the step walks the plan's lists instead: no levels)
   const unsigned long long *below = reinterpret_cast<const unsigned long long *>(kmer_code);
   uint64_t n_below = plan->n_rows;
-  for (int k = 1; k <= D.P - 1; ++k) {
+  int misses = 0;
+  for (int k = 1; k <= D.P - 1 && misses < 3; ++k) {
     bear_level_dev lv;
     const int st = bear_level_build(below, n_below, lag - k, &lv, s);
     if (st != BEAR_OK) {
       if (st == BEAR_ERR_HIP) g_last_hip_error = bear_count_last_hip_error();
       return st;
     }
-    // a level pays when it is clearly smaller than the one below (a position per row either way, plus the row traffic)
+    // a level pays when it is clearly smaller than the last one kept (a position per row either way, plus the row traffic); a
+    // prefix length that does not (a sparser table: its prefixes of lag - 1 letters hardly repeat) is skipped -- the level below
+    // then evaluates that position too -- and the next shorter one is tried against the same rows
     if (10 * lv.n > 6 * n_below) {
       bear_level_free(&lv);
-      break;
+      ++misses;
+      continue;
     }
+    misses = 0;
     plan->cnn_levels[plan->n_cnn_levels++] = lv;
     plan->bytes += lv.n * (8 + 4 + 16 * 8) + 4 * n_below;
     below = lv.codes;
@@ -1763,9 +1773,12 @@ int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int 
   return BEAR_OK;
 }
 
-int bear_plan_cnn_level_rows(const bear_plan *plan, uint64_t *rows_out, int capacity) {
+int bear_plan_cnn_level_rows(const bear_plan *plan, uint64_t *rows_out, int *letters_out, int capacity) {
   if (!plan || (capacity > 0 && !rows_out)) return BEAR_ERR_INVALID_ARG;
-  for (int k = 0; k < plan->n_cnn_levels && k < capacity; ++k) rows_out[k] = plan->cnn_levels[k].n;
+  for (int k = 0; k < plan->n_cnn_levels && k < capacity; ++k) {
+    rows_out[k] = plan->cnn_levels[k].n;
+    if (letters_out) letters_out[k] = plan->cnn_levels[k].letters;
+  }
   return plan->n_cnn_levels;
 }
 
@@ -1775,10 +1788,7 @@ static int cnn_forward_levels(bear_ws *ws, const bear_plan *plan, const cnn_dims
   const int K = plan->n_cnn_levels;
   const size_t fwd_lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)D.fw * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);
   for (int k = K; k >= 0; --k) {
-    cnn_level_io io = cnn_all_positions(D);
-    io.p_lo = k == K ? 0 : D.P - 1 - k;
-    io.p_hi = D.P - k;
-    io.head = k == 0;
+    cnn_level_io io = cnn_level_positions(plan, D, k);
     if (k < K) {
       io.t1_parent = plan->cnn_levels[k].rows;                 // level k + 1
       io.parent = plan->cnn_levels[k].parent_of_below;

@@ -170,14 +170,15 @@ class Plan:
         self.cnn_codes = kmer_code if n.value else None
         return int(n.value)
 
-    def cnn_level_rows(self):
-        """Rows of the attached prefix levels 1 .. n (``bear_plan_cnn_level_rows``); [] without levels."""
-        n = int(_lib.lib().bear_plan_cnn_level_rows(self._h, None, 0))
+    def cnn_level_rows(self, with_letters=False):
+        """Rows of the attached prefix levels 1 .. n (``bear_plan_cnn_level_rows``); [] without levels.  ``with_letters``: (rows,
+        prefix lengths)."""
+        n = int(_lib.lib().bear_plan_cnn_level_rows(self._h, None, None, 0))
         if n <= 0:
-            return []
-        rows = (ctypes.c_uint64 * n)()
-        _lib.lib().bear_plan_cnn_level_rows(self._h, rows, n)
-        return [int(r) for r in rows]
+            return ([], []) if with_letters else []
+        rows, letters = (ctypes.c_uint64 * n)(), (ctypes.c_int * n)()
+        _lib.lib().bear_plan_cnn_level_rows(self._h, rows, letters, n)
+        return ([int(r) for r in rows], [int(x) for x in letters]) if with_letters else [int(r) for r in rows]
 
     def tiles(self):
         """Diagnostics (``bear_plan_tile_info``): (row0 [T] uint64, rows [T] uint32, items [T] uint32, stream_offset [T] uint64)."""

@@ -478,7 +478,7 @@ def main():
         # ... with prefix levels (bear_plan_attach_cnn_levels, as bear_net.train attaches them to every sorted batch): a position is
         # evaluated once per distinct prefix of the batch, forward and backward
         n_levels = plan_kept.attach_cnn_levels(packed_kept, lag, fw)
-        level_rows = plan_kept.cnn_level_rows()
+        level_rows, level_letters = plan_kept.cnn_level_rows(with_letters=True)
         kept_ms = timed(lambda: kernels.net_cnn_train_reduce(plan_kept, packed_kept, lag, fw, theta, bufs_kept, pk), 3)
         levels_same = bool(abs(float(pk[0] - pk_plain[0])) <= 1e-12 * abs(float(pk_plain[0]))
                            and float((pk[2:] - pk_plain[2:]).abs().max()) <= 1e-10 * float(pk_plain[2:].abs().max()))
@@ -496,8 +496,8 @@ def main():
         n_kept = int(kept_frac * n + 0.5)
         pos_f = (cnn_f - flops_cnn(fw, fw)[0]) / (lag - fw)            # one position's share of a context's forward flops
         head_f = cnn_f - (lag - fw + 1) * pos_f
-        lv = [n_kept] + level_rows
-        pos_evals = sum(r * ((lag - fw + 1 - k) if k == len(lv) - 1 else 1) for k, r in enumerate(lv))
+        lv, ll = [n_kept] + level_rows, [lag] + level_letters + [fw - 1]      # level k evaluates the positions p with p + fw in (ll[k + 1], ll[k]]
+        pos_evals = sum(r * (ll[k] - ll[k + 1]) for k, r in enumerate(lv))
         exec_f = pos_evals * pos_f + n_kept * head_f
         extra["cnn_head"] = {"lag": lag, "filter_width": fw, "forward_ms": f_ms, "backward_ms": b_ms,
                              "rates_forward_rows_in_kmer_order": cnn_rates(cnn_f * n, None, fs_ms),
@@ -509,7 +509,7 @@ def main():
                              "train_step_ms": s_ms, "train_step_ms_rows_in_random_order": s_ms_random,
                              "train_step_ms_as_bear_net_train_holds_the_batch": kept_ms, "contexts_with_training_counts": kept_frac,
                              "train_step_ms_without_prefix_levels": kept_plain_ms,
-                             "prefix_levels": {"attached": n_levels, "rows": lv, "position_evaluations_per_context": pos_evals / max(n_kept, 1),
+                             "prefix_levels": {"attached": n_levels, "rows": lv, "prefix_letters": ll[:-1], "position_evaluations_per_context": pos_evals / max(n_kept, 1),
                                                "equals_step_without_levels": levels_same,
                                                "forward_ms": kept_fwd_ms,
                                                "forward_ms_scaled_to_all_contexts": kept_fwd_ms / max(kept_frac, 1e-9),

@@ -182,14 +182,15 @@ int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_
  * first p + filter_width letters, and those are neighbours; with levels attached, bear_net_cnn_train_reduce_f64 / _step_f64
  * called with this plan, this kmer_code pointer, lag and filter_width evaluate a position once per DISTINCT prefix, forward and
  * backward (one launch per level; the sums are the same up to rounding) -- about 1.3 instead of 6 positions per context on a
- * dense sorted table of 13-mers.  The levels are tied to the buffer kmer_code (bear_pack_kmers_u64 form; identity and contents,
+ * dense sorted table of 13-mers; sparser tables keep the prefix lengths that pay (e.g. from lag - 2 letters down).  The levels are tied to the buffer kmer_code (bear_pack_kmers_u64 form; identity and contents,
  * like the plan's count slab).  *n_levels (nullable) = 0: nothing was attached (rows in another order, a table too sparse for its
  * prefixes to repeat, a plan whose lists skip rows, a shape outside the fused kernels): the step runs as before.
  * Holds about 45 bytes per context on a dense table.  Synchronises `stream` (set-up path).
  */
 int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int lag, int filter_width, int *n_levels, void *stream);
-/* Rows of the attached levels 1 .. n (rows_out [host, nullable when capacity = 0]); returns their number. */
-int bear_plan_cnn_level_rows(const bear_plan *plan, uint64_t *rows_out, int capacity);
+/* Rows and prefix lengths (letters) of the attached levels 1 .. n (rows_out [host, nullable when capacity = 0], letters_out [host,
+ * nullable]); returns their number.  A prefix length whose prefixes hardly repeat is skipped: the level below evaluates its position too. */
+int bear_plan_cnn_level_rows(const bear_plan *plan, uint64_t *rows_out, int *letters_out, int capacity);
 /* bear_cnn_forward_f64 over the plan's prefix levels when they were attached for this kmer_code pointer, lag and filter width
  * (the plain forward otherwise); t1_save is required. */
 int bear_cnn_forward_plan_f64(bear_ws *ws, const bear_plan *plan, const uint64_t *kmer_code, uint64_t n_rows, int lag, int filter_width,

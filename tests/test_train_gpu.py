@@ -613,14 +613,15 @@ def test_cnn_step_on_a_dense_sorted_table_equals_its_three_kernels_over_all_rows
 
 
 @pytest.mark.parametrize("lag,fw,n,fixed,want_levels", [(13, 8, 300_000, 4, 5), (13, 8, 40_000, 6, 5), (7, 3, 50_000, 0, 4), (9, 9, 20_000, 0, 0),
-                                                       (13, 8, 5_000, 0, 0), (5, 3, 3_000, 0, 2), (21, 8, 60_000, 15, 0), (11, 6, 60_000, 4, None)])
+                                                       (13, 8, 5_000, 0, 0), (5, 3, 3_000, 0, 2), (13, 8, 200_000, 3, None), (21, 8, 60_000, 15, 0), (11, 6, 60_000, 4, None)])
 def test_cnn_step_over_prefix_levels_equals_the_plain_kernels(lag, fw, n, fixed, want_levels, monkeypatch):
     """bear_plan_attach_cnn_levels: with prefix levels the convolutional step evaluates a position once per distinct prefix of the
     sorted batch (forward: the levels' rows of layer-1 sums down to the contexts; backward: dT1 rows summed up the levels).  Its
     packed [sum LL, d/dh, d/d params] must equal the three plain kernels over all rows in RANDOM order, and the step without levels
     (BEAR_AMD_CNN_NO_LEVELS=1) -- on tables as dense in k-mer space as the benchmark, with duplicates, start symbols and unknown
-    letters, on shapes with one position (no level possible), on a table too sparse for any prefix to repeat (none attached) and
-    on a shape whose backward pass does not fit the part form of the kernel (lag 21: none attached either)."""
+    letters, on shapes with one position (no level possible), on a table too sparse for any prefix to repeat (none attached), on a
+    table whose prefixes of lag - 1 letters hardly repeat while shorter ones do (that length is skipped: the contexts evaluate two
+    positions) and on a shape whose backward pass does not fit the part form of the kernel (lag 21: none attached either)."""
     from bear_amd import kernels
     dev = torch.device("cuda", 0)
     gen = torch.Generator(dev).manual_seed(lag * 100 + fw)
@@ -650,6 +651,10 @@ def test_cnn_step_over_prefix_levels_equals_the_plain_kernels(lag, fw, n, fixed,
         assert got_levels == want_levels
     else:
         assert 1 <= got_levels <= lag - fw
+    rows, letters = plan.cnn_level_rows(with_letters=True)
+    assert len(rows) == got_levels and rows == sorted(rows, reverse=True) and letters == sorted(letters, reverse=True)
+    if (lag, fw, n, fixed) == (13, 8, 200_000, 3):
+        assert letters[0] < lag - 1                      # 12-letter prefixes (4^9 of them for 2e5 contexts) do not pay: skipped
     pk = torch.zeros(2 + flat.numel(), dtype=torch.float64, device=dev)
     for ar in (False, True):
         kernels.net_cnn_train_reduce(plan, packed_codes, lag, fw, theta, bufs, pk, train_ar=ar)
