@@ -21,11 +21,11 @@ for label, hs, van in (("1h+AR+3van", [1.0], [0.1, 1.0, 10.0]),):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); kernels.evaluate_planned(plan, f, hs, van, row_ids=ids); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
-    nb, nw = 256, 12
+    nb, nw = 256, 16          # EVP_THREADS 1024: 14 compute waves + 2 DMA waves
     buf = np.zeros(nb * nw * 8, dtype=np.uint64)
     assert L.bear_debug_read_timing(plan.ws.handle, buf.ctypes.data, buf.size) == 0
     a = buf.reshape(nb, nw, 8).astype(np.float64)
-    for role, sl in (("compute waves", slice(0, 10)), ("DMA waves", slice(10, 12))):
+    for role, sl in (("compute waves", slice(0, 14)), ("DMA waves", slice(14, 16))):
         tot = a[:, sl].sum(-1).mean()
         print(f"{label} [{role}]: kernel {ms:.3f} ms (stamped build); ticks per wave {tot:.0f}")
         for k, nme in enumerate(names):
