@@ -1743,6 +1743,8 @@ int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int 
   const unsigned long long *below = reinterpret_cast<const unsigned long long *>(kmer_code);
   uint64_t n_below = plan->n_rows;
   int misses = 0;
+  double keep_ratio = 0.6;
+  if (const char *r = getenv("BEAR_AMD_CNN_LEVEL_RATIO")) keep_ratio = atof(r);     // developer switch (scripts/dev/cnn_levels_time.py)
   for (int k = 1; k <= D.P - 1 && misses < 3; ++k) {
     bear_level_dev lv;
     const int st = bear_level_build(below, n_below, lag - k, &lv, s);
@@ -1753,7 +1755,7 @@ int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int 
     // a level pays when it is clearly smaller than the last one kept (a position per row either way, plus the row traffic); a
     // prefix length that does not (a sparser table: its prefixes of lag - 1 letters hardly repeat) is skipped -- the level below
     // then evaluates that position too -- and the next shorter one is tried against the same rows
-    if (10 * lv.n > 6 * n_below) {
+    if ((double)lv.n > keep_ratio * (double)n_below) {
       bear_level_free(&lv);
       ++misses;
       continue;
