@@ -432,8 +432,7 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
           }
         }
       };
-      // the next ticket is drawn while the current unit runs (the LDS atomic's answer is back long before it is looked at)
-#if EVP_TICKET_PREFETCH
+#if EVP_TICKET_PREFETCH   // the next ticket is drawn while the current unit runs (measured slower: see the switch above)
       uint32_t w_next = pln_ticket_issue(&S.ticket[b], lane);
       for (;;) {
         const uint32_t w = srt_uniform(w_next);
