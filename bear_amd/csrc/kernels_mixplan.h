@@ -80,8 +80,9 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
     S.grad[PLN_SENTINEL] = 0.0;
     S.ticket = 0;
   }
+  pln_tile nxt = pln_load_tile(pv, blockIdx.x);      // descriptors one tile ahead (see dm_prior_plan_grad_kernel)
   for (uint64_t t = blockIdx.x; t < pv.n_tiles; t += gridDim.x) {
-    const pln_tile cur = pln_load_tile(pv, t);
+    const pln_tile cur = nxt;
     const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
     const uint32_t hc = cur.hc_hr >> 16, hr = cur.hc_hr & 0xffffu;
     const pln_layout L = pln_block_layout(rows, n_light, hc, hr);
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
       pln_dma(S.blk, pv.stream + (size_t)cur.off16 * 16, cur.blk16 * 16u, wave, lane, 2u * pieces);
     }
     if (tid == 0) S.ticket = 0;
+    nxt = pln_load_tile(pv, t + gridDim.x);
     srt_wait_dma();
     srt_sync();
     const uint16_t *E = reinterpret_cast<const uint16_t *>(S.blk);

@@ -1174,8 +1174,11 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
     S.pri[PLN_SENTINEL] = 1.0;
     S.ticket = 0;
   }
+  // (the descriptor of a tile is fetched one tile ahead, right behind the issue of the current tile's DMA: a scalar load shares
+  // lgkmcnt with the LDS, so fetched at the top of its own tile it cost every wave a memory latency per tile -- round 4)
+  pln_tile nxt = pln_load_tile(pv, blockIdx.x);
   for (uint64_t t = blockIdx.x; t < pv.n_tiles; t += gridDim.x) {
-    const pln_tile cur = pln_load_tile(pv, t);
+    const pln_tile cur = nxt;
     const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
     const uint32_t hc = cur.hc_hr >> 16, hr = cur.hc_hr & 0xffffu;
     const pln_layout L = pln_block_layout(rows, n_light, hc, hr);
@@ -1192,6 +1195,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
       pln_dma(S.blk, pv.stream + (size_t)cur.off16 * 16, cur.blk16 * 16u, wave, lane, (pbytes + 1023u) >> 10);
     }
     if (tid == 0) S.ticket = 0;
+    nxt = pln_load_tile(pv, t + gridDim.x);      // returns while this tile's DMA is waited for
     srt_wait_dma();
     srt_sync();
     const uint16_t *E = reinterpret_cast<const uint16_t *>(S.blk);
@@ -1247,7 +1251,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
     // context; here 51 against 44 without any prefetch); before the store phase it is too late (1.90 ms).  Not in the multinomial
     // mode, whose tiles have next to no compute to hide anything under (1.51 -> 1.62).
     if (!AR && wave < 10u) {
-      const pln_tile nx = pln_load_tile(pv, t + gridDim.x);
+      const pln_tile &nx = nxt;
       const uint32_t nrows = nx.rows_items >> 16;
       if (wave < 9u) pln_touch_lines(S.pf_scratch, prior + nx.row0 * 5, nrows * 40u, wave, lane);
       else pln_touch_lines(S.pf_scratch, pv.stream + (size_t)nx.off16 * 16, nx.blk16 * 16u, 0u, lane);
