@@ -1086,6 +1086,13 @@ int bear_plan_pair_contexts(bear_plan *plan, const uint64_t *kmer_index, int lag
   return BEAR_OK;
 }
 
+int bear_plan_pair_info(const bear_plan *plan, uint64_t *paired_tiles, uint64_t *plain_tiles) {
+  if (!plan) return BEAR_ERR_INVALID_ARG;
+  if (paired_tiles) *paired_tiles = plan->live2 ? plan->n_tiles_p : 0;
+  if (plain_tiles) *plain_tiles = plan->live2 ? plan->n_tiles_u : plan->n_tiles;
+  return plan->live2 ? 1 : 0;
+}
+
 int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code,
                        const double *mat, int lag, uint64_t n_rows, double h_signed, double eps, int train_ar,
                        double *out, double *grad_mat, void *stream) {

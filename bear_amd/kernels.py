@@ -156,6 +156,12 @@ class Plan:
         self.paired_codes = kmer_index if ok.value else None
         return bool(ok.value)
 
+    def pair_info(self):
+        """(tiles that take the paired form of the linear step, tiles that keep their plain list) -- ``bear_plan_pair_info``."""
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _lib.lib().bear_plan_pair_info(self._h, ctypes.byref(a), ctypes.byref(b))
+        return int(a.value), int(b.value)
+
     def attach_cnn_levels(self, kmer_code, lag, filter_width):
         """``bear_plan_attach_cnn_levels``: prefix levels of the (k-mer-sorted) packed contexts ``kmer_code`` (``pack_kmers``) of this
         plan's rows for the convolutional training step -- a position is then evaluated once per distinct prefix.  Returns the

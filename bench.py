@@ -406,6 +406,7 @@ def main():
         del packed, plain_out, paired_out
         extra["linear_head_fused_step"] = {"lag": lag, "kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3),
                                            "paired_contexts": lin_paired, "paired_equals_plain": lin_same,
+                                           "paired_tiles_and_plain_tiles": list(plans["net"].pair_info()),
                                            "kernel_ms_plain_lists": ms_plain,
                                            "kernel_ms_rows_in_random_order": ms_shuffled,
                                            "roofline": fp64_roofline(flops_linear(t["train"], lag), ms),

@@ -258,6 +258,9 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
  * of the tiles (a sparse table): the plan is then left as it was.  Synchronises `stream` (set-up path).
  */
 int bear_plan_pair_contexts(bear_plan *plan, const uint64_t *kmer_index, int lag, int *paired, void *stream);
+/* How the pairing went: tiles that take the paired form / tiles that keep their plain list (outputs nullable); returns 1 when the
+ * plan is paired, 0 when it is not. */
+int bear_plan_pair_info(const bear_plan *plan, uint64_t *paired_tiles, uint64_t *plain_tiles);
 
 /*
  * The linear AR function as prior ROWS, forward and backward: replaces make_ar_func_linear's ar_func (bear_model/ar_funcs.py:41-45)

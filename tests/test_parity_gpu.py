@@ -453,7 +453,10 @@ def test_fused_linear_head_paired_contexts(case, lag, dev, ysd1, monkeypatch):
     d_tr = _to_dev(tr, dev)
     plan = kernels.Plan(d_tr, 5)
     idx = kernels.linear_index(kernels.pack_kmers(torch.from_numpy(codes).to(dev)), lag)
+    assert plan.pair_info()[0] == 0
     assert plan.pair_contexts(idx, lag) is True
+    n_paired, n_plain = plan.pair_info()
+    assert n_paired >= 1 and n_paired + n_plain == len(plan.tiles()[0])
     other = idx.clone()
     for scale, cases in ((0.4, [(0.0, False), (-2.5, False), (0.3, True)]), (150.0, [(0.2, False)]), (3000.0, [(0.0, True)])):
         mat = rng.normal(size=(lag, 5, 5)) * scale
