@@ -32,6 +32,9 @@ SYMBOLS = [
 ]
 
 
+ERR_NOMEM = -5   # BEAR_ERR_NOMEM (include/bear_hip.h)
+
+
 class BearError(RuntimeError):
     def __init__(self, status, where):
         self.status = status

@@ -407,6 +407,7 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
         period *= max(1, min(GRAPH_MAX_BATCHES // period, (total_steps - done_steps) // (4 * period)))
         if dist.collective_active():
             dist.allreduce_sum_(torch.zeros_like(packed))     # the communicator comes up outside the capture
+        kernels.default_workspace(device, for_capture=True)   # exists before the capture (creating one allocates)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         try:
@@ -419,16 +420,32 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
             warnings.warn(f"HIP-graph capture of the training step failed ({err}); using the eager loop")
             graph = None
     eager_steps = done_steps
+    # device time of the steps that follow (HIP events on the launch stream; bench.py's per-config step times): the first quarter
+    # of them is left out of `timed_*` so that the clock ramp of a card that idled during set-up is not in the figure
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    loop_steps, timed_from = total_steps - done_steps, None
+    ev[0].record()
     if graph is not None:
         replays = (total_steps - done_steps) // period
-        for _ in range(replays):
+        for r in range(replays):
+            if r == replays // 4:
+                ev[1].record()
+                timed_from = done_steps + r * period
             graph.replay()
         done_steps += replays * period
+    first_eager = done_steps
     for i in range(done_steps, total_steps):
+        if timed_from is None and i - first_eager == (total_steps - first_eager) // 4:
+            ev[1].record()
+            timed_from = i
         one_step(i % n_batches, i + 1)
-    LAST_RUN.update(graph=graph is not None, replays=replays, period=period, eager_steps=eager_steps + total_steps - done_steps,
-                    world=world, collective=dist.collective_active())
+    ev[2].record()
     torch.cuda.synchronize()
+    LAST_RUN.update(graph=graph is not None, replays=replays, period=period, eager_steps=eager_steps + total_steps - done_steps,
+                    world=world, collective=dist.collective_active(), loop_steps=loop_steps,
+                    loop_ms=ev[0].elapsed_time(ev[2]) if loop_steps else 0.0,
+                    timed_steps=total_steps - timed_from if timed_from is not None else 0,
+                    timed_ms=ev[1].elapsed_time(ev[2]) if timed_from is not None else 0.0)
     return (loss_buf[:n_steps] / acc_steps).cpu().tolist()
 
 

@@ -176,9 +176,21 @@ def make_ar_func_cnn(lag, alphabet_size, filter_width=8, num_filters=30, kmer_la
         nn2 = torch.tensordot(F.elu(nn1), kmer_weights2, dims=([-1], [0])) + kmer_intercept2
         return torch.softmax(nn2, dim=-1)
     ar_func.fused = fused_ok       # integer codes on the device take the fused kernels; one-hot input the torch ops
+    # the un-fused path caches the index form of the last code tensor (~16 P fw bytes per row): the loops release it when they
+    # are done (release_ar_func_cache).  The key is (data_ptr, shape, _version): a code buffer REFILLED in place by a bear kernel
+    # does not bump _version -- code tensors handed to this function must not be rewritten in place while it is in use.
+    ar_func.clear_cache = windows.clear
     ar_func.cnn_params, ar_func.cnn_filter_width = params, filter_width
     ar_func.normalized_rows = True
     return ar_func, params
+
+
+def release_ar_func_cache(ar_func):
+    """Drops what an AR function cached for the batches of a finished loop (make_ar_func_cnn's window indices pin the memory
+    pool of a captured graph otherwise)."""
+    clear = getattr(ar_func, "clear_cache", None)
+    if clear is not None:
+        clear()
 
 
 def make_ar_func_stop(lag, alphabet_size, dtype=torch.float64, device=None, generator=None):

@@ -69,7 +69,8 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
             packs = [kernels.linear_index(q, lag) if q is not None else None for q in packs]
         if cnn_ok:
             fw = ar_func.cnn_filter_width
-            bufs = kernels.cnn_step_buffers(max(max(e["rows"] for e in res.batches), 1), lag, fw, device)   # one set, largest batch
+            cnn_ws = kernels.default_workspace(device)     # the workspace the plans below are created on: the step's reservation lives there
+            bufs = kernels.cnn_step_buffers(max(max(e["rows"] for e in res.batches), 1), lag, fw, device, ws=cnn_ws)   # one set, largest batch
 
         def reducer(k):
             e = res.batches[k]
@@ -106,6 +107,7 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
             return _train.scatter_live(out, live, e["rows"])
         losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, learning_rate, optimizer_name, train_ar,
                                            acc_steps, normalized, device)
+    ar_funcs.release_ar_func_cache(ar_func)
     _train.log_losses(losses, writer, loss_save, acc_steps)
     return params, h_signed, ar_func
 
@@ -131,6 +133,7 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
                 prior = out.expand(e["rows"], 5).contiguous() if live is None or out.shape[0] == 1 else _train.scatter_live(out, live, e["rows"])
             sums.add(e["test"], prior, e.get("train"), row_base=e["row0"], plan=res.eval_plan(k) if e["rows"] else None,
                      row_ids=e.get("row_ids") if e["rows"] else None)
+    ar_funcs.release_ar_func_cache(ar_func)
     return sums.result(), device
 
 

@@ -168,6 +168,7 @@ def _train_general(data, num_kmers, params, h_signed, ar_func, learning_rate, op
         ref_mix = (net_fn, lambda e: e["ref_in"], params[1], params[2])
     losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, learning_rate, optimizer_name, train_ar,
                                        acc_steps, ar_func.normalized_rows, device, ref_mix=ref_mix)
+    _ar_funcs.release_ar_func_cache(getattr(ar_func, "net_func", ar_func))
     _train.log_losses(losses, writer, loss_save, acc_steps)
     return params, h_signed, ar_func
 
@@ -203,4 +204,5 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
                     prior = _train.scatter_live(ar_func(e["codes_live_test"], e["ref_in_live_test"]), live, e["rows"])
             sums.add(e["test"], prior, e.get("train"), row_base=e["row0"], plan=res.eval_plan(k) if e["rows"] else None,
                      row_ids=e.get("row_ids") if e["rows"] else None)
+    _ar_funcs.release_ar_func_cache(getattr(ar_func, "net_func", ar_func))
     return _train.reduce_evaluation(sums.result(), device, np.ndim(hv) == 0)

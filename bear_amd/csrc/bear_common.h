@@ -36,7 +36,8 @@ struct bear_ws {
   double *eval_out;         // [EVL_MAX_OUT] scratch result vector (bear_bmm_f64)
   int eval_blocks;
   double *lin_partials;     // [num_cu][LIN_MAX_GRAD] d/d mat partials (kernels_linear.h)
-  unsigned *arrive;                // arrival counter of the launch that owns `partials` (last block sums them; zero between launches)
+  unsigned long long *arrive;      // arrival word of the launch that owns `partials` (bear_arrival: epoch << 24 | blocks arrived)
+  unsigned epoch;                  // host side: the stamp of the last launch that used `arrive` (never 0)
   double *cnn_partials;     // [cnn_blocks][cnn total] parameter-gradient partials (kernels_cnn.h), grown on demand
   size_t cnn_partials_cap;  // doubles
 };
@@ -129,12 +130,26 @@ __device__ __forceinline__ void block_store_partials(double (&acc)[NOUT], double
 // the LAST block to finish sums the per-block partials -- in the fixed order of finalize_kernel, whichever block that is.
 #define BEAR_THETA_NET 1   // theta = {h_signed, ...}                      (bear_net.py:43)
 #define BEAR_THETA_REF 2   // theta = {h_signed, tau_signed, net_weight_signed}  (bear_ref.py:45-47, 106)
+// The arrival word of a workspace and the stamp of THIS launch.  The word is `epoch << 24 | blocks arrived`, zero between
+// launches; every launch is handed the next epoch by the host (ws_arrival, bear_hip.hip).  A block first raises the word to its
+// own stamp (atomic max: a count left behind by an EARLIER launch -- one that faulted half way, or that overlapped on this
+// workspace -- is discarded there instead of silently breaking the last-block detection of every later launch), then counts
+// itself in: two one-way atomics per block, no retry loop (a compare-and-swap loop over 256 blocks that finish together cost
+// 0.19 ms per launch).  A launch replayed from a HIP graph keeps the stamp it was captured with: between launches the word is
+// back at zero (left there by the last block), so an older stamp counts from zero like any other.
+struct bear_arrival {
+  unsigned long long *word;
+  unsigned epoch;
+};
 struct bear_step_io {
   const double *theta;   // non-NULL: constants from these parameters (kind), else the by-value bear_params of the launch
   int kind;
+  unsigned epoch;        // this launch's stamp on the arrival word (in the padding behind `kind`: the argument block keeps its size)
   double *out;           // non-NULL: the last block writes the fixed-order sums here; NULL: a finalize_kernel launch follows
-  unsigned *arrive;      // arrival counter (bear_ws::arrive), zero between launches
+  unsigned long long *arrive_word;   // bear_ws::arrive
+  __host__ __device__ bear_arrival arrive() const { return bear_arrival{arrive_word, epoch}; }
 };
+static_assert(sizeof(bear_step_io) == 32, "bear_step_io: kernel-argument size");
 
 __device__ __forceinline__ double bear_uniform_f64(double v) {   // a wave-uniform value back into scalar registers
   const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -166,12 +181,15 @@ __device__ __forceinline__ bear_params bear_params_of(const bear_params &arg, co
 // thread waits for the acknowledgement of its own stores (s_waitcnt vmcnt(0): gfx9 counts stores there; a workgroup-scope
 // release fence compiles to nothing on gfx950) before the barrier, so the arrival counter is bumped only after all of this
 // block's partials are visible to the device.
-__device__ __forceinline__ bool bear_arrive_last(unsigned *arrive) {
+__device__ __forceinline__ bool bear_arrive_last(const bear_arrival &arrive) {
   __shared__ unsigned s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0)
-    s_last = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+  if (threadIdx.x == 0) {
+    const unsigned long long tag = (unsigned long long)arrive.epoch << 24;
+    __hip_atomic_fetch_max(arrive.word, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = __hip_atomic_fetch_add(arrive.word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag + (gridDim.x - 1u) ? 1u : 0u;
+  }
   __syncthreads();
   if (!s_last) return false;
   // the one block that goes on to read: a single agent-scope acquire (invalidates this CU's L1 and the XCD's L2 lines that may
@@ -180,8 +198,13 @@ __device__ __forceinline__ bool bear_arrive_last(unsigned *arrive) {
   return true;
 }
 
+// The last block is done with the partials: the word goes back to zero (a replay of this launch starts its count afresh).
+__device__ __forceinline__ void bear_arrive_reset(const bear_arrival &arrive) {
+  __hip_atomic_store(arrive.word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // The arithmetic of finalize_kernel (256 threads, same order) inside the last block of the producing launch.
-__device__ __forceinline__ void bear_finalize_in_block(const double *partials, int n_out, double *out, unsigned *arrive, bool accumulate = false) {
+__device__ __forceinline__ void bear_finalize_in_block(const double *partials, int n_out, double *out, const bear_arrival &arrive, bool accumulate = false) {
   __shared__ double fred[4][BEAR_MAX_OUT];
   const int n_blocks = (int)gridDim.x;
   if (threadIdx.x < 256) {
@@ -202,7 +225,7 @@ __device__ __forceinline__ void bear_finalize_in_block(const double *partials, i
     const double v = (fred[0][threadIdx.x] + fred[1][threadIdx.x]) + (fred[2][threadIdx.x] + fred[3][threadIdx.x]);
     out[threadIdx.x] = accumulate ? out[threadIdx.x] + v : v;    // (accumulate: the second launch of a step that takes two)
   }
-  if (threadIdx.x == 0) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch (stream order) starts from zero
+  if (threadIdx.x == 0) bear_arrive_reset(arrive);
 }
 
 template <int NOUT>
@@ -212,7 +235,7 @@ __device__ __forceinline__ void block_finish(double (&acc)[NOUT], double *partia
     return;
   }
   block_store_partials<NOUT, true>(acc, partials);
-  if (bear_arrive_last(io.arrive)) bear_finalize_in_block(partials, NOUT, io.out, io.arrive);
+  if (bear_arrive_last(io.arrive())) bear_finalize_in_block(partials, NOUT, io.out, io.arrive());
 }
 
 // ------------------------------------------------------------------ finalize: fixed-order sum of block partials

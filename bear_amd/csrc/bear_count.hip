@@ -324,6 +324,7 @@ void bear_level_free(bear_level_dev *lv) {
   lv->child_start = nullptr;
   lv->rows = nullptr;
   lv->n = 0;
+  lv->bytes = 0;
 }
 
 int bear_level_build(const unsigned long long *codes_below, uint64_t n_below, int letters, bear_level_dev *out, hipStream_t s) {
@@ -341,6 +342,7 @@ int bear_level_build(const unsigned long long *codes_below, uint64_t n_below, in
   out->parent_of_below = nullptr;
   out->child_start = nullptr;
   out->rows = nullptr;
+  out->bytes = 0;
   CNT_TRY(hipMalloc(&flag, n_below * sizeof(uint32_t)));
   CNT_TRY(hipMalloc(&scan, n_below * sizeof(uint32_t)));
   hipLaunchKernelGGL(level_flag_kernel, dim3(grid_for(n_below)), dim3(256), 0, s, codes_below, n_below, mask, flag);

@@ -85,8 +85,9 @@ int bear_ws_create(int device, bear_ws **out) {
       if (e == hipSuccess) e = hipMalloc(&ws->eval_partials, sizeof(double) * EVL_MAX_OUT * (size_t)ws->eval_blocks);
       if (e == hipSuccess) e = hipMalloc(&ws->eval_out, sizeof(double) * EVL_MAX_OUT);
       if (e == hipSuccess) e = hipMalloc(&ws->lin_partials, sizeof(double) * LIN_MAX_GRAD * (size_t)ws->num_cu);
-      if (e == hipSuccess) e = hipMalloc(&ws->arrive, sizeof(unsigned));
-      if (e == hipSuccess) e = hipMemset(ws->arrive, 0, sizeof(unsigned));
+      if (e == hipSuccess) e = hipMalloc(&ws->arrive, sizeof(unsigned long long));
+      if (e == hipSuccess) e = hipMemset(ws->arrive, 0, sizeof(unsigned long long));
+      ws->epoch = 0;
       for (const void *fn : {reinterpret_cast<const void *>(dm_linear_plan_kernel<false, false>),
                              reinterpret_cast<const void *>(dm_linear_plan_kernel<true, false>),
                              reinterpret_cast<const void *>(dm_linear_plan_kernel<false, true>),
@@ -181,6 +182,23 @@ int bear_ws_destroy(bear_ws *ws) {
   (void)hipSetDevice(prev);
   delete ws;
   return BEAR_OK;
+}
+
+// a fresh stamp for the launch that is about to use ws->arrive (bear_arrival, bear_common.h); 0 is the word's idle value
+static bear_arrival ws_arrival(bear_ws *ws) {
+  if (++ws->epoch == 0u) ws->epoch = 1u;
+  return bear_arrival{ws->arrive, ws->epoch};
+}
+
+static bear_step_io ws_io(bear_ws *ws, const double *theta, int kind, double *out) {
+  const bear_arrival a = ws_arrival(ws);
+  bear_step_io io;
+  io.theta = theta;
+  io.kind = kind;
+  io.epoch = a.epoch;
+  io.out = out;
+  io.arrive_word = a.word;
+  return io;
 }
 
 static int check_ws(const bear_ws *ws) {
@@ -643,7 +661,7 @@ static int launch_prior_plan(bear_ws *ws, const bear_plan *plan, const double *p
                              const double *theta, int train_ar, int prior_normalized, double *out, hipStream_t s) {
   const int grid = grid_plan(ws, plan->n_tiles);
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
-  const bear_step_io io{theta, BEAR_THETA_NET, out, ws->arrive};
+  const bear_step_io io = ws_io(ws, theta, BEAR_THETA_NET, out);
   if (train_ar)
     hipLaunchKernelGGL((dm_prior_plan_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_n), s, prior, n_rows, prm,
                        plan_view(plan), lt, ws->partials, io PLN_DBG_ARG);
@@ -679,7 +697,7 @@ static int launch_prior_plan_grad(bear_ws *ws, const bear_plan *plan, const doub
   const int grid = grid_plan(ws, plan->n_tiles);
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const pln_view pv = plan_view(plan);
-  const bear_step_io io{theta, BEAR_THETA_NET, out, ws->arrive};
+  const bear_step_io io = ws_io(ws, theta, BEAR_THETA_NET, out);
   if (train_ar)
     hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
                        grad_prior, ws->partials, io);
@@ -757,7 +775,7 @@ int bear_dm_refmix_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint3
   const int grid = grid_plan(ws, plan->n_tiles);
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const pln_view pv = plan_view(plan);
-  const bear_step_io io{nullptr, BEAR_THETA_REF, out, ws->arrive};
+  const bear_step_io io = ws_io(ws, nullptr, BEAR_THETA_REF, out);
   if (train_ar)
     hipLaunchKernelGGL(dm_refmix_plan_grad_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, net_rows, ref_rows,
                        h_signed_dev, tau_signed_dev, net_weight_signed_dev, eps, pv, lt, grad_net_rows, ws->partials, io);
@@ -784,7 +802,7 @@ int bear_dm_refmix_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint3
 static int launch_ref_plan(bear_ws *ws, const bear_plan *plan, const uint32_t *ref, uint64_t n_rows, const bear_params &prm,
                            const double *theta, int train_ar, double *out, hipStream_t s) {
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
-  const bear_step_io io{theta, BEAR_THETA_REF, out, ws->arrive};
+  const bear_step_io io = ws_io(ws, theta, BEAR_THETA_REF, out);
   int grid;
   if (plan->ref) {
     if (plan->ref != ref) return BEAR_ERR_INVALID_ARG;   // the plan is valid for the reference buffer it was built from
@@ -964,7 +982,9 @@ static void launch_linear(bear_ws *ws, const bear_plan *plan, const uint64_t *km
   const bool paired = plan->live2 && plan->pair_codes == kmer_code && plan->pair_lag == lag && !getenv("BEAR_AMD_LINEAR_UNPAIRED");
 #define LIN_LAUNCH(AR, PAIRED, PV, NT, ACC)                                                                                             \
   hipLaunchKernelGGL((dm_linear_plan_kernel<AR, PAIRED>), dim3(grid_plan(ws, NT)), dim3(PLN_THREADS), sizeof(pln_lds_lin), s, kc, mat,  \
-                     lag, prm, PV, lt, ws->partials, ws->lin_partials, io, grad_mat, ACC)
+                     lag, prm, PV, lt, ws->partials, ws->lin_partials, (ACC) ? io2 : io, grad_mat, ACC)
+  bear_step_io io2 = io;      // the second launch of a step: its own stamp on the arrival word
+  io2.epoch = ws_arrival(ws).epoch;
   pln_view pv = plan_view(plan);
   if (!paired) {
     if (train_ar) LIN_LAUNCH(true, false, pv, plan->n_tiles, 0);
@@ -1107,7 +1127,7 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
   memset(&prm, 0, sizeof(prm));
   prm.inv_h = 1.0 / exp(h_signed);
   prm.eps = eps;
-  const bear_step_io io{nullptr, BEAR_THETA_NET, out, ws->arrive};   // one launch: the last block sums the partials
+  const bear_step_io io = ws_io(ws, nullptr, BEAR_THETA_NET, out);   // one launch: the last block sums the partials
   launch_linear(ws, plan, kmer_code, mat, lag, prm, train_ar, io, grad_mat, s);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
@@ -1149,7 +1169,7 @@ int bear_linear_backward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_
     return BEAR_ERR_INVALID_ARG;
   hipLaunchKernelGGL(linear_rows_backward_kernel, dim3(linrows_grid(ws, n_rows)), dim3(LNR_THREADS), 0, s,
                      reinterpret_cast<const unsigned long long *>(kmer_code), n_rows, lag, prior, grad_prior, ws->lin_partials,
-                     ws->arrive, grad_mat);
+                     ws_arrival(ws), grad_mat);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
@@ -1193,7 +1213,7 @@ int bear_ref_mix_backward_f64(bear_ws *ws, const double *net_rows, const double 
       misaligned(grad_prior) || misaligned(grad_net_rows))
     return BEAR_ERR_INVALID_ARG;
   hipLaunchKernelGGL(ref_mix_backward_kernel, dim3(refmix_grid(ws, n_rows)), dim3(RMX_THREADS), 0, s, net_rows, ref_rows, grad_prior,
-                     tau_signed, net_weight_signed, n_rows, grad_net_rows, ws->partials, ws->arrive, grad_scalars);
+                     tau_signed, net_weight_signed, n_rows, grad_net_rows, ws->partials, ws_arrival(ws), grad_scalars);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
@@ -1211,7 +1231,7 @@ int bear_net_linear_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const u
   memset(&dummy, 0, sizeof(dummy));
   dummy.eps = eps;
   const double *mat = theta + 1;
-  const bear_step_io io{theta, BEAR_THETA_NET, packed, ws->arrive};   // constants from theta, sums by the last block: one launch
+  const bear_step_io io = ws_io(ws, theta, BEAR_THETA_NET, packed);   // constants from theta, sums by the last block: one launch
   launch_linear(ws, plan, kmer_code, mat, lag, dummy, train_ar, io, packed + 2, s);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
@@ -1731,18 +1751,22 @@ static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn
 }
 
 // Prefix levels of the plan's (k-mer-sorted) contexts for the convolutional step: see include/bear_hip.h.
+static void plan_drop_cnn_levels(bear_plan *plan) {
+  for (int k = 0; k < plan->n_cnn_levels; ++k) {
+    plan->bytes -= plan->cnn_levels[k].bytes;
+    bear_level_free(&plan->cnn_levels[k]);
+  }
+  plan->n_cnn_levels = 0;
+  plan->cnn_codes = nullptr;
+}
+
 int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int lag, int filter_width, int *n_levels, void *stream) {
   if (n_levels) *n_levels = 0;
   if (!plan || plan->ncol != 5 || lag < 1 || lag > CNN_MAX_LAG || filter_width < 1 || filter_width > lag) return BEAR_ERR_INVALID_ARG;
   if (plan->n_rows && (!kmer_code || misaligned(kmer_code))) return BEAR_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   HIP_TRY(hipStreamSynchronize(s));
-  for (int k = 0; k < plan->n_cnn_levels; ++k) {      // a plan holds one set of levels: the new one replaces it
-    plan->bytes -= plan->cnn_levels[k].n * (8 + 4 + 16 * 8) + 4 * (k == 0 ? plan->n_rows : plan->cnn_levels[k - 1].n);
-    bear_level_free(&plan->cnn_levels[k]);
-  }
-  plan->n_cnn_levels = 0;
-  plan->cnn_codes = nullptr;
+  plan_drop_cnn_levels(plan);                          // a plan holds one set of levels: the new one replaces it
   const cnn_dims D = cnn_make_dims(lag, filter_width);
   // (the part form of the backward kernel is the one with a position range: shapes whose staging does not fit keep the plain step)
   if (sizeof(double) * (cnnq_fixed_doubles(D) + (size_t)cnnq<2>::WAVES * cnnq<2>::WAVE_DOUBLES) > 160u * 1024u) return BEAR_OK;
@@ -1757,6 +1781,7 @@ int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int 
     const int st = bear_level_build(below, n_below, lag - k, &lv, s);
     if (st != BEAR_OK) {
       if (st == BEAR_ERR_HIP) g_last_hip_error = bear_count_last_hip_error();
+      plan_drop_cnn_levels(plan);                      // the levels built so far go with it: the plan is as it was without levels
       return st;
     }
     // a level pays when it is clearly smaller than the last one kept (a position per row either way, plus the row traffic); a
@@ -1768,8 +1793,9 @@ int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int 
       continue;
     }
     misses = 0;
+    lv.bytes = lv.n * (8 + 4 + 16 * 8) + 4 * n_below;
     plan->cnn_levels[plan->n_cnn_levels++] = lv;
-    plan->bytes += lv.n * (8 + 4 + 16 * 8) + 4 * n_below;
+    plan->bytes += lv.bytes;
     below = lv.codes;
     n_below = lv.n;
   }

@@ -11,6 +11,7 @@ struct bear_level_dev {
   uint32_t *parent_of_below;   // [n_below] row of this level that a row of the level below belongs to
   uint32_t *child_start;       // [n + 1] first row of the level below of each row (its rows are neighbours)
   double *rows;                // [n][16] the level's layer-1 sums (forward) / dT1 rows (backward)
+  uint64_t bytes;              // what the owner of the level has accounted for it (bear_plan::bytes)
 };
 
 // Builds `out` from the packed contexts of the level below (equal prefixes must be neighbours: a k-mer-sorted batch; any other

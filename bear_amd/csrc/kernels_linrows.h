@@ -60,7 +60,7 @@ static_assert(LIN_TAB_DOUBLES >= 3 * LIN_MAX_GRAD, "lin_sum_block_partials scrat
 __global__ __launch_bounds__(LNR_THREADS) void linear_rows_backward_kernel(const unsigned long long *__restrict__ kmer_code, uint64_t n,
                                                                            int lag, const double *__restrict__ prior,
                                                                            const double *__restrict__ grad_prior,
-                                                                           double *__restrict__ grad_partials, unsigned *arrive,
+                                                                           double *__restrict__ grad_partials, const bear_arrival arrive,
                                                                            double *__restrict__ grad_mat) {
   __shared__ lnr_lds_bwd S;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = srt_uniform(tid >> 6);
@@ -96,5 +96,5 @@ __global__ __launch_bounds__(LNR_THREADS) void linear_rows_backward_kernel(const
   lin_fold_tables(S.GT, G, (int)tid, LNR_THREADS, grad_partials + (size_t)blockIdx.x * LIN_MAX_GRAD);
   if (!bear_arrive_last(arrive)) return;
   lin_sum_block_partials(grad_partials, lag * 25, S.GT, (int)tid, LNR_THREADS, grad_mat);
-  if (tid == 0) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch starts from zero
+  if (tid == 0) bear_arrive_reset(arrive);
 }

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(RMX_THREADS) void ref_mix_backward_kernel(const dou
                                                                        const double *__restrict__ tau_signed,
                                                                        const double *__restrict__ nw_signed, uint64_t n,
                                                                        double *__restrict__ grad_net_rows, double *__restrict__ partials,
-                                                                       unsigned *arrive, double *__restrict__ grad_scalars) {
+                                                                       const bear_arrival arrive, double *__restrict__ grad_scalars) {
   __shared__ __attribute__((aligned(16))) double rows[RMX_WAVES][64 * 5];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const rmx_consts C = rmx_load(tau_signed, nw_signed);

@@ -1,6 +1,7 @@
 """Thin torch-facing wrappers over the C ABI (one call = one asynchronous launch on the
 current torch stream).  Tensors are passed as raw device pointers; nothing here computes."""
 import ctypes
+import warnings
 
 import numpy as np
 import torch
@@ -37,7 +38,7 @@ class Workspace:
 _default_ws = {}
 
 
-def default_workspace(device):
+def default_workspace(device, for_capture=False):
     """The workspace of (device, current stream).  A workspace serves ONE stream at a time (include/bear_hip.h: its block
     partials and the arrival counter of the "last block finalizes" kernels are per-launch state), so a side stream gets its own;
     a stream that is capturing a graph shares the device's first workspace (nothing may be allocated during capture, and a
@@ -46,7 +47,8 @@ def default_workspace(device):
     if idx is None:
         idx = torch.cuda.current_device()
     stream = torch.cuda.current_stream(idx)
-    key = (idx, 0 if (stream == torch.cuda.default_stream(idx) or torch.cuda.is_current_stream_capturing()) else stream.cuda_stream)
+    key = (idx, 0 if (for_capture or stream == torch.cuda.default_stream(idx) or torch.cuda.is_current_stream_capturing())
+           else stream.cuda_stream)       # for_capture: the one a capturing stream will resolve to (created BEFORE the capture)
     ws = _default_ws.get(key)
     if ws is None:
         ws = _default_ws[key] = Workspace(torch.device("cuda", idx))
@@ -151,7 +153,12 @@ class Plan:
             raise ValueError("kmer_index: one 16-byte aligned index word per row of the plan's count slab")
         ok = ctypes.c_int(0)
         with torch.cuda.device(self.counts.device):
+            torch.cuda.empty_cache()     # the lists come from hipMalloc: slabs the torch allocator has cached are out of its reach
             st = _lib.lib().bear_plan_pair_contexts(self._h, _ptr(kmer_index), int(lag), ctypes.byref(ok), _stream())
+        if st == _lib.ERR_NOMEM:         # an optional speed-up: a table close to the card's capacity runs the plain step
+            warnings.warn("bear_plan_pair_contexts: out of device memory, the linear step keeps its plain lists")
+            self.paired_codes = None
+            return False
         _lib.check(st, "bear_plan_pair_contexts")
         self.paired_codes = kmer_index if ok.value else None
         return bool(ok.value)
@@ -171,7 +178,12 @@ class Plan:
             raise ValueError("kmer_code: one 16-byte aligned packed context per row of the plan's count slab")
         n = ctypes.c_int(0)
         with torch.cuda.device(self.counts.device):
+            torch.cuda.empty_cache()     # (as in pair_contexts)
             st = _lib.lib().bear_plan_attach_cnn_levels(self._h, _ptr(kmer_code), int(lag), int(filter_width), ctypes.byref(n), _stream())
+        if st == _lib.ERR_NOMEM:
+            warnings.warn("bear_plan_attach_cnn_levels: out of device memory, the convolutional step runs without prefix levels")
+            self.cnn_codes = None
+            return 0
         _lib.check(st, "bear_plan_attach_cnn_levels")
         self.cnn_codes = kmer_code if n.value else None
         return int(n.value)
@@ -534,7 +546,12 @@ def cnn_forward(kmer_code, flat_params, lag, filter_width, save=True, ws=None, p
     pass then runs over its prefix levels when they were attached for this tensor (``bear_cnn_forward_plan_f64``; t1 is kept)."""
     _check_codes(kmer_code)
     n = kmer_code.shape[0]
+    if not (flat_params.is_cuda and flat_params.dtype == torch.float64 and flat_params.is_contiguous()
+            and flat_params.numel() == cnn_param_count(lag, filter_width)):
+        raise ValueError("flat_params must be the contiguous CUDA float64 parameter vector of bear_cnn_param_count elements")
     if plan is not None:
+        if plan.counts.shape[0] != n:
+            raise ValueError("plan: built for another number of rows than kmer_code holds")
         prior = torch.empty((n, 5), dtype=torch.float64, device=kmer_code.device)
         t1 = torch.empty((n, CNN_LAYER1_WIDTH), dtype=torch.float64, device=kmer_code.device)
         with torch.cuda.device(kmer_code.device):
@@ -542,9 +559,6 @@ def cnn_forward(kmer_code, flat_params, lag, filter_width, save=True, ws=None, p
                                                       CNN_LAYER1_WIDTH, _ptr(flat_params), _ptr(prior), _ptr(t1), _stream())
         _lib.check(st, "bear_cnn_forward_plan_f64")
         return prior, t1
-    if not (flat_params.is_cuda and flat_params.dtype == torch.float64 and flat_params.is_contiguous()
-            and flat_params.numel() == cnn_param_count(lag, filter_width)):
-        raise ValueError("flat_params must be the contiguous CUDA float64 parameter vector of bear_cnn_param_count elements")
     ws = ws or default_workspace(kmer_code.device)
     prior = torch.empty((n, 5), dtype=torch.float64, device=kmer_code.device)
     t1 = torch.empty((n, CNN_LAYER1_WIDTH), dtype=torch.float64, device=kmer_code.device) if save else None

@@ -130,6 +130,10 @@ def parse_args():
     ap.add_argument("--no-unnormalised-rows", action="store_true",
                     help="skip also.net_rows_not_normalised: it launches the HEADLINE's kernel instantiation on other data (2.5x slower per "
                          "launch), which a per-kernel-name profile of this command cannot tell apart (scripts/profile_round.sh passes it)")
+    ap.add_argument("--no-baseline-configs", action="store_true",
+                    help="skip also.baseline_configs / also.dense_table (scripts/baseline_configs.py: ~20 s)")
+    ap.add_argument("--no-strong-pass", action="store_true",
+                    help="N > 1, weak scaling: skip the additional strong-scaling pass (also.strong_scaling)")
     ap.add_argument("--ingest-rows", type=float, default=None,
                     help="rows of the text table of the also.ingest entry (text -> first step wall time); default: min(--contexts, 1e8); 0 = skip")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU smoke tests of the N > 1 path)")
@@ -166,6 +170,60 @@ def self_launch(n_ranks):
         else:
             sys.stderr.write(ln)
     return child.wait()
+
+
+def strong_pass(args, rank, world, dev, dev_index, wl, params):
+    """ONE table of --contexts rows cut into `world` contiguous row shards (what `--scaling strong` measures as the headline),
+    timed right after the weak measurement of the same launch: barrier + synchronize around K steps, MAX over ranks."""
+    from bear_amd import kernels
+    h_s, tau_s, nu_s = params
+    total = int(args.contexts)
+    base, rem = divmod(total, world)
+    row0, n = rank * base + min(rank, rem), base + (1 if rank < rem else 0)
+    want = ("train",) if wl == "net" else ("train", "ref")
+    t = kernels.synth_counts(SEED, row0, n, dev, want=want)
+    prior = kernels.synth_prior(SEED, row0, n, dev) if wl == "net" else None
+    plan = kernels.Plan(t["train"], 5) if wl == "net" else kernels.Plan(t["train"], 4, ref=t["ref"])
+    out = torch.zeros(2 if wl == "net" else 4, dtype=torch.float64, device=dev)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record()
+        if wl == "net":
+            kernels.dm_prior_planned(plan, prior, h_s, out=out)
+        else:
+            kernels.dm_ref_planned(plan, t["ref"], h_s, tau_s, nu_s, out=out)
+        if ev is not None:
+            ev[1].record()
+        dist.all_reduce(out)
+        if ev is not None:
+            ev[2].record()
+    for _ in range(max(args.warmup, 50)):       # (the card is warm from the weak pass; the shard's own first launches are not)
+        step()
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+    dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device=dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    mine = torch.tensor([float(np.mean([e[0].elapsed_time(e[1]) for e in evs])), float(np.mean([e[1].elapsed_time(e[2]) for e in evs])),
+                         float(n), float(dev_index)], dtype=torch.float64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    bpc = BYTES_PER_CONTEXT[wl]
+    return {"scaling": "strong", "contexts_total": total, "value": total * args.steps / elapsed, "unit": "contexts/s",
+            "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps,
+            "frac_of_n_gpu_hbm_roofline": total * bpc / (elapsed / args.steps) / 1e9 / (HBM_PEAK_GBPS * world),
+            "per_rank": [{"rank": r, "device": int(v[3].item()), "contexts": int(v[2].item()), "kernel_ms": float(v[0].item()),
+                          "allreduce_ms": float(v[1].item())} for r, v in enumerate(allr)],
+            "result": out.cpu().numpy().tolist(),
+            "note": "the same step (planned kernel + one packed all-reduce) on ONE table of contexts_total rows cut into one contiguous "
+                    "shard per rank; measured after the weak pass of this launch"}
 
 
 def main():
@@ -276,9 +334,26 @@ def main():
                 "rule": "groups of %d launches of the timed kernel until 3 consecutive group means agree within %.0f %% (cap %.1f s); "
                         "untimed, before --warmup" % (group, tol * 100, cap_s)}
 
+    def cold_run(wl, steps, warmup):
+        """What the same command reads WITHOUT the settle launches (`--no-settle`): `warmup` untimed steps, then `steps` timed ones,
+        on a card that idled through the set-up -- the figure of the driver's `--warmup 5` protocol alone, kept in the record."""
+        for _ in range(warmup):
+            step(wl)
+        barrier()
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            step(wl)
+        barrier()
+        return (time.perf_counter() - t_start) / steps * 1e3
+
     def measure(wl, steps, warmup, do_settle=False):
         gc.collect()         # now, not between the warm-up and the timed steps: the card must not idle there
+        cold_ms = cold_run(wl, min(steps, 20), warmup) if do_settle else None
         settle_info = settle(wl) if do_settle else None
+        if settle_info is not None:
+            settle_info["cold_ms_per_step_without_settle"] = cold_ms
+            settle_info["cold_note"] = ("ms_per_step of min(steps, 20) timed steps behind --warmup alone, taken BEFORE the settle launches "
+                                        "on the card as the set-up left it (what --no-settle reports)")
         for _ in range(warmup):
             step(wl)
         evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3 if multi else 2)) for _ in range(steps)]
@@ -569,11 +644,41 @@ def main():
             except Exception as err:    # e.g. no room for the text file on this box: reported, never fatal for the bench line
                 extra["ingest"] = {"rows": ingest_rows, "error": f"{type(err).__name__}: {err}"}
         del test, eplan
+        # every BASELINE config's own optimizer step at its stated size + the dense stress table (scripts/baseline_configs.py)
+        if not args.no_baseline_configs:
+            try:
+                import baseline_configs
+                torch.cuda.empty_cache()
+                extra["baseline_configs"] = baseline_configs.measure_configs(dev)
+                torch.cuda.empty_cache()
+                extra["dense_table"] = baseline_configs.measure_dense(dev)
+            except Exception as err:    # reported, never fatal for the bench line
+                extra.setdefault("baseline_configs", {"error": f"{type(err).__name__}: {err}"})
+                extra.setdefault("dense_table", {"error": f"{type(err).__name__}: {err}"})
+
+    # (7) N > 1 under weak scaling: the strong split of ONE --contexts table too (north_star: the 1e8 table at 1/2/4/8 GPUs)
+    strong = None
+    if multi and args.scaling == "weak" and not args.no_strong_pass:
+        strong = strong_pass(args, rank, world, dev, dev_index, primary, (h_s, tau_s, nu_s))
 
     value = total * args.steps / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     bpc = BYTES_PER_CONTEXT[primary]
     achieved = n * bpc / (k_ms * 1e-3) / 1e9  # per-GPU algorithmic GB/s of the dominant kernel
+
+    # what the collective actually ran on: the process group's own world size and backend (nccl = RCCL), how the ranks were started,
+    # and the two facts a scaling figure rests on -- RCCL carried the all-reduce and every rank had a card of its own
+    devices = [e["device"] for e in per_rank] if per_rank else [dev_index]
+    ranks_info = {"world_size": dist.get_world_size() if multi else 1, "backend": dist.get_backend() if multi else None,
+                  "launcher": os.environ.get("BEAR_BENCH_LAUNCHER", "external") if "WORLD_SIZE" in os.environ else "none (one process)",
+                  "devices": devices, "backend_is_rccl": (dist.get_backend() == "nccl") if multi else None,
+                  "devices_distinct": len(set(devices)) == len(devices)}
+    if world > 1 and "BEAR_BENCH_DEVICE" not in os.environ and args.backend == "nccl":
+        # (the override puts every rank on one card: single-GPU tests of this path; gloo: CPU-side smoke tests)
+        if not (ranks_info["backend_is_rccl"] and ranks_info["devices_distinct"] and ranks_info["world_size"] == world):
+            raise SystemExit(f"bench.py: --gpus {world} did not run as {world} RCCL ranks on {world} cards: {ranks_info}")
+    if strong is not None:
+        extra["strong_scaling"] = strong
 
     line = None
     if rank == 0 and extra:
@@ -668,9 +773,7 @@ def main():
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s"})(extra["net_with_gradient_rows"]),
             "settle": settle_info,
             # what the collective actually ran on: the process group's own world size and backend (nccl = RCCL), how the ranks were started
-            "ranks": {"world_size": dist.get_world_size() if multi else 1, "backend": dist.get_backend() if multi else None,
-                      "launcher": os.environ.get("BEAR_BENCH_LAUNCHER", "external") if "WORLD_SIZE" in os.environ else "none (one process)",
-                      "devices": [e["device"] for e in per_rank] if per_rank else [dev_index]},
+            "ranks": ranks_info,
             "per_rank": per_rank,
             "plan_build_s": plan_build_s,
             "plan_bytes_per_context": plan_nbytes[primary] / n,

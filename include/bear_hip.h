@@ -186,6 +186,8 @@ int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_
  * like the plan's count slab).  *n_levels (nullable) = 0: nothing was attached (rows in another order, a table too sparse for its
  * prefixes to repeat, a plan whose lists skip rows, a shape outside the fused kernels): the step runs as before.
  * Holds about 45 bytes per context on a dense table.  Synchronises `stream` (set-up path).
+ * A plan with levels attached carries PER-LAUNCH state (the levels' layer-1 / dT1 rows are written by every forward and backward
+ * pass over them, also through a `const bear_plan *`): like a workspace it serves one stream at a time.
  */
 int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int lag, int filter_width, int *n_levels, void *stream);
 /* Rows and prefix lengths (letters) of the attached levels 1 .. n (rows_out [host, nullable when capacity = 0], letters_out [host,

@@ -1,0 +1,155 @@
+"""BASELINE.json configs[1..4], each at the size the config states, through the HOST DRIVERS' own step loop
+(bear_ref.train / bear_net.train -> _train.run_device_steps: reduce + Adam per step, one period captured into a HIP graph and
+replayed), timed with HIP events around the replayed steps (_train.LAST_RUN: the last three quarters of the loop, behind the
+clock ramp), plus configs[4]'s held-out evaluation -- and the dense stress table of SURVEY section 8d (lambda = 1e4 ... 3e5, what the
+reference's only real table, data/ysd1_lag_5_file_0_preshuf.tsv, looks like: every item on the Stirling path).
+bench.py reports both as also.baseline_configs / also.dense_table; stand-alone:
+    python scripts/baseline_configs.py [configs|dense|all]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+SEED = 20211012
+
+
+def _table(n, lag, dev, cols, row0=0):
+    """Host arrays of rows [row0, row0 + n) of the synthetic table (what a parsed count file is): kmers uint8 [n, lag], counts
+    uint32 [len(cols), n, 5]."""
+    from bear_amd import kernels
+    t = kernels.synth_counts(SEED, row0, n, dev, want=cols)
+    counts = np.stack([t[k].cpu().numpy().view(np.uint32) for k in cols])
+    del t
+    gen = torch.Generator(dev).manual_seed(SEED + lag)
+    kmers = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (n, lag), device=dev, generator=gen)].cpu().numpy()
+    torch.cuda.empty_cache()
+    return kmers, counts
+
+
+def _train_config(mod, data, n, lag, make, kw, steps, extra=()):
+    """One train() call of `steps` optimizer steps; the loop's own event times."""
+    from bear_amd import _train
+    loss = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = mod.train(data.repeat(steps), n, steps, 0, *extra, "dna", lag, make, kw, 0.01, "Adam", False, loss_save=loss)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    lr = dict(_train.LAST_RUN)
+    ms = lr["timed_ms"] / max(lr["timed_steps"], 1)
+    return out, {"rows": n, "lag": lag, "optimizer_steps": steps, "us_per_step": ms * 1e3, "contexts_per_s": n / (ms * 1e-3),
+                 "steps_timed": lr["timed_steps"], "captured_in_hip_graph": bool(lr["graph"]), "steps_per_replay": lr["period"],
+                 "train_call_wall_s": wall, "elbo_first_step": loss[0], "elbo_last_step": loss[-1]}
+
+
+def measure_configs(dev, shrink=1):
+    """also.baseline_configs.  `shrink` > 1 divides every size (tests)."""
+    from bear_amd import ar_funcs, bear_net, bear_ref, dataloader
+    out = {"note": "one optimizer step = this rank's reduce (fused kernels) + Adam (bear_train_apply_f64), enqueued by bear_ref.train / "
+                   "bear_net.train themselves (run_device_steps: a period of steps captured into a HIP graph and replayed); us_per_step = "
+                   "HIP-event time of the last three quarters of the loop / its steps; one GPU, so configs[3] / [4] run one rank's "
+                   "shard of the 8-GPU job (no all-reduce in the figure)"}
+    n1 = 10_000_000 // shrink
+    kmers, counts = _table(n1, 13, dev, ("train", "test", "ref"))
+    data = dataloader.CountDataset(kmers, counts, "dna", n1)
+    _, out["configs[1] bear_ref, stop prior, k=13, 1e7 contexts"] = _train_config(
+        bear_ref, data, n1, 13, ar_funcs.make_ar_func_stop, {}, 2000, extra=(2,))
+    _, out["configs[2] bear_net, linear AR prior, k=13, 1e7 contexts"] = _train_config(
+        bear_net, data, n1, 13, ar_funcs.make_ar_func_linear, {}, 600)
+    del data, kmers, counts
+    n4 = 12_500_000 // shrink
+    kmers, counts = _table(n4, 13, dev, ("train", "test"))
+    data = dataloader.CountDataset(kmers, counts, "dna", n4)
+    (params, h_signed, ar_func), ent = _train_config(bear_net, data, n4, 13, ar_funcs.make_ar_func_cnn, {"filter_width": 8}, 24)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = bear_net.evaluation(data, 0, 1, "dna", torch.exp(h_signed).detach(), ar_func, np.array([0.1, 1.0, 10.0]))
+    torch.cuda.synchronize()
+    ent.update(heldout_evaluation_wall_s=time.perf_counter() - t0, heldout_perplexity_bear=float(res[3]),
+               heldout_perplexity_ar=float(res[4]), heldout_perplexity_bmm=[float(x) for x in np.atleast_1d(res[5])])
+    out["configs[4] bear_net, CNN AR prior, k=13, rank shard 1.25e7 of 1e8 contexts, + held-out evaluation"] = ent
+    del data, kmers, counts, params, ar_func
+    n3 = 125_000_000 // shrink
+    kmers, counts = _table(n3, 15, dev, ("train", "ref"), row0=3 * n3)
+    data = dataloader.CountDataset(kmers, counts, "dna", n3)
+    _, out["configs[3] bear_ref, k=15, rank shard 1.25e8 of 1e9 contexts"] = _train_config(
+        bear_ref, data, n3, 15, ar_funcs.make_ar_func_stop, {}, 400, extra=(1,))
+    return out
+
+
+def measure_dense(dev, n=20_000_000, check_rows=2_000_000):
+    """also.dense_table: the planned kernels on synth_counts(dense=True) -- every count in the thousands: every item takes the
+    Stirling path and the in-tile large-count lists (PLN_HCAP) overflow to the plan's global lists -- with the ELBO / gradients
+    of the timed launches checked against oracle/bear_oracle.c on the first `check_rows` rows (a plan of their own)."""
+    from bear_amd import kernels
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import c_oracle as co       # checker only
+    t = kernels.synth_counts(SEED, 0, n, dev, dense=True, want=("train", "ref"))
+    prior = kernels.synth_prior(SEED, 0, n, dev)
+    h_s, tau_s, nu_s = 0.0, float(np.log(1 / 30)), float(-np.log(100))
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / reps)
+        return best
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan_n, plan_r = kernels.Plan(t["train"], 5), kernels.Plan(t["train"], 4, ref=t["ref"])
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    ms_n = timed(lambda: kernels.dm_prior_planned(plan_n, prior, h_s))
+    ms_g = timed(lambda: kernels.dm_prior_planned(plan_n, prior, h_s, want_grad=True, normalized=True))
+    ms_r = timed(lambda: kernels.dm_ref_planned(plan_r, t["ref"], h_s, tau_s, nu_s))
+    ms_u = timed(lambda: kernels.dm_prior(t["train"], prior, h_s), reps=2)
+    # planned == unplanned on the whole table, both == the C oracle on the first check_rows rows
+    got_n = kernels.dm_prior_planned(plan_n, prior, h_s).cpu().numpy()
+    got_u = kernels.dm_prior(t["train"], prior, h_s)[0].cpu().numpy()
+    m = min(n, check_rows)
+    tr, rf, pr = (x[:m].contiguous() for x in (t["train"], t["ref"], prior))
+    sub_n, grad = kernels.dm_prior_planned(kernels.Plan(tr, 5), pr, h_s, want_grad=True, normalized=True)
+    sub_r = kernels.dm_ref_planned(kernels.Plan(tr, 4, ref=rf), rf, h_s, tau_s, nu_s).cpu().numpy()
+    trh, rfh, prh = tr.cpu().numpy().view(np.uint32), rf.cpu().numpy().view(np.uint32), pr.cpu().numpy()
+    cores = os.cpu_count() or 1
+    want_n, want_g = co.dm_prior(trh, prh, h_s, want_grad=True, nthreads=cores)
+    want_r = co.dm_ref(trh, rfh, h_s, tau_s, nu_s, nthreads=cores)
+    sub_n = sub_n.cpu().numpy()
+    mass_n = float(co.dm_prior_mass(trh, prh, h_s, nthreads=cores)[0])       # L1 masses: the scale a gradient's rounding errors live on
+    mass_r = co.dm_ref_mass(trh, rfh, h_s, tau_s, nu_s, nthreads=cores)
+    gerr = float(np.abs(grad.cpu().numpy() - want_g).max() / np.abs(want_g).max())
+    nbytes = {"net": plan_n.nbytes / n, "ref": plan_r.nbytes / n}
+    return {"contexts": n, "distribution": "synth_counts(dense=True): row rate lambda = 1e4 ... 3e5 (SURVEY section 8d), counts up to ~3e5",
+            "plan_build_s": build_s, "plan_bytes_per_context": nbytes,
+            "mode_N": {"kernel_ms": ms_n, "contexts_per_s": n / (ms_n * 1e-3), "credited_GBps_at_60_B": n * 60 / (ms_n * 1e-3) / 1e9,
+                       "frac_credited": n * 60 / (ms_n * 1e-3) / 1e9 / 8000.0, "unplanned_kernel_ms": ms_u},
+            "mode_N_with_gradient_rows": {"kernel_ms": ms_g, "contexts_per_s": n / (ms_g * 1e-3)},
+            "mode_R": {"kernel_ms": ms_r, "contexts_per_s": n / (ms_r * 1e-3)},
+            "check": {"planned_vs_unplanned_elbo_rel": float(abs(got_n[0] - got_u[0]) / abs(got_u[0])),
+                      "planned_vs_unplanned_dh_rel": float(abs(got_n[1] - got_u[1]) / abs(got_u[1])),
+                      "oracle_rows": m, "mode_N_elbo_rel_err": float(abs(sub_n[0] - want_n[0]) / abs(want_n[0])),
+                      "mode_N_dh_err_over_l1_mass": float(abs(sub_n[1] - want_n[1]) / mass_n),
+                      "gradient_rows_max_err_over_largest": gerr,
+                      "mode_R_elbo_rel_err": float(abs(sub_r[0] - want_r[0]) / abs(want_r[0])),
+                      "mode_R_grad_max_err_over_l1_mass": float((np.abs(sub_r[1:] - want_r[1:]) / mass_r).max()),
+                      "note": "the whole table: planned == unplanned kernels; the first oracle_rows rows: HIP == oracle/bear_oracle.c"}}
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    dev = torch.device("cuda", 0)
+    if what in ("configs", "all"):
+        print(json.dumps(measure_configs(dev), indent=1))
+    if what in ("dense", "all"):
+        print(json.dumps(measure_dense(dev), indent=1))

@@ -96,3 +96,68 @@ def test_config3_full_size_on_one_gpu_equals_its_eight_shards():
         tr, rf = t["train"][r * n:(r + 1) * n], t["ref"][r * n:(r + 1) * n]
         parts += kernels.dm_ref_planned(kernels.Plan(tr, 4, ref=rf), rf, *args).cpu().numpy()
     assert np.all(np.isfinite(whole)) and np.allclose(parts, whole, rtol=1e-12)
+
+
+def test_dense_full_size():
+    """SURVEY section 8d's dense stress distribution (lambda = 1e4 ... 3e5: what the reference's only real table, data/ysd1_*.tsv, looks
+    like) at 1e7 rows: every item takes the Stirling path and the in-tile large-count lists overflow to the plan's global lists.
+    The planned kernels == the unplanned ones on the whole table (modes N and R, gradient rows both ways), and a chunk from the
+    middle of the table == oracle/bear_oracle.c (through a plan of its own)."""
+    import torch
+    from bear_amd import kernels
+    dev = torch.device("cuda", 0)
+    n = 10_000_000
+    t = kernels.synth_counts(20211012, 0, n, dev, dense=True, want=("train", "ref"))
+    assert int(t["train"].max()) > 50_000                      # the large-count branch, not the product path
+    prior = kernels.synth_prior(20211012, 0, n, dev)
+    args = (-0.3, float(np.log(1 / 30)), float(-np.log(100)))
+    plan_n = kernels.Plan(t["train"], 5)
+    got, grad = kernels.dm_prior_planned(plan_n, prior, args[0], want_grad=True)
+    got_a, grad_a = kernels.dm_prior_planned(plan_n, prior, args[0], want_grad=True, normalized=True)
+    plain, grad_u = kernels.dm_prior(t["train"], prior, args[0], want_grad=True)
+    for a in (got, got_a):
+        assert torch.allclose(a, plain, rtol=1e-11, atol=0), (a, plain)
+    scale = float(grad_u.abs().max())
+    assert float((grad - grad_u).abs().max()) <= 1e-10 * scale and float((grad_a - grad_u).abs().max()) <= 1e-10 * scale
+    del grad, grad_a, grad_u
+    got_r = kernels.dm_ref_planned(kernels.Plan(t["train"], 4, ref=t["ref"]), t["ref"], *args)
+    stream_r = kernels.dm_ref_planned(kernels.Plan(t["train"], 4), t["ref"], *args)
+    plain_r = kernels.dm_ref(t["train"], t["ref"], *args)
+    assert torch.allclose(got_r, plain_r, rtol=1e-10, atol=0) and torch.allclose(stream_r, plain_r, rtol=1e-10, atol=0), (got_r, stream_r, plain_r)
+    lo, m = 4_000_004, 1_000_000
+    tr, rf, pr = (x[lo:lo + m].contiguous() for x in (t["train"], t["ref"], prior))
+    sub, g = kernels.dm_prior_planned(kernels.Plan(tr, 5), pr, args[0], want_grad=True)
+    sub_r = kernels.dm_ref_planned(kernels.Plan(tr, 4, ref=rf), rf, *args).cpu().numpy()
+    trh, rfh = tr.cpu().numpy().view(np.uint32), rf.cpu().numpy().view(np.uint32)
+    want, want_g = co.dm_prior(trh, pr.cpu().numpy(), args[0], want_grad=True, nthreads=min(os.cpu_count() or 4, 64))
+    want_r = co.dm_ref(trh, rfh, *args, nthreads=min(os.cpu_count() or 4, 64))
+    sub = sub.cpu().numpy()
+    mass = float(co.dm_prior_mass(trh, pr.cpu().numpy(), args[0], nthreads=min(os.cpu_count() or 4, 64))[0])   # L1 mass of d/dh: its error scale
+    assert abs(sub[0] - want[0]) <= 1e-10 * abs(want[0]) and abs(sub[1] - want[1]) <= 1e-11 * mass, (sub, want, mass)
+    assert np.abs(g.cpu().numpy() - want_g).max() <= 1e-9 * np.abs(want_g).max()
+    assert abs(sub_r[0] - want_r[0]) <= 1e-10 * abs(want_r[0]), (sub_r, want_r)
+    mass_r = co.dm_ref_mass(trh, rfh, *args, nthreads=min(os.cpu_count() or 4, 64))
+    assert np.all(np.abs(sub_r[1:] - want_r[1:]) <= 1e-11 * mass_r), (sub_r, want_r, mass_r)
+
+
+def test_baseline_configs_module_small():
+    """scripts/baseline_configs.py (bench.py's also.baseline_configs / also.dense_table) at 1/50 of the configs' sizes: every config
+    steps through its host driver's own loop, the loop reports its event-timed steps, the dense table's checks hold."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import baseline_configs
+    dev = torch.device("cuda", 0)
+    out = baseline_configs.measure_configs(dev, shrink=50)
+    ents = [v for k, v in out.items() if k.startswith("configs[")]
+    assert len(ents) == 4
+    for e in ents:
+        assert e["us_per_step"] > 0 and e["steps_timed"] > 0 and np.isfinite(e["elbo_last_step"])
+        assert e["elbo_last_step"] > e["elbo_first_step"]                 # the logged scalar is the ELBO: the optimizer raises it
+        assert abs(e["contexts_per_s"] - e["rows"] / (e["us_per_step"] * 1e-6)) <= 1e-6 * e["contexts_per_s"]
+    cnn = [v for k, v in out.items() if "configs[4]" in k][0]
+    assert 1.0 < cnn["heldout_perplexity_bear"] < 6.0
+    d = baseline_configs.measure_dense(dev, n=1_000_000, check_rows=200_000)
+    c = d["check"]
+    assert c["planned_vs_unplanned_elbo_rel"] <= 1e-11 and c["mode_N_elbo_rel_err"] <= 1e-10 and c["mode_R_elbo_rel_err"] <= 1e-10
+    assert c["gradient_rows_max_err_over_largest"] <= 1e-9 and c["mode_N_dh_err_over_l1_mass"] <= 1e-11 and c["mode_R_grad_max_err_over_l1_mass"] <= 1e-11

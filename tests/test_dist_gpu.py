@@ -261,8 +261,19 @@ def test_bench_bare_command_starts_its_own_ranks(scaling):
     d = json.loads(lines[0])
     total = n if scaling == "strong" else n * MANY
     assert d["n_gpus"] == MANY and d["scaling"] == scaling and d["steps"] == 6 and d["config"]["contexts_total"] == total
-    assert d["ranks"] == {"world_size": MANY, "backend": "gloo", "launcher": "self", "devices": [0] * MANY}
+    assert d["ranks"] == {"world_size": MANY, "backend": "gloo", "launcher": "self", "devices": [0] * MANY,
+                          "backend_is_rccl": False, "devices_distinct": False}       # (the line says what it ran on: one card, gloo)
     assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    ss = d["also"].get("strong_scaling")
+    if scaling == "weak":        # a weak run of N ranks also times the strong split of ONE --contexts table
+        assert ss["scaling"] == "strong" and ss["contexts_total"] == n and len(ss["per_rank"]) == MANY
+        assert sum(r["contexts"] for r in ss["per_rank"]) == n
+        assert abs(ss["value"] - n / (ss["ms_per_step"] * 1e-3)) <= 1e-6 * ss["value"]
+        t1 = kernels.synth_counts(20211012, 0, n, torch.device("cuda", 0), want=("train",))["train"]
+        w1 = kernels.dm_prior_planned(kernels.Plan(t1, 5), kernels.synth_prior(20211012, 0, n, torch.device("cuda", 0)), 0.0).cpu().numpy()
+        assert np.allclose(ss["result"], w1, rtol=1e-12), (ss["result"], w1)
+    else:
+        assert ss is None
     dev = torch.device("cuda", 0)
     t = kernels.synth_counts(20211012, 0, total, dev, want=("train",))["train"]
     want = kernels.dm_prior_planned(kernels.Plan(t, 5), kernels.synth_prior(20211012, 0, total, dev), 0.0).cpu().numpy()
@@ -273,7 +284,8 @@ def test_bench_single_rank_line_is_consistent():
     """bench.py as the driver runs it at N = 1 (small table): one JSON line whose roofline object follows from its own
     kernel time, with the 'also' entries of the other kernels in it."""
     n = 3_000_000
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3", "--contexts", str(n), "--no-cpu-baseline"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "3", "--contexts", str(n), "--no-cpu-baseline",
+                        "--no-baseline-configs"],      # (those run at the configs' own sizes: tests/test_config_shards_gpu.py covers the module)
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-6000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
