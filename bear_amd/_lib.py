@@ -13,9 +13,17 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("BEAR_AMD_LIB") or os.path.join(_HERE, "libbear_hip.so")  # env: developer A/B builds
+def _deterministic_requested():
+    v = os.environ.get("BEAR_AMD_DETERMINISTIC", "")
+    return bool(v) and v != "0"
 
-ABI_VERSION = 4   # BEAR_ABI_VERSION of include/bear_hip.h the argtypes below were written against
+
+# BEAR_AMD_DETERMINISTIC set when the package is first used: the deterministic build of the same sources (libbear_hip_det.so:
+# every sum of a launch bit-identical from run to run, include/bear_hip.h).  Set later, the regular library still switches its
+# parameter gradients over per call; BEAR_AMD_LIB: developer A/B builds.
+LIB_PATH = os.environ.get("BEAR_AMD_LIB") or os.path.join(_HERE, "libbear_hip_det.so" if _deterministic_requested() else "libbear_hip.so")
+
+ABI_VERSION = 5   # BEAR_ABI_VERSION of include/bear_hip.h the argtypes below were written against
 
 SYMBOLS = [
     "bear_abi_version", "bear_strerror", "bear_last_hip_error", "bear_ws_create", "bear_ws_destroy",
@@ -29,6 +37,7 @@ SYMBOLS = [
     "bear_shard_rows_count", "bear_parse_counts_tsv_shard",
     "bear_kmer_sort_create", "bear_kmer_sort_reduce", "bear_kmer_sort_destroy", "bear_count_last_hip_error", "bear_write_counts_tsv", "bear_fastx_size", "bear_fastx_encode",
     "bear_kmer_order_u64", "bear_gather_rows", "bear_plan_pair_contexts", "bear_plan_pair_info", "bear_plan_attach_cnn_levels", "bear_plan_cnn_level_rows", "bear_cnn_forward_plan_f64",
+    "bear_plan_count_total", "bear_plan_set_count_bound", "bear_deterministic_build",
 ]
 
 
@@ -136,6 +145,8 @@ def _load():
     L.bear_cnn_forward_plan_f64.argtypes = [vp, vp, vp, u64, cint, cint, cint, cint, vp, vp, vp, vp]
     L.bear_plan_attach_cnn_levels.argtypes = [vp, vp, cint, cint, ctypes.POINTER(cint), vp]
     L.bear_plan_pair_info.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.bear_plan_count_total.argtypes = [vp, ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
+    L.bear_plan_set_count_bound.argtypes = [vp, ctypes.POINTER(dbl)]
     L.bear_plan_pair_contexts.argtypes = [vp, vp, cint, ctypes.POINTER(cint), vp]
     L.bear_kmer_order_u64.argtypes = [vp, u64, cint, vp, vp, ctypes.POINTER(u64), vp]
     L.bear_gather_rows.argtypes = [vp, vp, vp, u64, ctypes.c_uint32, vp]

@@ -449,6 +449,12 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
     return (loss_buf[:n_steps] / acc_steps).cpu().tolist()
 
 
+def deterministic():
+    """BEAR_AMD_DETERMINISTIC=1: parameter gradients bit-identical from run to run (include/bear_hip.h)."""
+    v = os.environ.get("BEAR_AMD_DETERMINISTIC", "")
+    return bool(v) and v != "0"
+
+
 def live_rows(e, *columns, by="train"):
     """Row indices of a resident batch's contexts that hold counts in column ``by`` (cached in the batch entry, together with the
     gathered ``columns`` as ``<name>_live_<by>``), or None when (nearly) all of them do.  An AR function made of torch ops only has

@@ -77,6 +77,14 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
             if e["rows"] == 0:
                 return lambda packed: packed.zero_()
             plan = res.plan(k, "train", 5)           # built here, before any capture (plan creation allocates and synchronises)
+            if _train.deterministic() and fused_mat is not None:
+                # BEAR_AMD_DETERMINISTIC: the fixed-point scale of the linear step's gradient tables follows from the counts of the
+                # WHOLE batch -- every rank's piece -- so that d/d mat does not depend on the number of ranks (include/bear_hip.h)
+                own = plan.count_total()[0]
+                tot, cmax = torch.tensor(own[:2], dtype=torch.float64, device=device), torch.tensor(own[2:], dtype=torch.float64, device=device)
+                dist.allreduce_sum_(tot)
+                dist.allreduce_max_(cmax)
+                plan.set_count_bound(tot.tolist() + cmax.tolist())
             if fused_mat is not None and packs[k].data_ptr() % 16 == 0:
                 # neighbours of the sorted batch that share all letters but the last three go through the step two at a time
                 # (kernels_linear.h, paired lists); declined by the library for tables too sparse to gain from it

@@ -313,6 +313,39 @@ __global__ __launch_bounds__(256) void level_compact_kernel(const unsigned long 
 }
 }  // namespace
 
+namespace {
+struct rec16 { unsigned long long a, b; };
+struct rec16_less {
+  __device__ __host__ bool operator()(const rec16 &x, const rec16 &y) const { return x.a < y.a || (x.a == y.a && x.b < y.b); }
+};
+template <typename T, typename Less>
+int canonical_sort(T *d, uint64_t n, Less less, hipStream_t s) {
+  int st = BEAR_OK;
+  void *temp = nullptr;
+  size_t tb = 0;
+  T *out = nullptr;
+  CNT_TRY(hipMalloc(&out, n * sizeof(T)));
+  CNT_TRY(rocprim::merge_sort(nullptr, tb, d, out, n, less, s));
+  CNT_TRY(hipMalloc(&temp, tb ? tb : 8));
+  CNT_TRY(rocprim::merge_sort(temp, tb, d, out, n, less, s));
+  CNT_TRY(hipMemcpyAsync(d, out, n * sizeof(T), hipMemcpyDeviceToDevice, s));
+  CNT_TRY(hipStreamSynchronize(s));
+done:
+  if (temp) (void)hipFree(temp);
+  if (out) (void)hipFree(out);
+  return st;
+}
+}  // namespace
+
+int bear_canonical_order(void *records, uint64_t n, int width, hipStream_t s) {
+  if (n < 2) return BEAR_OK;
+  if (!records) return BEAR_ERR_INVALID_ARG;
+  if (width == 16) return canonical_sort(static_cast<rec16 *>(records), n, rec16_less(), s);
+  if (width == 8) return canonical_sort(static_cast<unsigned long long *>(records), n, rocprim::less<unsigned long long>(), s);
+  if (width == 4) return canonical_sort(static_cast<uint32_t *>(records), n, rocprim::less<uint32_t>(), s);
+  return BEAR_ERR_INVALID_ARG;
+}
+
 void bear_level_free(bear_level_dev *lv) {
   if (!lv) return;
   (void)hipFree(lv->codes);

@@ -88,10 +88,14 @@ int bear_ws_create(int device, bear_ws **out) {
       if (e == hipSuccess) e = hipMalloc(&ws->arrive, sizeof(unsigned long long));
       if (e == hipSuccess) e = hipMemset(ws->arrive, 0, sizeof(unsigned long long));
       ws->epoch = 0;
-      for (const void *fn : {reinterpret_cast<const void *>(dm_linear_plan_kernel<false, false>),
-                             reinterpret_cast<const void *>(dm_linear_plan_kernel<true, false>),
-                             reinterpret_cast<const void *>(dm_linear_plan_kernel<false, true>),
-                             reinterpret_cast<const void *>(dm_linear_plan_kernel<true, true>)})
+      for (const void *fn : {reinterpret_cast<const void *>(dm_linear_plan_kernel<false, false, false>),
+                             reinterpret_cast<const void *>(dm_linear_plan_kernel<true, false, false>),
+                             reinterpret_cast<const void *>(dm_linear_plan_kernel<false, true, false>),
+                             reinterpret_cast<const void *>(dm_linear_plan_kernel<true, true, false>),
+                             reinterpret_cast<const void *>(dm_linear_plan_kernel<false, false, true>),
+                             reinterpret_cast<const void *>(dm_linear_plan_kernel<true, false, true>),
+                             reinterpret_cast<const void *>(dm_linear_plan_kernel<false, true, true>),
+                             reinterpret_cast<const void *>(dm_linear_plan_kernel<true, true, true>)})
         if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_lin));
       if (e == hipSuccess) {
         // {r_i, -log r_i}: r_i = 1 / midpoint of the i-th mantissa cell of [0.5, 1) (bear_log_tab)
@@ -188,6 +192,25 @@ int bear_ws_destroy(bear_ws *ws) {
 static bear_arrival ws_arrival(bear_ws *ws) {
   if (++ws->epoch == 0u) ws->epoch = 1u;
   return bear_arrival{ws->arrive, ws->epoch};
+}
+
+// BEAR_AMD_DETERMINISTIC=1: parameter gradients that are bit-identical from run to run (kernels_linear.h: fixed-point gradient
+// tables; cnn_backward_grid: one wave per block).  Read per call: a process may switch it between steps (tests).
+static bool bear_deterministic() {
+#ifdef BEAR_DET_BUILD      // libbear_hip_det.so: everything deterministic, always (kernels_plan.h, PLN_FOR_UNITS)
+  return true;
+#else
+  const char *e = getenv("BEAR_AMD_DETERMINISTIC");
+  return e && e[0] && e[0] != '0';
+#endif
+}
+
+int bear_deterministic_build(void) {
+#ifdef BEAR_DET_BUILD
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 static bear_step_io ws_io(bear_ws *ws, const double *theta, int kind, double *out) {
@@ -319,6 +342,8 @@ struct bear_plan {
   uint64_t n_tiles;
   uint64_t n_heavy[3];
   uint64_t n_live_rows;      // five-column plans: contexts that hold any count (the kernels that walk `live` skip the lists when all do)
+  double count_total[3];     // of the table (all five columns): sum of all counts, cells that hold one, largest count
+  double count_bound[3];     // the same of everything that is added into one gradient (bear_plan_set_count_bound; default: count_total)
   uint64_t bytes;
   // bear_plan_pair_contexts: the paired form of `live` for the index words at pair_codes (kernels_linear.h), and the plan's
   // tiles sorted into those that took it (tiles_p) and those that keep their plain list (tiles_u), each followed by PLN_DESC_PAD
@@ -390,19 +415,21 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   // ---- pass A: product-path items per group of 4 contexts, heavy counts, histograms
   const uint64_t n_quads = (n_rows + PLN_QUAD - 1) / PLN_QUAD;
   uint8_t *d_quad = nullptr, *h_quad = nullptr;
-  unsigned long long *d_cnt = nullptr;  // [0..2] heavy counts, [3..5] fill cursors
+  unsigned long long *d_cnt = nullptr;  // [0..2] heavy counts, [3..5] fill cursors, [6..8] sum of all counts, cells that hold one, largest count
   std::vector<pln_tile> tiles;
   e = hipMalloc(&d_quad, 3 * n_quads);
-  if (e == hipSuccess) e = hipMalloc(&d_cnt, sizeof(unsigned long long) * 6);
-  if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(unsigned long long) * 6);
+  if (e == hipSuccess) e = hipMalloc(&d_cnt, sizeof(unsigned long long) * 9);
+  if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof(unsigned long long) * 9);
   if (e == hipSuccess) {
     uint64_t gb = (n_quads + 255) / 256;
     const int grid = (int)(gb < (uint64_t)ws->num_cu * 8 ? gb : (uint64_t)ws->num_cu * 8);
     hipLaunchKernelGGL(plan_scan_kernel, dim3(grid), dim3(256), 0, 0, counts, n_rows, ncol, d_quad, d_cnt, p->hist);
     e = hipGetLastError();
   }
-  unsigned long long h_cnt[3] = {0, 0, 0};
+  unsigned long long h_cnt[3] = {0, 0, 0}, h_total[3] = {0, 0, 0};
   if (e == hipSuccess) e = hipMemcpy(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(h_total, d_cnt + 6, sizeof(h_total), hipMemcpyDeviceToHost);
+  for (int k = 0; k < 3; ++k) p->count_total[k] = p->count_bound[k] = (double)h_total[k];
   // ---- tiles: greedy cut so that a tile holds <= PLN_NI items and <= PLN_RMAX contexts -- on the device (plan_cut_*_kernel);
   // BEAR_PLAN_CUT=host keeps the sequential host loop over the per-group counters (the definition; used by the tests to compare)
   uint64_t off16 = 0, n_tiles = 0;
@@ -519,6 +546,14 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   unsigned long long h_used[3] = {0, 0, 0};  // entries that actually went to the global lists
   if (e == hipSuccess) e = hipMemcpy(h_used, d_cnt + 3, sizeof(h_used), hipMemcpyDeviceToHost);
   for (int k = 0; k < 3; ++k) p->n_heavy[k] = h_used[k];
+#ifdef BEAR_DET_BUILD      // the global lists were filled through atomic cursors: canonical order (bear_levels.h)
+  if (e == hipSuccess) {
+    int cst = bear_canonical_order(p->heavy_col, h_used[0], 16, 0);
+    if (cst == BEAR_OK) cst = bear_canonical_order(p->heavy_row, h_used[1], 16, 0);
+    if (cst == BEAR_OK) cst = bear_canonical_order(p->heavy_stop, h_used[2], 8, 0);
+    if (cst != BEAR_OK) e = cst == BEAR_ERR_NOMEM ? hipErrorOutOfMemory : hipErrorUnknown;
+  }
+#endif
   p->n_live_rows = n_rows;
   if (e == hipSuccess && ncol == 5) {        // rows with a total of 1..SRT_CL (histogram) + rows with a larger one
     unsigned long long h_hist[SRT_NKEY];
@@ -618,6 +653,11 @@ int bear_plan_create_ref(bear_ws *ws, const uint32_t *train, const uint32_t *ref
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
+#ifdef BEAR_DET_BUILD      // the records of a bucket stand in the order of the blocks' cursor bumps: canonical order per bucket
+    for (int k = 0; k < RPL_NKEY && e == hipSuccess; ++k)
+      if (bear_canonical_order(p->ref_items + cur[k], h_meta[k], 16, 0) != BEAR_OK) e = hipErrorUnknown;
+    if (e == hipSuccess && bear_canonical_order(p->heavy0, p->n_heavy0, 4, 0) != BEAR_OK) e = hipErrorUnknown;
+#endif
   }
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
@@ -980,9 +1020,17 @@ static void launch_linear(bear_ws *ws, const bear_plan *plan, const uint64_t *km
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const unsigned long long *kc = reinterpret_cast<const unsigned long long *>(kmer_code);
   const bool paired = plan->live2 && plan->pair_codes == kmer_code && plan->pair_lag == lag && !getenv("BEAR_AMD_LINEAR_UNPAIRED");
-#define LIN_LAUNCH(AR, PAIRED, PV, NT, ACC)                                                                                             \
-  hipLaunchKernelGGL((dm_linear_plan_kernel<AR, PAIRED>), dim3(grid_plan(ws, NT)), dim3(PLN_THREADS), sizeof(pln_lds_lin), s, kc, mat,  \
-                     lag, prm, PV, lt, ws->partials, ws->lin_partials, (ACC) ? io2 : io, grad_mat, ACC)
+  // BEAR_AMD_DETERMINISTIC: fixed-point gradient tables (kernels_linear.h, lin_fx); the kernel derives their scale from these bounds
+  const bool det = bear_deterministic() && plan->count_bound[0] >= 1.0 && plan->count_bound[0] < 0x1p50;
+  const lin_fx_bound gt_bound = {plan->count_bound[0], plan->count_bound[1], log(plan->count_bound[2] > 1.0 ? plan->count_bound[2] : 1.0)};
+#define LIN_LAUNCH_D(AR, PAIRED, DET, PV, NT, ACC)                                                                                          \
+  hipLaunchKernelGGL((dm_linear_plan_kernel<AR, PAIRED, DET>), dim3(grid_plan(ws, NT)), dim3(PLN_THREADS), sizeof(pln_lds_lin), s, kc, mat, \
+                     lag, prm, PV, lt, ws->partials, ws->lin_partials, (ACC) ? io2 : io, grad_mat, ACC, gt_bound)
+#define LIN_LAUNCH(AR, PAIRED, PV, NT, ACC)                    \
+  do {                                                         \
+    if (det) LIN_LAUNCH_D(AR, PAIRED, true, PV, NT, ACC);      \
+    else LIN_LAUNCH_D(AR, PAIRED, false, PV, NT, ACC);         \
+  } while (0)
   bear_step_io io2 = io;      // the second launch of a step: its own stamp on the arrival word
   io2.epoch = ws_arrival(ws).epoch;
   pln_view pv = plan_view(plan);
@@ -1007,6 +1055,7 @@ static void launch_linear(bear_ws *ws, const bear_plan *plan, const uint64_t *km
   if (train_ar) LIN_LAUNCH(true, false, pu, plan->n_tiles_u, 1);
   else LIN_LAUNCH(false, false, pu, plan->n_tiles_u, 1);
 #undef LIN_LAUNCH
+#undef LIN_LAUNCH_D
 }
 
 static void plan_unpair(bear_plan *plan) {
@@ -1103,6 +1152,23 @@ int bear_plan_pair_contexts(bear_plan *plan, const uint64_t *kmer_index, int lag
   plan->pair_lag = lag;
   plan->bytes += nt * LIN_LIVE2_STRIDE * sizeof(uint16_t) + (nt + 2 * PLN_DESC_PAD) * sizeof(pln_tile);
   if (paired) *paired = 1;
+  return BEAR_OK;
+}
+
+int bear_plan_count_total(const bear_plan *plan, double *total, double *bound) {
+  if (!plan) return BEAR_ERR_INVALID_ARG;
+  for (int k = 0; k < 3; ++k) {
+    if (total) total[k] = plan->count_total[k];
+    if (bound) bound[k] = plan->count_bound[k];
+  }
+  return BEAR_OK;
+}
+
+int bear_plan_set_count_bound(bear_plan *plan, const double *bound) {
+  if (!plan || !bound) return BEAR_ERR_INVALID_ARG;
+  for (int k = 0; k < 3; ++k)
+    if (!(bound[k] >= plan->count_total[k]) || !(bound[k] < 0x1p50)) return BEAR_ERR_INVALID_ARG;
+  for (int k = 0; k < 3; ++k) plan->count_bound[k] = bound[k];
   return BEAR_OK;
 }
 
@@ -1590,21 +1656,26 @@ int bear_cnn_forward_f64(bear_ws *ws, const uint64_t *kmer_code, uint64_t n_rows
 
 // sizes the block-partial buffer of the CNN backward pass; returns the grid.  With may_alloc == 0 (inside a stream capture) a
 // buffer that is too small is an error: call bear_cnn_reserve first.
-static int cnn_backward_grid(bear_ws *ws, const cnn_dims &D, uint64_t n_rows, int filter_width, int *waves_out, size_t *lds_out,
-                             uint64_t *blocks_out, hipStream_t s, int may_alloc) {
+static int cnn_backward_grid(bear_ws *ws, const cnn_dims &D, uint64_t n_rows, int filter_width, int *waves_out, int *parts_out,
+                             size_t *lds_out, uint64_t *blocks_out, hipStream_t s, int may_alloc) {
   const size_t fixed = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (size_t)((D.total + 1) & ~1));
   // cnn_backward_parts_kernel<2>: two lanes per context, eight waves of 32-context tiles (two per SIMD), when the staging fits
   // next to the filter, parameter and gradient images (every reference config); otherwise 64-context tiles, one wave per SIMD.
   // `waves` names the form (8 / <= 4).  BEAR_CNN_BACKWARD=1 forces the second form (developer A/B runs, tests).
   const size_t lds2 = sizeof(double) * (cnnq_fixed_doubles(D) + (size_t)cnnq<2>::WAVES * cnnq<2>::WAVE_DOUBLES);
   const char *force = getenv("BEAR_CNN_BACKWARD");
-  int waves = 4;
+  // BEAR_AMD_DETERMINISTIC: ONE wave per block.  The block's gradient image takes LDS floating-point atomics from all its waves,
+  // in whatever order they get there; with one wave the adds happen in program order, the blocks' images are summed in a fixed
+  // order anyway (cnn_finalize_kernel) -- two runs of a step are bit-identical, at an eighth of the waves per CU.
+  const bool det = bear_deterministic();
+  int waves = det ? 1 : 4, parts = 0;
   while (waves > 1 && fixed + (size_t)waves * CNN_WAVE_DOUBLES * sizeof(double) > 160u * 1024u) waves >>= 1;
   size_t lds = fixed + (size_t)waves * CNN_WAVE_DOUBLES * sizeof(double);
   uint64_t per_block = (uint64_t)64 * waves;
   if (lds2 <= 160u * 1024u && !(force && force[0] == '1')) {
-    waves = cnnq<2>::WAVES;
-    lds = lds2;
+    parts = 1;
+    waves = det ? 1 : cnnq<2>::WAVES;
+    lds = sizeof(double) * (cnnq_fixed_doubles(D) + (size_t)waves * cnnq<2>::WAVE_DOUBLES);
     per_block = (uint64_t)cnnq<2>::TILE * waves;
   }
   if (lds > 160u * 1024u) return BEAR_ERR_INVALID_ARG;
@@ -1622,6 +1693,7 @@ static int cnn_backward_grid(bear_ws *ws, const cnn_dims &D, uint64_t n_rows, in
     ws->cnn_partials_cap = need;
   }
   *waves_out = waves;
+  *parts_out = parts;
   *lds_out = lds;
   *blocks_out = blocks;
   return BEAR_OK;
@@ -1631,12 +1703,12 @@ static int cnn_backward_grid(bear_ws *ws, const cnn_dims &D, uint64_t n_rows, in
 static int launch_cnn_backward(bear_ws *ws, const cnn_dims &D, const uint64_t *kmer_code, uint64_t n_rows, int filter_width,
                                const double *params, const double *t1_save, const double *prior, const double *grad_prior,
                                double *grad_params, hipStream_t s, int may_alloc, const bear_plan *live_plan = nullptr) {
-  int waves = 0;
+  int waves = 0, parts = 0;
   size_t lds = 0;
   uint64_t blocks = 0;
-  int st = cnn_backward_grid(ws, D, n_rows, filter_width, &waves, &lds, &blocks, s, may_alloc);
+  int st = cnn_backward_grid(ws, D, n_rows, filter_width, &waves, &parts, &lds, &blocks, s, may_alloc);
   if (st != BEAR_OK) return st;
-  const bool parts2 = waves == cnnq<2>::WAVES;
+  const bool parts2 = parts != 0;
   const void *fn = parts2 ? reinterpret_cast<const void *>(cnn_backward_parts_kernel<2>) : reinterpret_cast<const void *>(cnn_backward_kernel);
   if (may_alloc) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const unsigned long long *kc = reinterpret_cast<const unsigned long long *>(kmer_code);
@@ -1671,12 +1743,12 @@ int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, in
   int st = cnn_check(ws, lag, filter_width, num_filters, layer1_width);
   if (st != BEAR_OK) return st;
   const cnn_dims D = cnn_make_dims(lag, filter_width);
-  int waves = 0;
+  int waves = 0, parts = 0;
   size_t lds = 0;
   uint64_t blocks = 0;
-  st = cnn_backward_grid(ws, D, n_rows, filter_width, &waves, &lds, &blocks, nullptr, 1);
+  st = cnn_backward_grid(ws, D, n_rows, filter_width, &waves, &parts, &lds, &blocks, nullptr, 1);
   if (st != BEAR_OK) return st;
-  HIP_TRY(hipFuncSetAttribute(waves == cnnq<2>::WAVES ? reinterpret_cast<const void *>(cnn_backward_parts_kernel<2>)
+  HIP_TRY(hipFuncSetAttribute(parts ? reinterpret_cast<const void *>(cnn_backward_parts_kernel<2>)
                                                       : reinterpret_cast<const void *>(cnn_backward_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   return BEAR_OK;
@@ -1708,12 +1780,12 @@ static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn
                                    double *packed, hipStream_t s) {
   const int K = plan->n_cnn_levels;
   const double *params = theta + 1;
-  int bw_waves = 0;
+  int bw_waves = 0, bw_parts = 0;
   size_t bw_lds = 0;
   uint64_t bw_blocks = 0;
-  int st = cnn_backward_grid(ws, D, n_rows, D.fw, &bw_waves, &bw_lds, &bw_blocks, s, 0);
+  int st = cnn_backward_grid(ws, D, n_rows, D.fw, &bw_waves, &bw_parts, &bw_lds, &bw_blocks, s, 0);
   if (st != BEAR_OK) return st;
-  if (bw_waves != cnnq<2>::WAVES) return BEAR_ERR_INVALID_ARG;      // (attach refuses shapes whose staging does not fit: not reached)
+  if (!bw_parts) return BEAR_ERR_INVALID_ARG;      // (attach refuses shapes whose staging does not fit: not reached)
   auto level_codes = [&](int k) { return k == 0 ? reinterpret_cast<const unsigned long long *>(kmer_code) : plan->cnn_levels[k - 1].codes; };
   auto level_rows = [&](int k) { return k == 0 ? n_rows : plan->cnn_levels[k - 1].n; };
   auto level_table = [&](int k) { return k == 0 ? t1_buf : plan->cnn_levels[k - 1].rows; };
@@ -1736,12 +1808,12 @@ static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn
                          n, level_table(k));
     }
     io.dT1 = (k == 0 && K > 0) ? t1_buf : (k > 0 ? level_table(k) : nullptr);   // level 0 leaves its dT1 rows where its t1 rows were
-    const uint64_t per_block = (uint64_t)cnnq<2>::TILE * cnnq<2>::WAVES;
+    const uint64_t per_block = (uint64_t)cnnq<2>::TILE * (uint64_t)bw_waves;
     uint64_t blocks = (n + per_block - 1) / per_block;
     if (blocks > bw_blocks) blocks = bw_blocks;
     if (blocks == 0) blocks = 1;
     if (k == 0) blocks = bw_blocks;      // the first launch writes every row of the partial buffer the finalize reads
-    hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)blocks), dim3(64 * cnnq<2>::WAVES), bw_lds, s, level_codes(k), n, D, params,
+    hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)blocks), dim3(64 * bw_waves), bw_lds, s, level_codes(k), n, D, params,
                        t1_buf, prior_buf, grad_rows_buf, ws->cnn_partials, static_cast<const pln_tile *>(nullptr),
                        static_cast<const uint16_t *>(nullptr), (n + cnnq<2>::TILE - 1) / cnnq<2>::TILE, io);
   }
@@ -1872,12 +1944,12 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
     const size_t lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)filter_width * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);
     // only the contexts that hold training counts: the DM kernel reads nobody else's prior row (their gradient rows are zero).
     // Only together with the backward kernel that walks the same lists (shapes whose LDS does not fit take all rows in both).
-    int bw_waves = 0;
+    int bw_waves = 0, bw_parts = 0;
     size_t bw_lds = 0;
     uint64_t bw_blocks = 0;
-    st = cnn_backward_grid(ws, D, n_rows, filter_width, &bw_waves, &bw_lds, &bw_blocks, s, 0);
+    st = cnn_backward_grid(ws, D, n_rows, filter_width, &bw_waves, &bw_parts, &bw_lds, &bw_blocks, s, 0);
     if (st != BEAR_OK) return st;
-    const bool lists = plan->live && bw_waves == cnnq<2>::WAVES && plan->n_live_rows < n_rows;   // all rows live: plain groups of rows
+    const bool lists = plan->live && bw_parts && plan->n_live_rows < n_rows;   // all rows live: plain groups of rows
     const uint64_t groups = lists ? plan->n_tiles : (n_rows + 63) / 64;
     uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
     if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;

@@ -18,3 +18,8 @@ struct bear_level_dev {
 // order is still correct, a run is then one row).  Allocates out's arrays (the caller frees them); synchronises `stream`.
 int bear_level_build(const unsigned long long *codes_below, uint64_t n_below, int letters, bear_level_dev *out, hipStream_t stream);
 void bear_level_free(bear_level_dev *lv);
+
+// Deterministic build (-DBEAR_DET_BUILD): lists that were filled through atomic cursors, in whatever order the blocks got there,
+// are put into a canonical order -- records of `width` bytes (4, 8 or 16), ascending as unsigned integers (16: first word, then
+// second) -- so that the plan of a table is the same bits in every run.  Synchronises `stream`.
+int bear_canonical_order(void *records, uint64_t n, int width, hipStream_t stream);

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(CNN_THREADS, 4) void cnn_forward_kernel(const unsig
   extern __shared__ __attribute__((aligned(16))) double cnn_lds[];
   double *exptab = cnn_lds;                       // [128]
   double *Fs = cnn_lds + BEAR_EXPTAB_N;           // [fw][6][nf]
-  if (threadIdx.x < BEAR_EXPTAB_N) exptab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / BEAR_EXPTAB_N));
+  for (int k = threadIdx.x; k < BEAR_EXPTAB_N; k += blockDim.x) exptab[k] = exp2((double)k * (1.0 / BEAR_EXPTAB_N));   // (a block may be one wave)
   cnn_stage_filters(Fs, params, D);
   __syncthreads();
   // A wave walks groups of contexts, 64 at a time: without lists, group g = rows [64 g, 64 g + 64); with the plan's lists
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(CNN_THREADS) void cnn_backward_kernel(const unsigne
   double *E = G + ((D.total + 1) & ~1) + wave * CNN_WAVE_DOUBLES;   // [32][CNN_ES] staging
   double *T = E + CNN_E_DOUBLES;                                    // [16][CNN_ES] dT1
   unsigned long long *Cw = reinterpret_cast<unsigned long long *>(T + CNN_T_DOUBLES);   // [64] packed contexts
-  if (threadIdx.x < BEAR_EXPTAB_N) exptab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / BEAR_EXPTAB_N));
+  for (int k = threadIdx.x; k < BEAR_EXPTAB_N; k += blockDim.x) exptab[k] = exp2((double)k * (1.0 / BEAR_EXPTAB_N));   // (a block may be one wave)
   for (int k = threadIdx.x; k < D.fw * 6 * CNN_NF; k += blockDim.x) {
     const int w = k / (6 * CNN_NF), r = k - w * 6 * CNN_NF, a = r / CNN_NF, f = r - a * CNN_NF;
     Fs[k] = a < 5 ? params[D.oF + (w * 5 + a) * CNN_NF + f] : 0.0;
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
   double *T = E + C::E_DOUBLES;                                     // [16][ES] dT1
   unsigned long long *Cw = reinterpret_cast<unsigned long long *>(T + C::T_DOUBLES);   // [TILE] packed contexts
   double *Cy = T + C::T_DOUBLES + TILE;                                                // carried column sums and windows
-  if (threadIdx.x < BEAR_EXPTAB_N) exptab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / BEAR_EXPTAB_N));
+  for (int k = threadIdx.x; k < BEAR_EXPTAB_N; k += blockDim.x) exptab[k] = exp2((double)k * (1.0 / BEAR_EXPTAB_N));   // (a block may be one wave)
   for (int k = threadIdx.x; k < D.fw * 6 * CNN_NF; k += blockDim.x) {
     const int w = k / (6 * CNN_NF), r = k - w * 6 * CNN_NF, a = r / CNN_NF, f = r - a * CNN_NF;
     Fs[k] = a < 5 ? params[D.oF + (w * 5 + a) * CNN_NF + f] : 0.0;

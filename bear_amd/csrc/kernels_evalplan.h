@@ -439,7 +439,7 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
         if (w >= n_work) break;
         w_next = pln_ticket_issue(&S.ticket[b], lane);
 #else
-      for (uint32_t w = pln_ticket(&S.ticket[b], lane); w < n_work; w = pln_ticket(&S.ticket[b], lane)) {
+      PLN_FOR_UNITS(w, &S.ticket[b], n_work, wave, EVP_CWAVES) {      // (compute waves only)
 #endif
         if (w < w_k) {
           // ---- H unit: 64 rows with test transitions, largest totals first: the AR model's and the BEAR models' arg-max,

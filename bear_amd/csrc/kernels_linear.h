@@ -399,44 +399,83 @@ __device__ __forceinline__ void lin_row2(const double *T, const double *exptab, 
   }
 }
 
+// ---- BEAR_AMD_DETERMINISTIC: the gradient tables in 64-bit FIXED POINT.  LDS floating-point atomics from several waves land in
+// whatever order the waves get there, so d/d mat is reproducible to rounding only; integer adds commute exactly.  A context's
+// g_b = d L / d logit_b is bounded by its row total (x P(x, c) <= c, so w_b = f_b u P <= c_b and |g_b| <= n), hence every sum
+// of them by `bound` >= the sum of all counts that enter one gradient (bear_plan_set_count_bound; default: the plan's table).
+// With scale = 2^62 / bound (a power of two) every g becomes an integer BEFORE anything is added, no sum can leave 63 bits, and
+// the table sums are the exact integer sums -- whatever the order of the adds, the cut of the table into tiles and blocks, the
+// form of the lists.  The price: each g is rounded to bound 2^-62 once (2e-19 of the total count) instead of to its own last
+// bit; a block's / launch's integer sum becomes a double at the very end (one rounding).
+typedef long long lin_fx;
+__device__ __forceinline__ lin_fx lin_to_fixed(double v, double scale) { return (lin_fx)__builtin_rint(v * scale); }
+// The bound on the sum of |g_b| over everything that enters one gradient, from what a plan knows of its table (and of the
+// other shards of its batch, bear_plan_set_count_bound): the sum of all counts -- and, in BEAR mode, where
+// w_b = f u P(x, c) <= sum_j min(1, f u / j) <= 1 + u (1 + ln c), also cells (1 + u (1 + ln c_max)): tables of huge counts
+// under a large h (small u) have gradients far below their counts, and the tighter bound keeps the rounding unit
+// bound 2^-62 far below them.  Every block derives the same power of two from the launch's u.
+struct lin_fx_bound {
+  double counts, cells, ln_cmax;
+};
+__device__ __forceinline__ double lin_fx_scale(const lin_fx_bound &B, double u, bool ar) {
+  double bound = B.counts;
+  if (!ar) bound = __builtin_fmin(bound, B.cells * (1.0 + u * (1.0 + B.ln_cmax)));
+  bound = __builtin_fmax(bound, 1.0);
+  int e;
+  (void)frexp(bound, &e);                    // bound < 2^e
+  return bear_uniform_f64(ldexp(1.0, 62 - e));
+}
+template <typename T> __device__ __forceinline__ long long lin_bits(T v);
+template <> __device__ __forceinline__ long long lin_bits<double>(double v) { return __double_as_longlong(v); }
+template <> __device__ __forceinline__ long long lin_bits<lin_fx>(lin_fx v) { return v; }
+template <typename T> __device__ __forceinline__ T lin_unbits(long long q);
+template <> __device__ __forceinline__ double lin_unbits<double>(long long q) { return __longlong_as_double(q); }
+template <> __device__ __forceinline__ lin_fx lin_unbits<lin_fx>(long long q) { return q; }
+// one add into a gradient table (the table's words hold doubles or fixed-point integers, one kind per launch)
+__device__ __forceinline__ void lin_gt_add(double *p, double v) { atomicAdd(p, v); }
+__device__ __forceinline__ void lin_gt_add(double *p, lin_fx v) { atomicAdd(reinterpret_cast<unsigned long long *>(p), (unsigned long long)v); }
+
 // ---- cross-lane sums on DPP (a double = two 32-bit moves + one add per step; the generic __shfl_xor of a double costs
 // two ds_bpermute round trips: measured 0.76 ms per 1e8 contexts for the 24 of them a wave needs here)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double lin_dpp(double v) {
-  const long long q = __double_as_longlong(v);
+template <int CTRL, int ROW_MASK, typename T>
+__device__ __forceinline__ T lin_dpp(T v) {
+  const long long q = lin_bits<T>(v);
   const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)q, CTRL, ROW_MASK, 0xf, false);
   const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(q >> 32), CTRL, ROW_MASK, 0xf, false);
-  return __longlong_as_double(((long long)hi << 32) | (uint32_t)lo);
+  return lin_unbits<T>(((long long)hi << 32) | (uint32_t)lo);
 }
 // Sums of the four gradient letters over quads, rows of 16 and the wave, TRANSPOSED: lane i ends up with the sums of ONE letter,
 // lin_letter(i) -- which is how the block-level adds want them (lane <-> (group, letter)).  A quad exchanges two letters, then
 // one (the other lane of a pair keeps the other half), and from there every level is one add: 33 instructions instead of the
 // 80 of four separate butterflies.
 __device__ __forceinline__ uint32_t lin_letter(uint32_t lane) { return ((lane & 1u) << 1) | ((lane >> 1) & 1u); }
-__device__ __forceinline__ double lin_quad_letter_sum(const double (&g)[4], uint32_t lane) {
+template <typename T>
+__device__ __forceinline__ T lin_quad_letter_sum(const T (&g)[4], uint32_t lane) {
   const bool o1 = lane & 1u, o2 = lane & 2u;
-  double k0 = o1 ? g[2] : g[0], k1 = o1 ? g[3] : g[1];
-  k0 += lin_dpp<0xB1, 0xf>(o1 ? g[0] : g[2]);   // quad_perm [1,0,3,2]: the pair's sums of letters 2 o1, 2 o1 + 1
-  k1 += lin_dpp<0xB1, 0xf>(o1 ? g[1] : g[3]);
-  return (o2 ? k1 : k0) + lin_dpp<0x4E, 0xf>(o2 ? k0 : k1);   // quad_perm [2,3,0,1]
+  T k0 = o1 ? g[2] : g[0], k1 = o1 ? g[3] : g[1];
+  k0 += lin_dpp<0xB1, 0xf, T>(o1 ? g[0] : g[2]);   // quad_perm [1,0,3,2]: the pair's sums of letters 2 o1, 2 o1 + 1
+  k1 += lin_dpp<0xB1, 0xf, T>(o1 ? g[1] : g[3]);
+  return (o2 ? k1 : k0) + lin_dpp<0x4E, 0xf, T>(o2 ? k0 : k1);   // quad_perm [2,3,0,1]
 }
-__device__ __forceinline__ double lin_row16_sum(double quad_sum) {
-  double v = quad_sum;
-  v += lin_dpp<0x124, 0xf>(v);   // row_ror:4: the same letter of the next quad
-  v += lin_dpp<0x128, 0xf>(v);   // row_ror:8
+template <typename T>
+__device__ __forceinline__ T lin_row16_sum(T quad_sum) {
+  T v = quad_sum;
+  v += lin_dpp<0x124, 0xf, T>(v);   // row_ror:4: the same letter of the next quad
+  v += lin_dpp<0x128, 0xf, T>(v);   // row_ror:8
   return v;
 }
 // v_permlane16_swap / v_permlane32_swap (gfx950) of a value with itself: every lane gets the value of the same lane of the
 // neighbouring row of 16 / of the other half of the wave in the second result
-__device__ __forceinline__ double lin_wave_sum(double row_sum) {
-  double v = row_sum;
+template <typename T>
+__device__ __forceinline__ T lin_wave_sum(T row_sum) {
+  T v = row_sum;
 #pragma unroll
   for (int step = 0; step < 2; ++step) {
-    const long long q = __double_as_longlong(v);
+    const long long q = lin_bits<T>(v);
     const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
     const auto a = step == 0 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false) : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
     const auto c = step == 0 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false) : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    v = __longlong_as_double(((long long)c[0] << 32) | a[0]) + __longlong_as_double(((long long)c[1] << 32) | a[1]);
+    v = lin_unbits<T>(((long long)c[0] << 32) | a[0]) + lin_unbits<T>(((long long)c[1] << 32) | a[1]);
   }
   return v;
 }
@@ -516,10 +555,10 @@ __device__ __forceinline__ uint32_t lin_phase_a_paired(pln_lds_lin &S, const lin
 //   1. all groups whose row the whole wave shares: lane 4 g + b adds the wave's sum of g_b              (one instruction)
 //   2. up to four groups that a lane's row of 16 shares: lane (slot, b) of each row adds the row's sum   (one instruction)
 //   3. what is left (in a sorted table: the triple of the last letters): one add per context and letter (four per group)
-template <int NG>
-__device__ __forceinline__ void lin_scatter_grad(double *GT, unsigned long long cv, const double (&g)[4], bool nz, uint32_t lane,
+template <int NG, typename T = double>
+__device__ __forceinline__ void lin_scatter_grad(double *GT, unsigned long long cv, const T (&g)[4], bool nz, uint32_t lane,
                                                  double (&acc)[2]) {
-  const double tq = lin_quad_letter_sum(g, lane), th = lin_row16_sum(tq), tw = lin_wave_sum(th);   // of letter lin_letter(lane)
+  const T tq = lin_quad_letter_sum<T>(g, lane), th = lin_row16_sum<T>(tq), tw = lin_wave_sum<T>(th);   // of letter lin_letter(lane)
   const uint32_t bl = lin_letter(lane);
   // How many LEADING groups does my row of 16 share (l_row), how many the whole wave (l_wave)?  In a sorted table the shared
   // groups are the leading ones; anything else is merely handled one level lower than it could be.  e = my index word xor my
@@ -566,13 +605,13 @@ __device__ __forceinline__ void lin_scatter_grad(double *GT, unsigned long long 
   const uint32_t l_row = row_or ? min((uint32_t)(__builtin_ctzll(row_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG;   // >= l_wave
   const uint32_t l_quad = quad_or ? min((uint32_t)(__builtin_ctzll(quad_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG; // >= l_row
 #if LIN_DBG == 1
-  acc[1] += tw * 1e-300 + th * 1e-300 + (double)l_row * 1e-300;
+  acc[1] += (double)tw * 1e-300 + (double)th * 1e-300 + (double)l_row * 1e-300;
   return;
 #endif
   // 1. the groups the whole wave shares
   {
     const uint32_t gq = lane >> 2;
-    if (gq < l_wave && tw != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, gq, NG) >> 2)], tw);
+    if (gq < l_wave && tw != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, gq, NG) >> 2)], tw);
   }
 #if LIN_DBG == 2
   return;
@@ -581,7 +620,7 @@ __device__ __forceinline__ void lin_scatter_grad(double *GT, unsigned long long 
   // 2. the next (up to four) groups, shared by a row of 16: slot s of the row takes group l_wave + s
   {
     const uint32_t pick = l_wave + ((lane & 15u) >> 2);
-    if (pick < l_row && th != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
+    if (pick < l_row && th != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
   }
 #if LIN_DBG == 4
   return;
@@ -592,7 +631,7 @@ __device__ __forceinline__ void lin_scatter_grad(double *GT, unsigned long long 
   //     left to step 3.
   const bool quad_covers = l_row < l_quad && l_row < l_wave + 4u;    // (groups at or beyond l_wave + 4 are step 3's anyway)
   if (__builtin_amdgcn_ballot_w64(quad_covers)) {
-    if (quad_covers && tq != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, l_row, NG) >> 2)], tq);
+    if (quad_covers && tq != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, l_row, NG) >> 2)], tq);
   }
   // 3. one add per context and letter for every group not covered above
 #pragma unroll
@@ -609,15 +648,15 @@ __device__ __forceinline__ void lin_scatter_grad(double *GT, unsigned long long 
     if (mine) {
       double *gt = &GT[lin_off<NG>(cv, gq) >> 2];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) atomicAdd(&gt[b * LIN_GT_PLANE], g[b]);
+      for (int b = 0; b < 4; ++b) lin_gt_add(&gt[b * LIN_GT_PLANE], g[b]);
     }
   }
 }
 
 // ---- phase C for the thread's rows: g_b = w_b - f_b s into the gradient tables (lin_scatter_grad), whole waves at a time.
-template <int NG>
+template <int NG, bool DET>
 __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uint32_t tid, uint32_t lane_in, const double (&fA)[LIN_RPT][5],
-                                            const unsigned long long (&cA)[LIN_RPT], uint32_t rowA, double (&acc)[2]) {
+                                            const unsigned long long (&cA)[LIN_RPT], uint32_t rowA, double (&acc)[2], double gt_scale) {
   uint32_t lane = lane_in;
 #ifdef LIN_SKIP_C
   return;
@@ -652,20 +691,25 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uin
       const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)code, (int)last), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(code >> 32), (int)last);
       if (!live) cv = ((unsigned long long)hi << 32) | lo;
     }
-    lin_scatter_grad<NG>(S.GT, cv, g, nz, lane, acc);
+    if (DET) {
+      const lin_fx gi[4] = {lin_to_fixed(g[0], gt_scale), lin_to_fixed(g[1], gt_scale), lin_to_fixed(g[2], gt_scale), lin_to_fixed(g[3], gt_scale)};
+      lin_scatter_grad<NG, lin_fx>(S.GT, cv, gi, nz, lane, acc);
+    } else {
+      lin_scatter_grad<NG, double>(S.GT, cv, g, nz, lane, acc);
+    }
   }
 }
 
 // ---- lin_scatter_grad for 64 PAIRS of contexts (c0, c1 share every pair group; g0 / g1 their gradients, zero where there is no
 // context or no item): the pair groups take the pair's SUM gs through the same wave / row-of-16 / quad levels -- one reduction, one
 // run detection and one add per level for 128 contexts -- and each context adds its own g to its triple row.
-template <int NG>
-__device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned long long c0, unsigned long long c1, const double (&g0)[4],
-                                                        const double (&g1)[4], bool nz0, bool nz1, uint32_t lane) {
+template <int NG, typename T>
+__device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned long long c0, unsigned long long c1, const T (&g0)[4],
+                                                        const T (&g1)[4], bool nz0, bool nz1, uint32_t lane) {
   constexpr uint32_t NP = NG - 1;          // pair groups: the only ones the levels may share
   if (NP > 0) {
-    const double gs[4] = {g0[0] + g1[0], g0[1] + g1[1], g0[2] + g1[2], g0[3] + g1[3]};
-    const double tq = lin_quad_letter_sum(gs, lane), th = lin_row16_sum(tq), tw = lin_wave_sum(th);
+    const T gs[4] = {g0[0] + g1[0], g0[1] + g1[1], g0[2] + g1[2], g0[3] + g1[3]};
+    const T tq = lin_quad_letter_sum<T>(gs, lane), th = lin_row16_sum<T>(tq), tw = lin_wave_sum<T>(th);
     const uint32_t bl = lin_letter(lane);
     const unsigned long long pm = (1ull << (6 * NP)) - 1ull;
     const unsigned long long cv = c0 & pm;
@@ -709,16 +753,16 @@ __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned lon
     const uint32_t l_quad = quad_or ? ((uint32_t)(__builtin_ctzll(quad_or) * 43) >> 8) : NP;
     {
       const uint32_t gq = lane >> 2;
-      if (gq < l_wave && tw != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, gq, NG) >> 2)], tw);
+      if (gq < l_wave && tw != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, gq, NG) >> 2)], tw);
     }
     if (l_wave < NP) {
       {
         const uint32_t pick = l_wave + ((lane & 15u) >> 2);
-        if (pick < l_row && th != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
+        if (pick < l_row && th != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
       }
       const bool quad_covers = l_row < l_quad && l_row < l_wave + 4u;
       if (__builtin_amdgcn_ballot_w64(quad_covers)) {
-        if (quad_covers && tq != 0.0) atomicAdd(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, l_row, NG) >> 2)], tq);
+        if (quad_covers && tq != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, l_row, NG) >> 2)], tq);
       }
 #pragma unroll
       for (int gq = 0; gq < (int)NP; ++gq) {
@@ -728,7 +772,7 @@ __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned lon
         if (mine) {
           double *gt = &GT[lin_off<NG>(cv, gq) >> 2];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) atomicAdd(&gt[b * LIN_GT_PLANE], gs[b]);
+          for (int b = 0; b < 4; ++b) lin_gt_add(&gt[b * LIN_GT_PLANE], gs[b]);
         }
       }
     }
@@ -740,21 +784,22 @@ __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned lon
   if (nz0) {
     double *gt = &GT[lin_off<NG>(c0, NG - 1) >> 2];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) atomicAdd(&gt[b * LIN_GT_PLANE], g0[b]);
+    for (int b = 0; b < 4; ++b) lin_gt_add(&gt[b * LIN_GT_PLANE], g0[b]);
   }
   if (__builtin_amdgcn_ballot_w64(nz1)) {
     if (nz1) {
       double *gt = &GT[lin_off<NG>(c1, NG - 1) >> 2];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) atomicAdd(&gt[b * LIN_GT_PLANE], g1[b]);
+      for (int b = 0; b < 4; ++b) lin_gt_add(&gt[b * LIN_GT_PLANE], g1[b]);
     }
   }
 }
 
 // ---- phase C over the PAIRED list: a thread reads both of its rows back; a wave scatters 64 pairs at once.
-template <int NG>
+template <int NG, bool DET>
 __device__ __forceinline__ void lin_phase_c_paired(pln_lds_lin &S, uint32_t n_ent, uint32_t tid, uint32_t lane_in,
-                                                   const double (&fA)[LIN_RPT][5], const unsigned long long (&cA)[LIN_RPT], uint32_t rowA) {
+                                                   const double (&fA)[LIN_RPT][5], const unsigned long long (&cA)[LIN_RPT], uint32_t rowA,
+                                                   double gt_scale) {
   uint32_t lane = lane_in;
 #ifdef LIN_SKIP_C
   return;
@@ -793,7 +838,16 @@ __device__ __forceinline__ void lin_phase_c_paired(pln_lds_lin &S, uint32_t n_en
   if (g[0][0] + g[1][0] + g[0][1] + g[1][1] + g[0][2] + g[1][2] + g[0][3] + g[1][3] == 12345.678) S.GT[lane] = 1.0;
   return;
 #endif
-  lin_scatter_grad_paired<NG>(S.GT, c0, c1, g[0], g[1], nz[0], nz[1], lane);
+  if (DET) {
+    lin_fx gi[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) gi[k][b] = lin_to_fixed(g[k][b], gt_scale);
+    lin_scatter_grad_paired<NG, lin_fx>(S.GT, c0, c1, gi[0], gi[1], nz[0], nz[1], lane);
+  } else {
+    lin_scatter_grad_paired<NG, double>(S.GT, c0, c1, g[0], g[1], nz[0], nz[1], lane);
+  }
 }
 
 // ---- the group tables of a launch, built by the whole block (n_threads threads; *t_max: a word of LDS).  A row is the sum of mat[l][a_l][b] - mat[l][a_l][4] over the group's letters;
@@ -837,13 +891,18 @@ __device__ __forceinline__ bool lin_build_tables(double *T, unsigned long long *
 
 // ---- fold the group tables into this block's d/d mat[l][a][b] partials: sum over the group's other letters; only b < 4 was
 // accumulated (the softmax gradient of a context sums to zero over b: the last column is minus the sum of the others)
+// (DET: the table words are fixed-point integers; the fold adds them as integers and the partial keeps the integer's bits)
+template <bool DET = false>
 __device__ __forceinline__ void lin_fold_tables(const double *GT, const lin_geom &G, int tid, int n_threads, double *__restrict__ dst) {
+  using T = typename std::conditional<DET, lin_fx, double>::type;
   for (int k = tid; k < G.lag * 25; k += n_threads) {
     const int l = k / 25, r = k - l * 25, a = r / 5, b = r - a * 5;
-    double s = 0.0;
+    T s = T(0);
     auto add = [&](int row) {
       const double *gt = &GT[row];
-      s += b < 4 ? gt[b * LIN_GT_PLANE] : -((gt[0] + gt[LIN_GT_PLANE]) + (gt[2 * LIN_GT_PLANE] + gt[3 * LIN_GT_PLANE]));
+      const T v0 = lin_unbits<T>(__double_as_longlong(gt[0])), v1 = lin_unbits<T>(__double_as_longlong(gt[LIN_GT_PLANE])),
+              v2 = lin_unbits<T>(__double_as_longlong(gt[2 * LIN_GT_PLANE])), v3 = lin_unbits<T>(__double_as_longlong(gt[3 * LIN_GT_PLANE]));
+      s += b == 0 ? v0 : b == 1 ? v1 : b == 2 ? v2 : b == 3 ? v3 : -((v0 + v1) + (v2 + v3));
     };
     if (l >= G.tri) {
       const int pos = l - G.tri, base = G.npair * LIN_PAIR_COMBOS;
@@ -855,36 +914,41 @@ __device__ __forceinline__ void lin_fold_tables(const double *GT, const lin_geom
       const int g = l >> 1;
       for (int p = 0; p < 6; ++p) add(g * LIN_PAIR_COMBOS + ((l & 1) ? p * 6 + a : a * 6 + p));
     }
-    bear_store_agent(&dst[k], s);
+    bear_store_agent(&dst[k], __longlong_as_double(lin_bits<T>(s)));
   }
 }
 
 // ---- the last block to finish (bear_arrive_last): d/d mat[k] = sum over the blocks' partials [gridDim.x][LIN_MAX_GRAD] in a fixed
 // order -- three threads per entry take a third of the blocks each (independent loads, consecutive threads on consecutive
 // entries), their sums meet in `part` (3 * LIN_MAX_GRAD doubles of LDS).
+template <bool DET = false>
 __device__ __forceinline__ void lin_sum_block_partials(const double *__restrict__ grad_partials, int n_grad, double *part, int tid,
-                                                       int n_threads, double *__restrict__ grad_out, bool accumulate = false) {
+                                                       int n_threads, double *__restrict__ grad_out, bool accumulate = false,
+                                                       double inv_scale = 1.0) {
+  using T = typename std::conditional<DET, lin_fx, double>::type;
   const int nb = (int)gridDim.x, third = (nb + 2) / 3;
   for (int t = tid; t < 3 * n_grad; t += n_threads) {
     const int k = t % n_grad, c = t / n_grad;
     const int b0 = c * third, b1 = b0 + third < nb ? b0 + third : nb;
     // sixteen independent loads in flight per thread (the lines come from memory: the L2 was just invalidated); fixed order
     const double *src = grad_partials + k;
-    double s = 0.0;
+    T s = T(0);
     int b = b0;
     for (; b + 16 <= b1; b += 16) {
       double v[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(b + j) * LIN_MAX_GRAD];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) s += v[j];
+      for (int j = 0; j < 16; ++j) s += lin_unbits<T>(__double_as_longlong(v[j]));
     }
-    for (; b < b1; ++b) s += src[(size_t)b * LIN_MAX_GRAD];
-    part[c * LIN_MAX_GRAD + k] = s;
+    for (; b < b1; ++b) s += lin_unbits<T>(__double_as_longlong(src[(size_t)b * LIN_MAX_GRAD]));
+    part[c * LIN_MAX_GRAD + k] = __longlong_as_double(lin_bits<T>(s));
   }
   __syncthreads();
   for (int k = tid; k < n_grad; k += n_threads) {
-    const double v = (part[k] + part[LIN_MAX_GRAD + k]) + part[2 * LIN_MAX_GRAD + k];
+    const T t = (lin_unbits<T>(__double_as_longlong(part[k])) + lin_unbits<T>(__double_as_longlong(part[LIN_MAX_GRAD + k]))) +
+                lin_unbits<T>(__double_as_longlong(part[2 * LIN_MAX_GRAD + k]));
+    const double v = DET ? (double)t * inv_scale : (double)t;     // (DET: the launch's exact integer sum becomes a double here: one rounding)
     grad_out[k] = accumulate ? grad_out[k] + v : v;
   }
 }
@@ -916,11 +980,13 @@ __device__ unsigned long long lin_stamp_sums[8];
 #else
 #define LIN_STAMP(k)
 #endif
-template <bool AR, bool PAIRED>
+// DET (BEAR_AMD_DETERMINISTIC): the gradient tables hold fixed-point integers, gt_scale = 2^50 / bound (see lin_fx above)
+template <bool AR, bool PAIRED, bool DET = false>
 __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_kernel(
     const unsigned long long *__restrict__ kmer_code, const double *__restrict__ mat, int lag, bear_params prm_arg, pln_view pv,
     const double2 *__restrict__ logtab_g, double *__restrict__ partials, double *__restrict__ grad_partials,
-    const bear_step_io io, double *__restrict__ grad_out, int accumulate) {   // accumulate: add to io.out / grad_out (second launch of a step)
+    const bear_step_io io, double *__restrict__ grad_out, int accumulate,    // accumulate: add to io.out / grad_out (second launch of a step)
+    const lin_fx_bound gt_bound) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_lin &S = *reinterpret_cast<pln_lds_lin *>(srt_smem);
   const bear_params prm = bear_params_of(prm_arg, io);   // device-resident parameters: constants derived in the prologue
@@ -929,6 +995,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   const lin_geom G = lin_make_geom(lag);
   const int ng = G.ng;
   double acc[2] = {0.0, 0.0};
+  const double gt_scale = DET ? lin_fx_scale(gt_bound, u, AR) : 0.0;
 
   if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
   if (tid < SRT_NKEY) {
@@ -1020,9 +1087,9 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   };
   auto phase_c = [&]() {
     if (PAIRED) {
-      LIN_FOR_NG(ng, lin_phase_c_paired<NG>(S, n_live, tid, lane, fA, cA, rowA))
+      LIN_FOR_NG(ng, (lin_phase_c_paired<NG, DET>(S, n_live, tid, lane, fA, cA, rowA, gt_scale)))
     } else {
-      LIN_FOR_NG(ng, lin_phase_c<NG>(S, n_live, tid, lane, fA, cA, rowA, acc))
+      LIN_FOR_NG(ng, (lin_phase_c<NG, DET>(S, n_live, tid, lane, fA, cA, rowA, acc, gt_scale)))
     }
   };
 
@@ -1080,7 +1147,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     bool rows_done = (wave & 1u) != 0u;
     if (rows_done) rows_work();
 #endif
-    for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_work; w = pln_ticket(&S.ticket[slot], lane)) {
+    PLN_FOR_UNITS(w, &S.ticket[slot], n_work, wave, PLN_WAVES) {
 #ifdef LIN_MIX
       if (!rows_done && w >= n_work / 2u) {
         rows_done = true;
@@ -1198,7 +1265,12 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     for (int g = 0; g < ng; ++g) {
       double *gt = &S.GT[lin_off_any(cv, (uint32_t)g, (uint32_t)ng) >> 2];
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb) atomicAdd(&gt[bb * LIN_GT_PLANE], (bb == (int)b ? w : 0.0) - f[bb] * w);
+      for (int bb = 0; bb < 4; ++bb) {
+        // (an overflow item is ONE cell of its context: the context's g is the sum of these per-item parts, each bounded by its count)
+        const double gv = (bb == (int)b ? w : 0.0) - f[bb] * w;
+        if (DET) lin_gt_add(&gt[bb * LIN_GT_PLANE], lin_to_fixed(gv, gt_scale));
+        else lin_gt_add(&gt[bb * LIN_GT_PLANE], gv);
+      }
     }
   }
   for (uint64_t i = gtid; !AR && i < pv.n_heavy_row; i += gsz) {
@@ -1212,11 +1284,12 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     acc[1] = __builtin_fma(u * m, S.tabP[tid], acc[1]);
   }
   __syncthreads();
-  lin_fold_tables(S.GT, G, (int)tid, PLN_THREADS, grad_partials + (size_t)blockIdx.x * LIN_MAX_GRAD);
+  lin_fold_tables<DET>(S.GT, G, (int)tid, PLN_THREADS, grad_partials + (size_t)blockIdx.x * LIN_MAX_GRAD);
   block_store_partials<2, true>(acc, partials);      // (io.out is never NULL here: both entry points sum in this launch)
   if (!bear_arrive_last(io.arrive())) return;
   __syncthreads();
-  lin_sum_block_partials(grad_partials, lag * 25, reinterpret_cast<double *>(srt_smem), (int)tid, PLN_THREADS, grad_out, accumulate != 0);   // the tile loop is over: the dynamic LDS is free
+  lin_sum_block_partials<DET>(grad_partials, lag * 25, reinterpret_cast<double *>(srt_smem), (int)tid, PLN_THREADS, grad_out, accumulate != 0,
+                              DET ? 1.0 / gt_scale : 1.0);   // the tile loop is over: the dynamic LDS is free
   bear_finalize_in_block(partials, 2, io.out, io.arrive(), accumulate != 0);
 }
 

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
       return bear_dp{cnt * bear_log_tab(pp, S.logtab), cnt * bear_rcp(pp) * bear_rcp(u)};
     };
     const uint32_t n_hcu = (hc + 63u) >> 6, n_units = (n_light + 63u) >> 6;
-    for (uint32_t w = pln_ticket(&S.ticket, lane); w < n_hcu + n_units; w = pln_ticket(&S.ticket, lane)) {
+    PLN_FOR_UNITS(w, &S.ticket, n_hcu + n_units, wave, PLN_WAVES) {
       if (w < n_hcu) {
         const uint32_t i = w * 64u + lane;
         if (i < hc) {

@@ -103,6 +103,14 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
                                                         unsigned long long *__restrict__ hist) {
   __shared__ uint32_t s_heavy[3];
   __shared__ uint32_t s_hist[2 * SRT_NKEY];
+  __shared__ unsigned long long s_total, s_cells;   // sum of all counts / cells that hold one (heavy_counts[6], [7]: bear_plan::count_total)
+  __shared__ uint32_t s_cmax;                       // largest count (heavy_counts[8])
+  unsigned long long my_total = 0ull;
+  uint32_t my_cells = 0u, my_cmax = 0u;
+  if (threadIdx.x == 0) {
+    s_total = s_cells = 0ull;
+    s_cmax = 0u;
+  }
   if (threadIdx.x < 3) s_heavy[threadIdx.x] = 0;
   if (threadIdx.x < 2 * SRT_NKEY) s_hist[threadIdx.x] = 0;
   __syncthreads();
@@ -116,6 +124,9 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
         const uint32_t c = counts[r * 5 + b];
         const uint32_t s = nsat + c;
         nsat = s < nsat ? 0xffffffffu : s;
+        my_total += c;
+        my_cells += c != 0u;
+        my_cmax = c > my_cmax ? c : my_cmax;
         if (b < ncol) {
           light += (c != 0 && c <= SRT_CL);
           hcol += (c > SRT_CL);
@@ -134,7 +145,17 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
     quad_light[n_quads + g] = (uint8_t)qhc;
     quad_light[2 * n_quads + g] = (uint8_t)qhr;
   }
+  if (my_total) {
+    atomicAdd(&s_total, my_total);
+    atomicAdd(&s_cells, (unsigned long long)my_cells);
+    atomicMax(&s_cmax, my_cmax);
+  }
   __syncthreads();
+  if (threadIdx.x == 0 && s_total) {
+    atomicAdd(&heavy_counts[6], s_total);
+    atomicAdd(&heavy_counts[7], s_cells);
+    atomicMax(&heavy_counts[8], (unsigned long long)s_cmax);
+  }
   if (threadIdx.x < 3 && s_heavy[threadIdx.x]) atomicAdd(&heavy_counts[threadIdx.x], (unsigned long long)s_heavy[threadIdx.x]);
   if (threadIdx.x < 2 * SRT_NKEY && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
 }
@@ -289,6 +310,14 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
   __shared__ uint32_t scan[16];
   __shared__ uint16_t sorted[PLN_NI + 64];
   __shared__ uint32_t s_hc, s_hr;
+#ifdef BEAR_DET_BUILD
+  // The ranks below come from atomics: inside a count the items -- and the in-tile large-count lists -- stand in whatever order
+  // the threads got there.  The deterministic build sorts them (count, then offset: a bitonic pass over the tile; the lists by
+  // ranking) so that a table's plan, hence the grouping of every sum taken over it, is the same bits in every run.
+  __shared__ uint32_t comp[PLN_NI];
+  static_assert((PLN_NI & (PLN_NI - 1)) == 0 && PLN_NI == 2048, "bitonic sort over the tile's items");
+  __shared__ unsigned long long hkey[PLN_HCAP], htmp[PLN_HCAP];
+#endif
   const uint32_t tid = threadIdx.x, rep = tid & (SRT_REP - 1);
   for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const pln_tile ti = tiles[t];
@@ -309,6 +338,54 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
       s_hr = 0;
     }
     __syncthreads();
+#ifdef BEAR_DET_BUILD
+    // WHICH large-count cells / large-total rows stay inside the tile (the first hc_cap / hr_cap) must not depend on who gets to
+    // the counter first: positions in row order from a block-wide scan (rows lr = tid + 1024 k, k-major)
+    uint32_t det_hc[RPT], det_hr[RPT];
+    {
+      uint32_t base_c = 0, base_r = 0;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const uint32_t lr = tid + 1024u * k;
+        uint32_t nc = 0, nr = 0;
+        if (lr < rows) {
+          double n = 0.0;
+          for (int b = 0; b < 5; ++b) {
+            const uint32_t cv = counts[(ti.row0 + lr) * 5 + b];
+            n += (double)cv;
+            nc += (b < ncol && cv > SRT_CL) ? 1u : 0u;
+          }
+          nr = n > (double)SRT_CL ? 1u : 0u;
+        }
+        const uint32_t packed = nc | (nr << 16);            // (at most 5 * 1024 cells, 1024 rows per pass: both halves fit)
+        const int lane = tid & 63, wave = tid >> 6;
+        uint32_t incl = packed;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+          if (lane >= off) incl += o;
+        }
+        __syncthreads();                                     // (scan[] of the previous pass has been read)
+        if (lane == 63) scan[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int w = 0; w < 16; ++w) {
+          if (w < wave) before += scan[w];
+          total += scan[w];
+        }
+        const uint32_t excl = before + incl - packed;
+        det_hc[k] = base_c + (excl & 0xffffu);
+        det_hr[k] = base_r + (excl >> 16);
+        base_c += total & 0xffffu;
+        base_r += total >> 16;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        s_hc = base_c;
+        s_hr = base_r;
+      }
+    }
+#endif
     uint32_t c[RPT][5], rank[RPT][5];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -328,7 +405,11 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
         }
         nrow[lr] = n < 1.0 ? (uint8_t)0 : (n <= (double)SRT_CL ? (uint8_t)n : (uint8_t)255);  // 255: large total
         if (n > (double)SRT_CL) {
+#ifdef BEAR_DET_BUILD
+          const uint32_t k2 = hr_cap ? det_hr[k] : 0xffffffffu;
+#else
           const uint32_t k2 = hr_cap ? atomicAdd(&s_hr, 1u) : 0xffffffffu;
+#endif
           if (k2 < hr_cap) {  // evaluated inside the tile (prior row already in LDS)
             hrow[k2] = (uint16_t)lr;
             hn[k2] = n;
@@ -343,7 +424,11 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
         for (int b = 0; b < 5; ++b) {
           if (b >= ncol) c[k][b] = 0;
           if (c[k][b] > SRT_CL) {
+#ifdef BEAR_DET_BUILD
+            const uint32_t k2 = hc_cap ? det_hc[k]++ : 0xffffffffu;
+#else
             const uint32_t k2 = hc_cap ? atomicAdd(&s_hc, 1u) : 0xffffffffu;
+#endif
             if (k2 < hc_cap) {
               hoff[k2] = (uint16_t)(lr * 5 + b);
               hcnt[k2] = c[k][b];
@@ -388,6 +473,61 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
       for (int b = 0; b < 5; ++b)
         if (c[k][b] != 0) sorted[offs[(c[k][b] - 1) * SRT_REP + rep] + rank[k][b]] = (uint16_t)((tid + 1024u * k) * 5 + b);
     __syncthreads();
+#ifdef BEAR_DET_BUILD
+    {
+      // key of position i = the number of thresholds at or below it (the list is sorted by count already)
+      for (uint32_t i = tid; i < PLN_NI; i += 1024) {
+        uint32_t key = 0;
+        for (uint32_t q = 1; q < SRT_CL; ++q) key += offs[q * SRT_REP] <= i ? 1u : 0u;
+        comp[i] = i < n_light ? (key << 16) | sorted[i] : 0xffffffffu;
+      }
+      __syncthreads();
+      for (uint32_t size = 2; size <= PLN_NI; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+          const uint32_t lo = 2u * tid - (tid & (stride - 1u)), hi = lo + stride;      // PLN_NI / 2 = 1024 pairs, one per thread
+          const bool up = (lo & size) == 0u;
+          const uint32_t a = comp[lo], bq = comp[hi];
+          if ((a > bq) == up) {
+            comp[lo] = bq;
+            comp[hi] = a;
+          }
+          __syncthreads();
+        }
+      for (uint32_t i = tid; i < n_light; i += 1024) sorted[i] = (uint16_t)(comp[i] & 0xffffu);
+      __syncthreads();
+      // the in-tile large-count lists: rank by (offset) / (row)
+      const uint32_t nhc = s_hc < hc_cap ? s_hc : hc_cap, nhr = s_hr < hr_cap ? s_hr : hr_cap;
+      if (tid < nhc) hkey[tid] = ((unsigned long long)hoff[tid] << 32) | hcnt[tid];
+      __syncthreads();
+      if (tid < nhc) {
+        uint32_t r = 0;
+        for (uint32_t q = 0; q < nhc; ++q) r += hkey[q] < hkey[tid] ? 1u : 0u;
+        htmp[r] = hkey[tid];
+      }
+      __syncthreads();
+      if (tid < nhc) {
+        hoff[tid] = (uint16_t)(htmp[tid] >> 32);
+        hcnt[tid] = (uint32_t)htmp[tid];
+      }
+      __syncthreads();
+      if (tid < nhr) hkey[tid] = ((unsigned long long)hrow[tid] << 48) | tid;      // (rows are distinct)
+      if (tid < nhr) htmp[tid] = (unsigned long long)__double_as_longlong(hn[tid]);
+      __syncthreads();
+      uint32_t r = 0;
+      unsigned long long mine = 0ull, myn = 0ull;
+      if (tid < nhr) {
+        for (uint32_t q = 0; q < nhr; ++q) r += hkey[q] < hkey[tid] ? 1u : 0u;
+        mine = hkey[tid];
+        myn = htmp[tid];
+      }
+      __syncthreads();
+      if (tid < nhr) {
+        hrow[r] = (uint16_t)(mine >> 48);
+        hn[r] = __longlong_as_double((long long)myn);
+      }
+      __syncthreads();
+    }
+#endif
     const uint32_t padded = (n_light + 63u) & ~63u;
     for (uint32_t i = tid; i < padded; i += 1024) items[i] = i < n_light ? sorted[i] : (uint16_t)PLN_SENTINEL;
     __syncthreads();
@@ -532,6 +672,17 @@ __device__ __forceinline__ uint32_t pln_ticket(uint32_t *counter, uint32_t lane)
   if (lane == 0) t = atomicAdd(counter, 1u);
   return srt_uniform(t);
 }
+
+// Work units of a tile are DRAWN: whichever wave is free takes the next one, so which thread accumulates which items changes from
+// run to run and the fp64 sums of a launch are reproducible to rounding only (their order across blocks is fixed).  The
+// deterministic build (-DBEAR_DET_BUILD: libbear_hip_det.so, loaded when BEAR_AMD_DETERMINISTIC is set at import) deals them
+// out instead: drawing wave `first` of `stride` takes units first, first + stride, ... -- every sum is then bit-identical from
+// run to run, at the price of the dynamic balance.
+#ifdef BEAR_DET_BUILD
+#define PLN_FOR_UNITS(w, counter, n, first, stride) for (uint32_t w = (first); w < (n); w += (stride))
+#else
+#define PLN_FOR_UNITS(w, counter, n, first, stride) for (uint32_t w = pln_ticket(counter, lane); w < (n); w = pln_ticket(counter, lane))
+#endif
 
 // The same draw without waiting for its answer: lane 0's return value, to be made uniform (srt_uniform) when it is looked at.
 __device__ __forceinline__ uint32_t pln_ticket_issue(uint32_t *counter, uint32_t lane) {
@@ -750,7 +901,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
 #else
     const uint32_t n_work = n_heavy + n_units + ((NORM || AR) ? 0u : (rows + PLN_CHUNK - 1u) / PLN_CHUNK);
 #endif
-    for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_work; w = pln_ticket(&S.ticket[slot], lane)) {
+    PLN_FOR_UNITS(w, &S.ticket[slot], n_work, wave, PLN_WAVES - PLN_DMA_WAVES) {      // (the DMA waves never get here)
 #ifdef PLN_STAMPS
       {
         const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -1031,7 +1182,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
 #else
     const uint32_t n_units = (n_light + 63u) >> 6;
 #endif
-    for (uint32_t w = pln_ticket(&S.ticket[slot], lane); w < n_hcu + n_units; w = pln_ticket(&S.ticket[slot], lane)) {
+    PLN_FOR_UNITS(w, &S.ticket[slot], n_hcu + n_units, wave, CWAVES) {      // (compute waves only)
       if (w < n_hcu) {  // large-count column items of this tile (Stirling path), first
         const uint32_t i = w * 64u + lane;
         if (i < hc) {
@@ -1258,7 +1409,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
     }
     // ---- 3: item units (tickets, dearest first): ELBO, d/dh, and u P_b into the item's own cell
     const uint32_t n_hcu = (hc + 63u) >> 6, n_units = (n_light + 63u) >> 6;
-    for (uint32_t w = pln_ticket(&S.ticket, lane); w < n_hcu + n_units; w = pln_ticket(&S.ticket, lane)) {
+    PLN_FOR_UNITS(w, &S.ticket, n_hcu + n_units, wave, PLN_WAVES) {
       if (w < n_hcu) {
         const uint32_t i = w * 64u + lane;
         if (i < hc) {
@@ -1407,7 +1558,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
     const uint16_t *items = reinterpret_cast<const uint16_t *>(blk + L.items);
     // ---- 1: item units (tickets, dearest first): ELBO, d/dh, and the marked gradient into the item's own cell
     const uint32_t n_hcu = (hc + 63u) >> 6, n_units = (n_light + 63u) >> 6;
-    for (uint32_t w = pln_ticket(&S.ticket[b], lane); w < n_hcu + n_units; w = pln_ticket(&S.ticket[b], lane)) {
+    PLN_FOR_UNITS(w, &S.ticket[b], n_hcu + n_units, wave, PLN_WAVES) {
       if (w < n_hcu) {
         const uint32_t i = w * 64u + lane;
         if (i < hc) {

@@ -163,6 +163,19 @@ class Plan:
         self.paired_codes = kmer_index if ok.value else None
         return bool(ok.value)
 
+    def count_total(self):
+        """(total, bound) -- each [sum of all counts, cells that hold a count, largest count]: of the plan's table, and the values in
+        force for the deterministic mode's fixed-point scale (``bear_plan_count_total``)."""
+        a, b = (ctypes.c_double * 3)(), (ctypes.c_double * 3)()
+        _lib.check(_lib.lib().bear_plan_count_total(self._h, a, b), "bear_plan_count_total")
+        return list(a), list(b)
+
+    def set_count_bound(self, bound):
+        """``bear_plan_set_count_bound``: [sum of counts, non-zero cells, largest count] of EVERYTHING that is added into one gradient
+        together with this plan's rows (BEAR_AMD_DETERMINISTIC: the scale of the fixed-point gradient tables; ranks that share a batch
+        must agree on it: sums of the first two, maximum of the third)."""
+        _lib.check(_lib.lib().bear_plan_set_count_bound(self._h, (ctypes.c_double * 3)(*[float(x) for x in bound])), "bear_plan_set_count_bound")
+
     def pair_info(self):
         """(tiles that take the paired form of the linear step, tiles that keep their plain list) -- ``bear_plan_pair_info``."""
         a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BEAR_ABI_VERSION 4
+#define BEAR_ABI_VERSION 5
 #define BEAR_ROW_WIDTH 5 /* alphabet_size + 1 for dna/rna */
 
 typedef enum bear_status {
@@ -260,6 +260,26 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
  * of the tiles (a sparse table): the plan is then left as it was.  Synchronises `stream` (set-up path).
  */
 int bear_plan_pair_contexts(bear_plan *plan, const uint64_t *kmer_index, int lag, int *paired, void *stream);
+/* BEAR_AMD_DETERMINISTIC=1 (environment, read per call): parameter gradients that are bit-identical from run to run.
+ *   bear_dm_linear_f64 / bear_net_linear_train_*: the gradient tables of the fused linear step hold 64-bit fixed-point integers
+ *     scaled by 2^62 / bound, where bound >= the sum of |gradient| over everything that is added into one gradient -- derived from
+ *     the table's counts (sum, non-zero cells, maximum) and the launch's h (kernels_linear.h, lin_fx_bound):
+ *     d/d mat is then the exact integer sum of the contexts' rounded gradients -- independent of the order of the adds, of the
+ *     cut into tiles and blocks and of the form of the plan's lists -- turned into a double once at the end.  Each context's
+ *     gradient is rounded to bound * 2^-62 (instead of to its own last bit).
+ *   bear_cnn_backward_f64 / bear_net_cnn_train_*: the backward kernel runs ONE wave per block (the block's gradient image takes its
+ *     adds in program order); reproducible from run to run for a given launch geometry, at an eighth of the waves per CU.
+ * The scalar sums (sum LL, d/dh, d/dtau, d/dnet_weight) are fixed-order sums in every mode.
+ * bear_plan_count_total: total[3] / bound[3] [host, nullable] = {sum of all counts, cells that hold a count, largest count} of the
+ *   plan's table / the values in force for the scale (default: the table's own).
+ * bear_plan_set_count_bound: bound[3] >= the plan's own, each < 2^50 -- the same three of EVERYTHING that is added into one gradient
+ *   with this plan's rows (ranks that share a batch: sums of the first two, maximum of the third, over the ranks). */
+int bear_plan_count_total(const bear_plan *plan, double *total, double *bound);
+/* 1 for libbear_hip_det.so (built with -DBEAR_DET_BUILD): everything above is always on AND the work units of a tile are dealt to
+ * the waves statically instead of drawn, so that every sum of a launch -- sum LL and d/dh too -- is bit-identical from run to run
+ * (in the regular library those are fixed-order across blocks, but which thread adds which item inside a block follows the draw). */
+int bear_deterministic_build(void);
+int bear_plan_set_count_bound(bear_plan *plan, const double *bound);
 /* How the pairing went: tiles that take the paired form / tiles that keep their plain list (outputs nullable); returns 1 when the
  * plan is paired, 0 when it is not. */
 int bear_plan_pair_info(const bear_plan *plan, uint64_t *paired_tiles, uint64_t *plain_tiles);

@@ -126,7 +126,7 @@ def measure_dense(dev, n=20_000_000, check_rows=2_000_000):
     want_n, want_g = co.dm_prior(trh, prh, h_s, want_grad=True, nthreads=cores)
     want_r = co.dm_ref(trh, rfh, h_s, tau_s, nu_s, nthreads=cores)
     sub_n = sub_n.cpu().numpy()
-    mass_n = float(co.dm_prior_mass(trh, prh, h_s, nthreads=cores)[0])       # L1 masses: the scale a gradient's rounding errors live on
+    mass_n = float(co.dm_prior_mass(trh, prh, h_s, nthreads=cores))       # L1 masses: the scale a gradient's rounding errors live on
     mass_r = co.dm_ref_mass(trh, rfh, h_s, tau_s, nu_s, nthreads=cores)
     gerr = float(np.abs(grad.cpu().numpy() - want_g).max() / np.abs(want_g).max())
     nbytes = {"net": plan_n.nbytes / n, "ref": plan_r.nbytes / n}

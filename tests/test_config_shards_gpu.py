@@ -132,7 +132,7 @@ def test_dense_full_size():
     want, want_g = co.dm_prior(trh, pr.cpu().numpy(), args[0], want_grad=True, nthreads=min(os.cpu_count() or 4, 64))
     want_r = co.dm_ref(trh, rfh, *args, nthreads=min(os.cpu_count() or 4, 64))
     sub = sub.cpu().numpy()
-    mass = float(co.dm_prior_mass(trh, pr.cpu().numpy(), args[0], nthreads=min(os.cpu_count() or 4, 64))[0])   # L1 mass of d/dh: its error scale
+    mass = float(co.dm_prior_mass(trh, pr.cpu().numpy(), args[0], nthreads=min(os.cpu_count() or 4, 64)))   # L1 mass of d/dh: its error scale
     assert abs(sub[0] - want[0]) <= 1e-10 * abs(want[0]) and abs(sub[1] - want[1]) <= 1e-11 * mass, (sub, want, mass)
     assert np.abs(g.cpu().numpy() - want_g).max() <= 1e-9 * np.abs(want_g).max()
     assert abs(sub_r[0] - want_r[0]) <= 1e-10 * abs(want_r[0]), (sub_r, want_r)

@@ -316,7 +316,9 @@ def test_bench_single_rank_line_is_consistent():
     lin = also["linear_head_fused_step"]
     assert lin["paired_equals_plain"] is True and isinstance(lin["paired_contexts"], bool)
     assert also["net_rows_not_normalised"]["kernel_ms"] >= r["kernel_ms"] * 0.9
-    assert d["ranks"] == {"world_size": 1, "backend": None, "launcher": "none (one process)", "devices": [0]}
+    assert d["ranks"] == {"world_size": 1, "backend": None, "launcher": "none (one process)", "devices": [0],
+                          "backend_is_rccl": None, "devices_distinct": True}
+    assert d["settle"]["cold_ms_per_step_without_settle"] > 0          # the figure of the same command without the settle launches
 
 
 def test_bench_rccl_path_on_a_group_of_one():
