@@ -1,7 +1,15 @@
 """End-to-end anchor on the reference's published results (docs/usage.rst:236-265): the six example configs, trained for
 the documented 10 000 steps on the bundled YSD1 lag-5 table through the config driver, must land on the documented
-held-out perplexity / accuracy and on the documented fitted h (which the reference quotes to three digits).  The
-values depend on the random initialisation only weakly except for the CNN AR model, whose tolerance is wider."""
+held-out perplexity / accuracy and on the documented fitted h (which the reference quotes to three digits).
+
+The linear and reference configs do not depend on the initialisation (h = 0.0432576 ... 0.0432609 over 14 seeds).  The CNN
+configs do, and the docs quote ONE run of the reference: profiles/r05_docs_cnn_seeds.jsonl holds 14 seeds of each in the
+deterministic build (every run bit-reproducible: seed 10 twice gives the same h to the last digit), scripts/seed_sweep.py:
+  bear_cnn_bear  h          0.01071 ... 0.01290, mean 0.01203, sd 0.00065   docs 0.0119  (0.2 sd below the mean)
+  bear_cnn_ar    perplexity 3.8500 ... 3.8788,  median 3.8527, sd 0.0069    docs 3.85
+                 accuracy   35.21 ... 35.73 %,  median 35.62,  sd 0.12      docs 35.8    (1.8 sd above the mean)
+The documented values are draws from those distributions; the tolerances of the CNN rows below are mean +- 3 sd of them (the
+regular build adds summation-order noise of +-0.0003 in h at a fixed seed: two runs of seed 10 gave 0.01206 and 0.01244)."""
 import configparser
 import json
 import os
@@ -14,7 +22,7 @@ pytestmark = pytest.mark.gpu
 
 DOCS = {  # config: (kind, which, perplexity, accuracy %, h, perplexity tol, accuracy tol)   docs/usage.rst:258-264
     "bear_lin_ar": ("net", "AR", 3.99, 32.9, None, 0.01, 0.15),
-    "bear_cnn_ar": ("net", "AR", 3.85, 35.8, None, 0.04, 1.5),
+    "bear_cnn_ar": ("net", "AR", 3.85, 35.8, None, 0.035, 0.7),     # observed 3.850 ... 3.879, 35.21 ... 35.73 %
     "bear_stop_ar": ("ref", "AR", 3.84, 36.5, None, 0.01, 0.15),
     "bear_lin_bear": ("net", "BEAR", 3.79, 36.8, 0.0433, 0.006, 0.1),
     "bear_cnn_bear": ("net", "BEAR", 3.79, 36.8, 0.0119, 0.006, 0.1),
@@ -38,6 +46,7 @@ def test_example_config_reproduces_documented_results(name, tmp_path):
     bmm = json.loads(r["heldout_perplex_BMM"])
     assert all(abs(v - 3.79) < 0.006 for v in bmm)                                  # docs/usage.rst:261
     if h is not None:
-        # the CNN's fitted h moves with the summation order of its gradient atomics (0.0120 ... 0.0132 over runs of this build,
-        # chaotic over 10 000 Adam steps; the docs quote one run of the reference); the others are stable to three digits
-        assert abs(float(r["h"]) - h) / h < (0.25 if "cnn" in name else 0.015)
+        if "cnn" in name:     # mean +- 3 sd of the seed distribution (module docstring); the documented 0.0119 lies inside it
+            assert abs(float(r["h"]) - 0.01203) < 3 * 0.00065 and abs(h - 0.01203) < 3 * 0.00065
+        else:                 # stable to three digits
+            assert abs(float(r["h"]) - h) / h < 0.015
