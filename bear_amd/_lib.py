@@ -37,7 +37,7 @@ SYMBOLS = [
     "bear_shard_rows_count", "bear_parse_counts_tsv_shard",
     "bear_kmer_sort_create", "bear_kmer_sort_reduce", "bear_kmer_sort_destroy", "bear_count_last_hip_error", "bear_write_counts_tsv", "bear_fastx_size", "bear_fastx_encode",
     "bear_kmer_order_u64", "bear_gather_rows", "bear_plan_pair_contexts", "bear_plan_pair_info", "bear_plan_attach_cnn_levels", "bear_plan_cnn_level_rows", "bear_cnn_forward_plan_f64",
-    "bear_plan_count_total", "bear_plan_set_count_bound", "bear_deterministic_build",
+    "bear_plan_count_total", "bear_plan_set_count_bound", "bear_deterministic_build", "bear_plan_cnn_window_rows",
 ]
 
 
@@ -142,6 +142,7 @@ def _load():
     L.bear_eval_plan_bytes.argtypes = [vp]
     L.bear_eval_plan_bytes.restype = u64
     L.bear_plan_cnn_level_rows.argtypes = [vp, vp, vp, cint]
+    L.bear_plan_cnn_window_rows.argtypes = [vp, vp, vp, cint]
     L.bear_cnn_forward_plan_f64.argtypes = [vp, vp, vp, u64, cint, cint, cint, cint, vp, vp, vp, vp]
     L.bear_plan_attach_cnn_levels.argtypes = [vp, vp, cint, cint, ctypes.POINTER(cint), vp]
     L.bear_plan_pair_info.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]

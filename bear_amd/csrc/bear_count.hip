@@ -346,6 +346,111 @@ int bear_canonical_order(void *records, uint64_t n, int width, hipStream_t s) {
   return BEAR_ERR_INVALID_ARG;
 }
 
+// ------------------------------------------------------------------ window tables (bear_levels.h, kernels_cnn.h)
+namespace {
+__global__ __launch_bounds__(256) void window_keys_kernel(const unsigned long long *__restrict__ codes, uint64_t n, int shift, unsigned long long mask,
+                                                          unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    keys[i] = (codes[i] >> shift) & mask;
+    vals[i] = (uint32_t)i;
+  }
+}
+// sorted position j belongs to run scan[j] - 1; a run's first position writes the window's record; every position its context's row
+__global__ __launch_bounds__(256) void window_compact_kernel(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ perm, uint64_t n,
+                                                             int shift, unsigned long long fill, const uint32_t *__restrict__ flag,
+                                                             const uint32_t *__restrict__ scan, unsigned long long *__restrict__ out_codes,
+                                                             uint32_t *__restrict__ child_start, uint32_t *__restrict__ row_of_context,
+                                                             uint64_t n_runs) {
+  for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (uint64_t)gridDim.x * 256) {
+    const uint32_t run = scan[j] - 1u;
+    if (flag[j]) {
+      out_codes[run] = (keys[j] << shift) | fill;
+      child_start[run] = (uint32_t)j;
+    }
+    row_of_context[perm[j]] = run;
+    if (j == 0) child_start[n_runs] = (uint32_t)n;
+  }
+}
+}  // namespace
+
+void bear_window_free(bear_window_dev *wt) {
+  if (!wt) return;
+  (void)hipFree(wt->codes);
+  (void)hipFree(wt->row_of_context);
+  (void)hipFree(wt->perm);
+  (void)hipFree(wt->child_start);
+  (void)hipFree(wt->rows);
+  wt->codes = nullptr;
+  wt->row_of_context = wt->perm = wt->child_start = nullptr;
+  wt->rows = nullptr;
+  wt->n = 0;
+  wt->bytes = 0;
+}
+
+int bear_window_build(const unsigned long long *codes, uint64_t n_rows, int pos, int fw, bear_window_dev *out, hipStream_t s) {
+  if (!codes || !out || n_rows == 0 || n_rows > 0xfffffffeull || pos < 0 || fw < 1 || pos + fw > 21) return BEAR_ERR_INVALID_ARG;
+  int st = BEAR_OK;
+  const int shift = 3 * pos;
+  const unsigned long long mask = (1ull << (3 * fw)) - 1ull;      // (fw <= 21: at most 63 bits)
+  unsigned long long fill = 0ull;
+  for (int l = 0; l < 21; ++l)
+    if (l < pos || l >= pos + fw) fill |= 5ull << (3 * l);
+  unsigned long long *keys_in = nullptr, *keys = nullptr;
+  uint32_t *vals_in = nullptr, *flag = nullptr, *scan = nullptr, n_runs = 0;
+  void *temp = nullptr;
+  size_t tb = 0, tb2 = 0;
+  out->pos = pos;
+  out->n = 0;
+  out->codes = nullptr;
+  out->row_of_context = out->perm = out->child_start = nullptr;
+  out->rows = nullptr;
+  out->bytes = 0;
+  CNT_TRY(hipMalloc(&keys_in, n_rows * 8));
+  CNT_TRY(hipMalloc(&keys, n_rows * 8));
+  CNT_TRY(hipMalloc(&vals_in, n_rows * 4));
+  CNT_TRY(hipMalloc(&out->perm, n_rows * 4));
+  CNT_TRY(hipMalloc(&out->row_of_context, n_rows * 4));
+  hipLaunchKernelGGL(window_keys_kernel, dim3(grid_for(n_rows)), dim3(256), 0, s, codes, n_rows, shift, mask, keys_in, vals_in);
+  CNT_TRY(hipGetLastError());
+  CNT_TRY(rocprim::radix_sort_pairs(nullptr, tb, keys_in, keys, vals_in, out->perm, n_rows, 0u, (unsigned)(3 * fw), s));
+  CNT_TRY(hipMalloc(&temp, tb ? tb : 8));
+  CNT_TRY(rocprim::radix_sort_pairs(temp, tb, keys_in, keys, vals_in, out->perm, n_rows, 0u, (unsigned)(3 * fw), s));   // stable: ties keep row order
+  CNT_TRY(hipStreamSynchronize(s));
+  (void)hipFree(temp);
+  temp = nullptr;
+  (void)hipFree(keys_in);
+  keys_in = nullptr;
+  // runs of equal windows (the flag / scan of the prefix levels, on the sorted keys)
+  flag = vals_in;          // (the unsorted row numbers are no longer needed)
+  vals_in = nullptr;
+  CNT_TRY(hipMalloc(&scan, n_rows * 4));
+  hipLaunchKernelGGL(level_flag_kernel, dim3(grid_for(n_rows)), dim3(256), 0, s, keys, n_rows, ~0ull, flag);
+  CNT_TRY(hipGetLastError());
+  CNT_TRY(rocprim::inclusive_scan(nullptr, tb2, flag, scan, n_rows, rocprim::plus<uint32_t>(), s));
+  CNT_TRY(hipMalloc(&temp, tb2 ? tb2 : 8));
+  CNT_TRY(rocprim::inclusive_scan(temp, tb2, flag, scan, n_rows, rocprim::plus<uint32_t>(), s));
+  CNT_TRY(hipMemcpyAsync(&n_runs, scan + (n_rows - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  CNT_TRY(hipStreamSynchronize(s));
+  CNT_TRY(hipMalloc(&out->codes, (size_t)n_runs * 8));
+  CNT_TRY(hipMalloc(&out->child_start, ((size_t)n_runs + 1) * 4));
+  CNT_TRY(hipMalloc(&out->rows, (size_t)n_runs * 16 * sizeof(double)));
+  hipLaunchKernelGGL(window_compact_kernel, dim3(grid_for(n_rows)), dim3(256), 0, s, keys, out->perm, n_rows, shift, fill, flag, scan, out->codes,
+                     out->child_start, out->row_of_context, (uint64_t)n_runs);
+  CNT_TRY(hipGetLastError());
+  CNT_TRY(hipStreamSynchronize(s));
+  out->n = n_runs;
+  out->bytes = (uint64_t)n_runs * (8 + 4 + 128) + n_rows * 8;
+done:
+  if (temp) (void)hipFree(temp);
+  if (keys_in) (void)hipFree(keys_in);
+  if (keys) (void)hipFree(keys);
+  if (vals_in) (void)hipFree(vals_in);
+  if (flag) (void)hipFree(flag);
+  if (scan) (void)hipFree(scan);
+  if (st != BEAR_OK) bear_window_free(out);
+  return st;
+}
+
 void bear_level_free(bear_level_dev *lv) {
   if (!lv) return;
   (void)hipFree(lv->codes);

@@ -352,6 +352,10 @@ struct bear_plan {
   // (kernels_cnn.h, cnn_level_io); levels[k - 1] = level k, k = 1 .. n_cnn_levels
   bear_level_dev cnn_levels[CNN_MAX_LAG];
   int n_cnn_levels, cnn_lag, cnn_fw;
+  // ... and window tables (bear_window_dev) of the LAST n_cnn_windows positions the contexts themselves would evaluate:
+  // cnn_windows[q] is the table of position P - n_cnn_windows + q
+  bear_window_dev cnn_windows[CNN_MAX_WIN];
+  int n_cnn_windows;
   const uint64_t *cnn_codes;
   uint16_t *live2;
   pln_tile *tiles_p, *tiles_u;
@@ -378,6 +382,7 @@ static void plan_free(bear_plan *p) {
   (void)hipFree(p->hist);
   (void)hipFree(p->live);
   for (int k = 0; k < p->n_cnn_levels; ++k) bear_level_free(&p->cnn_levels[k]);
+  for (int q = 0; q < p->n_cnn_windows; ++q) bear_window_free(&p->cnn_windows[q]);
   (void)hipFree(p->live2);
   (void)hipFree(p->tiles_p);
   (void)hipFree(p->tiles_u);
@@ -1765,6 +1770,15 @@ static cnn_level_io cnn_level_positions(const bear_plan *plan, const cnn_dims &D
   io.p_hi = L - D.fw + 1;
   io.p_lo = k == K ? 0 : plan->cnn_levels[k].letters - D.fw + 1;
   io.head = k == 0;
+  if (k == 0) io.p_hi -= plan->n_cnn_windows;          // the contexts' last positions come from window tables
+  return io;
+}
+// the launch over the rows of window table q: its one position, no head, no parent
+static cnn_level_io cnn_window_positions(const bear_plan *plan, const cnn_dims &D, int q) {
+  cnn_level_io io = cnn_all_positions(D);
+  io.p_lo = plan->cnn_windows[q].pos;
+  io.p_hi = io.p_lo + 1;
+  io.head = 0;
   return io;
 }
 static bool cnn_parts_form_forced_off() {      // BEAR_CNN_BACKWARD=1 (cnn_backward_grid): the 64-context form of the backward kernel, which has no position range
@@ -1778,7 +1792,7 @@ static bool cnn_parts_form_forced_off() {      // BEAR_CNN_BACKWARD=1 (cnn_backw
 static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn_dims &D, const uint64_t *kmer_code, uint64_t n_rows,
                                    const double *theta, double *prior_buf, double *t1_buf, double *grad_rows_buf, double eps, int train_ar,
                                    double *packed, hipStream_t s) {
-  const int K = plan->n_cnn_levels;
+  const int K = plan->n_cnn_levels, W = plan->n_cnn_windows;
   const double *params = theta + 1;
   int bw_waves = 0, bw_parts = 0;
   size_t bw_lds = 0;
@@ -1807,7 +1821,7 @@ static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn
       hipLaunchKernelGGL(cnn_level_sum_kernel, dim3((unsigned)sb), dim3(256), 0, s, level_table(k - 1), plan->cnn_levels[k - 1].child_start,
                          n, level_table(k));
     }
-    io.dT1 = (k == 0 && K > 0) ? t1_buf : (k > 0 ? level_table(k) : nullptr);   // level 0 leaves its dT1 rows where its t1 rows were
+    io.dT1 = (k == 0 && (K > 0 || W > 0)) ? t1_buf : (k > 0 ? level_table(k) : nullptr);   // level 0 leaves its dT1 rows where its t1 rows were
     const uint64_t per_block = (uint64_t)cnnq<2>::TILE * (uint64_t)bw_waves;
     uint64_t blocks = (n + per_block - 1) / per_block;
     if (blocks > bw_blocks) blocks = bw_blocks;
@@ -1816,6 +1830,20 @@ static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn
     hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)blocks), dim3(64 * bw_waves), bw_lds, s, level_codes(k), n, D, params,
                        t1_buf, prior_buf, grad_rows_buf, ws->cnn_partials, static_cast<const pln_tile *>(nullptr),
                        static_cast<const uint16_t *>(nullptr), (n + cnnq<2>::TILE - 1) / cnnq<2>::TILE, io);
+    for (int q = 0; k == 0 && q < W; ++q) {      // the window tables of the contexts' last positions: a window's dT1 row = the sum of its contexts'
+      const bear_window_dev &wt = plan->cnn_windows[q];
+      uint64_t sb = (wt.n + 3) / 4;
+      if (sb > (uint64_t)ws->num_cu * 8) sb = (uint64_t)ws->num_cu * 8;
+      hipLaunchKernelGGL(cnn_window_sum_kernel, dim3((unsigned)sb), dim3(256), 0, s, t1_buf, wt.perm, wt.child_start, wt.n, wt.rows);
+      cnn_level_io wio = cnn_window_positions(plan, D, q);
+      wio.accumulate = 1;
+      wio.dT1 = wt.rows;
+      uint64_t wb = (wt.n + per_block - 1) / per_block;
+      if (wb > bw_blocks) wb = bw_blocks;
+      hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)wb), dim3(64 * bw_waves), bw_lds, s, wt.codes, wt.n, D, params,
+                         t1_buf, prior_buf, grad_rows_buf, ws->cnn_partials, static_cast<const pln_tile *>(nullptr),
+                         static_cast<const uint16_t *>(nullptr), (wt.n + cnnq<2>::TILE - 1) / cnnq<2>::TILE, wio);
+    }
   }
   hipLaunchKernelGGL(cnn_finalize_kernel, dim3((D.total + 3) / 4), dim3(256), 0, s, ws->cnn_partials, (int)bw_blocks, D.total, packed + 2);
   HIP_TRY(hipGetLastError());
@@ -1828,7 +1856,12 @@ static void plan_drop_cnn_levels(bear_plan *plan) {
     plan->bytes -= plan->cnn_levels[k].bytes;
     bear_level_free(&plan->cnn_levels[k]);
   }
+  for (int q = 0; q < plan->n_cnn_windows; ++q) {
+    plan->bytes -= plan->cnn_windows[q].bytes;
+    bear_window_free(&plan->cnn_windows[q]);
+  }
   plan->n_cnn_levels = 0;
+  plan->n_cnn_windows = 0;
   plan->cnn_codes = nullptr;
 }
 
@@ -1871,13 +1904,51 @@ int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int 
     below = lv.codes;
     n_below = lv.n;
   }
-  if (plan->n_cnn_levels) {
+  // Window tables for the positions that are left to the contexts themselves (their windows end in the letters below the shortest
+  // prefix level: in a sorted batch those vary from context to context) -- the last CNN_MAX_WIN of them at most, from the last one
+  // up, each only while the batch holds at least eight contexts per distinct window (a table costs a row of one position per
+  // window plus a 128-byte gather per context and direction; a position evaluated per context costs ~25 times that gather).
+  if (!getenv("BEAR_AMD_CNN_NO_WINDOWS")) {
+    const int p_lo0 = plan->n_cnn_levels ? plan->cnn_levels[0].letters - filter_width + 1 : 0;      // level 0 evaluates [p_lo0, P)
+    bear_window_dev built[CNN_MAX_WIN];
+    int nb = 0;
+    for (int p = D.P - 1; p >= p_lo0 && nb < CNN_MAX_WIN; --p) {
+      bear_window_dev wt;
+      const int st = bear_window_build(reinterpret_cast<const unsigned long long *>(kmer_code), plan->n_rows, p, filter_width, &wt, s);
+      if (st != BEAR_OK) {
+        if (st == BEAR_ERR_HIP) g_last_hip_error = bear_count_last_hip_error();
+        for (int q = 0; q < nb; ++q) bear_window_free(&built[q]);
+        plan_drop_cnn_levels(plan);
+        return st;
+      }
+      if (wt.n * 8 > plan->n_rows) {
+        bear_window_free(&wt);
+        break;
+      }
+      built[nb++] = wt;
+    }
+    for (int q = 0; q < nb; ++q) {         // ascending positions: cnn_windows[q] = position P - nb + q
+      plan->cnn_windows[q] = built[nb - 1 - q];
+      plan->bytes += plan->cnn_windows[q].bytes;
+    }
+    plan->n_cnn_windows = nb;
+  }
+  if (plan->n_cnn_levels || plan->n_cnn_windows) {
     plan->cnn_codes = kmer_code;
     plan->cnn_lag = lag;
     plan->cnn_fw = filter_width;
   }
   if (n_levels) *n_levels = plan->n_cnn_levels;
   return BEAR_OK;
+}
+
+int bear_plan_cnn_window_rows(const bear_plan *plan, uint64_t *rows_out, int *pos_out, int capacity) {
+  if (!plan || (capacity > 0 && !rows_out)) return BEAR_ERR_INVALID_ARG;
+  for (int q = 0; q < plan->n_cnn_windows && q < capacity; ++q) {
+    rows_out[q] = plan->cnn_windows[q].n;
+    if (pos_out) pos_out[q] = plan->cnn_windows[q].pos;
+  }
+  return plan->n_cnn_windows;
 }
 
 int bear_plan_cnn_level_rows(const bear_plan *plan, uint64_t *rows_out, int *letters_out, int capacity) {
@@ -1892,13 +1963,29 @@ int bear_plan_cnn_level_rows(const bear_plan *plan, uint64_t *rows_out, int *let
 // The forward pass alone over a plan's prefix levels (evaluation-style callers, bench.py): prior rows and the contexts' layer-1 sums.
 static int cnn_forward_levels(bear_ws *ws, const bear_plan *plan, const cnn_dims &D, const uint64_t *kmer_code, uint64_t n_rows,
                               const double *params, double *prior, double *t1_buf, hipStream_t s) {
-  const int K = plan->n_cnn_levels;
+  const int K = plan->n_cnn_levels, W = plan->n_cnn_windows;
   const size_t fwd_lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)D.fw * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);
+  for (int q = 0; q < W; ++q) {          // the window tables first: one position over the batch's distinct windows
+    const bear_window_dev &wt = plan->cnn_windows[q];
+    const uint64_t groups = (wt.n + 63) / 64;
+    uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
+    if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
+    hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), fwd_lds, s, wt.codes, wt.n, D, params,
+                       static_cast<double *>(nullptr), wt.rows, static_cast<const pln_tile *>(nullptr), static_cast<const uint16_t *>(nullptr),
+                       groups, cnn_window_positions(plan, D, q));
+  }
   for (int k = K; k >= 0; --k) {
     cnn_level_io io = cnn_level_positions(plan, D, k);
     if (k < K) {
       io.t1_parent = plan->cnn_levels[k].rows;                 // level k + 1
       io.parent = plan->cnn_levels[k].parent_of_below;
+    }
+    if (k == 0) {
+      io.n_win = W;
+      for (int q = 0; q < W; ++q) {
+        io.win_rows[q] = plan->cnn_windows[q].rows;
+        io.win_row_of[q] = plan->cnn_windows[q].row_of_context;
+      }
     }
     const uint64_t n = k == 0 ? n_rows : plan->cnn_levels[k - 1].n, groups = (n + 63) / 64;
     uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
@@ -1919,7 +2006,7 @@ int bear_cnn_forward_plan_f64(bear_ws *ws, const bear_plan *plan, const uint64_t
   if (!plan || plan->n_rows != n_rows || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
   if (n_rows == 0) return BEAR_OK;
   if (!kmer_code || !params || !prior || !t1_save || misaligned(t1_save) || (reinterpret_cast<uintptr_t>(prior) & 7u)) return BEAR_ERR_INVALID_ARG;
-  if (!(plan->n_cnn_levels > 0 && plan->cnn_codes == kmer_code && plan->cnn_lag == lag && plan->cnn_fw == filter_width) ||
+  if (!((plan->n_cnn_levels > 0 || plan->n_cnn_windows > 0) && plan->cnn_codes == kmer_code && plan->cnn_lag == lag && plan->cnn_fw == filter_width) ||
       getenv("BEAR_AMD_CNN_NO_LEVELS"))
     return bear_cnn_forward_f64(ws, kmer_code, n_rows, lag, filter_width, num_filters, layer1_width, params, prior, t1_save, stream);
   return cnn_forward_levels(ws, plan, cnn_make_dims(lag, filter_width), kmer_code, n_rows, params, prior, t1_save, static_cast<hipStream_t>(stream));
@@ -1937,7 +2024,7 @@ int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint
   hipStream_t s = static_cast<hipStream_t>(stream);
   const cnn_dims D = cnn_make_dims(lag, filter_width);
   const double *params = theta + 1;
-  if (plan->n_cnn_levels > 0 && plan->cnn_codes == kmer_code && plan->cnn_lag == lag && plan->cnn_fw == filter_width &&
+  if ((plan->n_cnn_levels > 0 || plan->n_cnn_windows > 0) && plan->cnn_codes == kmer_code && plan->cnn_lag == lag && plan->cnn_fw == filter_width &&
       plan->n_live_rows == n_rows && !getenv("BEAR_AMD_CNN_NO_LEVELS") && !cnn_parts_form_forced_off())
     return cnn_train_reduce_levels(ws, plan, D, kmer_code, n_rows, theta, prior_buf, t1_buf, grad_rows_buf, eps, train_ar, packed, s);
   {

@@ -70,6 +70,7 @@ static inline cnn_dims cnn_make_dims(int lag, int fw) {
 // positions that are left).  Forward runs the levels from the shortest prefixes down to the contexts; backward runs them the
 // other way, a level's dT1 rows being the sums of its children's (everything a position does with dT1 is linear in it).  Both
 // are the kernels below with a position range and a row source: a dense sorted table does ~1.3 positions per context, not 6.
+#define CNN_MAX_WIN 3             // window tables a launch may read (the positions the contexts themselves would evaluate)
 struct cnn_level_io {
   int p_lo, p_hi;                 // the positions this launch evaluates
   int head;                       // 1: the rows are contexts -- layer 1 onwards (forward: prior rows; backward: dT1 from the head)
@@ -78,6 +79,10 @@ struct cnn_level_io {
   const uint32_t *parent;         // forward: [n_rows] row of t1_parent
   double *dT1;                    // backward: head -> the contexts' dT1 rows are also written here [n_rows][16] (NULL: not wanted; may be the
                                   // t1 buffer itself); no head -> the rows' dT1 are READ from here
+  // forward: window tables (bear_window_dev) of positions this launch does NOT evaluate itself: a row adds its window's row of each
+  int n_win;
+  const double *win_rows[CNN_MAX_WIN];        // [n_windows][16]
+  const uint32_t *win_row_of[CNN_MAX_WIN];    // [n_rows] the window row of each row of this launch
 };
 static inline cnn_level_io cnn_all_positions(const cnn_dims &D) {
   cnn_level_io io;
@@ -88,6 +93,11 @@ static inline cnn_level_io cnn_all_positions(const cnn_dims &D) {
   io.t1_parent = nullptr;
   io.parent = nullptr;
   io.dT1 = nullptr;
+  io.n_win = 0;
+  for (int q = 0; q < CNN_MAX_WIN; ++q) {
+    io.win_rows[q] = nullptr;
+    io.win_row_of[q] = nullptr;
+  }
   return io;
 }
 
@@ -288,6 +298,18 @@ __global__ __launch_bounds__(CNN_THREADS, 4) void cnn_forward_kernel(const unsig
         const double2 v = src[j];
         t1[2 * j] = v.x;
         t1[2 * j + 1] = v.y;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CNN_MAX_WIN; ++q) {      // positions that come from window tables: one 128-byte gather each (the tables are a few MB)
+      if (q < io.n_win) {
+        const double2 *src = reinterpret_cast<const double2 *>(io.win_rows[q] + (size_t)io.win_row_of[q][i] * CNN_L1);
+#pragma unroll
+        for (int j = 0; j < CNN_L1 / 2; ++j) {
+          const double2 v = src[j];
+          t1[2 * j] += v.x;
+          t1[2 * j + 1] += v.y;
+        }
       }
     }
     // In a k-mer-sorted batch (bear_net.train sorts at upload) the 64 contexts of a wave share their leading letters: a window
@@ -1481,6 +1503,35 @@ __global__ __launch_bounds__(256) void cnn_level_sum_kernel(const double *__rest
     }
     if (c < c1) s2[0] += child_rows[(size_t)c * CNN_L1 + j];
     rows[t] = s2[0] + s2[1];
+  }
+}
+
+// a window's dT1 row from its contexts' rows (bear_window_dev: the contexts of window w are perm[child_start[w] .. child_start[w + 1]),
+// anywhere in the batch): one wave per window, four contexts x 16 units per load instruction (a context's row is 128 contiguous
+// bytes), four such loads in flight; fixed order, no atomics
+__global__ __launch_bounds__(256) void cnn_window_sum_kernel(const double *__restrict__ child_rows, const uint32_t *__restrict__ perm,
+                                                             const uint32_t *__restrict__ child_start, uint64_t n_windows,
+                                                             double *__restrict__ rows) {
+  const uint32_t lane = threadIdx.x & 63u, j = lane & 15u, slot = lane >> 4;
+  const uint64_t wave_id = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * 256) >> 6;
+  for (uint64_t w = wave_id; w < n_windows; w += n_waves) {
+    const uint32_t c0 = child_start[w], c1 = child_start[w + 1];
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    uint32_t c = c0 + slot;
+    for (; c + 12 < c1; c += 16) {
+      uint32_t r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[k] = perm[c + 4 * k];
+      double v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = child_rows[(size_t)r[k] * CNN_L1 + j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s4[k] += v[k];
+    }
+    for (; c < c1; c += 4) s4[0] += child_rows[(size_t)perm[c] * CNN_L1 + j];
+    double v = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    v = cnn_rows_sum(v);                        // the same unit of the four slots (rows of 16 lanes)
+    if (slot == 0) rows[w * CNN_L1 + j] = v;
   }
 }
 

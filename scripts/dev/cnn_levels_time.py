@@ -42,3 +42,8 @@ print(f"{n} kept contexts of {N}; plain step {ms0:.2f} ms")
 print("levels attached:", plan.attach_cnn_levels(packed, LAG, FW), "plan bytes per context", plan.nbytes / n)
 ms1 = timed(lambda: kernels.net_cnn_train_reduce(plan, packed, LAG, FW, theta, bufs, pk))
 print(f"with prefix levels {ms1:.2f} ms; ELBO rel diff {abs((pk[0]-ref[0])/ref[0]).item():.2e}, max grad diff {(pk[2:]-ref[2:]).abs().max().item():.3e} of {ref[2:].abs().max().item():.3e}")
+print("level rows", plan.cnn_level_rows(with_letters=True), "window tables (position, windows)", plan.cnn_window_rows())
+os.environ["BEAR_AMD_CNN_NO_WINDOWS"] = "1"
+plan.attach_cnn_levels(packed, LAG, FW)
+ms2 = timed(lambda: kernels.net_cnn_train_reduce(plan, packed, LAG, FW, theta, bufs, pk))
+print(f"prefix levels without window tables {ms2:.2f} ms; max grad diff {(pk[2:]-ref[2:]).abs().max().item():.3e}")
