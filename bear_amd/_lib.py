@@ -142,7 +142,7 @@ def _load():
     L.bear_eval_plan_bytes.argtypes = [vp]
     L.bear_eval_plan_bytes.restype = u64
     L.bear_plan_cnn_level_rows.argtypes = [vp, vp, vp, cint]
-    L.bear_plan_cnn_window_rows.argtypes = [vp, vp, vp, cint]
+    L.bear_plan_cnn_window_rows.argtypes = [vp, vp, vp, vp, cint]
     L.bear_cnn_forward_plan_f64.argtypes = [vp, vp, vp, u64, cint, cint, cint, cint, vp, vp, vp, vp]
     L.bear_plan_attach_cnn_levels.argtypes = [vp, vp, cint, cint, ctypes.POINTER(cint), vp]
     L.bear_plan_pair_info.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]

@@ -352,10 +352,11 @@ struct bear_plan {
   // (kernels_cnn.h, cnn_level_io); levels[k - 1] = level k, k = 1 .. n_cnn_levels
   bear_level_dev cnn_levels[CNN_MAX_LAG];
   int n_cnn_levels, cnn_lag, cnn_fw;
-  // ... and window tables (bear_window_dev) of the LAST n_cnn_windows positions the contexts themselves would evaluate:
-  // cnn_windows[q] is the table of position P - n_cnn_windows + q
-  bear_window_dev cnn_windows[CNN_MAX_WIN];
-  int n_cnn_windows;
+  // ... and window tables (bear_window_dev) per level k = 0 (the contexts) .. n_cnn_levels: cnn_win[k][q], q < n_cnn_win[k], are the
+  // tables of the LAST n_cnn_win[k] positions of the level's range, ascending
+  bear_window_dev cnn_win[CNN_MAX_LAG + 1][CNN_MAX_WIN];
+  int n_cnn_win[CNN_MAX_LAG + 1];
+  int n_cnn_windows;         // all of them
   const uint64_t *cnn_codes;
   uint16_t *live2;
   pln_tile *tiles_p, *tiles_u;
@@ -382,7 +383,8 @@ static void plan_free(bear_plan *p) {
   (void)hipFree(p->hist);
   (void)hipFree(p->live);
   for (int k = 0; k < p->n_cnn_levels; ++k) bear_level_free(&p->cnn_levels[k]);
-  for (int q = 0; q < p->n_cnn_windows; ++q) bear_window_free(&p->cnn_windows[q]);
+  for (int k = 0; k <= CNN_MAX_LAG; ++k)
+    for (int q = 0; q < p->n_cnn_win[k]; ++q) bear_window_free(&p->cnn_win[k][q]);
   (void)hipFree(p->live2);
   (void)hipFree(p->tiles_p);
   (void)hipFree(p->tiles_u);
@@ -1770,16 +1772,28 @@ static cnn_level_io cnn_level_positions(const bear_plan *plan, const cnn_dims &D
   io.p_hi = L - D.fw + 1;
   io.p_lo = k == K ? 0 : plan->cnn_levels[k].letters - D.fw + 1;
   io.head = k == 0;
-  if (k == 0) io.p_hi -= plan->n_cnn_windows;          // the contexts' last positions come from window tables
+  io.p_hi -= plan->n_cnn_win[k];          // the level's last positions come from its window tables
   return io;
 }
-// the launch over the rows of window table q: its one position, no head, no parent
-static cnn_level_io cnn_window_positions(const bear_plan *plan, const cnn_dims &D, int q) {
+// the launch over the rows of a window table: its one position, no head, no parent
+static cnn_level_io cnn_window_positions(const cnn_dims &D, const bear_window_dev &wt) {
   cnn_level_io io = cnn_all_positions(D);
-  io.p_lo = plan->cnn_windows[q].pos;
+  io.p_lo = wt.pos;
   io.p_hi = io.p_lo + 1;
   io.head = 0;
   return io;
+}
+// what level k's rows put their layer-1 sums together from besides their own positions: the parent level's rows and the window tables
+static void cnn_level_sources(const bear_plan *plan, int k, cnn_level_io &io) {
+  if (k < plan->n_cnn_levels) {
+    io.t1_parent = plan->cnn_levels[k].rows;                 // level k + 1
+    io.parent = plan->cnn_levels[k].parent_of_below;
+  }
+  io.n_win = plan->n_cnn_win[k];
+  for (int q = 0; q < plan->n_cnn_win[k]; ++q) {
+    io.win_rows[q] = plan->cnn_win[k][q].rows;
+    io.win_row_of[q] = plan->cnn_win[k][q].row_of_context;
+  }
 }
 static bool cnn_parts_form_forced_off() {      // BEAR_CNN_BACKWARD=1 (cnn_backward_grid): the 64-context form of the backward kernel, which has no position range
   const char *force = getenv("BEAR_CNN_BACKWARD");
@@ -1792,7 +1806,7 @@ static bool cnn_parts_form_forced_off() {      // BEAR_CNN_BACKWARD=1 (cnn_backw
 static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn_dims &D, const uint64_t *kmer_code, uint64_t n_rows,
                                    const double *theta, double *prior_buf, double *t1_buf, double *grad_rows_buf, double eps, int train_ar,
                                    double *packed, hipStream_t s) {
-  const int K = plan->n_cnn_levels, W = plan->n_cnn_windows;
+  const int K = plan->n_cnn_levels;
   const double *params = theta + 1;
   int bw_waves = 0, bw_parts = 0;
   size_t bw_lds = 0;
@@ -1804,17 +1818,34 @@ static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn
   auto level_rows = [&](int k) { return k == 0 ? n_rows : plan->cnn_levels[k - 1].n; };
   auto level_table = [&](int k) { return k == 0 ? t1_buf : plan->cnn_levels[k - 1].rows; };
   auto level_io = [&](int k) { return cnn_level_positions(plan, D, k); };
-  st = cnn_forward_levels(ws, plan, D, kmer_code, n_rows, params, prior_buf, t1_buf, s);
+  // Level 0 evaluates no position itself (all of them come from its parent level and the window tables): the forward pass then keeps
+  // no layer-1 sums of the contexts -- the backward pass puts them together again from the same rows (cnn_backward_parts_kernel)
+  const cnn_level_io io0 = level_io(0);
+  const bool recompute_t1 = io0.p_lo >= io0.p_hi && !getenv("BEAR_AMD_CNN_KEEP_T1");
+  st = cnn_forward_levels(ws, plan, D, kmer_code, n_rows, params, prior_buf, recompute_t1 ? nullptr : t1_buf, s);
   if (st != BEAR_OK) return st;
   bear_params only_eps;
   memset(&only_eps, 0, sizeof(only_eps));
   only_eps.eps = eps;
   st = launch_prior_plan_grad(ws, plan, prior_buf, only_eps, theta, train_ar, 1, packed, grad_rows_buf, s);   // softmax rows: normalised
   if (st != BEAR_OK) return st;
+  const uint64_t per_block = (uint64_t)cnnq<2>::TILE * (uint64_t)bw_waves;
+  bool first_launch = true;      // the first backward launch writes every row of the partial buffer the finalize reads, the others add
+  auto backward = [&](const unsigned long long *codes, uint64_t n, const double *t1_in, cnn_level_io io) {
+    uint64_t blocks = (n + per_block - 1) / per_block;
+    if (blocks > bw_blocks) blocks = bw_blocks;
+    if (blocks == 0) blocks = 1;
+    if (first_launch) blocks = bw_blocks;
+    io.accumulate = first_launch ? 0 : 1;
+    first_launch = false;
+    hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)blocks), dim3(64 * bw_waves), bw_lds, s, codes, n, D, params, t1_in, prior_buf,
+                       grad_rows_buf, ws->cnn_partials, static_cast<const pln_tile *>(nullptr), static_cast<const uint16_t *>(nullptr),
+                       (n + cnnq<2>::TILE - 1) / cnnq<2>::TILE, io);
+  };
   for (int k = 0; k <= K; ++k) {
     cnn_level_io io = level_io(k);
-    io.accumulate = k > 0;
     const uint64_t n = level_rows(k);
+    const int W = plan->n_cnn_win[k];
     if (k > 0) {        // this level's dT1 rows = the sums of its children's
       uint64_t sb = (n * CNN_L1 + 255) / 256;
       if (sb > (uint64_t)ws->num_cu * 32) sb = (uint64_t)ws->num_cu * 32;
@@ -1822,27 +1853,17 @@ static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn
                          n, level_table(k));
     }
     io.dT1 = (k == 0 && (K > 0 || W > 0)) ? t1_buf : (k > 0 ? level_table(k) : nullptr);   // level 0 leaves its dT1 rows where its t1 rows were
-    const uint64_t per_block = (uint64_t)cnnq<2>::TILE * (uint64_t)bw_waves;
-    uint64_t blocks = (n + per_block - 1) / per_block;
-    if (blocks > bw_blocks) blocks = bw_blocks;
-    if (blocks == 0) blocks = 1;
-    if (k == 0) blocks = bw_blocks;      // the first launch writes every row of the partial buffer the finalize reads
-    hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)blocks), dim3(64 * bw_waves), bw_lds, s, level_codes(k), n, D, params,
-                       t1_buf, prior_buf, grad_rows_buf, ws->cnn_partials, static_cast<const pln_tile *>(nullptr),
-                       static_cast<const uint16_t *>(nullptr), (n + cnnq<2>::TILE - 1) / cnnq<2>::TILE, io);
-    for (int q = 0; k == 0 && q < W; ++q) {      // the window tables of the contexts' last positions: a window's dT1 row = the sum of its contexts'
-      const bear_window_dev &wt = plan->cnn_windows[q];
+    if (k == 0 && recompute_t1) cnn_level_sources(plan, 0, io);
+    // (a level of prefixes whose positions all come from window tables has nothing to do itself: its dT1 rows feed the tables below)
+    if (k == 0 || io.p_lo < io.p_hi) backward(level_codes(k), n, (k == 0 && recompute_t1) ? static_cast<const double *>(nullptr) : t1_buf, io);
+    for (int q = 0; q < W; ++q) {      // the level's window tables: a window's dT1 row = the sum of its rows' (anywhere in the level)
+      const bear_window_dev &wt = plan->cnn_win[k][q];
       uint64_t sb = (wt.n + 3) / 4;
       if (sb > (uint64_t)ws->num_cu * 8) sb = (uint64_t)ws->num_cu * 8;
-      hipLaunchKernelGGL(cnn_window_sum_kernel, dim3((unsigned)sb), dim3(256), 0, s, t1_buf, wt.perm, wt.child_start, wt.n, wt.rows);
-      cnn_level_io wio = cnn_window_positions(plan, D, q);
-      wio.accumulate = 1;
+      hipLaunchKernelGGL(cnn_window_sum_kernel, dim3((unsigned)sb), dim3(256), 0, s, level_table(k), wt.perm, wt.child_start, wt.n, wt.rows);
+      cnn_level_io wio = cnn_window_positions(D, wt);
       wio.dT1 = wt.rows;
-      uint64_t wb = (wt.n + per_block - 1) / per_block;
-      if (wb > bw_blocks) wb = bw_blocks;
-      hipLaunchKernelGGL(cnn_backward_parts_kernel<2>, dim3((unsigned)wb), dim3(64 * bw_waves), bw_lds, s, wt.codes, wt.n, D, params,
-                         t1_buf, prior_buf, grad_rows_buf, ws->cnn_partials, static_cast<const pln_tile *>(nullptr),
-                         static_cast<const uint16_t *>(nullptr), (wt.n + cnnq<2>::TILE - 1) / cnnq<2>::TILE, wio);
+      backward(wt.codes, wt.n, t1_buf, wio);
     }
   }
   hipLaunchKernelGGL(cnn_finalize_kernel, dim3((D.total + 3) / 4), dim3(256), 0, s, ws->cnn_partials, (int)bw_blocks, D.total, packed + 2);
@@ -1856,9 +1877,12 @@ static void plan_drop_cnn_levels(bear_plan *plan) {
     plan->bytes -= plan->cnn_levels[k].bytes;
     bear_level_free(&plan->cnn_levels[k]);
   }
-  for (int q = 0; q < plan->n_cnn_windows; ++q) {
-    plan->bytes -= plan->cnn_windows[q].bytes;
-    bear_window_free(&plan->cnn_windows[q]);
+  for (int k = 0; k <= CNN_MAX_LAG; ++k) {
+    for (int q = 0; q < plan->n_cnn_win[k]; ++q) {
+      plan->bytes -= plan->cnn_win[k][q].bytes;
+      bear_window_free(&plan->cnn_win[k][q]);
+    }
+    plan->n_cnn_win[k] = 0;
   }
   plan->n_cnn_levels = 0;
   plan->n_cnn_windows = 0;
@@ -1904,34 +1928,40 @@ int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int 
     below = lv.codes;
     n_below = lv.n;
   }
-  // Window tables for the positions that are left to the contexts themselves (their windows end in the letters below the shortest
-  // prefix level: in a sorted batch those vary from context to context) -- the last CNN_MAX_WIN of them at most, from the last one
-  // up, each only while the batch holds at least eight contexts per distinct window (a table costs a row of one position per
-  // window plus a 128-byte gather per context and direction; a position evaluated per context costs ~25 times that gather).
+  // Window tables, level by level (level 0 = the contexts): for the level's own positions, from the last one up, CNN_MAX_WIN at most,
+  // each only while the level holds at least eight rows per distinct window (a table costs one position per window plus a 128-byte
+  // gather per row and direction; a position evaluated per row costs ~25 times that gather).
   if (!getenv("BEAR_AMD_CNN_NO_WINDOWS")) {
-    const int p_lo0 = plan->n_cnn_levels ? plan->cnn_levels[0].letters - filter_width + 1 : 0;      // level 0 evaluates [p_lo0, P)
-    bear_window_dev built[CNN_MAX_WIN];
-    int nb = 0;
-    for (int p = D.P - 1; p >= p_lo0 && nb < CNN_MAX_WIN; --p) {
-      bear_window_dev wt;
-      const int st = bear_window_build(reinterpret_cast<const unsigned long long *>(kmer_code), plan->n_rows, p, filter_width, &wt, s);
-      if (st != BEAR_OK) {
-        if (st == BEAR_ERR_HIP) g_last_hip_error = bear_count_last_hip_error();
-        for (int q = 0; q < nb; ++q) bear_window_free(&built[q]);
-        plan_drop_cnn_levels(plan);
-        return st;
+    const int K = plan->n_cnn_levels;
+    for (int k = 0; k <= K; ++k) {
+      const unsigned long long *codes_k = k == 0 ? reinterpret_cast<const unsigned long long *>(kmer_code) : plan->cnn_levels[k - 1].codes;
+      const uint64_t n_k = k == 0 ? plan->n_rows : plan->cnn_levels[k - 1].n;
+      const int L = k == 0 ? lag : plan->cnn_levels[k - 1].letters;
+      const int p_hi = L - filter_width + 1, p_lo = k == K ? 0 : plan->cnn_levels[k].letters - filter_width + 1;
+      bear_window_dev built[CNN_MAX_WIN];
+      int nb = 0;
+      for (int p = p_hi - 1; p >= p_lo && nb < CNN_MAX_WIN && n_k >= 64; --p) {
+        bear_window_dev wt;
+        const int st = bear_window_build(codes_k, n_k, p, filter_width, &wt, s);
+        if (st != BEAR_OK) {
+          if (st == BEAR_ERR_HIP) g_last_hip_error = bear_count_last_hip_error();
+          for (int q = 0; q < nb; ++q) bear_window_free(&built[q]);
+          plan_drop_cnn_levels(plan);
+          return st;
+        }
+        if (wt.n * 8 > n_k) {
+          bear_window_free(&wt);
+          break;
+        }
+        built[nb++] = wt;
       }
-      if (wt.n * 8 > plan->n_rows) {
-        bear_window_free(&wt);
-        break;
+      for (int q = 0; q < nb; ++q) {         // ascending positions
+        plan->cnn_win[k][q] = built[nb - 1 - q];
+        plan->bytes += plan->cnn_win[k][q].bytes;
       }
-      built[nb++] = wt;
+      plan->n_cnn_win[k] = nb;
+      plan->n_cnn_windows += nb;
     }
-    for (int q = 0; q < nb; ++q) {         // ascending positions: cnn_windows[q] = position P - nb + q
-      plan->cnn_windows[q] = built[nb - 1 - q];
-      plan->bytes += plan->cnn_windows[q].bytes;
-    }
-    plan->n_cnn_windows = nb;
   }
   if (plan->n_cnn_levels || plan->n_cnn_windows) {
     plan->cnn_codes = kmer_code;
@@ -1942,12 +1972,16 @@ int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int 
   return BEAR_OK;
 }
 
-int bear_plan_cnn_window_rows(const bear_plan *plan, uint64_t *rows_out, int *pos_out, int capacity) {
+int bear_plan_cnn_window_rows(const bear_plan *plan, uint64_t *rows_out, int *pos_out, int *level_out, int capacity) {
   if (!plan || (capacity > 0 && !rows_out)) return BEAR_ERR_INVALID_ARG;
-  for (int q = 0; q < plan->n_cnn_windows && q < capacity; ++q) {
-    rows_out[q] = plan->cnn_windows[q].n;
-    if (pos_out) pos_out[q] = plan->cnn_windows[q].pos;
-  }
+  int t = 0;
+  for (int k = 0; k <= plan->n_cnn_levels; ++k)
+    for (int q = 0; q < plan->n_cnn_win[k]; ++q, ++t)
+      if (t < capacity) {
+        rows_out[t] = plan->cnn_win[k][q].n;
+        if (pos_out) pos_out[t] = plan->cnn_win[k][q].pos;
+        if (level_out) level_out[t] = k;
+      }
   return plan->n_cnn_windows;
 }
 
@@ -1963,30 +1997,20 @@ int bear_plan_cnn_level_rows(const bear_plan *plan, uint64_t *rows_out, int *let
 // The forward pass alone over a plan's prefix levels (evaluation-style callers, bench.py): prior rows and the contexts' layer-1 sums.
 static int cnn_forward_levels(bear_ws *ws, const bear_plan *plan, const cnn_dims &D, const uint64_t *kmer_code, uint64_t n_rows,
                               const double *params, double *prior, double *t1_buf, hipStream_t s) {
-  const int K = plan->n_cnn_levels, W = plan->n_cnn_windows;
+  const int K = plan->n_cnn_levels;
   const size_t fwd_lds = sizeof(double) * (BEAR_EXPTAB_N + (size_t)D.fw * 6 * CNN_NF + (CNN_THREADS / 64) * CNN_FWD_SCRATCH);
-  for (int q = 0; q < W; ++q) {          // the window tables first: one position over the batch's distinct windows
-    const bear_window_dev &wt = plan->cnn_windows[q];
-    const uint64_t groups = (wt.n + 63) / 64;
-    uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
-    if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
-    hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), fwd_lds, s, wt.codes, wt.n, D, params,
-                       static_cast<double *>(nullptr), wt.rows, static_cast<const pln_tile *>(nullptr), static_cast<const uint16_t *>(nullptr),
-                       groups, cnn_window_positions(plan, D, q));
-  }
   for (int k = K; k >= 0; --k) {
+    for (int q = 0; q < plan->n_cnn_win[k]; ++q) {          // the level's window tables first: one position over its distinct windows
+      const bear_window_dev &wt = plan->cnn_win[k][q];
+      const uint64_t groups = (wt.n + 63) / 64;
+      uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
+      if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
+      hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), fwd_lds, s, wt.codes, wt.n, D, params,
+                         static_cast<double *>(nullptr), wt.rows, static_cast<const pln_tile *>(nullptr), static_cast<const uint16_t *>(nullptr),
+                         groups, cnn_window_positions(D, wt));
+    }
     cnn_level_io io = cnn_level_positions(plan, D, k);
-    if (k < K) {
-      io.t1_parent = plan->cnn_levels[k].rows;                 // level k + 1
-      io.parent = plan->cnn_levels[k].parent_of_below;
-    }
-    if (k == 0) {
-      io.n_win = W;
-      for (int q = 0; q < W; ++q) {
-        io.win_rows[q] = plan->cnn_windows[q].rows;
-        io.win_row_of[q] = plan->cnn_windows[q].row_of_context;
-      }
-    }
+    cnn_level_sources(plan, k, io);
     const uint64_t n = k == 0 ? n_rows : plan->cnn_levels[k - 1].n, groups = (n + 63) / 64;
     uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
     if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;

@@ -1048,12 +1048,39 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
       gp[b] = 0.0;
     }
     if (live) {
+      if (io.head && !t1_save) {
+        // the forward pass kept no layer-1 sums: every position of these contexts came from a parent row and window rows
+        // (cnn_level_io), and the sums are put together again exactly as the forward kernel did -- two or three gathers that
+        // mostly hit the caches instead of a 128-byte row written and read back per context
+        if (io.t1_parent) {
+          const double2 *src = reinterpret_cast<const double2 *>(io.t1_parent + (size_t)io.parent[i] * CNN_L1 + h * JH);
+#pragma unroll
+          for (int j = 0; j < JH / 2; ++j) {
+            const double2 v = src[j];
+            t1[2 * j] = v.x;
+            t1[2 * j + 1] = v.y;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < CNN_MAX_WIN; ++q) {
+          if (q < io.n_win) {
+            const double2 *src = reinterpret_cast<const double2 *>(io.win_rows[q] + (size_t)io.win_row_of[q][i] * CNN_L1 + h * JH);
+#pragma unroll
+            for (int j = 0; j < JH / 2; ++j) {
+              const double2 v = src[j];
+              t1[2 * j] += v.x;
+              t1[2 * j + 1] += v.y;
+            }
+          }
+        }
+      } else {
       const double2 *src = reinterpret_cast<const double2 *>((io.head ? t1_save : io.dT1) + i * CNN_L1 + h * JH);
 #pragma unroll
       for (int j = 0; j < JH / 2; ++j) {
         const double2 v = src[j];
         t1[2 * j] = v.x;
         t1[2 * j + 1] = v.y;
+      }
       }
       if (io.head) {
 #pragma unroll

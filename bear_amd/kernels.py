@@ -202,13 +202,14 @@ class Plan:
         return int(n.value)
 
     def cnn_window_rows(self):
-        """[(position, distinct windows)] of the window tables attached with the prefix levels (``bear_plan_cnn_window_rows``)."""
-        n = int(_lib.lib().bear_plan_cnn_window_rows(self._h, None, None, 0))
+        """[(level, position, distinct windows)] of the window tables attached with the prefix levels (``bear_plan_cnn_window_rows``;
+        level 0 = the contexts)."""
+        n = int(_lib.lib().bear_plan_cnn_window_rows(self._h, None, None, None, 0))
         if n <= 0:
             return []
-        rows, pos = (ctypes.c_uint64 * n)(), (ctypes.c_int * n)()
-        _lib.lib().bear_plan_cnn_window_rows(self._h, rows, pos, n)
-        return [(int(pos[q]), int(rows[q])) for q in range(n)]
+        rows, pos, lev = (ctypes.c_uint64 * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
+        _lib.lib().bear_plan_cnn_window_rows(self._h, rows, pos, lev, n)
+        return [(int(lev[q]), int(pos[q]), int(rows[q])) for q in range(n)]
 
     def cnn_level_rows(self, with_letters=False):
         """Rows of the attached prefix levels 1 .. n (``bear_plan_cnn_level_rows``); [] without levels.  ``with_letters``: (rows,

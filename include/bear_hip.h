@@ -193,14 +193,14 @@ int bear_plan_attach_cnn_levels(bear_plan *plan, const uint64_t *kmer_code, int 
 /* Rows and prefix lengths (letters) of the attached levels 1 .. n (rows_out [host, nullable when capacity = 0], letters_out [host,
  * nullable]); returns their number.  A prefix length whose prefixes hardly repeat is skipped: the level below evaluates its position too. */
 int bear_plan_cnn_level_rows(const bear_plan *plan, uint64_t *rows_out, int *letters_out, int capacity);
-/* bear_plan_attach_cnn_levels also attaches WINDOW TABLES for the positions that are left to the contexts themselves (the last ones:
- * their windows end in the letters that vary from context to context in a sorted batch): what a position adds to a context's layer-1
- * sums depends on its filter_width-letter window alone, and a batch holds at most 6^filter_width distinct windows (65 536 for eight
- * letters of ACGT) however many contexts it has.  Forward: the position is evaluated once per distinct window, a context gathers
- * its window's row; backward: a window's dT1 row is the sum of its contexts' rows (listed by window at attach time: fixed order, no
- * atomics), then the position's backward pass over the windows.  A table is attached while the batch holds >= 8 contexts per
- * distinct window; 8 bytes per context and table.  Rows and positions of the attached tables (nullable outputs); returns their number. */
-int bear_plan_cnn_window_rows(const bear_plan *plan, uint64_t *rows_out, int *pos_out, int capacity);
+/* bear_plan_attach_cnn_levels also attaches WINDOW TABLES to every level (level 0 = the contexts) for the positions the level's rows
+ * would evaluate themselves, from the last one up: what a position adds to a row's layer-1 sums depends on its filter_width-letter
+ * window alone, and a batch holds at most 6^filter_width distinct windows (65 536 for eight letters of ACGT) however many rows a
+ * level has.  Forward: the position is evaluated once per distinct window, a row gathers its window's row; backward: a window's dT1
+ * row is the sum of its rows' dT1 rows (listed by window at attach time: fixed order, no atomics), then the position's backward pass
+ * over the windows.  A table is attached while the level holds >= 8 rows per distinct window (at most 3 per level); 8 bytes per row
+ * and table.  Distinct windows, positions and levels of the attached tables (nullable outputs); returns their number. */
+int bear_plan_cnn_window_rows(const bear_plan *plan, uint64_t *rows_out, int *pos_out, int *level_out, int capacity);
 /* bear_cnn_forward_f64 over the plan's prefix levels when they were attached for this kmer_code pointer, lag and filter width
  * (the plain forward otherwise); t1_save is required. */
 int bear_cnn_forward_plan_f64(bear_ws *ws, const bear_plan *plan, const uint64_t *kmer_code, uint64_t n_rows, int lag, int filter_width,
