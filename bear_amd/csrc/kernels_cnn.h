@@ -1136,28 +1136,42 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
 #pragma unroll
       for (int j = 0; j < JH; ++j) t1[j] = r1 * (t1[j] - ma - n1[j] * mb);     // dT1
     }
-    // the 117 small gradient columns leave through rounds of 32 staged columns.  d weights2[j][b] is column j 5 + b of the
-    // parameter vector; part h owns columns [W2Q h, W2Q h + W2Q): round rd stages its columns COLQ rd .. COLQ rd + COLQ - 1 at
-    // staging column COLQ h + (k - COLQ rd)
+    // d weights2[j][b] = the sum over the tile's contexts of e1[ctx][j] dz[ctx][b]: ONE 16 x 16 accumulation on the matrix core over
+    // K = contexts (rows = units, columns = letters: 5 of 16 used) -- e1 and dz staged once (13 LDS writes, 16 reads per lane)
+    // instead of three rounds of 32 staged product columns and their column sums (96 LDS operations per lane and tile)
 #pragma unroll
-    for (int rd = 0; rd < 3; ++rd) {
+    for (int j = 0; j < JH; ++j) E[(h * JH + j) * ES + ctx] = e1[j];
+    if (h == 0) {
 #pragma unroll
-      for (int kk = 0; kk < C::COLQ; ++kk) {
-        const int k = C::COLQ * rd + kk;
-        if (k < C::W2Q) E[(h * C::COLQ + kk) * CS + ctx] = e1[k / 5] * dz[k % 5];
-      }
-      const double cs = cnnq_colsum<Q>(E, lane);
-      const uint32_t c = lane & 31u, ch = c / C::COLQ, k = C::COLQ * rd + c % C::COLQ;
-      if (k < (uint32_t)C::W2Q) cnn_lds_add(G + D.oW2 + C::W2Q * (int)ch + (int)k, cs);
-      __builtin_amdgcn_sched_barrier(0);   // one round's products at a time (hoisted together they spilled 116 registers)
-    }
-    if (h == 0) {                          // d intercept2: five columns
-#pragma unroll
-      for (int b = 0; b < 5; ++b) E[b * CS + ctx] = dz[b];
+      for (int b = 0; b < 5; ++b) E[(CNN_L1 + b) * ES + ctx] = dz[b];
     }
     {
-      const double cs = cnnq_colsum<Q>(E, lane);
-      if ((lane & 31u) < 5u) cnn_lds_add(G + D.ob2 + (int)(lane & 31u), cs);
+      cnn_d4 acc = {0.0, 0.0, 0.0, 0.0};
+      const bool col_in = lr < 5u;
+      const double *arow = E + lr * ES + lq, *brow = E + (CNN_L1 + (col_in ? lr : 0u)) * ES + lq;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const double a = arow[4 * ks], bv = col_in ? brow[4 * ks] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc, 0, 0, 0);
+      }
+      if (col_in) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cnn_lds_add(G + D.oW2 + ((int)lq + 4 * r) * 5 + (int)lr, acc[r]);
+      }
+    }
+    {                                      // d intercept2[b]: the column sums of the staged dz rows (lane: letter lane & 31, half of the contexts)
+      const uint32_t c = lane_t & 31u;
+      if (c < 5u) {
+        const double2 *src = reinterpret_cast<const double2 *>(E + (CNN_L1 + c) * ES + (lane_t >> 5) * (TILE / 2));
+        double s2[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < TILE / 4; ++k) {
+          const double2 v = src[k];
+          s2[0] += v.x;
+          s2[1] += v.y;
+        }
+        cnn_lds_add(G + D.ob2 + (int)c, s2[0] + s2[1]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < JH; ++j) {
@@ -1175,6 +1189,7 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
       for (int j = 0; j < JH / 2; ++j) o[j] = make_double2(t1[2 * j], t1[2 * j + 1]);
     }
     }
+    if (io.p_lo >= io.p_hi) continue;      // rows whose positions all come from window tables / the parent level: nothing else to do here
 #pragma unroll
     for (int j = 0; j < JH; ++j) T[(h * JH + j) * ES + ctx] = t1[j];
     // positions whose window every context of the tile shares (see cnn_backward_shared_window): handled here, once per tile,
