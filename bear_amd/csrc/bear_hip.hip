@@ -97,6 +97,9 @@ int bear_ws_create(int device, bear_ws **out) {
                              reinterpret_cast<const void *>(dm_linear_plan_kernel<false, true, true>),
                              reinterpret_cast<const void *>(dm_linear_plan_kernel<true, true, true>)})
         if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_lin));
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(cnn_backward_head_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)cnh_lds_bytes());
       if (e == hipSuccess) {
         // {r_i, -log r_i}: r_i = 1 / midpoint of the i-th mantissa cell of [0.5, 1) (bear_log_tab)
         double tab[2 * BEAR_LOGTAB_N];
@@ -1855,7 +1858,15 @@ static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn
     io.dT1 = (k == 0 && (K > 0 || W > 0)) ? t1_buf : (k > 0 ? level_table(k) : nullptr);   // level 0 leaves its dT1 rows where its t1 rows were
     if (k == 0 && recompute_t1) cnn_level_sources(plan, 0, io);
     // (a level of prefixes whose positions all come from window tables has nothing to do itself: its dT1 rows feed the tables below)
-    if (k == 0 || io.p_lo < io.p_hi) backward(level_codes(k), n, (k == 0 && recompute_t1) ? static_cast<const double *>(nullptr) : t1_buf, io);
+    if (k == 0 && io.p_lo >= io.p_hi && !getenv("BEAR_AMD_CNN_NO_HEAD_KERNEL")) {
+      // the contexts evaluate no position themselves: the head-only kernel (kernels_cnn.h); always the step's first backward launch
+      io.accumulate = first_launch ? 0 : 1;
+      first_launch = false;
+      hipLaunchKernelGGL(cnn_backward_head_kernel, dim3((unsigned)bw_blocks), dim3(CNH_WAVES * 64), cnh_lds_bytes(), s, n, D, params,
+                         recompute_t1 ? static_cast<const double *>(nullptr) : t1_buf, prior_buf, grad_rows_buf, ws->cnn_partials, io);
+    } else if (k == 0 || io.p_lo < io.p_hi) {
+      backward(level_codes(k), n, (k == 0 && recompute_t1) ? static_cast<const double *>(nullptr) : t1_buf, io);
+    }
     for (int q = 0; q < W; ++q) {      // the level's window tables: a window's dT1 row = the sum of its rows' (anywhere in the level)
       const bear_window_dev &wt = plan->cnn_win[k][q];
       uint64_t sb = (wt.n + 3) / 4;

@@ -1530,6 +1530,199 @@ __global__ __launch_bounds__(cnnq<Q>::WAVES * 64) void cnn_backward_parts_kernel
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, head only
+// The contexts of a step whose positions ALL come from their parent level and window tables (bear_plan_attach_cnn_levels on a
+// table dense enough: every reference-sized batch) need nothing from cnn_backward_parts_kernel but its head: layer 1, softmax and
+// layer-2 backward, their dT1 row, and the 117 gradients of layer 2 / layer 1's norm.  A kernel of its own for that: no position
+// loop, hence a third of the registers (three waves per SIMD instead of two), the gradient sums in REGISTERS across a wave's
+// tiles (d weights2 in the accumulator of one f64 MFMA per four contexts, the others per lane) instead of staging rounds and LDS
+// atomics per tile, and one fixed-order sum over lanes and waves at the end -- no atomics at all: reproducible bit for bit.
+// Same lane layout as the part kernel: a wave tile = 32 contexts x 2 halves, half h owns layer-1 units [8 h, 8 h + 8).
+#define CNH_WAVES 12
+#define CNH_NG (CNN_L1 * 5 + 5 + 2 * CNN_L1)      // d weights2 [16][5] | d intercept2 [5] | d scale1 [16] | d intercept1 [16]
+#define CNH_ES 36
+#define CNH_WAVE_DOUBLES ((CNN_L1 + 5) * CNH_ES)
+static inline size_t cnh_lds_bytes() { return sizeof(double) * (BEAR_EXPTAB_N + 2 * CNN_L1 + CNN_L1 * 5 + (size_t)CNH_WAVES * (CNH_WAVE_DOUBLES + CNH_NG)); }
+
+__global__ __launch_bounds__(CNH_WAVES * 64) void cnn_backward_head_kernel(uint64_t n_rows, cnn_dims D, const double *__restrict__ params,
+                                                                           const double *__restrict__ t1_save, const double *__restrict__ prior,
+                                                                           const double *__restrict__ grad_prior, double *__restrict__ partials,
+                                                                           const cnn_level_io io) {
+  constexpr int TILE = 32, JH = CNN_L1 / 2, ES = CNH_ES, KS = TILE / 4;
+  extern __shared__ __attribute__((aligned(16))) double cnn_lds[];
+  double *exptab = cnn_lds, *Ps1 = exptab + BEAR_EXPTAB_N, *Pb1 = Ps1 + CNN_L1, *PW2 = Pb1 + CNN_L1;
+  const uint32_t lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  double *E = PW2 + CNN_L1 * 5 + wave * CNH_WAVE_DOUBLES;                 // [16 + 5][ES]: e1 rows, dz rows
+  double *GW = PW2 + CNN_L1 * 5 + n_waves * CNH_WAVE_DOUBLES + wave * CNH_NG;   // this wave's sums
+  for (int k = threadIdx.x; k < BEAR_EXPTAB_N; k += blockDim.x) exptab[k] = exp2((double)k * (1.0 / BEAR_EXPTAB_N));
+  for (int k = threadIdx.x; k < CNN_L1; k += blockDim.x) {
+    Ps1[k] = params[D.os1 + k];
+    Pb1[k] = params[D.ob1 + k];
+  }
+  for (int k = threadIdx.x; k < CNN_L1 * 5; k += blockDim.x) PW2[k] = params[D.oW2 + k];
+  __syncthreads();
+  const uint32_t ctx = lane & (TILE - 1), h = lane / TILE, lq = lane >> 4, lr = lane & 15u;
+  cnn_d4 acc_w2 = {0.0, 0.0, 0.0, 0.0};
+  double acc_s1[JH], acc_b1[JH], acc_b2[5];
+#pragma unroll
+  for (int j = 0; j < JH; ++j) acc_s1[j] = acc_b1[j] = 0.0;
+#pragma unroll
+  for (int b = 0; b < 5; ++b) acc_b2[b] = 0.0;
+  const uint64_t n_tiles = (n_rows + TILE - 1) / TILE;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * n_waves + wave, wave_cnt = (uint64_t)gridDim.x * n_waves;
+  for (uint64_t g = n_tiles * wave_id / wave_cnt; g < n_tiles * (wave_id + 1) / wave_cnt; ++g) {
+    const uint64_t i = g * TILE + ctx;
+    const bool live = i < n_rows;
+    double t1[JH], n1[JH], e1[JH], dy1[JH];
+#pragma unroll
+    for (int j = 0; j < JH; ++j) t1[j] = 0.0;
+    double pr[5], gp[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      pr[b] = 0.2;
+      gp[b] = 0.0;
+    }
+    if (live) {
+      if (!t1_save) {      // the layer-1 sums put together again from the rows the forward pass took them from (cnn_level_io)
+        if (io.t1_parent) {
+          const double2 *src = reinterpret_cast<const double2 *>(io.t1_parent + (size_t)io.parent[i] * CNN_L1 + h * JH);
+#pragma unroll
+          for (int j = 0; j < JH / 2; ++j) {
+            const double2 v = src[j];
+            t1[2 * j] = v.x;
+            t1[2 * j + 1] = v.y;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < CNN_MAX_WIN; ++q) {
+          if (q < io.n_win) {
+            const double2 *src = reinterpret_cast<const double2 *>(io.win_rows[q] + (size_t)io.win_row_of[q][i] * CNN_L1 + h * JH);
+#pragma unroll
+            for (int j = 0; j < JH / 2; ++j) {
+              const double2 v = src[j];
+              t1[2 * j] += v.x;
+              t1[2 * j + 1] += v.y;
+            }
+          }
+        }
+      } else {
+        const double2 *src = reinterpret_cast<const double2 *>(t1_save + i * CNN_L1 + h * JH);
+#pragma unroll
+        for (int j = 0; j < JH / 2; ++j) {
+          const double2 v = src[j];
+          t1[2 * j] = v.x;
+          t1[2 * j + 1] = v.y;
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        pr[b] = prior[i * 5 + b];
+        gp[b] = grad_prior[i * 5 + b];
+      }
+    }
+    // layer 1 forward again (norm over the 16 units of the two halves, elu), as the part kernel
+    double r1;
+    {
+      double mu = 0.0;
+#pragma unroll
+      for (int j = 0; j < JH; ++j) mu += t1[j];
+      mu = cnnq_psum<2>(mu) * (1.0 / CNN_L1);
+      double var = 0.0;
+#pragma unroll
+      for (int j = 0; j < JH; ++j) {
+        n1[j] = t1[j] - mu;
+        var = __builtin_fma(n1[j], n1[j], var);
+      }
+      r1 = cnn_rsqrt(cnnq_psum<2>(var) * (1.0 / CNN_L1) + CNN_LN_EPS);
+    }
+    double dz[5], sg = 0.0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) sg = __builtin_fma(pr[b], gp[b], sg);
+#pragma unroll
+    for (int b = 0; b < 5; ++b) dz[b] = pr[b] * (gp[b] - sg);
+    {
+      double ma = 0.0, mb = 0.0;
+#pragma unroll
+      for (int j = 0; j < JH; ++j) {
+        n1[j] *= r1;
+        double d1;
+        e1[j] = cnn_elu(__builtin_fma(Ps1[h * JH + j], n1[j], Pb1[h * JH + j]), exptab, d1);
+        double de = 0.0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) de = __builtin_fma(PW2[(h * JH + j) * 5 + b], dz[b], de);
+        dy1[j] = de * d1;
+        const double dn = dy1[j] * Ps1[h * JH + j];
+        t1[j] = dn;
+        ma += dn;
+        mb = __builtin_fma(dn, n1[j], mb);
+        acc_s1[j] = __builtin_fma(dy1[j], n1[j], acc_s1[j]);       // d scale1, d intercept1: per lane, summed over lanes at the end
+        acc_b1[j] += dy1[j];
+      }
+      ma = cnnq_psum<2>(ma) * (1.0 / CNN_L1);
+      mb = cnnq_psum<2>(mb) * (1.0 / CNN_L1);
+#pragma unroll
+      for (int j = 0; j < JH; ++j) t1[j] = r1 * (t1[j] - ma - n1[j] * mb);     // dT1
+    }
+#pragma unroll
+    for (int b = 0; b < 5; ++b) acc_b2[b] += dz[b];                 // (both halves hold the context's dz: half 0 is counted at the end)
+    // d weights2 += e1 (x) dz over the tile's contexts: the MFMA accumulator carries the sum across the wave's tiles
+#pragma unroll
+    for (int j = 0; j < JH; ++j) E[(h * JH + j) * ES + ctx] = e1[j];
+    if (h == 0) {
+#pragma unroll
+      for (int b = 0; b < 5; ++b) E[(CNN_L1 + b) * ES + ctx] = dz[b];
+    }
+    {
+      const bool col_in = lr < 5u;
+      const double *arow = E + lr * ES + lq, *brow = E + (CNN_L1 + (col_in ? lr : 0u)) * ES + lq;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const double a = arow[4 * ks], bv = col_in ? brow[4 * ks] : 0.0;
+        acc_w2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc_w2, 0, 0, 0);
+      }
+    }
+    if (io.dT1 && live) {
+      double2 *o = reinterpret_cast<double2 *>(io.dT1 + i * CNN_L1 + h * JH);
+#pragma unroll
+      for (int j = 0; j < JH / 2; ++j) o[j] = make_double2(t1[2 * j], t1[2 * j + 1]);
+    }
+  }
+  // this wave's sums into its LDS slot: sums over the 32 contexts of a half in a fixed butterfly, every entry written by one lane
+  if (lr < 5u) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) GW[((int)lq + 4 * r) * 5 + (int)lr] = acc_w2[r];
+  }
+#pragma unroll
+  for (int b = 0; b < 5; ++b) {
+    const double v = cnn_half_sum_all(acc_b2[b]);
+    if (lane == 0u) GW[CNN_L1 * 5 + b] = v;
+  }
+#pragma unroll
+  for (int j = 0; j < JH; ++j) {
+    const double vs = cnn_half_sum_all(acc_s1[j]), vb = cnn_half_sum_all(acc_b1[j]);
+    if (ctx == 0u) {
+      GW[CNN_L1 * 5 + 5 + h * JH + j] = vs;
+      GW[CNN_L1 * 5 + 5 + CNN_L1 + h * JH + j] = vb;
+    }
+  }
+  __syncthreads();
+  // the block's row of the partial buffer: the waves' sums in wave order; everything else of the row is zero (first launch of a
+  // step) or untouched (a later one)
+  const double *G0 = PW2 + CNN_L1 * 5 + n_waves * CNH_WAVE_DOUBLES;
+  double *row = partials + (size_t)blockIdx.x * D.total;
+  if (!io.accumulate)
+    for (int k = threadIdx.x; k < D.total; k += blockDim.x) row[k] = 0.0;
+  __syncthreads();
+  for (int k = threadIdx.x; k < CNH_NG; k += blockDim.x) {
+    double v = 0.0;
+    for (uint32_t w = 0; w < n_waves; ++w) v += G0[w * CNH_NG + k];
+    const int dst = k < CNN_L1 * 5 ? D.oW2 + k : k < CNN_L1 * 5 + 5 ? D.ob2 + (k - CNN_L1 * 5)
+                  : k < CNN_L1 * 5 + 5 + CNN_L1 ? D.os1 + (k - CNN_L1 * 5 - 5) : D.ob1 + (k - CNN_L1 * 5 - 5 - CNN_L1);
+    row[dst] = io.accumulate ? row[dst] + v : v;
+  }
+}
+
 // a level's dT1 rows from its children's (the children of a row are neighbours): one thread per (row, unit)
 __global__ __launch_bounds__(256) void cnn_level_sum_kernel(const double *__restrict__ child_rows, const uint32_t *__restrict__ child_start,
                                                             uint64_t n_rows, double *__restrict__ rows) {

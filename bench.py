@@ -555,6 +555,7 @@ def main():
         # evaluated once per distinct prefix of the batch, forward and backward
         n_levels = plan_kept.attach_cnn_levels(packed_kept, lag, fw)
         level_rows, level_letters = plan_kept.cnn_level_rows(with_letters=True)
+        window_tables = plan_kept.cnn_window_rows()         # [(level, position, distinct windows)]
         kept_ms = timed(lambda: kernels.net_cnn_train_reduce(plan_kept, packed_kept, lag, fw, theta, bufs_kept, pk), 3)
         levels_same = bool(abs(float(pk[0] - pk_plain[0])) <= 1e-12 * abs(float(pk_plain[0]))
                            and float((pk[2:] - pk_plain[2:]).abs().max()) <= 1e-10 * float(pk_plain[2:].abs().max()))
@@ -573,7 +574,9 @@ def main():
         pos_f = (cnn_f - flops_cnn(fw, fw)[0]) / (lag - fw)            # one position's share of a context's forward flops
         head_f = cnn_f - (lag - fw + 1) * pos_f
         lv, ll = [n_kept] + level_rows, [lag] + level_letters + [fw - 1]      # level k evaluates the positions p with p + fw in (ll[k + 1], ll[k]]
-        pos_evals = sum(r * (ll[k] - ll[k + 1]) for k, r in enumerate(lv))
+        # ... minus the positions a level takes from its window tables (evaluated once per distinct window instead)
+        n_win = [sum(1 for w in window_tables if w[0] == k) for k in range(len(lv))]
+        pos_evals = sum(r * (ll[k] - ll[k + 1] - n_win[k]) for k, r in enumerate(lv)) + sum(w[2] for w in window_tables)
         exec_f = pos_evals * pos_f + n_kept * head_f
         extra["cnn_head"] = {"lag": lag, "filter_width": fw, "forward_ms": f_ms, "backward_ms": b_ms,
                              "rates_forward_rows_in_kmer_order": cnn_rates(cnn_f * n, None, fs_ms),
@@ -587,13 +590,16 @@ def main():
                              "train_step_ms_without_prefix_levels": kept_plain_ms,
                              "prefix_levels": {"attached": n_levels, "rows": lv, "prefix_letters": ll[:-1], "position_evaluations_per_context": pos_evals / max(n_kept, 1),
                                                "equals_step_without_levels": levels_same,
+                                               "window_tables_level_position_windows": [list(w) for w in window_tables],
                                                "forward_ms": kept_fwd_ms,
                                                "forward_ms_scaled_to_all_contexts": kept_fwd_ms / max(kept_frac, 1e-9),
                                                "rates_forward": cnn_rates(cnn_f * n_kept, exec_f, kept_fwd_ms),
                                                "rates_step_forward_plus_backward": cnn_rates((cnn_f + cnn_b) * n_kept, exec_f * (1 + cnn_b / cnn_f),
                                                                                            kept_ms - extra["net_with_gradient_rows"]["kernel_ms_rows_asserted_normalized"] * kept_frac),
                                                "note": "bear_plan_attach_cnn_levels: rows[k] = distinct prefixes of lag - k letters of the sorted batch; level k "
-                                                       "evaluates position P - 1 - k once per row (the last level the positions left), forward and backward"},
+                                                       "evaluates position P - 1 - k once per row (the last level the positions left), forward and backward; "
+                                                       "window tables (round 5): a level's position once per DISTINCT filter_width-letter window of the "
+                                                       "batch (65 536), its rows gather the window's layer-1 row forward and are summed by window backward"},
                              "step_contexts_per_s": n / (kept_ms * 1e-3),
                              "note": "forward_ms / backward_ms: bear_cnn_forward_f64 / bear_cnn_backward_f64 over all rows in random order (any caller); "
                                      "train_step_ms: bear_net_cnn_train_reduce_f64 = forward + planned DM kernel with gradient rows + "
