@@ -310,7 +310,7 @@ def test_bench_single_rank_line_is_consistent():
     lv = c["prefix_levels"]
     assert lv["equals_step_without_levels"] is True and lv["rows"][0] == round(c["contexts_with_training_counts"] * n)
     if lv["attached"]:
-        assert lv["rows"] == sorted(lv["rows"], reverse=True) and 1.0 <= lv["position_evaluations_per_context"] < 6.0
+        assert lv["rows"] == sorted(lv["rows"], reverse=True) and 0.0 < lv["position_evaluations_per_context"] < 6.0      # (< 1 since round 5: window tables)
         assert lv["rates_forward"]["executed_fp64_flops"] < lv["rates_forward"]["credited_fp64_flops"]
     assert "frac_of_fp64_peak" not in c["rates_forward_rows_in_kmer_order"]           # (no executed-flop count there: no utilisation claimed)
     lin = also["linear_head_fused_step"]
