@@ -908,3 +908,79 @@ def test_c_example_compiles_and_runs(tmp_path):
     want = co.dm_ref(t["train"].cpu().numpy().view(np.uint32), t["ref"].cpu().numpy().view(np.uint32), 0.0, np.log(1 / 30), -np.log(100))
     assert np.isclose(vals[0], want[0], rtol=1e-11)            # printed with 12 digits
     assert np.allclose(vals[1:], want[1:], rtol=1e-5)          # printed with 6 digits
+
+
+@pytest.mark.parametrize("lag,fw,n,fixed", [(10, 4, 300_000, 0), (13, 8, 2_400_000, 5), (7, 3, 50_000, 0), (8, 2, 100_000, 0)])
+def test_cnn_step_over_window_tables_equals_the_plain_kernels(lag, fw, n, fixed, monkeypatch):
+    """Window tables (round 5): a level's own positions evaluated once per distinct filter_width-letter window, rows gathering their
+    window's row forward and summed by window backward.  The step with them == the step with prefix levels alone
+    (BEAR_AMD_CNN_NO_WINDOWS at attach time) == the plain step (BEAR_AMD_CNN_NO_LEVELS) == the three kernels over all rows in random
+    order -- on tables with duplicates, start symbols and unknown letters; shapes with tables at several levels, with several
+    tables at level 0 (a table too sparse for prefix levels), with two-letter windows (36 rows per table)."""
+    from bear_amd import kernels
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(dev).manual_seed(lag * 131 + fw)
+    codes = torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev, generator=gen)
+    if fixed:
+        codes[:, :fixed] = torch.randint(0, 4, (fixed,), dtype=torch.int8, device=dev, generator=gen)
+    odd = torch.randperm(n, device=dev, generator=gen)[:max(2, n // 150)]
+    codes[odd[::2], 0] = 4
+    codes[odd[1::2], torch.randint(0, lag, (odd[1::2].numel(),), device=dev, generator=gen)] = -1
+    key = torch.zeros(n, dtype=torch.int64, device=dev)
+    for l in range(lag):
+        c = codes[:, l].to(torch.int64)
+        key = key * 6 + torch.where(c >= 0, c, torch.full_like(c, 5))
+    codes = codes[torch.argsort(key)].contiguous()
+    counts = kernels.synth_counts(11, 0, n, dev, want=("train",))["train"]
+    counts[:, 4] += (counts == 0).all(dim=1).to(counts.dtype)
+    torch.manual_seed(5)
+    _, params = ar_funcs.make_ar_func_cnn(lag, 4, filter_width=fw, device=dev)
+    flat = torch.cat([q.detach().reshape(-1) for q in params]).contiguous()
+    h_s = 0.2
+    theta = torch.cat([torch.tensor([h_s], dtype=torch.float64, device=dev), flat]).contiguous()
+    packed_codes = kernels.pack_kmers(codes)
+    plan = kernels.Plan(counts, 5)
+    bufs = kernels.cnn_step_buffers(n, lag, fw, dev, ws=plan.ws)
+    plan.attach_cnn_levels(packed_codes, lag, fw)
+    tables = plan.cnn_window_rows()
+    levels = plan.cnn_level_rows()
+    assert tables, (levels, tables)
+    assert all(0 <= lev <= len(levels) and 0 <= pos <= lag - fw and rows >= 1 for lev, pos, rows in tables)
+    assert all(rows * 8 <= ([n] + levels)[lev] for lev, pos, rows in tables)       # the attach rule: >= 8 rows per distinct window
+    assert len({(lev, pos) for lev, pos, _ in tables}) == len(tables)
+    pk = torch.zeros(2 + flat.numel(), dtype=torch.float64, device=dev)
+    perm = torch.randperm(n, device=dev, generator=gen)
+    counts_p, codes_p = counts[perm].contiguous(), kernels.pack_kmers(codes[perm].contiguous())
+    for ar in (False, True):
+        kernels.net_cnn_train_reduce(plan, packed_codes, lag, fw, theta, bufs, pk, train_ar=ar)
+        with_tables = pk.clone()
+        monkeypatch.setenv("BEAR_AMD_CNN_KEEP_T1", "1")          # the contexts' layer-1 rows stored by the forward pass instead of put together again
+        kernels.net_cnn_train_reduce(plan, packed_codes, lag, fw, theta, bufs, pk, train_ar=ar)
+        monkeypatch.delenv("BEAR_AMD_CNN_KEEP_T1")
+        kept_t1 = pk.clone()
+        monkeypatch.setenv("BEAR_AMD_CNN_NO_HEAD_KERNEL", "1")   # ... and the part kernel's head instead of the head-only kernel
+        kernels.net_cnn_train_reduce(plan, packed_codes, lag, fw, theta, bufs, pk, train_ar=ar)
+        monkeypatch.delenv("BEAR_AMD_CNN_NO_HEAD_KERNEL")
+        part_head = pk.clone()
+        monkeypatch.setenv("BEAR_AMD_CNN_NO_LEVELS", "1")
+        kernels.net_cnn_train_reduce(plan, packed_codes, lag, fw, theta, bufs, pk, train_ar=ar)
+        monkeypatch.delenv("BEAR_AMD_CNN_NO_LEVELS")
+        plain = pk.clone()
+        prior, t1 = kernels.cnn_forward(codes_p, flat, lag, fw)
+        out, g = kernels.dm_prior_planned(kernels.Plan(counts_p, 5), prior, h_s, want_grad=True, train_ar=ar)
+        want = torch.cat([out[:2], kernels.cnn_backward(codes_p, flat, lag, fw, t1, prior, g)])
+        for name, got in (("window tables", with_tables), ("stored layer-1 rows", kept_t1), ("part kernel's head", part_head), ("plain step", plain)):
+            assert abs(float(got[0] - want[0])) <= 1e-12 * abs(float(want[0])), (name, ar)
+            assert abs(float(got[1] - want[1])) <= 1e-10 * max(abs(float(want[1])), 1.0), (name, ar)
+            assert (got[2:] - want[2:]).abs().max().item() <= 1e-10 * want[2:].abs().max().item(), (name, ar)
+    # the forward pass alone over the same levels and tables (evaluation-style callers): the prior rows of the plain kernel
+    prior_l, t1_l = kernels.cnn_forward(packed_codes, flat, lag, fw, plan=plan)
+    prior_p, t1_p = kernels.cnn_forward(packed_codes, flat, lag, fw)
+    assert torch.allclose(prior_l, prior_p, rtol=1e-11, atol=1e-300) and torch.allclose(t1_l, t1_p, rtol=1e-10, atol=1e-10)
+    # prefix levels alone
+    monkeypatch.setenv("BEAR_AMD_CNN_NO_WINDOWS", "1")
+    plan.attach_cnn_levels(packed_codes, lag, fw)
+    monkeypatch.delenv("BEAR_AMD_CNN_NO_WINDOWS")
+    assert plan.cnn_window_rows() == []
+    kernels.net_cnn_train_reduce(plan, packed_codes, lag, fw, theta, bufs, pk, train_ar=True)
+    assert (pk[2:] - want[2:]).abs().max().item() <= 1e-10 * want[2:].abs().max().item()
