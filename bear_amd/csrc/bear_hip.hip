@@ -2025,6 +2025,12 @@ static int cnn_forward_levels(bear_ws *ws, const bear_plan *plan, const cnn_dims
     const uint64_t n = k == 0 ? n_rows : plan->cnn_levels[k - 1].n, groups = (n + 63) / 64;
     uint64_t blocks = (groups + CNN_THREADS / 64 - 1) / (CNN_THREADS / 64);
     if (blocks > (uint64_t)ws->num_cu * 16) blocks = (uint64_t)ws->num_cu * 16;
+    if (k == 0 && io.p_lo >= io.p_hi && !getenv("BEAR_AMD_CNN_NO_HEAD_KERNEL")) {      // the contexts evaluate no position themselves: the head alone
+      uint64_t hb = (n + 32 * 16 - 1) / (32 * 16);
+      if (hb > (uint64_t)ws->num_cu * 2) hb = (uint64_t)ws->num_cu * 2;
+      hipLaunchKernelGGL(cnn_forward_head_kernel, dim3((unsigned)hb), dim3(1024), 0, s, n, D, params, prior, t1_buf, io);
+      continue;
+    }
     hipLaunchKernelGGL(cnn_forward_kernel, dim3((unsigned)blocks), dim3(CNN_THREADS), fwd_lds, s,
                        k == 0 ? reinterpret_cast<const unsigned long long *>(kmer_code) : plan->cnn_levels[k - 1].codes, n, D, params,
                        k == 0 ? prior : static_cast<double *>(nullptr), k == 0 ? t1_buf : plan->cnn_levels[k - 1].rows,

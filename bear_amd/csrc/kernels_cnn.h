@@ -1723,6 +1723,100 @@ __global__ __launch_bounds__(CNH_WAVES * 64) void cnn_backward_head_kernel(uint6
   }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, head only
+// The forward counterpart of cnn_backward_head_kernel: contexts whose layer-1 sums come from their parent level and window tables
+// alone -- two or three 128-byte gathers, layer 1 (norm, elu), layer 2, softmax, the prior row.  Two lanes per context as in the
+// backward kernels (a lane gathers and normalises 8 of the 16 units; the letters' logits meet through v_permlane32_swap).
+__global__ __launch_bounds__(1024) void cnn_forward_head_kernel(uint64_t n_rows, cnn_dims D, const double *__restrict__ params,
+                                                                double *__restrict__ prior, double *__restrict__ t1_save, const cnn_level_io io) {
+  constexpr int TILE = 32, JH = CNN_L1 / 2;
+  __shared__ double exptab[BEAR_EXPTAB_N], Ps1[CNN_L1], Pb1[CNN_L1], PW2[CNN_L1 * 5], Pb2[5];
+  for (int k = threadIdx.x; k < BEAR_EXPTAB_N; k += blockDim.x) exptab[k] = exp2((double)k * (1.0 / BEAR_EXPTAB_N));
+  for (int k = threadIdx.x; k < CNN_L1; k += blockDim.x) {
+    Ps1[k] = params[D.os1 + k];
+    Pb1[k] = params[D.ob1 + k];
+  }
+  for (int k = threadIdx.x; k < CNN_L1 * 5; k += blockDim.x) PW2[k] = params[D.oW2 + k];
+  if (threadIdx.x < 5) Pb2[threadIdx.x] = params[D.ob2 + threadIdx.x];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t ctx = lane & (TILE - 1), h = lane / TILE;
+  const uint64_t n_tiles = (n_rows + TILE - 1) / TILE;
+  const uint64_t wave_id = (uint64_t)blockIdx.x * n_waves + wave, wave_cnt = (uint64_t)gridDim.x * n_waves;
+  for (uint64_t g = n_tiles * wave_id / wave_cnt; g < n_tiles * (wave_id + 1) / wave_cnt; ++g) {
+    const uint64_t i = g * TILE + ctx;
+    const bool live = i < n_rows;
+    double t1[JH];
+#pragma unroll
+    for (int j = 0; j < JH; ++j) t1[j] = 0.0;
+    if (live) {
+      if (io.t1_parent) {
+        const double2 *src = reinterpret_cast<const double2 *>(io.t1_parent + (size_t)io.parent[i] * CNN_L1 + h * JH);
+#pragma unroll
+        for (int j = 0; j < JH / 2; ++j) {
+          const double2 v = src[j];
+          t1[2 * j] = v.x;
+          t1[2 * j + 1] = v.y;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < CNN_MAX_WIN; ++q) {
+        if (q < io.n_win) {
+          const double2 *src = reinterpret_cast<const double2 *>(io.win_rows[q] + (size_t)io.win_row_of[q][i] * CNN_L1 + h * JH);
+#pragma unroll
+          for (int j = 0; j < JH / 2; ++j) {
+            const double2 v = src[j];
+            t1[2 * j] += v.x;
+            t1[2 * j + 1] += v.y;
+          }
+        }
+      }
+      if (t1_save) {
+        double2 *o = reinterpret_cast<double2 *>(t1_save + i * CNN_L1 + h * JH);
+#pragma unroll
+        for (int j = 0; j < JH / 2; ++j) o[j] = make_double2(t1[2 * j], t1[2 * j + 1]);
+      }
+    }
+    double mu = 0.0;
+#pragma unroll
+    for (int j = 0; j < JH; ++j) mu += t1[j];
+    mu = cnnq_psum<2>(mu) * (1.0 / CNN_L1);
+    double var = 0.0;
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+      t1[j] -= mu;
+      var = __builtin_fma(t1[j], t1[j], var);
+    }
+    const double r1 = cnn_rsqrt(cnnq_psum<2>(var) * (1.0 / CNN_L1) + CNN_LN_EPS);
+    double z[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+    for (int j = 0; j < JH; ++j) {      // (two units at a time: all eight exponentials in flight took 190 registers)
+      double dv;
+      const double e = cnn_elu(__builtin_fma(Ps1[h * JH + j], t1[j] * r1, Pb1[h * JH + j]), exptab, dv);
+#pragma unroll
+      for (int b = 0; b < 5; ++b) z[b] = __builtin_fma(e, PW2[(h * JH + j) * 5 + b], z[b]);
+    }
+    double m = -INFINITY;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      z[b] = cnnq_psum<2>(z[b]) + Pb2[b];
+      m = z[b] > m ? z[b] : m;
+    }
+    double tot = 0.0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+      z[b] = bear_exp_tab(z[b] - m, exptab);
+      tot += z[b];
+    }
+    const double rt = bear_rcp(tot);
+    if (live && h == 0) {
+#pragma unroll
+      for (int b = 0; b < 5; ++b) prior[i * 5 + b] = z[b] * rt;
+    }
+  }
+}
+
 // a level's dT1 rows from its children's (the children of a row are neighbours): one thread per (row, unit)
 __global__ __launch_bounds__(256) void cnn_level_sum_kernel(const double *__restrict__ child_rows, const uint32_t *__restrict__ child_start,
                                                             uint64_t n_rows, double *__restrict__ rows) {
