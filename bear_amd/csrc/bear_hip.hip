@@ -556,14 +556,15 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   unsigned long long h_used[3] = {0, 0, 0};  // entries that actually went to the global lists
   if (e == hipSuccess) e = hipMemcpy(h_used, d_cnt + 3, sizeof(h_used), hipMemcpyDeviceToHost);
   for (int k = 0; k < 3; ++k) p->n_heavy[k] = h_used[k];
-#ifdef BEAR_DET_BUILD      // the global lists were filled through atomic cursors: canonical order (bear_levels.h)
+  // The global lists were filled through atomic cursors, in whatever order the blocks got there: into row order (bear_levels.h).
+  // Neighbouring threads of the kernels that walk them then read neighbouring prior cells and -- the gradient fix-up -- update
+  // neighbouring gradient cells without atomics; and the lists are the same bits in every build of the plan.
   if (e == hipSuccess) {
     int cst = bear_canonical_order(p->heavy_col, h_used[0], 16, 0);
     if (cst == BEAR_OK) cst = bear_canonical_order(p->heavy_row, h_used[1], 16, 0);
     if (cst == BEAR_OK) cst = bear_canonical_order(p->heavy_stop, h_used[2], 8, 0);
     if (cst != BEAR_OK) e = cst == BEAR_ERR_NOMEM ? hipErrorOutOfMemory : hipErrorUnknown;
   }
-#endif
   p->n_live_rows = n_rows;
   if (e == hipSuccess && ncol == 5) {        // rows with a total of 1..SRT_CL (histogram) + rows with a larger one
     unsigned long long h_hist[SRT_NKEY];
@@ -758,17 +759,21 @@ static int launch_prior_plan_grad(bear_ws *ws, const bear_plan *plan, const doub
     hipLaunchKernelGGL((dm_prior_plan_grad_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
                        grad_prior, ws->partials, io);
   HIP_TRY(hipGetLastError());
-  if (pv.n_heavy_col + pv.n_heavy_row) {
-    const uint64_t nh = pv.n_heavy_col + pv.n_heavy_row;
-    const int g2 = (int)((nh + 255) / 256 < (uint64_t)ws->num_cu * 4 ? (nh + 255) / 256 : (uint64_t)ws->num_cu * 4);
-    if (train_ar)
-      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, true>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, io);
-    else if (prior_normalized)
-      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<true, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, io);
-    else
-      hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<false, false>), dim3(g2), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, io);
-    HIP_TRY(hipGetLastError());
+  // the plan's global overflow lists (dense tables): the contexts' base, then the column items (kernels_plan.h)
+  auto fixup_grid = [&](uint64_t nh) { return (int)((nh + 255) / 256 < (uint64_t)ws->num_cu * 8 ? (nh + 255) / 256 : (uint64_t)ws->num_cu * 8); };
+#define FIXUP(NORM, AR, ROWS, N) \
+  hipLaunchKernelGGL((dm_prior_grad_fixup_kernel<NORM, AR, ROWS>), dim3(fixup_grid(N)), dim3(256), 0, s, prior, prm, pv, lt, grad_prior, io)
+  if (pv.n_heavy_row && !train_ar) {
+    if (prior_normalized) FIXUP(true, false, true, pv.n_heavy_row);
+    else FIXUP(false, false, true, pv.n_heavy_row);
   }
+  if (pv.n_heavy_col) {
+    if (train_ar) FIXUP(true, true, false, pv.n_heavy_col);
+    else if (prior_normalized) FIXUP(true, false, false, pv.n_heavy_col);
+    else FIXUP(false, false, false, pv.n_heavy_col);
+  }
+#undef FIXUP
+  HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
 
