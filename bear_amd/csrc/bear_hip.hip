@@ -559,10 +559,17 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   // The global lists were filled through atomic cursors, in whatever order the blocks got there: into row order (bear_levels.h).
   // Neighbouring threads of the kernels that walk them then read neighbouring prior cells and -- the gradient fix-up -- update
   // neighbouring gradient cells without atomics; and the lists are the same bits in every build of the plan.
+  // (lists of a few thousand entries -- every sparse k-mer table -- are left as they are: nothing to coalesce, and the sorts' set-up
+  // would triple the plan's build time; the deterministic build sorts them all)
+#ifdef BEAR_DET_BUILD
+  const uint64_t sort_from = 2;
+#else
+  const uint64_t sort_from = 1u << 16;
+#endif
   if (e == hipSuccess) {
-    int cst = bear_canonical_order(p->heavy_col, h_used[0], 16, 0);
-    if (cst == BEAR_OK) cst = bear_canonical_order(p->heavy_row, h_used[1], 16, 0);
-    if (cst == BEAR_OK) cst = bear_canonical_order(p->heavy_stop, h_used[2], 8, 0);
+    int cst = h_used[0] >= sort_from ? bear_canonical_order(p->heavy_col, h_used[0], 16, 0) : BEAR_OK;
+    if (cst == BEAR_OK && h_used[1] >= sort_from) cst = bear_canonical_order(p->heavy_row, h_used[1], 16, 0);
+    if (cst == BEAR_OK && h_used[2] >= sort_from) cst = bear_canonical_order(p->heavy_stop, h_used[2], 8, 0);
     if (cst != BEAR_OK) e = cst == BEAR_ERR_NOMEM ? hipErrorOutOfMemory : hipErrorUnknown;
   }
   p->n_live_rows = n_rows;
