@@ -70,7 +70,7 @@ static inline cnn_dims cnn_make_dims(int lag, int fw) {
 // positions that are left).  Forward runs the levels from the shortest prefixes down to the contexts; backward runs them the
 // other way, a level's dT1 rows being the sums of its children's (everything a position does with dT1 is linear in it).  Both
 // are the kernels below with a position range and a row source: a dense sorted table does ~1.3 positions per context, not 6.
-#define CNN_MAX_WIN 3             // window tables a launch may read (the positions the contexts themselves would evaluate)
+#define CNN_MAX_WIN 6             // window tables a launch may read (the positions the contexts themselves would evaluate)
 struct cnn_level_io {
   int p_lo, p_hi;                 // the positions this launch evaluates
   int head;                       // 1: the rows are contexts -- layer 1 onwards (forward: prior rows; backward: dT1 from the head)
