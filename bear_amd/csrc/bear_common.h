@@ -181,14 +181,28 @@ __device__ __forceinline__ bear_params bear_params_of(const bear_params &arg, co
 // thread waits for the acknowledgement of its own stores (s_waitcnt vmcnt(0): gfx9 counts stores there; a workgroup-scope
 // release fence compiles to nothing on gfx950) before the barrier, so the arrival counter is bumped only after all of this
 // block's partials are visible to the device.
+// Two levels: a block arrives at one of BEAR_ARRIVE_SUBS counters (its number mod 16, each on a cache line of its own), the last one
+// of a counter at the top word.  Atomics on ONE address serialise (~12 ns each): 2048 blocks that finish together spent 25 us there
+// with one counter -- half the duration of a launch-bound step (dm_ref_items_kernel at 1e7 contexts: 59 us, 15 of them work).
+#define BEAR_ARRIVE_SUBS 16
+#define BEAR_ARRIVE_STRIDE 16            // words between counters (128 bytes)
+#define BEAR_ARRIVE_WORDS ((BEAR_ARRIVE_SUBS + 1) * BEAR_ARRIVE_STRIDE)
+__device__ __forceinline__ bool bear_arrive_count(unsigned long long *word, unsigned long long tag, unsigned expected) {
+  __hip_atomic_fetch_max(word, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag + (expected - 1u);
+}
 __device__ __forceinline__ bool bear_arrive_last(const bear_arrival &arrive) {
   __shared__ unsigned s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned long long tag = (unsigned long long)arrive.epoch << 24;
-    __hip_atomic_fetch_max(arrive.word, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = __hip_atomic_fetch_add(arrive.word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag + (gridDim.x - 1u) ? 1u : 0u;
+    const unsigned sub = blockIdx.x % BEAR_ARRIVE_SUBS, grid = gridDim.x;
+    const unsigned in_sub = (grid - sub + BEAR_ARRIVE_SUBS - 1u) / BEAR_ARRIVE_SUBS;      // blocks with this residue
+    const unsigned subs = grid < BEAR_ARRIVE_SUBS ? grid : BEAR_ARRIVE_SUBS;               // counters in use
+    bool last = bear_arrive_count(arrive.word + (1u + sub) * BEAR_ARRIVE_STRIDE, tag, in_sub);
+    if (last) last = bear_arrive_count(arrive.word, tag, subs);
+    s_last = last ? 1u : 0u;
   }
   __syncthreads();
   if (!s_last) return false;
@@ -198,9 +212,11 @@ __device__ __forceinline__ bool bear_arrive_last(const bear_arrival &arrive) {
   return true;
 }
 
-// The last block is done with the partials: the word goes back to zero (a replay of this launch starts its count afresh).
+// The last block is done with the partials: the words go back to zero (a replay of this launch starts its count afresh).
 __device__ __forceinline__ void bear_arrive_reset(const bear_arrival &arrive) {
-  __hip_atomic_store(arrive.word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int k = 0; k <= BEAR_ARRIVE_SUBS; ++k)
+    __hip_atomic_store(arrive.word + k * BEAR_ARRIVE_STRIDE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The arithmetic of finalize_kernel (256 threads, same order) inside the last block of the producing launch.

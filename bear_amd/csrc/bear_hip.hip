@@ -85,8 +85,8 @@ int bear_ws_create(int device, bear_ws **out) {
       if (e == hipSuccess) e = hipMalloc(&ws->eval_partials, sizeof(double) * EVL_MAX_OUT * (size_t)ws->eval_blocks);
       if (e == hipSuccess) e = hipMalloc(&ws->eval_out, sizeof(double) * EVL_MAX_OUT);
       if (e == hipSuccess) e = hipMalloc(&ws->lin_partials, sizeof(double) * LIN_MAX_GRAD * (size_t)ws->num_cu);
-      if (e == hipSuccess) e = hipMalloc(&ws->arrive, sizeof(unsigned long long));
-      if (e == hipSuccess) e = hipMemset(ws->arrive, 0, sizeof(unsigned long long));
+      if (e == hipSuccess) e = hipMalloc(&ws->arrive, sizeof(unsigned long long) * BEAR_ARRIVE_WORDS);
+      if (e == hipSuccess) e = hipMemset(ws->arrive, 0, sizeof(unsigned long long) * BEAR_ARRIVE_WORDS);
       ws->epoch = 0;
       for (const void *fn : {reinterpret_cast<const void *>(dm_linear_plan_kernel<false, false, false>),
                              reinterpret_cast<const void *>(dm_linear_plan_kernel<true, false, false>),

@@ -198,7 +198,7 @@ int bear_plan_cnn_level_rows(const bear_plan *plan, uint64_t *rows_out, int *let
  * window alone, and a batch holds at most 6^filter_width distinct windows (65 536 for eight letters of ACGT) however many rows a
  * level has.  Forward: the position is evaluated once per distinct window, a row gathers its window's row; backward: a window's dT1
  * row is the sum of its rows' dT1 rows (listed by window at attach time: fixed order, no atomics), then the position's backward pass
- * over the windows.  A table is attached while the level holds >= 8 rows per distinct window (at most 3 per level); 8 bytes per row
+ * over the windows.  A table is attached while the level holds >= 8 rows per distinct window (at most 6 per level); 8 bytes per row
  * and table.  Distinct windows, positions and levels of the attached tables (nullable outputs); returns their number. */
 int bear_plan_cnn_window_rows(const bear_plan *plan, uint64_t *rows_out, int *pos_out, int *level_out, int capacity);
 /* bear_cnn_forward_f64 over the plan's prefix levels when they were attached for this kmer_code pointer, lag and filter width
