@@ -30,6 +30,22 @@ def test_library_exports_every_declared_symbol():
     assert L.bear_strerror(0) == b"ok"
 
 
+def test_deterministic_build_exports_the_same_abi():
+    """libbear_hip_det.so (the library BEAR_AMD_DETERMINISTIC=1 selects at import) is the same ABI built with -DBEAR_DET_BUILD: every
+    declared symbol, the same version; bear_deterministic_build tells the two apart."""
+    from bear_amd import _lib
+    reg = _lib.lib()
+    det_path = os.path.join(ROOT, "bear_amd", "libbear_hip_det.so")
+    assert os.path.exists(det_path), "make -C bear_amd/csrc builds both libraries"
+    det = ctypes.CDLL(det_path)
+    for n in _declared_symbols():
+        assert hasattr(det, n), n
+    assert det.bear_abi_version() == reg.bear_abi_version()
+    if not os.environ.get("BEAR_AMD_DETERMINISTIC"):
+        assert reg.bear_deterministic_build() == 0
+    assert det.bear_deterministic_build() == 1
+
+
 def test_no_device_is_a_loud_error():
     import torch
     if torch.cuda.is_available():
