@@ -930,18 +930,18 @@ __device__ __forceinline__ void lin_sum_block_partials(const double *__restrict_
   for (int t = tid; t < 3 * n_grad; t += n_threads) {
     const int k = t % n_grad, c = t / n_grad;
     const int b0 = c * third, b1 = b0 + third < nb ? b0 + third : nb;
-    // sixteen independent loads in flight per thread (the lines come from memory: the L2 was just invalidated); fixed order
+    // 32 independent loads in flight per thread (the lines come from memory: the L2 was just invalidated), the ragged end of a
+    // thread's range as predicated loads of the same batch -- a scalar loop over it waited for every load in turn: a launch of
+    // any size spent ~15 us here on one CU (scripts/dev/lin_fixed_cost.py); fixed order
     const double *src = grad_partials + k;
     T s = T(0);
-    int b = b0;
-    for (; b + 16 <= b1; b += 16) {
-      double v[16];
+    for (int b = b0; b < b1; b += 32) {
+      double v[32];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = src[(size_t)(b + j) * LIN_MAX_GRAD];
+      for (int j = 0; j < 32; ++j) v[j] = b + j < b1 ? src[(size_t)(b + j) * LIN_MAX_GRAD] : __longlong_as_double(lin_bits<T>(T(0)));
 #pragma unroll
-      for (int j = 0; j < 16; ++j) s += lin_unbits<T>(__double_as_longlong(v[j]));
+      for (int j = 0; j < 32; ++j) s += lin_unbits<T>(__double_as_longlong(v[j]));
     }
-    for (; b < b1; ++b) s += lin_unbits<T>(__double_as_longlong(src[(size_t)b * LIN_MAX_GRAD]));
     part[c * LIN_MAX_GRAD + k] = __longlong_as_double(lin_bits<T>(s));
   }
   __syncthreads();
