@@ -1005,8 +1005,8 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
   }
   if (tid == 0) {
     S.pri[PLN_SENTINEL] = 1.0;
-    S.ticket[0] = 0;
-    S.ticket[1] = 0;
+    S.ticket[0] = PLN_TICKET_START(PLN_WAVES);
+    S.ticket[1] = PLN_TICKET_START(PLN_WAVES);
     S.c_done = 0;
   }
   if (tid < BEAR_EXPTAB_N) S.exptab[tid] = exp2((double)tid * (1.0 / BEAR_EXPTAB_N));
@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     const pln_layout L = pln_block_layout(rows, n_light, hc, hr);
     const uint16_t *E = reinterpret_cast<const uint16_t *>(B.blk);
     const uint16_t *items = reinterpret_cast<const uint16_t *>(B.blk + L.items);
-    if (tid == 0) S.ticket[slot ^ 1u] = 0;
+    if (tid == 0) S.ticket[slot ^ 1u] = PLN_TICKET_START(PLN_WAVES);
     // ---- B: items (tickets, dearest first): ELBO / d/dh, and -w = -f q into the item's own cell
     auto item = [&](uint32_t off, double D, double P, double x, double cnt) {
       const double fb = S.pri[off];
@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
     bool rows_done = (wave & 1u) != 0u;
     if (rows_done) rows_work();
 #endif
-    PLN_FOR_UNITS(w, &S.ticket[slot], n_work, wave, PLN_WAVES) {
+    PLN_FOR_UNITS_F(w, &S.ticket[slot], n_work, wave, PLN_WAVES) {
 #ifdef LIN_MIX
       if (!rows_done && w >= n_work / 2u) {
         rows_done = true;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
   if (tid == 0) {
     S.pri[PLN_SENTINEL] = 1.0;    // what the unoccupied lanes of an item unit read (their count is zero)
     S.grad[PLN_SENTINEL] = 0.0;
-    S.ticket = 0;
+    S.ticket = PLN_TICKET_START(PLN_WAVES);
   }
   pln_tile nxt = pln_load_tile(pv, blockIdx.x);      // descriptors one tile ahead (see dm_prior_plan_grad_kernel)
   for (uint64_t t = blockIdx.x; t < pv.n_tiles; t += gridDim.x) {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
       }
       pln_dma(S.blk, pv.stream + (size_t)cur.off16 * 16, cur.blk16 * 16u, wave, lane, 2u * pieces);
     }
-    if (tid == 0) S.ticket = 0;
+    if (tid == 0) S.ticket = PLN_TICKET_START(PLN_WAVES);
     nxt = pln_load_tile(pv, t + gridDim.x);
     srt_wait_dma();
     srt_sync();
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_gra
       return bear_dp{cnt * bear_log_tab(pp, S.logtab), cnt * bear_rcp(pp) * bear_rcp(u)};
     };
     const uint32_t n_hcu = (hc + 63u) >> 6, n_units = (n_light + 63u) >> 6;
-    PLN_FOR_UNITS(w, &S.ticket, n_hcu + n_units, wave, PLN_WAVES) {
+    PLN_FOR_UNITS_F(w, &S.ticket, n_hcu + n_units, wave, PLN_WAVES) {
       if (w < n_hcu) {
         const uint32_t i = w * 64u + lane;
         if (i < hc) {

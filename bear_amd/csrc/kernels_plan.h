@@ -683,6 +683,15 @@ __device__ __forceinline__ uint32_t pln_ticket(uint32_t *counter, uint32_t lane)
 #else
 #define PLN_FOR_UNITS(w, counter, n, first, stride) for (uint32_t w = pln_ticket(counter, lane); w < (n); w = pln_ticket(counter, lane))
 #endif
+// The same with a wave's FIRST unit dealt (drawing wave `first` of `stride` starts with unit `first`, the counter starts at `stride`:
+// PLN_TICKET_START): one LDS atomic round trip less per wave and tile.
+#if defined(BEAR_DET_BUILD) || defined(PLN_NO_FIRST_UNIT_DEALT)
+#define PLN_FOR_UNITS_F(w, counter, n, first, stride) PLN_FOR_UNITS(w, counter, n, first, stride)
+#define PLN_TICKET_START(stride) 0u
+#else
+#define PLN_FOR_UNITS_F(w, counter, n, first, stride) for (uint32_t w = (first); w < (n); w = pln_ticket(counter, lane))
+#define PLN_TICKET_START(stride) ((uint32_t)(stride))
+#endif
 
 // The same draw without waiting for its answer: lane 0's return value, to be made uniform (srt_uniform) when it is looked at.
 __device__ __forceinline__ uint32_t pln_ticket_issue(uint32_t *counter, uint32_t lane) {
@@ -775,7 +784,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
   }
   if (tid < PLN_NBUF) {
     S.buf[tid].pri[PLN_SENTINEL] = 1.0;
-    S.ticket[tid] = 0;
+    S.ticket[tid] = PLN_TICKET_START(PLN_WAVES - PLN_DMA_WAVES);
   }
 
   // One wave of the block (the last) is the DMA wave: it streams the tiles into the LDS ring and never computes.
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
     const uint16_t *E = reinterpret_cast<const uint16_t *>(B.blk);
     const uint8_t *nrow = B.blk + L.nrow;
     const uint16_t *items = reinterpret_cast<const uint16_t *>(B.blk + L.items);
-    if (tid == 0) S.ticket[(slot + 1) % PLN_NBUF] = 0;  // next tile's counter (its last readers passed the barrier above)
+    if (tid == 0) S.ticket[(slot + 1) % PLN_NBUF] = PLN_TICKET_START(PLN_WAVES - PLN_DMA_WAVES);  // next tile's counter (its last readers passed the barrier above)
     // Work list of the tile, dearest first: the large-count column items and contexts (Stirling path), the
     // item units from the sorted tail down (long loops), then the 64-context chunks of the context terms.
     // Waves draw tickets until the list is exhausted.
@@ -901,7 +910,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kern
 #else
     const uint32_t n_work = n_heavy + n_units + ((NORM || AR) ? 0u : (rows + PLN_CHUNK - 1u) / PLN_CHUNK);
 #endif
-    PLN_FOR_UNITS(w, &S.ticket[slot], n_work, wave, PLN_WAVES - PLN_DMA_WAVES) {      // (the DMA waves never get here)
+    PLN_FOR_UNITS_F(w, &S.ticket[slot], n_work, wave, PLN_WAVES - PLN_DMA_WAVES) {      // (the DMA waves never get here)
 #ifdef PLN_STAMPS
       {
         const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -1087,7 +1096,10 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
     S.tabD[which][j] = o.D;
     S.tabP[which][j] = o.P;
   }
-  if (tid < PLN_RSLOT) S.ticket[tid] = S.landed[tid] = S.left[tid] = 0u;
+  if (tid < PLN_RSLOT) {
+    S.landed[tid] = S.left[tid] = 0u;
+    S.ticket[tid] = PLN_TICKET_START(PLN_WAVES - PLN_DMA_WAVES);
+  }
   if (tid < 4 * PLN_RSLOT) S.buf[tid >> 2].ref[PLN_SENTINEL + (tid & 3)] = 0;  // neutral cell: reference row of zeros
 
   // Streaming protocol WITHOUT a workgroup barrier (measured: with dm_prior_plan_kernel's two-slot ring and one barrier per
@@ -1120,7 +1132,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
     if (lane == 0) {
       S.meta[b][0] = ti.rows_items;
       S.meta[b][1] = ti.hc_hr;
-      S.ticket[b] = 0u;
+      S.ticket[b] = PLN_TICKET_START(PLN_WAVES - PLN_DMA_WAVES);
     }
   };
   // bear_ref.py:30-33 (Jukes-Cantor on the L1-normalised reference row), :63-68 (mix), bear_ref.py:106
@@ -1182,7 +1194,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel
 #else
     const uint32_t n_units = (n_light + 63u) >> 6;
 #endif
-    PLN_FOR_UNITS(w, &S.ticket[slot], n_hcu + n_units, wave, CWAVES) {      // (compute waves only)
+    PLN_FOR_UNITS_F(w, &S.ticket[slot], n_hcu + n_units, wave, CWAVES) {      // (compute waves only)
       if (w < n_hcu) {  // large-count column items of this tile (Stirling path), first
         const uint32_t i = w * 64u + lane;
         if (i < hc) {
@@ -1323,7 +1335,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
   }
   if (tid == 0) {
     S.pri[PLN_SENTINEL] = 1.0;
-    S.ticket = 0;
+    S.ticket = PLN_TICKET_START(PLN_WAVES);
   }
   // (the descriptor of a tile is fetched one tile ahead, right behind the issue of the current tile's DMA: a scalar load shares
   // lgkmcnt with the LDS, so fetched at the top of its own tile it cost every wave a memory latency per tile -- round 4)
@@ -1345,7 +1357,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
       }
       pln_dma(S.blk, pv.stream + (size_t)cur.off16 * 16, cur.blk16 * 16u, wave, lane, (pbytes + 1023u) >> 10);
     }
-    if (tid == 0) S.ticket = 0;
+    if (tid == 0) S.ticket = PLN_TICKET_START(PLN_WAVES);
     nxt = pln_load_tile(pv, t + gridDim.x);      // returns while this tile's DMA is waited for
     srt_wait_dma();
     srt_sync();
@@ -1409,7 +1421,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
     }
     // ---- 3: item units (tickets, dearest first): ELBO, d/dh, and u P_b into the item's own cell
     const uint32_t n_hcu = (hc + 63u) >> 6, n_units = (n_light + 63u) >> 6;
-    PLN_FOR_UNITS(w, &S.ticket, n_hcu + n_units, wave, PLN_WAVES) {
+    PLN_FOR_UNITS_F(w, &S.ticket, n_hcu + n_units, wave, PLN_WAVES) {
       if (w < n_hcu) {
         const uint32_t i = w * 64u + lane;
         if (i < hc) {
@@ -1523,8 +1535,8 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
   if (tid == 0) {
     S.pri[0][PLN_SENTINEL] = 1.0;
     S.pri[1][PLN_SENTINEL] = 1.0;
-    S.ticket[0] = 0;
-    S.ticket[1] = 0;
+    S.ticket[0] = PLN_TICKET_START(PLN_WAVES);
+    S.ticket[1] = PLN_TICKET_START(PLN_WAVES);
   }
   auto stage = [&](const pln_tile &ti, uint32_t b) {
     const uint32_t rows = ti.rows_items >> 16;
@@ -1550,7 +1562,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
     srt_wait_dma();   // this tile has landed (requested a whole iteration ago); this wave's stores of the previous tile are out
     srt_sync();       // ... everybody's; nobody reads the other buffer any more (its rows left LDS before the stores were issued)
     stage(nxt, b ^ 1u);
-    if (tid == 0) S.ticket[b ^ 1u] = 0;
+    if (tid == 0) S.ticket[b ^ 1u] = PLN_TICKET_START(PLN_WAVES);
     double *P = S.pri[b];
     const unsigned char *blk = S.blk[b];
     const uint16_t *E = reinterpret_cast<const uint16_t *>(blk);
@@ -1558,7 +1570,7 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad
     const uint16_t *items = reinterpret_cast<const uint16_t *>(blk + L.items);
     // ---- 1: item units (tickets, dearest first): ELBO, d/dh, and the marked gradient into the item's own cell
     const uint32_t n_hcu = (hc + 63u) >> 6, n_units = (n_light + 63u) >> 6;
-    PLN_FOR_UNITS(w, &S.ticket[b], n_hcu + n_units, wave, PLN_WAVES) {
+    PLN_FOR_UNITS_F(w, &S.ticket[b], n_hcu + n_units, wave, PLN_WAVES) {
       if (w < n_hcu) {
         const uint32_t i = w * 64u + lane;
         if (i < hc) {
