@@ -1411,7 +1411,8 @@ struct bear_eval_plan {
   uint64_t n_rows, n_tiles;
   const uint32_t *test, *train;  // the buffers the plan was built from (identity check only; train may be NULL)
   uint16_t *items;       // [n_tiles][EVP_ITEMS_CAP]
-  uint32_t *tile_info;   // [n_tiles]
+  uint2 *tile_info;      // [n_tiles]
+  unsigned long long *consts;   // [EVP_NCONST]: what the vanilla models, the total length need of the table as a whole (kernels_evalplan.h, EVP_C_*)
   uint64_t bytes;
 };
 
@@ -1433,11 +1434,14 @@ int bear_eval_plan_create(bear_ws *ws, const uint32_t *test, const uint32_t *tra
     // + 1 KiB: the last DMA piece of a tile's lists may be issued for a partial KiB
     const size_t ibytes = sizeof(uint16_t) * EVP_ITEMS_CAP * (size_t)p->n_tiles + 1024;
     hipError_t e = hipMalloc(&p->items, ibytes);
-    if (e == hipSuccess) e = hipMalloc(&p->tile_info, sizeof(uint32_t) * ((size_t)p->n_tiles + 2));
-    if (e == hipSuccess) e = hipMemsetAsync(p->tile_info, 0, sizeof(uint32_t) * ((size_t)p->n_tiles + 2), static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipMalloc(&p->tile_info, sizeof(uint2) * ((size_t)p->n_tiles + 2));
+    if (e == hipSuccess) e = hipMalloc(&p->consts, sizeof(unsigned long long) * EVP_NCONST);
+    if (e == hipSuccess) e = hipMemsetAsync(p->tile_info, 0, sizeof(uint2) * ((size_t)p->n_tiles + 2), static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipMemsetAsync(p->consts, 0, sizeof(unsigned long long) * EVP_NCONST, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) {
       (void)hipFree(p->items);
       (void)hipFree(p->tile_info);
+      (void)hipFree(p->consts);
       delete p;
       g_last_hip_error = (int)e;
       return e == hipErrorOutOfMemory ? BEAR_ERR_NOMEM : BEAR_ERR_HIP;
@@ -1445,16 +1449,17 @@ int bear_eval_plan_create(bear_ws *ws, const uint32_t *test, const uint32_t *tra
     const uint64_t cap = (uint64_t)ws->num_cu * 16;
     const int grid = (int)(p->n_tiles < cap ? p->n_tiles : cap);
     hipLaunchKernelGGL(evp_build_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), test, train, n_rows, p->n_tiles,
-                       p->items, p->tile_info);
+                       p->items, p->tile_info, p->consts);
     e = hipGetLastError();
     if (e != hipSuccess) {
       (void)hipFree(p->items);
       (void)hipFree(p->tile_info);
+      (void)hipFree(p->consts);
       delete p;
       g_last_hip_error = (int)e;
       return BEAR_ERR_HIP;
     }
-    p->bytes = ibytes + sizeof(uint32_t) * ((size_t)p->n_tiles + 2);
+    p->bytes = ibytes + sizeof(uint2) * ((size_t)p->n_tiles + 2) + sizeof(unsigned long long) * EVP_NCONST;
   }
   *out = p;
   return BEAR_OK;
@@ -1467,6 +1472,7 @@ int bear_eval_plan_destroy(bear_eval_plan *plan) {
   (void)hipSetDevice(plan->device);
   (void)hipFree(plan->items);
   (void)hipFree(plan->tile_info);
+  (void)hipFree(plan->consts);
   (void)hipSetDevice(prev);
   delete plan;
   return BEAR_OK;
@@ -1486,6 +1492,12 @@ int bear_eval_plan_f64(bear_ws *ws, const bear_eval_plan *plan, const uint32_t *
   st = eval_make_args(test, train, prior, n_rows, h, n_h, with_ar, van_reg, n_van, eps, noise_seed, row_base, out, &A);
   if (st != BEAR_OK) return st;
   A.has_rid = row_ids ? 1 : 0;
+  // The plan decides the vanilla models' arg-max on the INTEGER training counts (a letter a whole count below the top cannot win):
+  // that is the arg-max of count + van_reg + eps + noise only while 17.5 sigma = 1750 eps stays below a count and the sum keeps
+  // the counts apart (bear_eval_f64 takes any values).
+  if (A.n_van && !(1750.0 * eps < 0.5)) return BEAR_ERR_INVALID_ARG;
+  for (int k = 0; k < A.n_van; ++k)
+    if (!(van_reg[k] >= 0.0 && van_reg[k] <= 0x1p30)) return BEAR_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int n_models = A.n_h + A.n_van;
   const uint64_t nt = plan->n_tiles;
@@ -1520,7 +1532,7 @@ int bear_eval_plan_f64(bear_ws *ws, const bear_eval_plan *plan, const uint32_t *
 #endif
 #define EVP_LAUNCH(NH_, NV_)                                                                                                        \
   hipLaunchKernelGGL((eval_plan_kernel<NH_, NV_>), dim3(grid), dim3(EVP_THREADS), sizeof(evp_lds), s, test, train, prior, row_ids, n_rows, A, \
-                     h0, nh, v0, nv, common, plan->items, plan->tile_info, nt, lt, ws->eval_partials EVP_DBG_ARG)
+                     h0, nh, v0, nv, common, plan->items, plan->tile_info, plan->consts, nt, lt, ws->eval_partials EVP_DBG_ARG)
     if (nh == 0) EVP_LAUNCH(0, 4);
     else if (nh == 1 && nv == 0) EVP_LAUNCH(1, 0);
     else if (nh == 1) EVP_LAUNCH(1, 4);

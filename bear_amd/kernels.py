@@ -417,6 +417,9 @@ def evaluate_planned(plan, prior, h, van_reg, eps=EPSILON, with_ar=True, noise_s
             raise ValueError("prior must be 16-byte aligned with one row per planned context")
     hs, hp = _host_f64(h) if h is not None else (np.zeros(0), ctypes.c_void_p(0))
     vs, vp = _host_f64(van_reg) if van_reg is not None else (np.zeros(0), ctypes.c_void_p(0))
+    if vs.size and not (1750.0 * float(eps) < 0.5 and (vs >= 0.0).all() and (vs <= 2.0 ** 30).all()):
+        raise ValueError("a planned evaluation decides the vanilla models' arg-max on the integer counts: it needs 1750 eps < 0.5 "
+                         "and 0 <= van_reg <= 2^30 (kernels.evaluate takes any values)")
     out = torch.empty(2 * (hs.size + vs.size) + 3, dtype=torch.float64, device=test.device)
     with torch.cuda.device(test.device):
         st = _lib.lib().bear_eval_plan_f64(plan.ws.handle, plan._h, _ptr(test), _ptr(train), _ptr(prior), n, hp, hs.size, int(bool(with_ar)),

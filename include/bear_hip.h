@@ -394,13 +394,18 @@ int bear_eval_f64(bear_ws *ws, const uint32_t *test, const uint32_t *train, cons
 /*
  * The same on a sorted plan of the TEST column, for a table that stays resident (a held-out evaluation after training, the
  * train-set evaluation, every value of an h_scan): bear_eval_plan_create lists, per tile of 448 contexts, the cells and the rows
- * with a non-zero test count sorted by count, and the rows whose largest TRAINING counts tie (their vanilla arg-max is decided
- * by the noise) -- asynchronous on `stream`, ~13 B of plan per context.  `train` [dev, nullable] is the conditioning column the
+ * with a non-zero test count sorted by count, the rows whose largest TRAINING counts tie (their vanilla arg-max is decided
+ * by the noise: which letters tie, most first) and the rows beyond the vanilla models' histogram bins (training + test total >=
+ * 2048), and counts once what the vanilla models need of the table as a whole (histograms of the integer arguments of their
+ * lgamma differences, the test counts under a unique largest training count, the total length) -- asynchronous on `stream`,
+ * ~16 B of plan per context.  `train` [dev, nullable] is the conditioning column the
  * evaluations will use (NULL: none); bear_eval_plan_f64 must be given the same test / train buffers.  It streams the row slabs
  * and the plan through a three-slot LDS ring and evaluates wave-uniform units of equal counts without a workgroup barrier --
  * rows without test transitions cost nothing.  Arguments, output vector and noise stream are those of bear_eval_f64
  * (identical results up to the order of the fp64 sums; accuracies exactly).  The plan is valid for exactly the buffer contents
- * it was built from.
+ * it was built from.  With vanilla models the plan's tie lists stand for the arg-max of count + van_reg + eps + noise only while
+ * the noise cannot bridge a whole count: BEAR_ERR_INVALID_ARG unless 1750 eps < 0.5 and 0 <= van_reg <= 2^30 (bear_eval_f64
+ * takes any values).
  *   row_ids [dev, nullable] uint32 [n_rows], 16-byte aligned: the buffers hold a COMPACTED batch -- only the contexts with
  *           held-out counts (nothing else enters any of the sums) -- and row i is row `row_base + row_ids[i]` of the table: the
  *           key of its tie-breaking noise, so the accuracies of a compacted batch equal those of the whole batch exactly.

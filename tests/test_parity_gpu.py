@@ -818,6 +818,11 @@ def test_eval_plan_many_models_and_zero_rows(dev):
         assert np.allclose(parts[k], want[k], rtol=ELBO_RTOL, atol=0), k
     for k in (3, 4, 5, 6):
         assert np.array_equal(np.asarray(parts[k]), np.asarray(want[k])), k
+    # the plan decides the vanilla arg-max on the integer counts: values for which that is not the arg-max of count + van_reg +
+    # eps + noise are refused (include/bear_hip.h); the unplanned entry takes them
+    for bad in (dict(eps=1e-3), dict(van_reg=[2.0 ** 31])):
+        with pytest.raises(ValueError):
+            kernels.evaluate_planned(plan, _to_dev(f, dev), [1.0], bad.get("van_reg", [1.0]), eps=bad.get("eps", 1e-7))
     empty = torch.zeros((0, 5), dtype=torch.int32, device=dev)
     pe = kernels.EvalPlan(empty, empty.clone())
     z = kernels.evaluate_planned(pe, torch.zeros((0, 5), dtype=torch.float64, device=dev), [1.0], [1.0]).cpu().numpy()
