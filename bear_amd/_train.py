@@ -193,9 +193,18 @@ def sort_by_kmer(codes, lag):
 
 class ResidentBatches:
     """This rank's row shard of every batch of one epoch, uploaded once: per batch the device slabs of the
-    requested dataset columns, the k-mer codes, and (lazily) the kernel plans."""
+    requested dataset columns, the k-mer codes, and (lazily) the kernel plans.
 
-    def __init__(self, data, columns, device, want_codes=False, drop_empty=None, kmer_order=False, prebuild=(), per_row_extra=0):
+    STREAMING (``self.streaming``; the reference's ``tf.data`` pipeline with ``cache=False``, dataloader.py:36-50): when this
+    rank's share of the epoch does not fit its HBM -- or BEAR_AMD_STREAM=1 asks for it -- only a window of batches is on the
+    device: ``load(k)`` makes batch k resident (upload through the pinned ring, compaction, k-mer order, plans: exactly what a
+    resident batch gets), drops every other batch and starts the upload of the batch after it on the side stream, so that a
+    step's kernels run under the next batch's PCIe transfer.  ``self.batches[k]`` is then the same dict object for the whole
+    run -- meta data only (``global_rows``, ``row0``, the uploaded row count) while the batch is not loaded -- and every
+    epoch re-uploads every batch: such a run is bound by PCIe (~45 GB/s), not by the kernels; more ranks are the fast way."""
+
+    def __init__(self, data, columns, device, want_codes=False, drop_empty=None, kmer_order=False, prebuild=(), per_row_extra=0,
+                 stream=None):
         """``drop_empty``: name of the column a training run fits, or an evaluation scores.  A context without counts in it adds
         exactly nothing to the ELBO or to any gradient (``D(x, 0) = 0``, core.py:73-74) -- nor to any of the seven sums of
         ``_evaluation_step`` (bear_net.py:323-371: every term carries a held-out count as a factor) -- so its row is left out of the
@@ -216,9 +225,29 @@ class ResidentBatches:
         codes = data.codes() if (want_codes and not fast_codes) else None
         rank, world = dist.world()
         pieces = list(zip(data.batch_bounds(), data.rank_pieces(rank, world)))
+        self.streaming = False
+        self.loads = 0                      # streaming: batches made resident so far
         if not on_dev:
-            hbm_budget_check(data, len(columns), want_codes, device, rows=sum(g1 - g0 for _, (g0, g1, _) in pieces),
-                             per_row_extra=per_row_extra)
+            if stream is None:
+                stream = bool(os.environ.get("BEAR_AMD_STREAM")) and os.environ.get("BEAR_AMD_STREAM") != "0"
+            largest = max([g1 - g0 for _, (g0, g1, _) in pieces] + [0])
+            if not stream:
+                try:
+                    hbm_budget_check(data, len(columns), want_codes, device, rows=sum(g1 - g0 for _, (g0, g1, _) in pieces),
+                                     per_row_extra=per_row_extra)
+                except MemoryError as err:
+                    if data.shuffle_seed is not None or len(pieces) < 2:    # (a shuffled epoch is permuted on the device as a whole)
+                        raise
+                    stream = str(err)
+            if stream:
+                if data.shuffle_seed is not None:
+                    raise ValueError("a streamed epoch cannot be shuffled on the device (the shuffle permutes the whole shard in HBM)")
+                # the window: the batch in use, the batch landing, and the blocks of the batch just dropped (free for the side
+                # stream only once the steps that read them have run)
+                hbm_budget_check(data, len(columns), want_codes, device, rows=3 * largest, per_row_extra=per_row_extra)
+                if isinstance(stream, str):
+                    warnings.warn(f"{stream}  --  streaming the epoch instead: batches are re-uploaded every epoch (PCIe-bound)")
+                self.streaming = True
         up = None if on_dev else Uploader(device, expect_bytes=max(
             [(g1 - g0) * 20 for _, (g0, g1, _) in pieces] + [data.local_rows * 20 if data.shuffle_seed is not None else 0, 1]))
         self.upload_bytes = 0
@@ -269,8 +298,9 @@ class ResidentBatches:
                     entry["codes"], entry["_raw_codes"] = device_codes(lo, hi)
             return entry
 
-        def finish(entry):
-            """Everything of a landed batch that runs on the compute stream: encode, drop the empty rows, k-mer order, plans."""
+        def finish(entry, slot=None):
+            """Everything of a landed batch that runs on the compute stream: encode, drop the empty rows, k-mer order, plans.
+            ``slot`` (streaming): the batch's place in ``self.batches`` -- its dict is refilled in place."""
             if entry.pop("_raw_codes", False):
                 entry["codes"] = kernels.encode_kmers(entry["codes"], data.alphabet)
             if drop_empty and entry["rows"] and not os.environ.get("BEAR_AMD_ALL_ROWS"):
@@ -293,10 +323,24 @@ class ResidentBatches:
                     # (the evaluation's tie-breaking noise is keyed by the table row, whatever the order or the sharding)
                     entry["row_ids"] = order.to(torch.int32).contiguous()
                 del order
-            self.batches.append(entry)
+            if slot is None:
+                self.batches.append(entry)
+                slot = len(self.batches) - 1
+            else:
+                entry["uploaded_rows"], entry["_loaded"] = self.batches[slot]["uploaded_rows"], True
+                self.batches[slot].clear()
+                self.batches[slot].update(entry)
             if entry["rows"]:
                 for column, ncol, ref_column in prebuild:
-                    self.plan(len(self.batches) - 1, column, ncol, ref_column)
+                    self.plan(slot, column, ncol, ref_column)
+        if self.streaming:
+            import concurrent.futures
+            self._enqueue, self._finish, self._up = enqueue, finish, up
+            self._pool = concurrent.futures.ThreadPoolExecutor(1)
+            self._pending = None            # (batch, future of its enqueued upload)
+            for (a, b), (g0, g1, _) in pieces:
+                self.batches.append({"global_rows": b - a, "rows": g1 - g0, "uploaded_rows": g1 - g0, "row0": g0, "plans": {}, "_loaded": False})
+            return
 
         # one batch in flight: a worker thread feeds batch k + 1 through the staging ring (memcpy and waits release the GIL)
         # while this thread compacts, sorts and plans batch k on the compute stream
@@ -319,6 +363,54 @@ class ResidentBatches:
             self.upload_bytes = up.bytes
             torch.cuda.current_stream(device).synchronize()    # the staging buffers go away with `up`
 
+    def load(self, k):
+        """Batch k's entry with its slabs on the device.  Resident epochs: ``self.batches[k]``.  Streaming: see the class."""
+        e = self.batches[k]
+        if not self.streaming:
+            return e
+        stream = torch.cuda.current_stream(self.device)
+        if not e["_loaded"]:
+            for other in self.batches:              # (plans go with their entry: bear_plan_destroy synchronises the device)
+                if other["_loaded"] and other is not e:
+                    keep = {key: other[key] for key in ("global_rows", "uploaded_rows", "row0")}
+                    other.clear()
+                    other.update(keep, rows=keep["uploaded_rows"], plans={}, _loaded=False)
+            if self._pending is not None and self._pending[0] != k:
+                self._pending[1].result()           # a prefetch nobody asked for (batches taken out of order): dropped
+                self._pending = None
+            if self._pending is None:
+                self._up.stream.wait_stream(stream)
+                landed = self._enqueue(k)
+            else:
+                landed = self._pending[1].result()
+            self._pending = None
+            self._up.wait()                         # the compute stream waits for the copies (not the host)
+            self._finish(landed, slot=k)
+            self.loads += 1
+            self.upload_bytes = self._up.bytes
+        nxt = (k + 1) % len(self.batches)
+        if self._pending is None and not self.batches[nxt]["_loaded"]:
+            # the next batch goes up while this one's kernels run: its blocks may be those of a batch dropped above, so the side
+            # stream first waits for everything enqueued so far (the steps that read them)
+            self._up.stream.wait_stream(stream)
+            self._pending = (nxt, self._pool.submit(self._enqueue, nxt))
+        return e
+
+    def loaded(self):
+        """(k, entry) over the batches in order, each resident while it is the current one."""
+        for k in range(len(self.batches)):
+            yield k, self.load(k)
+
+    def close(self):
+        """Streaming: waits for an upload still in flight and drops the staging state (the end of a driver's loop)."""
+        if self.streaming and getattr(self, "_pool", None) is not None:
+            if self._pending is not None:
+                self._pending[1].result()
+                self._pending = None
+            self._pool.shutdown(wait=True)
+            self._pool = None
+            torch.cuda.current_stream(self.device).synchronize()    # the staging buffers go away with the uploader
+
     def eval_plan(self, k, column="test", train_column="train"):
         """Sorted plan of batch k's test column given its conditioning column, if any (built on first use, kept for later
         evaluations of the same shard)."""
@@ -336,6 +428,24 @@ class ResidentBatches:
         if key not in e["plans"]:
             e["plans"][key] = kernels.Plan(e[column], ncol, ref=None if ref_column is None else e[ref_column])
         return e["plans"][key]
+
+
+def reducers(res, make):
+    """The batches' reduce functions from ``make(k)``, which loads batch k and builds what its step needs (plans, paired lists,
+    prefix levels).  Resident epochs: all of them now, before anything is captured.  Streamed epochs: batch k's is made each time
+    the batch comes up and dropped with it."""
+    if not res.streaming:
+        return [make(k) for k in range(len(res.batches))]
+
+    def lazy(k):
+        def reduce(packed):
+            e = res.load(k)
+            fn = e.get("_reduce")
+            if fn is None:
+                fn = e["_reduce"] = make(k)
+            fn(packed)
+        return reduce
+    return [lazy(k) for k in range(len(res.batches))]
 
 
 def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimizer_name, train_ar, acc_steps, device,
@@ -533,6 +643,7 @@ def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, lear
             for p in rest:
                 p.grad = None
             sums = out
+            res.load(k)                            # (streamed epochs: the batch comes up now; resident ones: nothing to do)
             if e["rows"] and ref_mix is not None:
                 net_fn, ref_fn, tau_p, nw_p = ref_mix
                 net = net_fn(e)
@@ -568,7 +679,7 @@ def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, lear
     max_rows = max([e["global_rows"] for e in res.batches] + [0])
     return run_device_steps([reducer(k) for k in range(len(res.batches))], scales, theta, repeats, learning_rate, optimizer_name,
                             train_ar, acc_steps, device, eager_first_period=True,
-                            graph_ok=max_rows <= int(os.environ.get("BEAR_AMD_GRAPH_MAX_ROWS", 1 << 22)))
+                            graph_ok=not res.streaming and max_rows <= int(os.environ.get("BEAR_AMD_GRAPH_MAX_ROWS", 1 << 22)))
 
 
 def compute_dtype(dtype):

@@ -64,18 +64,21 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
         # fused kernels [-> all-reduce of the packed vector] -> Adam, no host round trip (_train.run_device_steps)
         theta = torch.cat([h_signed.detach().reshape(1)] + [p.detach().reshape(-1) for p in ar_params]).to(
             device=device, dtype=torch.float64).contiguous()
-        packs = [kernels.pack_kmers(e["codes"].contiguous()) if e["rows"] else None for e in res.batches]
-        if fused_mat is not None:       # the linear head reads table-row words, not packed letters
-            packs = [kernels.linear_index(q, lag) if q is not None else None for q in packs]
+        def pack_of(e):                 # the batch's k-mers as the fused kernels read them (kept with the batch)
+            if "pack" not in e:
+                q = kernels.pack_kmers(e["codes"].contiguous())
+                e["pack"] = kernels.linear_index(q, lag) if fused_mat is not None else q    # the linear head reads table-row words, not packed letters
+            return e["pack"]
         if cnn_ok:
             fw = ar_func.cnn_filter_width
             cnn_ws = kernels.default_workspace(device)     # the workspace the plans below are created on: the step's reservation lives there
             bufs = kernels.cnn_step_buffers(max(max(e["rows"] for e in res.batches), 1), lag, fw, device, ws=cnn_ws)   # one set, largest batch
 
         def reducer(k):
-            e = res.batches[k]
+            e = res.load(k)
             if e["rows"] == 0:
                 return lambda packed: packed.zero_()
+            pack = pack_of(e)
             plan = res.plan(k, "train", 5)           # built here, before any capture (plan creation allocates and synchronises)
             if _train.deterministic() and fused_mat is not None:
                 # BEAR_AMD_DETERMINISTIC: the fixed-point scale of the linear step's gradient tables follows from the counts of the
@@ -85,20 +88,21 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
                 dist.allreduce_sum_(tot)
                 dist.allreduce_max_(cmax)
                 plan.set_count_bound(tot.tolist() + cmax.tolist())
-            if fused_mat is not None and packs[k].data_ptr() % 16 == 0:
+            if fused_mat is not None and pack.data_ptr() % 16 == 0:
                 # neighbours of the sorted batch that share all letters but the last three go through the step two at a time
                 # (kernels_linear.h, paired lists); declined by the library for tables too sparse to gain from it
-                plan.pair_contexts(packs[k], lag)
+                plan.pair_contexts(pack, lag)
             if cnn_ok:
-                if packs[k].data_ptr() % 16 == 0:
+                if pack.data_ptr() % 16 == 0:
                     # a position of the sorted batch once per distinct prefix (kernels_cnn.h, prefix levels); none attached when the
                     # prefixes of the table do not repeat
-                    plan.attach_cnn_levels(packs[k], lag, fw)
+                    plan.attach_cnn_levels(pack, lag, fw)
                 views = tuple(b[:e["rows"]] for b in bufs)
-                return lambda packed: kernels.net_cnn_train_reduce(plan, packs[k], lag, fw, theta, views, packed, train_ar=train_ar)
-            return lambda packed: kernels.net_linear_train_reduce(plan, packs[k], lag, theta, packed, train_ar=train_ar)
-        reduce_fns = [reducer(k) for k in range(len(res.batches))]
-        losses = _train.run_device_steps(reduce_fns, scales, theta, data.repeats, learning_rate, optimizer_name, train_ar, acc_steps, device)
+                return lambda packed: kernels.net_cnn_train_reduce(plan, pack, lag, fw, theta, views, packed, train_ar=train_ar)
+            return lambda packed: kernels.net_linear_train_reduce(plan, pack, lag, theta, packed, train_ar=train_ar)
+        reduce_fns = _train.reducers(res, reducer)
+        losses = _train.run_device_steps(reduce_fns, scales, theta, data.repeats, learning_rate, optimizer_name, train_ar, acc_steps, device,
+                                         graph_ok=not res.streaming)
         with torch.no_grad():
             k = 0
             for p in params:
@@ -115,6 +119,7 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
             return _train.scatter_live(out, live, e["rows"])
         losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, learning_rate, optimizer_name, train_ar,
                                            acc_steps, normalized, device)
+    res.close()
     ar_funcs.release_ar_func_cache(ar_func)
     _train.log_losses(losses, writer, loss_save, acc_steps)
     return params, h_signed, ar_func
@@ -132,7 +137,7 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
                                  kmer_order=ar_funcs.wants_kmer_order(ar_func))
     sums = _train.EvaluationSums(h, van_reg, noise_seed=seed)     # the batches' sums stay on the device until all are enqueued
     with torch.no_grad():
-        for k, e in enumerate(res.batches):
+        for k, e in res.loaded():
             if not e["rows"]:
                 prior = torch.zeros((0, 5), dtype=dtype, device=device)
             else:                                        # prior rows of the contexts with held-out counts: nothing else enters a sum
@@ -141,6 +146,7 @@ def _eval(data, ds_loc_train, ds_loc_test, alphabet, h, ar_func, van_reg, dtype,
                 prior = out.expand(e["rows"], 5).contiguous() if live is None or out.shape[0] == 1 else _train.scatter_live(out, live, e["rows"])
             sums.add(e["test"], prior, e.get("train"), row_base=e["row0"], plan=res.eval_plan(k) if e["rows"] else None,
                      row_ids=e.get("row_ids") if e["rows"] else None)
+    res.close()
     ar_funcs.release_ar_func_cache(ar_func)
     return sums.result(), device
 

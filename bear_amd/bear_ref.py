@@ -112,16 +112,18 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
     theta = torch.stack([p.detach().reshape(()) for p in params[:3]]).to(device=device, dtype=torch.float64).contiguous()
 
     def reducer(k):
-        e = res.batches[k]
+        e = res.load(k)
         if e["rows"] == 0:
             return lambda packed: packed.zero_()
         # built here, before any capture (plan creation allocates and synchronises); the reference column is resident too, so the
         # plan folds the contexts without reference counts into a histogram and a step streams only the others' items
         plan = res.plan(k, "train", 4, ref_column="ref")
         return lambda packed: kernels.ref_train_reduce(plan, e["ref"], theta, packed, train_ar=train_ar)
-    reduce_fns = [reducer(k) for k in range(len(res.batches))]
+    reduce_fns = _train.reducers(res, reducer)
     scales = [-(num_kmers / e["global_rows"]) for e in res.batches]       # loss = -(num_kmers / B) sum LL, bear_ref.py:252-253
-    losses = _train.run_device_steps(reduce_fns, scales, theta, data.repeats, learning_rate, optimizer_name, train_ar, acc_steps, device)
+    losses = _train.run_device_steps(reduce_fns, scales, theta, data.repeats, learning_rate, optimizer_name, train_ar, acc_steps, device,
+                                     graph_ok=not res.streaming)
+    res.close()
     with torch.no_grad():
         for p, val in zip(params[:3], theta):
             p.copy_(val)
@@ -168,6 +170,7 @@ def _train_general(data, num_kmers, params, h_signed, ar_func, learning_rate, op
         ref_mix = (net_fn, lambda e: e["ref_in"], params[1], params[2])
     losses = _train.run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, data.repeats, learning_rate, optimizer_name, train_ar,
                                        acc_steps, ar_func.normalized_rows, device, ref_mix=ref_mix)
+    res.close()
     _ar_funcs.release_ar_func_cache(getattr(ar_func, "net_func", ar_func))
     _train.log_losses(losses, writer, loss_save, acc_steps)
     return params, h_signed, ar_func
@@ -191,7 +194,7 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
     hv = float(torch.as_tensor(h).item()) if np.ndim(torch.as_tensor(h).detach().cpu().numpy()) == 0 else torch.as_tensor(h).detach().cpu().numpy()
     sums = _train.EvaluationSums(hv, van_reg, noise_seed=seed)     # the batches' sums stay on the device until all are enqueued
     with torch.no_grad():
-        for k, e in enumerate(res.batches):
+        for k, e in res.loaded():
             if not e["rows"]:
                 prior = torch.zeros((0, 5), dtype=dtype, device=device)
             else:                                        # prior rows of the contexts with held-out counts: nothing else enters a sum
@@ -204,5 +207,6 @@ def evaluation(data, ds_loc_train, ds_loc_test, ds_loc_ref, alphabet, h, ar_func
                     prior = _train.scatter_live(ar_func(e["codes_live_test"], e["ref_in_live_test"]), live, e["rows"])
             sums.add(e["test"], prior, e.get("train"), row_base=e["row0"], plan=res.eval_plan(k) if e["rows"] else None,
                      row_ids=e.get("row_ids") if e["rows"] else None)
+    res.close()
     _ar_funcs.release_ar_func_cache(getattr(ar_func, "net_func", ar_func))
     return _train.reduce_evaluation(sums.result(), device, np.ndim(hv) == 0)

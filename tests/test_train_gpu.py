@@ -316,6 +316,80 @@ def test_uploader_and_hbm_budget(monkeypatch, ysd1):
         bear_net.evaluation(data, 0, 1, "dna", torch.tensor(0.4), ar_funcs.make_ar_func_linear(5, 4, device="cuda")[0], np.array([1.0]))
 
 
+@pytest.mark.parametrize("which", ["bear_ref + stop", "bear_net + linear (fused)", "bear_net + cnn (fused)", "bear_net + cnn plugin (autograd)",
+                                   "bear_ref + linear net (autograd)"])
+def test_streamed_epochs_equal_resident_epochs(which, monkeypatch):
+    """An epoch that does not stay in HBM is STREAMED (the reference's tf.data pipeline with cache=False, dataloader.py:36-50): a
+    window of batches on the device, every batch re-uploaded, compacted, sorted and planned each epoch, the next one crossing PCIe
+    while a step runs.  Same kernels on the same batches in the same order as the resident loop: same losses and parameters (to
+    the order of a plan's sums), for every driver; the held-out evaluation likewise (accuracies exactly); and the switch happens
+    by itself when the budget check refuses the whole epoch but takes the window."""
+    data = dataloader.dataloader(YSD1, "dna", 300, 3)           # 5 batches per epoch, the last one short
+    data.counts[0, ::4] = 0
+    n, epochs = data.num_rows, 3
+    seen = {}
+    budget = _train.hbm_budget_check
+
+    def train_once():
+        torch.manual_seed(11)
+        ls = []
+        if which.startswith("bear_ref + stop"):
+            out = bear_ref.train(data.repeat(epochs), n, epochs, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False, loss_save=ls)
+        elif which.startswith("bear_ref"):
+            out = bear_ref.train(data.repeat(epochs), n, epochs, 0, 2, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", False, loss_save=ls)
+        elif "linear" in which:
+            out = bear_net.train(data.repeat(epochs), n, epochs, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", False, loss_save=ls)
+        elif "plugin" in which:
+            out = bear_net.train(data.repeat(epochs), n, epochs, 0, "dna", 5, ar_funcs.make_ar_func_cnn,
+                                 {"num_filters": 20, "filter_width": 3, "kmer_layer1_width": 16}, 0.01, "Adam", False, loss_save=ls)
+        else:
+            out = bear_net.train(data.repeat(epochs), n, epochs, 0, "dna", 5, ar_funcs.make_ar_func_cnn, CNN_CFG, 0.01, "Adam", False, loss_save=ls)
+        return ls, np.concatenate([p.detach().cpu().numpy().reshape(-1) for p in out[0]]), dict(_train.LAST_RUN), out
+    resident = train_once()
+    assert len(resident[0]) == 5 * epochs
+    monkeypatch.setenv("BEAR_AMD_STREAM", "1")
+    loads = []
+    real_load = _train.ResidentBatches.load
+
+    def counting_load(self, k):
+        e = real_load(self, k)
+        loads.append((k, self.loads, sum(b.get("_loaded", True) for b in self.batches)))
+        return e
+    monkeypatch.setattr(_train.ResidentBatches, "load", counting_load)
+    streamed = train_once()
+    assert streamed[2]["graph"] is False
+    assert loads and max(x[2] for x in loads) == 1 and loads[-1][1] == 5 * epochs       # one batch resident at a time; every batch, every epoch
+    assert np.allclose(streamed[0], resident[0], rtol=1e-11, atol=0)
+    assert np.allclose(streamed[1], resident[1], rtol=1e-8, atol=1e-10)
+    # the held-out evaluation over streamed batches
+    if which.startswith("bear_net"):
+        ev = lambda: bear_net.evaluation(data, 0, 1, "dna", torch.exp(streamed[3][1]).detach(), streamed[3][2], np.array([0.1, 1.0]))
+    else:
+        ev = lambda: bear_ref.evaluation(data, 0, 1, 2, "dna", torch.exp(streamed[3][1]).detach(), streamed[3][2], np.array([0.1, 1.0]))
+    loads.clear()
+    got = ev()
+    assert len(loads) == 5
+    monkeypatch.delenv("BEAR_AMD_STREAM")
+    want = ev()
+    for a, b in zip(got, want):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        assert np.allclose(a, b, rtol=1e-11, atol=0)
+    for k in (6, 7, 8):                      # accuracies: counts of exactly decided arg-maxes over the same rows
+        assert np.array_equal(np.asarray(got[k]), np.asarray(want[k]))
+    # ... and without being asked: the whole epoch is refused, the window is not
+    def tight(data_, n_columns, want_codes, device, rows=None, per_row_extra=0):
+        seen.setdefault("rows", []).append(rows)
+        if rows is not None and rows > 3 * 300:
+            raise MemoryError("this rank's contexts need more HBM than is free: shard the rows over more GPUs")
+        return budget(data_, n_columns, want_codes, device, rows=rows, per_row_extra=per_row_extra)
+    monkeypatch.setattr(_train, "hbm_budget_check", tight)
+    loads.clear()
+    with pytest.warns(UserWarning, match="streaming the epoch"):
+        auto = train_once()
+    assert seen["rows"][:2] == [n, 900] and loads and loads[-1][1] == 5 * epochs
+    assert np.allclose(auto[0], resident[0], rtol=1e-11, atol=0)
+
+
 @pytest.mark.parametrize("kind", ["net", "ref"])
 def test_run_config_driver(kind, ysd1):
     """bear_model/tests/test_run.py:12-51 re-stated: the bear_test.cfg workflow returns 1 and the train-set BMM
