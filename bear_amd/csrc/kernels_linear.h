@@ -542,7 +542,7 @@ __device__ __forceinline__ uint32_t lin_phase_a_paired(pln_lds_lin &S, const lin
     rows = reinterpret_cast<const uint32_t *>(B.live)[1 + tid];       // entries 2 tid, 2 tid + 1 behind the two header words
     const uint32_t r0 = rows & 0xffffu, r1 = rows >> 16;              // (plan_pair_kernel: an empty entry only ever sits in the odd slot)
     cA[0] = B.codes[r0];
-    cA[1] = r1 != LIN_EMPTY ? B.codes[r1] : cA[0];
+    cA[1] = B.codes[r1 != LIN_EMPTY ? r1 : r0];                       // (both reads in flight: a read behind a branch waited for the first)
     lin_row2<NG, EXP>(S.T, S.exptab, cA[0], cA[1], fA[0], fA[1]);
   }
   return rows;
@@ -780,6 +780,9 @@ __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned lon
   // the triple rows: one add per context and letter
 #ifdef LIN_SKIP_TRIPLE   // developer build (timing only)
   return;
+#endif
+#ifdef LIN_FAKE_TRIPLE_ROWS   // developer build (timing only): the triple's adds without bank or address conflicts (lane = row)
+  c0 = c1 = (unsigned long long)lane << (6 * (NG - 1));
 #endif
   if (nz0) {
     double *gt = &GT[lin_off<NG>(c0, NG - 1) >> 2];
