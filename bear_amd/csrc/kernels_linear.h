@@ -156,31 +156,123 @@ __global__ void linear_index_kernel(const unsigned long long *__restrict__ raw, 
 // ---- bear_plan_pair_contexts: the paired lists of every tile (see LIN_PAIR_CAP).  One thread per tile walks the tile's list (set-up
 // path: once per batch); the number of entries goes to the list's first word and to n_ent[tile] (0xffff: the list does not fit, the
 // tile keeps its plain list -- the host sorts the tiles into two descriptor arrays, one per form of the kernel).
+//
+// WHICH contexts of a run of equal leading letters (a "block": all pair groups equal) share a lane, and in which order the lanes
+// follow each other inside the block, is free -- every sum is the same -- and decides what the triple's gradient adds cost: an LDS
+// fp64 atomic of 64 lanes is carried out in four passes of 16 lanes, and a pass takes as many turns as its fullest bank pair holds
+// lanes (measured with timing-only builds, profiles/NOTES_r05.md: rows = lane % 16 cost what 64 distinct rows cost, rows = lane / 2
+// cost 0.1 ms more per 1e8 contexts).  The bank pair of a context's add is its triple row mod 16, so the builder deals a block's
+// contexts to the (16 lanes x slot) groups greedily: per lane and slot the context whose class is not yet in the group and has the
+// most contexts left in the block; when every class left is taken, the second slot stays empty (while the list has room) or the
+// fullest class goes anyway.  Ties go to the context whose ROW class (row mod 16: the bank pair of its softmax row in phases A and
+// C) is new to the group.  Measured on the 1e8 table, same box: 1.479 -> 1.455 ms from the order alone, 1.447 with the empty slots,
+// 1.432 with the row classes.  `scratch` (uint16 [n_tiles][PLN_LIVE_STRIDE]): a block's rows bucketed by class.
 __global__ __launch_bounds__(64) void plan_pair_kernel(const pln_tile *__restrict__ tiles, uint64_t n_tiles, const uint16_t *__restrict__ live,
                                                        const unsigned long long *__restrict__ kmer_index, int lag, uint16_t *__restrict__ live2,
-                                                       uint16_t *__restrict__ n_ent) {
+                                                       uint16_t *__restrict__ n_ent, uint16_t *__restrict__ scratch, int empty_slots) {
   const lin_geom G = lin_make_geom(lag);
   const unsigned long long pair_mask = (1ull << (6 * G.npair)) - 1ull;      // every pair group of the index word (bear_linear_index_u64)
+  const int tri_shift = 6 * G.npair;
   for (uint64_t t = (uint64_t)blockIdx.x * 64 + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * 64) {
     const uint16_t *in = live + t * PLN_LIVE_STRIDE;
-    uint16_t *out = live2 + t * LIN_LIVE2_STRIDE;
+    uint16_t *out = live2 + t * LIN_LIVE2_STRIDE, *bucket = scratch + t * PLN_LIVE_STRIDE;
     const uint64_t row0 = tiles[t].row0;
     const uint32_t n = in[0];
-    uint32_t m = 0;
-    unsigned long long prev = 0ull;
-    for (uint32_t j = 0; j < n; ++j) {
-      const uint32_t row = in[1 + j];
-      const unsigned long long p = kmer_index[row0 + row] & pair_mask;
-      if (j && p != prev && (m & 1u)) {
-        if (m < LIN_PAIR_CAP) out[2 + m] = (uint16_t)LIN_EMPTY;
-        ++m;
-      }
-      if (m < LIN_PAIR_CAP) out[2 + m] = (uint16_t)row;
+    uint32_t m = 0;                       // entries written (or that would have been: the list is dropped when m > LIN_PAIR_CAP)
+    uint32_t used[2] = {0u, 0u};          // classes present in the current group of 16 lanes, per slot
+    uint32_t used_row[2] = {0u, 0u};      // ... and the classes of the contexts' ROWS (row mod 16: the bank pair of the lane's softmax row in
+                                          // phases A and C, five doubles per row and 5 is odd)
+    // entries the blocks need at least (a block's contexts, rounded up to whole lanes): empty slots beyond that only while the list
+    // is sure to fit without them too
+    uint32_t need = 0;
+    for (uint32_t s = 0; s < n;) {
+      const unsigned long long p = kmer_index[row0 + in[1 + s]] & pair_mask;
+      uint32_t e = s + 1u;
+      while (e < n && (kmer_index[row0 + in[1 + e]] & pair_mask) == p) ++e;
+      need += (e - s + 1u) & ~1u;
+      s = e;
+    }
+    auto put = [&](uint32_t v) {
+      if (m < LIN_PAIR_CAP) out[2 + m] = (uint16_t)v;
       ++m;
-      prev = p;
+    };
+    for (uint32_t s = 0; s < n;) {
+      // the block [s, e): contexts with the leading letters of entry s
+      const unsigned long long p = kmer_index[row0 + in[1 + s]] & pair_mask;
+      uint32_t cnt[16], cur[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) cnt[q] = 0u;
+      uint32_t e = s;
+      for (; e < n; ++e) {
+        const unsigned long long w = kmer_index[row0 + in[1 + e]];
+        if ((w & pair_mask) != p) break;
+        const uint32_t cl = (uint32_t)(w >> tri_shift) & 15u;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cnt[q] += (uint32_t)q == cl ? 1u : 0u;
+      }
+      {
+        uint32_t run = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          cur[q] = run;
+          run += cnt[q];
+        }
+      }
+      for (uint32_t i = s; i < e; ++i) {                       // bucket the block's rows by class (order inside a class: as listed)
+        const uint32_t row = in[1 + i];
+        const uint32_t cl = (uint32_t)(kmer_index[row0 + row] >> tri_shift) & 15u;
+        uint32_t at = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if ((uint32_t)q == cl) at = cur[q]++;
+        bucket[at] = (uint16_t)row;
+      }
+      // cur[q] is now the END of class q's bucket; cnt[q] contexts of it are left, the next one sits at cur[q] - cnt[q]
+      uint32_t left = e - s;
+      need -= (left + 1u) & ~1u;                               // (of the blocks behind this one)
+      while (left) {
+        for (int slot = 0; slot < 2; ++slot) {
+          if ((m & 31u) == 0u) used[0] = used[1] = used_row[0] = used_row[1] = 0u;         // a new group of 16 lanes
+          if (!left) {
+            put(LIN_EMPTY);                                    // (only ever behind a first slot: m is odd here)
+            continue;
+          }
+          // of the classes not in the group yet the one with the most contexts left -- among those whose next context also brings a
+          // new row class, if there is one (score: 2 x count + 1)
+          uint32_t best = 16u, best_n = 0u, any = 16u, any_n = 0u;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const uint32_t c = cnt[q];
+            if (c > any_n) any_n = c, any = (uint32_t)q;
+            if (c != 0u && !((used[slot] >> q) & 1u)) {
+              const uint32_t rc = (uint32_t)bucket[cur[q] - c] & 15u;
+              const uint32_t rn = ((used_row[slot] >> rc) & 1u) ? 0u : 1u;
+              const uint32_t score = 2u * c + rn;       // (the row class as the first criterion instead: the same time)
+              if (score > best_n) best_n = score, best = (uint32_t)q;
+            }
+          }
+          // every class left is in this group already: an empty second slot while the tile's list keeps room for what is left
+          if (empty_slots && best == 16u && slot == 1 && m + 1u + ((left + 1u) & ~1u) + need <= LIN_PAIR_CAP) {
+            put(LIN_EMPTY);
+            continue;
+          }
+          const uint32_t cl = best != 16u ? best : any;
+          uint32_t row = 0;
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if ((uint32_t)q == cl) {
+              row = bucket[cur[q] - cnt[q]];
+              --cnt[q];
+            }
+          used[slot] |= 1u << cl;
+          used_row[slot] |= 1u << (row & 15u);
+          put(row);
+          --left;
+        }
+      }
+      s = e;
     }
     const bool fits = m <= LIN_PAIR_CAP;
-    if (fits && (m & 1u)) out[2 + m] = (uint16_t)LIN_EMPTY, ++m;     // (LIN_PAIR_CAP is even: this stays inside)
     out[0] = fits ? (uint16_t)m : (uint16_t)0;
     out[1] = 0;
     n_ent[t] = fits ? (uint16_t)m : (uint16_t)0xffffu;
@@ -782,7 +874,11 @@ __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned lon
   return;
 #endif
 #ifdef LIN_FAKE_TRIPLE_ROWS   // developer build (timing only): the triple's adds without bank or address conflicts (lane = row)
-  c0 = c1 = (unsigned long long)lane << (6 * (NG - 1));
+  {   // 1: row = lane; 2: lane % 32 (pairs of equal rows, one per half-wave); 3: lane / 2 (adjacent pairs); 4: lane % 16; 5: lane % 8
+    const uint32_t fr = LIN_FAKE_TRIPLE_ROWS == 1 ? lane : LIN_FAKE_TRIPLE_ROWS == 2 ? lane % 32u : LIN_FAKE_TRIPLE_ROWS == 3 ? lane / 2u
+                        : LIN_FAKE_TRIPLE_ROWS == 4 ? lane % 16u : lane % 8u;
+    c0 = c1 = (unsigned long long)fr << (6 * (NG - 1));
+  }
 #endif
   if (nz0) {
     double *gt = &GT[lin_off<NG>(c0, NG - 1) >> 2];
@@ -1181,7 +1277,12 @@ __global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_ker
       const uint32_t un = n_work - 1u - w;
       uint32_t cmin, cmax;
       const uint32_t ci[1] = {pln_unit_counts(E, n_light, un, lane, &cmin, &cmax)};
+#ifdef LIN_FAKE_ITEM_OFFS   // developer build (timing only): the items' cells without bank conflicts (64 consecutive cells per unit)
+      const uint32_t off_true = items[un * 64u + lane];
+      const uint32_t off = off_true == (uint32_t)PLN_SENTINEL ? off_true : (un * 64u + lane) % (rows * 5u);
+#else
       const uint32_t off = items[un * 64u + lane];
+#endif
       const double x[1] = {__builtin_fma(S.pri[off], u, eps)};
       bear_dp o[1] = {{0.0, 0.0}};
       if (!AR) srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
