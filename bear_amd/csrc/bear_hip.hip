@@ -1581,6 +1581,18 @@ int bear_debug_read_timing(bear_ws *ws, unsigned long long *host, int n_words) {
   return BEAR_OK;
 }
 
+// Developer probe: the paired lists (bear_plan_pair_contexts) of tiles [first, first + n) and their first rows, to the host
+// (scripts/dev/pair_conflicts.py counts the bank-pair collisions of the triple adds from them).
+extern "C" int bear_debug_pair_lists(const bear_plan *plan, uint64_t first, uint64_t n, uint16_t *lists, uint64_t *row0) {
+  if (!plan || !plan->live2 || !lists || !row0 || first + n > plan->n_tiles) return BEAR_ERR_INVALID_ARG;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(lists, plan->live2 + first * LIN_LIVE2_STRIDE, n * LIN_LIVE2_STRIDE * sizeof(uint16_t), hipMemcpyDeviceToHost));
+  std::vector<pln_tile> t(n);
+  HIP_TRY(hipMemcpy(t.data(), plan->tiles + first, n * sizeof(pln_tile), hipMemcpyDeviceToHost));
+  for (uint64_t k = 0; k < n; ++k) row0[k] = t[k].row0;
+  return BEAR_OK;
+}
+
 int bear_debug_occupancy(int which) {
   int nb = -1;
   hipError_t e = which == 0

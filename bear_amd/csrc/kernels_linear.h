@@ -164,7 +164,9 @@ __global__ void linear_index_kernel(const unsigned long long *__restrict__ raw, 
 // cost 0.1 ms more per 1e8 contexts).  The bank pair of a context's add is its triple row mod 16, so the builder deals a block's
 // contexts to the (16 lanes x slot) groups greedily: per lane and slot the context whose class is not yet in the group and has the
 // most contexts left in the block; when every class left is taken, the second slot stays empty (while the list has room) or the
-// fullest class goes anyway.  Ties go to the context whose ROW class (row mod 16: the bank pair of its softmax row in phases A and
+// fullest class goes anyway.  Two copies of one k-mer (the benchmark table draws its k-mers with replacement: 28 % of them occur
+// twice or more) take ONE lane: the kernel adds the sum of their gradients to the triple row once (lin_scatter_grad_paired).
+// Ties go to the context whose ROW class (row mod 16: the bank pair of its softmax row in phases A and
 // C) is new to the group.  Measured on the 1e8 table, same box: 1.479 -> 1.455 ms from the order alone, 1.447 with the empty slots,
 // 1.432 with the row classes.  `scratch` (uint16 [n_tiles][PLN_LIVE_STRIDE]): a block's rows bucketed by class.
 __global__ __launch_bounds__(64) void plan_pair_kernel(const pln_tile *__restrict__ tiles, uint64_t n_tiles, const uint16_t *__restrict__ live,
@@ -230,44 +232,65 @@ __global__ __launch_bounds__(64) void plan_pair_kernel(const pln_tile *__restric
       // cur[q] is now the END of class q's bucket; cnt[q] contexts of it are left, the next one sits at cur[q] - cnt[q]
       uint32_t left = e - s;
       need -= (left + 1u) & ~1u;                               // (of the blocks behind this one)
+      // the next context of class q, and whether the one behind it in the bucket is the SAME k-mer (equal index words; the rows of
+      // a class keep their sorted order, so copies of a k-mer are neighbours): such a pair shares a lane and the kernel adds the
+      // sum of the two gradients to the triple row once
+      auto head = [&](int q) -> uint32_t { return bucket[cur[q] - cnt[q]]; };
+      auto head_is_double = [&](int q) -> bool {
+        return cnt[q] >= 2u && kmer_index[row0 + bucket[cur[q] - cnt[q]]] == kmer_index[row0 + bucket[cur[q] - cnt[q] + 1u]];
+      };
       while (left) {
+        if ((m & 31u) == 0u) used[0] = used[1] = used_row[0] = used_row[1] = 0u;         // a new group of 16 lanes
         for (int slot = 0; slot < 2; ++slot) {
-          if ((m & 31u) == 0u) used[0] = used[1] = used_row[0] = used_row[1] = 0u;         // a new group of 16 lanes
           if (!left) {
             put(LIN_EMPTY);                                    // (only ever behind a first slot: m is odd here)
             continue;
           }
           // of the classes not in the group yet the one with the most contexts left -- among those whose next context also brings a
-          // new row class, if there is one (score: 2 x count + 1)
-          uint32_t best = 16u, best_n = 0u, any = 16u, any_n = 0u;
+          // new row class, if there is one (score: 2 x count + 1); the second slot leaves the doubles to the first slots while it can
+          uint32_t best = 16u, best_n = 0u, any = 16u, any_n = 0u, best_d = 16u, best_dn = 0u;
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
             const uint32_t c = cnt[q];
             if (c > any_n) any_n = c, any = (uint32_t)q;
             if (c != 0u && !((used[slot] >> q) & 1u)) {
-              const uint32_t rc = (uint32_t)bucket[cur[q] - c] & 15u;
+              const uint32_t rc = head(q) & 15u;
               const uint32_t rn = ((used_row[slot] >> rc) & 1u) ? 0u : 1u;
               const uint32_t score = 2u * c + rn;       // (the row class as the first criterion instead: the same time)
-              if (score > best_n) best_n = score, best = (uint32_t)q;
+              if (slot == 1 && head_is_double(q)) {
+                if (score > best_dn) best_dn = score, best_d = (uint32_t)q;
+              } else if (score > best_n) {
+                best_n = score, best = (uint32_t)q;
+              }
             }
           }
+          if (best == 16u) best = best_d;
           // every class left is in this group already: an empty second slot while the tile's list keeps room for what is left
           if (empty_slots && best == 16u && slot == 1 && m + 1u + ((left + 1u) & ~1u) + need <= LIN_PAIR_CAP) {
             put(LIN_EMPTY);
             continue;
           }
           const uint32_t cl = best != 16u ? best : any;
-          uint32_t row = 0;
+          uint32_t row = 0, twin = LIN_EMPTY;
 #pragma unroll
           for (int q = 0; q < 16; ++q)
             if ((uint32_t)q == cl) {
-              row = bucket[cur[q] - cnt[q]];
+              if (slot == 0 && head_is_double(q)) {
+                twin = bucket[cur[q] - cnt[q] + 1u];
+                --cnt[q];
+              }
+              row = bucket[cur[q] - cnt[q] - (twin != LIN_EMPTY ? 1u : 0u)];
               --cnt[q];
             }
           used[slot] |= 1u << cl;
           used_row[slot] |= 1u << (row & 15u);
           put(row);
           --left;
+          if (twin != LIN_EMPTY) {                             // the lane is full: the copy adds nothing of its own in the second slot's instruction
+            put(twin);
+            --left;
+            break;
+          }
         }
       }
       s = e;
@@ -874,19 +897,24 @@ __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned lon
   return;
 #endif
 #ifdef LIN_FAKE_TRIPLE_ROWS   // developer build (timing only): the triple's adds without bank or address conflicts (lane = row)
-  {   // 1: row = lane; 2: lane % 32 (pairs of equal rows, one per half-wave); 3: lane / 2 (adjacent pairs); 4: lane % 16; 5: lane % 8
+  {   // 1: row = lane; 2: lane % 32 (pairs of equal rows, one per half-wave); 3: lane / 2 (adjacent pairs); 4: lane % 16; 5: lane % 8; 6, 7: below
     const uint32_t fr = LIN_FAKE_TRIPLE_ROWS == 1 ? lane : LIN_FAKE_TRIPLE_ROWS == 2 ? lane % 32u : LIN_FAKE_TRIPLE_ROWS == 3 ? lane / 2u
-                        : LIN_FAKE_TRIPLE_ROWS == 4 ? lane % 16u : lane % 8u;
+                        : LIN_FAKE_TRIPLE_ROWS == 4 ? lane % 16u : LIN_FAKE_TRIPLE_ROWS == 5 ? lane % 8u
+                        : LIN_FAKE_TRIPLE_ROWS == 6 ? (lane & 7u) + 16u * ((lane >> 3) & 1u)        // 6: two ROWS per bank pair in every pass of 16 lanes
+                        : (lane & 7u) + 16u * ((lane >> 3) & 7u);                                   // 7: ... all rows distinct (lanes 8 apart share a bank pair)
     c0 = c1 = (unsigned long long)fr << (6 * (NG - 1));
   }
 #endif
-  if (nz0) {
+  // (two copies of one k-mer in a lane -- the builder pairs them -- are one row: their sum goes up once)
+  const bool twin = nz1 && c1 == c0;
+  if (nz0 || twin) {
     double *gt = &GT[lin_off<NG>(c0, NG - 1) >> 2];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) lin_gt_add(&gt[b * LIN_GT_PLANE], g0[b]);
+    for (int b = 0; b < 4; ++b) lin_gt_add(&gt[b * LIN_GT_PLANE], twin ? g0[b] + g1[b] : g0[b]);
   }
-  if (__builtin_amdgcn_ballot_w64(nz1)) {
-    if (nz1) {
+  const bool own1 = nz1 && !twin;
+  if (__builtin_amdgcn_ballot_w64(own1)) {
+    if (own1) {
       double *gt = &GT[lin_off<NG>(c1, NG - 1) >> 2];
 #pragma unroll
       for (int b = 0; b < 4; ++b) lin_gt_add(&gt[b * LIN_GT_PLANE], g1[b]);
