@@ -457,8 +457,14 @@ __device__ __forceinline__ void lin_row2(const double *T, const double *exptab, 
       }
     if (g0 + CH < NP) asm("" : "+v"(cw) : "v"(e[0]));     // as in lin_row: the next rows' addresses wait for this product
   }
+#ifdef LIN_FAKE_T_ROWS   // developer build (timing only): the triple's table rows of a wave on consecutive rows (1) / one row for all lanes (2)
+  const uint32_t fake_row = LIN_FAKE_T_ROWS == 1 ? (threadIdx.x & 63u) : 0u;
+  const double2 *t0 = reinterpret_cast<const double2 *>(T + (NG - 1) * LIN_PSTRIDE + fake_row * 4u);
+  const double2 *t1 = reinterpret_cast<const double2 *>(T + (NG - 1) * LIN_PSTRIDE + (fake_row + 64u) * 4u);
+#else
   const double2 *t0 = reinterpret_cast<const double2 *>(T + lin_off<NG>(c0, NG - 1));
   const double2 *t1 = reinterpret_cast<const double2 *>(T + lin_off<NG>(c1, NG - 1));
+#endif
   const double2 a0 = t0[0], b0 = t0[1], a1 = t1[0], b1 = t1[1];
   if (EXP) {
     const double x0[4] = {e[0] * a0.x, e[1] * a0.y, e[2] * b0.x, e[3] * b0.y};
@@ -636,7 +642,11 @@ __device__ __forceinline__ uint32_t lin_phase_a(pln_lds_lin &S, const lin_buf &B
 __device__ __forceinline__ void lin_phase_a_store(pln_lds_lin &S, const double (&fA)[LIN_RPT][5], uint32_t rows) {
 #pragma unroll
   for (int k = 0; k < LIN_RPT; ++k) {
+#ifdef LIN_FAKE_PRI_ROWS   // developer build (timing only): the softmax rows of a wave on consecutive rows (no bank conflicts)
+    const uint32_t row = ((rows >> (16 * k)) & 0xffffu) == 0xffffu ? 0xffffu : (threadIdx.x * 2u + (uint32_t)k) % PLN_RMAX;
+#else
     const uint32_t row = (rows >> (16 * k)) & 0xffffu;
+#endif
     if (row != 0xffffu) {
 #pragma unroll
       for (int b = 0; b < 5; ++b) S.pri[row * 5 + b] = fA[k][b];
@@ -938,7 +948,11 @@ __device__ __forceinline__ void lin_phase_c_paired(pln_lds_lin &S, uint32_t n_en
   bool nz[2] = {false, false};
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
+#ifdef LIN_FAKE_PRI_ROWS
+    const uint32_t row = ((rowA >> (16 * k)) & 0xffffu) == LIN_EMPTY ? LIN_EMPTY : (tid * 2u + (uint32_t)k) % PLN_RMAX;
+#else
     const uint32_t row = (rowA >> (16 * k)) & 0xffffu;
+#endif
     if (row != LIN_EMPTY) {
       double w[5], sw = 0.0;
 #pragma unroll
