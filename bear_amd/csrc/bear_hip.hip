@@ -1889,7 +1889,7 @@ static int cnn_train_reduce_levels(bear_ws *ws, const bear_plan *plan, const cnn
     const uint64_t n = level_rows(k);
     const int W = plan->n_cnn_win[k];
     if (k > 0) {        // this level's dT1 rows = the sums of its children's
-      uint64_t sb = (n * CNN_L1 + 255) / 256;
+      uint64_t sb = (n * (CNN_L1 / 2) + 255) / 256;
       if (sb > (uint64_t)ws->num_cu * 32) sb = (uint64_t)ws->num_cu * 32;
       hipLaunchKernelGGL(cnn_level_sum_kernel, dim3((unsigned)sb), dim3(256), 0, s, level_table(k - 1), plan->cnn_levels[k - 1].child_start,
                          n, level_table(k));

@@ -1817,50 +1817,75 @@ __global__ __launch_bounds__(1024) void cnn_forward_head_kernel(uint64_t n_rows,
   }
 }
 
-// a level's dT1 rows from its children's (the children of a row are neighbours): one thread per (row, unit)
+// a level's dT1 rows from its children's (the children of a row are neighbours): one thread per (row, PAIR of units) -- 16-byte
+// loads: the kernel is a stream of 128-byte rows bound by the bytes its waves keep in flight (round 5: 8-byte loads ran at 4 TB/s)
 __global__ __launch_bounds__(256) void cnn_level_sum_kernel(const double *__restrict__ child_rows, const uint32_t *__restrict__ child_start,
                                                             uint64_t n_rows, double *__restrict__ rows) {
-  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n_rows * CNN_L1; t += (uint64_t)gridDim.x * 256) {
-    const uint64_t u = t / CNN_L1;
-    const uint32_t j = (uint32_t)(t - u * CNN_L1);
+  static_assert(CNN_L1 % 2 == 0, "rows of double2");
+  constexpr uint32_t H = CNN_L1 / 2;
+  const double2 *__restrict__ src = reinterpret_cast<const double2 *>(child_rows);
+  double2 *__restrict__ dst = reinterpret_cast<double2 *>(rows);
+  for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < n_rows * H; t += (uint64_t)gridDim.x * 256) {
+    const uint64_t u = t / H;
+    const uint32_t j = (uint32_t)(t - u * H);
     const uint32_t c0 = child_start[u], c1 = child_start[u + 1];
-    double s2[2] = {0.0, 0.0};
+    double2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
     uint32_t c = c0;
     for (; c + 1 < c1; c += 2) {
-      s2[0] += child_rows[(size_t)c * CNN_L1 + j];
-      s2[1] += child_rows[(size_t)(c + 1) * CNN_L1 + j];
+      const double2 a = src[(size_t)c * H + j], b = src[(size_t)(c + 1) * H + j];
+      s0.x += a.x;
+      s0.y += a.y;
+      s1.x += b.x;
+      s1.y += b.y;
     }
-    if (c < c1) s2[0] += child_rows[(size_t)c * CNN_L1 + j];
-    rows[t] = s2[0] + s2[1];
+    if (c < c1) {
+      const double2 a = src[(size_t)c * H + j];
+      s0.x += a.x;
+      s0.y += a.y;
+    }
+    dst[t] = make_double2(s0.x + s1.x, s0.y + s1.y);
   }
 }
 
 // a window's dT1 row from its contexts' rows (bear_window_dev: the contexts of window w are perm[child_start[w] .. child_start[w + 1]),
-// anywhere in the batch): one wave per window, four contexts x 16 units per load instruction (a context's row is 128 contiguous
-// bytes), four such loads in flight; fixed order, no atomics
+// anywhere in the batch): one wave per window, eight contexts x 8 pairs of units per load instruction (a context's row is 128
+// contiguous bytes, 16 per lane), four such loads in flight; fixed order, no atomics
 __global__ __launch_bounds__(256) void cnn_window_sum_kernel(const double *__restrict__ child_rows, const uint32_t *__restrict__ perm,
                                                              const uint32_t *__restrict__ child_start, uint64_t n_windows,
                                                              double *__restrict__ rows) {
-  const uint32_t lane = threadIdx.x & 63u, j = lane & 15u, slot = lane >> 4;
+  constexpr uint32_t H = CNN_L1 / 2;
+  static_assert(H == 8, "eight lanes per row");
+  const double2 *__restrict__ src = reinterpret_cast<const double2 *>(child_rows);
+  const uint32_t lane = threadIdx.x & 63u, j = lane & 7u, slot = lane >> 3;
   const uint64_t wave_id = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * 256) >> 6;
   for (uint64_t w = wave_id; w < n_windows; w += n_waves) {
     const uint32_t c0 = child_start[w], c1 = child_start[w + 1];
-    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    double2 s4[4] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
     uint32_t c = c0 + slot;
-    for (; c + 12 < c1; c += 16) {
+    for (; c + 24 < c1; c += 32) {
       uint32_t r[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) r[k] = perm[c + 4 * k];
-      double v[4];
+      for (int k = 0; k < 4; ++k) r[k] = perm[c + 8 * k];
+      double2 v[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = child_rows[(size_t)r[k] * CNN_L1 + j];
+      for (int k = 0; k < 4; ++k) v[k] = src[(size_t)r[k] * H + j];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) s4[k] += v[k];
+      for (int k = 0; k < 4; ++k) {
+        s4[k].x += v[k].x;
+        s4[k].y += v[k].y;
+      }
     }
-    for (; c < c1; c += 4) s4[0] += child_rows[(size_t)perm[c] * CNN_L1 + j];
-    double v = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-    v = cnn_rows_sum(v);                        // the same unit of the four slots (rows of 16 lanes)
-    if (slot == 0) rows[w * CNN_L1 + j] = v;
+    for (; c < c1; c += 8) {
+      const double2 v = src[(size_t)perm[c] * H + j];
+      s4[0].x += v.x;
+      s4[0].y += v.y;
+    }
+    double vx = (s4[0].x + s4[1].x) + (s4[2].x + s4[3].x), vy = (s4[0].y + s4[1].y) + (s4[2].y + s4[3].y);
+    vx += cnn_dpp<0x128>(vx);                   // row_ror:8: the two slots of a row of 16 lanes
+    vy += cnn_dpp<0x128>(vy);
+    vx = cnn_rows_sum(vx);                      // ... and the four rows
+    vy = cnn_rows_sum(vy);
+    if (slot == 0) reinterpret_cast<double2 *>(rows)[w * H + j] = make_double2(vx, vy);
   }
 }
 
