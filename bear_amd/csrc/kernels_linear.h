@@ -431,6 +431,13 @@ __device__ __forceinline__ void lin_row2(const double *T, const double *exptab, 
 #pragma unroll
     for (int j = 0; j < CH; ++j)
       if (g0 + j < NP) {
+#ifdef LIN_FAKE_SHARED_ROWS   // developer build (timing only): what do the table reads of the leading pair groups cost?  (no reads: constants)
+        if (g0 + j < NP - 1) {
+          lo[j] = make_double2(1.0 + 1e-9 * (double)(cw & 1ull), 1.0);
+          hi[j] = make_double2(1.0, 1.0);
+          continue;
+        }
+#endif
         const double2 *t = reinterpret_cast<const double2 *>(T + lin_off<NG>(cw, g0 + j));
         lo[j] = t[0];
         hi[j] = t[1];
@@ -668,7 +675,12 @@ __device__ __forceinline__ uint32_t lin_phase_a_paired(pln_lds_lin &S, const lin
     const uint32_t r0 = rows & 0xffffu, r1 = rows >> 16;              // (plan_pair_kernel: an empty entry only ever sits in the odd slot)
     cA[0] = B.codes[r0];
     cA[1] = B.codes[r1 != LIN_EMPTY ? r1 : r0];                       // (both reads in flight: a read behind a branch waited for the first)
+#ifdef LIN_SKIP_A_ROWS   // developer build (timing only): no table reads, no softmax
+#pragma unroll
+    for (int b = 0; b < 5; ++b) fA[0][b] = fA[1][b] = 0.2 + 1e-12 * (double)(uint32_t)cA[b & 1];
+#else
     lin_row2<NG, EXP>(S.T, S.exptab, cA[0], cA[1], fA[0], fA[1]);
+#endif
   }
   return rows;
 }
