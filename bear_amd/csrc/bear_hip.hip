@@ -455,7 +455,7 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
     while (q < n_quads) {
       uint32_t items = 0, rows = 0, hcol = 0, hrow = 0;
       const uint64_t q0 = q;
-      while (q < n_quads && rows + PLN_QUAD <= PLN_RMAX && items + h_quad[q] <= PLN_NI) {
+      while (q < n_quads && rows + PLN_QUAD <= PLN_RMAX && items + h_quad[q] <= PLN_NI_CUT) {
         items += h_quad[q];
         hcol += h_quad[n_quads + q];
         hrow += h_quad[2 * n_quads + q];

@@ -33,6 +33,9 @@
 #define PLN_UNITS 32                          // units per tile: two per wave, drawn dynamically, dearest first
 #endif
 #define PLN_NI (PLN_UNITS * 64)               // product-path items per tile (at most)
+#ifndef PLN_NI_CUT
+#define PLN_NI_CUT PLN_NI                      // ... that the greedy cut gives a tile
+#endif
 #ifndef PLN_RMAX
 #define PLN_RMAX 1664                         // contexts per tile (at most; LDS)
 #endif
@@ -176,7 +179,7 @@ __device__ __forceinline__ uint64_t plan_cut_one(const uint8_t *__restrict__ qua
                                                  uint32_t *hcol, uint32_t *hrow) {
   uint32_t it = 0, hc = 0, hr = 0, rows = 0;
   uint64_t q = q0;
-  while (q < n_quads && rows + PLN_QUAD <= PLN_RMAX && it + quad[q] <= PLN_NI) {
+  while (q < n_quads && rows + PLN_QUAD <= PLN_RMAX && it + quad[q] <= PLN_NI_CUT) {
     it += quad[q];
     if (hcol) {
       hc += quad[n_quads + q];
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void plan_cut_step_kernel(const uint8_t *__res
       r = q;
       items = 0;
     }
-    while (r < n_quads && (uint32_t)(r - q + 1) * PLN_QUAD <= PLN_RMAX && items + quad[r] <= PLN_NI) items += quad[r++];
+    while (r < n_quads && (uint32_t)(r - q + 1) * PLN_QUAD <= PLN_RMAX && items + quad[r] <= PLN_NI_CUT) items += quad[r++];
     step[q] = (uint16_t)(r - q);
     items -= quad[q];
   }
