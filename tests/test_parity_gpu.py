@@ -488,6 +488,70 @@ def test_fused_linear_head_paired_contexts(case, lag, dev, ysd1, monkeypatch):
     assert torch.allclose(a, b, rtol=1e-13, atol=0) and float((ga - gb).abs().max()) <= 1e-11 * float(gb.abs().max())
 
 
+def test_paired_lists_are_dealt_permutations_of_the_live_contexts(dev):
+    """What plan_pair_kernel may and may not do (kernels_linear.h): a tile's paired list holds every context of the tile that has
+    counts exactly once; entries 2 j and 2 j + 1 share every pair group (a lane's two contexts read the same leading table rows);
+    an empty entry only ever sits in the second slot; the lanes of a run of equal leading letters stay together.  Inside such a run
+    the builder is free, and uses it: the 16 lanes of a pass of an LDS atomic meet on few bank pairs (triple row mod 16) -- held
+    here to the level the dealing reaches on a table as dense in k-mer space as the 1e8-context benchmark (the sorted order
+    alone: ~11 turns per instruction, 4 = no conflict)."""
+    import ctypes
+    import torch
+    from bear_amd import _lib, kernels
+    lag, n = 13, 400_000
+    gen = torch.Generator(dev).manual_seed(3)
+    codes = torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev, generator=gen)
+    codes[:, :4] = torch.tensor([2, 0, 3, 1], dtype=torch.int8, device=dev)          # 4^9 k-mers behind a fixed prefix: 1.5 contexts per k-mer
+    key = torch.zeros(n, dtype=torch.int64, device=dev)
+    for l in range(lag):
+        key = key * 6 + codes[:, l].to(torch.int64)
+    order = torch.argsort(key)
+    codes = codes[order].contiguous()
+    tr = kernels.synth_counts(11, 0, n, dev, want=("train",))["train"][order].contiguous()
+    idx = kernels.linear_index(kernels.pack_kmers(codes), lag)
+    plan = kernels.Plan(tr, 5)
+    assert plan.pair_contexts(idx, lag) is True
+    n_tiles = len(plan.tiles()[0])
+    L = _lib.lib()
+    stride = 2 * (1024 - 128) + 8                       # LIN_LIVE2_STRIDE
+    lists, row0 = np.zeros((n_tiles, stride), dtype=np.uint16), np.zeros(n_tiles, dtype=np.uint64)
+    L.bear_debug_pair_lists.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    assert L.bear_debug_pair_lists(plan._h, 0, n_tiles, lists.ctypes.data, row0.ctypes.data) == 0
+    words = idx.cpu().numpy().view(np.uint64)
+    live = (tr != 0).any(dim=1).cpu().numpy()
+    npair = (lag - 3 + 1) // 2
+    pair_mask = np.uint64((1 << (6 * npair)) - 1)
+    ends = np.append(row0[1:], np.uint64(n)).astype(np.int64)
+    turns, instr = 0, 0
+    for t in range(n_tiles):
+        m = int(lists[t, 0])
+        assert m % 2 == 0 and m > 0
+        e = lists[t, 2:2 + m].astype(np.int64)
+        assert not (e[0::2] == 0xffff).any()
+        rows = e[e != 0xffff]
+        want = np.flatnonzero(live[int(row0[t]):ends[t]])
+        assert len(rows) == len(want) and np.array_equal(np.sort(rows), want), t
+        w = words[int(row0[t]) + np.where(e == 0xffff, 0, e)]
+        blk = w & pair_mask
+        second = e[1::2] != 0xffff
+        assert np.array_equal(blk[1::2][second], blk[0::2][second]), t
+        lane_blk = blk[0::2]                                        # runs of equal leading letters stay together
+        starts = np.flatnonzero(np.append(True, lane_blk[1:] != lane_blk[:-1]))
+        assert len(np.unique(lane_blk[starts])) == len(starts), t
+        cl = np.where(e == 0xffff, -1, ((w >> np.uint64(6 * npair)) & np.uint64(255)).astype(np.int64) % 16)
+        twin = (e[1::2] != 0xffff) & (w[1::2] == w[0::2])           # copies of one k-mer in a lane: one add
+        cl[1::2] = np.where(twin, -1, cl[1::2])
+        cl = np.concatenate([cl, -np.ones((-m) % 128, dtype=np.int64)]).reshape(-1, 64, 2)
+        for slot in (0, 1):
+            q = cl[:, :, slot].reshape(-1, 4, 16)
+            mx = np.zeros(q.shape[:2], dtype=np.int64)
+            for v in range(16):
+                mx = np.maximum(mx, (q == v).sum(-1))
+            turns += int(mx.sum())
+            instr += int((q >= 0).any(-1).any(-1).sum())
+    assert turns / instr < 7.0, turns / instr
+
+
 def test_pairing_declines_a_sparse_table(dev):
     """A table of random 13-mers has runs of one context: a paired list would be twice the plain one and no longer fit the
     kernel's row threads -- bear_plan_pair_contexts says so, leaves the plan as it was, and the step runs in its plain form."""
