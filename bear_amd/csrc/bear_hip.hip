@@ -1105,7 +1105,7 @@ int bear_plan_pair_contexts(bear_plan *plan, const uint64_t *kmer_index, int lag
   }
   const uint64_t nt = plan->n_tiles;
   if (nt == 0 || !plan->live) return BEAR_OK;
-  uint16_t *live2 = nullptr, *n_ent_dev = nullptr, *scratch = nullptr;
+  uint16_t *live2 = nullptr, *n_ent_dev = nullptr;
   pln_tile *tp = nullptr, *tu = nullptr;
   std::vector<uint16_t> n_ent;
   std::vector<pln_tile> host, hp, hu;
@@ -1117,12 +1117,11 @@ int bear_plan_pair_contexts(bear_plan *plan, const uint64_t *kmer_index, int lag
   }
   hipError_t e = hipMalloc(&live2, nt * LIN_LIVE2_STRIDE * sizeof(uint16_t));
   if (e == hipSuccess) e = hipMalloc(&n_ent_dev, nt * sizeof(uint16_t));
-  if (e == hipSuccess) e = hipMalloc(&scratch, nt * PLN_LIVE_STRIDE * sizeof(uint16_t));     // the builder's buckets (freed below)
   if (e == hipSuccess) {
-    uint64_t blocks = (nt + 63) / 64;
-    if (blocks > 65536) blocks = 65536;
+    uint64_t blocks = nt;                   // one wave per tile
+    if (blocks > (1u << 18)) blocks = 1u << 18;
     hipLaunchKernelGGL(plan_pair_kernel, dim3((unsigned)blocks), dim3(64), 0, s, plan->tiles, nt, plan->live,
-                       reinterpret_cast<const unsigned long long *>(kmer_index), lag, live2, n_ent_dev, scratch,
+                       reinterpret_cast<const unsigned long long *>(kmer_index), lag, live2, n_ent_dev,
                        getenv("BEAR_AMD_PAIR_NO_EMPTY") ? 0 : 1);     // (developer switch: the dealt order without the extra empty slots)
     e = hipGetLastError();
   }
@@ -1130,7 +1129,6 @@ int bear_plan_pair_contexts(bear_plan *plan, const uint64_t *kmer_index, int lag
   if (e == hipSuccess) e = hipMemcpyAsync(host.data(), plan->tiles, nt * sizeof(pln_tile), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)hipFree(n_ent_dev);
-  (void)hipFree(scratch);
   uint64_t n_p = 0;
   bool keep = false;
   if (e == hipSuccess) {

@@ -168,18 +168,47 @@ __global__ void linear_index_kernel(const unsigned long long *__restrict__ raw, 
 // twice or more) take ONE lane: the kernel adds the sum of their gradients to the triple row once (lin_scatter_grad_paired).
 // Ties go to the context whose ROW class (row mod 16: the bank pair of its softmax row in phases A and
 // C) is new to the group.  Measured on the 1e8 table, same box: 1.479 -> 1.455 ms from the order alone, 1.447 with the empty slots,
-// 1.432 with the row classes.  `scratch` (uint16 [n_tiles][PLN_LIVE_STRIDE]): a block's rows bucketed by class.
+// 1.432 with the row classes.
+// One wave per tile: the lanes fetch the tile's list and what the dealing needs of each context's index word into LDS (a byte: class,
+// first of its block, copy of its predecessor); then LANE q KEEPS CLASS q (q < 16: its bucket of the block, how many contexts it has
+// left, its next context's row class and whether that context has a copy behind it) and a pick is three 16-lane maxima instead
+// of a scan over the classes; the lanes write the list out.  (A thread per tile out of global memory was latency-bound: 43 ms per
+// 1e8 contexts and 13 ms for any small batch; one lane per tile out of LDS 54 ms: ~400 dependent instructions per pick.)
+__device__ __forceinline__ uint32_t lin_max16(uint32_t v) {       // the maximum over lanes 0..15 (the other lanes hold 0), in every one of them
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+    v = o > v ? o : v;
+  }
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
 __global__ __launch_bounds__(64) void plan_pair_kernel(const pln_tile *__restrict__ tiles, uint64_t n_tiles, const uint16_t *__restrict__ live,
                                                        const unsigned long long *__restrict__ kmer_index, int lag, uint16_t *__restrict__ live2,
-                                                       uint16_t *__restrict__ n_ent, uint16_t *__restrict__ scratch, int empty_slots) {
+                                                       uint16_t *__restrict__ n_ent, int empty_slots) {
   const lin_geom G = lin_make_geom(lag);
   const unsigned long long pair_mask = (1ull << (6 * G.npair)) - 1ull;      // every pair group of the index word (bear_linear_index_u64)
   const int tri_shift = 6 * G.npair;
-  for (uint64_t t = (uint64_t)blockIdx.x * 64 + threadIdx.x; t < n_tiles; t += (uint64_t)gridDim.x * 64) {
+  __shared__ uint16_t row_l[PLN_RMAX];        // the tile's list: rows of the contexts with counts, in sorted order
+  __shared__ uint8_t meta[PLN_RMAX + 1];      // per list position: class (4 bits) | 16: first of its block | 32: same k-mer as its predecessor
+  __shared__ uint16_t bucket[PLN_RMAX];       // a block's list positions bucketed by class
+  __shared__ uint16_t out_l[LIN_LIVE2_STRIDE];
+  __shared__ uint32_t cnt_s[16];
+  const uint32_t lane = threadIdx.x, q = lane & 15u;
+  const bool keeper = lane < 16u;
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
     const uint16_t *in = live + t * PLN_LIVE_STRIDE;
-    uint16_t *out = live2 + t * LIN_LIVE2_STRIDE, *bucket = scratch + t * PLN_LIVE_STRIDE;
     const uint64_t row0 = tiles[t].row0;
     const uint32_t n = in[0];
+    for (uint32_t i = lane; i < n; i += 64) {
+      const uint32_t row = in[1 + i];
+      const unsigned long long w = kmer_index[row0 + row];
+      const unsigned long long wp = i ? kmer_index[row0 + in[i]] : ~w;
+      row_l[i] = (uint16_t)row;
+      meta[i] = (uint8_t)(((uint32_t)(w >> tri_shift) & 15u) | (((w ^ wp) & pair_mask) != 0ull || i == 0u ? 16u : 0u) | (w == wp ? 32u : 0u));
+    }
+    if (lane == 0) meta[n] = 16u;             // (a block ends where the next one starts)
+    __syncthreads();
+    // everything below is wave-uniform control flow; m, used*, need, left are the same numbers in every lane
     uint32_t m = 0;                       // entries written (or that would have been: the list is dropped when m > LIN_PAIR_CAP)
     uint32_t used[2] = {0u, 0u};          // classes present in the current group of 16 lanes, per slot
     uint32_t used_row[2] = {0u, 0u};      // ... and the classes of the contexts' ROWS (row mod 16: the bank pair of the lane's softmax row in
@@ -188,117 +217,114 @@ __global__ __launch_bounds__(64) void plan_pair_kernel(const pln_tile *__restric
     // is sure to fit without them too
     uint32_t need = 0;
     for (uint32_t s = 0; s < n;) {
-      const unsigned long long p = kmer_index[row0 + in[1 + s]] & pair_mask;
       uint32_t e = s + 1u;
-      while (e < n && (kmer_index[row0 + in[1 + e]] & pair_mask) == p) ++e;
+      while (!(meta[e] & 16u)) ++e;
       need += (e - s + 1u) & ~1u;
       s = e;
     }
-    auto put = [&](uint32_t v) {
-      if (m < LIN_PAIR_CAP) out[2 + m] = (uint16_t)v;
-      ++m;
+    auto put = [&](uint32_t v) {           // (called by ONE lane)
+      if (m < LIN_PAIR_CAP) out_l[2 + m] = (uint16_t)v;
     };
     for (uint32_t s = 0; s < n;) {
-      // the block [s, e): contexts with the leading letters of entry s
-      const unsigned long long p = kmer_index[row0 + in[1 + s]] & pair_mask;
-      uint32_t cnt[16], cur[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) cnt[q] = 0u;
-      uint32_t e = s;
-      for (; e < n; ++e) {
-        const unsigned long long w = kmer_index[row0 + in[1 + e]];
-        if ((w & pair_mask) != p) break;
-        const uint32_t cl = (uint32_t)(w >> tri_shift) & 15u;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) cnt[q] += (uint32_t)q == cl ? 1u : 0u;
+      // the block [s, e): contexts with the leading letters of entry s; my class's share of it
+      uint32_t e = s + 1u;
+      while (!(meta[e] & 16u)) ++e;
+      uint32_t cnt = 0;
+      if (keeper)
+        for (uint32_t i = s; i < e; ++i) cnt += (meta[i] & 15u) == q ? 1u : 0u;
+      if (keeper) cnt_s[q] = cnt;
+      __syncthreads();
+      uint32_t end = 0;                    // my bucket is [end - cnt, end) once it is filled
+      for (uint32_t k = 0; k < 16u; ++k) end += k <= q ? cnt_s[k] : 0u;
+      if (keeper) {
+        uint32_t at = end - cnt;
+        for (uint32_t i = s; i < e; ++i)
+          if ((meta[i] & 15u) == q) bucket[at++] = (uint16_t)i;       // (order inside a class: as listed)
       }
-      {
-        uint32_t run = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          cur[q] = run;
-          run += cnt[q];
+      __syncthreads();
+      // my class's next context: its row class, and whether the one behind it in the bucket is the SAME k-mer (the positions of a
+      // class keep their sorted order, so copies of a k-mer are neighbours in the list and in the bucket): such a pair shares a
+      // lane and the kernel adds the sum of the two gradients to the triple row once
+      uint32_t head_rc = 0u;
+      bool head_dbl = false;
+      auto refresh = [&]() {
+        head_rc = 0u;
+        head_dbl = false;
+        if (!keeper || cnt == 0u) return;
+        const uint32_t a0 = bucket[end - cnt];
+        head_rc = (uint32_t)row_l[a0] & 15u;
+        if (cnt >= 2u) {
+          const uint32_t a1 = bucket[end - cnt + 1u];
+          head_dbl = a1 == a0 + 1u && (meta[a1] & 32u);
         }
-      }
-      for (uint32_t i = s; i < e; ++i) {                       // bucket the block's rows by class (order inside a class: as listed)
-        const uint32_t row = in[1 + i];
-        const uint32_t cl = (uint32_t)(kmer_index[row0 + row] >> tri_shift) & 15u;
-        uint32_t at = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-          if ((uint32_t)q == cl) at = cur[q]++;
-        bucket[at] = (uint16_t)row;
-      }
-      // cur[q] is now the END of class q's bucket; cnt[q] contexts of it are left, the next one sits at cur[q] - cnt[q]
+      };
+      refresh();
       uint32_t left = e - s;
       need -= (left + 1u) & ~1u;                               // (of the blocks behind this one)
-      // the next context of class q, and whether the one behind it in the bucket is the SAME k-mer (equal index words; the rows of
-      // a class keep their sorted order, so copies of a k-mer are neighbours): such a pair shares a lane and the kernel adds the
-      // sum of the two gradients to the triple row once
-      auto head = [&](int q) -> uint32_t { return bucket[cur[q] - cnt[q]]; };
-      auto head_is_double = [&](int q) -> bool {
-        return cnt[q] >= 2u && kmer_index[row0 + bucket[cur[q] - cnt[q]]] == kmer_index[row0 + bucket[cur[q] - cnt[q] + 1u]];
-      };
       while (left) {
         if ((m & 31u) == 0u) used[0] = used[1] = used_row[0] = used_row[1] = 0u;         // a new group of 16 lanes
         for (int slot = 0; slot < 2; ++slot) {
           if (!left) {
-            put(LIN_EMPTY);                                    // (only ever behind a first slot: m is odd here)
+            if (lane == 0) put(LIN_EMPTY);                     // (only ever behind a first slot: m is odd here)
+            ++m;
             continue;
           }
           // of the classes not in the group yet the one with the most contexts left -- among those whose next context also brings a
-          // new row class, if there is one (score: 2 x count + 1); the second slot leaves the doubles to the first slots while it can
-          uint32_t best = 16u, best_n = 0u, any = 16u, any_n = 0u, best_d = 16u, best_dn = 0u;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const uint32_t c = cnt[q];
-            if (c > any_n) any_n = c, any = (uint32_t)q;
-            if (c != 0u && !((used[slot] >> q) & 1u)) {
-              const uint32_t rc = head(q) & 15u;
-              const uint32_t rn = ((used_row[slot] >> rc) & 1u) ? 0u : 1u;
-              const uint32_t score = 2u * c + rn;       // (the row class as the first criterion instead: the same time)
-              if (slot == 1 && head_is_double(q)) {
-                if (score > best_dn) best_dn = score, best_d = (uint32_t)q;
-              } else if (score > best_n) {
-                best_n = score, best = (uint32_t)q;
-              }
+          // new row class, if there is one (score: 2 x count + 1); the second slot leaves the doubles to the first slots while it can;
+          // equal scores: the lowest class
+          const bool fresh = keeper && cnt != 0u && !((used[slot] >> q) & 1u);
+          const uint32_t score = fresh ? (2u * cnt + (((used_row[slot] >> head_rc) & 1u) ? 0u : 1u)) * 16u + (15u - q) : 0u;
+          const bool dbl2 = slot == 1 && head_dbl;
+          uint32_t key = lin_max16(dbl2 ? 0u : score);
+          if (key == 0u) key = lin_max16(dbl2 ? score : 0u);
+          if (key == 0u) {
+            // every class left is in this group already: an empty second slot while the tile's list keeps room for what is left
+            if (empty_slots && slot == 1 && m + 1u + ((left + 1u) & ~1u) + need <= LIN_PAIR_CAP) {
+              if (lane == 0) put(LIN_EMPTY);
+              ++m;
+              continue;
             }
+            key = lin_max16(keeper && cnt != 0u ? cnt * 16u + (15u - q) : 0u);       // ... or the fullest class goes anyway
           }
-          if (best == 16u) best = best_d;
-          // every class left is in this group already: an empty second slot while the tile's list keeps room for what is left
-          if (empty_slots && best == 16u && slot == 1 && m + 1u + ((left + 1u) & ~1u) + need <= LIN_PAIR_CAP) {
-            put(LIN_EMPTY);
-            continue;
-          }
-          const uint32_t cl = best != 16u ? best : any;
-          uint32_t row = 0, twin = LIN_EMPTY;
-#pragma unroll
-          for (int q = 0; q < 16; ++q)
-            if ((uint32_t)q == cl) {
-              if (slot == 0 && head_is_double(q)) {
-                twin = bucket[cur[q] - cnt[q] + 1u];
-                --cnt[q];
-              }
-              row = bucket[cur[q] - cnt[q] - (twin != LIN_EMPTY ? 1u : 0u)];
-              --cnt[q];
+          const uint32_t cl = 15u - (key & 15u);
+          uint32_t row = 0u, twin = 0u;
+          if (keeper && q == cl) {
+            const uint32_t pos = bucket[end - cnt];
+            row = row_l[pos];
+            put(row);
+            if (slot == 0 && head_dbl) {                       // the lane is full: the copy adds nothing of its own in the second slot's instruction
+              twin = 1u;
+              ++m;
+              put(row_l[bucket[end - cnt + 1u]]);
+              --m;
+              --cnt;
             }
+            --cnt;
+            refresh();
+          }
+          row = (uint32_t)__builtin_amdgcn_readlane((int)row, (int)cl);
+          twin = (uint32_t)__builtin_amdgcn_readlane((int)twin, (int)cl);
           used[slot] |= 1u << cl;
           used_row[slot] |= 1u << (row & 15u);
-          put(row);
-          --left;
-          if (twin != LIN_EMPTY) {                             // the lane is full: the copy adds nothing of its own in the second slot's instruction
-            put(twin);
-            --left;
-            break;
-          }
+          m += 1u + twin;
+          left -= 1u + twin;
+          if (twin) break;
         }
       }
       s = e;
+      __syncthreads();                     // (the buckets are refilled for the next block)
     }
+    __syncthreads();
     const bool fits = m <= LIN_PAIR_CAP;
-    out[0] = fits ? (uint16_t)m : (uint16_t)0;
-    out[1] = 0;
-    n_ent[t] = fits ? (uint16_t)m : (uint16_t)0xffffu;
+    uint16_t *out = live2 + t * LIN_LIVE2_STRIDE;
+    if (fits)
+      for (uint32_t i = lane; i < m; i += 64) out[2 + i] = out_l[2 + i];
+    if (lane == 0) {
+      out[0] = fits ? (uint16_t)m : (uint16_t)0;
+      out[1] = 0;
+      n_ent[t] = fits ? (uint16_t)m : (uint16_t)0xffffu;
+    }
+    __syncthreads();
   }
 }
 // offset (in doubles) of group g's table row; g a constant after unrolling

@@ -659,11 +659,16 @@ def main():
         # every BASELINE config's own optimizer step at its stated size + the dense stress table (scripts/baseline_configs.py)
         if not args.no_baseline_configs:
             try:
+                if os.path.join(ROOT, "scripts") not in sys.path:
+                    sys.path.insert(0, os.path.join(ROOT, "scripts"))
                 import baseline_configs
                 torch.cuda.empty_cache()
                 extra["baseline_configs"] = baseline_configs.measure_configs(dev)
                 torch.cuda.empty_cache()
                 extra["dense_table"] = baseline_configs.measure_dense(dev)
+                import stream_time          # an epoch that does not stay on the card (the reference's cache=False pipeline)
+                torch.cuda.empty_cache()
+                extra["streamed_epochs"] = stream_time.measure(5_000_000, 3, 2, dev)
             except Exception as err:    # reported, never fatal for the bench line
                 extra.setdefault("baseline_configs", {"error": f"{type(err).__name__}: {err}"})
                 extra.setdefault("dense_table", {"error": f"{type(err).__name__}: {err}"})

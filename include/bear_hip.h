@@ -262,7 +262,7 @@ int bear_dm_linear_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *count
  * contexts of the plan's lists that share all letters but the last three, so that the fused step reads their shared table rows
  * once and reduces their gradients together, and orders the pairs of such a run so that the 16 lanes of a pass of an LDS atomic
  * meet on as few bank pairs as the run allows (copies of one k-mer share a lane and one add) -- about 15 % off a step on a
- * k-mer-sorted table; the sums are the same.  ~0.04 s per 1e8 contexts.  The pairing is tied to the buffer kmer_index (identity and contents: it must not change afterwards, like the
+ * k-mer-sorted table; the sums are the same.  ~0.03 s per 1e8 contexts (3 ms for a batch of 5e6).  The pairing is tied to the buffer kmer_index (identity and contents: it must not change afterwards, like the
  * plan's count slab) and to lag: bear_dm_linear_f64 / bear_net_linear_train_*_f64 called with that pointer and lag take the
  * paired form, any other call the plain one.  A tile whose paired list would not fit the kernel's row threads (a stretch of
  * the table where neighbours share nothing) keeps its plain list; *paired (nullable) = 0 when that is true of more than half
