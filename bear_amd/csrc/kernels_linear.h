@@ -273,6 +273,7 @@ __global__ __launch_bounds__(64) void plan_pair_kernel(const pln_tile *__restric
           // new row class, if there is one (score: 2 x count + 1); the second slot leaves the doubles to the first slots while it can;
           // equal scores: the lowest class
           const bool fresh = keeper && cnt != 0u && !((used[slot] >> q) & 1u);
+          // (a third criterion -- class mod 8 new to the current EIGHT lanes, for the 16-byte table reads of phase A -- changed nothing)
           const uint32_t score = fresh ? (2u * cnt + (((used_row[slot] >> head_rc) & 1u) ? 0u : 1u)) * 16u + (15u - q) : 0u;
           const bool dbl2 = slot == 1 && head_dbl;
           uint32_t key = lin_max16(dbl2 ? 0u : score);
@@ -339,6 +340,24 @@ __device__ __forceinline__ uint32_t lin_off_any(unsigned long long cv, uint32_t 
   return g * LIN_PSTRIDE + idx * 4u;
 }
 
+// A group's table row of a context (g a constant after unrolling).  The pairs' rows are four doubles side by side; the TRIPLE's rows
+// are split into two planes of 16-byte halves (letters 0, 1 | letters 2, 3): the lanes of a wave read different triple rows, and a
+// 16-byte LDS read serves eight lanes per pass -- rows of 32 bytes put them on four of the eight 16-byte bank groups, halves that
+// follow each other on all eight.
+template <int NG>
+__device__ __forceinline__ void lin_table_row(const double *T, unsigned long long cv, int g, double2 &lo, double2 &hi) {
+  if (g == NG - 1) {
+    const uint32_t idx = (uint32_t)(cv >> (6 * g)) & 255u;
+    const double *base = T + (NG - 1) * LIN_PSTRIDE;
+    lo = *reinterpret_cast<const double2 *>(base + idx * 2u);
+    hi = *reinterpret_cast<const double2 *>(base + 2 * LIN_TRI_COMBOS + idx * 2u);
+  } else {
+    const double2 *t = reinterpret_cast<const double2 *>(T + lin_off<NG>(cv, g));
+    lo = t[0];
+    hi = t[1];
+  }
+}
+
 // exp(d ln2 / 128): the tables hold logits in units of ln2 / 128, so the argument reduction of bear_exp_tab is a
 // rounding and an exact subtraction; 2^(j/128) from the table, degree-5 polynomial on |r| <= 1/2 unit, v_ldexp for the rest.
 #define LIN_EXP_UNIT 184.66496523378731    // 128 / ln 2
@@ -368,9 +387,7 @@ __device__ __forceinline__ void lin_row(const double *T, const double *exptab, u
 #pragma unroll
       for (int j = 0; j < CH; ++j)
         if (g0 + j < NG) {
-          const double2 *t = reinterpret_cast<const double2 *>(T + lin_off<NG>(cw, g0 + j));
-          lo[j] = t[0];
-          hi[j] = t[1];
+          lin_table_row<NG>(T, cw, g0 + j, lo[j], hi[j]);
         }
 #pragma unroll
       for (int j = 0; j < CH; ++j)
@@ -403,9 +420,7 @@ __device__ __forceinline__ void lin_row(const double *T, const double *exptab, u
 #pragma unroll
     for (int j = 0; j < CH; ++j)
       if (g0 + j < NG) {
-        const double2 *t = reinterpret_cast<const double2 *>(T + lin_off<NG>(cv, g0 + j));
-        lo[j] = t[0];
-        hi[j] = t[1];
+        lin_table_row<NG>(T, cv, g0 + j, lo[j], hi[j]);
       }
 #pragma unroll
     for (int j = 0; j < CH; ++j)
@@ -494,11 +509,12 @@ __device__ __forceinline__ void lin_row2(const double *T, const double *exptab, 
   const uint32_t fake_row = LIN_FAKE_T_ROWS == 1 ? (threadIdx.x & 63u) : 0u;
   const double2 *t0 = reinterpret_cast<const double2 *>(T + (NG - 1) * LIN_PSTRIDE + fake_row * 4u);
   const double2 *t1 = reinterpret_cast<const double2 *>(T + (NG - 1) * LIN_PSTRIDE + (fake_row + 64u) * 4u);
-#else
-  const double2 *t0 = reinterpret_cast<const double2 *>(T + lin_off<NG>(c0, NG - 1));
-  const double2 *t1 = reinterpret_cast<const double2 *>(T + lin_off<NG>(c1, NG - 1));
-#endif
   const double2 a0 = t0[0], b0 = t0[1], a1 = t1[0], b1 = t1[1];
+#else
+  double2 a0, b0, a1, b1;
+  lin_table_row<NG>(T, c0, NG - 1, a0, b0);
+  lin_table_row<NG>(T, c1, NG - 1, a1, b1);
+#endif
   if (EXP) {
     const double x0[4] = {e[0] * a0.x, e[1] * a0.y, e[2] * b0.x, e[3] * b0.y};
     const double x1[4] = {e[0] * a1.x, e[1] * a1.y, e[2] * b1.x, e[3] * b1.y};
@@ -1056,7 +1072,12 @@ __device__ __forceinline__ bool lin_build_tables(double *T, unsigned long long *
       letter(G.tri + 1, (combo / 6) % 6, b);
       letter(G.tri + 2, combo % 6, b);
     }
-    T[k] = v;
+    int kk = k;                            // (the triple's rows in two planes: lin_table_row)
+    if (k >= G.npair * LIN_PSTRIDE) {
+      const int r = k - G.npair * LIN_PSTRIDE, combo = r >> 2, b = r & 3;
+      kk = G.npair * LIN_PSTRIDE + (b < 2 ? 0 : 2 * LIN_TRI_COMBOS) + combo * 2 + (b & 1);
+    }
+    T[kk] = v;
     t_abs = __builtin_fmax(t_abs, __builtin_fabs(v));
   }
   __syncthreads();                                                        // t_max has been zeroed
