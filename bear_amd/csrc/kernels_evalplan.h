@@ -535,12 +535,7 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
           if (dbg_flags & 8) continue;
 #endif
           const uint32_t un = n_tu - 1u - (w - w_t);
-#ifdef EVP_FAKE_ROWS   // developer build (timing only): the units' gathers without bank conflicts (consecutive rows / cells)
-          const uint32_t row_true = B.items[tot_base + un * 64u + lane];
-          const uint32_t row = row_true == (uint32_t)EVP_SENT_ROW ? row_true : (un * 64u + lane) % EVP_ROWS;
-#else
           const uint32_t row = B.items[tot_base + un * 64u + lane];
-#endif
           uint32_t t[5], r[5];
           double f[5];
 #pragma unroll
@@ -651,12 +646,7 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
         if (dbg_flags & 4) continue;
 #endif
         const uint32_t un = n_cu - 1u - (w - w_v);
-#ifdef EVP_FAKE_ROWS
-        const uint32_t idx_true = B.items[un * 64u + lane];
-        const uint32_t idx = idx_true == (uint32_t)EVP_SENT_CELL ? idx_true : (un * 64u + lane) % (EVP_ROWS * 5u);
-#else
         const uint32_t idx = B.items[un * 64u + lane];
-#endif
         const uint32_t c = B.tst[idx], ru = B.trn[idx];
         const double f = B.pri[idx];
         const bool live = c != 0u, heavy = c > SRT_CL;
