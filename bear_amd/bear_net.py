@@ -76,18 +76,20 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
 
         def reducer(k):
             e = res.load(k)
-            if e["rows"] == 0:
-                return lambda packed: packed.zero_()
-            pack = pack_of(e)
-            plan = res.plan(k, "train", 5)           # built here, before any capture (plan creation allocates and synchronises)
+            plan = res.plan(k, "train", 5) if e["rows"] else None     # built here, before any capture (plan creation allocates and synchronises)
             if _train.deterministic() and fused_mat is not None:
                 # BEAR_AMD_DETERMINISTIC: the fixed-point scale of the linear step's gradient tables follows from the counts of the
-                # WHOLE batch -- every rank's piece -- so that d/d mat does not depend on the number of ranks (include/bear_hip.h)
-                own = plan.count_total()[0]
+                # WHOLE batch -- every rank's piece -- so that d/d mat does not depend on the number of ranks (include/bear_hip.h);
+                # a rank whose piece of the batch is empty takes part in the two all-reduces with zeros
+                own = plan.count_total()[0] if plan is not None else [0.0, 0.0, 0.0]
                 tot, cmax = torch.tensor(own[:2], dtype=torch.float64, device=device), torch.tensor(own[2:], dtype=torch.float64, device=device)
                 dist.allreduce_sum_(tot)
                 dist.allreduce_max_(cmax)
-                plan.set_count_bound(tot.tolist() + cmax.tolist())
+                if plan is not None:
+                    plan.set_count_bound(tot.tolist() + cmax.tolist())
+            if plan is None:
+                return lambda packed: packed.zero_()
+            pack = pack_of(e)
             if fused_mat is not None and pack.data_ptr() % 16 == 0:
                 # neighbours of the sorted batch that share all letters but the last three go through the step two at a time
                 # (kernels_linear.h, paired lists); declined by the library for tables too sparse to gain from it

@@ -93,6 +93,36 @@ def test_two_rank_training_matches_single_rank(tmp_path):
     assert got["eval"][8] == np.asarray(r[8]).tolist()
 
 
+def test_many_ranks_deterministic_mode_with_empty_pieces(tmp_path):
+    """BEAR_AMD_DETERMINISTIC=1 with MANY ranks on a table whose last batch leaves most ranks WITHOUT rows: the count bound of the
+    fixed-point gradient tables is all-reduced over the ranks when a batch's step is set up (bear_net.train), and a rank with an
+    empty piece has to take part (it used to return before the collective: the group aborted).  Losses and parameters equal the
+    single-process deterministic run's to rounding."""
+    torch.manual_seed(3)
+    _, lin = ar_funcs.make_ar_func_linear(5, 4)
+    restart = {"linear": np.array([np.array(0.1)] + [x.detach().numpy() for x in lin], dtype=object)}
+    np.savez(tmp_path / "restart.npz", **restart)
+    small = tmp_path / "small.tsv"
+    with open(YSD1) as fh:
+        small.write_text("".join(fh.readlines()[:23]))
+    out_file = tmp_path / "out.json"
+    _launch([os.path.join(ROOT, "tests", "dist_worker_n.py")],
+            {"BEAR_RESTART": str(tmp_path / "restart.npz"), "BEAR_OUT": str(out_file), "BEAR_TABLES": json.dumps([["small", str(small), 7]]),
+             "BEAR_EXPECT_WORLD": str(MANY), "BEAR_AMD_DETERMINISTIC": "1"}, tmp_path, nproc=MANY)
+    got = json.load(open(out_file))["small"]
+    assert np.asarray(got["pieces"]).min() == 0
+    data = dataloader.dataloader(str(small), "dna", 7, 3)
+    ls = []
+    os.environ["BEAR_AMD_DETERMINISTIC"] = "1"
+    try:
+        p, _, _ = bear_net.train(data.repeat(4), data.num_rows, 4, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", False,
+                                 params_restart=list(restart["linear"]), loss_save=ls)
+    finally:
+        del os.environ["BEAR_AMD_DETERMINISTIC"]
+    assert len(ls) == len(got["net_linear"]["loss"]) and np.allclose(got["net_linear"]["loss"], ls, rtol=1e-10)
+    assert np.allclose(_flat(got["net_linear"]["params"]), _flat([x.detach().cpu().numpy() for x in p]), rtol=1e-7, atol=1e-10)
+
+
 def test_many_ranks_match_single_rank_with_empty_and_uneven_pieces(tmp_path):
     """MANY processes under torch.distributed.run (all on cuda:0, gloo): bear_ref.train, bear_net.train (linear; BEAR mode, and AR
     mode with gradient accumulation) and both evaluations on row shards reproduce the single-process run -- on the bundled table
