@@ -231,23 +231,36 @@ class ResidentBatches:
             if stream is None:
                 stream = bool(os.environ.get("BEAR_AMD_STREAM")) and os.environ.get("BEAR_AMD_STREAM") != "0"
             largest = max([g1 - g0 for _, (g0, g1, _) in pieces] + [0])
+            # 0 = the epoch stays resident, 1 = streamed, 2 = neither works.  The RANKS AGREE on it (one MAX all-reduce): a rank
+            # that streams runs an eager loop, a resident one captures a graph and issues a warm-up all-reduce first -- with
+            # different decisions the ranks' collectives would pair up wrongly (and the job hang at its end)
+            status, why = (1 if stream else 0), None
             if not stream:
                 try:
                     hbm_budget_check(data, len(columns), want_codes, device, rows=sum(g1 - g0 for _, (g0, g1, _) in pieces),
                                      per_row_extra=per_row_extra)
                 except MemoryError as err:
-                    if data.shuffle_seed is not None or len(pieces) < 2:    # (a shuffled epoch is permuted on the device as a whole)
-                        raise
-                    stream = str(err)
-            if stream:
-                if data.shuffle_seed is not None:
-                    raise ValueError("a streamed epoch cannot be shuffled on the device (the shuffle permutes the whole shard in HBM)")
+                    # (a shuffled epoch is permuted on the device as a whole; one batch cannot be streamed around itself)
+                    status, why = (2 if data.shuffle_seed is not None or len(pieces) < 2 else 1), str(err)
+            if status == 1 and data.shuffle_seed is None:
                 # the window: the batch in use, the batch landing, and the blocks of the batch just dropped (free for the side
                 # stream only once the steps that read them have run)
-                hbm_budget_check(data, len(columns), want_codes, device, rows=3 * largest, per_row_extra=per_row_extra)
-                if isinstance(stream, str):
-                    warnings.warn(f"{stream}  --  streaming the epoch instead: batches are re-uploaded every epoch (PCIe-bound)")
+                try:
+                    hbm_budget_check(data, len(columns), want_codes, device, rows=3 * largest, per_row_extra=per_row_extra)
+                except MemoryError as err:
+                    status, why = 2, str(err)
+            agreed = dist.agree_max(status, device)
+            if agreed == 2:
+                raise MemoryError(why or "another rank's share of the epoch fits its HBM neither resident nor streamed: every rank stops")
+            if agreed == 1:
+                if data.shuffle_seed is not None:
+                    raise ValueError("a streamed epoch cannot be shuffled on the device (the shuffle permutes the whole shard in HBM)")
+                if why is not None:
+                    warnings.warn(f"{why}  --  streaming the epoch instead: batches are re-uploaded every epoch (PCIe-bound)")
+                elif not stream:
+                    warnings.warn("another rank has to stream its share of the epoch: this rank streams too (the ranks run the same loop)")
                 self.streaming = True
+        LAST_RUN["streaming"] = self.streaming
         up = None if on_dev else Uploader(device, expect_bytes=max(
             [(g1 - g0) * 20 for _, (g0, g1, _) in pieces] + [data.local_rows * 20 if data.shuffle_seed is not None else 0, 1]))
         self.upload_bytes = 0
@@ -565,9 +578,32 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
 
 
 def deterministic():
-    """BEAR_AMD_DETERMINISTIC=1: parameter gradients bit-identical from run to run (include/bear_hip.h)."""
+    """BEAR_AMD_DETERMINISTIC=1 -- or the deterministic BUILD of the library is the one loaded (``libbear_hip_det.so`` through
+    BEAR_AMD_LIB, or the variable unset again after import: its kernels take the fixed-point path whatever the variable says
+    now): parameter gradients bit-identical from run to run (include/bear_hip.h)."""
     v = os.environ.get("BEAR_AMD_DETERMINISTIC", "")
-    return bool(v) and v != "0"
+    if bool(v) and v != "0":
+        return True
+    return bool(_lib.lib().bear_deterministic_build())
+
+
+def deterministic_agreed(device=None):
+    """``deterministic()`` after checking ONCE per process group that every rank answers alike: the deterministic mode adds two
+    all-reduces per batch set-up (the count bound of the fixed-point tables, bear_net.train), so ranks that disagree -- the variable
+    exported on some of them only -- would deadlock there, or scale their gradient tables differently without a word."""
+    mine = deterministic()
+    world = dist.world()[1]
+    if world > 1 and _DET_AGREED.get("world") != (world, mine):
+        hi = dist.agree_max(1 if mine else 0, device)
+        lo = -dist.agree_max(-1 if mine else 0, device)       # min over the ranks
+        if hi != lo:
+            raise RuntimeError("BEAR_AMD_DETERMINISTIC (or the deterministic build of libbear_hip) is in effect on some ranks only: "
+                               "export the variable to every rank of the job")
+        _DET_AGREED["world"] = (world, mine)
+    return mine
+
+
+_DET_AGREED = {}
 
 
 def live_rows(e, *columns, by="train"):

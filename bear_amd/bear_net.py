@@ -77,7 +77,7 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
         def reducer(k):
             e = res.load(k)
             plan = res.plan(k, "train", 5) if e["rows"] else None     # built here, before any capture (plan creation allocates and synchronises)
-            if _train.deterministic() and fused_mat is not None:
+            if _train.deterministic_agreed(device) and fused_mat is not None:
                 # BEAR_AMD_DETERMINISTIC: the fixed-point scale of the linear step's gradient tables follows from the counts of the
                 # WHOLE batch -- every rank's piece -- so that d/d mat does not depend on the number of ranks (include/bear_hip.h);
                 # a rank whose piece of the batch is empty takes part in the two all-reduces with zeros

@@ -84,7 +84,7 @@ int bear_ws_create(int device, bear_ws **out) {
       ws->eval_blocks = ws->num_cu * 8;
       if (e == hipSuccess) e = hipMalloc(&ws->eval_partials, sizeof(double) * EVL_MAX_OUT * (size_t)ws->eval_blocks);
       if (e == hipSuccess) e = hipMalloc(&ws->eval_out, sizeof(double) * EVL_MAX_OUT);
-      if (e == hipSuccess) e = hipMalloc(&ws->lin_partials, sizeof(double) * LIN_MAX_GRAD * (size_t)ws->num_cu);
+      if (e == hipSuccess) e = hipMalloc(&ws->lin_partials, sizeof(double) * LIN_MAX_GRAD * (size_t)ws->num_cu * PLN_BLOCKS_PER_CU);
       if (e == hipSuccess) e = hipMalloc(&ws->arrive, sizeof(unsigned long long) * BEAR_ARRIVE_WORDS);
       if (e == hipSuccess) e = hipMemset(ws->arrive, 0, sizeof(unsigned long long) * BEAR_ARRIVE_WORDS);
       ws->epoch = 0;
@@ -707,7 +707,7 @@ static pln_view plan_view(const bear_plan *p) {
 }
 
 static int grid_plan(const bear_ws *ws, uint64_t n_tiles) {
-  uint64_t g = (uint64_t)ws->num_cu;  // one resident 1024-thread block per CU (LDS ring)
+  uint64_t g = (uint64_t)ws->num_cu * PLN_BLOCKS_PER_CU;  // one resident 1024-thread block per CU (LDS ring; the half-tile build: two of 512)
   if (g > (uint64_t)ws->max_blocks) g = ws->max_blocks;
   if (n_tiles < g) g = n_tiles;
   return g < 1 ? 1 : (int)g;

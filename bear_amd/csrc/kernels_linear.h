@@ -36,7 +36,9 @@
 #define LIN_DBG 0   // developer cut-offs of phase C (results are then meaningless)
 #endif
 
+#ifndef LIN_MAX_LAG
 #define LIN_MAX_LAG 21
+#endif
 #ifndef LIN_CH
 #define LIN_CH 4
 #endif
@@ -1153,21 +1155,22 @@ __device__ __forceinline__ void lin_sum_block_partials(const double *__restrict_
   }
 }
 
-// compile-time group count from the run-time one
+// compile-time group count from the run-time one (a build with a smaller LIN_MAX_LAG never sees the larger counts)
+#define LIN_NG_CLAMP(k) ((k) <= LIN_MAX_GROUPS ? (k) : LIN_MAX_GROUPS)
 #define LIN_FOR_NG(ng, CALL)                   \
   switch (ng) {                                \
-    case 1: { constexpr int NG = 1; CALL; } break;   \
-    case 2: { constexpr int NG = 2; CALL; } break;   \
-    case 3: { constexpr int NG = 3; CALL; } break;   \
-    case 4: { constexpr int NG = 4; CALL; } break;   \
-    case 5: { constexpr int NG = 5; CALL; } break;   \
-    case 6: { constexpr int NG = 6; CALL; } break;   \
-    case 7: { constexpr int NG = 7; CALL; } break;   \
-    case 8: { constexpr int NG = 8; CALL; } break;   \
-    case 9: { constexpr int NG = 9; CALL; } break;   \
+    case 1: { constexpr int NG = LIN_NG_CLAMP(1); CALL; } break;   \
+    case 2: { constexpr int NG = LIN_NG_CLAMP(2); CALL; } break;   \
+    case 3: { constexpr int NG = LIN_NG_CLAMP(3); CALL; } break;   \
+    case 4: { constexpr int NG = LIN_NG_CLAMP(4); CALL; } break;   \
+    case 5: { constexpr int NG = LIN_NG_CLAMP(5); CALL; } break;   \
+    case 6: { constexpr int NG = LIN_NG_CLAMP(6); CALL; } break;   \
+    case 7: { constexpr int NG = LIN_NG_CLAMP(7); CALL; } break;   \
+    case 8: { constexpr int NG = LIN_NG_CLAMP(8); CALL; } break;   \
+    case 9: { constexpr int NG = LIN_NG_CLAMP(9); CALL; } break;   \
     default: { constexpr int NG = LIN_MAX_GROUPS; CALL; } break; \
   }
-static_assert(LIN_MAX_GROUPS == 10, "LIN_FOR_NG lists the group counts");
+static_assert(LIN_MAX_GROUPS <= 10, "LIN_FOR_NG lists the group counts");
 
 #ifdef LIN_STAMPS   // developer build: clocks per section of the tile loop, summed over the waves (scripts/dev/lin_stamps.py)
 __device__ unsigned long long lin_stamp_sums[8];
@@ -1182,7 +1185,7 @@ __device__ unsigned long long lin_stamp_sums[8];
 #endif
 // DET (BEAR_AMD_DETERMINISTIC): the gradient tables hold fixed-point integers, gt_scale = 2^50 / bound (see lin_fx above)
 template <bool AR, bool PAIRED, bool DET = false>
-__global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_linear_plan_kernel(
+__global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     const unsigned long long *__restrict__ kmer_code, const double *__restrict__ mat, int lag, bear_params prm_arg, pln_view pv,
     const double2 *__restrict__ logtab_g, double *__restrict__ partials, double *__restrict__ grad_partials,
     const bear_step_io io, double *__restrict__ grad_out, int accumulate,    // accumulate: add to io.out / grad_out (second launch of a step)

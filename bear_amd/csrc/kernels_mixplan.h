@@ -58,7 +58,7 @@ __device__ __forceinline__ void mxp_cell(const double *__restrict__ g_row, const
 }
 
 template <bool AR>
-__global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_refmix_plan_grad_kernel(
+__global__ __launch_bounds__(PLN_THREADS, 4) void dm_refmix_plan_grad_kernel(
     const double *__restrict__ net_rows, const double *__restrict__ ref_rows, const double *__restrict__ h_s,
     const double *__restrict__ tau_s, const double *__restrict__ nw_s, double eps_arg, pln_view pv, const double2 *__restrict__ logtab_g,
     double *__restrict__ grad_out, double *__restrict__ partials, const bear_step_io io) {

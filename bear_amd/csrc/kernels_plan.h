@@ -27,7 +27,9 @@
 #pragma once
 #include "kernels_sorted.h"
 
+#ifndef PLN_THREADS
 #define PLN_THREADS 1024
+#endif
 #define PLN_WAVES (PLN_THREADS / 64)
 #ifndef PLN_UNITS
 #define PLN_UNITS 32                          // units per tile: two per wave, drawn dynamically, dearest first
@@ -39,7 +41,10 @@
 #ifndef PLN_RMAX
 #define PLN_RMAX 1664                         // contexts per tile (at most; LDS)
 #endif
+#ifndef PLN_HCAP
 #define PLN_HCAP 128                          // large-count items / contexts evaluated inside a tile (rest: global lists)
+#endif
+#define PLN_BLOCKS_PER_CU (1024 / PLN_THREADS)   // resident blocks of the planned step kernels per CU (LDS: 160 KB / that many)
 #define PLN_QUAD 4                            // tiles start on multiples of 4 contexts (16-byte aligned rows)
 #define PLN_LIVE_STRIDE (PLN_RMAX + 8)        // uint16 per tile of the live-context lists (a multiple of 8: 16-byte rows)
 #define PLN_SENTINEL (PLN_RMAX * 5)           // flat offset of the neutral cell (prior = 1 / ref row = 0)
@@ -762,7 +767,7 @@ __device__ __forceinline__ pln_tile pln_desc(const pln_tile (*ring)[PLN_DESC_CHU
 // AR: multinomial mode (train_ar, core.py:138-139 with probs = prior + eps, bear_net.py:68): sum LL =
 // sum over cells c log(prior + eps); no context terms, no h gradient.
 template <bool NORM, bool AR>
-__global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_kernel(const double *__restrict__ prior,
+__global__ __launch_bounds__(PLN_THREADS, 4) void dm_prior_plan_kernel(const double *__restrict__ prior,
                                                                                     uint64_t n_rows, bear_params prm_arg,
                                                                                     pln_view pv,
                                                                                     const double2 *__restrict__ logtab_g,
@@ -1072,7 +1077,7 @@ __device__ __forceinline__ uint32_t pln_peek(const uint32_t *p) {
 
 // AR: multinomial mode of bear_ref (train_ar): sum LL = sum c log(f + eps); gradients w.r.t. tau_s, nu_s only.
 template <bool AR>
-__global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_ref_plan_kernel(const uint32_t *__restrict__ ref,
+__global__ __launch_bounds__(PLN_THREADS, 4) void dm_ref_plan_kernel(const uint32_t *__restrict__ ref,
                                                                                   uint64_t n_rows, bear_params prm_arg,
                                                                                   pln_view pv,
                                                                                   const double2 *__restrict__ logtab_g,
@@ -1318,7 +1323,7 @@ __device__ __forceinline__ void pln_touch_lines(uint32_t *scratch, const void *s
 }
 
 template <bool NORM, bool AR>
-__global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad_kernel(const double *__restrict__ prior,
+__global__ __launch_bounds__(PLN_THREADS, 4) void dm_prior_plan_grad_kernel(const double *__restrict__ prior,
                                                                                          bear_params prm_arg, pln_view pv,
                                                                                          const double2 *__restrict__ logtab_g,
                                                                                          double *__restrict__ grad_out,
@@ -1517,7 +1522,7 @@ struct pln_lds_gi {
 };
 static_assert(sizeof(pln_lds_gi) <= 158 * 1024, "in-place gradient kernel: LDS budget");
 
-__global__ __launch_bounds__(PLN_THREADS, PLN_WAVES / 4) void dm_prior_plan_grad_inplace_kernel(const double *__restrict__ prior,
+__global__ __launch_bounds__(PLN_THREADS, 4) void dm_prior_plan_grad_inplace_kernel(const double *__restrict__ prior,
                                                                                                  bear_params prm_arg, pln_view pv,
                                                                                                  const double2 *__restrict__ logtab_g,
                                                                                                  double *__restrict__ grad_out,

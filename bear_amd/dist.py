@@ -32,6 +32,10 @@ def init_from_env():
     Returns ``(rank, world_size)``."""
     if dist.is_available() and dist.is_initialized():
         return world()
+    # dmabuf IPC: RCCL between processes (and CUDA-tensor sharing) needs it on this host driver -- without it the first
+    # collective of an externally launched job fails in hipIpcGetMemHandle.  The HSA runtime reads the variable when the GPU is
+    # first touched, which is why this function must run before any GPU call.  A value the launcher exported wins.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev_index = int(os.environ.get("BEAR_AMD_DEVICE", local_rank))
@@ -109,6 +113,18 @@ def allreduce_max_(t):
         else:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
+
+
+def agree_max(value, device=None):
+    """The largest ``value`` (an int) any rank holds: every rank calls it and every rank gets the same answer, so a decision
+    that a rank would otherwise take from its OWN state (free HBM, an environment switch) and that changes which collectives
+    it issues is taken by all of them alike.  One process: the value itself."""
+    if world()[1] <= 1:
+        return int(value)
+    on = device if (device is not None and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=on)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
 
 
 def broadcast_params(params, src=0):

@@ -153,8 +153,13 @@ class Plan:
             raise ValueError("kmer_index: one 16-byte aligned index word per row of the plan's count slab")
         ok = ctypes.c_int(0)
         with torch.cuda.device(self.counts.device):
-            torch.cuda.empty_cache()     # the lists come from hipMalloc: slabs the torch allocator has cached are out of its reach
             st = _lib.lib().bear_plan_pair_contexts(self._h, _ptr(kmer_index), int(lag), ctypes.byref(ok), _stream())
+            if st == _lib.ERR_NOMEM:
+                # the lists come from hipMalloc: slabs the torch allocator has cached are out of its reach.  Given back only now --
+                # emptying the cache on every call made a streamed epoch pay hipFree / hipMalloc (device-wide synchronisations that
+                # serialise with the side stream's prefetch) on every batch load
+                torch.cuda.empty_cache()
+                st = _lib.lib().bear_plan_pair_contexts(self._h, _ptr(kmer_index), int(lag), ctypes.byref(ok), _stream())
         if st == _lib.ERR_NOMEM:         # an optional speed-up: a table close to the card's capacity runs the plain step
             warnings.warn("bear_plan_pair_contexts: out of device memory, the linear step keeps its plain lists")
             self.paired_codes = None
@@ -191,8 +196,10 @@ class Plan:
             raise ValueError("kmer_code: one 16-byte aligned packed context per row of the plan's count slab")
         n = ctypes.c_int(0)
         with torch.cuda.device(self.counts.device):
-            torch.cuda.empty_cache()     # (as in pair_contexts)
             st = _lib.lib().bear_plan_attach_cnn_levels(self._h, _ptr(kmer_code), int(lag), int(filter_width), ctypes.byref(n), _stream())
+            if st == _lib.ERR_NOMEM:
+                torch.cuda.empty_cache()     # (as in pair_contexts: only when the first attempt ran out)
+                st = _lib.lib().bear_plan_attach_cnn_levels(self._h, _ptr(kmer_code), int(lag), int(filter_width), ctypes.byref(n), _stream())
         if st == _lib.ERR_NOMEM:
             warnings.warn("bear_plan_attach_cnn_levels: out of device memory, the convolutional step runs without prefix levels")
             self.cnn_codes = None
@@ -456,6 +463,40 @@ def synth_prior(seed, row0, n_rows, device):
         st = _lib.lib().bear_synth_prior_f64(int(seed), int(row0), int(n_rows), _ptr(prior), _stream())
     _lib.check(st, "bear_synth_prior_f64")
     return prior
+
+
+def synth_kmer_ids(seed, row0, n_rows, lag, device):
+    """The k-mers of rows [row0, row0 + n_rows) of the synthetic table as integers in [0, 4^lag) (letter 0 most significant,
+    two bits per letter): row index -> a FIXED BIJECTION of [0, 4^lag) -- the contexts of a table are DISTINCT,
+    as the contexts of any count table are (summarize.py:429-449 writes one row per k-mer), in a scrambled order, and rows
+    [a, b) are the same k-mers however the table is cut into shards.  The bijection: rounds of an odd multiplier + constant
+    (mod 4^lag) and a right xor-shift, each invertible on 2 lag bits.  torch ops only: the same numbers on the CPU and the card
+    (measurement tooling, like synth_counts; the parity tests draw their own small tables)."""
+    lag = int(lag)
+    if not 1 <= lag <= 31:
+        raise ValueError("synth_kmer_ids: 1 <= lag <= 31")
+    bits = 2 * lag
+    if row0 < 0 or row0 + n_rows > (1 << bits):
+        raise ValueError(f"rows [{row0}, {row0 + n_rows}) of a table of distinct {lag}-mers: only 4^{lag} = {1 << bits} exist")
+    mask = (1 << bits) - 1
+    x = torch.arange(int(row0), int(row0) + int(n_rows), dtype=torch.int64, device=device)
+    s = (int(seed) * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & ((1 << 62) - 1)
+    for r in range(4):
+        mul = ((s >> (7 * r)) | 1) & mask | 1                      # odd: invertible mod 2^bits
+        add = (s >> (5 * r + 3)) & mask
+        x = (x * mul + add) & mask                                 # (int64 products wrap: the low `bits` bits are exact)
+        x = x ^ (x >> max(1, bits // 2 + (r & 1)))
+    return x
+
+
+def synth_kmer_codes(seed, row0, n_rows, lag, device, sort=False):
+    """int8 letter codes [n_rows, lag] (0..3 = A, C, G, T: core.encode_kmers) of ``synth_kmer_ids``; ``sort``: in k-mer order
+    (the order bear_net.train gives a batch) -- the ids ascending."""
+    ids = synth_kmer_ids(seed, row0, n_rows, lag, device)
+    if sort:
+        ids = torch.sort(ids).values
+    shifts = torch.arange(2 * (int(lag) - 1), -1, -2, dtype=torch.int64, device=ids.device)
+    return ((ids[:, None] >> shifts[None, :]) & 3).to(torch.int8).contiguous()
 
 
 def log_gamma(conc, n_samples, seed):

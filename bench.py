@@ -236,6 +236,9 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the two must agree")
+    # an EXTERNAL launcher (`python -m torch.distributed.run ... bench.py --gpus N`) may not have exported it: dmabuf IPC, which
+    # RCCL between processes needs on this host driver; read by the HSA runtime at the first GPU call, so set before it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs MI355X devices"
     dev_index = int(os.environ.get("BEAR_BENCH_DEVICE", local_rank))  # override only for single-GPU smoke tests
     torch.cuda.set_device(dev_index)

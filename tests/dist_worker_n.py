@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from bear_amd import ar_funcs, bear_net, bear_ref, dataloader, dist
+from bear_amd import _train, ar_funcs, bear_net, bear_ref, dataloader, dist
 
 
 def main():
@@ -20,6 +20,8 @@ def main():
     assert world == int(os.environ["BEAR_EXPECT_WORLD"]) and torch.cuda.current_device() == 0
     restart = np.load(os.environ["BEAR_RESTART"], allow_pickle=True)
     out = {}
+    if os.environ.get("BEAR_TEST_STREAM_RANK", "") == str(rank):
+        os.environ["BEAR_AMD_STREAM"] = "1"          # ONE rank is told to stream its epochs: the ranks have to agree on it
     for name, path, batch in json.loads(os.environ["BEAR_TABLES"]):
         data = dataloader.dataloader(path, "dna", batch, 3, shard="auto")
         pieces = [g1 - g0 for g0, g1, _ in data.rank_pieces(rank, world)]
@@ -33,6 +35,9 @@ def main():
         p, _, _ = bear_net.train(data.repeat(4), data.num_rows, 4, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", False,
                                  params_restart=list(restart["linear"]), loss_save=ls)
         res["net_linear"] = {"loss": ls, "params": [x.detach().cpu().numpy().tolist() for x in p]}
+        streamed = [None] * world
+        torch.distributed.all_gather_object(streamed, bool(_train.LAST_RUN.get("streaming")))
+        res["streamed"] = streamed
         ls = []
         p, _, _ = bear_net.train(data.repeat(4), data.num_rows, 4, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", True, acc_steps=2,
                                  params_restart=list(restart["linear"]), loss_save=ls)

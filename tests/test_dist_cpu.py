@@ -17,7 +17,10 @@ import numpy as np, torch, torch.distributed as dist
 import bear_oracle as o
 from bear_amd import dist as bdist
 from util import sparse_table, prior_rows
+assert "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ     # (the test's launcher took it out: an external launcher may not export it)
 rank, world = bdist.init_from_env()          # the product's own set-up (BEAR_AMD_DIST_BACKEND=gloo here, RCCL on the GPU node)
+# dmabuf IPC for RCCL between processes: exported by init_from_env itself, before the process group (and any GPU call) exists
+assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 W = int(os.environ["BEAR_EXPECT_WORLD"])
 assert world == W and bdist.world() == (rank, W) and dist.get_backend() == "gloo"
 # mirrored variables: rank 1 draws other initial values, rank 0's win
@@ -80,6 +83,7 @@ def test_gloo_step(tmp_path, world):
     import socket
     env = dict(os.environ, BEAR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", BEAR_AMD_DIST_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo",
                BEAR_EXPECT_WORLD=str(world))
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
     with socket.socket() as sk:         # a free port (a fixed one may still be held by an earlier run)
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -108,3 +112,33 @@ def test_bench_bare_multi_gpu_command_fails_loudly_without_the_devices():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo"], env=dict(env, BEAR_BENCH_DEVICE="0"),
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and p.stdout == "" and "bench.py needs MI355X devices" in p.stderr
+
+
+def test_driver_path_exports_the_ipc_mode_before_the_process_group(monkeypatch):
+    """`torchrun ... train_bear_ref.py cfg` under an external launcher: `dist.init_from_env()` is the drivers' first call
+    (models/_driver.py) and exports HSA_ENABLE_IPC_MODE_LEGACY=0 before `init_process_group` -- a value the launcher set wins."""
+    import torch.distributed as tdist
+    from bear_amd import dist as bdist
+    seen = {}
+
+    def fake_init(backend, **kw):
+        seen["env"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+        raise RuntimeError("stop here")
+    monkeypatch.setattr(tdist, "init_process_group", fake_init)
+    for preset, want in ((None, "0"), ("1", "1")):
+        if preset is None:
+            monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+        else:
+            monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", preset)
+        monkeypatch.setenv("WORLD_SIZE", "2")
+        monkeypatch.setenv("RANK", "0")
+        monkeypatch.setenv("LOCAL_RANK", "0")
+        monkeypatch.setenv("BEAR_AMD_DIST_BACKEND", "gloo")
+        with pytest.raises(RuntimeError, match="stop here"):
+            bdist.init_from_env()
+        assert seen["env"] == want
+    # the config driver calls it before it touches anything else
+    src = open(os.path.join(ROOT, "bear_amd", "models", "_driver.py")).read()
+    body = src[src.index("def _run"):]
+    first = [ln.strip() for ln in body.splitlines()[1:] if ln.strip() and not ln.strip().startswith(("#", '"'))][0]
+    assert first == "rank, world = dist.init_from_env()", first

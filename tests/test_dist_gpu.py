@@ -123,6 +123,34 @@ def test_many_ranks_deterministic_mode_with_empty_pieces(tmp_path):
     assert np.allclose(_flat(got["net_linear"]["params"]), _flat([x.detach().cpu().numpy() for x in p]), rtol=1e-7, atol=1e-10)
 
 
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_one_rank_streams_every_rank_streams(tmp_path, deterministic):
+    """Whether an epoch is streamed is decided from a rank's OWN free HBM (or BEAR_AMD_STREAM): the ranks agree on it with one MAX
+    all-reduce before any of them acts (`ResidentBatches`, `dist.agree_max`) -- a streaming rank runs an eager loop, a resident one
+    captures a graph behind a warm-up all-reduce, and in deterministic mode the count-bound all-reduces come per batch load on the
+    one and up front on the other: the collectives would pair up wrongly.  Rank 1 alone is told to stream here; both stream, and
+    the losses and parameters equal the single-process run's."""
+    torch.manual_seed(3)
+    _, lin = ar_funcs.make_ar_func_linear(5, 4)
+    restart = {"linear": np.array([np.array(0.1)] + [x.detach().numpy() for x in lin], dtype=object)}
+    np.savez(tmp_path / "restart.npz", **restart)
+    out_file = tmp_path / "out.json"
+    extra = {"BEAR_AMD_DETERMINISTIC": "1"} if deterministic else {}
+    _launch([os.path.join(ROOT, "tests", "dist_worker_n.py")],
+            {"BEAR_RESTART": str(tmp_path / "restart.npz"), "BEAR_OUT": str(out_file), "BEAR_TABLES": json.dumps([["ysd1", YSD1, 500]]),
+             "BEAR_EXPECT_WORLD": "2", "BEAR_TEST_STREAM_RANK": "1", **extra}, tmp_path, nproc=2)
+    got = json.load(open(out_file))["ysd1"]
+    assert got["streamed"] == [True, True]
+    data = dataloader.dataloader(YSD1, "dna", 500, 3)
+    for key, fn, args, kw in (("ref_stop", bear_ref.train, (data.repeat(4), 1365, 4, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False), {}),
+                              ("net_linear", bear_net.train, (data.repeat(4), 1365, 4, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", False),
+                               {"params_restart": list(restart["linear"])})):
+        ls = []
+        p, _, _ = fn(*args, loss_save=ls, **kw)
+        assert len(ls) == len(got[key]["loss"]) and np.allclose(got[key]["loss"], ls, rtol=1e-10), key
+        assert np.allclose(_flat(got[key]["params"]), _flat([x.detach().cpu().numpy() for x in p]), rtol=1e-7, atol=1e-10), key
+
+
 def test_many_ranks_match_single_rank_with_empty_and_uneven_pieces(tmp_path):
     """MANY processes under torch.distributed.run (all on cuda:0, gloo): bear_ref.train, bear_net.train (linear; BEAR mode, and AR
     mode with gradient accumulation) and both evaluations on row shards reproduce the single-process run -- on the bundled table
