@@ -448,21 +448,34 @@ class ResidentBatches:
         return e["plans"][key]
 
 
+class StepFns:
+    """What a driver hands run_device_steps per batch: ``reduce(packed)`` enqueues this rank's shard reduce; ``step(packed, m, v, t,
+    learning_rate, scale, loss_buf)`` (optional) enqueues the WHOLE optimizer step -- reduce and tf.keras Adam in one launch
+    (``bear_*_train_step_f64``: the last block of the reduce kernel runs the update) -- which the loop takes when nothing has to
+    happen between the two halves (one rank, Adam, no gradient accumulation)."""
+
+    def __init__(self, reduce, step=None):
+        self.reduce, self.step = reduce, step
+
+
 def reducers(res, make):
-    """The batches' reduce functions from ``make(k)``, which loads batch k and builds what its step needs (plans, paired lists,
-    prefix levels).  Resident epochs: all of them now, before anything is captured.  Streamed epochs: batch k's is made each time
-    the batch comes up and dropped with it."""
+    """The batches' step functions (``StepFns``; a bare callable = reduce only) from ``make(k)``, which loads batch k and builds what
+    its step needs (plans, paired lists, prefix levels).  Resident epochs: all of them now, before anything is captured.  Streamed
+    epochs: batch k's is made each time the batch comes up and dropped with it."""
+    def wrap(fn):
+        return fn if isinstance(fn, StepFns) else StepFns(fn)
     if not res.streaming:
-        return [make(k) for k in range(len(res.batches))]
+        return [wrap(make(k)) for k in range(len(res.batches))]
 
     def lazy(k):
         def reduce(packed):
             e = res.load(k)
             fn = e.get("_reduce")
             if fn is None:
-                fn = e["_reduce"] = make(k)
-            fn(packed)
-        return reduce
+                fn = e["_reduce"] = wrap(make(k))
+            fn.reduce(packed)
+        # (a streamed batch's functions exist only while it is loaded, and its step is bound by PCIe, not by a launch: reduce + update)
+        return StepFns(reduce)
     return [lazy(k) for k in range(len(res.batches))]
 
 
@@ -479,6 +492,7 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
     ``eager_first_period`` (reduce functions made of torch ops and autograd, ``run_autograd_steps``): the first period of steps is
     enqueued eagerly before anything is captured -- the libraries behind the ops pick their algorithms, the allocator its blocks and
     the plans are cut outside the capture.  ``graph_ok = False``: never capture."""
+    reduce_fns = [f if isinstance(f, StepFns) else StepFns(f) for f in reduce_fns]
     n_theta, n_batches = theta.numel(), len(reduce_fns)
     world = dist.world()[1]
     packed = torch.zeros(n_theta + 1, dtype=torch.float64, device=device)
@@ -503,10 +517,18 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
             done[0] += 1
 
     acc = torch.zeros_like(packed) if acc_steps > 1 else None
+    # One launch per optimizer step where nothing sits between the reduce and the update: one rank (no all-reduce), Adam, no
+    # accumulation -- the reduce kernel's last block runs the update (bear_*_train_step_f64).  BEAR_AMD_TWO_LAUNCH_STEP=1: as before.
+    fuse = adam and acc is None and not dist.collective_active() and not os.environ.get("BEAR_AMD_TWO_LAUNCH_STEP")
+    fused_steps = [0]
 
     def one_step(k, step):
         """Batch k as optimizer-loop step number `step` (1-based): reduce -> [one all-reduce] -> update (every acc_steps steps)."""
-        reduce_fns[k](packed)
+        if fuse and reduce_fns[k].step is not None:
+            reduce_fns[k].step(packed, m, v, t, learning_rate, scales[k], loss_buf)
+            fused_steps[0] += 1
+            return
+        reduce_fns[k].reduce(packed)
         dist.allreduce_sum_(packed)
         if acc is None:
             update(packed, scales[k])
@@ -570,7 +592,7 @@ def run_device_steps(reduce_fns, scales, theta, repeats, learning_rate, optimize
     ev[2].record()
     torch.cuda.synchronize()
     LAST_RUN.update(graph=graph is not None, replays=replays, period=period, eager_steps=eager_steps + total_steps - done_steps,
-                    world=world, collective=dist.collective_active(), loop_steps=loop_steps,
+                    world=world, collective=dist.collective_active(), loop_steps=loop_steps, one_launch_steps=fuse and fused_steps[0] > 0,
                     loop_ms=ev[0].elapsed_time(ev[2]) if loop_steps else 0.0,
                     timed_steps=total_steps - timed_from if timed_from is not None else 0,
                     timed_ms=ev[1].elapsed_time(ev[2]) if timed_from is not None else 0.0)

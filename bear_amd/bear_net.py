@@ -101,7 +101,10 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
                     plan.attach_cnn_levels(pack, lag, fw)
                 views = tuple(b[:e["rows"]] for b in bufs)
                 return lambda packed: kernels.net_cnn_train_reduce(plan, pack, lag, fw, theta, views, packed, train_ar=train_ar)
-            return lambda packed: kernels.net_linear_train_reduce(plan, pack, lag, theta, packed, train_ar=train_ar)
+            return _train.StepFns(
+                lambda packed: kernels.net_linear_train_reduce(plan, pack, lag, theta, packed, train_ar=train_ar),
+                lambda packed, m, v, t, lr, scale, loss_buf: kernels.net_linear_train_step(plan, pack, lag, theta, m, v, t, packed, lr, scale,
+                                                                                           loss_buf, train_ar=train_ar))
         reduce_fns = _train.reducers(res, reducer)
         losses = _train.run_device_steps(reduce_fns, scales, theta, data.repeats, learning_rate, optimizer_name, train_ar, acc_steps, device,
                                          graph_ok=not res.streaming)

@@ -118,7 +118,10 @@ def train(data, num_kmers, epochs, ds_loc, ds_loc_ref, alphabet, lag, make_ar_fu
         # built here, before any capture (plan creation allocates and synchronises); the reference column is resident too, so the
         # plan folds the contexts without reference counts into a histogram and a step streams only the others' items
         plan = res.plan(k, "train", 4, ref_column="ref")
-        return lambda packed: kernels.ref_train_reduce(plan, e["ref"], theta, packed, train_ar=train_ar)
+        return _train.StepFns(
+            lambda packed: kernels.ref_train_reduce(plan, e["ref"], theta, packed, train_ar=train_ar),
+            lambda packed, m, v, t, lr, scale, loss_buf: kernels.ref_train_step(plan, e["ref"], theta, m, v, t, lr, scale, packed, loss_buf,
+                                                                                train_ar=train_ar))
     reduce_fns = _train.reducers(res, reducer)
     scales = [-(num_kmers / e["global_rows"]) for e in res.batches]       # loss = -(num_kmers / B) sum LL, bear_ref.py:252-253
     losses = _train.run_device_steps(reduce_fns, scales, theta, data.repeats, learning_rate, optimizer_name, train_ar, acc_steps, device,

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/bear_hip.h"
+#include "bear_release_guard.h"
 #include "bear_math.h"
 
 #define BEAR_THREADS 256
@@ -137,6 +138,12 @@ __device__ __forceinline__ void block_store_partials(double (&acc)[NOUT], double
 // itself in: two one-way atomics per block, no retry loop (a compare-and-swap loop over 256 blocks that finish together cost
 // 0.19 ms per launch).  A launch replayed from a HIP graph keeps the stamp it was captured with: between launches the word is
 // back at zero (left there by the last block), so an older stamp counts from zero like any other.
+// LIMIT of the self-healing: it works for EAGER launches only (each carries a newer stamp than anything left behind).  A graph
+// replay carries the stamp of its capture: if an eager launch with a NEWER stamp has left a partial count behind (it faulted, or
+// overlapped on this workspace against the header's rule), later replays never see their last block and io.out keeps stale sums;
+// the host-side counter also wraps after 2^32 launches.  After a failed launch or synchronisation a caller therefore destroys
+// the workspace (bear_ws_destroy / bear_ws_create zero the words) and captures its graph again -- the Python loop does not
+// survive a BearError either way (it propagates).
 struct bear_arrival {
   unsigned long long *word;
   unsigned epoch;
@@ -244,6 +251,50 @@ __device__ __forceinline__ void bear_finalize_in_block(const double *partials, i
   if (threadIdx.x == 0) bear_arrive_reset(arrive);
 }
 
+// ---- the optimizer update (tf.keras Adam, bear_net.py:278-282) of a step whose sums need no all-reduce, INSIDE the launch that
+// formed them: a launch-bound step (configs[1]: ~15 us of kernel) is then ONE launch instead of two.  The last block -- every other
+// block has arrived, i.e. is done reading theta -- runs the update on `packed` = io.out = [sum LL, d/d theta...] it has just written.
+// theta == NULL: no update (the two-launch form: reduce, [all-reduce], bear_train_apply_f64).
+struct bear_apply_io {
+  double *theta;            // [n_theta], updated in place
+  double *m, *v;            // Adam moments [n_theta]
+  double *t_state;          // [1]: steps taken so far
+  double *loss_buf;         // [loss_cap] or NULL: loss_buf[step] = -scale * packed[0]
+  unsigned long long loss_cap;
+  double lr, scale;         // gradients are scale * packed[1 + k]
+  int n_theta, train_ar;    // train_ar: theta[0] = h_signed gets no update (bear_net.py:194-196)
+};
+
+// tf.keras Adam on theta[k], k = tid, tid + n_threads, ... -- the body of adam_vec_kernel and of the fused step alike (one source:
+// the two forms end in the same bits).  Every thread reads the step counter before the barrier, thread 0 advances it behind it.
+__device__ __forceinline__ void bear_adam_update(const bear_apply_io &A, const double *packed, int tid, int n_threads) {
+  const double t0 = A.t_state[0], t = t0 + 1.0;
+  const double b1 = 0.9, b2 = 0.999, aeps = 1e-7;
+  const double lr_t = A.lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
+  for (int k = tid; k < A.n_theta; k += n_threads) {
+    if (A.train_ar && k == 0) continue;
+    const double g = A.scale * packed[1 + k];
+    const double mk = b1 * A.m[k] + (1.0 - b1) * g, vk = b2 * A.v[k] + (1.0 - b2) * g * g;
+    A.m[k] = mk;
+    A.v[k] = vk;
+    A.theta[k] -= lr_t * mk / (sqrt(vk) + aeps);
+  }
+  if (tid == 0) {
+    const unsigned long long step = (unsigned long long)t0;
+    if (A.loss_buf && step < A.loss_cap) A.loss_buf[step] = -A.scale * packed[0];
+  }
+  __syncthreads();
+  if (tid == 0) A.t_state[0] = t;
+}
+
+// ... by the last block of a reduce launch, behind its fixed-order sums (block-uniform call)
+__device__ __forceinline__ void bear_apply_in_block(const bear_apply_io &A, const double *packed) {
+  if (!A.theta) return;
+  __threadfence_block();
+  __syncthreads();            // packed[] was written by other threads of this block
+  bear_adam_update(A, packed, (int)threadIdx.x, (int)blockDim.x);
+}
+
 template <int NOUT>
 __device__ __forceinline__ void block_finish(double (&acc)[NOUT], double *partials, const bear_step_io &io) {
   if (!io.out) {
@@ -252,6 +303,18 @@ __device__ __forceinline__ void block_finish(double (&acc)[NOUT], double *partia
   }
   block_store_partials<NOUT, true>(acc, partials);
   if (bear_arrive_last(io.arrive())) bear_finalize_in_block(partials, NOUT, io.out, io.arrive());
+}
+template <int NOUT>
+__device__ __forceinline__ void block_finish(double (&acc)[NOUT], double *partials, const bear_step_io &io, const bear_apply_io &apply) {
+  if (!io.out) {                                        // (a finalize_kernel launch follows: never together with an update)
+    block_store_partials<NOUT>(acc, partials);
+    return;
+  }
+  block_store_partials<NOUT, true>(acc, partials);
+  if (bear_arrive_last(io.arrive())) {
+    bear_finalize_in_block(partials, NOUT, io.out, io.arrive());
+    bear_apply_in_block(apply, io.out);
+  }
 }
 
 // ------------------------------------------------------------------ finalize: fixed-order sum of block partials

@@ -861,8 +861,10 @@ int bear_dm_refmix_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint3
 
 // The mode-R step on a plan: the reference-aware item stream when the plan was built with this reference column
 // (bear_plan_create_ref), the streaming kernel otherwise.  theta != NULL: constants from the device-resident parameters.
+static const bear_apply_io NO_APPLY = {};      // theta == NULL: the launch only reduces
+
 static int launch_ref_plan(bear_ws *ws, const bear_plan *plan, const uint32_t *ref, uint64_t n_rows, const bear_params &prm,
-                           const double *theta, int train_ar, double *out, hipStream_t s) {
+                           const double *theta, int train_ar, double *out, hipStream_t s, const bear_apply_io &apply = NO_APPLY) {
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const bear_step_io io = ws_io(ws, theta, BEAR_THETA_REF, out);
   int grid;
@@ -878,17 +880,17 @@ static int launch_ref_plan(bear_ws *ws, const bear_plan *plan, const uint32_t *r
     const uint64_t units = (plan->n_ref_items + 63) / 64, want = (units + 3) / 4 + 2;   // 4 waves per block
     grid = (int)(want < (uint64_t)ws->num_cu * 8 ? want : (uint64_t)ws->num_cu * 8);
     if (train_ar)
-      hipLaunchKernelGGL(dm_ref_items_kernel<true>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, io);
+      hipLaunchKernelGGL(dm_ref_items_kernel<true>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, io, apply);
     else
-      hipLaunchKernelGGL(dm_ref_items_kernel<false>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, io);
+      hipLaunchKernelGGL(dm_ref_items_kernel<false>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, io, apply);
   } else {
     grid = grid_plan(ws, plan->n_tiles);
     if (train_ar)
       hipLaunchKernelGGL(dm_ref_plan_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan), lt,
-                         ws->partials, io);
+                         ws->partials, io, apply);
     else
       hipLaunchKernelGGL(dm_ref_plan_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_r), s, ref, n_rows, prm, plan_view(plan), lt,
-                         ws->partials, io);
+                         ws->partials, io, apply);
   }
   HIP_TRY(hipGetLastError());
   (void)grid;
@@ -920,10 +922,32 @@ int bear_dm_ref_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *tra
 // ---- optimizer step in two halves: the shard's reduce (constants from theta -> planned kernel -> finalize into `packed`) and the
 // apply (tf.keras Adam on theta from packed).  One rank runs them back to back (bear_*_train_step_f64, graph-capturable);
 // several ranks put ONE all-reduce of `packed` between them (bear_net.py:278-290) -- no host round trip either way.
+static bear_apply_io make_apply(double *theta, int n_theta, double *adam_m, double *adam_v, double *adam_t, double learning_rate,
+                                double scale, int train_ar, double *loss_buf, uint64_t loss_cap) {
+  bear_apply_io A;
+  A.theta = theta;
+  A.m = adam_m;
+  A.v = adam_v;
+  A.t_state = adam_t;
+  A.loss_buf = loss_buf;
+  A.loss_cap = (unsigned long long)loss_cap;
+  A.lr = learning_rate;
+  A.scale = scale;
+  A.n_theta = n_theta;
+  A.train_ar = train_ar;
+  return A;
+}
+
+// BEAR_AMD_TWO_LAUNCH_STEP=1: bear_*_train_step_f64 as reduce + bear_train_apply_f64 again (two launches; tests compare the two forms)
+static bool two_launch_step() {
+  const char *e = getenv("BEAR_AMD_TWO_LAUNCH_STEP");
+  return e && e[0] && e[0] != '0';
+}
+
 static int launch_train_apply(double *theta, int n_theta, const double *packed, double *adam_m, double *adam_v, double *adam_t,
                               double learning_rate, double scale, int train_ar, double *loss_buf, uint64_t loss_cap, hipStream_t s) {
-  hipLaunchKernelGGL(adam_vec_kernel, dim3(1), dim3(1024), 0, s, theta, packed, packed + 2, n_theta - 1, adam_m, adam_v,
-                     adam_t, learning_rate, scale, train_ar, loss_buf, (unsigned long long)loss_cap);
+  hipLaunchKernelGGL(adam_vec_kernel, dim3(1), dim3(1024), 0, s,
+                     make_apply(theta, n_theta, adam_m, adam_v, adam_t, learning_rate, scale, train_ar, loss_buf, loss_cap), packed);
   HIP_TRY(hipGetLastError());
   return BEAR_OK;
 }
@@ -954,10 +978,23 @@ int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *
                             double *theta, double *adam_m, double *adam_v, double *adam_t, double eps, int train_ar,
                             double learning_rate, double scale, double *out, double *loss_buf, uint64_t loss_cap, void *stream) {
   if (!adam_m || !adam_v || !adam_t) return BEAR_ERR_INVALID_ARG;
-  int st = bear_ref_train_reduce_f64(ws, plan, train, ref, n_rows, theta, eps, train_ar, out, stream);
+  if (two_launch_step()) {
+    int st = bear_ref_train_reduce_f64(ws, plan, train, ref, n_rows, theta, eps, train_ar, out, stream);
+    if (st != BEAR_OK) return st;
+    return launch_train_apply(theta, 3, out, adam_m, adam_v, adam_t, learning_rate, scale, train_ar, loss_buf, loss_cap,
+                              static_cast<hipStream_t>(stream));
+  }
+  // ONE launch: the last block of the reduce kernel runs the update behind its sums (bear_apply_in_block)
+  int st = check_ws(ws);
   if (st != BEAR_OK) return st;
-  return launch_train_apply(theta, 3, out, adam_m, adam_v, adam_t, learning_rate, scale, train_ar, loss_buf, loss_cap,
-                            static_cast<hipStream_t>(stream));
+  if (!plan || !out || !theta || !n_rows || !train || !ref) return BEAR_ERR_INVALID_ARG;
+  if (plan->ncol != 4 || plan->n_rows != n_rows || plan->counts != train || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
+  if (misaligned(ref) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
+  bear_params only_eps;
+  memset(&only_eps, 0, sizeof(only_eps));
+  only_eps.eps = eps;
+  return launch_ref_plan(ws, plan, ref, n_rows, only_eps, theta, train_ar, out, static_cast<hipStream_t>(stream),
+                         make_apply(theta, 3, adam_m, adam_v, adam_t, learning_rate, scale, train_ar, loss_buf, loss_cap));
 }
 
 int bear_dm_items_f64(bear_ws *ws, const double *x, const uint32_t *c, uint64_t n, int path, double *D, double *P,
@@ -1038,16 +1075,18 @@ int bear_encode_kmers_i8(const uint8_t *ascii, uint64_t n_rows, int lag, int rna
 // over the paired tiles and, when some tiles kept their plain list, a second launch of the plain form over those, which adds
 // its sums to the first one's (same stream: the workspace is free again when it starts).
 static void launch_linear(bear_ws *ws, const bear_plan *plan, const uint64_t *kmer_code, const double *mat, int lag, const bear_params &prm,
-                          int train_ar, const bear_step_io &io, double *grad_mat, hipStream_t s) {
+                          int train_ar, const bear_step_io &io, double *grad_mat, hipStream_t s, const bear_apply_io &apply = NO_APPLY) {
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const unsigned long long *kc = reinterpret_cast<const unsigned long long *>(kmer_code);
   const bool paired = plan->live2 && plan->pair_codes == kmer_code && plan->pair_lag == lag && !getenv("BEAR_AMD_LINEAR_UNPAIRED");
   // BEAR_AMD_DETERMINISTIC: fixed-point gradient tables (kernels_linear.h, lin_fx); the kernel derives their scale from these bounds
   const bool det = bear_deterministic() && plan->count_bound[0] >= 1.0 && plan->count_bound[0] < 0x1p50;
   const lin_fx_bound gt_bound = {plan->count_bound[0], plan->count_bound[1], log(plan->count_bound[2] > 1.0 ? plan->count_bound[2] : 1.0)};
+  // (the update, if any, goes with the step's LAST launch: the one that completes the sums)
 #define LIN_LAUNCH_D(AR, PAIRED, DET, PV, NT, ACC)                                                                                          \
   hipLaunchKernelGGL((dm_linear_plan_kernel<AR, PAIRED, DET>), dim3(grid_plan(ws, NT)), dim3(PLN_THREADS), sizeof(pln_lds_lin), s, kc, mat, \
-                     lag, prm, PV, lt, ws->partials, ws->lin_partials, (ACC) ? io2 : io, grad_mat, ACC, gt_bound)
+                     lag, prm, PV, lt, ws->partials, ws->lin_partials, (ACC) ? io2 : io, grad_mat, ACC, gt_bound,                            \
+                     ((ACC) || !two_launches) ? apply : NO_APPLY)
 #define LIN_LAUNCH(AR, PAIRED, PV, NT, ACC)                    \
   do {                                                         \
     if (det) LIN_LAUNCH_D(AR, PAIRED, true, PV, NT, ACC);      \
@@ -1056,6 +1095,7 @@ static void launch_linear(bear_ws *ws, const bear_plan *plan, const uint64_t *km
   bear_step_io io2 = io;      // the second launch of a step: its own stamp on the arrival word
   io2.epoch = ws_arrival(ws).epoch;
   pln_view pv = plan_view(plan);
+  const bool two_launches = paired && plan->n_tiles_u != 0;
   if (!paired) {
     if (train_ar) LIN_LAUNCH(true, false, pv, plan->n_tiles, 0);
     else LIN_LAUNCH(false, false, pv, plan->n_tiles, 0);
@@ -1331,10 +1371,27 @@ int bear_net_linear_train_step_f64(bear_ws *ws, const bear_plan *plan, const uin
                                    double eps, int train_ar, double learning_rate, double scale, double *loss_buf,
                                    uint64_t loss_cap, void *stream) {
   if (!adam_m || !adam_v || !adam_t) return BEAR_ERR_INVALID_ARG;
-  int st = bear_net_linear_train_reduce_f64(ws, plan, counts, kmer_code, lag, n_rows, theta, eps, train_ar, packed, stream);
+  if (two_launch_step()) {
+    int st = bear_net_linear_train_reduce_f64(ws, plan, counts, kmer_code, lag, n_rows, theta, eps, train_ar, packed, stream);
+    if (st != BEAR_OK) return st;
+    return launch_train_apply(theta, 1 + lag * 25, packed, adam_m, adam_v, adam_t, learning_rate, scale, train_ar, loss_buf, loss_cap,
+                              static_cast<hipStream_t>(stream));
+  }
+  // ONE launch: the last block of the step's (last) kernel runs the update behind its sums
+  int st = check_ws(ws);
   if (st != BEAR_OK) return st;
-  return launch_train_apply(theta, 1 + lag * 25, packed, adam_m, adam_v, adam_t, learning_rate, scale, train_ar, loss_buf, loss_cap,
-                            static_cast<hipStream_t>(stream));
+  if (!plan || !packed || !theta || lag < 1 || lag > LIN_MAX_LAG || !n_rows) return BEAR_ERR_INVALID_ARG;
+  if (plan->counts != counts || plan->n_rows != n_rows || plan->ncol != 5 || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
+  if (!kmer_code || misaligned(kmer_code) || (reinterpret_cast<uintptr_t>(packed) & 7u)) return BEAR_ERR_INVALID_ARG;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  bear_params dummy;
+  memset(&dummy, 0, sizeof(dummy));
+  dummy.eps = eps;
+  const bear_step_io io = ws_io(ws, theta, BEAR_THETA_NET, packed);
+  launch_linear(ws, plan, kmer_code, theta + 1, lag, dummy, train_ar, io, packed + 2, s,
+                make_apply(theta, 1 + lag * 25, adam_m, adam_v, adam_t, learning_rate, scale, train_ar, loss_buf, loss_cap));
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
 }
 
 static int launch_eval(bear_ws *ws, const uint32_t *test, const uint32_t *train, const double *prior, uint64_t n_rows,
@@ -1528,9 +1585,6 @@ int bear_eval_plan_f64(bear_ws *ws, const bear_eval_plan *plan, const uint32_t *
       S.slot[2 * EVS_CHUNK + 1] = n_models + 1 + A.n_h;
       S.slot[2 * EVS_CHUNK + 2] = 2 * n_models + 2;
     }
-#ifdef EVP_DEBUG_SWITCHES
-    if (const char *dbgs = getenv("BEAR_EVP_DEBUG")) common |= atoi(dbgs) << 4;
-#endif
 #define EVP_LAUNCH(NH_, NV_)                                                                                                        \
   hipLaunchKernelGGL((eval_plan_kernel<NH_, NV_>), dim3(grid), dim3(EVP_THREADS), sizeof(evp_lds), s, test, train, prior, row_ids, n_rows, A, \
                      h0, nh, v0, nv, common, plan->items, plan->tile_info, plan->consts, nt, lt, ws->eval_partials EVP_DBG_ARG)

@@ -335,10 +335,6 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
   evp_lds &S = *reinterpret_cast<evp_lds *>(srt_smem);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = srt_uniform(tid >> 6);
   const double eps = A.eps, sig_dm = 100.0 * A.eps;
-#ifdef EVP_DEBUG_SWITCHES
-  const int dbg_flags = do_common >> 4;   // developer build: 2 = no tie units, 4 = no cell units, 8 = no H units, 16 = no V units
-  do_common &= 15;
-#endif
   double accH_ll[NHA], accH_cor[NHA], accV_ll[NVA], accV_cor[NVA], acc_arm = 0.0, acc_carm = 0.0, acc_tot = 0.0;
 #pragma unroll
   for (int k = 0; k < NHA; ++k) accH_ll[k] = accH_cor[k] = 0.0;
@@ -479,9 +475,6 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
           // ---- tie unit: 64 rows whose largest training counts tie, ONE vanilla model: the noise decides among the TIED letters
           //      (the others are a whole count below the top: 17.5 sigma = 1750 eps cannot bridge that, bear_eval_plan_f64 checks).
           //      The plan lists the rows with the most tied letters first, so the rounds of a unit are (nearly) wave-uniform.
-#ifdef EVP_DEBUG_SWITCHES
-          if (dbg_flags & 2) continue;
-#endif
           const uint32_t km = w / n_ku, un = w - km * n_ku;            // model of the launch, unit of the list
           const uint32_t ent = B.items[tie_base + un * 64u + lane];
           const uint32_t row = ent & 511u, top_mask = ent >> 9;      // (padding: EVP_SENT_ROW with no letter)
@@ -531,9 +524,6 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
         if (w < w_h) {
           // ---- H unit: 64 rows with test transitions, largest totals first: the AR model's and the BEAR models' arg-max,
           //      the BEAR models' -D(A, n)
-#ifdef EVP_DEBUG_SWITCHES
-          if (dbg_flags & 8) continue;
-#endif
           const uint32_t un = n_tu - 1u - (w - w_t);
           const uint32_t row = B.items[tot_base + un * 64u + lane];
           uint32_t t[5], r[5];
@@ -619,9 +609,6 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
           // ---- V unit: 64 rows with test transitions whose totals leave the vanilla models' tables (N_r + n >= EVP_TABK; every
           //      row of a dense table, hardly any of a k-mer table): -D(N_r + 5 (v + eps), n) by the general routine.  Their
           //      arg-max is in the plan's constants (unique largest training count) or a tie unit's.
-#ifdef EVP_DEBUG_SWITCHES
-          if (dbg_flags & 16) continue;
-#endif
           const uint32_t row = B.items[vr_base + (w - w_h) * 64u + lane];
           double n = 0.0, Nr = 0.0;
 #pragma unroll
@@ -642,9 +629,6 @@ __global__ __launch_bounds__(EVP_THREADS) void eval_plan_kernel(const uint32_t *
           continue;
         }
         // ---- a unit of 64 cells, largest counts first
-#ifdef EVP_DEBUG_SWITCHES
-        if (dbg_flags & 4) continue;
-#endif
         const uint32_t un = n_cu - 1u - (w - w_v);
         const uint32_t idx = B.items[un * 64u + lane];
         const uint32_t c = B.tst[idx], ru = B.trn[idx];

@@ -32,10 +32,6 @@
 #pragma once
 #include "kernels_plan.h"
 #include <type_traits>
-#ifndef LIN_DBG
-#define LIN_DBG 0   // developer cut-offs of phase C (results are then meaningless)
-#endif
-
 #ifndef LIN_MAX_LAG
 #define LIN_MAX_LAG 21
 #endif
@@ -474,13 +470,6 @@ __device__ __forceinline__ void lin_row2(const double *T, const double *exptab, 
 #pragma unroll
     for (int j = 0; j < CH; ++j)
       if (g0 + j < NP) {
-#ifdef LIN_FAKE_SHARED_ROWS   // developer build (timing only): what do the table reads of the leading pair groups cost?  (no reads: constants)
-        if (g0 + j < NP - 1) {
-          lo[j] = make_double2(1.0 + 1e-9 * (double)(cw & 1ull), 1.0);
-          hi[j] = make_double2(1.0, 1.0);
-          continue;
-        }
-#endif
         const double2 *t = reinterpret_cast<const double2 *>(T + lin_off<NG>(cw, g0 + j));
         lo[j] = t[0];
         hi[j] = t[1];
@@ -507,16 +496,9 @@ __device__ __forceinline__ void lin_row2(const double *T, const double *exptab, 
       }
     if (g0 + CH < NP) asm("" : "+v"(cw) : "v"(e[0]));     // as in lin_row: the next rows' addresses wait for this product
   }
-#ifdef LIN_FAKE_T_ROWS   // developer build (timing only): the triple's table rows of a wave on consecutive rows (1) / one row for all lanes (2)
-  const uint32_t fake_row = LIN_FAKE_T_ROWS == 1 ? (threadIdx.x & 63u) : 0u;
-  const double2 *t0 = reinterpret_cast<const double2 *>(T + (NG - 1) * LIN_PSTRIDE + fake_row * 4u);
-  const double2 *t1 = reinterpret_cast<const double2 *>(T + (NG - 1) * LIN_PSTRIDE + (fake_row + 64u) * 4u);
-  const double2 a0 = t0[0], b0 = t0[1], a1 = t1[0], b1 = t1[1];
-#else
   double2 a0, b0, a1, b1;
   lin_table_row<NG>(T, c0, NG - 1, a0, b0);
   lin_table_row<NG>(T, c1, NG - 1, a1, b1);
-#endif
   if (EXP) {
     const double x0[4] = {e[0] * a0.x, e[1] * a0.y, e[2] * b0.x, e[3] * b0.y};
     const double x1[4] = {e[0] * a1.x, e[1] * a1.y, e[2] * b1.x, e[3] * b1.y};
@@ -693,11 +675,7 @@ __device__ __forceinline__ uint32_t lin_phase_a(pln_lds_lin &S, const lin_buf &B
 __device__ __forceinline__ void lin_phase_a_store(pln_lds_lin &S, const double (&fA)[LIN_RPT][5], uint32_t rows) {
 #pragma unroll
   for (int k = 0; k < LIN_RPT; ++k) {
-#ifdef LIN_FAKE_PRI_ROWS   // developer build (timing only): the softmax rows of a wave on consecutive rows (no bank conflicts)
-    const uint32_t row = ((rows >> (16 * k)) & 0xffffu) == 0xffffu ? 0xffffu : (threadIdx.x * 2u + (uint32_t)k) % PLN_RMAX;
-#else
     const uint32_t row = (rows >> (16 * k)) & 0xffffu;
-#endif
     if (row != 0xffffu) {
 #pragma unroll
       for (int b = 0; b < 5; ++b) S.pri[row * 5 + b] = fA[k][b];
@@ -719,12 +697,7 @@ __device__ __forceinline__ uint32_t lin_phase_a_paired(pln_lds_lin &S, const lin
     const uint32_t r0 = rows & 0xffffu, r1 = rows >> 16;              // (plan_pair_kernel: an empty entry only ever sits in the odd slot)
     cA[0] = B.codes[r0];
     cA[1] = B.codes[r1 != LIN_EMPTY ? r1 : r0];                       // (both reads in flight: a read behind a branch waited for the first)
-#ifdef LIN_SKIP_A_ROWS   // developer build (timing only): no table reads, no softmax
-#pragma unroll
-    for (int b = 0; b < 5; ++b) fA[0][b] = fA[1][b] = 0.2 + 1e-12 * (double)(uint32_t)cA[b & 1];
-#else
     lin_row2<NG, EXP>(S.T, S.exptab, cA[0], cA[1], fA[0], fA[1]);
-#endif
   }
   return rows;
 }
@@ -785,27 +758,17 @@ __device__ __forceinline__ void lin_scatter_grad(double *GT, unsigned long long 
   const uint32_t l_wave = wave_or ? min((uint32_t)(__builtin_ctzll(wave_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG;
   const uint32_t l_row = row_or ? min((uint32_t)(__builtin_ctzll(row_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG;   // >= l_wave
   const uint32_t l_quad = quad_or ? min((uint32_t)(__builtin_ctzll(quad_or) * 43) >> 8, (uint32_t)NG - 1u) : (uint32_t)NG; // >= l_row
-#if LIN_DBG == 1
-  acc[1] += (double)tw * 1e-300 + (double)th * 1e-300 + (double)l_row * 1e-300;
-  return;
-#endif
   // 1. the groups the whole wave shares
   {
     const uint32_t gq = lane >> 2;
     if (gq < l_wave && tw != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, gq, NG) >> 2)], tw);
   }
-#if LIN_DBG == 2
-  return;
-#endif
   if (l_wave == (uint32_t)NG) return;
   // 2. the next (up to four) groups, shared by a row of 16: slot s of the row takes group l_wave + s
   {
     const uint32_t pick = l_wave + ((lane & 15u) >> 2);
     if (pick < l_row && th != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
   }
-#if LIN_DBG == 4
-  return;
-#endif
   // 2b. the first group a row does NOT share, where my quad still does: in a sorted table a row of 16 that straddles two prefix
   //     blocks has one such group (the last pair), and per context its adds hit ONE address with eight lanes at a time (LDS
   //     atomics on one address serialise).  Lane (quad, letter) adds the quad's sum instead; only the quad on the boundary is
@@ -818,12 +781,6 @@ __device__ __forceinline__ void lin_scatter_grad(double *GT, unsigned long long 
 #pragma unroll
   for (int gq = 0; gq < NG; ++gq) {
     if ((uint32_t)gq < l_wave) continue;                   // wave-uniform test
-#ifdef LIN_SKIP_TRIPLE   // developer build (timing only): what do the triple's per-context adds cost?
-    if (gq == NG - 1) continue;
-#endif
-#ifdef LIN_SKIP_PAIRS3   // developer build (timing only): ... and those of every other group?
-    if (gq != NG - 1) continue;
-#endif
     const bool mine = nz && ((uint32_t)gq >= l_row || (uint32_t)gq >= l_wave + 4u) && !(quad_covers && (uint32_t)gq == l_row);
     if (!__builtin_amdgcn_ballot_w64(mine)) continue;
     if (mine) {
@@ -839,9 +796,6 @@ template <int NG, bool DET>
 __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uint32_t tid, uint32_t lane_in, const double (&fA)[LIN_RPT][5],
                                             const unsigned long long (&cA)[LIN_RPT], uint32_t rowA, double (&acc)[2], double gt_scale) {
   uint32_t lane = lane_in;
-#ifdef LIN_SKIP_C
-  return;
-#endif
 #pragma unroll
   for (int k = 0; k < LIN_RPT; ++k) {
     const uint32_t j0 = (tid & ~63u) + LIN_ROW_THREADS * k;  // first of this wave's 64 consecutive list entries
@@ -959,18 +913,6 @@ __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned lon
     }
   }
   // the triple rows: one add per context and letter
-#ifdef LIN_SKIP_TRIPLE   // developer build (timing only)
-  return;
-#endif
-#ifdef LIN_FAKE_TRIPLE_ROWS   // developer build (timing only): the triple's adds without bank or address conflicts (lane = row)
-  {   // 1: row = lane; 2: lane % 32 (pairs of equal rows, one per half-wave); 3: lane / 2 (adjacent pairs); 4: lane % 16; 5: lane % 8; 6, 7: below
-    const uint32_t fr = LIN_FAKE_TRIPLE_ROWS == 1 ? lane : LIN_FAKE_TRIPLE_ROWS == 2 ? lane % 32u : LIN_FAKE_TRIPLE_ROWS == 3 ? lane / 2u
-                        : LIN_FAKE_TRIPLE_ROWS == 4 ? lane % 16u : LIN_FAKE_TRIPLE_ROWS == 5 ? lane % 8u
-                        : LIN_FAKE_TRIPLE_ROWS == 6 ? (lane & 7u) + 16u * ((lane >> 3) & 1u)        // 6: two ROWS per bank pair in every pass of 16 lanes
-                        : (lane & 7u) + 16u * ((lane >> 3) & 7u);                                   // 7: ... all rows distinct (lanes 8 apart share a bank pair)
-    c0 = c1 = (unsigned long long)fr << (6 * (NG - 1));
-  }
-#endif
   // (two copies of one k-mer in a lane -- the builder pairs them -- are one row: their sum goes up once)
   const bool twin = nz1 && c1 == c0;
   if (nz0 || twin) {
@@ -994,9 +936,6 @@ __device__ __forceinline__ void lin_phase_c_paired(pln_lds_lin &S, uint32_t n_en
                                                    const double (&fA)[LIN_RPT][5], const unsigned long long (&cA)[LIN_RPT], uint32_t rowA,
                                                    double gt_scale) {
   uint32_t lane = lane_in;
-#ifdef LIN_SKIP_C
-  return;
-#endif
   const uint32_t j0 = 2u * (tid & ~63u);                      // first entry of this wave's 64 pairs
   if (tid >= LIN_ROW_THREADS || j0 >= n_ent) return;          // wave-uniform
   asm volatile("" : "+v"(lane));
@@ -1004,11 +943,7 @@ __device__ __forceinline__ void lin_phase_c_paired(pln_lds_lin &S, uint32_t n_en
   bool nz[2] = {false, false};
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-#ifdef LIN_FAKE_PRI_ROWS
-    const uint32_t row = ((rowA >> (16 * k)) & 0xffffu) == LIN_EMPTY ? LIN_EMPTY : (tid * 2u + (uint32_t)k) % PLN_RMAX;
-#else
     const uint32_t row = (rowA >> (16 * k)) & 0xffffu;
-#endif
     if (row != LIN_EMPTY) {
       double w[5], sw = 0.0;
 #pragma unroll
@@ -1031,10 +966,6 @@ __device__ __forceinline__ void lin_phase_c_paired(pln_lds_lin &S, uint32_t n_en
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cA[0], (int)last), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cA[0] >> 32), (int)last);
     if (lane > last) c0 = c1 = ((unsigned long long)hi << 32) | lo;
   }
-#ifdef LIN_SKIP_SCATTER   // developer build (timing only): read-back and g only
-  if (g[0][0] + g[1][0] + g[0][1] + g[1][1] + g[0][2] + g[1][2] + g[0][3] + g[1][3] == 12345.678) S.GT[lane] = 1.0;
-  return;
-#endif
   if (DET) {
     lin_fx gi[2][4];
 #pragma unroll
@@ -1189,7 +1120,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     const unsigned long long *__restrict__ kmer_code, const double *__restrict__ mat, int lag, bear_params prm_arg, pln_view pv,
     const double2 *__restrict__ logtab_g, double *__restrict__ partials, double *__restrict__ grad_partials,
     const bear_step_io io, double *__restrict__ grad_out, int accumulate,    // accumulate: add to io.out / grad_out (second launch of a step)
-    const lin_fx_bound gt_bound) {
+    const lin_fx_bound gt_bound, const bear_apply_io apply) {   // apply.theta != NULL: the Adam update by the last block (grad_out == io.out + 2)
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_lin &S = *reinterpret_cast<pln_lds_lin *>(srt_smem);
   const bear_params prm = bear_params_of(prm_arg, io);   // device-resident parameters: constants derived in the prologue
@@ -1279,9 +1210,6 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     const uint32_t rows = ti.rows_items >> 16;
     n_live = rows ? srt_uniform((uint32_t)B.live[0]) : 0u;
     rowA = 0xffffffffu;
-#ifdef LIN_SKIP_A
-    return;
-#endif
     if (PAIRED) {
       LIN_FOR_NG(ng, rowA = (lin_phase_a_paired<NG, EXP>(S, B, n_live, tid, fA, cA)))
     } else {
@@ -1334,29 +1262,8 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
       if (cnt != 0.0) S.pri[off] = -(fb * q);
     };
     const uint32_t n_hcu = (hc + 63u) >> 6, n_hru = AR ? 0u : (hr + 63u) >> 6, n_units = (n_light + 63u) >> 6;
-#ifdef LIN_SKIP_B
-    const uint32_t n_work = 0u * (n_hcu + n_hru + n_units);
-#else
     const uint32_t n_work = n_hcu + n_hru + n_units;
-#endif
-#ifdef LIN_MIX   // developer build (timing only, results meaningless): half of the waves do their row work (C, A) before the items,
-                 // the other half after half of the items, no synchronisation inside an iteration -- how much would a kernel gain
-                 // whose LDS-bound and VALU-bound parts overlap instead of alternating?
-    auto rows_work = [&]() {
-      phase_c();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      phase_a(S.buf[slot ^ 1u], nxt);
-    };
-    bool rows_done = (wave & 1u) != 0u;
-    if (rows_done) rows_work();
-#endif
     PLN_FOR_UNITS_F(w, &S.ticket[slot], n_work, wave, PLN_WAVES) {
-#ifdef LIN_MIX
-      if (!rows_done && w >= n_work / 2u) {
-        rows_done = true;
-        rows_work();
-      }
-#endif
       if (w < n_hcu) {
         const uint32_t i = w * 64u + lane;
         if (i < hc) {
@@ -1381,26 +1288,16 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
       const uint32_t un = n_work - 1u - w;
       uint32_t cmin, cmax;
       const uint32_t ci[1] = {pln_unit_counts(E, n_light, un, lane, &cmin, &cmax)};
-#ifdef LIN_FAKE_ITEM_OFFS   // developer build (timing only): the items' cells without bank conflicts (64 consecutive cells per unit)
-      const uint32_t off_true = items[un * 64u + lane];
-      const uint32_t off = off_true == (uint32_t)PLN_SENTINEL ? off_true : (un * 64u + lane) % (rows * 5u);
-#else
       const uint32_t off = items[un * 64u + lane];
-#endif
       const double x[1] = {__builtin_fma(S.pri[off], u, eps)};
       bear_dp o[1] = {{0.0, 0.0}};
       if (!AR) srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
       if (off != (uint32_t)PLN_SENTINEL) item(off, o[0].D, o[0].P, x[0], (double)ci[0]);
     }
-#ifdef LIN_MIX
-    if (!rows_done) rows_work();
-#endif
     LIN_STAMP(0)     // B: items
     srt_wait_dma();  // the next tile's codes and plan block (issued a whole iteration ago)
     LIN_STAMP(1)     // wait for the DMA
-#if !defined(LIN_NOSYNC) && !defined(LIN_MIX)   // developer build (timing only, results meaningless): the waves run free of each other
     srt_sync();      // ... and every item of this tile has left its mark: nobody reads this tile's buffers any more
-#endif
     LIN_STAMP(2)     // barrier after the items
     cur = nxt;
     nxt = read_desc((iter + 2u) & 3u);    // landed an iteration ago; this block's DMA wave has waited for it, the barrier published it
@@ -1409,23 +1306,17 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     ++iter;
     // ---- C of this tile (rows, index words and softmax rows from phase A's registers), A of the next
     LIN_STAMP(3)     // staging the tile after next
-#ifndef LIN_MIX
     phase_c();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my reads of this tile's LDS rows have returned
     LIN_STAMP(4)     // C
     if (lane == 0) atomicAdd(&S.c_done, 1u);
     c_target += PLN_WAVES;
     phase_a(S.buf[slot ^ 1u], cur);
-#endif
     LIN_STAMP(5)     // A (compute)
-#if !defined(LIN_NOSYNC) && !defined(LIN_MIX)
     while (pln_peek(&S.c_done) < c_target) __builtin_amdgcn_s_sleep(1);   // every wave has: the rows may be overwritten
-#endif
     LIN_STAMP(6)     // wait for the other waves' read-backs
     lin_phase_a_store(S, fA, rowA);
-#ifndef LIN_NOSYNC
     srt_sync();      // the next tile's rows are in place for its items
-#endif
     LIN_STAMP(7)     // row stores + barrier
     slot ^= 1u;
   }
@@ -1434,13 +1325,8 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     for (int k = 0; k < 8; ++k) atomicAdd(&lin_stamp_sums[k], tph[k]);
 #endif
   };
-#ifdef LIN_ONLY_EXP   // developer builds: one form only
-  if (LIN_ONLY_EXP) tile_loop(std::true_type{});
-  else tile_loop(std::false_type{});
-#else
   if (exp_tables) tile_loop(std::true_type{});
   else tile_loop(std::false_type{});
-#endif
   srt_wait_dma();
   __syncthreads();
   // ---- items / contexts that overflowed to the plan's global lists (very dense tiles): self-contained
@@ -1499,6 +1385,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
   lin_sum_block_partials<DET>(grad_partials, lag * 25, reinterpret_cast<double *>(srt_smem), (int)tid, PLN_THREADS, grad_out, accumulate != 0,
                               DET ? 1.0 / gt_scale : 1.0);   // the tile loop is over: the dynamic LDS is free
   bear_finalize_in_block(partials, 2, io.out, io.arrive(), accumulate != 0);
+  bear_apply_in_block(apply, io.out);
 }
 
 // ---- the bear_net / linear optimizer step on the device (HIP-graph replay) ---------------------------------------
@@ -1506,27 +1393,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
 // vector with gradients grad[k] * scale (k = 0: d/dh from out[1], skipped in AR mode; k >= 1: d/d mat).
 // ONE block: every thread reads the step counter before the barrier and thread 0 advances it after it, so the update and the
 // tick are a single launch (a step is launch-bound on small shards: scripts/dev/step_latency.py).
-__global__ __launch_bounds__(1024) void adam_vec_kernel(double *__restrict__ theta, const double *__restrict__ out2,
-                                                        const double *__restrict__ grad_rest, int n_rest, double *__restrict__ m,
-                                                        double *__restrict__ v, double *__restrict__ t_state, double lr,
-                                                        double scale, int train_ar, double *__restrict__ loss_buf,
-                                                        unsigned long long loss_cap) {
-  const double t0 = t_state[0], t = t0 + 1.0;
-  const double b1 = 0.9, b2 = 0.999, aeps = 1e-7;
-  const double lr_t = lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t));
-  for (int k = threadIdx.x; k <= n_rest; k += 1024) {
-    if (train_ar && k == 0) continue;
-    const double g = scale * (k == 0 ? out2[1] : grad_rest[k - 1]);
-    const double mk = b1 * m[k] + (1.0 - b1) * g, vk = b2 * v[k] + (1.0 - b2) * g * g;
-    m[k] = mk;
-    v[k] = vk;
-    theta[k] -= lr_t * mk / (sqrt(vk) + aeps);
-  }
-  if (threadIdx.x == 0) {
-    const unsigned long long step = (unsigned long long)t0;
-    if (loss_buf && step < loss_cap) loss_buf[step] = -scale * out2[0];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) t_state[0] = t;
+__global__ __launch_bounds__(1024) void adam_vec_kernel(const bear_apply_io A, const double *__restrict__ packed) {
+  bear_adam_update(A, packed, (int)threadIdx.x, 1024);
 }
 

@@ -913,11 +913,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_prior_plan_kernel(const dou
     // Waves draw tickets until the list is exhausted.
     const uint32_t n_hcu = (hc + 63u) >> 6, n_hru = AR ? 0u : (hr + 63u) >> 6, n_heavy = n_hcu + n_hru;
     const uint32_t n_units = (n_light + 63u) >> 6;
-#ifdef PLN_NOWORK
-    const uint32_t n_work = 0;
-#else
     const uint32_t n_work = n_heavy + n_units + ((NORM || AR) ? 0u : (rows + PLN_CHUNK - 1u) / PLN_CHUNK);
-#endif
     PLN_FOR_UNITS_F(w, &S.ticket[slot], n_work, wave, PLN_WAVES - PLN_DMA_WAVES) {      // (the DMA waves never get here)
 #ifdef PLN_STAMPS
       {
@@ -1082,7 +1078,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_ref_plan_kernel(const uint3
                                                                                   pln_view pv,
                                                                                   const double2 *__restrict__ logtab_g,
                                                                                   double *__restrict__ partials,
-                                                                                  const bear_step_io io) {
+                                                                                  const bear_step_io io, const bear_apply_io apply) {
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_r &S = *reinterpret_cast<pln_lds_r *>(srt_smem);
   // parameters by value, or -- for a step that is replayed from a HIP graph while the optimizer moves them -- from device memory
@@ -1197,11 +1193,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_ref_plan_kernel(const uint3
     // context: their sums over the table are the plan's histograms times two small tables (added
     // once, after the loop).  Per tile only the column items b < 4 remain; waves draw units, dearest first.
     const uint32_t n_hcu = (hc + 63u) >> 6;
-#ifdef PLN_NOWORK
-    const uint32_t n_units = 0u * n_light;
-#else
     const uint32_t n_units = (n_light + 63u) >> 6;
-#endif
     PLN_FOR_UNITS_F(w, &S.ticket[slot], n_hcu + n_units, wave, CWAVES) {      // (compute waves only)
       if (w < n_hcu) {  // large-count column items of this tile (Stirling path), first
         const uint32_t i = w * 64u + lane;
@@ -1260,7 +1252,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_ref_plan_kernel(const uint3
     acc[0] = __builtin_fma(c4sum, bear_log_tab(p4, S.logtab), acc[0]);
     acc[3] = __builtin_fma(c4sum * bear_rcp(p4), nwV * (1.0 - f4), acc[3]);  // d f_4 / d nu_s = nw V (1 - f_4)
     __syncthreads();
-    block_finish<4>(acc, partials, io);
+    block_finish<4>(acc, partials, io, apply);
     return;
   }
   for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
@@ -1284,7 +1276,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_ref_plan_kernel(const uint3
     acc[3] = __builtin_fma(VU * nwV, P4, acc[3]);                 // d alpha_4/d nu_s = u nw V^2
   }
   __syncthreads();
-  block_finish<4>(acc, partials, io);
+  block_finish<4>(acc, partials, io, apply);
 }
 
 // ---- mode N with gradient rows --------------------------------------------------------------

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void rpl_build_kernel(const uint32_t *__restri
 // AR: multinomial mode of bear_ref (train_ar): sum LL = sum c log(f + eps); gradients w.r.t. tau_s, nu_s only.
 template <bool AR>
 __global__ __launch_bounds__(256) void dm_ref_items_kernel(bear_params prm_arg, rpl_view rv, pln_view pv, const double2 *__restrict__ logtab_g,
-                                                           double *__restrict__ partials, const bear_step_io io) {
+                                                           double *__restrict__ partials, const bear_step_io io, const bear_apply_io apply) {
   __shared__ double2 s_log[BEAR_LOGTAB_N];
   const bear_params prm = bear_params_of(prm_arg, io);
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void dm_ref_items_kernel(bear_params prm_arg, 
     acc[0] = __builtin_fma(c4sum, bear_log_tab(p4, s_log), acc[0]);
     acc[3] = __builtin_fma(c4sum * bear_rcp(p4), nwV * (1.0 - f4), acc[3]);  // d f_4 / d nu_s = nw V (1 - f_4)
     __syncthreads();
-    block_finish<4>(acc, partials, io);
+    block_finish<4>(acc, partials, io, apply);
     return;
   }
   const double x0 = alpha_from(0.0, R0);
@@ -228,5 +228,5 @@ __global__ __launch_bounds__(256) void dm_ref_items_kernel(bear_params prm_arg, 
     acc[3] = __builtin_fma(VU * nwV, P4, acc[3]);                 // d alpha_4/d nu_s = u nw V^2
   }
   __syncthreads();
-  block_finish<4>(acc, partials, io);
+  block_finish<4>(acc, partials, io, apply);
 }

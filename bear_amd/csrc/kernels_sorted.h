@@ -134,25 +134,24 @@ __device__ __forceinline__ void srt_light(const double (&x)[ILP], const uint32_t
     dp[i] = 0.0;
     t[i] = x[i];
   }
+  // One factor: dp = dp t + p, p = p t, t = t + 1 -- three VOP3 instructions, spelled out: left to itself the compiler forms the
+  // first as v_fmac (accumulator = a COPY of p) and shuffles the pairs around it, five instructions per factor instead of three;
+  // under predication it turned the three results into six v_cndmask instead of masking the lanes (-ffp-contract=off: the same
+  // three roundings either way).
+#define SRT_FACTOR(dp, p, t) \
+  asm("v_fma_f64 %0, %0, %2, %1\n\tv_mul_f64 %1, %1, %2\n\tv_add_f64 %2, %2, 1.0" : "+v"(dp), "+v"(p), "+v"(t))
   uint32_t j = 0;
   for (; j < cmin; ++j) {
 #pragma unroll
-    for (int i = 0; i < ILP; ++i) {
-      dp[i] = __builtin_fma(dp[i], t[i], p[i]);
-      p[i] *= t[i];
-      t[i] += 1.0;
-    }
+    for (int i = 0; i < ILP; ++i) SRT_FACTOR(dp[i], p[i], t[i]);
   }
   for (; j < cmax; ++j) {
 #pragma unroll
     for (int i = 0; i < ILP; ++i) {
-      if (j < c[i]) {
-        dp[i] = __builtin_fma(dp[i], t[i], p[i]);
-        p[i] *= t[i];
-        t[i] += 1.0;
-      }
+      if (j < c[i]) SRT_FACTOR(dp[i], p[i], t[i]);
     }
   }
+#undef SRT_FACTOR
   bool odd = false;
 #pragma unroll
   for (int i = 0; i < ILP; ++i) {

@@ -460,18 +460,28 @@ def main():
                     "the headline's rows are softmax outputs (every reference AR function) and take the shared-A table"}
         lag = 13
         mat = 0.05 * torch.randn(lag, 5, 5, dtype=torch.float64, device=dev, generator=torch.Generator(dev).manual_seed(10))
-        codes = torch.randint(0, 4, (n, lag), dtype=torch.int8, device=dev, generator=torch.Generator(dev).manual_seed(SEED))
-        packed_raw = kernels.pack_kmers(codes)          # 3 bits per letter: what the convolutional head reads
-        packed = kernels.linear_index(packed_raw, lag)   # table-row words: what the linear head reads
+        # ---- the AR-function entries (fused linear head, linear rows, convolutional head) run on a table of DISTINCT contexts: row
+        # index -> a fixed bijection of [0, 4^13) (kernels.synth_kmer_ids).  Only 4^13 = 6.7e7 13-mers exist, so the k = 13
+        # table of these entries is the first 6.0e7 rows of the synthetic table (every entry states its contexts and a
+        # per-1e8-contexts figure); rounds 1-5 drew 1e8 13-mers WITH replacement (28 % of the k-mers with counts occurred twice or
+        # more: no count table looks like that, summarize.py:429-449) -- that figure stays one more round as `..._with_replacement`.
+        n_all, n = n, min(n, 60_000_000)
+        per_1e8 = 1e8 / n
+        train_all, ref_all, prior_all, plan_all = t["train"], t["ref"], prior, plans["net"]
+        t = dict(t, train=t["train"][:n], ref=t["ref"][:n])
+        prior = prior[:n]
+        plans = dict(plans, net=plan_all if n == n_all else kernels.Plan(t["train"], 5))
+        ids = kernels.synth_kmer_ids(SEED, 0, n, lag, dev)
+        shifts = torch.arange(2 * (lag - 1), -1, -2, dtype=torch.int64, device=dev)
+        to_codes = lambda v: ((v[:, None] >> shifts[None, :]) & 3).to(torch.int8).contiguous()
+        packed_raw = kernels.pack_kmers(to_codes(ids))      # 3 bits per letter, table order: what the convolutional head reads
+        packed = kernels.linear_index(packed_raw, lag)      # table-row words: what the linear head reads
         ms_shuffled = timed(lambda: kernels.dm_linear(plans["net"], packed, mat, h_s), 5)
         # bear_net.train sorts the rows of a batch by k-mer at upload; the synthetic counts are independent of the contexts, so
         # sorting the contexts alone gives the same kind of table in that order
-        key = torch.zeros(n, dtype=torch.int64, device=dev)
-        for l in range(lag):
-            key = key * 6 + codes[:, l].to(torch.int64)
-        packed_sorted_raw = kernels.pack_kmers(codes[torch.argsort(key)].contiguous())
+        packed_sorted_raw = kernels.pack_kmers(to_codes(torch.sort(ids).values))
         packed = kernels.linear_index(packed_sorted_raw, lag)
-        del key, codes
+        del ids
         ms_plain = timed(lambda: kernels.dm_linear(plans["net"], packed, mat, h_s), 5)
         plain_out = [x.clone() for x in kernels.dm_linear(plans["net"], packed, mat, h_s)]
         # ... and as bear_net.train runs it on a sorted batch: neighbouring contexts that share all letters but the last three
@@ -482,7 +492,8 @@ def main():
         lin_same = bool(torch.allclose(paired_out[0], plain_out[0], rtol=1e-12, atol=0)
                         and float((paired_out[1] - plain_out[1]).abs().max()) <= 1e-10 * float(plain_out[1].abs().max()))
         del packed, plain_out, paired_out
-        extra["linear_head_fused_step"] = {"lag": lag, "kernel_ms": ms, "contexts_per_s": n / (ms * 1e-3),
+        extra["linear_head_fused_step"] = {"lag": lag, "contexts": n, "kmers": "distinct (bijection of the row index)",
+                                           "kernel_ms": ms, "kernel_ms_per_1e8_contexts": ms * per_1e8, "contexts_per_s": n / (ms * 1e-3),
                                            "paired_contexts": lin_paired, "paired_equals_plain": lin_same,
                                            "paired_tiles_and_plain_tiles": list(plans["net"].pair_info()),
                                            "kernel_ms_plain_lists": ms_plain,
@@ -566,14 +577,11 @@ def main():
         del pk_plain
         # the gradient-row kernel as bear_net.train runs it for an AR function made of torch ops: on the kept table (every row holds
         # counts, so no gradient row of zeros is written and no prior row of a context without counts is read)
-        pr_kept = prior.index_select(0, keep).contiguous()
-        grad_kept_ms = timed(lambda: kernels.dm_prior_planned(plan_kept, pr_kept, h_s, want_grad=True, normalized=True), 5)
-        del pr_kept
         lin_kept = kernels.linear_index(packed_kept, lag)
         plan_kept.pair_contexts(lin_kept, lag)
         lin_k_ms = timed(lambda: kernels.dm_linear(plan_kept, lin_kept, mat, h_s), 5)
         extra["linear_head_fused_step"]["kernel_ms_as_bear_net_train_holds_the_batch"] = lin_k_ms
-        extra["net_with_gradient_rows"]["kernel_ms_as_bear_net_train_holds_the_batch"] = grad_kept_ms
+        extra["linear_head_fused_step"]["kernel_ms_per_1e8_contexts_as_bear_net_train_holds_the_batch"] = lin_k_ms * per_1e8
         kept_frac = keep.numel() / n
         del keep, tr_kept, packed_kept, plan_kept, bufs_kept, lin_kept
         cnn_f, cnn_b = flops_cnn(lag, fw)
@@ -587,7 +595,9 @@ def main():
         n_win = [sum(1 for w in window_tables if w[0] == k) for k in range(len(lv))]
         pos_evals = sum(r * (ll[k] - ll[k + 1] - n_win[k]) for k, r in enumerate(lv)) + sum(w[2] for w in window_tables)
         exec_f = pos_evals * pos_f + n_kept * head_f
-        extra["cnn_head"] = {"lag": lag, "filter_width": fw, "forward_ms": f_ms, "backward_ms": b_ms,
+        extra["cnn_head"] = {"lag": lag, "filter_width": fw, "contexts": n, "kmers": "distinct (bijection of the row index)",
+                             "train_step_ms_per_1e8_contexts_as_bear_net_train_holds_the_batch": kept_ms * per_1e8,
+                             "forward_ms": f_ms, "backward_ms": b_ms,
                              "rates_forward_rows_in_kmer_order": cnn_rates(cnn_f * n, None, fs_ms),
                              "rates_backward_rows_in_kmer_order": cnn_rates(cnn_b * n, None, bs_ms),
                              "roofline_forward_rows_in_random_order": fp64_roofline(cnn_f * n, f_ms),
@@ -619,6 +629,38 @@ def main():
                                      "1e8).  rates_*: credited flops / time is an algorithmic speed, not a utilisation (sorted-order kernels skip shared "
                                      "work); frac_of_fp64_peak only where the executed flops are counted"}
         del packed, packed_raw, packed_sorted_raw, bufs, pk, theta
+        # ... the fused linear head once more on rounds 1-5's table (1e8 13-mers drawn with replacement, sorted, paired) and on 1e8
+        # DISTINCT 14-mers (density 0.37 of all 14-mers: a block of equal leading letters holds 24 of its 64 contexts, not 57)
+        if n_all > n:
+            for label, lag_x, draw in (("with_replacement", 13, True), ("k14_distinct", 14, False)):
+                if draw:
+                    c = torch.randint(0, 4, (n_all, lag_x), dtype=torch.int8, device=dev, generator=torch.Generator(dev).manual_seed(SEED))
+                    key = torch.zeros(n_all, dtype=torch.int64, device=dev)
+                    for l in range(lag_x):
+                        key = key * 4 + c[:, l].to(torch.int64)
+                    c = c[torch.argsort(key)].contiguous()
+                    del key
+                else:
+                    c = kernels.synth_kmer_codes(SEED, 0, n_all, lag_x, dev, sort=True)
+                idx = kernels.linear_index(kernels.pack_kmers(c), lag_x)
+                del c
+                mat_x = 0.05 * torch.randn(lag_x, 5, 5, dtype=torch.float64, device=dev, generator=torch.Generator(dev).manual_seed(10))
+                paired_x = plan_all.pair_contexts(idx, lag_x)
+                ms_x = timed(lambda: kernels.dm_linear(plan_all, idx, mat_x, h_s), 5)
+                extra["linear_head_fused_step"]["kernel_ms_1e8_contexts_" + label] = ms_x
+                extra["linear_head_fused_step"]["paired_" + label] = paired_x
+                del idx
+            torch.cuda.empty_cache()
+        t, prior, plans, n = dict(t, train=train_all, ref=ref_all), prior_all, dict(plans, net=plan_all), n_all
+        del train_all, ref_all, prior_all, plan_all
+        # the gradient-row kernel as bear_net.train runs it for an AR function made of torch ops: on the kept table (every row holds
+        # counts, so no gradient row of zeros is written and no prior row of a context without counts is read) -- of all n rows
+        keep = (t["train"] != 0).any(dim=1).nonzero().squeeze(1)
+        tr_kept, pr_kept = t["train"].index_select(0, keep).contiguous(), prior.index_select(0, keep).contiguous()
+        plan_kept = kernels.Plan(tr_kept, 5)
+        extra["net_with_gradient_rows"]["kernel_ms_as_bear_net_train_holds_the_batch"] = timed(
+            lambda: kernels.dm_prior_planned(plan_kept, pr_kept, h_s, want_grad=True, normalized=True), 5)
+        del keep, tr_kept, pr_kept, plan_kept
         m = min(n, 20_000_000)
         test = kernels.synth_counts(SEED, row0, m, dev, want=("test",))["test"]
         tr_m, pr_m = t["train"][:m], prior[:m]

@@ -59,7 +59,9 @@ int bear_last_hip_error(void);
 /* Allocates the workspace on `device` (makes no change to the caller's current device).
  * A workspace serves ONE stream at a time: the block partials and the arrival counter of the kernels whose last block
  * forms the final sums are per-launch state, so launches that may overlap (two streams, two host threads) each take
- * their own workspace; launches ordered on one stream share one freely. */
+ * their own workspace; launches ordered on one stream share one freely.  After a launch or synchronisation FAILED, destroy
+ * the workspace and create a new one before replaying a captured graph that uses it: an arrival counter left half way by the
+ * failed launch is discarded by later EAGER launches only (their stamps are newer), not by replays of an older capture. */
 int bear_ws_create(int device, bear_ws **out);
 int bear_ws_destroy(bear_ws *ws);
 
@@ -215,7 +217,11 @@ int bear_cnn_reserve(bear_ws *ws, uint64_t n_rows, int lag, int filter_width, in
 int bear_net_cnn_train_reduce_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const uint64_t *kmer_code, uint64_t n_rows,
                                   int lag, int filter_width, int num_filters, int layer1_width, const double *theta, double *prior_buf,
                                   double *t1_buf, double *grad_rows_buf, double eps, int train_ar, double *packed, void *stream);
-/* reduce + apply in one call (single rank); `out` / `packed` as above. */
+/* reduce + apply in one call (single rank); `out` / `packed` as above.  bear_ref_train_step_f64 and
+ * bear_net_linear_train_step_f64 are ONE launch since round 6: the last block of the reduce kernel -- every other block has
+ * arrived, i.e. is done reading theta -- runs the update of bear_train_apply_f64 behind its fixed-order sums (same source, same
+ * bits as the two-launch form; BEAR_AMD_TWO_LAUNCH_STEP=1 in the environment of the call restores reduce + apply).  The
+ * convolutional step stays forward / DM / backward launches + apply. */
 int bear_ref_train_step_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *train, const uint32_t *ref, uint64_t n_rows,
                             double *theta, double *adam_m, double *adam_v, double *adam_t, double eps, int train_ar,
                             double learning_rate, double scale, double *out, double *loss_buf, uint64_t loss_cap, void *stream);

@@ -24,8 +24,11 @@ def _table(n, lag, dev, cols, row0=0):
     t = kernels.synth_counts(SEED, row0, n, dev, want=cols)
     counts = np.stack([t[k].cpu().numpy().view(np.uint32) for k in cols])
     del t
-    gen = torch.Generator(dev).manual_seed(SEED + lag)
-    kmers = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (n, lag), device=dev, generator=gen)].cpu().numpy()
+    # DISTINCT contexts (row index -> a fixed bijection of [0, 4^lag), kernels.synth_kmer_ids) in a scrambled order, as the
+    # rows of a pre-shuffled count file are; rounds 1-5 drew them with replacement
+    codes = kernels.synth_kmer_codes(SEED, row0, n, lag, dev)
+    kmers = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[codes.long()].cpu().numpy()
+    del codes
     torch.cuda.empty_cache()
     return kmers, counts
 
@@ -61,6 +64,8 @@ def measure_configs(dev, shrink=1):
     _, out["configs[2] bear_net, linear AR prior, k=13, 1e7 contexts"] = _train_config(
         bear_net, data, n1, 13, ar_funcs.make_ar_func_linear, {}, 600)
     del data, kmers, counts
+    # (a 1e8-context table does not exist at k = 13 -- 4^13 = 6.7e7 -- so "one rank's 1.25e7 rows of the pre-shuffled table" is 1.25e7
+    # distinct 13-mers, a random 19 % of all of them: the density such a shard has whatever the table's size)
     n4 = 12_500_000 // shrink
     kmers, counts = _table(n4, 13, dev, ("train", "test"))
     data = dataloader.CountDataset(kmers, counts, "dna", n4)

@@ -193,3 +193,33 @@ def test_sharded_reader_large_file_threads(tmp_path):
                 assert np.array_equal(part.kmers[o:o + g1 - g0], full.kmers[g0:g1])
     finally:
         os.environ.pop("BEAR_PARSE_THREADS")
+
+
+def test_release_build_refuses_developer_switches():
+    """The kernel sources carried "timing only, results meaningless" branches behind macros until round 6 (one stray -D and the
+    shipped library computed garbage).  They are gone from the sources (scripts/dev/patches/timing_switches.patch re-adds them),
+    and `bear_release_guard.h` -- included by every kernel source through bear_common.h -- stops a build that defines one of
+    their names, or a stamp / probe switch, without -DBEAR_DEV_BUILD."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "bear_amd", "csrc")
+    guard = os.path.join(csrc, "bear_release_guard.h")
+
+    def preprocess(*defs):
+        return subprocess.run(["gcc", "-E", "-x", "c++", *defs, guard], capture_output=True, text=True)
+    assert preprocess().returncode == 0
+    for name in ("LIN_SKIP_B", "LIN_FAKE_TRIPLE_ROWS=1", "LIN_MIX", "LIN_NOSYNC", "LIN_DBG=2", "PLN_NOWORK", "EVP_DEBUG_SWITCHES", "LIN_STAMPS",
+                 "PLN_STAMPS", "EVP_STAMPS", "CNN_STAMPS"):
+        p = preprocess("-D" + name)
+        assert p.returncode != 0 and "release builds refuse it" in p.stderr, name
+        assert preprocess("-D" + name, "-DBEAR_DEV_BUILD").returncode == 0, name
+    assert '#include "bear_release_guard.h"' in open(os.path.join(csrc, "bear_common.h")).read()
+    # no shipped source still tests one of the timing-only names, and the Makefile defines none of them
+    names = re.findall(r"defined\((\w+)\)", open(guard).read().split("#error")[0])
+    assert "LIN_SKIP_B" in names and "PLN_NOWORK" in names
+    for fn in os.listdir(csrc):
+        if fn == "bear_release_guard.h" or not fn.endswith((".h", ".hip", ".cpp", "Makefile")):
+            continue
+        text = open(os.path.join(csrc, fn)).read()
+        for n in names:
+            assert not re.search(r"\b%s\b" % n, text), (fn, n)

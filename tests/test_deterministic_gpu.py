@@ -159,6 +159,17 @@ for name, mod, make, kw, extra in (("linear", bear_net, ar_funcs.make_ar_func_li
         params, h, _ = mod.train(data.repeat(300), 1365, 300, 0, *extra, "dna", 5, make, kw, 0.01, "Adam", False)
         ds.append(digest(params, h))
     out["train_" + name] = ds[0] == ds[1]
+    if name != "cnn":
+        # ... and the ONE-launch optimizer step (the reduce kernel's last block runs Adam: what the two runs above took) ends in the
+        # same bits as reduce + bear_train_apply_f64 in two launches
+        from bear_amd import _train
+        out["one_launch_" + name] = bool(_train.LAST_RUN.get("one_launch_steps"))
+        os.environ["BEAR_AMD_TWO_LAUNCH_STEP"] = "1"
+        torch.manual_seed(10)
+        params, h, _ = mod.train(data.repeat(300), 1365, 300, 0, *extra, "dna", 5, make, kw, 0.01, "Adam", False)
+        del os.environ["BEAR_AMD_TWO_LAUNCH_STEP"]
+        out["two_launch_" + name] = not _train.LAST_RUN.get("one_launch_steps")
+        out["one_launch_equals_two_launch_" + name] = digest(params, h) == ds[0]
 print("RESULT " + json.dumps(out))
 """
 

@@ -213,3 +213,25 @@ def test_count_newlines_is_wc_l(tmp_path):
     assert dataloader.count_newlines(YSD1) == 1365
     with pytest.raises(Exception):
         dataloader.count_newlines(tmp_path / "missing.tsv")
+
+
+def test_synthetic_kmers_are_a_bijection_of_the_row_index():
+    """the synthetic tables' contexts are the row index mapped through a FIXED BIJECTION to k-mers -- distinct, as the
+    contexts of any count table are (summarize.py:429-449 writes one row per k-mer), scrambled, and the same whatever the shard."""
+    import torch
+    from bear_amd import kernels
+    for lag in (1, 2, 5, 8):
+        ids = kernels.synth_kmer_ids(20211012, 0, 4 ** lag, lag, "cpu")
+        assert ids.dtype == torch.int64 and int(ids.min()) == 0 and int(ids.max()) == 4 ** lag - 1
+        assert ids.unique().numel() == 4 ** lag                       # every k-mer exactly once
+    a = kernels.synth_kmer_ids(7, 12345, 1000, 13, "cpu")
+    assert torch.equal(a, kernels.synth_kmer_ids(7, 0, 20000, 13, "cpu")[12345:13345])      # rows [a, b): the same k-mers in any shard
+    assert not torch.equal(a, kernels.synth_kmer_ids(8, 12345, 1000, 13, "cpu"))
+    big = kernels.synth_kmer_ids(20211012, 0, 1_000_000, 13, "cpu")
+    assert big.unique().numel() == 1_000_000
+    assert abs(float(big.double().mean()) / 4 ** 13 - 0.5) < 0.01       # scrambled over the whole range
+    codes = kernels.synth_kmer_codes(20211012, 0, 4 ** 3, 3, "cpu", sort=True)
+    assert codes.dtype == torch.int8 and codes.shape == (64, 3)
+    assert codes.tolist() == [[a, b, c] for a in range(4) for b in range(4) for c in range(4)]   # k-mer order = ids ascending
+    with pytest.raises(ValueError, match="only 4\\^13"):
+        kernels.synth_kmer_ids(1, 0, 100_000_000, 13, "cpu")

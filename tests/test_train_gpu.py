@@ -390,6 +390,40 @@ def test_streamed_epochs_equal_resident_epochs(which, monkeypatch):
     assert np.allclose(auto[0], resident[0], rtol=1e-11, atol=0)
 
 
+@pytest.mark.parametrize("driver", ["bear_ref + stop", "bear_net + linear"])
+@pytest.mark.parametrize("train_ar", [False, True])
+def test_one_launch_step_matches_the_two_launch_step(driver, train_ar, monkeypatch):
+    """With one rank, Adam and no accumulation nothing sits between a step's reduce and its update, and the step is ONE launch:
+    the last block of the reduce kernel runs tf.keras Adam behind its sums (`bear_*_train_step_f64`, bear_apply_in_block; the
+    update's source is the two-launch form's).  Same losses and parameters as reduce + `bear_train_apply_f64` (to the order of the
+    sums of a launch; bit for bit in the deterministic build: tests/test_deterministic_gpu.py); accumulation keeps two launches."""
+    data = dataloader.dataloader(YSD1, "dna", 500, 3)
+
+    def run(acc_steps=1):
+        torch.manual_seed(4)
+        ls = []
+        if driver.startswith("bear_ref"):
+            p, _, _ = bear_ref.train(data.repeat(20), 1365, 20, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", train_ar,
+                                     acc_steps=acc_steps, loss_save=ls)
+        else:
+            p, _, _ = bear_net.train(data.repeat(20), 1365, 20, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", train_ar,
+                                     acc_steps=acc_steps, loss_save=ls)
+        return np.array(ls), np.concatenate([x.detach().cpu().numpy().reshape(-1) for x in p]), dict(_train.LAST_RUN)
+    one = run()
+    assert one[2]["one_launch_steps"] is True and one[2]["graph"] is True and len(one[0]) == 60
+    monkeypatch.setenv("BEAR_AMD_TWO_LAUNCH_STEP", "1")
+    two = run()
+    assert two[2]["one_launch_steps"] is False
+    assert np.allclose(one[0], two[0], rtol=1e-12, atol=0)
+    assert np.allclose(one[1], two[1], rtol=1e-9, atol=1e-12)
+    monkeypatch.delenv("BEAR_AMD_TWO_LAUNCH_STEP")
+    assert run(acc_steps=3)[2]["one_launch_steps"] is False
+    monkeypatch.setenv("BEAR_AMD_NO_GRAPH", "1")                 # the eager loop takes the one-launch step too
+    eager = run()
+    assert eager[2]["one_launch_steps"] is True and eager[2]["graph"] is False
+    assert np.allclose(one[0], eager[0], rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("kind", ["net", "ref"])
 def test_run_config_driver(kind, ysd1):
     """bear_model/tests/test_run.py:12-51 re-stated: the bear_test.cfg workflow returns 1 and the train-set BMM
