@@ -277,6 +277,7 @@ class ResidentBatches:
                     return data.kmers_dev[lo:hi].to(device).contiguous(), True
                 return up.put(data.kmers[lo:hi], torch.uint8), True
             return up.put(codes[lo:hi], torch.int8), False
+        row_index = getattr(data, "row_index", None)      # dataloader.KmerDealtDataset
         shuffled = {}
         if data.shuffle_seed is not None and data.num_rows:
             # whole columns go up once, are permuted by one gather pass each (same seed: columns stay aligned), and the
@@ -302,6 +303,8 @@ class ResidentBatches:
             (a, b), (g0, g1, off) = pieces[k]
             lo, hi = off, off + (g1 - g0)           # this rank's piece of the batch inside the dataset's arrays
             entry = {"global_rows": b - a, "rows": hi - lo, "row0": g0, "plans": {}}
+            if row_index is not None:           # rows dealt by k-mer range: row i of the piece is table row g0 + row_ids[i]
+                entry["row_ids"] = up.put(row_index[lo:hi], torch.int32)
             for name, col in columns.items():
                 entry[name] = shuffled[name][lo:hi].clone() if shuffled else device_column(col, lo, hi)
             if want_codes:
@@ -325,7 +328,7 @@ class ResidentBatches:
                         entry[name] = entry[name].index_select(0, idx).contiguous()
                     entry["rows"] = n_keep
                     # row i of the compacted batch is row row0 + row_ids[i] of the table: the key of the evaluation's tie noise
-                    entry["row_ids"] = idx.to(torch.int32).contiguous()
+                    entry["row_ids"] = (entry["row_ids"].index_select(0, idx) if "row_ids" in entry else idx.to(torch.int32)).contiguous()
                 del keep
             if kmer_order and want_codes and entry["rows"] > 1:
                 order = sort_by_kmer(entry["codes"], data.lag)

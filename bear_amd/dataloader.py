@@ -87,6 +87,34 @@ class CountDataset:
             off += hi - lo
         return out
 
+    def deal_by_kmer(self, rank, world):
+        """This rank's rows of every batch when the batches are dealt to the ranks BY K-MER RANGE instead of by contiguous row
+        pieces (``KmerDealtDataset``).  Needs the whole table (every rank parses it and keeps its range: no exchange); the
+        cut points follow from the batch's own histogram of leading letters, so every rank computes the same ones."""
+        if self.shard is not None:
+            raise ValueError("deal_by_kmer starts from the whole table (load it unsharded)")
+        if self.shuffle_seed is not None:
+            raise ValueError("a table shuffled on the device cannot be dealt by k-mer")
+        if world <= 1:
+            return self
+        keep, index, piece_rows = [], [], []
+        for a, b in self.batch_bounds():
+            key = kmer_deal_keys(self.kmers[a:b], self.alphabet)
+            hist = np.bincount(key, minlength=6 ** min(self.lag, KMER_DEAL_LETTERS))
+            cum = np.concatenate([[0], np.cumsum(hist)])
+            # rank r takes the bins [cut[r], cut[r + 1]): the first bin whose rows reach past r / world of the batch opens rank r's range
+            targets = [(b - a) * r // world for r in range(world + 1)]
+            cut = [int(np.searchsorted(cum, t, side="left")) for t in targets]
+            cut[0], cut[-1] = 0, len(hist)
+            mine = np.nonzero((key >= cut[rank]) & (key < cut[rank + 1]))[0]
+            keep.append(a + mine)
+            index.append(mine)
+            piece_rows.append(len(mine))
+        rows = np.concatenate(keep) if keep else np.zeros(0, dtype=np.int64)
+        return KmerDealtDataset(np.ascontiguousarray(self.kmers[rows]), np.ascontiguousarray(self.counts[:, rows]),
+                                np.concatenate(index) if index else np.zeros(0, dtype=np.int32), piece_rows, self.alphabet,
+                                self.batch_size, self.dtype, self.repeats, rank, world, self.num_rows)
+
     def __len__(self):
         return len(self.batch_bounds()) * self.repeats
 
@@ -140,6 +168,59 @@ class CountDataset:
             t = torch.from_numpy(np.ascontiguousarray(self.counts[ds_loc, a:b]).view(np.int32)).to(device)
             self._device_cache[key] = t
         return t
+
+
+class KmerDealtDataset(CountDataset):
+    """This rank's rows of every batch, dealt BY K-MER RANGE (``CountDataset.deal_by_kmer``): of every batch ``[a, b)`` the rows whose
+    leading letters fall into this rank's range of the batch's k-mers -- ranges in k-mer order, cut so that the ranks hold the
+    same number of rows to within one bin of leading letters.  ``row_index`` int32 [local rows]: each row's number inside its
+    batch (the rows of a piece are not a contiguous row range of the table: the key of the evaluation's tie-breaking noise
+    travels with them).  The sums of a step do not depend on WHICH rows a rank holds; what the fused AR-function kernels gain is
+    density: a rank's piece of a k-mer-sorted batch keeps the whole batch's density of distinct prefixes and windows, where a
+    contiguous row piece of a pre-shuffled table is a random 1 / world of its k-mers (kernels_cnn.h prefix levels, window tables;
+    kernels_linear.h paired lists)."""
+
+    def __init__(self, kmers, counts, row_index, piece_rows, alphabet, batch_size, dtype, repeats, rank, world, total_rows):
+        self.row_index = np.ascontiguousarray(row_index, dtype=np.int32)
+        self.piece_rows = [int(x) for x in piece_rows]          # rows of this rank in each batch
+        super().__init__(kmers, counts, alphabet, batch_size, dtype, repeats=repeats, shard=(rank, world), total_rows=total_rows)
+
+    def _pieces(self):
+        return [(a, a + c) for (a, b), c in zip(self.batch_bounds(), self.piece_rows)]
+
+    def rank_pieces(self, rank, world):
+        """Per batch: (batch start a, a + rows of this rank's piece, offset of the piece in this dataset's arrays): the piece's
+        rows are ``a + row_index[offset : offset + rows]``."""
+        if self.shard != (rank, world):
+            raise ValueError(f"dataset was dealt for rank/world {self.shard}, asked for {(rank, world)}")
+        out, off = [], 0
+        for (a, b), c in zip(self.batch_bounds(), self.piece_rows):
+            out.append((a, a + c, off))
+            off += c
+        return out
+
+    def _like(self, **kw):
+        args = dict(alphabet=self.alphabet, batch_size=self.batch_size, dtype=self.dtype, repeats=self.repeats)
+        if kw.get("shuffle_seed") is not None:
+            raise ValueError("a dealt table cannot be shuffled on the device")
+        args.update({k: v for k, v in kw.items() if k in args})
+        return KmerDealtDataset(self.kmers, self.counts, self.row_index, self.piece_rows, args["alphabet"], args["batch_size"], args["dtype"],
+                                args["repeats"], self.shard[0], self.shard[1], self.total_rows)
+
+
+KMER_DEAL_LETTERS = 6      # leading letters that decide a row's rank (6^6 = 46 656 bins per batch)
+
+
+def kmer_deal_keys(kmers, alphabet):
+    """The dealing key of every row: its leading KMER_DEAL_LETTERS letters as a number in the k-mer order of the device sort
+    (``bear_kmer_order_u64``: first letter most significant, letters in alphabet order, the start symbol behind them, anything
+    else last)."""
+    codes = core.encode_kmers(kmers[:, :KMER_DEAL_LETTERS], alphabet).astype(np.int64)
+    codes[codes < 0] = 5
+    key = np.zeros(kmers.shape[0], dtype=np.int64)
+    for l in range(codes.shape[1]):
+        key = key * 6 + codes[:, l]
+    return key
 
 
 class MappedDataset:
@@ -292,9 +373,17 @@ def dataloader(file, alphabet, batch_size, num_ds, cache=True, header=False, n_p
     A1 = len(core.alphabets_tf[alphabet])
     if A1 != 5:
         raise NotImplementedError("the HIP kernels are built for 4-letter alphabets (+ stop): dna / rna")
-    if shard == "auto":
+    deal_kmer = shard == "kmer"
+    if shard in ("auto", "kmer"):
         from . import dist
         shard = dist.world() if dist.world()[1] > 1 else None
+    if deal_kmer and shard is not None:
+        # rows dealt to the ranks by k-mer range (KmerDealtDataset): every rank parses the whole table and keeps its range
+        whole = dataloader(file, alphabet, batch_size, num_ds, cache=cache, header=header, n_par=n_par, dtype=dtype,
+                           binary_cache=binary_cache, shard=None)
+        if row_base or total_rows is not None:
+            raise ValueError("shard='kmer' deals one whole table: concatenate the files first")
+        return whole.deal_by_kmer(*shard)
     if binary_cache is None:
         binary_cache = os.environ.get("BEAR_AMD_CACHE_DIR") or None
     if shard is not None:

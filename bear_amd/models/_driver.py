@@ -84,7 +84,18 @@ def _run(config, kind):
         bc = config["data"]["binary_cache"]
         extra_kw["binary_cache"] = True if bc == "True" else bc
     shuffle_seed = config["data"].get("shuffle_seed")
-    if world > 1 and load is dataloader.dataloader and not shuffle_seed:
+    # a third one: [data] shard = kmer deals every batch to the ranks BY K-MER RANGE instead of by contiguous row pieces (or
+    # BEAR_AMD_SHARD=kmer): every rank parses the whole table and keeps its range.  The sums of a step do not depend on which rows a
+    # rank holds; a rank's piece then keeps the table's density of distinct prefixes / windows, which is what the fused linear and
+    # convolutional steps live on (a contiguous piece of a pre-shuffled table is a random 1 / world of its k-mers).
+    deal_kmer = (config["data"].get("shard") or os.environ.get("BEAR_AMD_SHARD", "")) == "kmer"
+    if world > 1 and deal_kmer and load is dataloader.dataloader and not shuffle_seed:
+        parts = [load(f, config["data"]["alphabet"], kmer_batch_size, num_ds, cache=config["train"]["cache"] == "True", dtype=dtype,
+                      **extra_kw) for f in files]
+        whole = parts[0] if len(parts) == 1 else dataloader.concatenate(parts)
+        parts = [whole.deal_by_kmer(rank, world)]
+        del whole
+    elif world > 1 and load is dataloader.dataloader and not shuffle_seed:
         # every rank decodes and holds only its pieces of the batches (the device shuffle needs whole columns: then, as for the
         # small sparse format, each rank loads the table and slices its rows at upload)
         if extra_kw.get("binary_cache"):

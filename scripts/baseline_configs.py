@@ -49,21 +49,40 @@ def _train_config(mod, data, n, lag, make, kw, steps, extra=()):
                  "train_call_wall_s": wall, "elbo_first_step": loss[0], "elbo_last_step": loss[-1]}
 
 
-def measure_configs(dev, shrink=1):
-    """also.baseline_configs.  `shrink` > 1 divides every size (tests)."""
+def measure_configs(dev, shrink=1, only=None):
+    """also.baseline_configs.  `shrink` > 1 divides every size (tests); `only` = 1 ... 4: that config alone (one config per profiled
+    process: scripts/profile_round.sh)."""
     from bear_amd import ar_funcs, bear_net, bear_ref, dataloader
     out = {"note": "one optimizer step = this rank's reduce (fused kernels) + Adam (bear_train_apply_f64), enqueued by bear_ref.train / "
                    "bear_net.train themselves (run_device_steps: a period of steps captured into a HIP graph and replayed); us_per_step = "
                    "HIP-event time of the last three quarters of the loop / its steps; one GPU, so configs[3] / [4] run one rank's "
                    "shard of the 8-GPU job (no all-reduce in the figure)"}
-    n1 = 10_000_000 // shrink
-    kmers, counts = _table(n1, 13, dev, ("train", "test", "ref"))
-    data = dataloader.CountDataset(kmers, counts, "dna", n1)
-    _, out["configs[1] bear_ref, stop prior, k=13, 1e7 contexts"] = _train_config(
-        bear_ref, data, n1, 13, ar_funcs.make_ar_func_stop, {}, 2000, extra=(2,))
-    _, out["configs[2] bear_net, linear AR prior, k=13, 1e7 contexts"] = _train_config(
-        bear_net, data, n1, 13, ar_funcs.make_ar_func_linear, {}, 600)
-    del data, kmers, counts
+    want = lambda k: only is None or only == k
+    if want(1) or want(2):
+        n1 = 10_000_000 // shrink
+        kmers, counts = _table(n1, 13, dev, ("train", "test", "ref"))
+        data = dataloader.CountDataset(kmers, counts, "dna", n1)
+        if want(1):
+            _, out["configs[1] bear_ref, stop prior, k=13, 1e7 contexts"] = _train_config(
+                bear_ref, data, n1, 13, ar_funcs.make_ar_func_stop, {}, 2000, extra=(2,))
+        if want(2):
+            _, out["configs[2] bear_net, linear AR prior, k=13, 1e7 contexts"] = _train_config(
+                bear_net, data, n1, 13, ar_funcs.make_ar_func_linear, {}, 600)
+        del data, kmers, counts
+    if want(4):
+        _config4(dev, shrink, out)
+    if want(3):
+        from bear_amd import ar_funcs as af
+        n3 = 125_000_000 // shrink
+        kmers, counts = _table(n3, 15, dev, ("train", "ref"), row0=3 * n3)
+        data = dataloader.CountDataset(kmers, counts, "dna", n3)
+        _, out["configs[3] bear_ref, k=15, rank shard 1.25e8 of 1e9 contexts"] = _train_config(
+            bear_ref, data, n3, 15, af.make_ar_func_stop, {}, 400, extra=(1,))
+    return out
+
+
+def _config4(dev, shrink, out):
+    from bear_amd import ar_funcs, bear_net, dataloader
     # (a 1e8-context table does not exist at k = 13 -- 4^13 = 6.7e7 -- so "one rank's 1.25e7 rows of the pre-shuffled table" is 1.25e7
     # distinct 13-mers, a random 19 % of all of them: the density such a shard has whatever the table's size)
     n4 = 12_500_000 // shrink
@@ -78,12 +97,26 @@ def measure_configs(dev, shrink=1):
                heldout_perplexity_ar=float(res[4]), heldout_perplexity_bmm=[float(x) for x in np.atleast_1d(res[5])])
     out["configs[4] bear_net, CNN AR prior, k=13, rank shard 1.25e7 of 1e8 contexts, + held-out evaluation"] = ent
     del data, kmers, counts, params, ar_func
-    n3 = 125_000_000 // shrink
-    kmers, counts = _table(n3, 15, dev, ("train", "ref"), row0=3 * n3)
-    data = dataloader.CountDataset(kmers, counts, "dna", n3)
-    _, out["configs[3] bear_ref, k=15, rank shard 1.25e8 of 1e9 contexts"] = _train_config(
-        bear_ref, data, n3, 15, ar_funcs.make_ar_func_stop, {}, 400, extra=(1,))
-    return out
+    # The same job on a table that exists -- 6.0e7 distinct 13-mers over 8 ranks, 7.5e6 contexts each -- with a rank's piece cut both
+    # ways: a contiguous row piece of the pre-shuffled table (a random eighth of its k-mers) and the piece `shard = kmer` deals
+    # (dataloader.KmerDealtDataset: the rank's RANGE of the sorted k-mers, here the first eighth).  The synthetic counts do not depend
+    # on the contexts, so rows [0, 7.5e6) of the count table serve both.
+    from bear_amd import kernels
+    n_tab, n_piece = 60_000_000 // shrink, 7_500_000 // shrink
+    t = kernels.synth_counts(SEED, 0, n_piece, dev, want=("train", "test"))
+    counts = np.stack([t[k].cpu().numpy().view(np.uint32) for k in ("train", "test")])
+    del t
+    ids = kernels.synth_kmer_ids(SEED, 0, n_tab, 13, dev)
+    letters = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    shifts = torch.arange(24, -1, -2, dtype=torch.int64, device=dev)
+    for label, mine in (("contiguous row piece", ids[:n_piece]), ("piece dealt by k-mer range", torch.sort(ids).values[:n_piece])):
+        kmers = letters[((mine[:, None] >> shifts[None, :]) & 3)].cpu().numpy()
+        data = dataloader.CountDataset(kmers, counts, "dna", n_piece)
+        _, e2 = _train_config(bear_net, data, n_piece, 13, ar_funcs.make_ar_func_cnn, {"filter_width": 8}, 24)
+        out["configs[4] on a 6e7-context table over 8 ranks, 7.5e6 contexts per rank: " + label] = e2
+        del data, kmers
+        torch.cuda.empty_cache()
+    del ids, counts
 
 
 def measure_dense(dev, n=20_000_000, check_rows=2_000_000):
@@ -156,5 +189,7 @@ if __name__ == "__main__":
     dev = torch.device("cuda", 0)
     if what in ("configs", "all"):
         print(json.dumps(measure_configs(dev), indent=1))
+    if what in ("configs1", "configs2", "configs3", "configs4"):
+        print(json.dumps(measure_configs(dev, only=int(what[-1])), indent=1))
     if what in ("dense", "all"):
         print(json.dumps(measure_dense(dev), indent=1))

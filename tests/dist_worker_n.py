@@ -23,7 +23,7 @@ def main():
     if os.environ.get("BEAR_TEST_STREAM_RANK", "") == str(rank):
         os.environ["BEAR_AMD_STREAM"] = "1"          # ONE rank is told to stream its epochs: the ranks have to agree on it
     for name, path, batch in json.loads(os.environ["BEAR_TABLES"]):
-        data = dataloader.dataloader(path, "dna", batch, 3, shard="auto")
+        data = dataloader.dataloader(path, "dna", batch, 3, shard=os.environ.get("BEAR_TEST_SHARD", "auto"))    # "kmer": dealt by k-mer range
         pieces = [g1 - g0 for g0, g1, _ in data.rank_pieces(rank, world)]
         every = [None] * world
         torch.distributed.all_gather_object(every, pieces)

@@ -150,12 +150,12 @@ def test_baseline_configs_module_small():
     dev = torch.device("cuda", 0)
     out = baseline_configs.measure_configs(dev, shrink=50)
     ents = [v for k, v in out.items() if k.startswith("configs[")]
-    assert len(ents) == 4
+    assert len(ents) == 6             # the four configs + configs[4]'s rank piece cut both ways (contiguous rows / k-mer range)
     for e in ents:
         assert e["us_per_step"] > 0 and e["steps_timed"] > 0 and np.isfinite(e["elbo_last_step"])
         assert e["elbo_last_step"] > e["elbo_first_step"]                 # the logged scalar is the ELBO: the optimizer raises it
         assert abs(e["contexts_per_s"] - e["rows"] / (e["us_per_step"] * 1e-6)) <= 1e-6 * e["contexts_per_s"]
-    cnn = [v for k, v in out.items() if "configs[4]" in k][0]
+    cnn = [v for k, v in out.items() if "configs[4] bear_net" in k][0]
     assert 1.0 < cnn["heldout_perplexity_bear"] < 6.0
     d = baseline_configs.measure_dense(dev, n=1_000_000, check_rows=200_000)
     c = d["check"]

@@ -142,3 +142,42 @@ def test_driver_path_exports_the_ipc_mode_before_the_process_group(monkeypatch):
     body = src[src.index("def _run"):]
     first = [ln.strip() for ln in body.splitlines()[1:] if ln.strip() and not ln.strip().startswith(("#", '"'))][0]
     assert first == "rank, world = dist.init_from_env()", first
+
+
+def test_batches_dealt_by_kmer_range_tile_every_batch():
+    """`CountDataset.deal_by_kmer(rank, world)` (dataloader(..., shard="kmer")): for any world size the ranks' pieces of EVERY batch
+    are disjoint and cover it, each rank's rows are one range of the batch's k-mers (in the k-mer order of the device sort), the
+    pieces are balanced to a bin of leading letters, `row_index` says where each row sits in its batch, and the dealt dataset
+    still describes the whole table (num_rows, batch_bounds)."""
+    from bear_amd import dataloader
+    ysd1 = os.path.join(ROOT, "tests", "golden", "ysd1_lag_5_file_0_preshuf.tsv")
+    whole = dataloader.dataloader(ysd1, "dna", 500, 3)
+    assert whole.deal_by_kmer(0, 1) is whole
+    for world in (2, 3, 8):
+        parts = [whole.deal_by_kmer(r, world) for r in range(world)]
+        assert all(p.num_rows == 1365 and p.batch_bounds() == whole.batch_bounds() and p.shard == (r, world) for r, p in enumerate(parts))
+        assert sum(p.local_rows for p in parts) == 1365
+        for k, (a, b) in enumerate(whole.batch_bounds()):
+            rows, keys = [], []
+            for r, p in enumerate(parts):
+                g0, g1, off = p.rank_pieces(r, world)[k]
+                assert g0 == a and g1 - g0 == p.piece_rows[k]
+                idx = p.row_index[off:off + g1 - g0]
+                assert np.all(np.diff(idx) > 0)                                     # file order inside a piece
+                assert np.array_equal(p.kmers[off:off + g1 - g0], whole.kmers[a + idx])
+                assert np.array_equal(p.counts[:, off:off + g1 - g0], whole.counts[:, a + idx])
+                rows.append(a + idx)
+                keys.append(dataloader.kmer_deal_keys(whole.kmers[a + idx], "dna"))
+            assert np.array_equal(np.sort(np.concatenate(rows)), np.arange(a, b))       # disjoint, complete
+            sizes = [len(x) for x in rows]
+            assert max(sizes) - min(sizes) <= 2, sizes                                  # (lag 5 < 6 letters: a bin is one k-mer)
+            held = [kk for kk in keys if len(kk)]
+            assert all(held[i].max() < held[i + 1].min() for i in range(len(held) - 1))   # rank r's k-mers all precede rank r + 1's
+        # the reference-shaped iteration yields this rank's piece of every batch
+        got = [km.shape[0] for km, _ in parts[1]]
+        assert got == parts[1].piece_rows
+        with pytest.raises(ValueError):
+            parts[0].rank_pieces(1, world)
+        with pytest.raises(ValueError):
+            parts[0].shuffle(3)
+        assert parts[0].repeat(3).repeats == 3 and parts[0].repeat(3).piece_rows == parts[0].piece_rows

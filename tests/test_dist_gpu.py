@@ -199,6 +199,53 @@ def test_many_ranks_match_single_rank_with_empty_and_uneven_pieces(tmp_path):
             assert g[key][6] == np.asarray(want[6]).tolist() and g[key][8] == np.asarray(want[8]).tolist(), (name, key)
 
 
+def test_ranks_dealt_by_kmer_range_match_single_rank(tmp_path):
+    """`dataloader(..., shard="kmer")`: every batch is dealt to the ranks BY K-MER RANGE (dataloader.KmerDealtDataset: each rank
+    parses the table and keeps the rows whose leading letters fall into its range -- its piece of a k-mer-sorted batch keeps the
+    batch's density of prefixes and windows) instead of by contiguous row pieces.  Sums do not depend on which rows a rank
+    holds: losses and parameters of bear_ref.train / bear_net.train (linear; BEAR mode and AR mode with accumulation) equal the
+    single-process run's, and so do both evaluations -- the accuracy COUNTS exactly: the rows' table positions travel with them as
+    row_ids, the key of the tie-breaking noise.  Tables: the bundled one and 23 rows in batches of 7 (pieces of 2, 1, 0 rows)."""
+    torch.manual_seed(3)
+    _, lin = ar_funcs.make_ar_func_linear(5, 4)
+    restart = {"linear": np.array([np.array(0.1)] + [x.detach().numpy() for x in lin], dtype=object)}
+    np.savez(tmp_path / "restart.npz", **restart)
+    small = tmp_path / "small.tsv"
+    with open(YSD1) as fh:
+        small.write_text("".join(fh.readlines()[:23]))
+    tables = [["ysd1", YSD1, 500], ["small", str(small), 7]]
+    out_file = tmp_path / "out.json"
+    _launch([os.path.join(ROOT, "tests", "dist_worker_n.py")],
+            {"BEAR_RESTART": str(tmp_path / "restart.npz"), "BEAR_OUT": str(out_file), "BEAR_TABLES": json.dumps(tables),
+             "BEAR_EXPECT_WORLD": str(MANY), "BEAR_TEST_SHARD": "kmer"}, tmp_path, nproc=MANY)
+    got = json.load(open(out_file))
+    assert np.asarray(got["ysd1"]["pieces"]).sum() == 1365 and np.asarray(got["small"]["pieces"]).sum() == 23
+    for name, path, batch in tables:
+        data = dataloader.dataloader(path, "dna", batch, 3)
+        g = got[name]
+
+        def check(key, fn, *args, **kw):
+            ls = []
+            p, _, _ = fn(*args, loss_save=ls, **kw)
+            assert len(g[key]["loss"]) == len(ls) and len(ls) > 0, (name, key)
+            assert np.allclose(g[key]["loss"], ls, rtol=1e-10), (name, key)
+            assert np.allclose(_flat(g[key]["params"]), _flat([x.detach().cpu().numpy() for x in p]), rtol=1e-7, atol=1e-10), (name, key)
+        check("ref_stop", bear_ref.train, data.repeat(4), data.num_rows, 4, 0, 2, "dna", 5, ar_funcs.make_ar_func_stop, {}, 0.01, "Adam", False)
+        check("net_linear", bear_net.train, data.repeat(4), data.num_rows, 4, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam", False,
+              params_restart=list(restart["linear"]))
+        check("net_linear_ar_acc2", bear_net.train, data.repeat(4), data.num_rows, 4, 0, "dna", 5, ar_funcs.make_ar_func_linear, {}, 0.01, "Adam",
+              True, acc_steps=2, params_restart=list(restart["linear"]))
+        torch.manual_seed(1)
+        f, _ = ar_funcs.make_ar_func_linear(5, 4, device="cuda")
+        r = bear_net.evaluation(data, 0, 1, "dna", torch.tensor(0.37), f, np.array([0.1, 1.0, 10.0]), seed=11)
+        fr, _ = bear_ref._make_ref_ar_func(5, 4, ar_funcs.make_ar_func_stop, {}, device="cuda")
+        rr = bear_ref.evaluation(data, 0, 1, 2, "dna", torch.tensor(0.21), fr, np.array([0.5, 2.0]), seed=3)
+        for key, want in (("eval", r), ("eval_ref", rr)):
+            for a, b in zip(g[key], want):
+                assert np.allclose(a, np.asarray(b), rtol=1e-11), (name, key)
+            assert g[key][6] == np.asarray(want[6]).tolist() and g[key][8] == np.asarray(want[8]).tolist(), (name, key)
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_under_the_launcher_many_ranks(scaling, tmp_path):
     """bench.py --gpus MANY (gloo, all ranks on cuda:0) in both scaling modes: the whole-job value counts every rank's contexts,
