@@ -58,7 +58,13 @@
 // add serves 128 contexts instead of 64 (phase C).  A tile whose list would grow beyond what the row threads take (2 per thread: a
 // stretch of the table where a run is one context) keeps its plain list: the step is then two launches, the paired form of the
 // kernel over the paired tiles and the plain form over the rest (both forms in one kernel ran out of registers).
-#define LIN_PAIR_CAP (2 * (PLN_THREADS - 64 * 2))           // entries the row threads of a block take (LIN_RPT * LIN_ROW_THREADS, asserted below)
+#ifndef LIN_DMA_WAVES
+#define LIN_DMA_WAVES 2
+#endif
+#ifndef LIN_ROW_THREADS
+#define LIN_ROW_THREADS (PLN_THREADS - 64 * LIN_DMA_WAVES)     // (see "The waves that issue a tile's DMA" below)
+#endif
+#define LIN_PAIR_CAP (2 * LIN_ROW_THREADS)                  // entries the row threads of a block take (LIN_RPT * LIN_ROW_THREADS, asserted below)
 #define LIN_LIVE2_STRIDE (LIN_PAIR_CAP + 8)                 // uint16 per tile of the paired lists (a multiple of 8: 16-byte rows)
 #define LIN_EMPTY 0xffffu
 

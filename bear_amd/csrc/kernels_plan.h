@@ -323,7 +323,7 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
   // the threads got there.  The deterministic build sorts them (count, then offset: a bitonic pass over the tile; the lists by
   // ranking) so that a table's plan, hence the grouping of every sum taken over it, is the same bits in every run.
   __shared__ uint32_t comp[PLN_NI];
-  static_assert((PLN_NI & (PLN_NI - 1)) == 0 && PLN_NI == 2048, "bitonic sort over the tile's items");
+  static_assert((PLN_NI & (PLN_NI - 1)) == 0 && PLN_NI <= 2048, "bitonic sort over the tile's items: PLN_NI / 2 pairs, at most one per thread");
   __shared__ unsigned long long hkey[PLN_HCAP], htmp[PLN_HCAP];
 #endif
   const uint32_t tid = threadIdx.x, rep = tid & (SRT_REP - 1);
@@ -492,12 +492,14 @@ __global__ __launch_bounds__(1024) void plan_fill_kernel(const uint32_t *__restr
       __syncthreads();
       for (uint32_t size = 2; size <= PLN_NI; size <<= 1)
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-          const uint32_t lo = 2u * tid - (tid & (stride - 1u)), hi = lo + stride;      // PLN_NI / 2 = 1024 pairs, one per thread
-          const bool up = (lo & size) == 0u;
-          const uint32_t a = comp[lo], bq = comp[hi];
-          if ((a > bq) == up) {
-            comp[lo] = bq;
-            comp[hi] = a;
+          const uint32_t lo = 2u * tid - (tid & (stride - 1u)), hi = lo + stride;      // PLN_NI / 2 pairs, one per thread
+          if (tid < PLN_NI / 2) {
+            const bool up = (lo & size) == 0u;
+            const uint32_t a = comp[lo], bq = comp[hi];
+            if ((a > bq) == up) {
+              comp[lo] = bq;
+              comp[hi] = a;
+            }
           }
           __syncthreads();
         }
@@ -701,6 +703,9 @@ __device__ __forceinline__ uint32_t pln_ticket(uint32_t *counter, uint32_t lane)
 #define PLN_TICKET_START(stride) ((uint32_t)(stride))
 #endif
 
+// (Round 6, measured and not kept: the NEXT ticket drawn in front of the current unit -- the draw's LDS round trip, ~1000 clocks on a
+// CU whose LDS queue the units keep busy, then hides behind the unit -- made the linear step 4.7 % SLOWER, 0.902 against 0.861 ms:
+// a wave holds the phase's last units while others idle at the barrier.  The evaluation kernel had found the same in round 4.)
 // The same draw without waiting for its answer: lane 0's return value, to be made uniform (srt_uniform) when it is looked at.
 __device__ __forceinline__ uint32_t pln_ticket_issue(uint32_t *counter, uint32_t lane) {
   uint32_t t = 0;
