@@ -36,7 +36,8 @@ struct bear_ws {
   double *eval_partials;    // [eval_blocks][EVL_MAX_OUT] (kernels_eval.h)
   double *eval_out;         // [EVL_MAX_OUT] scratch result vector (bear_bmm_f64)
   int eval_blocks;
-  double *lin_partials;     // [num_cu][LIN_MAX_GRAD] d/d mat partials (kernels_linear.h)
+  double *lin_partials;     // [num_cu][LIN_MAX_GRAD] d/d mat partials (kernels_linrows.h)
+  double *lin_accum;        // [LIN_MAX_GRAD] d/d mat accumulator of the fused linear step (kernels_linear.h): zero between launches
   unsigned long long *arrive;      // arrival word of the launch that owns `partials` (bear_arrival: epoch << 24 | blocks arrived)
   unsigned epoch;                  // host side: the stamp of the last launch that used `arrive` (never 0)
   double *cnn_partials;     // [cnn_blocks][cnn total] parameter-gradient partials (kernels_cnn.h), grown on demand

@@ -85,6 +85,8 @@ int bear_ws_create(int device, bear_ws **out) {
       if (e == hipSuccess) e = hipMalloc(&ws->eval_partials, sizeof(double) * EVL_MAX_OUT * (size_t)ws->eval_blocks);
       if (e == hipSuccess) e = hipMalloc(&ws->eval_out, sizeof(double) * EVL_MAX_OUT);
       if (e == hipSuccess) e = hipMalloc(&ws->lin_partials, sizeof(double) * LIN_MAX_GRAD * (size_t)ws->num_cu * PLN_BLOCKS_PER_CU);
+      if (e == hipSuccess) e = hipMalloc(&ws->lin_accum, sizeof(double) * LIN_MAX_GRAD);
+      if (e == hipSuccess) e = hipMemset(ws->lin_accum, 0, sizeof(double) * LIN_MAX_GRAD);
       if (e == hipSuccess) e = hipMalloc(&ws->arrive, sizeof(unsigned long long) * BEAR_ARRIVE_WORDS);
       if (e == hipSuccess) e = hipMemset(ws->arrive, 0, sizeof(unsigned long long) * BEAR_ARRIVE_WORDS);
       ws->epoch = 0;
@@ -184,6 +186,7 @@ int bear_ws_destroy(bear_ws *ws) {
   (void)hipFree(ws->eval_partials);
   (void)hipFree(ws->eval_out);
   (void)hipFree(ws->lin_partials);
+  (void)hipFree(ws->lin_accum);
   if (ws->cnn_partials) (void)hipFree(ws->cnn_partials);
   if (ws->arrive) (void)hipFree(ws->arrive);
   (void)hipSetDevice(prev);
@@ -877,7 +880,10 @@ static int launch_ref_plan(bear_ws *ws, const bear_plan *plan, const uint32_t *r
     rv.heavy0 = plan->heavy0;
     rv.n_heavy0 = plan->n_heavy0;
     rv.sum0 = plan->sum0;
-    const uint64_t units = (plan->n_ref_items + 63) / 64, want = (units + 3) / 4 + 2;   // 4 waves per block
+    // 4 waves per block, ~3 units per wave: a block's fixed work (the log table into LDS, its partials, two arrival atomics, its
+    // share of the last block's sum) is worth about three units -- configs[1] (1e7 contexts, 11 000 units): 22.8 us per step on 3-4
+    // blocks per CU, 25.5 on 8 (one unit per wave), 27.3 on 2 (scripts/dev/cfg1_grid.py); larger tables reach the cap of 8 per CU either way
+    const uint64_t units = (plan->n_ref_items + 63) / 64, want = (units + 11) / 12 + 2;
     grid = (int)(want < (uint64_t)ws->num_cu * 8 ? want : (uint64_t)ws->num_cu * 8);
     if (train_ar)
       hipLaunchKernelGGL(dm_ref_items_kernel<true>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, io, apply);
@@ -1085,7 +1091,7 @@ static void launch_linear(bear_ws *ws, const bear_plan *plan, const uint64_t *km
   // (the update, if any, goes with the step's LAST launch: the one that completes the sums)
 #define LIN_LAUNCH_D(AR, PAIRED, DET, PV, NT, ACC)                                                                                          \
   hipLaunchKernelGGL((dm_linear_plan_kernel<AR, PAIRED, DET>), dim3(grid_plan(ws, NT)), dim3(PLN_THREADS), sizeof(pln_lds_lin), s, kc, mat, \
-                     lag, prm, PV, lt, ws->partials, ws->lin_partials, (ACC) ? io2 : io, grad_mat, ACC, gt_bound,                            \
+                     lag, prm, PV, lt, ws->partials, ws->lin_accum, (ACC) ? io2 : io, grad_mat, ACC, gt_bound,                            \
                      ((ACC) || !two_launches) ? apply : NO_APPLY)
 #define LIN_LAUNCH(AR, PAIRED, PV, NT, ACC)                    \
   do {                                                         \

@@ -1057,6 +1057,54 @@ __device__ __forceinline__ void lin_fold_tables(const double *GT, const lin_geom
   }
 }
 
+// ---- the same fold ADDED into the launch's accumulator [n_grad] (device memory, zero between launches): one hardware atomic per
+// entry and block (global_atomic_add_f64; DET: 64-bit integer adds, exact in any order) instead of a partial the last block has
+// to fetch -- its fixed-order sum over 256 x 325 partials (665 KB through one CU) was ~10 us of EVERY launch, a twentieth of
+// configs[2]'s step.  The regular build's d/d mat was reproducible to rounding only before (LDS float atomics); it still is.
+template <bool DET = false>
+__device__ __forceinline__ void lin_fold_tables_add(const double *GT, const lin_geom &G, int tid, int n_threads, double *__restrict__ accum) {
+  using T = typename std::conditional<DET, lin_fx, double>::type;
+  for (int k = tid; k < G.lag * 25; k += n_threads) {
+    const int l = k / 25, r = k - l * 25, a = r / 5, b = r - a * 5;
+    T s = T(0);
+    auto add = [&](int row) {
+      const double *gt = &GT[row];
+      const T v0 = lin_unbits<T>(__double_as_longlong(gt[0])), v1 = lin_unbits<T>(__double_as_longlong(gt[LIN_GT_PLANE])),
+              v2 = lin_unbits<T>(__double_as_longlong(gt[2 * LIN_GT_PLANE])), v3 = lin_unbits<T>(__double_as_longlong(gt[3 * LIN_GT_PLANE]));
+      s += b == 0 ? v0 : b == 1 ? v1 : b == 2 ? v2 : b == 3 ? v3 : -((v0 + v1) + (v2 + v3));
+    };
+    if (l >= G.tri) {
+      const int pos = l - G.tri, base = G.npair * LIN_PAIR_COMBOS;
+      for (int p = 0; p < 36; ++p) {
+        const int p0 = p / 6, p1 = p % 6;
+        add(base + (pos == 0 ? (a * 6 + p0) * 6 + p1 : pos == 1 ? (p0 * 6 + a) * 6 + p1 : (p0 * 6 + p1) * 6 + a));
+      }
+    } else {
+      const int g = l >> 1;
+      for (int p = 0; p < 6; ++p) add(g * LIN_PAIR_COMBOS + ((l & 1) ? p * 6 + a : a * 6 + p));
+    }
+    // AGENT scope: the blocks of a launch sit on eight XCDs with an L2 each -- the add has to happen where all of them see it
+    if (DET) {
+      if (s != T(0)) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&accum[k]), (unsigned long long)lin_bits<T>(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (s != T(0)) __hip_atomic_fetch_add(&accum[k], (double)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+// ... and the last block: the accumulator's sums -> grad_out, the accumulator back to zero (the next launch starts from it)
+template <bool DET = false>
+__device__ __forceinline__ void lin_take_accum(double *__restrict__ accum, int n_grad, int tid, int n_threads, double *__restrict__ grad_out,
+                                               bool accumulate, double inv_scale) {
+  using T = typename std::conditional<DET, lin_fx, double>::type;
+  for (int k = tid; k < n_grad; k += n_threads) {
+    const double raw = __hip_atomic_load(&accum[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const T t = lin_unbits<T>(__double_as_longlong(raw));
+    const double v = DET ? (double)t * inv_scale : (double)t;     // (DET: the launch's exact integer sum becomes a double here: one rounding)
+    grad_out[k] = accumulate ? grad_out[k] + v : v;
+    __hip_atomic_store(&accum[k], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---- the last block to finish (bear_arrive_last): d/d mat[k] = sum over the blocks' partials [gridDim.x][LIN_MAX_GRAD] in a fixed
 // order -- three threads per entry take a third of the blocks each (independent loads, consecutive threads on consecutive
 // entries), their sums meet in `part` (3 * LIN_MAX_GRAD doubles of LDS).
@@ -1384,12 +1432,11 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     acc[1] = __builtin_fma(u * m, S.tabP[tid], acc[1]);
   }
   __syncthreads();
-  lin_fold_tables<DET>(S.GT, G, (int)tid, PLN_THREADS, grad_partials + (size_t)blockIdx.x * LIN_MAX_GRAD);
+  lin_fold_tables_add<DET>(S.GT, G, (int)tid, PLN_THREADS, grad_partials);     // (grad_partials: the launch's accumulator, bear_ws::lin_accum)
   block_store_partials<2, true>(acc, partials);      // (io.out is never NULL here: both entry points sum in this launch)
-  if (!bear_arrive_last(io.arrive())) return;
+  if (!bear_arrive_last(io.arrive())) return;        // (its s_waitcnt vmcnt(0) covers the atomics: they are acknowledged before a block arrives)
   __syncthreads();
-  lin_sum_block_partials<DET>(grad_partials, lag * 25, reinterpret_cast<double *>(srt_smem), (int)tid, PLN_THREADS, grad_out, accumulate != 0,
-                              DET ? 1.0 / gt_scale : 1.0);   // the tile loop is over: the dynamic LDS is free
+  lin_take_accum<DET>(grad_partials, lag * 25, (int)tid, PLN_THREADS, grad_out, accumulate != 0, DET ? 1.0 / gt_scale : 1.0);
   bear_finalize_in_block(partials, 2, io.out, io.arrive(), accumulate != 0);
   bear_apply_in_block(apply, io.out);
 }
