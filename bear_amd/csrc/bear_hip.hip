@@ -880,11 +880,12 @@ static int launch_ref_plan(bear_ws *ws, const bear_plan *plan, const uint32_t *r
     rv.heavy0 = plan->heavy0;
     rv.n_heavy0 = plan->n_heavy0;
     rv.sum0 = plan->sum0;
-    // 4 waves per block, ~3 units per wave: a block's fixed work (the log table into LDS, its partials, two arrival atomics, its
-    // share of the last block's sum) is worth about three units -- configs[1] (1e7 contexts, 11 000 units): 22.8 us per step on 3-4
-    // blocks per CU, 25.5 on 8 (one unit per wave), 27.3 on 2 (scripts/dev/cfg1_grid.py); larger tables reach the cap of 8 per CU either way
-    const uint64_t units = (plan->n_ref_items + 63) / 64, want = (units + 11) / 12 + 2;
-    grid = (int)(want < (uint64_t)ws->num_cu * 8 ? want : (uint64_t)ws->num_cu * 8);
+    // 4 waves per block; blocks per CU by measurement (scripts/dev/cfg1_grid.py: a block's fixed work -- the log table into LDS, its
+    // partials, two arrival atomics, its share of the last block's sum -- against the balance of more blocks): configs[1] (1e7
+    // contexts, ~3e4 units) 25.3 / 23.9 / 22.2 / 23.4 / 27.3 us per step on 8 / 6 / 4 / 3 / 2 blocks per CU, configs[3] (1.25e8
+    // contexts, ~4e5 units) 160 / 154 / 174 / 196 / 256 us
+    const uint64_t units = (plan->n_ref_items + 63) / 64, want = (units + 3) / 4 + 2, cap = (uint64_t)ws->num_cu * (units > 131072 ? 6 : 4);
+    grid = (int)(want < cap ? want : cap);
     if (train_ar)
       hipLaunchKernelGGL(dm_ref_items_kernel<true>, dim3(grid), dim3(256), 0, s, prm, rv, plan_view(plan), lt, ws->partials, io, apply);
     else
@@ -1091,8 +1092,8 @@ static void launch_linear(bear_ws *ws, const bear_plan *plan, const uint64_t *km
   // (the update, if any, goes with the step's LAST launch: the one that completes the sums)
 #define LIN_LAUNCH_D(AR, PAIRED, DET, PV, NT, ACC)                                                                                          \
   hipLaunchKernelGGL((dm_linear_plan_kernel<AR, PAIRED, DET>), dim3(grid_plan(ws, NT)), dim3(PLN_THREADS), sizeof(pln_lds_lin), s, kc, mat, \
-                     lag, prm, PV, lt, ws->partials, ws->lin_accum, (ACC) ? io2 : io, grad_mat, ACC, gt_bound,                            \
-                     ((ACC) || !two_launches) ? apply : NO_APPLY)
+                     lag, prm, PV, lt, ws->partials, ws->lin_accum, (ACC) == 1 ? io2 : io, grad_mat, ACC, gt_bound,                       \
+                     ((ACC) == 1 || !two_launches) ? apply : NO_APPLY)
 #define LIN_LAUNCH(AR, PAIRED, PV, NT, ACC)                    \
   do {                                                         \
     if (det) LIN_LAUNCH_D(AR, PAIRED, true, PV, NT, ACC);      \
@@ -1111,7 +1112,10 @@ static void launch_linear(bear_ws *ws, const bear_plan *plan, const uint64_t *km
   pp.tiles = plan->tiles_p;
   pp.n_tiles = plan->n_tiles_p;
   pp.subset = 1;
-  if (train_ar) LIN_LAUNCH(true, true, pp, plan->n_tiles_p, 0);
+  if (two_launches) {
+    if (train_ar) LIN_LAUNCH(true, true, pp, plan->n_tiles_p, 2);
+    else LIN_LAUNCH(false, true, pp, plan->n_tiles_p, 2);
+  } else if (train_ar) LIN_LAUNCH(true, true, pp, plan->n_tiles_p, 0);
   else LIN_LAUNCH(false, true, pp, plan->n_tiles_p, 0);
   if (plan->n_tiles_u == 0) return;
   pln_view pu = pv;           // the rest: tiles only

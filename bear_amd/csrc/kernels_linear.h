@@ -1173,7 +1173,7 @@ template <bool AR, bool PAIRED, bool DET = false>
 __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     const unsigned long long *__restrict__ kmer_code, const double *__restrict__ mat, int lag, bear_params prm_arg, pln_view pv,
     const double2 *__restrict__ logtab_g, double *__restrict__ partials, double *__restrict__ grad_partials,
-    const bear_step_io io, double *__restrict__ grad_out, int accumulate,    // accumulate: add to io.out / grad_out (second launch of a step)
+    const bear_step_io io, double *__restrict__ grad_out, int accumulate,    // 0: the step's only launch; 2: the first of two (d/d mat stays in the accumulator); 1: the second (adds to io.out, takes d/d mat)
     const lin_fx_bound gt_bound, const bear_apply_io apply) {   // apply.theta != NULL: the Adam update by the last block (grad_out == io.out + 2)
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_lin &S = *reinterpret_cast<pln_lds_lin *>(srt_smem);
@@ -1436,8 +1436,11 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
   block_store_partials<2, true>(acc, partials);      // (io.out is never NULL here: both entry points sum in this launch)
   if (!bear_arrive_last(io.arrive())) return;        // (its s_waitcnt vmcnt(0) covers the atomics: they are acknowledged before a block arrives)
   __syncthreads();
-  lin_take_accum<DET>(grad_partials, lag * 25, (int)tid, PLN_THREADS, grad_out, accumulate != 0, DET ? 1.0 / gt_scale : 1.0);
-  bear_finalize_in_block(partials, 2, io.out, io.arrive(), accumulate != 0);
+  // a step of two launches (paired tiles, then the tiles that kept their plain lists): the first leaves its d/d mat in the
+  // accumulator, the second takes the sum of both -- in the deterministic mode ONE conversion of the exact integer total, whatever
+  // the split of the tiles between the two forms
+  if (accumulate != 2) lin_take_accum<DET>(grad_partials, lag * 25, (int)tid, PLN_THREADS, grad_out, false, DET ? 1.0 / gt_scale : 1.0);
+  bear_finalize_in_block(partials, 2, io.out, io.arrive(), accumulate == 1);
   bear_apply_in_block(apply, io.out);
 }
 

@@ -280,8 +280,11 @@ int bear_plan_pair_contexts(bear_plan *plan, const uint64_t *kmer_index, int lag
  *     scaled by 2^62 / bound, where bound >= the sum of |gradient| over everything that is added into one gradient -- derived from
  *     the table's counts (sum, non-zero cells, maximum) and the launch's h (kernels_linear.h, lin_fx_bound):
  *     d/d mat is then the exact integer sum of the contexts' rounded gradients -- independent of the order of the adds, of the
- *     cut into tiles and blocks and of the form of the plan's lists -- turned into a double once at the end.  Each context's
- *     gradient is rounded to bound * 2^-62 (instead of to its own last bit).
+ *     cut into tiles and blocks and of the form of the plan's lists (a step that takes two launches -- paired tiles, then the
+ *     tiles that kept their plain lists -- keeps the first launch's integers in the workspace's accumulator: round 6) -- turned into
+ *     a double once at the end of the STEP.  Each context's gradient is rounded to bound * 2^-62 (instead of to its own last bit).
+ *     Across ranks every rank converts its own integer sum before the all-reduce adds the doubles: bit-reproducible for a given
+ *     number of ranks and cut of the batch, equal to rounding (<= 1e-15 of the largest entry) between different ones.
  *   bear_cnn_backward_f64 / bear_net_cnn_train_*: the backward kernel runs ONE wave per block (the block's gradient image takes its
  *     adds in program order); reproducible from run to run for a given launch geometry, at an eighth of the waves per CU.
  * The scalar sums (sum LL, d/dh, d/dtau, d/dnet_weight) are fixed-order sums in every mode.
