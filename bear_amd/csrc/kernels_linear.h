@@ -1169,7 +1169,17 @@ __device__ unsigned long long lin_stamp_sums[8];
 #define LIN_STAMP(k)
 #endif
 // DET (BEAR_AMD_DETERMINISTIC): the gradient tables hold fixed-point integers, gt_scale = 2^50 / bound (see lin_fx above)
-template <bool AR, bool PAIRED, bool DET = false>
+// NGK: the number of letter groups as a compile-time constant (0: taken from `lag` at run time through LIN_FOR_NG).  With it a
+// launch's kernel holds ONE form of phases A and C instead of ten behind a switch inside the tile loop: a tenth of the code (the
+// instruction cache), no dispatch, and the register allocator sees one variant (round 6).
+#define LIN_FOR_NGK(ng, CALL)                    \
+  if (NGK != 0) {                                \
+    constexpr int NG = NGK ? NGK : 1;            \
+    CALL;                                        \
+  } else {                                       \
+    LIN_FOR_NG(ng, CALL)                         \
+  }
+template <bool AR, bool PAIRED, bool DET = false, int NGK = 0>
 __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     const unsigned long long *__restrict__ kmer_code, const double *__restrict__ mat, int lag, bear_params prm_arg, pln_view pv,
     const double2 *__restrict__ logtab_g, double *__restrict__ partials, double *__restrict__ grad_partials,
@@ -1265,16 +1275,16 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     n_live = rows ? srt_uniform((uint32_t)B.live[0]) : 0u;
     rowA = 0xffffffffu;
     if (PAIRED) {
-      LIN_FOR_NG(ng, rowA = (lin_phase_a_paired<NG, EXP>(S, B, n_live, tid, fA, cA)))
+      LIN_FOR_NGK(ng, rowA = (lin_phase_a_paired<NG, EXP>(S, B, n_live, tid, fA, cA)))
     } else {
-      LIN_FOR_NG(ng, rowA = (lin_phase_a<NG, EXP>(S, B, n_live, tid, fA, cA)))
+      LIN_FOR_NGK(ng, rowA = (lin_phase_a<NG, EXP>(S, B, n_live, tid, fA, cA)))
     }
   };
   auto phase_c = [&]() {
     if (PAIRED) {
-      LIN_FOR_NG(ng, (lin_phase_c_paired<NG, DET>(S, n_live, tid, lane, fA, cA, rowA, gt_scale)))
+      LIN_FOR_NGK(ng, (lin_phase_c_paired<NG, DET>(S, n_live, tid, lane, fA, cA, rowA, gt_scale)))
     } else {
-      LIN_FOR_NG(ng, (lin_phase_c<NG, DET>(S, n_live, tid, lane, fA, cA, rowA, acc, gt_scale)))
+      LIN_FOR_NGK(ng, (lin_phase_c<NG, DET>(S, n_live, tid, lane, fA, cA, rowA, acc, gt_scale)))
     }
   };
 
@@ -1393,9 +1403,9 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     double f[5];
     cv = kmer_code[row];
     if (exp_tables) {
-      LIN_FOR_NG(ng, (lin_row<NG, true>(S.T, S.exptab, cv, f)))
+      LIN_FOR_NGK(ng, (lin_row<NG, true>(S.T, S.exptab, cv, f)))
     } else {
-      LIN_FOR_NG(ng, (lin_row<NG, false>(S.T, S.exptab, cv, f)))
+      LIN_FOR_NGK(ng, (lin_row<NG, false>(S.T, S.exptab, cv, f)))
     }
     double q;
     if (AR) {

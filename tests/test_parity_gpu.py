@@ -988,3 +988,32 @@ def test_reference_aware_plan_full_size(dev):
     rf_m = t["ref"][:m].clone()
     got = kernels.dm_ref_planned(kernels.Plan(t["train"][:m].clone(), 4, ref=rf_m), rf_m, *args).cpu().numpy()
     assert np.allclose(got, want, rtol=1e-10)
+
+
+@pytest.mark.parametrize("lag", [5, 13, 14, 9])
+def test_fused_linear_head_group_count_specialisations(lag, monkeypatch):
+    """`launch_linear` takes a kernel with the number of letter groups as a compile-time constant for the common lags (12 / 13: 6
+    groups, 14 / 15: 7, 4 / 5: 2) and the run-time form (`LIN_FOR_NG`) for the rest; BEAR_AMD_LINEAR_GENERIC=1 forces the latter.
+    Same arithmetic in the same order: sum LL and d/dh equal to rounding of the draw of the work units, d/d mat to 1e-12 of its largest
+    entry, plain and paired lists, both modes."""
+    from bear_amd import kernels
+    dev = torch.device("cuda", 0)
+    n = 300_000
+    t = kernels.synth_counts(11, 0, n, dev, want=("train",))["train"]
+    codes = kernels.synth_kmer_codes(5, 0, min(n, 4 ** lag), lag, dev, sort=True)
+    if codes.shape[0] < n:                      # (lag 5: 1024 k-mers exist -- repeat them: copies of a k-mer are neighbours)
+        codes = codes.repeat_interleave(-(-n // codes.shape[0]), dim=0)[:n].contiguous()
+    idx = kernels.linear_index(kernels.pack_kmers(codes), lag)
+    mat = 0.2 * torch.randn(lag, 5, 5, dtype=torch.float64, device=dev, generator=torch.Generator(dev).manual_seed(2))
+    plan = kernels.Plan(t, 5)
+    for paired in (False, True):
+        if paired:
+            plan.pair_contexts(idx, lag)
+        for train_ar in (False, True):
+            monkeypatch.delenv("BEAR_AMD_LINEAR_GENERIC", raising=False)
+            a = [x.clone() for x in kernels.dm_linear(plan, idx, mat, -0.3, train_ar=train_ar)]
+            monkeypatch.setenv("BEAR_AMD_LINEAR_GENERIC", "1")
+            b = [x.clone() for x in kernels.dm_linear(plan, idx, mat, -0.3, train_ar=train_ar)]
+            assert torch.allclose(a[0], b[0], rtol=1e-12, atol=0), (lag, paired, train_ar)
+            assert float((a[1] - b[1]).abs().max()) <= 1e-12 * float(b[1].abs().max()), (lag, paired, train_ar)
+    monkeypatch.delenv("BEAR_AMD_LINEAR_GENERIC", raising=False)
