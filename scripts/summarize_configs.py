@@ -19,7 +19,9 @@ for k in (1, 2, 3, 4):
     txt = open(logs[0]).read()
     m = re.search(r"\{.*\}", txt, re.S)
     ent = json.loads(m.group(0)) if m else {}
-    name, cfg = next(((n, v) for n, v in ent.items() if isinstance(v, dict)), ("configs[%d]" % k, {}))
+    # (a process that trains several times -- configs[4]: the record's shard, then a rank's piece cut both ways -- : the trace's
+    # last `optimizer_steps` step markers belong to the LAST train() call, so that entry is the one reported)
+    name, cfg = ([(n, v) for n, v in ent.items() if isinstance(v, dict)] or [("configs[%d]" % k, {})])[-1]
     rows = sorted(csv.DictReader(open(kt[0])), key=lambda r: int(r["Start_Timestamp"]))
     steps = int(cfg.get("optimizer_steps", 0))
     # the optimizer loop = the last stretch of launches whose kernels repeat; take the launches of the second half of the trace's
