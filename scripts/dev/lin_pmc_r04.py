@@ -7,13 +7,18 @@ import torch
 from bear_amd import kernels, ar_funcs
 N, LAG = int(float(os.environ.get("N", "1e8"))), 13
 dev = torch.device("cuda", 0)
-t = kernels.synth_counts(20211012, 0, N, dev, want=("train",))["train"]
-codes = torch.randint(0, 4, (N, LAG), dtype=torch.int8, device=dev, generator=torch.Generator(dev).manual_seed(20211012))
-key = torch.zeros(N, dtype=torch.int64, device=dev)
-for l in range(LAG):
-    key = key * 6 + codes[:, l].to(torch.int64)
-order = torch.argsort(key); del key
-tr = t[order].contiguous(); idx = kernels.linear_index(kernels.pack_kmers(codes[order].contiguous()), LAG); del order, codes, t
+if os.environ.get("TABLE") == "distinct13":      # round 6: DISTINCT contexts (kernels.synth_kmer_ids); N <= 4^13
+    N = min(N, 60_000_000)
+    tr = kernels.synth_counts(20211012, 0, N, dev, want=("train",))["train"]
+    idx = kernels.linear_index(kernels.pack_kmers(kernels.synth_kmer_codes(20211012, 0, N, LAG, dev, sort=True)), LAG)
+else:
+    t = kernels.synth_counts(20211012, 0, N, dev, want=("train",))["train"]
+    codes = torch.randint(0, 4, (N, LAG), dtype=torch.int8, device=dev, generator=torch.Generator(dev).manual_seed(20211012))
+    key = torch.zeros(N, dtype=torch.int64, device=dev)
+    for l in range(LAG):
+        key = key * 6 + codes[:, l].to(torch.int64)
+    order = torch.argsort(key); del key
+    tr = t[order].contiguous(); idx = kernels.linear_index(kernels.pack_kmers(codes[order].contiguous()), LAG); del order, codes, t
 torch.manual_seed(0)
 _, (mat,) = ar_funcs.make_ar_func_linear(LAG, 4, device=dev)
 plan = kernels.Plan(tr, 5)
