@@ -1194,6 +1194,9 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
   const int ng = G.ng;
   double acc[2] = {0.0, 0.0};
   const double gt_scale = DET ? lin_fx_scale(gt_bound, u, AR) : 0.0;
+  // every item's argument x = f u + eps has f in [0, 1] (a softmax row formed by this kernel): inside the product path's domain
+  // (0, SRT_XMAX] whenever eps > 0 and u + eps <= SRT_XMAX -- the item units then skip their domain test (srt_light)
+  const bool x_in_domain = srt_uniform((uint32_t)(eps > 0.0 && u > 0.0 && u + eps <= SRT_XMAX)) != 0u;
 
   if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
   if (tid < SRT_NKEY) {
@@ -1355,7 +1358,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
       const uint32_t off = items[un * 64u + lane];
       const double x[1] = {__builtin_fma(S.pri[off], u, eps)};
       bear_dp o[1] = {{0.0, 0.0}};
-      if (!AR) srt_light<1>(x, ci, cmin, cmax, S.logtab, o);
+      if (!AR) srt_light<1>(x, ci, cmin, cmax, S.logtab, o, x_in_domain);
       if (off != (uint32_t)PLN_SENTINEL) item(off, o[0].D, o[0].P, x[0], (double)ci[0]);
     }
     LIN_STAMP(0)     // B: items

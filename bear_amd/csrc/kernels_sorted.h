@@ -124,9 +124,11 @@ __device__ __noinline__ bear_dp srt_general_fast(double x, double c, const doubl
 // Every lane runs `cmin` un-predicated factors (wave-uniform lower bound of the occupied lanes'
 // counts; unoccupied lanes carry c == 0 and a harmless x), then the ragged remainder up to `cmax`
 // under predication.  c == 0 yields D = P = 0.
+// `in_domain` (wave-uniform): the CALLER guarantees 0 < x <= SRT_XMAX for every occupied lane (the linear step: x = f u + eps with
+// f a softmax output it formed itself), so the per-unit domain test -- eight vector instructions of a unit's ~95 -- is skipped.
 template <int ILP>
 __device__ __forceinline__ void srt_light(const double (&x)[ILP], const uint32_t (&c)[ILP], uint32_t cmin, uint32_t cmax,
-                                          const double2 *logtab, bear_dp (&o)[ILP]) {
+                                          const double2 *logtab, bear_dp (&o)[ILP], bool in_domain = false) {
   double p[ILP], dp[ILP], t[ILP];
 #pragma unroll
   for (int i = 0; i < ILP; ++i) {
@@ -158,10 +160,10 @@ __device__ __forceinline__ void srt_light(const double (&x)[ILP], const uint32_t
     const bool live = c[i] != 0;
     o[i].D = live ? bear_log_tab(p[i], logtab) : 0.0;
     o[i].P = live ? dp[i] * bear_rcp(p[i]) : 0.0;
-    odd |= live && !(x[i] > 0.0 && x[i] <= SRT_XMAX);
+    if (!in_domain) odd |= live && !(x[i] > 0.0 && x[i] <= SRT_XMAX);
   }
   // Out-of-domain / out-of-range arguments take the general routine (rare, wave-uniform test).
-  if (__builtin_amdgcn_ballot_w64(odd)) {
+  if (!in_domain && __builtin_amdgcn_ballot_w64(odd)) {
 #pragma unroll
     for (int i = 0; i < ILP; ++i)
       if (c[i] != 0 && !(x[i] > 0.0 && x[i] <= SRT_XMAX)) o[i] = srt_general(x[i], (double)c[i]);
