@@ -413,8 +413,8 @@ int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int n
   p->ncol = ncol;
   p->n_rows = n_rows;
   p->counts = counts;
-  hipError_t e = hipMalloc(&p->hist, sizeof(unsigned long long) * 2 * SRT_NKEY);
-  if (e == hipSuccess) e = hipMemset(p->hist, 0, sizeof(unsigned long long) * 2 * SRT_NKEY);
+  hipError_t e = hipMalloc(&p->hist, sizeof(unsigned long long) * (2 * SRT_NKEY + PLN_NBIG + 1));     // (+ the large totals' histogram)
+  if (e == hipSuccess) e = hipMemset(p->hist, 0, sizeof(unsigned long long) * (2 * SRT_NKEY + PLN_NBIG + 1));
   if (e != hipSuccess) {
     g_last_hip_error = (int)e;
     plan_free(p);
@@ -698,6 +698,8 @@ static pln_view plan_view(const bear_plan *p) {
   v.heavy_row = p->heavy_row;
   v.heavy_stop = p->heavy_stop;
   v.hist = p->hist;
+  v.hist_big = p->hist + 2 * SRT_NKEY;
+  v.big_in_hist = 1;
   v.live = p->live;
   v.live2 = p->live2;
   v.subset = 0;
@@ -1134,6 +1136,7 @@ static void launch_linear(bear_ws *ws, const bear_plan *plan, const uint64_t *km
   pu.subset = 1;
   pu.n_heavy_col = pu.n_heavy_row = pu.n_heavy_stop = 0;
   pu.hist = nullptr;
+  pu.hist_big = nullptr;
   if (train_ar) LIN_LAUNCH(true, false, pu, plan->n_tiles_u, 1);
   else LIN_LAUNCH(false, false, pu, plan->n_tiles_u, 1);
 #undef LIN_LAUNCH

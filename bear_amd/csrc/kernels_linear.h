@@ -1344,11 +1344,16 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
         continue;
       }
       if (w < n_hcu + n_hru) {  // contexts with a large total: context terms only (no gradient: the base cancels)
+        // (totals up to PLN_NBIG are in the plan's histogram -- pln_big_totals below: on a k-mer table the whole unit is skipped)
         const uint32_t i = (w - n_hcu) * 64u + lane;
-        if (i < hr) {
-          const bear_dp o = srt_general_fast(u + eps5, reinterpret_cast<const double *>(B.blk + L.hn)[i], S.logtab);
-          acc[0] -= o.D;
-          acc[1] = __builtin_fma(u, o.P, acc[1]);
+        const double n = i < hr ? reinterpret_cast<const double *>(B.blk + L.hn)[i] : 0.0;
+        const bool mine = i < hr && !pln_in_big_hist(pv, n);
+        if (__builtin_amdgcn_ballot_w64(mine)) {
+          if (mine) {
+            const bear_dp o = srt_general_fast(u + eps5, n, S.logtab);
+            acc[0] -= o.D;
+            acc[1] = __builtin_fma(u, o.P, acc[1]);
+          }
         }
         continue;
       }
@@ -1435,10 +1440,13 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     }
   }
   for (uint64_t i = gtid; !AR && i < pv.n_heavy_row; i += gsz) {
-    const bear_dp o = srt_general_fast(u + eps5, pv.heavy_row[i].n, S.logtab);
+    const double n = pv.heavy_row[i].n;
+    if (pln_in_big_hist(pv, n)) continue;
+    const bear_dp o = srt_general_fast(u + eps5, n, S.logtab);
     acc[0] -= o.D;
     acc[1] = __builtin_fma(u, o.P, acc[1]);
   }
+  if (!AR) pln_big_totals(pv, u + eps5, u, gtid, gsz, S.logtab, acc[0], acc[1]);      // totals in (SRT_CL, PLN_NBIG]: the plan's histogram
   if (!AR && pv.hist && blockIdx.x == 0 && tid < SRT_CL) {  // context terms of the small totals: the plan's histogram
     const double m = (double)pv.hist[tid];
     acc[0] -= m * S.tabD[tid];

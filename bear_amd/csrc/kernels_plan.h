@@ -44,6 +44,13 @@
 #ifndef PLN_HCAP
 #define PLN_HCAP 128                          // large-count items / contexts evaluated inside a tile (rest: global lists)
 #endif
+// Row totals n in (SRT_CL, PLN_NBIG] are ALSO counted in a histogram of the plan (bear_plan::hist + 2 SRT_NKEY, [n]): where every
+// context shares its concentration total A (softmax rows: A = u + 5 eps; mode R always) the context term -D(A, n) is a function of n
+// alone, and sum over rows = sum_n count[n] D(A, n) -- a few thousand Stirling evaluations per LAUNCH instead of one per row
+// (5 % of the rows of the k = 13 table: a 64-lane unit of ~400 dependent instructions per tile, and 3.5e5 evaluations in the mode-R
+// step of configs[1]).  The lists keep every such row (kernels with a concentration total per row read them as before); kernels
+// that take the histogram skip the listed rows with n <= PLN_NBIG (round 6).
+#define PLN_NBIG 4096
 #define PLN_BLOCKS_PER_CU (1024 / PLN_THREADS)   // resident blocks of the planned step kernels per CU (LDS: 160 KB / that many)
 #define PLN_QUAD 4                            // tiles start on multiples of 4 contexts (16-byte aligned rows)
 #define PLN_LIVE_STRIDE (PLN_RMAX + 8)        // uint16 per tile of the live-context lists (a multiple of 8: 16-byte rows)
@@ -111,6 +118,7 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
                                                         unsigned long long *__restrict__ hist) {
   __shared__ uint32_t s_heavy[3];
   __shared__ uint32_t s_hist[2 * SRT_NKEY];
+  __shared__ uint32_t s_big[PLN_NBIG + 1];          // row totals in (SRT_CL, PLN_NBIG]: hist[2 SRT_NKEY + n]
   __shared__ unsigned long long s_total, s_cells;   // sum of all counts / cells that hold one (heavy_counts[6], [7]: bear_plan::count_total)
   __shared__ uint32_t s_cmax;                       // largest count (heavy_counts[8])
   unsigned long long my_total = 0ull;
@@ -121,6 +129,7 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
   }
   if (threadIdx.x < 3) s_heavy[threadIdx.x] = 0;
   if (threadIdx.x < 2 * SRT_NKEY) s_hist[threadIdx.x] = 0;
+  for (uint32_t k = threadIdx.x; k <= PLN_NBIG; k += 256) s_big[k] = 0;
   __syncthreads();
   const uint64_t n_quads = (n_rows + PLN_QUAD - 1) / PLN_QUAD;
   for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < n_quads; g += (uint64_t)gridDim.x * 256) {
@@ -143,8 +152,10 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
       qhc += hcol;
       qhr += nsat > SRT_CL;
       if (hcol) atomicAdd(&s_heavy[0], hcol);
-      if (nsat > SRT_CL) atomicAdd(&s_heavy[1], 1u);
-      else if (nsat != 0) atomicAdd(&s_hist[nsat - 1], 1u);
+      if (nsat > SRT_CL) {
+        atomicAdd(&s_heavy[1], 1u);
+        if (nsat <= PLN_NBIG) atomicAdd(&s_big[nsat], 1u);
+      } else if (nsat != 0) atomicAdd(&s_hist[nsat - 1], 1u);
       const uint32_t c4 = counts[r * 5 + 4];
       if (ncol == 4 && c4 > SRT_CL) atomicAdd(&s_heavy[2], 1u);
       else if (ncol == 4 && c4 != 0) atomicAdd(&s_hist[SRT_NKEY + c4 - 1], 1u);
@@ -166,6 +177,8 @@ __global__ __launch_bounds__(256) void plan_scan_kernel(const uint32_t *__restri
   }
   if (threadIdx.x < 3 && s_heavy[threadIdx.x]) atomicAdd(&heavy_counts[threadIdx.x], (unsigned long long)s_heavy[threadIdx.x]);
   if (threadIdx.x < 2 * SRT_NKEY && s_hist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)s_hist[threadIdx.x]);
+  for (uint32_t k = threadIdx.x; k <= PLN_NBIG; k += 256)
+    if (s_big[k]) atomicAdd(&hist[2 * SRT_NKEY + k], (unsigned long long)s_big[k]);
 }
 
 // ---- tile cutting on the device --------------------------------------------------------------------------------------------
@@ -590,11 +603,31 @@ struct pln_view {  // device-side view of a plan
   const pln_heavy_row *heavy_row;
   const uint64_t *heavy_stop;
   const unsigned long long *hist;  // [0..31] contexts with total n = j+1, [32..63] with stop count j+1 (<= SRT_CL)
+  const unsigned long long *hist_big;   // [n], SRT_CL < n <= PLN_NBIG: contexts with that total (also in the lists); NULL: this launch does not add them
+  int big_in_hist;                 // the listed rows with a total <= PLN_NBIG are accounted for by the histogram (this launch's, or -- a
+                                   // step of two launches over subsets of the tiles -- its sibling's): kernels that take it skip them
   uint64_t n_tiles, n_heavy_col, n_heavy_row, n_heavy_stop;
   const uint16_t *live;            // [n_tiles][PLN_LIVE_STRIDE] (five-column plans): [0] = contexts with counts, then their rows, ascending
   const uint16_t *live2;           // [n_tiles][LIN_LIVE2_STRIDE] or NULL: the paired form of `live` for one set of k-mers (kernels_linear.h)
   int subset;                      // `tiles` is a subset of the plan's tiles: a descriptor's spare word holds (tile number << 32 | list length)
 };
+
+// Context terms of the rows with a total in (SRT_CL, PLN_NBIG] from the plan's histogram, for kernels whose contexts share the
+// concentration total A: acc_D -= m D(A, n), acc_P += scale m P(A, n), the bins dealt over the launch's threads.
+__device__ __forceinline__ void pln_big_totals(const pln_view &pv, double A, double scale, uint64_t gtid, uint64_t gsz, const double2 *logtab,
+                                               double &acc_D, double &acc_P) {
+  if (!pv.hist_big) return;
+  for (uint64_t n = SRT_CL + 1 + gtid; n <= PLN_NBIG; n += gsz) {
+    const unsigned long long m = pv.hist_big[n];
+    if (m) {
+      const bear_dp o = srt_general_fast(A, (double)n, logtab);
+      acc_D -= (double)m * o.D;
+      acc_P = __builtin_fma(scale * (double)m, o.P, acc_P);
+    }
+  }
+}
+// ... and whether a listed row is one of them (then the histogram has it)
+__device__ __forceinline__ bool pln_in_big_hist(const pln_view &pv, double n) { return pv.big_in_hist && n <= (double)PLN_NBIG; }
 
 // DMA of `bytes` (multiple of 16) to LDS: 1 KiB pieces round-robin over the waves starting at wave
 // `first` (so successive slabs spread over different waves), the last piece with surplus lanes masked.
@@ -1261,10 +1294,13 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_ref_plan_kernel(const uint3
     return;
   }
   for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
-    const bear_dp o = srt_general_fast(A, pv.heavy_row[i].n, S.logtab);
+    const double n = pv.heavy_row[i].n;
+    if (pln_in_big_hist(pv, n)) continue;      // (totals up to PLN_NBIG: the plan's histogram, next line)
+    const bear_dp o = srt_general_fast(A, n, S.logtab);
     acc[0] -= o.D;
     acc[1] = __builtin_fma(u, o.P, acc[1]);
   }
+  pln_big_totals(pv, A, u, gtid, gsz, S.logtab, acc[0], acc[1]);
   for (uint64_t i = gtid; i < pv.n_heavy_stop; i += gsz) {
     const bear_dp o = srt_general_fast(x4, (double)pv.heavy_stop[i], S.logtab);
     acc[0] += o.D;

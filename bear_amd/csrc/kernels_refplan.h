@@ -207,10 +207,13 @@ __global__ __launch_bounds__(256) void dm_ref_items_kernel(bear_params prm_arg, 
   for (uint64_t i = gtid; i < rv.n_heavy0; i += gsz) accumulate(x0, 1.0, srt_general_fast(x0, (double)rv.heavy0[i], s_log));
   // ---- context terms and the stop column: shared concentrations, the plan's histograms (as dm_ref_plan_kernel)
   for (uint64_t i = gtid; i < pv.n_heavy_row; i += gsz) {
-    const bear_dp o = srt_general_fast(A, pv.heavy_row[i].n, s_log);
+    const double n = pv.heavy_row[i].n;
+    if (pln_in_big_hist(pv, n)) continue;      // (totals up to PLN_NBIG: the plan's histogram, next line)
+    const bear_dp o = srt_general_fast(A, n, s_log);
     acc[0] -= o.D;
     acc[1] = __builtin_fma(u, o.P, acc[1]);
   }
+  pln_big_totals(pv, A, u, gtid, gsz, s_log, acc[0], acc[1]);
   for (uint64_t i = gtid; i < pv.n_heavy_stop; i += gsz) {
     const bear_dp o = srt_general_fast(x4, (double)pv.heavy_stop[i], s_log);
     acc[0] += o.D;
