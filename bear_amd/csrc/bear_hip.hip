@@ -1658,8 +1658,10 @@ int bear_debug_read_timing(bear_ws *ws, unsigned long long *host, int n_words) {
 }
 
 // Developer probe: the paired lists (bear_plan_pair_contexts) of tiles [first, first + n) and their first rows, to the host
-// (scripts/dev/pair_conflicts.py counts the bank-pair collisions of the triple adds from them).
+// (scripts/dev/pair_conflicts.py counts the bank-pair collisions of the triple adds from them).  A row is LIN_LIVE2_STRIDE uint16:
+// [0] = entries m, [1] = 0, m entries, then lin_lev_len(m) level words; a call with lists == NULL returns that stride instead.
 extern "C" int bear_debug_pair_lists(const bear_plan *plan, uint64_t first, uint64_t n, uint16_t *lists, uint64_t *row0) {
+  if (!lists) return (int)LIN_LIVE2_STRIDE;
   if (!plan || !plan->live2 || !lists || !row0 || first + n > plan->n_tiles) return BEAR_ERR_INVALID_ARG;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(lists, plan->live2 + first * LIN_LIVE2_STRIDE, n * LIN_LIVE2_STRIDE * sizeof(uint16_t), hipMemcpyDeviceToHost));

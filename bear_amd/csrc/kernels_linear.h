@@ -65,7 +65,13 @@
 #define LIN_ROW_THREADS (PLN_THREADS - 64 * LIN_DMA_WAVES)     // (see "The waves that issue a tile's DMA" below)
 #endif
 #define LIN_PAIR_CAP (2 * LIN_ROW_THREADS)                  // entries the row threads of a block take (LIN_RPT * LIN_ROW_THREADS, asserted below)
-#define LIN_LIVE2_STRIDE (LIN_PAIR_CAP + 8)                 // uint16 per tile of the paired lists (a multiple of 8: 16-byte rows)
+// Behind a tile's entries the list carries one LEVEL word per pair, padded to whole units of 64 pairs: how many LEADING pair groups
+// the pair's unit of 64 / its row of 16 / its quad share (bits 0-3 / 4-7 / 8-11).  They decide which of phase C's adds a lane makes
+// and depend on the k-mers alone, so the builder works them out once per batch instead of every wave of every launch (~35
+// vector instructions of cross-lane ORs and bit scans per 128 contexts: round 6).
+#define LIN_LEV_CAP (((LIN_PAIR_CAP / 2) + 63) / 64 * 64)
+#define LIN_LIVE2_STRIDE ((2 + LIN_PAIR_CAP + LIN_LEV_CAP + 7) / 8 * 8)   // uint16 per tile of the paired lists (a multiple of 8: 16-byte rows)
+__host__ __device__ inline uint32_t lin_lev_len(uint32_t n_ent) { return ((n_ent >> 1) + 63u) & ~63u; }      // level words behind n_ent entries
 #define LIN_EMPTY 0xffffu
 
 struct lin_buf {
@@ -178,6 +184,7 @@ __global__ void linear_index_kernel(const unsigned long long *__restrict__ raw, 
 // left, its next context's row class and whether that context has a copy behind it) and a pick is three 16-lane maxima instead
 // of a scan over the classes; the lanes write the list out.  (A thread per tile out of global memory was latency-bound: 43 ms per
 // 1e8 contexts and 13 ms for any small batch; one lane per tile out of LDS 54 ms: ~400 dependent instructions per pick.)
+__device__ __forceinline__ uint32_t lin_pair_levels(unsigned long long cv, uint32_t lane, uint32_t np);      // (below, next to its consumer)
 __device__ __forceinline__ uint32_t lin_max16(uint32_t v) {       // the maximum over lanes 0..15 (the other lanes hold 0), in every one of them
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) {
@@ -324,6 +331,15 @@ __global__ __launch_bounds__(64) void plan_pair_kernel(const pln_tile *__restric
     uint16_t *out = live2 + t * LIN_LIVE2_STRIDE;
     if (fits)
       for (uint32_t i = lane; i < m; i += 64) out[2 + i] = out_l[2 + i];
+    if (fits && m) {
+      // the level words (lin_pair_levels), a unit of 64 pairs at a time; lanes beyond the list's last pair repeat it
+      const uint32_t n_pairs = m >> 1;
+      for (uint32_t u0 = 0; u0 < n_pairs; u0 += 64u) {
+        const uint32_t pr = u0 + lane < n_pairs ? u0 + lane : n_pairs - 1u;
+        const unsigned long long cv = kmer_index[row0 + out_l[2 + 2u * pr]] & pair_mask;
+        out[2 + m + u0 + lane] = (uint16_t)lin_pair_levels(cv, lane, (uint32_t)G.npair);
+      }
+    }
     if (lane == 0) {
       out[0] = fits ? (uint16_t)m : (uint16_t)0;
       out[1] = 0;
@@ -841,12 +857,59 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uin
   }
 }
 
+// ---- the level word of a lane's pair inside its unit of 64 pairs (cv: the pair groups' bits of its index word; lanes beyond the end
+// of a list hold the last pair's): leading pair groups shared by the unit | by my row of 16 << 4 | by my quad << 8.  e = my word xor my
+// predecessor's (wave_ror:1); a row shares the groups below the lowest set bit of the OR of e over its lanes 1..15, the unit those
+// below the lowest set bit of the OR over all lanes (lane 0's e = word 0 xor word 63 is the xor of all the others: it cannot
+// lower that bit), a quad likewise over its lanes 1..3.  Run by plan_pair_kernel (one wave per tile) when the lists are built.
+__device__ __forceinline__ uint32_t lin_pair_levels(unsigned long long cv, uint32_t lane, uint32_t np) {
+  const uint32_t clo = (uint32_t)cv, chi = (uint32_t)(cv >> 32);
+  const uint32_t elo = clo ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clo, 0x13C, 0xf, 0xf, false);
+  const uint32_t ehi = chi ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)chi, 0x13C, 0xf, 0xf, false);
+  const bool row_first = (lane & 15u) == 0u;
+  uint32_t rlo = row_first ? 0u : elo, rhi = row_first ? 0u : ehi;
+  rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x121, 0xf, 0xf, false);   // row_ror:1, 2, 4, 8: OR over the row in every lane
+  rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x121, 0xf, 0xf, false);
+  rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x122, 0xf, 0xf, false);
+  rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x122, 0xf, 0xf, false);
+  rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x124, 0xf, 0xf, false);
+  rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x124, 0xf, 0xf, false);
+  rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x128, 0xf, 0xf, false);
+  rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x128, 0xf, 0xf, false);
+  uint32_t wlo = rlo | elo, whi = rhi | ehi;                     // lanes 0, 16, 32, 48 carry the steps between rows
+  {
+    auto a = __builtin_amdgcn_permlane16_swap(wlo, wlo, false, false);
+    auto c = __builtin_amdgcn_permlane16_swap(whi, whi, false, false);
+    wlo = a[0] | a[1];
+    whi = c[0] | c[1];
+    a = __builtin_amdgcn_permlane32_swap(wlo, wlo, false, false);
+    c = __builtin_amdgcn_permlane32_swap(whi, whi, false, false);
+    wlo = a[0] | a[1];
+    whi = c[0] | c[1];
+  }
+  const unsigned long long wave_or = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)whi) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readfirstlane((int)wlo);
+  const unsigned long long row_or = ((unsigned long long)rhi << 32) | rlo;
+  const bool quad_first = (lane & 3u) == 0u;
+  uint32_t qlo = quad_first ? 0u : elo, qhi = quad_first ? 0u : ehi;
+  qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2], [2,3,0,1]
+  qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0xB1, 0xf, 0xf, false);
+  qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0x4E, 0xf, 0xf, false);
+  qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0x4E, 0xf, 0xf, false);
+  const unsigned long long quad_or = ((unsigned long long)qhi << 32) | qlo;
+  // group of bit position p: p / 6 (only pair bits are in the words: no clamp beyond np); 43 / 256 ~ 1 / 6 is exact for p < 64
+  const uint32_t l_wave = wave_or ? ((uint32_t)(__builtin_ctzll(wave_or) * 43) >> 8) : np;
+  const uint32_t l_row = row_or ? ((uint32_t)(__builtin_ctzll(row_or) * 43) >> 8) : np;
+  const uint32_t l_quad = quad_or ? ((uint32_t)(__builtin_ctzll(quad_or) * 43) >> 8) : np;
+  return l_wave | (l_row << 4) | (l_quad << 8);
+}
+
 // ---- lin_scatter_grad for 64 PAIRS of contexts (c0, c1 share every pair group; g0 / g1 their gradients, zero where there is no
 // context or no item): the pair groups take the pair's SUM gs through the same wave / row-of-16 / quad levels -- one reduction, one
 // run detection and one add per level for 128 contexts -- and each context adds its own g to its triple row.
 template <int NG, typename T>
 __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned long long c0, unsigned long long c1, const T (&g0)[4],
-                                                        const T (&g1)[4], bool nz0, bool nz1, uint32_t lane) {
+                                                        const T (&g1)[4], bool nz0, bool nz1, uint32_t lane, uint32_t lev) {
   constexpr uint32_t NP = NG - 1;          // pair groups: the only ones the levels may share
   if (NP > 0) {
     const T gs[4] = {g0[0] + g1[0], g0[1] + g1[1], g0[2] + g1[2], g0[3] + g1[3]};
@@ -854,44 +917,8 @@ __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned lon
     const uint32_t bl = lin_letter(lane);
     const unsigned long long pm = (1ull << (6 * NP)) - 1ull;
     const unsigned long long cv = c0 & pm;
-    const uint32_t clo = (uint32_t)cv, chi = (uint32_t)(cv >> 32);
-    const uint32_t elo = clo ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)clo, 0x13C, 0xf, 0xf, false);
-    const uint32_t ehi = chi ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)chi, 0x13C, 0xf, 0xf, false);
-    const bool row_first = (lane & 15u) == 0u;
-    uint32_t rlo = row_first ? 0u : elo, rhi = row_first ? 0u : ehi;
-    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x121, 0xf, 0xf, false);
-    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x121, 0xf, 0xf, false);
-    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x122, 0xf, 0xf, false);
-    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x122, 0xf, 0xf, false);
-    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x124, 0xf, 0xf, false);
-    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x124, 0xf, 0xf, false);
-    rlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rlo, 0x128, 0xf, 0xf, false);
-    rhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rhi, 0x128, 0xf, 0xf, false);
-    uint32_t wlo = rlo | elo, whi = rhi | ehi;
-    {
-      auto a = __builtin_amdgcn_permlane16_swap(wlo, wlo, false, false);
-      auto c = __builtin_amdgcn_permlane16_swap(whi, whi, false, false);
-      wlo = a[0] | a[1];
-      whi = c[0] | c[1];
-      a = __builtin_amdgcn_permlane32_swap(wlo, wlo, false, false);
-      c = __builtin_amdgcn_permlane32_swap(whi, whi, false, false);
-      wlo = a[0] | a[1];
-      whi = c[0] | c[1];
-    }
-    const unsigned long long wave_or = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)whi) << 32) |
-                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)wlo);
-    const unsigned long long row_or = ((unsigned long long)rhi << 32) | rlo;
-    const bool quad_first = (lane & 3u) == 0u;
-    uint32_t qlo = quad_first ? 0u : elo, qhi = quad_first ? 0u : ehi;
-    qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0xB1, 0xf, 0xf, false);
-    qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0xB1, 0xf, 0xf, false);
-    qlo |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qlo, 0x4E, 0xf, 0xf, false);
-    qhi |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)qhi, 0x4E, 0xf, 0xf, false);
-    const unsigned long long quad_or = ((unsigned long long)qhi << 32) | qlo;
-    // leading PAIR groups shared by the wave / my row of 16 / my quad (only pair bits are in the words: no clamp beyond NP)
-    const uint32_t l_wave = wave_or ? ((uint32_t)(__builtin_ctzll(wave_or) * 43) >> 8) : NP;
-    const uint32_t l_row = row_or ? ((uint32_t)(__builtin_ctzll(row_or) * 43) >> 8) : NP;
-    const uint32_t l_quad = quad_or ? ((uint32_t)(__builtin_ctzll(quad_or) * 43) >> 8) : NP;
+    // leading PAIR groups shared by the wave / my row of 16 / my quad: the list's level word (lin_pair_levels, at build time)
+    const uint32_t l_wave = srt_uniform(lev & 15u), l_row = (lev >> 4) & 15u, l_quad = (lev >> 8) & 15u;
     {
       const uint32_t gq = lane >> 2;
       if (gq < l_wave && tw != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, gq, NG) >> 2)], tw);
@@ -940,7 +967,7 @@ __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned lon
 template <int NG, bool DET>
 __device__ __forceinline__ void lin_phase_c_paired(pln_lds_lin &S, uint32_t n_ent, uint32_t tid, uint32_t lane_in,
                                                    const double (&fA)[LIN_RPT][5], const unsigned long long (&cA)[LIN_RPT], uint32_t rowA,
-                                                   double gt_scale) {
+                                                   uint32_t levA, double gt_scale) {
   uint32_t lane = lane_in;
   const uint32_t j0 = 2u * (tid & ~63u);                      // first entry of this wave's 64 pairs
   if (tid >= LIN_ROW_THREADS || j0 >= n_ent) return;          // wave-uniform
@@ -978,9 +1005,9 @@ __device__ __forceinline__ void lin_phase_c_paired(pln_lds_lin &S, uint32_t n_en
     for (int k = 0; k < 2; ++k)
 #pragma unroll
       for (int b = 0; b < 4; ++b) gi[k][b] = lin_to_fixed(g[k][b], gt_scale);
-    lin_scatter_grad_paired<NG, lin_fx>(S.GT, c0, c1, gi[0], gi[1], nz[0], nz[1], lane);
+    lin_scatter_grad_paired<NG, lin_fx>(S.GT, c0, c1, gi[0], gi[1], nz[0], nz[1], lane, levA);
   } else {
-    lin_scatter_grad_paired<NG, double>(S.GT, c0, c1, g[0], g[1], nz[0], nz[1], lane);
+    lin_scatter_grad_paired<NG, double>(S.GT, c0, c1, g[0], g[1], nz[0], nz[1], lane, levA);
   }
 }
 
@@ -1250,7 +1277,8 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     // are indexed by it) and, for the paired form, the length of its paired list
     const uint64_t ltile = pv.subset ? ti.pad >> 32 : tile;
     const uint32_t cb = (rows * 8u) & ~15u, bb = ti.blk16 * 16u,
-                   lb = PAIRED ? ((((uint32_t)ti.pad & 0xffffu) + 2u) * 2u + 15u) & ~15u : ((rows + 1u) * 2u + 15u) & ~15u;
+                   lb = PAIRED ? ((((uint32_t)ti.pad & 0xffffu) + 2u + lin_lev_len((uint32_t)ti.pad & 0xffffu)) * 2u + 15u) & ~15u   // entries + level words
+                               : ((rows + 1u) * 2u + 15u) & ~15u;
     const uint32_t pc = (cb + 1023u) >> 10, pb = (bb + 1023u) >> 10, pl = (lb + 1023u) >> 10;
     for (uint32_t q = dw; q < pc + pb + pl; q += LIN_DMA_WAVES) {
       if (q < pc) pln_dma_piece(S.buf[b].codes, kmer_code + ti.row0, cb, q, lane);
@@ -1273,10 +1301,12 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
   unsigned long long cA[LIN_RPT] = {0ull, 0ull};
   uint32_t n_live = 0;   // of the tile whose phase A ran last
   uint32_t rowA = 0xffffffffu;
+  uint32_t levA = 0u;    // (paired form) the level word of this lane's pair: read with the entries, used by phase C
   auto phase_a = [&](const lin_buf &B, const pln_tile &ti) {
     const uint32_t rows = ti.rows_items >> 16;
     n_live = rows ? srt_uniform((uint32_t)B.live[0]) : 0u;
     rowA = 0xffffffffu;
+    if (PAIRED && tid < LIN_ROW_THREADS && 2u * (tid & ~63u) < n_live) levA = B.live[2u + n_live + tid];     // (whole units: padded by the builder)
     if (PAIRED) {
       LIN_FOR_NGK(ng, rowA = (lin_phase_a_paired<NG, EXP>(S, B, n_live, tid, fA, cA)))
     } else {
@@ -1285,7 +1315,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
   };
   auto phase_c = [&]() {
     if (PAIRED) {
-      LIN_FOR_NGK(ng, (lin_phase_c_paired<NG, DET>(S, n_live, tid, lane, fA, cA, rowA, gt_scale)))
+      LIN_FOR_NGK(ng, (lin_phase_c_paired<NG, DET>(S, n_live, tid, lane, fA, cA, rowA, levA, gt_scale)))
     } else {
       LIN_FOR_NGK(ng, (lin_phase_c<NG, DET>(S, n_live, tid, lane, fA, cA, rowA, acc, gt_scale)))
     }

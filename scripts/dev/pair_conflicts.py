@@ -17,10 +17,10 @@ tr_s = t["train"][order].contiguous(); packed_s = kernels.linear_index(kernels.p
 plan = kernels.Plan(tr_s, 5)
 plan.pair_contexts(packed_s, LAG)
 L = _lib.lib()
-STRIDE = 1792 + 8
+L.bear_debug_pair_lists.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+STRIDE = L.bear_debug_pair_lists(None, 0, 0, None, None)
 n_t = 400
 lists = np.zeros((n_t, STRIDE), dtype=np.uint16); row0 = np.zeros(n_t, dtype=np.uint64)
-L.bear_debug_pair_lists.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
 assert L.bear_debug_pair_lists(plan._h, 1000, n_t, lists.ctypes.data, row0.ctypes.data) == 0
 words = packed_s.cpu().numpy().view(np.uint64)
 npair = (LAG - 3 + 1) // 2

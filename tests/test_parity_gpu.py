@@ -513,9 +513,10 @@ def test_paired_lists_are_dealt_permutations_of_the_live_contexts(dev):
     assert plan.pair_contexts(idx, lag) is True
     n_tiles = len(plan.tiles()[0])
     L = _lib.lib()
-    stride = 2 * (1024 - 128) + 8                       # LIN_LIVE2_STRIDE
-    lists, row0 = np.zeros((n_tiles, stride), dtype=np.uint16), np.zeros(n_tiles, dtype=np.uint64)
     L.bear_debug_pair_lists.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+    stride = L.bear_debug_pair_lists(None, 0, 0, None, None)        # LIN_LIVE2_STRIDE: entries, then one level word per pair
+    assert stride >= 2 * (1024 - 128) + 8
+    lists, row0 = np.zeros((n_tiles, stride), dtype=np.uint16), np.zeros(n_tiles, dtype=np.uint64)
     assert L.bear_debug_pair_lists(plan._h, 0, n_tiles, lists.ctypes.data, row0.ctypes.data) == 0
     words = idx.cpu().numpy().view(np.uint64)
     live = (tr != 0).any(dim=1).cpu().numpy()
@@ -538,6 +539,23 @@ def test_paired_lists_are_dealt_permutations_of_the_live_contexts(dev):
         lane_blk = blk[0::2]                                        # runs of equal leading letters stay together
         starts = np.flatnonzero(np.append(True, lane_blk[1:] != lane_blk[:-1]))
         assert len(np.unique(lane_blk[starts])) == len(starts), t
+        # the level words behind the entries: leading pair groups a pair's unit of 64 / row of 16 / quad of 4 share (the list's last
+        # pair fills the last unit) -- what phase C's adds are gated by, restated from the k-mers
+        n_pairs = m // 2
+        n_lev = (n_pairs + 63) // 64 * 64
+        lev = lists[t, 2 + m:2 + m + n_lev].astype(np.int64).reshape(-1, 64)
+        cv = np.concatenate([lane_blk, np.repeat(lane_blk[-1:], n_lev - n_pairs)]).reshape(-1, 64)
+        step = cv ^ np.roll(cv, 1, axis=1)
+
+        def shared(width):
+            s = step.reshape(-1, 64 // width, width).copy()
+            s[:, :, 0] = 0 if width < 64 else s[:, :, 0]            # a group's first lane steps in from the group before
+            o = np.bitwise_or.reduce(s, axis=2)
+            low = np.array([[(int(x) & -int(x)).bit_length() - 1 for x in r] for r in o])
+            return np.repeat(np.where(o == 0, npair, low // 6), width, axis=1)
+        assert np.array_equal(lev & 15, shared(64)), t
+        assert np.array_equal((lev >> 4) & 15, shared(16)), t
+        assert np.array_equal((lev >> 8) & 15, shared(4)), t
         cl = np.where(e == 0xffff, -1, ((w >> np.uint64(6 * npair)) & np.uint64(255)).astype(np.int64) % 16)
         twin = (e[1::2] != 0xffff) & (w[1::2] == w[0::2])           # copies of one k-mer in a lane: one add
         cl[1::2] = np.where(twin, -1, cl[1::2])
