@@ -114,6 +114,23 @@ __device__ __forceinline__ bear_dp bear_dm_item(double x, double c) {
   return o;
 }
 
+// log1p-type polynomial shared with bear_log_tab: log(1 + t) for |t| <= 2^-8 (|err| < 3e-18).  The Horner steps are spelled as
+// three-address v_fma_f64: where a coefficient lives in a register pair the compiler forms v_fmac behind a 64-bit COPY of it
+// (two instructions a step; same rounding, -ffp-contract=off).
+__device__ __forceinline__ double bear_fma3(double a, double b, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ double bear_log1p_small(double t) {
+  double q = -1.0 / 6.0;
+  q = bear_fma3(q, t, 0.2);
+  q = __builtin_fma(q, t, -0.25);
+  q = bear_fma3(q, t, 1.0 / 3.0);
+  q = __builtin_fma(q, t, -0.5);
+  return __builtin_fma(t * t, q, t);
+}
+
 // ---- table-driven log -------------------------------------------------------------
 // log(p) for finite p > 0 (normal or subnormal).  p = m * 2^e with m in [0.5, 1); the top 7
 // mantissa bits pick r_i ~ 1/m from a 128-entry table {r_i, -log r_i} (built on the host with
@@ -127,24 +144,10 @@ __device__ __forceinline__ double bear_log_tab(double p, const double2 *__restri
   const uint32_t hi = (uint32_t)(__double_as_longlong(m) >> 32);
   const double2 rl = tab[(hi >> 13) & 127u];
   const double t = __builtin_fma(m, rl.x, -1.0);
-  double q = -1.0 / 6.0;
-  q = __builtin_fma(q, t, 0.2);
-  q = __builtin_fma(q, t, -0.25);
-  q = __builtin_fma(q, t, 1.0 / 3.0);
-  q = __builtin_fma(q, t, -0.5);
-  const double l1p = __builtin_fma(t * t, q, t);
+  const double l1p = bear_log1p_small(t);
   return __builtin_fma((double)e, 0.6931471805599453094, rl.y + l1p);
 }
 
-// log1p-type polynomial shared with bear_log_tab: log(1 + t) for |t| <= 2^-8 (|err| < 3e-18).
-__device__ __forceinline__ double bear_log1p_small(double t) {
-  double q = -1.0 / 6.0;
-  q = __builtin_fma(q, t, 0.2);
-  q = __builtin_fma(q, t, -0.25);
-  q = __builtin_fma(q, t, 1.0 / 3.0);
-  q = __builtin_fma(q, t, -0.5);
-  return __builtin_fma(t * t, q, t);
-}
 
 // General item on the table log (x > 0 finite, c >= 1 an exact integer in a double): the same
 // shifted-Stirling evaluation as bear_dm_item at ~150 instead of ~500 instructions.

@@ -1217,6 +1217,8 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
   const bear_params prm = bear_params_of(prm_arg, io);   // device-resident parameters: constants derived in the prologue
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
+  double eps_v = eps;       // eps in a vector register pair: an instruction takes ONE scalar operand, and x = f u + eps of the item units has two
+  asm volatile("" : "+v"(eps_v));
   const lin_geom G = lin_make_geom(lag);
   const int ng = G.ng;
   double acc[2] = {0.0, 0.0};
@@ -1391,10 +1393,12 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
       uint32_t cmin, cmax;
       const uint32_t ci[1] = {pln_unit_counts(E, n_light, un, lane, &cmin, &cmax)};
       const uint32_t off = items[un * 64u + lane];
-      const double x[1] = {__builtin_fma(S.pri[off], u, eps)};
+      const double x[1] = {__builtin_fma(S.pri[off], u, eps_v)};
       bear_dp o[1] = {{0.0, 0.0}};
       if (!AR) srt_light<1>(x, ci, cmin, cmax, S.logtab, o, x_in_domain);
-      if (off != (uint32_t)PLN_SENTINEL) item(off, o[0].D, o[0].P, x[0], (double)ci[0]);
+      // (no test for the padding of a tile's last unit: its lanes read the neutral cell -- 1.0 -- with a count of zero, so D = P = 0
+      // add nothing and nothing is written; the test cost a compare and, through the accumulators' two paths, four 64-bit moves)
+      item(off, o[0].D, o[0].P, x[0], (double)ci[0]);
     }
     LIN_STAMP(0)     // B: items
     srt_wait_dma();  // the next tile's codes and plan block (issued a whole iteration ago)

@@ -710,9 +710,13 @@ __device__ __forceinline__ pln_tile pln_load_tile(const pln_view &pv, uint64_t t
 }
 
 // Dynamic work distribution inside a tile: every wave draws tickets from an LDS counter.
+// Lane 0's `ds_add_rtn_u32` is spelled out: of an atomicAdd under `if (lane == 0)` the compiler makes its wave-aggregated form
+// (count the active lanes with v_mbcnt x 2 + s_bcnt1, elect one, add the count, hand every lane its own offset: nine vector
+// instructions and the LDS one), which a draw by one known lane does not need.  All 64 lanes are active at every call.
 __device__ __forceinline__ uint32_t pln_ticket(uint32_t *counter, uint32_t lane) {
   uint32_t t = 0;
-  if (lane == 0) t = atomicAdd(counter, 1u);
+  if (lane == 0)
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t) : "v"((uint32_t)(uintptr_t)counter), "v"(1u) : "memory");
   return srt_uniform(t);
 }
 
@@ -754,8 +758,11 @@ __device__ __forceinline__ uint32_t pln_unit_counts(const uint16_t *E, uint32_t 
   const uint32_t base = un * 64u, idx = base + lane;
   const uint32_t last = (base + 64u <= n_light ? base + 64u : n_light) - 1u;  // last occupied index (unit not empty)
   const uint32_t e = lane < 30u ? (uint32_t)E[lane] : 0xffffffffu;  // E[30], E[31]: heavy list lengths
-  const uint32_t lo = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(e <= base));
-  const uint32_t hi = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(e <= last));
+  // (s_bcnt1 by name: the 32-bit results of __builtin_popcountll stay 64-bit values to the compiler, and with no scalar 64-bit
+  // "less than" the loop test below became a v_cmp_ge_u64 behind two moves)
+  uint32_t lo, hi;
+  asm("s_bcnt1_i32_b64 %0, %1" : "=s"(lo) : "s"(__builtin_amdgcn_ballot_w64(e <= base)) : "scc");
+  asm("s_bcnt1_i32_b64 %0, %1" : "=s"(hi) : "s"(__builtin_amdgcn_ballot_w64(e <= last)) : "scc");
   uint32_t c = lo;
   for (uint32_t k = lo; k < hi; ++k) c += idx >= (uint32_t)__builtin_amdgcn_readlane((int)e, (int)k) ? 1u : 0u;
   *cmin = base + 64u <= n_light ? lo : 0u;  // un-predicated factors only in full units
