@@ -616,8 +616,10 @@ __device__ __forceinline__ void lin_gt_add(double *p, lin_fx v) { atomicAdd(rein
 template <int CTRL, int ROW_MASK, typename T>
 __device__ __forceinline__ T lin_dpp(T v) {
   const long long q = lin_bits<T>(v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)q, CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(q >> 32), CTRL, ROW_MASK, 0xf, false);
+  // (mov_dpp: no "old" value -- every pattern used here gives every lane a source lane, and update_dpp's old = 0 cost a v_mov per move)
+  static_assert(ROW_MASK == 0xf, "lin_dpp: all rows");
+  const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)q, CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(q >> 32), CTRL, ROW_MASK, 0xf, true);
   return lin_unbits<T>(((long long)hi << 32) | (uint32_t)lo);
 }
 // Sums of the four gradient letters over quads, rows of 16 and the wave, TRANSPOSED: lane i ends up with the sums of ONE letter,
@@ -831,11 +833,9 @@ __device__ __forceinline__ void lin_phase_c(pln_lds_lin &S, uint32_t n_live, uin
     if (live) {
       double w[5];
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        const double v = S.pri[row * 5 + b];
-        w[b] = __builtin_fmax(-v, 0.0);     // cells an item has marked hold -w; the others still hold f_b >= 0
-        sw += w[b];
-      }
+      for (int b = 0; b < 5; ++b)           // cells an item has marked hold -w; the others still hold f_b >= 0 (one v_max_f64: see the paired form)
+        asm("v_max_f64 %0, -%1, 0" : "=v"(w[b]) : "v"(S.pri[row * 5 + b]));
+      sw = (((w[0] + w[1]) + w[2]) + w[3]) + w[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) g[b] = __builtin_fma(-fA[k][b], sw, w[b]);
     }
@@ -929,14 +929,13 @@ __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned lon
         if (pick < l_row && th != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, pick, NG) >> 2)], th);
       }
       const bool quad_covers = l_row < l_quad && l_row < l_wave + 4u;
-      if (__builtin_amdgcn_ballot_w64(quad_covers)) {
-        if (quad_covers && tq != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, l_row, NG) >> 2)], tq);
-      }
+      // (no ballot in front of the divergent adds below: the branch over an empty exec mask is the wave-uniform skip, and a ballot
+      // of a condition the compiler already holds as a lane mask went through a register and back -- two instructions a test)
+      if (quad_covers && tq != T(0)) lin_gt_add(&GT[bl * LIN_GT_PLANE + (lin_off_any(cv, l_row, NG) >> 2)], tq);
 #pragma unroll
       for (int gq = 0; gq < (int)NP; ++gq) {
         if ((uint32_t)gq < l_wave) continue;
         const bool mine = (nz0 || nz1) && ((uint32_t)gq >= l_row || (uint32_t)gq >= l_wave + 4u) && !(quad_covers && (uint32_t)gq == l_row);
-        if (!__builtin_amdgcn_ballot_w64(mine)) continue;
         if (mine) {
           double *gt = &GT[lin_off<NG>(cv, gq) >> 2];
 #pragma unroll
@@ -954,12 +953,10 @@ __device__ __forceinline__ void lin_scatter_grad_paired(double *GT, unsigned lon
     for (int b = 0; b < 4; ++b) lin_gt_add(&gt[b * LIN_GT_PLANE], twin ? g0[b] + g1[b] : g0[b]);
   }
   const bool own1 = nz1 && !twin;
-  if (__builtin_amdgcn_ballot_w64(own1)) {
-    if (own1) {
-      double *gt = &GT[lin_off<NG>(c1, NG - 1) >> 2];
+  if (own1) {
+    double *gt = &GT[lin_off<NG>(c1, NG - 1) >> 2];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) lin_gt_add(&gt[b * LIN_GT_PLANE], g1[b]);
-    }
+    for (int b = 0; b < 4; ++b) lin_gt_add(&gt[b * LIN_GT_PLANE], g1[b]);
   }
 }
 
@@ -972,24 +969,22 @@ __device__ __forceinline__ void lin_phase_c_paired(pln_lds_lin &S, uint32_t n_en
   const uint32_t j0 = 2u * (tid & ~63u);                      // first entry of this wave's 64 pairs
   if (tid >= LIN_ROW_THREADS || j0 >= n_ent) return;          // wave-uniform
   asm volatile("" : "+v"(lane));
-  double g[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-  bool nz[2] = {false, false};
+  double g[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, sw[2] = {0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const uint32_t row = (rowA >> (16 * k)) & 0xffffu;
     if (row != LIN_EMPTY) {
-      double w[5], sw = 0.0;
+      // a cell holds the item's mark -w < 0 or the untouched f >= 0: w = max(-cell, 0) as ONE v_max_f64 (fmax() canonicalises -cell
+      // with a second one first)
+      double w[5];
 #pragma unroll
-      for (int b = 0; b < 5; ++b) {
-        const double v = S.pri[row * 5 + b];
-        w[b] = __builtin_fmax(-v, 0.0);
-        sw += w[b];
-      }
+      for (int b = 0; b < 5; ++b) asm("v_max_f64 %0, -%1, 0" : "=v"(w[b]) : "v"(S.pri[row * 5 + b]));
+      sw[k] = (((w[0] + w[1]) + w[2]) + w[3]) + w[4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) g[k][b] = __builtin_fma(-fA[k][b], sw, w[b]);
-      nz[k] = sw > 0.0;
+      for (int b = 0; b < 4; ++b) g[k][b] = __builtin_fma(-fA[k][b], sw[k], w[b]);
     }
   }
+  const bool nz[2] = {sw[0] > 0.0, sw[1] > 0.0};
   if (__builtin_amdgcn_ballot_w64(nz[0] || nz[1]) == 0ull) return;
   // lanes beyond the end of the list repeat the last pair's leading letters: they add nothing and never break a run
   const uint32_t n_pairs = (n_ent - j0) >> 1;                 // wave-uniform (both even)
