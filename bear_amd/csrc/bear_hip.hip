@@ -1039,6 +1039,11 @@ extern "C" int bear_dbg_lin_stamps(unsigned long long *host_out, int reset) {   
   }
   return BEAR_OK;
 }
+extern "C" int bear_dbg_lin_pe_stamps(unsigned long long *host_out) {   // prologue / epilogue sections of the last launch (12 words)
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(lin_pe_stamps), sizeof(unsigned long long) * 12));
+  return BEAR_OK;
+}
 #endif
 
 // ---- fused linear AR head (kernels_linear.h) -----------------------------------------------------------

@@ -208,8 +208,43 @@ __device__ __forceinline__ double bear_exp_tab(double z, const double *__restric
 }
 
 // ---- reductions -----------------------------------------------------------------
+// Sum over the 64 lanes, in every lane: quads and rows of 16 on DPP moves, the rows and halves on v_permlane16/32_swap (gfx950) --
+// ~25 instructions where six __shfl_down of a double were twelve ds_bpermute round trips (every planned kernel's epilogue, twice).
+template <int CTRL>
+__device__ __forceinline__ double bear_dpp_mov(double v) {
+  const long long q = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)q, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(q >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) | (uint32_t)lo);
+}
 __device__ __forceinline__ double bear_wave_sum(double v) {
+  v += bear_dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += bear_dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += bear_dpp_mov<0x124>(v);   // row_ror:4
+  v += bear_dpp_mov<0x128>(v);   // row_ror:8
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;  // valid in lane 0
+  for (int step = 0; step < 2; ++step) {
+    const long long q = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
+    const auto a = step == 0 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false) : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto c = step == 0 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false) : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __longlong_as_double(((long long)c[0] << 32) | a[0]) + __longlong_as_double(((long long)c[1] << 32) | a[1]);
+  }
+  return v;  // in every lane
+}
+// ... and the largest of 64 non-negative values, the same way
+__device__ __forceinline__ double bear_wave_max(double v) {
+  v = __builtin_fmax(v, bear_dpp_mov<0xB1>(v));
+  v = __builtin_fmax(v, bear_dpp_mov<0x4E>(v));
+  v = __builtin_fmax(v, bear_dpp_mov<0x124>(v));
+  v = __builtin_fmax(v, bear_dpp_mov<0x128>(v));
+#pragma unroll
+  for (int step = 0; step < 2; ++step) {
+    const long long q = __double_as_longlong(v);
+    const uint32_t lo = (uint32_t)q, hi = (uint32_t)(q >> 32);
+    const auto a = step == 0 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false) : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto c = step == 0 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false) : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __builtin_fmax(__longlong_as_double(((long long)c[0] << 32) | a[0]), __longlong_as_double(((long long)c[1] << 32) | a[1]));
+  }
+  return v;
 }

@@ -95,6 +95,7 @@ struct pln_lds_lin {
   unsigned long long t_max;      // bits of the largest |logit| in the group tables (table build)
 };
 static_assert(sizeof(pln_lds_lin) <= 160 * 1024, "linear-head kernel: LDS budget");
+static_assert(PLN_RMAX * 5 >= LIN_MAX_LAG * 25 + 75 * 9, "pln_lds_lin::pri doubles as the scratch of the table build and the fold");
 
 // group geometry of a lag: npair pair groups over the letters before the triple (the last pair holds one letter when their
 // number is odd), then the triple over letters [tri, tri + 3) (positions >= lag hold the "unknown" letter: they add nothing)
@@ -1012,10 +1013,19 @@ __device__ __forceinline__ void lin_phase_c_paired(pln_lds_lin &S, uint32_t n_en
 // produces), the tables hold exp(logit) and a context's softmax numerators are PRODUCTS of table entries: no exponential
 // per context (about a third of phase A's instructions) -- returns true.  Otherwise logits in units of ln2 / 128
 // (lin_exp_units) and the per-context form.  Ends with a barrier.
-__device__ __forceinline__ bool lin_build_tables(double *T, unsigned long long *t_max, const double *__restrict__ mat, const lin_geom &G,
-                                                 int tid, int n_threads) {
+// `mat_lds` (NULL or lag * 25 doubles of LDS nobody else uses yet): the parameters are fetched ONCE, one element a thread, and the
+// rows are formed from the copy -- a table entry is up to six parameter reads behind conditions, which the compiler turned into
+// three dependent round trips to memory per entry (~7 us of every launch of the fused step: the `group tables` stamp of round 6).
+__device__ __forceinline__ bool lin_build_tables(double *T, unsigned long long *t_max, const double *__restrict__ mat_g, const lin_geom &G,
+                                                 int tid, int n_threads, double *mat_lds = nullptr) {
   const int lag = G.lag, n_tab = G.npair * LIN_PSTRIDE + LIN_TRI_COMBOS * 4;
   if (tid == 0) *t_max = 0ull;
+  const double *mat = mat_g;
+  if (mat_lds) {
+    for (int k = tid; k < lag * 25; k += n_threads) mat_lds[k] = mat_g[k];
+    mat = mat_lds;
+    __syncthreads();
+  }
   double t_abs = 0.0;
   for (int k = tid; k < n_tab; k += n_threads) {
     double v = 0.0;
@@ -1042,7 +1052,9 @@ __device__ __forceinline__ bool lin_build_tables(double *T, unsigned long long *
     t_abs = __builtin_fmax(t_abs, __builtin_fabs(v));
   }
   __syncthreads();                                                        // t_max has been zeroed
-  atomicMax(t_max, (unsigned long long)__double_as_longlong(t_abs));      // non-negative doubles order like their bit patterns
+  // (one atomic a WAVE: 1024 LDS atomics on one word are served one after the other -- ~6 us of every launch, the `group tables` stamp)
+  t_abs = bear_wave_max(t_abs);
+  if ((tid & 63) == 0) atomicMax(t_max, (unsigned long long)__double_as_longlong(t_abs));      // non-negative doubles order like their bit patterns
   __syncthreads();
   const bool exp_tables = srt_uniform((uint32_t)(__longlong_as_double((long long)*t_max) * (double)G.ng < 600.0)) != 0u;
   for (int k = tid; k < n_tab; k += n_threads) T[k] = exp_tables ? exp(T[k]) : T[k] * LIN_EXP_UNIT;
@@ -1083,27 +1095,54 @@ __device__ __forceinline__ void lin_fold_tables(const double *GT, const lin_geom
 // entry and block (global_atomic_add_f64; DET: 64-bit integer adds, exact in any order) instead of a partial the last block has
 // to fetch -- its fixed-order sum over 256 x 325 partials (665 KB through one CU) was ~10 us of EVERY launch, a twentieth of
 // configs[2]'s step.  The regular build's d/d mat was reproducible to rounding only before (LDS float atomics); it still is.
+// The sums are dealt to ALL threads of the block: a letter of the triple sums 36 table rows, a letter of a pair 6 -- left to one thread
+// per entry, a launch's last 75 entries kept six of the sixteen waves busy for ~8000 clocks while the others idled at the
+// barrier.  Items: one per pair-letter entry (6 rows), LIN_FOLD_SLICES per triple-letter entry (4 rows each); the slices meet in
+// `part` (lin_fold_items(G) doubles of LDS: the tile loop's row buffer, idle by now).  A thread reads the plane of ITS b only.
+#define LIN_FOLD_SLICES 9
+__host__ __device__ inline int lin_fold_items(const lin_geom &G) { return G.tri * 25 + 75 * LIN_FOLD_SLICES; }
 template <bool DET = false>
-__device__ __forceinline__ void lin_fold_tables_add(const double *GT, const lin_geom &G, int tid, int n_threads, double *__restrict__ accum) {
+__device__ __forceinline__ void lin_fold_tables_add(const double *GT, const lin_geom &G, int tid, int n_threads, double *__restrict__ accum,
+                                                    double *part) {
   using T = typename std::conditional<DET, lin_fx, double>::type;
-  for (int k = tid; k < G.lag * 25; k += n_threads) {
+  const int n_pair_out = G.tri * 25, n_items = lin_fold_items(G);
+  for (int it = tid; it < n_items; it += n_threads) {
+    const int k = it < n_pair_out ? it : n_pair_out + (it - n_pair_out) / LIN_FOLD_SLICES;
+    const int slice = it < n_pair_out ? 0 : (it - n_pair_out) % LIN_FOLD_SLICES;
     const int l = k / 25, r = k - l * 25, a = r / 5, b = r - a * 5;
     T s = T(0);
     auto add = [&](int row) {
       const double *gt = &GT[row];
-      const T v0 = lin_unbits<T>(__double_as_longlong(gt[0])), v1 = lin_unbits<T>(__double_as_longlong(gt[LIN_GT_PLANE])),
-              v2 = lin_unbits<T>(__double_as_longlong(gt[2 * LIN_GT_PLANE])), v3 = lin_unbits<T>(__double_as_longlong(gt[3 * LIN_GT_PLANE]));
-      s += b == 0 ? v0 : b == 1 ? v1 : b == 2 ? v2 : b == 3 ? v3 : -((v0 + v1) + (v2 + v3));
+      if (b < 4) {
+        s += lin_unbits<T>(__double_as_longlong(gt[b * LIN_GT_PLANE]));
+      } else {
+        const T v0 = lin_unbits<T>(__double_as_longlong(gt[0])), v1 = lin_unbits<T>(__double_as_longlong(gt[LIN_GT_PLANE])),
+                v2 = lin_unbits<T>(__double_as_longlong(gt[2 * LIN_GT_PLANE])), v3 = lin_unbits<T>(__double_as_longlong(gt[3 * LIN_GT_PLANE]));
+        s -= (v0 + v1) + (v2 + v3);
+      }
     };
     if (l >= G.tri) {
       const int pos = l - G.tri, base = G.npair * LIN_PAIR_COMBOS;
-      for (int p = 0; p < 36; ++p) {
+      for (int p = slice * (36 / LIN_FOLD_SLICES); p < (slice + 1) * (36 / LIN_FOLD_SLICES); ++p) {
         const int p0 = p / 6, p1 = p % 6;
         add(base + (pos == 0 ? (a * 6 + p0) * 6 + p1 : pos == 1 ? (p0 * 6 + a) * 6 + p1 : (p0 * 6 + p1) * 6 + a));
       }
     } else {
       const int g = l >> 1;
       for (int p = 0; p < 6; ++p) add(g * LIN_PAIR_COMBOS + ((l & 1) ? p * 6 + a : a * 6 + p));
+    }
+    part[it] = __longlong_as_double(lin_bits<T>(s));
+  }
+  __syncthreads();
+  for (int k = tid; k < G.lag * 25; k += n_threads) {
+    T s;
+    if (k < n_pair_out) {
+      s = lin_unbits<T>(__double_as_longlong(part[k]));
+    } else {
+      const double *q = &part[n_pair_out + (k - n_pair_out) * LIN_FOLD_SLICES];
+      s = T(0);
+#pragma unroll
+      for (int j = 0; j < LIN_FOLD_SLICES; ++j) s += lin_unbits<T>(__double_as_longlong(q[j]));
     }
     // AGENT scope: the blocks of a launch sit on eight XCDs with an L2 each -- the add has to happen where all of them see it
     if (DET) {
@@ -1187,8 +1226,17 @@ __device__ unsigned long long lin_stamp_sums[8];
     tph[k] += now - t_prev;                                       \
     t_prev = now;                                                 \
   }
+// ... and of a launch's prologue / epilogue, thread 0 of block 0 (the sections after the arrival: of the launch's LAST block)
+__device__ unsigned long long lin_pe_stamps[12];
+#define LIN_PE(k)                                                 \
+  if (tid == 0 && (blockIdx.x == 0 || (k) >= 9)) {                \
+    const unsigned long long now = __builtin_amdgcn_s_memtime();  \
+    lin_pe_stamps[k] = now - pe_prev;                             \
+    pe_prev = now;                                                \
+  }
 #else
 #define LIN_STAMP(k)
+#define LIN_PE(k)
 #endif
 // DET (BEAR_AMD_DETERMINISTIC): the gradient tables hold fixed-point integers, gt_scale = 2^50 / bound (see lin_fx above)
 // NGK: the number of letter groups as a compile-time constant (0: taken from `lag` at run time through LIN_FOR_NG).  With it a
@@ -1209,8 +1257,11 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     const lin_fx_bound gt_bound, const bear_apply_io apply) {   // apply.theta != NULL: the Adam update by the last block (grad_out == io.out + 2)
   extern __shared__ __attribute__((aligned(16))) unsigned char srt_smem[];
   pln_lds_lin &S = *reinterpret_cast<pln_lds_lin *>(srt_smem);
-  const bear_params prm = bear_params_of(prm_arg, io);   // device-resident parameters: constants derived in the prologue
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = srt_uniform(tid >> 6);
+#ifdef LIN_STAMPS
+  unsigned long long pe_prev = __builtin_amdgcn_s_memtime();
+#endif
+  const bear_params prm = bear_params_of(prm_arg, io);   // device-resident parameters: constants derived in the prologue
   const double u = prm.inv_h, eps = prm.eps, eps5 = 5.0 * prm.eps;
   double eps_v = eps;       // eps in a vector register pair: an instruction takes ONE scalar operand, and x = f u + eps of the item units has two
   asm volatile("" : "+v"(eps_v));
@@ -1223,11 +1274,6 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
   const bool x_in_domain = srt_uniform((uint32_t)(eps > 0.0 && u > 0.0 && u + eps <= SRT_XMAX)) != 0u;
 
   if (tid < BEAR_LOGTAB_N) S.logtab[tid] = logtab_g[tid];
-  if (tid < SRT_NKEY) {
-    const bear_dp o = srt_general_fast(u + eps5, (double)(tid + 1), logtab_g);
-    S.tabD[tid] = o.D;
-    S.tabP[tid] = o.P;
-  }
   if (tid == 0) {
     S.pri[PLN_SENTINEL] = 1.0;
     S.ticket[0] = PLN_TICKET_START(PLN_WAVES);
@@ -1236,7 +1282,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
   }
   if (tid < BEAR_EXPTAB_N) S.exptab[tid] = exp2((double)tid * (1.0 / BEAR_EXPTAB_N));
   for (int k = tid; k < LIN_TAB_DOUBLES; k += PLN_THREADS) S.GT[k] = 0.0;
-  const bool exp_tables = lin_build_tables(S.T, &S.t_max, mat, G, tid, PLN_THREADS);
+  LIN_PE(0)      // parameters, log / exp tables, zeroed gradient tables
 
   // LIN_DMA_WAVES waves issue the tile DMA (the last ones of the block); measured in round 2, when they also had rows: 16 / 8 / 4 / 2 waves: 1.92 / 1.89 / 1.87 / 1.86 ms
   // Tile descriptors reach the waves through LDS: a scalar load inside the tile loop costs every wave a full memory latency per
@@ -1291,6 +1337,19 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     }
   };
 
+  // the block's first tile is on its way while the group tables are built (its DMA was ~2 us of every launch behind them)
+  const uint64_t GR = gridDim.x;
+  const pln_tile cur0 = pln_load_tile(pv, blockIdx.x), nxt0 = pln_load_tile(pv, blockIdx.x + GR);    // (prologue: scalar loads)
+  LIN_PE(2)      // first descriptors (scalar loads)
+  stage(cur0, blockIdx.x, 0);
+  const bool exp_tables = lin_build_tables(S.T, &S.t_max, mat, G, tid, PLN_THREADS, S.pri);     // (S.pri: scratch until the first phase A)
+  LIN_PE(1)      // group tables
+  if (tid < SRT_NKEY) {      // (read in the epilogue; from the LDS copy of the log table, which the table build's barriers have published)
+    const bear_dp o = srt_general_fast(u + eps5, (double)(tid + 1), S.logtab);
+    S.tabD[tid] = o.D;
+    S.tabP[tid] = o.P;
+  }
+
   // the tile loop, compiled once per table form (one loop with both forms of phase A in it ran out of registers)
   auto tile_loop = [&](auto exp_tag) {
   constexpr bool EXP = decltype(exp_tag)::value;
@@ -1318,14 +1377,14 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     }
   };
 
-  const uint64_t GR = gridDim.x;
-  pln_tile cur = pln_load_tile(pv, blockIdx.x), nxt = pln_load_tile(pv, blockIdx.x + GR);    // (prologue: scalar loads)
-  stage(cur, blockIdx.x, 0);
+  pln_tile cur = cur0, nxt = nxt0;
   srt_wait_dma();
   srt_sync();
+  LIN_PE(3)      // first tile landed
   phase_a(S.buf[0], cur);
   lin_phase_a_store(S, fA, rowA);
   srt_sync();
+  LIN_PE(4)      // its phase A
   stage(nxt, blockIdx.x + GR, 1);
   stage_desc(blockIdx.x + 2 * GR, 2);     // descriptor j of this block's tiles lives in ring slot j & 3
   uint32_t slot = 0, c_target = 0, iter = 0;
@@ -1430,6 +1489,7 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
   else tile_loop(std::false_type{});
   srt_wait_dma();
   __syncthreads();
+  LIN_PE(5)      // tile loop
   // ---- items / contexts that overflowed to the plan's global lists (very dense tiles): self-contained
   const uint64_t gtid = (uint64_t)blockIdx.x * PLN_THREADS + tid, gsz = (uint64_t)gridDim.x * PLN_THREADS;
   for (uint64_t i = gtid; i < pv.n_heavy_col; i += gsz) {
@@ -1482,16 +1542,26 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_linear_plan_kernel(
     acc[1] = __builtin_fma(u * m, S.tabP[tid], acc[1]);
   }
   __syncthreads();
-  lin_fold_tables_add<DET>(S.GT, G, (int)tid, PLN_THREADS, grad_partials);     // (grad_partials: the launch's accumulator, bear_ws::lin_accum)
+  LIN_PE(6)      // overflow lists, histograms
+  lin_fold_tables_add<DET>(S.GT, G, (int)tid, PLN_THREADS, grad_partials, S.pri);     // (grad_partials: the launch's accumulator, bear_ws::lin_accum)
+  LIN_PE(7)      // fold + adds into the accumulator
   block_store_partials<2, true>(acc, partials);      // (io.out is never NULL here: both entry points sum in this launch)
+  LIN_PE(8)      // block sums
+#ifdef LIN_STAMPS
+  pe_prev = __builtin_amdgcn_s_memtime();
+#endif
   if (!bear_arrive_last(io.arrive())) return;        // (its s_waitcnt vmcnt(0) covers the atomics: they are acknowledged before a block arrives)
   __syncthreads();
+  LIN_PE(9)      // the last block's arrival
   // a step of two launches (paired tiles, then the tiles that kept their plain lists): the first leaves its d/d mat in the
   // accumulator, the second takes the sum of both -- in the deterministic mode ONE conversion of the exact integer total, whatever
   // the split of the tiles between the two forms
-  if (accumulate != 2) lin_take_accum<DET>(grad_partials, lag * 25, (int)tid, PLN_THREADS, grad_out, false, DET ? 1.0 / gt_scale : 1.0);
+  // (waves 4.. take the accumulator while waves 0-3 fetch the block partials in bear_finalize_in_block: two round trips to memory side by side)
+  if (accumulate != 2 && tid >= 256) lin_take_accum<DET>(grad_partials, lag * 25, (int)tid - 256, PLN_THREADS - 256, grad_out, false, DET ? 1.0 / gt_scale : 1.0);
+  LIN_PE(10)     // d/d mat out of the accumulator
   bear_finalize_in_block(partials, 2, io.out, io.arrive(), accumulate == 1);
   bear_apply_in_block(apply, io.out);
+  LIN_PE(11)     // sums of the partials, the update
 }
 
 // ---- the bear_net / linear optimizer step on the device (HIP-graph replay) ---------------------------------------
