@@ -123,8 +123,8 @@ __device__ __forceinline__ double bear_fma3(double a, double b, double c) {
   return r;
 }
 __device__ __forceinline__ double bear_log1p_small(double t) {
-  double q = -1.0 / 6.0;
-  q = bear_fma3(q, t, 0.2);
+  double q;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "s"(-1.0 / 6.0), "v"(t), "v"(0.2));     // (the leading coefficient stays a scalar pair: registers)
   q = __builtin_fma(q, t, -0.25);
   q = bear_fma3(q, t, 1.0 / 3.0);
   q = __builtin_fma(q, t, -0.5);
