@@ -122,9 +122,14 @@ __device__ __forceinline__ double bear_fma3(double a, double b, double c) {
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// COEF_V: the leading coefficient in a vector register pair too (a kernel short of SCALAR registers: the fused linear step, 1 % by
+// A/B); by default it stays a scalar pair -- two more vector registers moved dm_ref_items_kernel from 78 to 82 and from 6 waves per
+// SIMD to 5 (configs[3]: 128 -> 164 us).
+template <bool COEF_V = false>
 __device__ __forceinline__ double bear_log1p_small(double t) {
   double q;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "s"(-1.0 / 6.0), "v"(t), "v"(0.2));     // (the leading coefficient stays a scalar pair: registers)
+  if (COEF_V) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "v"(-1.0 / 6.0), "v"(t), "v"(0.2));
+  else asm("v_fma_f64 %0, %1, %2, %3" : "=v"(q) : "s"(-1.0 / 6.0), "v"(t), "v"(0.2));
   q = __builtin_fma(q, t, -0.25);
   q = bear_fma3(q, t, 1.0 / 3.0);
   q = __builtin_fma(q, t, -0.5);
@@ -138,13 +143,14 @@ __device__ __forceinline__ double bear_log1p_small(double t) {
 //   log p = e ln2 - log r_i + log1p(t),   log1p by a degree-6 Taylor polynomial (|err| < 3e-18).
 // ~15 fp64-rate instructions + one 16-byte LDS read, versus ~60 for the library log.
 #define BEAR_LOGTAB_N 128
+template <bool COEF_V = false>
 __device__ __forceinline__ double bear_log_tab(double p, const double2 *__restrict__ tab) {
   const double m = __builtin_amdgcn_frexp_mant(p);
   const int e = __builtin_amdgcn_frexp_exp(p);
   const uint32_t hi = (uint32_t)(__double_as_longlong(m) >> 32);
   const double2 rl = tab[(hi >> 13) & 127u];
   const double t = __builtin_fma(m, rl.x, -1.0);
-  const double l1p = bear_log1p_small(t);
+  const double l1p = bear_log1p_small<COEF_V>(t);
   return __builtin_fma((double)e, 0.6931471805599453094, rl.y + l1p);
 }
 

@@ -126,7 +126,7 @@ __device__ __noinline__ bear_dp srt_general_fast(double x, double c, const doubl
 // under predication.  c == 0 yields D = P = 0.
 // `in_domain` (wave-uniform): the CALLER guarantees 0 < x <= SRT_XMAX for every occupied lane (the linear step: x = f u + eps with
 // f a softmax output it formed itself), so the per-unit domain test -- eight vector instructions of a unit's ~95 -- is skipped.
-template <int ILP>
+template <int ILP, bool COEF_V = false>      // (COEF_V: bear_log1p_small)
 __device__ __forceinline__ void srt_light(const double (&x)[ILP], const uint32_t (&c)[ILP], uint32_t cmin, uint32_t cmax,
                                           const double2 *logtab, bear_dp (&o)[ILP], bool in_domain = false) {
   double p[ILP], dp[ILP], t[ILP];
@@ -158,7 +158,7 @@ __device__ __forceinline__ void srt_light(const double (&x)[ILP], const uint32_t
 #pragma unroll
   for (int i = 0; i < ILP; ++i) {
     const bool live = c[i] != 0;
-    o[i].D = live ? bear_log_tab(p[i], logtab) : 0.0;
+    o[i].D = live ? bear_log_tab<COEF_V>(p[i], logtab) : 0.0;
     o[i].P = live ? dp[i] * bear_rcp(p[i]) : 0.0;
     if (!in_domain) odd |= live && !(x[i] > 0.0 && x[i] <= SRT_XMAX);
   }

@@ -9,7 +9,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
-from bear_amd import kernels
+import ctypes
+
+from bear_amd import kernels, _lib
 
 SEED = 20211012
 dev = torch.device("cuda", 0)
@@ -69,6 +71,19 @@ def main():
         print(f"{lib} {kind}: n={n} rows={train.shape[0]} tiles={len(plan.tiles()[0])} paired={paired} {plan.pair_info()} "
               f"plain {ms_plain:.4f} ms  paired {ms_pair:.4f} ms  per 1e8: {ms_pair * 1e8 / n:.4f}  "
               f"LL {float(out[0][0]):.15e} dh {float(out[0][1]):.15e} |dmat| {float(out[1].abs().sum()):.12e} paired-vs-plain {same:.2e}", flush=True)
+        L = _lib.lib()
+        if hasattr(L, "bear_dbg_lin_stamps"):       # -DBEAR_DEV_BUILD -DLIN_STAMPS: the waves' clocks per section of the tile loop
+            L.bear_dbg_lin_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            torch.cuda.synchronize()
+            L.bear_dbg_lin_stamps(None, 1)
+            kernels.dm_linear(plan, packed, mat, 0.0)
+            torch.cuda.synchronize()
+            buf = (ctypes.c_ulonglong * 8)()
+            L.bear_dbg_lin_stamps(buf, 0)
+            names = ["B items", "wait DMA", "barrier after B", "staging", "C", "A", "wait read-backs", "row stores + barrier"]
+            n_t = len(plan.tiles()[0])
+            print("    clocks per tile and wave: " + "  ".join(f"{nm} {buf[k] / (16 * n_t):.0f}" for k, nm in enumerate(names))
+                  + f"  total {sum(buf) / (16 * n_t):.0f}", flush=True)
         del plan, packed, train, out, out_p
         torch.cuda.empty_cache()
 
