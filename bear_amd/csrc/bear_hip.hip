@@ -127,10 +127,7 @@ int bear_ws_create(int device, bear_ws **out) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_kernel<false, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_g));
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_inplace_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_gi));
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_inplace_kernel<false>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_prior_plan_grad_inplace_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pln_lds_gi));
       if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(dm_refmix_plan_grad_kernel<false>),
@@ -347,7 +344,6 @@ struct bear_plan {
   uint64_t *heavy_stop;
   unsigned long long *hist;  // [64]
   uint16_t *live;            // five-column plans: per-tile lists of the contexts that hold counts (plan_live_kernel)
-  unsigned long long *live_off;   // [n_tiles + 1], built on first use (bear_plan_live_rows / bear_dm_prior_plan_grad_live_f64)
   uint64_t n_tiles;
   uint64_t n_heavy[3];
   uint64_t n_live_rows;      // five-column plans: contexts that hold any count (the kernels that walk `live` skip the lists when all do)
@@ -391,7 +387,6 @@ static void plan_free(bear_plan *p) {
   (void)hipFree(p->heavy_stop);
   (void)hipFree(p->hist);
   (void)hipFree(p->live);
-  (void)hipFree(p->live_off);
   for (int k = 0; k < p->n_cnn_levels; ++k) bear_level_free(&p->cnn_levels[k]);
   for (int k = 0; k <= CNN_MAX_LAG; ++k)
     for (int q = 0; q < p->n_cnn_win[k]; ++q) bear_window_free(&p->cnn_win[k][q]);
@@ -706,7 +701,6 @@ static pln_view plan_view(const bear_plan *p) {
   v.hist_big = p->hist + 2 * SRT_NKEY;
   v.big_in_hist = 1;
   v.live = p->live;
-  v.live_off = p->live_off;
   v.live2 = p->live2;
   v.subset = 0;
   v.n_tiles = p->n_tiles;
@@ -770,7 +764,7 @@ static int launch_prior_plan_grad(bear_ws *ws, const bear_plan *plan, const doub
     hipLaunchKernelGGL((dm_prior_plan_grad_kernel<true, true>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
                        grad_prior, ws->partials, io);
   else if (prior_normalized)   // rows asserted normalised: the in-place, double-buffered form
-    hipLaunchKernelGGL(dm_prior_plan_grad_inplace_kernel<false>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_gi), s, prior, prm, pv, lt,
+    hipLaunchKernelGGL(dm_prior_plan_grad_inplace_kernel, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_gi), s, prior, prm, pv, lt,
                        grad_prior, ws->partials, io);
   else
     hipLaunchKernelGGL((dm_prior_plan_grad_kernel<false, false>), dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_g), s, prior, prm, pv, lt,
@@ -809,71 +803,6 @@ int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32
   prm.eps = eps;
   return launch_prior_plan_grad(ws, plan, prior, prm, nullptr, train_ar, prior_normalized, out, grad_prior,
                                 static_cast<hipStream_t>(stream));
-}
-
-// ---- gradient rows of the contexts that hold counts only (include/bear_hip.h)
-int bear_plan_live_rows(bear_ws *ws, bear_plan *plan, uint64_t *n_live, int64_t *rows, void *stream) {
-  int st = check_ws(ws);
-  if (st != BEAR_OK) return st;
-  if (!plan || !n_live || plan->ncol != 5 || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
-  if (rows && (reinterpret_cast<uintptr_t>(rows) & 7u)) return BEAR_ERR_INVALID_ARG;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  *n_live = plan->n_tiles ? plan->n_live_rows : 0;
-  if (plan->n_tiles == 0) return BEAR_OK;
-  if (!plan->live) return BEAR_ERR_INVALID_ARG;
-  if (!plan->live_off) {
-    unsigned long long *off = nullptr;
-    hipError_t e = hipMalloc(&off, sizeof(unsigned long long) * (plan->n_tiles + 1));
-    if (e != hipSuccess) {
-      g_last_hip_error = (int)e;
-      (void)hipGetLastError();
-      return e == hipErrorOutOfMemory ? BEAR_ERR_NOMEM : BEAR_ERR_HIP;
-    }
-    hipLaunchKernelGGL(plan_live_offsets_kernel, dim3(1), dim3(1024), 0, s, plan->live, plan->n_tiles, off);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(s);   // (built once per plan; later launches on any stream read it)
-    if (e != hipSuccess) {
-      (void)hipFree(off);
-      g_last_hip_error = (int)e;
-      return BEAR_ERR_HIP;
-    }
-    plan->live_off = off;
-    plan->bytes += sizeof(unsigned long long) * (plan->n_tiles + 1);
-  }
-  if (rows) {
-    const uint64_t nt = plan->n_tiles;
-    const int grid = (int)(nt < (uint64_t)ws->num_cu * 8 ? nt : (uint64_t)ws->num_cu * 8);
-    hipLaunchKernelGGL(plan_live_rows_kernel, dim3(grid), dim3(256), 0, s, plan->tiles, nt, plan->live, plan->live_off,
-                       reinterpret_cast<long long *>(rows));
-    HIP_TRY(hipGetLastError());
-  }
-  return BEAR_OK;
-}
-
-int bear_dm_prior_plan_grad_live_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *counts, const double *prior, uint64_t n_rows,
-                                     double h_signed, double eps, double *out, double *grad_live, void *stream) {
-  int st = check_ws(ws);
-  if (st != BEAR_OK) return st;
-  if (!plan || !out || !grad_live || (n_rows && (!counts || !prior))) return BEAR_ERR_INVALID_ARG;
-  if (plan->ncol != 5 || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device) return BEAR_ERR_INVALID_ARG;
-  if (misaligned(prior) || (reinterpret_cast<uintptr_t>(grad_live) & 7u) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
-  // the compact rows have no place for the cells of the plan's GLOBAL overflow lists (tiles of a dense table: the fix-up launches
-  // address a cell by its table row): such a plan takes bear_dm_prior_plan_grad_f64
-  if (plan->n_heavy[0] + plan->n_heavy[1] != 0) return BEAR_ERR_INVALID_ARG;
-  if (plan->n_tiles && !plan->live_off) return BEAR_ERR_INVALID_ARG;      // bear_plan_live_rows first: it numbers the rows
-  bear_params prm;
-  memset(&prm, 0, sizeof(prm));
-  prm.inv_h = 1.0 / exp(h_signed);
-  prm.eps = eps;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int grid = grid_plan(ws, plan->n_tiles);
-  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
-  const pln_view pv = plan_view(plan);
-  const bear_step_io io = ws_io(ws, nullptr, BEAR_THETA_NET, out);
-  hipLaunchKernelGGL(dm_prior_plan_grad_inplace_kernel<true>, dim3(grid), dim3(PLN_THREADS), sizeof(pln_lds_gi), s, prior, prm, pv, lt,
-                     grad_live, ws->partials, io);
-  HIP_TRY(hipGetLastError());
-  return BEAR_OK;
 }
 
 // h_signed read from device memory (a parameter the optimizer updates on the device): the step is enqueued without the host

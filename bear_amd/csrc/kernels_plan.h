@@ -596,48 +596,6 @@ __global__ __launch_bounds__(1024) void plan_live_kernel(const pln_tile *__restr
   }
 }
 
-// ... their running number across the tiles: off[t] = contexts with counts in tiles [0, t), off[n_tiles] = all of them (one block:
-// a plan has at most a few 1e5 tiles).  The position of a tile's compact gradient rows (dm_prior_plan_grad_inplace_kernel<true>).
-__global__ __launch_bounds__(1024) void plan_live_offsets_kernel(const uint16_t *__restrict__ live, uint64_t n_tiles,
-                                                                 unsigned long long *__restrict__ off) {
-  __shared__ unsigned long long wsum[16];
-  __shared__ unsigned long long carry;
-  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = 0ull;
-  __syncthreads();
-  for (uint64_t t0 = 0; t0 < n_tiles; t0 += 1024) {
-    const uint64_t t = t0 + tid;
-    const unsigned long long c = t < n_tiles ? (unsigned long long)live[t * PLN_LIVE_STRIDE] : 0ull;
-    unsigned long long incl = c;   // inclusive scan inside the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned long long o = __shfl_up(incl, d, 64);
-      if ((int)lane >= d) incl += o;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    unsigned long long base = carry;
-    for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
-    if (t < n_tiles) off[t] = base + incl - c;
-    __syncthreads();
-    if (tid == 1023) carry = base + incl;
-    __syncthreads();
-  }
-  if (tid == 0) off[n_tiles] = carry;
-}
-// ... and their table rows, in the order of the compact gradient rows
-__global__ __launch_bounds__(256) void plan_live_rows_kernel(const pln_tile *__restrict__ tiles, uint64_t n_tiles,
-                                                             const uint16_t *__restrict__ live, const unsigned long long *__restrict__ off,
-                                                             long long *__restrict__ rows_out) {
-  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const uint16_t *l = live + t * PLN_LIVE_STRIDE;
-    const uint32_t m = l[0];
-    const uint64_t row0 = tiles[t].row0;
-    long long *out = rows_out + off[t];
-    for (uint32_t j = threadIdx.x; j < m; j += 256) out[j] = (long long)(row0 + l[1 + j]);
-  }
-}
-
 struct pln_view {  // device-side view of a plan
   const pln_tile *tiles;
   const unsigned char *stream;
@@ -650,7 +608,6 @@ struct pln_view {  // device-side view of a plan
                                    // step of two launches over subsets of the tiles -- its sibling's): kernels that take it skip them
   uint64_t n_tiles, n_heavy_col, n_heavy_row, n_heavy_stop;
   const uint16_t *live;            // [n_tiles][PLN_LIVE_STRIDE] (five-column plans): [0] = contexts with counts, then their rows, ascending
-  const unsigned long long *live_off;   // [n_tiles + 1] or NULL: contexts with counts in the tiles before (bear_plan_live_rows)
   const uint16_t *live2;           // [n_tiles][LIN_LIVE2_STRIDE] or NULL: the paired form of `live` for one set of k-mers (kernels_linear.h)
   int subset;                      // `tiles` is a subset of the plan's tiles: a descriptor's spare word holds (tile number << 32 | list length)
 };
@@ -1602,14 +1559,9 @@ struct pln_lds_gi {
   double tabD[SRT_NKEY];
   double tabP[SRT_NKEY];
   uint32_t ticket[2];
-  uint32_t cnt[2 * 16];       // COMPACT: contexts with counts per wave and half of the tile
 };
 static_assert(sizeof(pln_lds_gi) <= 158 * 1024, "in-place gradient kernel: LDS budget");
 
-// COMPACT (bear_dm_prior_plan_grad_live_f64): only the rows of contexts that hold counts leave, closed up, tile t's behind
-// pv.live_off[t] of them (the order of bear_plan_live_rows) -- a context without counts has a gradient row of zeros, and on a k-mer
-// table they are 30 % of the rows: 40 + 4 + 28 bytes per context instead of 40 + 4 + 40.  Which rows: nrow != 0, as the plan's lists.
-template <bool COMPACT>
 __global__ __launch_bounds__(PLN_THREADS, 4) void dm_prior_plan_grad_inplace_kernel(const double *__restrict__ prior,
                                                                                                  bear_params prm_arg, pln_view pv,
                                                                                                  const double2 *__restrict__ logtab_g,
@@ -1648,12 +1600,10 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_prior_plan_grad_inplace_ker
     pln_dma(S.blk[b], pv.stream + (size_t)ti.off16 * 16, ti.blk16 * 16u, wave, lane, (pbytes + 1023u) >> 10);
   };
   pln_tile cur = pln_load_tile(pv, blockIdx.x);
-  unsigned long long off_cur = COMPACT && blockIdx.x < pv.n_tiles ? pv.live_off[blockIdx.x] : 0ull;   // (scalar loads, a tile ahead like the descriptors)
   stage(cur, 0);
   uint32_t b = 0;
   for (uint64_t t = blockIdx.x; t < pv.n_tiles; t += gridDim.x, b ^= 1u) {
     const pln_tile nxt = pln_load_tile(pv, t + gridDim.x);
-    const unsigned long long off_nxt = COMPACT && t + gridDim.x < pv.n_tiles ? pv.live_off[t + gridDim.x] : 0ull;
     const uint32_t rows = cur.rows_items >> 16, n_light = cur.rows_items & 0xffffu;
     const uint32_t hc = cur.hc_hr >> 16, hr = cur.hc_hr & 0xffffu;
     const pln_layout L = pln_block_layout(rows, n_light, hc, hr);
@@ -1722,42 +1672,6 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_prior_plan_grad_inplace_ker
       for (int c = 0; c < 5; ++c) P[row * 5 + c] -= u * o.P;
     }
     srt_sync();
-    if (COMPACT) {
-      // ---- 4': the rows of the contexts with counts close up (every thread holds its two rows while they move), then leave
-      static_assert(PLN_RMAX <= 2 * PLN_THREADS && PLN_THREADS == 1024, "two rows a thread");
-      unsigned long long mask[2];
-      double v[2][5];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const uint32_t lr = tid + 1024u * k;
-        const bool lv = lr < rows && nrow[lr] != 0;
-        mask[k] = __builtin_amdgcn_ballot_w64(lv);
-        if (lane == 0) S.cnt[k * 16 + wave] = (uint32_t)__builtin_popcountll(mask[k]);
-        if (lv) {
-#pragma unroll
-          for (int c = 0; c < 5; ++c) v[k][c] = P[lr * 5 + c];
-        }
-      }
-      srt_sync();      // the counts are out, and every row that moves has been read
-      uint32_t total = 0;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        uint32_t base = total;
-        for (uint32_t w = 0; w < 16; ++w) {
-          const uint32_t c = S.cnt[k * 16 + w];
-          if (w < wave) base += c;
-          total += c;
-        }
-        if ((mask[k] >> lane) & 1ull) {
-          const uint32_t q = base + (uint32_t)__builtin_popcountll(mask[k] & ((1ull << lane) - 1ull));
-#pragma unroll
-          for (int c = 0; c < 5; ++c) P[q * 5 + c] = v[k][c];
-        }
-      }
-      srt_sync();
-      double *dst = grad_out + off_cur * 5ull;      // (8-byte aligned only: 40-byte rows behind an odd number of them)
-      for (uint32_t i = tid; i < total * 5u; i += PLN_THREADS) dst[i] = P[i];
-    } else
     // ---- 4: the tile's gradient rows leave as one coalesced stream (from registers: the buffer is free once they are read)
     {
       const uint32_t n_dw = rows * 10u;  // dwords
@@ -1767,7 +1681,6 @@ __global__ __launch_bounds__(PLN_THREADS, 4) void dm_prior_plan_grad_inplace_ker
       if ((n_dw & 3u) && tid == 0) grad_out[(cur.row0 + rows) * 5 - 1] = P[rows * 5 - 1];  // odd row count
     }
     cur = nxt;
-    off_cur = off_nxt;
   }
   // ---- ELBO / d/dh of the items that overflowed to the global lists (their gradient cells: fix-up kernel)
   srt_wait_dma();
