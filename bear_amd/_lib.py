@@ -38,6 +38,7 @@ SYMBOLS = [
     "bear_kmer_sort_create", "bear_kmer_sort_reduce", "bear_kmer_sort_destroy", "bear_count_last_hip_error", "bear_write_counts_tsv", "bear_fastx_size", "bear_fastx_encode",
     "bear_kmer_order_u64", "bear_gather_rows", "bear_plan_pair_contexts", "bear_plan_pair_info", "bear_plan_attach_cnn_levels", "bear_plan_cnn_level_rows", "bear_cnn_forward_plan_f64",
     "bear_plan_count_total", "bear_plan_set_count_bound", "bear_deterministic_build", "bear_plan_cnn_window_rows",
+    "bear_plan_create_auto",
 ]
 
 
@@ -84,6 +85,7 @@ def _load():
     L.bear_plan_bytes.restype = u64
     L.bear_dm_prior_plan_f64.argtypes = [vp, vp, vp, vp, u64, dbl, dbl, cint, cint, vp, vp]
     L.bear_dm_prior_plan_grad_f64.argtypes = [vp, vp, vp, vp, u64, dbl, dbl, cint, cint, vp, vp, vp]
+    L.bear_plan_create_auto.argtypes = [vp, vp, u64, ctypes.POINTER(cint), ctypes.POINTER(vp)]
     L.bear_eval_f64.argtypes = [vp, vp, vp, vp, u64, vp, cint, cint, vp, cint, dbl, u64, u64, vp, vp]
     L.bear_pack_kmers_u64.argtypes = [vp, u64, cint, vp, vp]
     L.bear_linear_index_u64.argtypes = [vp, u64, cint, vp, vp]

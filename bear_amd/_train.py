@@ -443,12 +443,20 @@ class ResidentBatches:
 
     def plan(self, k, column, ncol, ref_column=None):
         """Training plan of batch k (built on first use).  ref_column (ncol = 4): the reference column of bear_ref with the stop net
-        function -- the plan then folds the contexts without reference counts into a histogram (``bear_plan_create_ref``)."""
+        function -- the plan then folds the contexts without reference counts into a histogram (``bear_plan_create_ref``).
+        ncol = "5 rows if dense": the five-column plan of a step that only calls the mode-N entry points (any torch AR function) --
+        a table of large counts gets the plan's dense form (``kernels.Plan(..., rows_if_dense=True)``)."""
         e = self.batches[k]
         key = (column, ncol, ref_column)
         if key not in e["plans"]:
-            e["plans"][key] = kernels.Plan(e[column], ncol, ref=None if ref_column is None else e[ref_column])
+            if ncol == ROWS_IF_DENSE:
+                e["plans"][key] = kernels.Plan(e[column], 5, rows_if_dense=True)
+            else:
+                e["plans"][key] = kernels.Plan(e[column], ncol, ref=None if ref_column is None else e[ref_column])
         return e["plans"][key]
+
+
+ROWS_IF_DENSE = "5 rows if dense"       # ResidentBatches.plan: a five-column plan for the mode-N entry points only
 
 
 class StepFns:
@@ -730,7 +738,7 @@ def run_autograd_steps(res, prior_fn, params, h_signed, num_kmers, repeats, lear
                     check_normalized_rows(prior, "the AR function")
                     promise_checked[0] = True
                 need_rows = prior.requires_grad                    # parameter-free AR function (stop): nothing to feed back
-                r = kernels.dm_prior_planned_dev(res.plan(k, "train", 5), prior.detach(), h_dev, out=out, want_grad=need_rows,
+                r = kernels.dm_prior_planned_dev(res.plan(k, "train", ROWS_IF_DENSE), prior.detach(), h_dev, out=out, want_grad=need_rows,
                                                  train_ar=train_ar, normalized=normalized)
                 if need_rows:
                     prior.backward(r[1])                           # d sum LL / d AR parameters

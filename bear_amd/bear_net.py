@@ -56,7 +56,7 @@ def train(data, num_kmers, epochs, ds_loc, alphabet, lag, make_ar_func, af_kwarg
     # convolutional kernels evaluate a window that all contexts of a wave share once (kernels_cnn.h).  The plans are cut as the
     # batches land, while the next batch is still being uploaded.
     res = _train.ResidentBatches(data, {"train": ds_loc}, device, want_codes=True, drop_empty="train", kmer_order=fused,
-                                 prebuild=[("train", 5, None)],     # (+ paired lists of the linear head / prefix levels of the cnn step)
+                                 prebuild=[("train", 5 if fused else _train.ROWS_IF_DENSE, None)],     # (+ paired lists of the linear head / prefix levels of the cnn step)
                                  per_row_extra=(8 + (208 + 64 if cnn_ok else 4)) if fused else 80)
     scales = [-(num_kmers / e["global_rows"]) for e in res.batches]       # bear_net.py:190-191 with the global batch
     if fused:

@@ -606,6 +606,63 @@ int bear_plan_destroy(bear_plan *plan) {
 
 uint64_t bear_plan_bytes(const bear_plan *plan) { return plan ? plan->bytes : 0; }
 
+// ---- the dense form: a five-column plan that keeps nothing per item (kernels_rows.h, dm_prior_rows_kernel).  Internally ncol =
+// PLAN_ROWS: every entry point that walks a plan's tiles and lists asks for ncol == 5 and so turns such a plan away; the mode-N
+// entry points (bear_dm_prior_plan_f64 / _grad_f64 / _dev_f64) take both.
+#define PLAN_ROWS 15
+static bool plan_is_rows(const bear_plan *p) { return p->ncol == PLAN_ROWS; }
+int bear_plan_create_auto(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int *rowwise, bear_plan **out) {
+  if (rowwise) *rowwise = 0;
+  int st = bear_plan_create(ws, counts, n_rows, 5, out);
+  if (st != BEAR_OK) return st;
+  bear_plan *p = *out;
+  // cells that hold a count (count_total[1]) against those the sorted encoding could not keep in its tiles (the global list of
+  // large-count items): a table of large counts is all list
+  const double cells = p->count_total[1], listed = (double)p->n_heavy[0];
+  if (!(cells > 0.0) || listed * 2.0 <= cells) return BEAR_OK;
+  (void)hipFree(p->tiles);
+  (void)hipFree(p->stream);
+  (void)hipFree(p->heavy_col);
+  (void)hipFree(p->heavy_row);
+  (void)hipFree(p->heavy_stop);
+  (void)hipFree(p->live);
+  p->tiles = nullptr;
+  p->stream = nullptr;
+  p->heavy_col = nullptr;
+  p->heavy_row = nullptr;
+  p->heavy_stop = nullptr;
+  p->live = nullptr;
+  p->n_tiles = 0;
+  p->n_heavy[0] = p->n_heavy[1] = p->n_heavy[2] = 0;
+  p->ncol = PLAN_ROWS;
+  p->bytes = sizeof(unsigned long long) * (2 * SRT_NKEY + PLN_NBIG + 1);      // (the histograms stay: nothing else does)
+  if (rowwise) *rowwise = 1;
+  return BEAR_OK;
+}
+// mode N on such a plan: one launch (the last block sums), parameters by value or from device memory
+static int launch_prior_rows(bear_ws *ws, const bear_plan *plan, const double *prior, const bear_params &prm, const double *theta,
+                             int train_ar, double *out, double *grad_prior, hipStream_t s) {
+  const uint64_t tiles = (plan->n_rows + DPR_TILE_ROWS - 1) / DPR_TILE_ROWS;
+  uint64_t g = (uint64_t)ws->num_cu * DPR_BLOCKS_PER_CU;
+  if (g > (uint64_t)ws->max_blocks) g = ws->max_blocks;
+  const int grid = (int)(tiles < g ? (tiles ? tiles : 1) : g);
+  const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
+  const bear_step_io io = ws_io(ws, theta, BEAR_THETA_NET, out);
+#define ROWS_LAUNCH(AR, GRAD) \
+  hipLaunchKernelGGL((dm_prior_rows_kernel<AR, GRAD>), dim3(grid), dim3(BEAR_THREADS), 0, s, plan->counts, prior, plan->n_rows, prm, grad_prior, lt, \
+                     ws->partials, io)
+  if (train_ar) {
+    if (grad_prior) ROWS_LAUNCH(true, true);
+    else ROWS_LAUNCH(true, false);
+  } else {
+    if (grad_prior) ROWS_LAUNCH(false, true);
+    else ROWS_LAUNCH(false, false);
+  }
+#undef ROWS_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return BEAR_OK;
+}
+
 uint64_t bear_plan_tile_count(const bear_plan *plan) { return plan ? plan->n_tiles : 0; }
 
 int bear_plan_tile_info(const bear_plan *plan, uint64_t first, uint64_t count, uint64_t *row0, uint32_t *rows, uint32_t *items,
@@ -743,13 +800,14 @@ int bear_dm_prior_plan_f64(bear_ws *ws, const bear_plan *plan, const uint32_t *c
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
   if (!plan || !out || (n_rows && (!counts || !prior))) return BEAR_ERR_INVALID_ARG;
-  if (plan->ncol != 5 || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
+  if ((plan->ncol != 5 && !plan_is_rows(plan)) || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
     return BEAR_ERR_INVALID_ARG;
   if (misaligned(prior) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
   bear_params prm;
   memset(&prm, 0, sizeof(prm));
   prm.inv_h = 1.0 / exp(h_signed);
   prm.eps = eps;
+  if (plan_is_rows(plan)) return launch_prior_rows(ws, plan, prior, prm, nullptr, train_ar, out, nullptr, static_cast<hipStream_t>(stream));
   return launch_prior_plan(ws, plan, prior, n_rows, prm, nullptr, train_ar, prior_normalized, out, static_cast<hipStream_t>(stream));
 }
 
@@ -794,13 +852,14 @@ int bear_dm_prior_plan_grad_f64(bear_ws *ws, const bear_plan *plan, const uint32
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
   if (!plan || !out || !grad_prior || (n_rows && (!counts || !prior))) return BEAR_ERR_INVALID_ARG;
-  if (plan->ncol != 5 || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
+  if ((plan->ncol != 5 && !plan_is_rows(plan)) || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
     return BEAR_ERR_INVALID_ARG;
   if (misaligned(prior) || misaligned(grad_prior) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
   bear_params prm;
   memset(&prm, 0, sizeof(prm));
   prm.inv_h = 1.0 / exp(h_signed);
   prm.eps = eps;
+  if (plan_is_rows(plan)) return launch_prior_rows(ws, plan, prior, prm, nullptr, train_ar, out, grad_prior, static_cast<hipStream_t>(stream));
   return launch_prior_plan_grad(ws, plan, prior, prm, nullptr, train_ar, prior_normalized, out, grad_prior,
                                 static_cast<hipStream_t>(stream));
 }
@@ -813,13 +872,14 @@ int bear_dm_prior_plan_dev_f64(bear_ws *ws, const bear_plan *plan, const uint32_
   int st = check_ws(ws);
   if (st != BEAR_OK) return st;
   if (!plan || !out || !h_signed_dev || (n_rows && (!counts || !prior))) return BEAR_ERR_INVALID_ARG;
-  if (plan->ncol != 5 || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
+  if ((plan->ncol != 5 && !plan_is_rows(plan)) || plan->n_rows != n_rows || plan->counts != counts || plan->device != ws->device)
     return BEAR_ERR_INVALID_ARG;
   if (misaligned(prior) || misaligned(grad_prior) || (reinterpret_cast<uintptr_t>(out) & 7u)) return BEAR_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   bear_params only_eps;
   memset(&only_eps, 0, sizeof(only_eps));
   only_eps.eps = eps;
+  if (plan_is_rows(plan)) return launch_prior_rows(ws, plan, prior, only_eps, h_signed_dev, train_ar, out, grad_prior, s);
   if (grad_prior) return launch_prior_plan_grad(ws, plan, prior, only_eps, h_signed_dev, train_ar, prior_normalized, out, grad_prior, s);
   return launch_prior_plan(ws, plan, prior, n_rows, only_eps, h_signed_dev, train_ar, prior_normalized, out, s);
 }

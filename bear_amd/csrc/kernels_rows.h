@@ -22,20 +22,26 @@ __device__ __forceinline__ void stage_dwords(uint32_t *lds, const uint32_t *src,
 
 // ------------------------------------------------------------------ row math
 // BEAR mode: LL_i and g_b = dLL_i/dalpha_b from counts c[5] and concentrations a[5].
-__device__ __forceinline__ double dm_row(const uint32_t (&c)[5], const double (&a)[5], double (&g)[5]) {
+// `tab` != NULL: the table-log form of an item (bear_dm_item_fast: ~150 instead of ~500 instructions, the planned kernels' routine)
+// wherever its argument is inside that routine's domain (x > 0 and finite); the library form elsewhere.
+__device__ __forceinline__ bear_dp dm_row_item(double x, double c, const double2 *tab) {
+  if (tab && x > 0.0 && x < INFINITY) return bear_dm_item_fast(x, c, tab);
+  return bear_dm_item(x, c);
+}
+__device__ __forceinline__ double dm_row(const uint32_t (&c)[5], const double (&a)[5], double (&g)[5], const double2 *tab = nullptr) {
   const double n = (((double)c[0] + (double)c[1]) + ((double)c[2] + (double)c[3])) + (double)c[4];
   double ll = 0.0;
 #pragma unroll
   for (int b = 0; b < 5; ++b) g[b] = 0.0;
   if (n == 0.0) return 0.0;
   double A = ((a[0] + a[1]) + (a[2] + a[3])) + a[4];
-  bear_dp tn = bear_dm_item(A, n);
+  bear_dp tn = dm_row_item(A, n, tab);
   ll = -tn.D;
 #pragma unroll
   for (int b = 0; b < 5; ++b) {
     g[b] = -tn.P;
     if (c[b] != 0) {
-      bear_dp tb = bear_dm_item(a[b], (double)c[b]);
+      bear_dp tb = dm_row_item(a[b], (double)c[b], tab);
       ll += tb.D;
       g[b] += tb.P;
     }
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(BEAR_THREADS) void dm_prior_kernel(const uint32_t *
         double a[5], g[5];
 #pragma unroll
         for (int b = 0; b < 5; ++b) a[b] = __builtin_fma(f[b], prm.inv_h, prm.eps);
-        acc[0] += dm_row(c, a, g);
+        acc[0] += dm_row(c, a, g, s_log);
         double dh = 0.0;
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
@@ -101,6 +107,75 @@ __global__ __launch_bounds__(BEAR_THREADS) void dm_prior_kernel(const uint32_t *
     }
   }
   block_store_partials<2>(acc, partials);
+}
+
+// ------------------------------------------------------------------ mode N on a ROW-WISE plan (bear_plan_create_auto)
+// The dense form of the plan: where most of a table's cells are beyond the product path (counts of 1e3 ... 1e5: a k-mer table at
+// k = 5, the reference's data/ysd1_lag_5 table) the sorted encoding holds nothing but overflow lists -- 16-byte records and a
+// gathered prior cell per item, ~100 B per context -- and the step is bound by those gathers.  Such a plan keeps NOTHING per item:
+// the step streams the caller's count rows (20 B) and prior rows (40 B), a context per thread, every cell through the table-log
+// form of the Stirling difference (dm_row_item), device-resident parameters and the last block's fixed-order sum as in the
+// planned kernels (one launch).  2e7 dense contexts: 1.30 -> ~1.0 ms, with gradient rows 2.76 -> 1.18 ms (round 6).
+// (tiles of DPR_TILE_ROWS contexts: the per-cell routine is a dependent chain of ~150 instructions, so what this kernel needs is waves in
+// flight -- 30 KB of LDS a block and four blocks = 16 waves per CU; with dm_prior_kernel's 1024-row tiles it was two blocks)
+#ifndef DPR_TILE_ROWS
+#define DPR_TILE_ROWS 512
+#endif
+#define DPR_BLOCKS_PER_CU 4
+template <bool AR, bool GRAD>
+__global__ __launch_bounds__(BEAR_THREADS, DPR_BLOCKS_PER_CU / 4) void dm_prior_rows_kernel(const uint32_t *__restrict__ counts, const double *__restrict__ prior,
+                                                                      uint64_t n_rows, bear_params prm_arg, double *__restrict__ grad_prior,
+                                                                      const double2 *__restrict__ logtab_g, double *__restrict__ partials,
+                                                                      const bear_step_io io) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_cnt[DPR_TILE_ROWS * 5];
+  __shared__ __attribute__((aligned(16))) double s_pri[DPR_TILE_ROWS * 5];
+  __shared__ double2 s_log[BEAR_LOGTAB_N];
+  const bear_params prm = bear_params_of(prm_arg, io);
+  if (threadIdx.x < BEAR_LOGTAB_N) s_log[threadIdx.x] = logtab_g[threadIdx.x];
+  const uint64_t n_tiles = (n_rows + DPR_TILE_ROWS - 1) / DPR_TILE_ROWS;
+  double acc[2] = {0.0, 0.0};
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t row0 = tile * DPR_TILE_ROWS;
+    const uint32_t rows = (uint32_t)((n_rows - row0 < DPR_TILE_ROWS) ? (n_rows - row0) : DPR_TILE_ROWS);
+    __syncthreads();  // previous tile fully consumed (and the log table is in place)
+    stage_dwords(s_cnt, counts + row0 * 5, rows * 5);
+    stage_dwords(reinterpret_cast<uint32_t *>(s_pri), reinterpret_cast<const uint32_t *>(prior + row0 * 5), rows * 10);
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < (DPR_TILE_ROWS / BEAR_THREADS); ++k) {
+      const uint32_t r = threadIdx.x + k * BEAR_THREADS;
+      if (r >= rows) break;
+      uint32_t c[5];
+      double f[5];
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        c[b] = s_cnt[r * 5 + b];
+        f[b] = s_pri[r * 5 + b];
+      }
+      if (AR) {      // core.py:138-139 with probs = prior + eps (bear_net.py:68)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          const double p = f[b] + prm.eps, cb = (double)c[b];
+          if (c[b] != 0) acc[0] += cb * (p > 0.0 ? bear_log_tab(p, s_log) : bear_log(p));
+          if (GRAD) grad_prior[(row0 + r) * 5 + b] = c[b] != 0 ? cb * bear_rcp(p) : 0.0;
+        }
+      } else {
+        double a[5], g[5];
+#pragma unroll
+        for (int b = 0; b < 5; ++b) a[b] = __builtin_fma(f[b], prm.inv_h, prm.eps);
+        acc[0] += dm_row(c, a, g, s_log);
+        double dh = 0.0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          dh = __builtin_fma(g[b], f[b], dh);
+          if (GRAD) grad_prior[(row0 + r) * 5 + b] = g[b] * prm.inv_h;
+        }
+        acc[1] -= dh * prm.inv_h;  // d alpha_b / d h_signed = -f_b / h
+      }
+    }
+  }
+  __syncthreads();
+  block_finish<2>(acc, partials, io);
 }
 
 // ------------------------------------------------------------------ mode R: train + reference counts

@@ -117,13 +117,17 @@ class Plan:
     """Count-dependent part of the hot path for a table that stays resident across optimizer steps
     (work items sorted by count; include/bear_hip.h "Planned variants").  Keeps the count tensor alive."""
 
-    def __init__(self, counts, ncol, ws=None, ref=None):
+    def __init__(self, counts, ncol, ws=None, ref=None, rows_if_dense=False):
         """ref (ncol = 4 only): the reference column the planned mode-R entries will be called with -- the plan then folds the
-        contexts without reference counts into a histogram (``bear_plan_create_ref``)."""
+        contexts without reference counts into a histogram (``bear_plan_create_ref``).
+        rows_if_dense (ncol = 5, a plan for ``dm_prior_planned`` / ``dm_prior_planned_dev`` ONLY): ``bear_plan_create_auto`` -- a table
+        whose cells are mostly beyond the product path gets the dense form (``self.rowwise``: nothing kept per item, the step streams
+        the count and prior rows); the fused linear / convolutional steps refuse such a plan."""
         counts = _check_rows(counts, torch.int32, "counts")
         self.counts = counts
         self.ncol = int(ncol)
         self.ref = None
+        self.rowwise = False
         self.ws = ws or default_workspace(counts.device)
         h = ctypes.c_void_p()
         with torch.cuda.device(counts.device):
@@ -135,6 +139,13 @@ class Plan:
                 self.ref = ref
                 st = _lib.lib().bear_plan_create_ref(self.ws.handle, _ptr(counts), _ptr(ref), counts.shape[0], ctypes.byref(h))
                 _lib.check(st, "bear_plan_create_ref")
+            elif rows_if_dense:
+                if self.ncol != 5:
+                    raise ValueError("rows_if_dense: five-column plans")
+                rw = ctypes.c_int(0)
+                st = _lib.lib().bear_plan_create_auto(self.ws.handle, _ptr(counts), counts.shape[0], ctypes.byref(rw), ctypes.byref(h))
+                _lib.check(st, "bear_plan_create_auto")
+                self.rowwise = bool(rw.value)
             else:
                 st = _lib.lib().bear_plan_create(self.ws.handle, _ptr(counts), counts.shape[0], self.ncol, ctypes.byref(h))
                 _lib.check(st, "bear_plan_create")

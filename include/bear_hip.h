@@ -107,6 +107,15 @@ int bear_dm_ref_f64(bear_ws *ws, const uint32_t *train, const uint32_t *ref, uin
  */
 typedef struct bear_plan bear_plan;
 int bear_plan_create(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int ncol, bear_plan **out);
+/* The same for a caller that only runs the mode-N entry points (bear_dm_prior_plan_f64 / _grad_f64 / _dev_f64: any torch AR
+ * function) on the plan: where more than half of the table's cells are beyond the sorted encoding's product path (counts of
+ * 1e3 ... 1e5 -- a k-mer table at small k, bear_model/data/ysd1_lag_5_file_0_preshuf.tsv) the plan comes back in its DENSE form,
+ * *rowwise = 1: it keeps nothing per item (a few KB of histograms), and the step streams the caller's count rows and prior rows,
+ * a context per thread, every cell through the table-log form of the Stirling difference -- the sorted form of such a table is
+ * ~100 B per context of overflow lists whose gathers bound the step (2e7 dense contexts: 1.30 -> 0.9 ms, with gradient rows 2.76 ->
+ * 1.18 ms).  Same results to rounding.  Every other entry point that takes a plan (the fused linear / convolutional steps,
+ * bear_plan_pair_contexts, ...) returns BEAR_ERR_INVALID_ARG for a dense-form plan: they walk the sorted encoding. */
+int bear_plan_create_auto(bear_ws *ws, const uint32_t *counts, uint64_t n_rows, int *rowwise, bear_plan **out);
 int bear_plan_destroy(bear_plan *plan);
 uint64_t bear_plan_bytes(const bear_plan *plan);
 /* Diagnostics: the tiles of a plan -- first context, number of contexts, number of product-path items (1 <= count <= 24) and

@@ -145,11 +145,19 @@ def measure_dense(dev, n=20_000_000, check_rows=2_000_000):
         return best
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    plan_n, plan_r = kernels.Plan(t["train"], 5), kernels.Plan(t["train"], 4, ref=t["ref"])
+    # mode N: the plan a caller of the mode-N entry points gets (bear_plan_create_auto: this table takes the plan's DENSE form -- nothing
+    # kept per item, count and prior rows streamed, a context per thread; round 6); the sorted encoding of the same table next to it
+    plan_n, plan_r = kernels.Plan(t["train"], 5, rows_if_dense=True), kernels.Plan(t["train"], 4, ref=t["ref"])
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     ms_n = timed(lambda: kernels.dm_prior_planned(plan_n, prior, h_s))
     ms_g = timed(lambda: kernels.dm_prior_planned(plan_n, prior, h_s, want_grad=True, normalized=True))
+    plan_s = kernels.Plan(t["train"], 5)
+    ms_n_sorted = timed(lambda: kernels.dm_prior_planned(plan_s, prior, h_s))
+    ms_g_sorted = timed(lambda: kernels.dm_prior_planned(plan_s, prior, h_s, want_grad=True, normalized=True))
+    got_s = kernels.dm_prior_planned(plan_s, prior, h_s).cpu().numpy()
+    sorted_bytes = plan_s.nbytes / n
+    del plan_s
     ms_r = timed(lambda: kernels.dm_ref_planned(plan_r, t["ref"], h_s, tau_s, nu_s))
     ms_u = timed(lambda: kernels.dm_prior(t["train"], prior, h_s), reps=2)
     # planned == unplanned on the whole table, both == the C oracle on the first check_rows rows
@@ -157,7 +165,7 @@ def measure_dense(dev, n=20_000_000, check_rows=2_000_000):
     got_u = kernels.dm_prior(t["train"], prior, h_s)[0].cpu().numpy()
     m = min(n, check_rows)
     tr, rf, pr = (x[:m].contiguous() for x in (t["train"], t["ref"], prior))
-    sub_n, grad = kernels.dm_prior_planned(kernels.Plan(tr, 5), pr, h_s, want_grad=True, normalized=True)
+    sub_n, grad = kernels.dm_prior_planned(kernels.Plan(tr, 5, rows_if_dense=True), pr, h_s, want_grad=True, normalized=True)
     sub_r = kernels.dm_ref_planned(kernels.Plan(tr, 4, ref=rf), rf, h_s, tau_s, nu_s).cpu().numpy()
     trh, rfh, prh = tr.cpu().numpy().view(np.uint32), rf.cpu().numpy().view(np.uint32), pr.cpu().numpy()
     cores = os.cpu_count() or 1
@@ -169,10 +177,13 @@ def measure_dense(dev, n=20_000_000, check_rows=2_000_000):
     gerr = float(np.abs(grad.cpu().numpy() - want_g).max() / np.abs(want_g).max())
     nbytes = {"net": plan_n.nbytes / n, "ref": plan_r.nbytes / n}
     return {"contexts": n, "distribution": "synth_counts(dense=True): row rate lambda = 1e4 ... 3e5 (SURVEY section 8d), counts up to ~3e5",
-            "plan_build_s": build_s, "plan_bytes_per_context": nbytes,
+            "plan_build_s": build_s, "plan_bytes_per_context": nbytes, "mode_N_plan_is_the_dense_form": bool(plan_n.rowwise),
+            "plan_bytes_per_context_sorted_form": sorted_bytes,
             "mode_N": {"kernel_ms": ms_n, "contexts_per_s": n / (ms_n * 1e-3), "credited_GBps_at_60_B": n * 60 / (ms_n * 1e-3) / 1e9,
-                       "frac_credited": n * 60 / (ms_n * 1e-3) / 1e9 / 8000.0, "unplanned_kernel_ms": ms_u},
-            "mode_N_with_gradient_rows": {"kernel_ms": ms_g, "contexts_per_s": n / (ms_g * 1e-3)},
+                       "frac_credited": n * 60 / (ms_n * 1e-3) / 1e9 / 8000.0, "unplanned_kernel_ms": ms_u,
+                       "kernel_ms_sorted_form": ms_n_sorted,
+                       "dense_vs_sorted_form_elbo_rel": float(abs(got_s[0] - kernels.dm_prior_planned(plan_n, prior, h_s).cpu().numpy()[0]) / abs(got_s[0]))},
+            "mode_N_with_gradient_rows": {"kernel_ms": ms_g, "contexts_per_s": n / (ms_g * 1e-3), "kernel_ms_sorted_form": ms_g_sorted},
             "mode_R": {"kernel_ms": ms_r, "contexts_per_s": n / (ms_r * 1e-3)},
             "check": {"planned_vs_unplanned_elbo_rel": float(abs(got_n[0] - got_u[0]) / abs(got_u[0])),
                       "planned_vs_unplanned_dh_rel": float(abs(got_n[1] - got_u[1]) / abs(got_u[1])),

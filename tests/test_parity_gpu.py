@@ -288,6 +288,52 @@ def test_planned_kernels_parity(case, dev, ysd1):
 
 
 @pytest.mark.parametrize("case", ["ysd1", "sparse", "sparse_hot", "dense", "edge", "one_row"])
+def test_dense_form_of_the_plan(case, dev, ysd1):
+    """bear_plan_create_auto: the dense tables (the reference's own ysd1 table, SURVEY 8d's dense stress table) get the plan's dense
+    form -- nothing kept per item, the mode-N entry points stream the count and prior rows -- and the sparse ones the sorted
+    encoding; either way the oracle's sums, scalar gradients and gradient rows at the planned kernels' tolerances, in BEAR and
+    multinomial mode, parameters by value and from device memory; the fused steps turn a dense-form plan away."""
+    import torch
+    from bear_amd import _lib, kernels
+    if case == "ysd1":
+        tr = ysd1[1][:, 0].astype(np.uint32)
+    else:
+        tr, _ = CASES_REF[case]()
+    n = len(tr)
+    d_tr = _to_dev(tr, dev)
+    plan = kernels.Plan(d_tr, 5, rows_if_dense=True)
+    assert plan.rowwise == (case in ("ysd1", "dense")), (case, plan.rowwise)
+    if plan.rowwise:
+        assert plan.nbytes < 64 * 1024                       # histograms only
+        with pytest.raises(_lib.BearError):
+            plan.pair_contexts(torch.zeros(n, dtype=torch.int64, device=dev), 5)
+    for seed, h_s, conc in [(1, 0.0, 1.0), (2, -3.0, 0.2), (3, 1.7, 5.0)]:
+        f = prior_rows(n, seed, conc)
+        if seed == 3:
+            f = f * np.linspace(0.5, 3.0, n)[:, None]
+        d_f = _to_dev(f, dev)
+        want, wantg = co.dm_prior(tr, f, h_s, want_grad=True, nthreads=4)
+        mass_h = co.dm_prior_mass(tr, f, h_s, nthreads=4)
+        for norm in ([False, True] if seed != 3 else [False]):
+            got = kernels.dm_prior_planned(plan, d_f, h_s, normalized=norm).cpu().numpy()
+            _close(got[0], want[0], ELBO_RTOL)
+            _mass_close(got[1], want[1], mass_h, (case, seed, norm))
+            got, g = kernels.dm_prior_planned(plan, d_f, h_s, normalized=norm, want_grad=True)
+            _close(got.cpu().numpy()[0], want[0], ELBO_RTOL)
+            _mass_close(got.cpu().numpy()[1], want[1], mass_h, (case, seed, norm, "rows"))
+            g = g.cpu().numpy()
+            assert np.allclose(g, wantg, rtol=1e-9, atol=1e-9 * np.abs(wantg).max()), (case, seed, np.abs(g - wantg).max())
+        h_dev = torch.tensor([h_s], dtype=torch.float64, device=dev)
+        got, g = kernels.dm_prior_planned_dev(plan, d_f, h_dev, want_grad=True)
+        _close(got.cpu().numpy()[0], want[0], ELBO_RTOL)
+        assert np.allclose(g.cpu().numpy(), wantg, rtol=1e-9, atol=1e-9 * np.abs(wantg).max()), (case, seed, "dev")
+        want_ar, wantg_ar = co.dm_prior(tr, f, h_s, train_ar=True, want_grad=True, nthreads=4)
+        got, g = kernels.dm_prior_planned(plan, d_f, h_s, train_ar=True, want_grad=True)
+        _close(got.cpu().numpy()[0], want_ar[0], ELBO_RTOL)
+        assert np.allclose(g.cpu().numpy(), wantg_ar, rtol=1e-12, atol=1e-12 * (np.abs(wantg_ar).max() + 1e-300)), (case, seed, "ar")
+
+
+@pytest.mark.parametrize("case", ["ysd1", "sparse", "sparse_hot", "dense", "edge", "one_row"])
 def test_planned_ar_mode_parity(case, dev, ysd1):
     """train_ar (multinomial, core.py:138-139) on the plan: sum c log(f + eps), gradients w.r.t. tau_s, nu_s
     (mode R) and the prior rows (mode N) against the oracle."""
