@@ -115,6 +115,12 @@ __device__ __noinline__ bear_dp srt_general(double x, double c) {
   return bear_dm_item(x, c);
 }
 // The same on the table log (LDS or global table): ~3x fewer instructions.
+__device__ __noinline__ bear_dp srt_general_fast(double x, double c, const double2 *tab);
+// the table-log form wherever its argument is in that routine's domain (x > 0 and finite), the library form elsewhere: the heavy
+// items of the UNPLANNED sorted kernels (round 6: they had kept the ~500-instruction form; a dense table ran 2.24 ms per 2e7 contexts)
+__device__ __forceinline__ bear_dp srt_general_auto(double x, double c, const double2 *tab) {
+  return x > 0.0 && x < INFINITY ? srt_general_fast(x, c, tab) : srt_general(x, c);
+}
 __device__ __noinline__ bear_dp srt_general_fast(double x, double c, const double2 *tab) {
   if (!(x > 0.0) || !(x < 0x1p1000)) return bear_dp{__builtin_nan(""), __builtin_nan("")};
   return bear_dm_item_fast(x, c, tab);
@@ -368,12 +374,12 @@ __global__ __launch_bounds__(SRT_THREADS, 4) void dm_prior_sorted_kernel(const u
             const uint32_t *cr = &cnt[row * 5];
             const double A = __builtin_fma(S.rowS[row], u, eps5);
             const double n = (((double)cr[0] + (double)cr[1]) + ((double)cr[2] + (double)cr[3])) + (double)cr[4];
-            const bear_dp o = srt_general(A, n);
+            const bear_dp o = srt_general_auto(A, n, S.logtab);
             acc[0] -= o.D;
             acc[1] = __builtin_fma(A - eps5, o.P, acc[1]);
           } else {
             const double x = __builtin_fma(pri[rec], u, eps);
-            const bear_dp o = srt_general(x, (double)cnt[rec]);
+            const bear_dp o = srt_general_auto(x, (double)cnt[rec], S.logtab);
             acc[0] += o.D;
             acc[1] = __builtin_fma(eps - x, o.P, acc[1]);
           }
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(SRT_THREADS, 4) void dm_ref_sorted_kernel(const uin
         if (idx < h_end) {
           const uint32_t off = S.items[idx];
           const double x = alpha_of(off);
-          const bear_dp o = srt_general(x, (double)trn[off]);
+          const bear_dp o = srt_general_auto(x, (double)trn[off], S.logtab);
           const double w1 = eps - x;
           acc[0] += o.D;
           acc[1] = __builtin_fma(w1, o.P, acc[1]);
@@ -592,12 +598,12 @@ __global__ __launch_bounds__(SRT_THREADS, 4) void dm_ref_sorted_kernel(const uin
     for (uint32_t i = tid; i < nh_n; i += SRT_THREADS) {
       const uint32_t *cr = &trn[(uint32_t)S.heavy_n[i] * 5];
       const double n = (((double)cr[0] + (double)cr[1]) + ((double)cr[2] + (double)cr[3])) + (double)cr[4];
-      const bear_dp o = srt_general(A, n);
+      const bear_dp o = srt_general_auto(A, n, S.logtab);
       acc[0] -= o.D;
       acc[1] = __builtin_fma(u, o.P, acc[1]);
     }
     for (uint32_t i = tid; i < nh_4; i += SRT_THREADS) {
-      const bear_dp o = srt_general(x4, (double)trn[(uint32_t)S.heavy_4[i] * 5 + 4]);
+      const bear_dp o = srt_general_auto(x4, (double)trn[(uint32_t)S.heavy_4[i] * 5 + 4], S.logtab);
       acc[0] += o.D;
       acc[1] = __builtin_fma(eps - x4, o.P, acc[1]);
       acc[3] = __builtin_fma(VU * nwV, o.P, acc[3]);
