@@ -119,7 +119,13 @@ def test_dense_full_size():
         assert torch.allclose(a, plain, rtol=1e-11, atol=0), (a, plain)
     scale = float(grad_u.abs().max())
     assert float((grad - grad_u).abs().max()) <= 1e-10 * scale and float((grad_a - grad_u).abs().max()) <= 1e-10 * scale
-    del grad, grad_a, grad_u
+    # the plan's dense form (bear_plan_create_auto: this table keeps nothing per item) == the sorted form and the unplanned kernels
+    plan_d = kernels.Plan(t["train"], 5, rows_if_dense=True)
+    assert plan_d.rowwise and plan_d.nbytes < 64 * 1024 and plan_n.nbytes > 50 * n
+    got_d, grad_d = kernels.dm_prior_planned(plan_d, prior, args[0], want_grad=True, normalized=True)
+    assert torch.allclose(got_d, plain, rtol=1e-11, atol=0) and torch.allclose(kernels.dm_prior_planned(plan_d, prior, args[0]), plain, rtol=1e-11, atol=0)
+    assert float((grad_d - grad_u).abs().max()) <= 1e-10 * scale
+    del grad, grad_a, grad_u, grad_d, plan_d
     got_r = kernels.dm_ref_planned(kernels.Plan(t["train"], 4, ref=t["ref"]), t["ref"], *args)
     stream_r = kernels.dm_ref_planned(kernels.Plan(t["train"], 4), t["ref"], *args)
     plain_r = kernels.dm_ref(t["train"], t["ref"], *args)
@@ -127,6 +133,7 @@ def test_dense_full_size():
     lo, m = 4_000_004, 1_000_000
     tr, rf, pr = (x[lo:lo + m].contiguous() for x in (t["train"], t["ref"], prior))
     sub, g = kernels.dm_prior_planned(kernels.Plan(tr, 5), pr, args[0], want_grad=True)
+    sub_d, g_d = kernels.dm_prior_planned(kernels.Plan(tr, 5, rows_if_dense=True), pr, args[0], want_grad=True)      # (the dense form against the oracle)
     sub_r = kernels.dm_ref_planned(kernels.Plan(tr, 4, ref=rf), rf, *args).cpu().numpy()
     trh, rfh = tr.cpu().numpy().view(np.uint32), rf.cpu().numpy().view(np.uint32)
     want, want_g = co.dm_prior(trh, pr.cpu().numpy(), args[0], want_grad=True, nthreads=min(os.cpu_count() or 4, 64))
@@ -135,6 +142,9 @@ def test_dense_full_size():
     mass = float(co.dm_prior_mass(trh, pr.cpu().numpy(), args[0], nthreads=min(os.cpu_count() or 4, 64)))   # L1 mass of d/dh: its error scale
     assert abs(sub[0] - want[0]) <= 1e-10 * abs(want[0]) and abs(sub[1] - want[1]) <= 1e-11 * mass, (sub, want, mass)
     assert np.abs(g.cpu().numpy() - want_g).max() <= 1e-9 * np.abs(want_g).max()
+    sub_d = sub_d.cpu().numpy()
+    assert abs(sub_d[0] - want[0]) <= 1e-10 * abs(want[0]) and abs(sub_d[1] - want[1]) <= 1e-11 * mass, (sub_d, want, mass)
+    assert np.abs(g_d.cpu().numpy() - want_g).max() <= 1e-9 * np.abs(want_g).max()
     assert abs(sub_r[0] - want_r[0]) <= 1e-10 * abs(want_r[0]), (sub_r, want_r)
     mass_r = co.dm_ref_mass(trh, rfh, *args, nthreads=min(os.cpu_count() or 4, 64))
     assert np.all(np.abs(sub_r[1:] - want_r[1:]) <= 1e-11 * mass_r), (sub_r, want_r, mass_r)
