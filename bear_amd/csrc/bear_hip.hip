@@ -346,6 +346,7 @@ struct bear_plan {
   uint16_t *live;            // five-column plans: per-tile lists of the contexts that hold counts (plan_live_kernel)
   uint64_t n_tiles;
   uint64_t n_heavy[3];
+  int rows_ref;              // bear_plan_create_ref: the DENSE form (a table of large counts: nothing kept per item, dm_ref_rows_kernel)
   uint64_t n_live_rows;      // five-column plans: contexts that hold any count (the kernels that walk `live` skip the lists when all do)
   double count_total[3];     // of the table (all five columns): sum of all counts, cells that hold one, largest count
   double count_bound[3];     // the same of everything that is added into one gradient (bear_plan_set_count_bound; default: count_total)
@@ -696,6 +697,26 @@ int bear_plan_create_ref(bear_ws *ws, const uint32_t *train, const uint32_t *ref
   int st = bear_plan_create(ws, train, n_rows, 4, &p);   // tiles, histograms of totals / stop counts, heavy lists
   if (st != BEAR_OK) return st;
   p->ref = ref;
+  // a table of large counts (more than half of its cells beyond the sorted encoding's tiles: bear_plan_create_auto's test) keeps
+  // nothing per item: the mode-R step then streams the training and reference rows, a context per thread (dm_ref_rows_kernel)
+  if (p->count_total[1] > 0.0 && (double)p->n_heavy[0] * 2.0 > p->count_total[1]) {
+    (void)hipFree(p->tiles);
+    (void)hipFree(p->stream);
+    (void)hipFree(p->heavy_col);
+    (void)hipFree(p->heavy_row);
+    (void)hipFree(p->heavy_stop);
+    p->tiles = nullptr;
+    p->stream = nullptr;
+    p->heavy_col = nullptr;
+    p->heavy_row = nullptr;
+    p->heavy_stop = nullptr;
+    p->n_tiles = 0;
+    p->n_heavy[0] = p->n_heavy[1] = p->n_heavy[2] = 0;
+    p->rows_ref = 1;
+    p->bytes = sizeof(unsigned long long) * (2 * SRT_NKEY + PLN_NBIG + 1);
+    *out = p;
+    return BEAR_OK;
+  }
   unsigned long long *d_meta = nullptr;   // [0..31] bucket sizes / cursors, [32..63] hist0, [64] n_heavy0
   hipError_t e = hipMalloc(&d_meta, sizeof(unsigned long long) * 72);
   if (e == hipSuccess) e = hipMemset(d_meta, 0, sizeof(unsigned long long) * 72);
@@ -932,7 +953,17 @@ static int launch_ref_plan(bear_ws *ws, const bear_plan *plan, const uint32_t *r
   const double2 *lt = reinterpret_cast<const double2 *>(ws->logtab);
   const bear_step_io io = ws_io(ws, theta, BEAR_THETA_REF, out);
   int grid;
-  if (plan->ref) {
+  if (plan->rows_ref) {       // the dense form: rows streamed (kernels_rows.h)
+    if (plan->ref != ref) return BEAR_ERR_INVALID_ARG;
+    const uint64_t tiles = (n_rows + DPR_TILE_ROWS - 1) / DPR_TILE_ROWS;
+    uint64_t g = (uint64_t)ws->num_cu * DPR_BLOCKS_PER_CU;
+    if (g > (uint64_t)ws->max_blocks) g = ws->max_blocks;
+    grid = (int)(tiles < g ? (tiles ? tiles : 1) : g);
+    if (train_ar)
+      hipLaunchKernelGGL(dm_ref_rows_kernel<true>, dim3(grid), dim3(BEAR_THREADS), 0, s, plan->counts, ref, n_rows, prm, lt, ws->partials, io, apply);
+    else
+      hipLaunchKernelGGL(dm_ref_rows_kernel<false>, dim3(grid), dim3(BEAR_THREADS), 0, s, plan->counts, ref, n_rows, prm, lt, ws->partials, io, apply);
+  } else if (plan->ref) {
     if (plan->ref != ref) return BEAR_ERR_INVALID_ARG;   // the plan is valid for the reference buffer it was built from
     rpl_view rv;
     rv.items = plan->ref_items;

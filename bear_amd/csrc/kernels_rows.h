@@ -256,3 +256,83 @@ __global__ __launch_bounds__(BEAR_THREADS) void dm_ref_kernel(const uint32_t *__
   block_store_partials<4>(acc, partials);
 }
 
+// ------------------------------------------------------------------ mode R on the DENSE form of a reference-aware plan
+// As dm_prior_rows_kernel: a table of large counts keeps nothing per item (bear_plan_create_ref decides), the step streams the
+// training and reference rows (20 + 20 B), a context per thread, the cells through the table-log Stirling difference; device-resident
+// parameters, the last block's fixed-order sum and -- bear_ref_train_step_f64 -- the Adam update, as the planned kernels.
+template <bool AR>
+__global__ __launch_bounds__(BEAR_THREADS) void dm_ref_rows_kernel(const uint32_t *__restrict__ train, const uint32_t *__restrict__ ref,
+                                                                    uint64_t n_rows, bear_params prm_arg, const double2 *__restrict__ logtab_g,
+                                                                    double *__restrict__ partials, const bear_step_io io,
+                                                                    const bear_apply_io apply) {
+  __shared__ double2 s_log[BEAR_LOGTAB_N];
+  __shared__ __attribute__((aligned(16))) uint32_t s_trn[DPR_TILE_ROWS * 5];
+  __shared__ __attribute__((aligned(16))) uint32_t s_ref[DPR_TILE_ROWS * 5];
+  const bear_params prm = bear_params_of(prm_arg, io);
+  if (threadIdx.x < BEAR_LOGTAB_N) s_log[threadIdx.x] = logtab_g[threadIdx.x];
+  const uint64_t n_tiles = (n_rows + DPR_TILE_ROWS - 1) / DPR_TILE_ROWS;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t row0 = tile * DPR_TILE_ROWS;
+    const uint32_t rows = (uint32_t)((n_rows - row0 < DPR_TILE_ROWS) ? (n_rows - row0) : DPR_TILE_ROWS);
+    __syncthreads();
+    stage_dwords(s_trn, train + row0 * 5, rows * 5);
+    stage_dwords(s_ref, ref + row0 * 5, rows * 5);
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < DPR_TILE_ROWS / BEAR_THREADS; ++k) {
+      const uint32_t r = threadIdx.x + k * BEAR_THREADS;
+      if (r >= rows) break;
+      uint32_t c[5];
+      double rr[4];
+#pragma unroll
+      for (int b = 0; b < 5; ++b) c[b] = s_trn[r * 5 + b];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) rr[b] = (double)s_ref[r * 5 + b] + prm.eps;  // bear_ref.py:335-337
+      // bear_ref.py:30-33: L1-normalise, Jukes-Cantor; bear_ref.py:63-68: mix with the stop net
+      const double invR = bear_rcp((rr[0] + rr[1]) + (rr[2] + rr[3]));
+      double f[5], dft[5], dfn[5];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const double dev = __builtin_fma(rr[b], invR, -0.25);  // norm_b - 1/4
+        f[b] = __builtin_fma(prm.E, dev, 0.25) * prm.V;
+        dft[b] = -prm.tauE * dev * prm.V;                       // d f_b / d tau_signed
+        dfn[b] = -prm.nw * f[b] * prm.V;                        // d f_b / d nu_signed (g_net = 0)
+      }
+      f[4] = prm.nw * prm.V;
+      dft[4] = 0.0;
+      dfn[4] = prm.nw * (1.0 - f[4]) * prm.V;
+      double dLdf[5];
+      if (AR) {
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          const double p = f[b] + prm.eps, cb = (double)c[b];
+          dLdf[b] = 0.0;
+          if (c[b] != 0) {
+            acc[0] += cb * (p > 0.0 ? bear_log_tab(p, s_log) : bear_log(p));
+            dLdf[b] = cb * bear_rcp(p);
+          }
+        }
+      } else {
+        double a[5], g[5];
+#pragma unroll
+        for (int b = 0; b < 5; ++b) a[b] = __builtin_fma(f[b], prm.inv_h, prm.eps);
+        acc[0] += dm_row(c, a, g, s_log);
+        double dh = 0.0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+          dLdf[b] = g[b] * prm.inv_h;
+          dh = __builtin_fma(dLdf[b], f[b], dh);
+        }
+        acc[1] -= dh;
+      }
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        acc[2] = __builtin_fma(dLdf[b], dft[b], acc[2]);
+        acc[3] = __builtin_fma(dLdf[b], dfn[b], acc[3]);
+      }
+    }
+  }
+  __syncthreads();
+  block_finish<4>(acc, partials, io, apply);
+}

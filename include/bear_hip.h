@@ -128,7 +128,11 @@ int bear_plan_tile_info(const bear_plan *plan, uint64_t first, uint64_t count, u
  * set that the reference genome does not contain) share one concentration per letter, so all their items collapse into a
  * 24-bin histogram over the count, built here once; the step then streams only the items of contexts that do have reference
  * counts, as 16-byte records {count, r_b, sum r} sorted by count.  Results are those of the streaming path (same arithmetic
- * per item; the fp64 sums in another order).  The planned entries must be called with the same `train` and `ref` buffers. */
+ * per item; the fp64 sums in another order).  The planned entries must be called with the same `train` and `ref` buffers.
+ * A table of LARGE counts (more than half of its cells beyond the sorted encoding's product path: bear_plan_create_auto's test; the
+ * reference's ysd1 table) gets the plan's dense form here too: nothing kept per item, the planned mode-R entries and
+ * bear_ref_train_*_f64 stream the training and reference rows, a context per thread (2e7 such contexts: 1.41 -> ~0.9 ms, 153 -> 0.002 B
+ * of plan per context).  Nothing changes for the caller. */
 int bear_plan_create_ref(bear_ws *ws, const uint32_t *train, const uint32_t *ref, uint64_t n_rows, bear_plan **out);
 /* prior_normalized != 0: the caller asserts that every row of `prior` sums to one -- true for each
  * ar_func of the reference, all of which end in a softmax (bear_model/ar_funcs.py:44,97,121-126).

@@ -34,3 +34,12 @@ print("grad rows dense form vs sorted form, max rel diff", float((gd - pg).abs()
 print("dense form         %.3f ms" % timed(lambda: kernels.dm_prior_planned(pa, prior, -0.3)))
 print("dense form + rows  %.3f ms" % timed(lambda: kernels.dm_prior_planned(pa, prior, -0.3, want_grad=True)))
 print("dense form, AR     %.3f ms" % timed(lambda: kernels.dm_prior_planned(pa, prior, -0.3, train_ar=True)))
+import numpy as np
+rf = kernels.synth_counts(20211012, 0, n, dev, want=("ref",), dense=True)["ref"]
+argsr = (0.0, float(np.log(1 / 30)), float(-np.log(100)))
+pr = kernels.Plan(t, 4, ref=rf)
+print("mode R planned (reference-aware) %.3f ms, %.1f B per context" % (timed(lambda: kernels.dm_ref_planned(pr, rf, *argsr)), pr.nbytes / n))
+ps = kernels.Plan(t, 4)
+print("mode R planned (streaming)       %.3f ms, %.1f B per context" % (timed(lambda: kernels.dm_ref_planned(ps, rf, *argsr)), ps.nbytes / n))
+print("mode R unplanned                 %.3f ms" % timed(lambda: kernels.dm_ref(t, rf, *argsr)))
+print(kernels.dm_ref_planned(pr, rf, *argsr).tolist(), kernels.dm_ref(t, rf, *argsr).tolist())

@@ -1019,7 +1019,10 @@ def test_reference_aware_plan_parity(case, train_ar, dev, ysd1):
     d_tr, d_rf = _to_dev(tr, dev), _to_dev(rf, dev)
     plan = kernels.Plan(d_tr, 4, ref=d_rf)
     stream = kernels.Plan(d_tr, 4)
-    assert plan.nbytes >= stream.nbytes
+    if case in ("ysd1", "dense"):        # tables of large counts: the plan's dense form (nothing kept per item, the rows streamed)
+        assert plan.nbytes < 64 * 1024 < stream.nbytes
+    else:
+        assert plan.nbytes >= stream.nbytes
     for args in PARAMS:
         want = co.dm_ref(tr, rf, *args, train_ar=train_ar, nthreads=4)
         got = kernels.dm_ref_planned(plan, d_rf, *args, train_ar=train_ar).cpu().numpy()
