@@ -23,7 +23,7 @@ def _deterministic_requested():
 # parameter gradients over per call; BEAR_AMD_LIB: developer A/B builds.
 LIB_PATH = os.environ.get("BEAR_AMD_LIB") or os.path.join(_HERE, "libbear_hip_det.so" if _deterministic_requested() else "libbear_hip.so")
 
-ABI_VERSION = 5   # BEAR_ABI_VERSION of include/bear_hip.h the argtypes below were written against
+ABI_VERSION = 6   # BEAR_ABI_VERSION of include/bear_hip.h the argtypes below were written against
 
 SYMBOLS = [
     "bear_abi_version", "bear_strerror", "bear_last_hip_error", "bear_ws_create", "bear_ws_destroy",

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BEAR_ABI_VERSION 5
+#define BEAR_ABI_VERSION 6 /* 6: + bear_plan_create_auto; bear_plan_create_ref may hand back the plan's dense form (round 6) */
 #define BEAR_ROW_WIDTH 5 /* alphabet_size + 1 for dna/rna */
 
 typedef enum bear_status {
